@@ -1,0 +1,30 @@
+"""pytest configuration: registers the ``gpu`` marker and puts the repo root on sys.path."""
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

@@ -1,0 +1,343 @@
+"""Generate the golden fixtures in this directory by running the *real* reference.
+
+DEV-CONTAINER ONLY: imports facebookresearch/controllable_agent from /root/reference
+(with in-process stubs for hydra / omegaconf / dm_env / dm_control -- none of which carry
+arithmetic of the hot path) and records inputs and expected
+outputs of ``FBDDPGAgent.update()`` and ``ReplayBuffer.sample()``.  Only the *outputs*
+(``*.npz`` / ``*.json``, data not code) are committed; nothing here runs on the GPU box.
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+
+Random draws are injected (monkey-patched ``np.random.*``, ``torch.randperm``, ``torch.randn``,
+``utils._standard_normal``) from a numpy ``Generator`` so the same draws can be replayed through
+``oracle.fb_oracle`` and through the HIP path.
+"""
+from __future__ import annotations
+
+import contextlib
+import enum
+import json
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parents[1]))
+
+from oracle import fb_oracle as fo  # noqa: E402  (helpers for synthetic weights / storage / draws)
+
+
+# --------------------------------------------------------------------------- #
+def import_reference():
+    if not REF.exists():
+        raise SystemExit("make_golden.py needs /root/reference (dev container only)")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+
+    def mod(name, **kw):
+        m = types.ModuleType(name)
+        m.__dict__.update(kw)
+        sys.modules[name] = m
+        return m
+
+    class _CS:
+        _i = None
+
+        @classmethod
+        def instance(cls):
+            cls._i = cls._i or cls()
+            return cls._i
+
+        def store(self, **kw):
+            pass
+
+    mod("hydra").core = mod("hydra.core")
+    mod("hydra.core.config_store", ConfigStore=_CS)
+    mod("omegaconf", MISSING="???", II=lambda s: "${%s}" % s, SI=lambda s: s, DictConfig=dict)
+
+    class StepType(enum.IntEnum):
+        FIRST = 0
+        MID = 1
+        LAST = 2
+
+    class _Spec:
+        def __init__(self, shape=None, dtype=None, *a, **k):
+            self.shape, self.dtype = shape, dtype
+
+    specs = mod("dm_env.specs", Array=_Spec, BoundedArray=_Spec, DiscreteArray=_Spec)
+    mod("dm_env", StepType=StepType, specs=specs, TimeStep=object, Environment=object)
+    dc = mod("dm_control")
+    dc.suite = mod("dm_control.suite", ALL_TASKS=())
+    w = mod("dm_control.suite.wrappers")
+    w.action_scale = mod("dm_control.suite.wrappers.action_scale")
+    w.pixels = mod("dm_control.suite.wrappers.pixels")
+    mod("url_benchmark.custom_dmc_tasks")
+    mod("url_benchmark.goals", get_goal_space_dim={"simplified_walker": 3, "simplified_quadruped": 2}.__getitem__)
+    import url_benchmark  # noqa: F401
+    mod("url_benchmark.agent").__path__ = [str(REF / "url_benchmark/agent")]
+    from url_benchmark.agent import fb_ddpg
+    from url_benchmark.in_memory_replay_buffer import ReplayBuffer
+    from url_benchmark import dmc, utils
+    return types.SimpleNamespace(fb_ddpg=fb_ddpg, ReplayBuffer=ReplayBuffer, dmc=dmc, utils=utils, StepType=StepType)
+
+
+# --------------------------------------------------------------------------- #
+def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
+    return R.fb_ddpg.FBDDPGAgent(
+        obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cpu",
+        num_expl_steps=0, use_tb=True, use_wandb=False, use_hiplog=False, update_encoder=True,
+        goal_space=goal_space, lr=cfg.lr, lr_coef=cfg.lr_coef, fb_target_tau=cfg.fb_target_tau,
+        hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
+        z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
+        ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
+        update_every_steps=1, **extra)
+
+
+def load_nets(agent, nets):
+    for name in ("actor", "forward_net", "backward_net"):
+        getattr(agent, name).load_state_dict(nets[name])
+    agent.forward_target_net.load_state_dict(agent.forward_net.state_dict())
+    agent.backward_target_net.load_state_dict(agent.backward_net.state_dict())
+
+
+def fill_ref_buffer(R, storage, lengths, discount, future=0.99, max_len=None, meta_z=None):
+    """Fill a reference ReplayBuffer through its real ``add()`` (in_memory_replay_buffer.py:104-133)."""
+    n_eps = storage["observation"].shape[0]
+    has_goal = "goal" in storage
+    TS = R.dmc.ExtendedGoalTimeStep if has_goal else R.dmc.ExtendedTimeStep
+    rb = R.ReplayBuffer(max_episodes=n_eps, discount=discount, future=future, max_episode_length=max_len)
+    for e in range(n_eps):
+        L = int(lengths[e])
+        for s in range(L + 1):
+            st = R.StepType.FIRST if s == 0 else (R.StepType.LAST if s == L else R.StepType.MID)
+            kw = dict(step_type=st, reward=float(storage["reward"][e, s, 0]), discount=float(storage["discount"][e, s, 0]),
+                      observation=storage["observation"][e, s], action=storage["action"][e, s])
+            if has_goal:
+                kw["goal"] = storage["goal"][e, s]
+            ts = TS(**kw)
+            ts.physics = np.zeros(2, np.float32)
+            rb.add(ts, {} if meta_z is None else {"z": meta_z[e, s]})
+    return rb
+
+
+@contextlib.contextmanager
+def inject(R, d: fo.Draws, variable_len: bool):
+    """Route every random draw of one ``update()`` to the prepared values."""
+    calls = {"randint": 0}
+    o_randint, o_choice, o_uniform = np.random.randint, np.random.choice, np.random.uniform
+    o_randperm, o_randn, o_sn = torch.randperm, torch.randn, R.utils._standard_normal
+    eps_queue = [d.eps_next, d.eps_actor]
+
+    def randint(low, high=None, size=None, **kw):
+        calls["randint"] += 1
+        if variable_len:            # only the step draw uses randint (in_memory_replay_buffer.py:155)
+            return (d.step_idx - 1).copy()
+        return d.ep_idx.copy() if calls["randint"] == 1 else (d.step_idx - 1).copy()
+
+    def choice(a, size=None, p=None, **kw):
+        return d.ep_idx.copy()
+
+    def uniform(*a, size=None, **kw):
+        assert size == len(d.mix_uniform)
+        return d.mix_uniform.copy()
+
+    def randperm(n, **kw):
+        return torch.from_numpy(d.perm.copy())
+
+    def randn(*a, **kw):
+        return torch.from_numpy(d.z_gauss.copy())
+
+    def standard_normal(shape, dtype, device):
+        return torch.from_numpy(eps_queue.pop(0).copy())
+
+    np.random.randint, np.random.choice, np.random.uniform = randint, choice, uniform
+    torch.randperm, torch.randn, R.utils._standard_normal = randperm, randn, standard_normal
+    try:
+        yield
+    finally:
+        np.random.randint, np.random.choice, np.random.uniform = o_randint, o_choice, o_uniform
+        torch.randperm, torch.randn, R.utils._standard_normal = o_randperm, o_randn, o_sn
+    assert not eps_queue, "update() did not consume both action-noise draws"
+
+
+def ref_state(agent):
+    out = {}
+    for n in ("actor", "forward_net", "backward_net", "forward_target_net", "backward_target_net"):
+        for k, v in getattr(agent, n).state_dict().items():
+            out[f"{n}/{k}"] = v.detach().numpy().copy()
+    for opt, nets in ((agent.actor_opt, ("actor",)), (agent.fb_opt, ("forward_net", "backward_net"))):
+        for n in nets:
+            for (k, p) in getattr(agent, n).named_parameters():
+                st = opt.state.get(p, None)
+                if st:
+                    out[f"adam_m/{n}/{k}"] = st["exp_avg"].numpy().copy()
+                    out[f"adam_v/{n}/{k}"] = st["exp_avg_sq"].numpy().copy()
+    return out
+
+
+def checksums(state):
+    return {k: [float(np.sum(v, dtype=np.float64)), float(np.sqrt(np.sum(v.astype(np.float64) ** 2)))]
+            for k, v in state.items() if not k.startswith("adam_")}
+
+
+# --------------------------------------------------------------------------- #
+def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_space=None, variable_len=False,
+                  full_state=True, checksum_steps=()):
+    rng = np.random.default_rng(seed)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    lengths = None
+    if variable_len:
+        lengths = rng.integers(max(2, T // 2), T + 1, size=n_eps).astype(np.int32)
+        lengths[0] = T
+    storage, lengths = fo.synthetic_storage(rng, n_eps, T, cfg.obs_dim, cfg.action_dim,
+                                            cfg.goal_dim if cfg.use_goal else None, lengths)
+    agent = make_ref_agent(R, cfg, goal_space=goal_space)
+    load_nets(agent, nets)
+    rb = fill_ref_buffer(R, storage, lengths, cfg.discount, max_len=(T + 1) if variable_len else None)
+    assert rb._is_fixed_episode_length == (not variable_len)
+    arrays, meta = {}, {"name": name, "seed": seed, "n_eps": n_eps, "T": T, "n_steps": n_steps,
+                        "goal_space": goal_space, "variable_len": variable_len,
+                        "cfg": {k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, "metrics": [], "checksums": {}}
+    if full_state:
+        for n, p in nets.items():
+            for k, v in p.items():
+                arrays[f"init/{n}/{k}"] = v.numpy()
+        for k, v in storage.items():
+            arrays[f"storage/{k}"] = v
+        arrays["lengths"] = lengths
+    for s in range(n_steps):
+        d = fo.make_draws(rng, cfg, n_eps, lengths)
+        with inject(R, d, variable_len):
+            m = agent.update(rb, s)
+        meta["metrics"].append({k: float(v) for k, v in m.items()})
+        if full_state:
+            for f in d.__dataclass_fields__:
+                arrays[f"draws/{s}/{f}"] = getattr(d, f)
+            for k, v in ref_state(agent).items():
+                arrays[f"state/{s}/{k}"] = v
+        if (s + 1) in checksum_steps:
+            meta["checksums"][str(s + 1)] = checksums(ref_state(agent))
+    (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1))
+    if full_state:
+        np.savez_compressed(HERE / f"{name}.npz", **arrays)
+    print(f"[{name}] steps={n_steps} fb_loss={[round(m['fb_loss'], 4) for m in meta['metrics'][:3]]} "
+          f"actor_loss={[round(m['actor_loss'], 4) for m in meta['metrics'][:3]]}")
+
+
+def sampler_fixture(R):
+    """ReplayBuffer.sample KAT: variable lengths + goal + stored meta z; real numpy RNG, fixed seed."""
+    rng = np.random.default_rng(7)
+    n_eps, T, o, a, g, d = 6, 9, 4, 2, 3, 5
+    lengths = np.array([9, 5, 7, 9, 3, 8], np.int32)
+    storage, lengths = fo.synthetic_storage(rng, n_eps, T, o, a, g, lengths)
+    meta_z = rng.standard_normal((n_eps, T + 1, d)).astype(np.float32)
+    rb = fill_ref_buffer(R, storage, lengths, 0.98, future=1.0, max_len=T + 1, meta_z=meta_z)
+    B = 64
+    rec = {}
+    o_choice, o_randint = np.random.choice, np.random.randint
+
+    def choice(*a_, **k):
+        rec["ep"] = o_choice(*a_, **k)
+        return rec["ep"]
+
+    def randint(*a_, **k):
+        rec["step0"] = o_randint(*a_, **k)
+        return rec["step0"]
+    np.random.seed(123)
+    np.random.choice, np.random.randint = choice, randint
+    try:
+        b = rb.sample(B)
+    finally:
+        np.random.choice, np.random.randint = o_choice, o_randint
+    arrays = {f"storage/{k}": v for k, v in storage.items()}
+    arrays.update(lengths=lengths, meta_z=meta_z, ep_idx=rec["ep"], step_idx=rec["step0"] + 1,
+                  obs=b.obs, action=b.action, next_obs=b.next_obs, reward=b.reward, discount=b.discount,
+                  goal=b.goal, next_goal=b.next_goal, meta_z_out=b.meta["z"])
+    # the buffer's own bookkeeping (in_memory_replay_buffer.py:127-133, 135-137)
+    arrays.update(rb_len=np.int64(len(rb)), rb_full=np.bool_(rb._full), rb_idx=np.int64(rb._idx),
+                  avg_episode_length=np.int64(rb.avg_episode_length), rb_episodes_length=rb._episodes_length)
+    np.savez_compressed(HERE / "sampler_kat.npz", **arrays)
+    print("[sampler_kat] ok", b.obs.shape, "fixed_len:", rb._is_fixed_episode_length)
+
+
+def init_fixture(R):
+    """Reference constructor under torch.manual_seed: pins net construction order + orthogonal init
+    (fb_ddpg.py:119-141, utils.py:81-93).  Valid for the torch build it was generated with."""
+    cfg = tiny_cfg()
+    torch.manual_seed(1)
+    agent = make_ref_agent(R, cfg)
+    arrays = {k: v for k, v in ref_state(agent).items()}
+    arrays["torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(HERE / "init_seed1_tiny.npz", **arrays)
+    big = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=24, batch_size=256)
+    torch.manual_seed(1)
+    agent = make_ref_agent(R, big)
+    (HERE / "init_seed1_walker.json").write_text(json.dumps(
+        {"torch_version": torch.__version__, "checksums": checksums(ref_state(agent))}, indent=1))
+    print("[init] ok")
+
+
+def inference_fixture(R):
+    """act (eval) / infer_meta_from_obs_and_rewards / get_goal_meta / compute_z_correl on fixed weights
+    (fb_ddpg.py:177-222, 258-289)."""
+    cfg = tiny_cfg()
+    rng = np.random.default_rng(11)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    agent = make_ref_agent(R, cfg)
+    load_nets(agent, nets)
+    obs = rng.standard_normal((7, cfg.obs_dim)).astype(np.float32)
+    zs = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((7, cfg.z_dim)).astype(np.float32)), cfg.z_dim).numpy()
+    with torch.no_grad():       # callers wrap act() in no_grad + eval_mode (pretrain.py:628-632)
+        acts = np.stack([agent.act(obs[i], {"z": zs[i]}, 0, eval_mode=True) for i in range(7)])
+    rew = rng.uniform(0, 1, (40, 1)).astype(np.float32)
+    gobs = rng.standard_normal((40, cfg.obs_dim)).astype(np.float32)
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        zinf = agent.infer_meta_from_obs_and_rewards(torch.from_numpy(gobs), torch.from_numpy(rew))["z"]
+    zgoal = agent.get_goal_meta(gobs[0])["z"]
+    ts = types.SimpleNamespace(observation=obs[0], goal=None)
+    correl = agent.compute_z_correl(ts, {"z": zs[0]})
+    with torch.no_grad():
+        Bout = agent.backward_net(torch.from_numpy(gobs)).numpy()
+    arrays = {f"init/{n}/{k}": v.numpy() for n, p in nets.items() for k, v in p.items()}
+    arrays.update(obs=obs, z=zs, act_eval=acts, reward=rew, goal_obs=gobs, z_inferred=zinf, z_goal=zgoal,
+                  z_correl=np.float64(correl), backward_out=Bout)
+    np.savez_compressed(HERE / "inference_kat.npz", **arrays)
+    print("[inference_kat] ok")
+
+
+def tiny_cfg(**kw):
+    base = dict(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                backward_hidden_dim=18, batch_size=16, lr=1e-3)
+    base.update(kw)
+    return fo.OracleConfig(**base)
+
+
+def main():
+    R = import_reference()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    trace_fixture(R, "tiny_trace", tiny_cfg(), seed=101, n_eps=6, T=12, n_steps=5)
+    trace_fixture(R, "tiny_goal_trace", tiny_cfg(goal_dim=3, use_goal=True, q_loss=True, lr_coef=0.5, z_dim=10,
+                                                 backward_hidden_dim=22, batch_size=24),
+                  seed=102, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)
+    walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
+    trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
+                  n_steps=10, full_state=False, checksum_steps=(1, 5, 10))
+    trace_fixture(R, "walker_b1024", fo.OracleConfig(batch_size=1024, **walker), seed=202, n_eps=20, T=100,
+                  n_steps=3, full_state=False, checksum_steps=(1, 3))
+    trace_fixture(R, "quadruped_goal_b512",
+                  fo.OracleConfig(obs_dim=78, action_dim=12, goal_dim=2, z_dim=100, batch_size=512, use_goal=True),
+                  seed=203, n_eps=12, T=60, n_steps=3, goal_space="simplified_quadruped", full_state=False,
+                  checksum_steps=(1, 3))
+    sampler_fixture(R)
+    init_fixture(R)
+    inference_fixture(R)
+
+
+if __name__ == "__main__":
+    main()
