@@ -1,0 +1,896 @@
+// C-ABI of libfbhip.so (include/fbhip.h): layout of the flat parameter buffers, workspace carving, and the
+// launch sequence of one FBDDPGAgent.update() (url_benchmark/agent/fb_ddpg.py:427-520) on gfx950.
+//
+// Memory model: torch owns every byte.  The library computes offsets (fbhip_layout_*, fbhip_workspace_bytes),
+// the host allocates flat fp32 tensors and binds them; after that an update is ~100 asynchronous kernel
+// launches on the caller's stream with no allocation and no host synchronisation, so the whole step is
+// hipGraph-capturable (fbhip_update(use_graph=1) captures once and replays).
+#include "common.h"
+#include "fbhip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace fbhip;
+
+namespace {
+
+thread_local std::string g_err;
+
+// ------------------------------------------------------------------------------------------------ layout
+struct Slot { std::string name; int64_t off; int rows, cols, ld; };
+struct NetLayout {
+    std::vector<Slot> slots;            // reference parameters() order
+    std::map<std::string, Slot> by_name;
+    int64_t numel = 0;                  // padded floats
+    int64_t nparams = 0;                // logical parameter count
+};
+
+struct LayoutBuilder {
+    NetLayout L;
+    int64_t cur = 0;
+    void mat(const std::string& n, int rows, int cols) {
+        Slot s{n, cur, rows, cols, pad4(cols)};
+        cur += (int64_t)rows * s.ld;
+        L.by_name[n] = s;
+        L.nparams += (int64_t)rows * cols;
+    }
+    void vec(const std::string& n, int len) {
+        Slot s{n, cur, 1, len, pad4(len)};
+        cur += s.ld;
+        L.by_name[n] = s;
+        L.nparams += len;
+    }
+    void trunk(const std::string& p, int in, int H, int Fd) {     // mlp(in, H, "ntanh", Fd, "irelu"), fb_modules.py:60-78
+        mat(p + ".0.weight", H, in); vec(p + ".0.bias", H);
+        vec(p + ".1.weight", H); vec(p + ".1.bias", H);
+        mat(p + ".3.weight", Fd, H); vec(p + ".3.bias", Fd);
+    }
+    NetLayout finish(const std::vector<std::string>& order) {
+        for (const auto& n : order) L.slots.push_back(L.by_name.at(n));
+        L.numel = cur;
+        return L;
+    }
+};
+
+std::vector<std::string> trunk_names(const std::string& p) {
+    return {p + ".0.weight", p + ".0.bias", p + ".1.weight", p + ".1.bias", p + ".3.weight", p + ".3.bias"};
+}
+void append(std::vector<std::string>& a, const std::vector<std::string>& b) { a.insert(a.end(), b.begin(), b.end()); }
+
+NetLayout build_layout(const fbhip_dims& d, int net) {
+    const int o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim, Fd = d.feature_dim,
+              Hb = d.backward_hidden_dim;
+    LayoutBuilder b;
+    std::vector<std::string> order;
+    if (net == FBHIP_NET_FORWARD) {               // ForwardMap, fb_modules.py:165-182
+        b.trunk("obs_action_net", o + a, H, Fd);
+        b.trunk("obs_z_net", o + z, H, Fd);
+        // F1/F2 first layers are stored back to back so both heads run as ONE [2H x 2Fd] GEMM
+        b.mat("F1.0.weight", H, 2 * Fd); b.mat("F2.0.weight", H, 2 * Fd);
+        b.vec("F1.0.bias", H); b.vec("F2.0.bias", H);
+        b.mat("F1.2.weight", z, H); b.vec("F1.2.bias", z);
+        b.mat("F2.2.weight", z, H); b.vec("F2.2.bias", z);
+        append(order, trunk_names("obs_action_net")); append(order, trunk_names("obs_z_net"));
+        append(order, {"F1.0.weight", "F1.0.bias", "F1.2.weight", "F1.2.bias",
+                       "F2.0.weight", "F2.0.bias", "F2.2.weight", "F2.2.bias"});
+    } else if (net == FBHIP_NET_BACKWARD) {       // BackwardMap, fb_modules.py:220
+        b.mat("B.0.weight", Hb, g); b.vec("B.0.bias", Hb); b.vec("B.1.weight", Hb); b.vec("B.1.bias", Hb);
+        b.mat("B.3.weight", Hb, Hb); b.vec("B.3.bias", Hb);
+        b.mat("B.5.weight", z, Hb); b.vec("B.5.bias", z);
+        order = {"B.0.weight", "B.0.bias", "B.1.weight", "B.1.bias", "B.3.weight", "B.3.bias", "B.5.weight", "B.5.bias"};
+    } else {                                      // Actor, fb_modules.py:91-105
+        b.trunk("obs_net", o, H, Fd);
+        b.trunk("obs_z_net", o + z, H, Fd);
+        b.mat("policy.0.weight", H, 2 * Fd); b.vec("policy.0.bias", H);
+        b.mat("policy.2.weight", a, H); b.vec("policy.2.bias", a);
+        append(order, trunk_names("obs_net")); append(order, trunk_names("obs_z_net"));
+        append(order, {"policy.0.weight", "policy.0.bias", "policy.2.weight", "policy.2.bias"});
+    }
+    return b.finish(order);
+}
+
+int check_dims(const fbhip_dims* d) {
+    if (!d) return FBHIP_E_INVALID;
+    if (d->batch < 2 || d->obs_dim < 1 || d->action_dim < 1 || d->goal_dim < 1 || d->z_dim < 1 ||
+        d->hidden_dim < 4 || d->feature_dim < 4 || d->backward_hidden_dim < 1) { g_err = "fbhip: non-positive dimension"; return FBHIP_E_INVALID; }
+    if ((d->hidden_dim & 3) || (d->feature_dim & 3)) { g_err = "fbhip: hidden_dim and feature_dim must be multiples of 4"; return FBHIP_E_INVALID; }
+    if (d->hidden_dim > 2048 || d->backward_hidden_dim > 2048) { g_err = "fbhip: hidden dims > 2048 unsupported (LayerNorm row kernel)"; return FBHIP_E_INVALID; }
+    if (d->z_dim > 128) { g_err = "fbhip: z_dim > 128 unsupported (pairwise kernel)"; return FBHIP_E_INVALID; }
+    if (d->action_dim > 64) { g_err = "fbhip: action_dim > 64 unsupported"; return FBHIP_E_INVALID; }
+    if (d->batch > 8192) { g_err = "fbhip: batch > 8192 per GPU unsupported (permutation sort)"; return FBHIP_E_INVALID; }
+    if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
+    return FBHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+struct Buf { float* p = nullptr; int rows = 0, cols = 0, ld = 0; };
+struct BSet { Buf pre1, t1, r2, y, Bm; float* stats = nullptr; float* norms = nullptr; };
+struct FSet { Buf pre1a, t1a, pre1z, t1z, h, p, F1, F2; float* statsA = nullptr; float* statsZ = nullptr; };
+struct ASet { Buf pre1o, t1o, pre1z, t1z, h, p, premu, mu; float* statsO = nullptr; float* statsZ = nullptr; };
+
+struct Ws {
+    StepState* st = nullptr;
+    float* metrics = nullptr;
+    unsigned long long* perm_keys = nullptr;
+    SampleOut so{};
+    Buf Xoa, Xoz, Xnoz, Xnoa, Xopi, next_goal, bin, z, zrand;
+    float* disc = nullptr;
+    BSet bsA, bsO;
+    FSet fsT, fsO;
+    ASet as;
+    Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov;
+    float* ln_partials = nullptr;
+    float* pw_scratch = nullptr;
+    size_t total_bytes = 0;
+};
+
+struct Carver {
+    char* base;
+    size_t cur = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    void* take(size_t bytes) {
+        cur = (cur + 255) & ~(size_t)255;
+        void* p = base ? base + cur : nullptr;
+        cur += bytes;
+        return p;
+    }
+    float* f(size_t n) { return (float*)take(n * sizeof(float)); }
+    Buf buf(int rows, int cols) {
+        Buf b;
+        b.rows = rows; b.cols = cols; b.ld = pad4(cols);
+        b.p = f((size_t)rows * b.ld);
+        return b;
+    }
+};
+
+Ws carve(const fbhip_dims& d, void* base) {
+    Ws w;
+    Carver c(base);
+    const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
+              Fd = d.feature_dim, Hb = d.backward_hidden_dim;
+    w.st = (StepState*)c.take(sizeof(StepState));
+    w.metrics = c.f(FBHIP_NUM_METRICS);
+    w.perm_keys = (unsigned long long*)c.take((size_t)B * 8);
+    w.so.ep_idx = (int32_t*)c.take((size_t)B * 4);
+    w.so.step_idx = (int32_t*)c.take((size_t)B * 4);
+    w.so.perm = (int32_t*)c.take((size_t)B * 4);
+    w.so.mix_uniform = c.f(B);
+    w.so.z_gauss = c.f((size_t)B * z);
+    w.so.eps_next = c.f((size_t)B * a);
+    w.so.eps_actor = c.f((size_t)B * a);
+    w.Xoa = c.buf(B, o + a); w.Xoz = c.buf(B, o + z); w.Xnoz = c.buf(B, o + z); w.Xnoa = c.buf(B, o + a);
+    w.Xopi = c.buf(B, o + a); w.next_goal = c.buf(B, g); w.bin = c.buf(B, g); w.z = c.buf(B, z); w.zrand = c.buf(B, z);
+    w.disc = c.f(B);
+    for (BSet* s : {&w.bsA, &w.bsO}) {
+        s->pre1 = c.buf(B, Hb); s->t1 = c.buf(B, Hb); s->r2 = c.buf(B, Hb); s->y = c.buf(B, z); s->Bm = c.buf(B, z);
+        s->stats = c.f(2 * (size_t)B); s->norms = c.f(B);
+    }
+    for (FSet* s : {&w.fsT, &w.fsO}) {
+        s->pre1a = c.buf(B, H); s->t1a = c.buf(B, H); s->pre1z = c.buf(B, H); s->t1z = c.buf(B, H);
+        s->h = c.buf(B, 2 * Fd); s->p = c.buf(B, 2 * H); s->F1 = c.buf(B, z); s->F2 = c.buf(B, z);
+        s->statsA = c.f(2 * (size_t)B); s->statsZ = c.f(2 * (size_t)B);
+    }
+    w.as.pre1o = c.buf(B, H); w.as.t1o = c.buf(B, H); w.as.pre1z = c.buf(B, H); w.as.t1z = c.buf(B, H);
+    w.as.h = c.buf(B, 2 * Fd); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, a); w.as.mu = c.buf(B, a);
+    w.as.statsO = c.f(2 * (size_t)B); w.as.statsZ = c.f(2 * (size_t)B);
+    w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
+    w.dp = c.buf(B, 2 * H); w.dh = c.buf(B, 2 * Fd); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
+    w.b_dr2 = c.buf(B, Hb); w.b_dt1 = c.buf(B, Hb); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
+    w.cov = c.buf(z, z);
+    const int nmax = H > Hb ? H : Hb;
+    w.ln_partials = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
+    w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
+    w.total_bytes = (c.cur + 255) & ~(size_t)255;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+struct TrunkP { float *W1, *b1, *g1, *be1, *W2, *b2; int k1, ld1; };
+struct FwdP { TrunkP oa, oz; float *W3s, *b3s, *W4[2], *b4[2]; };
+struct BwdP { float *W1, *b1, *g1, *be1, *W2, *b2, *W3, *b3; };
+struct ActP { TrunkP o, oz; float *W3, *b3, *W4, *b4; };
+
+TrunkP trunk_p(float* base, const NetLayout& L, const std::string& p) {
+    const Slot& w1 = L.by_name.at(p + ".0.weight");
+    TrunkP t;
+    t.W1 = base + w1.off; t.k1 = w1.cols; t.ld1 = w1.ld;
+    t.b1 = base + L.by_name.at(p + ".0.bias").off;
+    t.g1 = base + L.by_name.at(p + ".1.weight").off;
+    t.be1 = base + L.by_name.at(p + ".1.bias").off;
+    t.W2 = base + L.by_name.at(p + ".3.weight").off;
+    t.b2 = base + L.by_name.at(p + ".3.bias").off;
+    return t;
+}
+FwdP fwd_p(float* base, const NetLayout& L) {
+    FwdP f;
+    f.oa = trunk_p(base, L, "obs_action_net"); f.oz = trunk_p(base, L, "obs_z_net");
+    f.W3s = base + L.by_name.at("F1.0.weight").off; f.b3s = base + L.by_name.at("F1.0.bias").off;
+    f.W4[0] = base + L.by_name.at("F1.2.weight").off; f.b4[0] = base + L.by_name.at("F1.2.bias").off;
+    f.W4[1] = base + L.by_name.at("F2.2.weight").off; f.b4[1] = base + L.by_name.at("F2.2.bias").off;
+    return f;
+}
+BwdP bwd_p(float* base, const NetLayout& L) {
+    BwdP b;
+    b.W1 = base + L.by_name.at("B.0.weight").off; b.b1 = base + L.by_name.at("B.0.bias").off;
+    b.g1 = base + L.by_name.at("B.1.weight").off; b.be1 = base + L.by_name.at("B.1.bias").off;
+    b.W2 = base + L.by_name.at("B.3.weight").off; b.b2 = base + L.by_name.at("B.3.bias").off;
+    b.W3 = base + L.by_name.at("B.5.weight").off; b.b3 = base + L.by_name.at("B.5.bias").off;
+    return b;
+}
+ActP act_p(float* base, const NetLayout& L) {
+    ActP a;
+    a.o = trunk_p(base, L, "obs_net"); a.oz = trunk_p(base, L, "obs_z_net");
+    a.W3 = base + L.by_name.at("policy.0.weight").off; a.b3 = base + L.by_name.at("policy.0.bias").off;
+    a.W4 = base + L.by_name.at("policy.2.weight").off; a.b4 = base + L.by_name.at("policy.2.bias").off;
+    return a;
+}
+
+struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; };
+
+}  // namespace
+
+struct fbhip_ctx {
+    fbhip_dims d;
+    NetLayout L[3];
+    float *fb_p = nullptr, *fb_g = nullptr, *fb_m = nullptr, *fb_v = nullptr, *fb_t = nullptr;
+    float *a_p = nullptr, *a_g = nullptr, *a_m = nullptr, *a_v = nullptr;
+    bool bound = false, replay_bound = false;
+    Ws w;
+    ReplayView rv{};
+    uint64_t seed = 0;
+    uint32_t rank = 0;
+    FwdP F_p, F_g, F_t;
+    BwdP K_p, K_g, K_t;
+    ActP A_p, A_g;
+    std::vector<GraphEntry> graphs;
+    std::string err;
+};
+
+namespace {
+
+#define HIPCK(ctx, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) {                                                                           \
+            char buf__[512];                                                                               \
+            snprintf(buf__, sizeof(buf__), "fbhip: %s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
+                     __FILE__, __LINE__);                                                                  \
+            g_err = buf__;                                                                                 \
+            if (ctx) (ctx)->err = buf__;                                                                   \
+            return FBHIP_E_HIP;                                                                            \
+        }                                                                                                  \
+    } while (0)
+
+#define RC(expr)                          \
+    do {                                  \
+        int rc__ = (expr);                \
+        if (rc__ != FBHIP_OK) return rc__; \
+    } while (0)
+
+GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc, float* C, int ldc, int M, int N,
+              int K, const float* bias = nullptr, int epi = EPI_NONE, const float* aux = nullptr, int ldaux = 0,
+              float* colsum = nullptr) {
+    GemmProblem p{};
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux = aux; p.colsum = colsum;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
+    p.a_kcontig = akc; p.b_kcontig = bkc; p.epi = epi;
+    return p;
+}
+
+int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
+    long tiles32 = 0;
+    int kmax = 0, nmax = 0, mmax = 0;
+    for (auto& p : v) {
+        tiles32 += (long)((p.M + 31) / 32) * ((p.N + 31) / 32);
+        kmax = p.K > kmax ? p.K : kmax; nmax = p.N > nmax ? p.N : nmax; mmax = p.M > mmax ? p.M : mmax;
+    }
+    int cfg;
+    if (kmax <= 64) cfg = (nmax <= 32) ? CFG_4x1x1 : CFG_2x2x1;
+    else if (tiles32 >= 768) cfg = CFG_2x2x1;
+    else if (tiles32 >= 320) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
+    else cfg = CFG_1x1x4;
+    size_t i = 0;
+    while (i < v.size()) {
+        GemmGroup g{};
+        int start = 0;
+        while (i < v.size() && g.n < MAX_GROUP) {
+            GemmProblem p = v[i++];
+            gemm_problem_finalize(p, cfg);
+            p.tile_start = start;
+            start += p.tiles_m * p.tiles_n;
+            g.p[g.n++] = p;
+        }
+        g.total_tiles = start;
+        HIPCK(ctx, launch_gemm_group(g, cfg, s));
+    }
+    return FBHIP_OK;
+}
+
+// ---- network passes --------------------------------------------------------------------------------------
+// ForwardMap.forward (fb_modules.py:186-199); Xa = [obs|action] panel, Xz = [obs|z] panel
+int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
+                    int rows, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
+    RC(run_gemms(c, {P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, S.pre1a.p, H, rows, H, W.oa.k1, W.oa.b1, EPI_BIAS),
+                     P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, S.pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s));
+    HIPCK(c, launch_ln_tanh_fwd(S.pre1a.p, H, W.oa.g1, W.oa.be1, S.t1a.p, H, S.statsA, rows, H, s));
+    HIPCK(c, launch_ln_tanh_fwd(S.pre1z.p, H, W.oz.g1, W.oz.be1, S.t1z.p, H, S.statsZ, rows, H, s));
+    RC(run_gemms(c, {P(S.t1a.p, H, 1, W.oa.W2, H, 1, S.h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU),
+                     P(S.t1z.p, H, 1, W.oz.W2, H, 1, S.h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s));
+    RC(run_gemms(c, {P(S.h.p, 2 * Fd, 1, W.W3s, 2 * Fd, 1, S.p.p, 2 * H, rows, 2 * H, 2 * Fd, W.b3s, EPI_BIAS_RELU)}, s));
+    RC(run_gemms(c, {P(S.p.p, 2 * H, 1, W.W4[0], H, 1, S.F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS),
+                     P(S.p.p + H, 2 * H, 1, W.W4[1], H, 1, S.F2.p, Lz, rows, z, H, W.b4[1], EPI_BIAS)}, s));
+    return FBHIP_OK;
+}
+
+// dgrad: dp = (dF_i . W4_i) * relu'(p)   (shared by the FB backward and the actor step)
+int forward_map_bwd_heads_dgrad(fbhip_ctx* c, const FwdP& W, FSet& S, int rows, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z);
+    Ws& w = c->w;
+    return run_gemms(c, {P(w.dF1.p, Lz, 1, W.W4[0], H, 0, w.dp.p, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p, 2 * H),
+                         P(w.dF2.p, Lz, 1, W.W4[1], H, 0, w.dp.p + H, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p + H, 2 * H)}, s);
+}
+
+// full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383)
+int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz, int ldz,
+                    FSet& S, int rows, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
+    Ws& w = c->w;
+    RC(run_gemms(c, {P(w.dF1.p, Lz, 0, S.p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]),
+                     P(w.dF2.p, Lz, 0, S.p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1])}, s));
+    RC(forward_map_bwd_heads_dgrad(c, W, S, rows, s));
+    RC(run_gemms(c, {P(w.dp.p, 2 * H, 0, S.h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s)}, s));
+    RC(run_gemms(c, {P(w.dp.p, 2 * H, 1, W.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, rows, 2 * Fd, 2 * H, nullptr, EPI_MASK_RELU, S.h.p, 2 * Fd)}, s));
+    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 0, S.t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2),
+                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, s));
+    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, W.oa.W2, H, 0, w.dt1a.p, H, rows, H, Fd),
+                     P(w.dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w.dt1z.p, H, rows, H, Fd)}, s));
+    HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, S.t1a.p, H, S.pre1a.p, H, S.statsA, W.oa.g1, w.dt1a.p, H, G.oa.g1, G.oa.be1,
+                                w.ln_partials, rows, H, s));
+    HIPCK(c, launch_ln_tanh_bwd(w.dt1z.p, H, S.t1z.p, H, S.pre1z.p, H, S.statsZ, W.oz.g1, w.dt1z.p, H, G.oz.g1, G.oz.be1,
+                                w.ln_partials, rows, H, s));
+    RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1),
+                     P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
+    return FBHIP_OK;
+}
+
+// BackwardMap.forward (fb_modules.py:223-230)
+int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad4(Hb), z = d.z_dim, Lz = pad4(z);
+    RC(run_gemms(c, {P(X, ldx, 1, W.W1, pad4(g), 1, S.pre1.p, Lb, rows, Hb, g, W.b1, EPI_BIAS)}, s));
+    HIPCK(c, launch_ln_tanh_fwd(S.pre1.p, Lb, W.g1, W.be1, S.t1.p, Lb, S.stats, rows, Hb, s));
+    RC(run_gemms(c, {P(S.t1.p, Lb, 1, W.W2, Lb, 1, S.r2.p, Lb, rows, Hb, Hb, W.b2, EPI_BIAS_RELU)}, s));
+    RC(run_gemms(c, {P(S.r2.p, Lb, 1, W.W3, Lb, 1, S.y.p, Lz, rows, z, Hb, W.b3, EPI_BIAS)}, s));
+    HIPCK(c, launch_l2norm_fwd(S.y.p, Lz, S.Bm.p, Lz, S.norms, rows, z, sqrtf((float)z), s));
+    return FBHIP_OK;
+}
+
+int backward_map_bwd(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S, const float* dy,
+                     int rows, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad4(Hb), z = d.z_dim, Lz = pad4(z);
+    Ws& w = c->w;
+    RC(run_gemms(c, {P(dy, Lz, 0, S.r2.p, Lb, 0, G.W3, Lb, z, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, s));
+    RC(run_gemms(c, {P(dy, Lz, 1, W.W3, Lb, 0, w.b_dr2.p, Lb, rows, Hb, z, nullptr, EPI_MASK_RELU, S.r2.p, Lb)}, s));
+    RC(run_gemms(c, {P(w.b_dr2.p, Lb, 0, S.t1.p, Lb, 0, G.W2, Lb, Hb, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2)}, s));
+    RC(run_gemms(c, {P(w.b_dr2.p, Lb, 1, W.W2, Lb, 0, w.b_dt1.p, Lb, rows, Hb, Hb)}, s));
+    HIPCK(c, launch_ln_tanh_bwd(w.b_dt1.p, Lb, S.t1.p, Lb, S.pre1.p, Lb, S.stats, W.g1, w.b_dt1.p, Lb, G.g1, G.be1,
+                                w.ln_partials, rows, Hb, s));
+    RC(run_gemms(c, {P(w.b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad4(g), Hb, g, rows, nullptr, EPI_NONE, nullptr, 0, G.b1)}, s));
+    return FBHIP_OK;
+}
+
+// Actor.forward up to the pre-tanh policy output (fb_modules.py:107-121); Xo supplies obs (first o cols)
+int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
+              hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
+    RC(run_gemms(c, {P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, S.pre1o.p, H, rows, H, W.o.k1, W.o.b1, EPI_BIAS),
+                     P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, S.pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s));
+    HIPCK(c, launch_ln_tanh_fwd(S.pre1o.p, H, W.o.g1, W.o.be1, S.t1o.p, H, S.statsO, rows, H, s));
+    HIPCK(c, launch_ln_tanh_fwd(S.pre1z.p, H, W.oz.g1, W.oz.be1, S.t1z.p, H, S.statsZ, rows, H, s));
+    RC(run_gemms(c, {P(S.t1o.p, H, 1, W.o.W2, H, 1, S.h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU),
+                     P(S.t1z.p, H, 1, W.oz.W2, H, 1, S.h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s));
+    RC(run_gemms(c, {P(S.h.p, 2 * Fd, 1, W.W3, 2 * Fd, 1, S.p.p, H, rows, H, 2 * Fd, W.b3, EPI_BIAS_RELU)}, s));
+    RC(run_gemms(c, {P(S.p.p, H, 1, W.W4, H, 1, S.premu.p, La, rows, a, H, W.b4, EPI_BIAS)}, s));
+    return FBHIP_OK;
+}
+
+int actor_bwd(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S,
+              int rows, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
+    Ws& w = c->w;
+    const float* dpm = w.a_dpremu.p;
+    RC(run_gemms(c, {P(dpm, La, 0, S.p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4)}, s));
+    RC(run_gemms(c, {P(dpm, La, 1, W.W4, H, 0, w.a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, S.p.p, H)}, s));
+    RC(run_gemms(c, {P(w.a_dp.p, H, 0, S.h.p, 2 * Fd, 0, G.W3, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, s));
+    RC(run_gemms(c, {P(w.a_dp.p, H, 1, W.W3, 2 * Fd, 0, w.dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, S.h.p, 2 * Fd)}, s));
+    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 0, S.t1o.p, H, 0, G.o.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b2),
+                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, s));
+    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, W.o.W2, H, 0, w.dt1a.p, H, rows, H, Fd),
+                     P(w.dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w.dt1z.p, H, rows, H, Fd)}, s));
+    HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, S.t1o.p, H, S.pre1o.p, H, S.statsO, W.o.g1, w.dt1a.p, H, G.o.g1, G.o.be1,
+                                w.ln_partials, rows, H, s));
+    HIPCK(c, launch_ln_tanh_bwd(w.dt1z.p, H, S.t1z.p, H, S.pre1z.p, H, S.statsZ, W.oz.g1, w.dt1z.p, H, G.oz.g1, G.oz.be1,
+                                w.ln_partials, rows, H, s));
+    RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1),
+                     P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
+    return FBHIP_OK;
+}
+
+// ---- one update(): fb_ddpg.py:427-520 ----------------------------------------------------------------------
+int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    Ws& w = c->w;
+    const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
+              Fd = d.feature_dim, Lz = pad4(z), La = pad4(a);
+    const float* next_goal = d.use_goal ? w.next_goal.p : w.Xnoz.p;          // fb_ddpg.py:440-443
+    const int ld_ng = d.use_goal ? w.next_goal.ld : w.Xnoz.ld;
+
+    if (mask & FBHIP_PHASE_SAMPLE) {
+        HIPCK(c, launch_step_advance(w.st, 2, s));
+        if (inj != nullptr) {
+            HIPCK(c, hipMemcpyAsync(w.so.ep_idx, inj->ep_idx, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, hipMemcpyAsync(w.so.step_idx, inj->step_idx, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, hipMemcpyAsync(w.so.perm, inj->perm, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, hipMemcpyAsync(w.so.mix_uniform, inj->mix_uniform, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, hipMemcpyAsync(w.so.z_gauss, inj->z_gauss, (size_t)B * z * 4, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, hipMemcpyAsync(w.so.eps_next, inj->eps_next, (size_t)B * a * 4, hipMemcpyDeviceToDevice, s));
+            HIPCK(c, hipMemcpyAsync(w.so.eps_actor, inj->eps_actor, (size_t)B * a * 4, hipMemcpyDeviceToDevice, s));
+        } else {
+            HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, w.perm_keys, s));
+        }
+        GatherArgs ga{};
+        ga.rv = c->rv; ga.ep_idx = w.so.ep_idx; ga.step_idx = w.so.step_idx; ga.perm = w.so.perm;
+        ga.Xoa = w.Xoa.p; ga.ld_oa = w.Xoa.ld; ga.Xoz = w.Xoz.p; ga.ld_oz = w.Xoz.ld; ga.Xnoz = w.Xnoz.p; ga.ld_noz = w.Xnoz.ld;
+        ga.Xnoa = w.Xnoa.p; ga.ld_noa = w.Xnoa.ld; ga.Xopi = w.Xopi.p; ga.ld_opi = w.Xopi.ld;
+        ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
+        ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount;
+        HIPCK(c, launch_gather(ga, s));
+        // sample_z: sqrt(d) * normalize(gauss)   (fb_ddpg.py:224-228)
+        HIPCK(c, launch_l2norm_fwd(w.so.z_gauss, z, w.zrand.p, Lz, nullptr, B, z, sqrtf((float)z), s));
+        if (hp.mix_ratio > 0.f) {               // fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm]))
+            RC(backward_map_fwd(c, c->K_p, w.bin.p, w.bin.ld, w.bsA, B, s));
+            HIPCK(c, launch_mix_z(w.zrand.p, w.bsA.Bm.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, w.Xoz.p, w.Xoz.ld,
+                                  w.Xnoz.p, w.Xnoz.ld, o, B, z, s));
+        } else {
+            HIPCK(c, launch_mix_z(w.zrand.p, w.zrand.p, Lz, w.so.mix_uniform, 0.f, w.z.p, w.Xoz.p, w.Xoz.ld, w.Xnoz.p,
+                                  w.Xnoz.ld, o, B, z, s));
+        }
+    }
+
+    if (mask & FBHIP_PHASE_FB_GRAD) {
+        // --- targets, no grad (fb_ddpg.py:303-315)
+        RC(actor_fwd(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, s));
+        HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_next, a, hp.stddev, hp.stddev_clip, nullptr, 0,
+                                      w.Xnoa.p + o, w.Xnoa.ld, B, a, s));
+        RC(forward_map_fwd(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, s));
+        RC(backward_map_fwd(c, c->K_t, next_goal, ld_ng, w.bsA, B, s));
+        // --- online F, B (fb_ddpg.py:318-319)
+        RC(forward_map_fwd(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
+        RC(backward_map_fwd(c, c->K_p, next_goal, ld_ng, w.bsO, B, s));
+        // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
+        HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, w.bsO.Bm.p, w.fsT.F1.p, w.fsT.F2.p, w.bsA.Bm.p, w.disc, B, z,
+                                    Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
+        if (hp.want_metrics) {                  // fb_ddpg.py:356-377
+            RC(run_gemms(c, {P(w.bsO.Bm.p, Lz, 0, w.bsO.Bm.p, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
+            HIPCK(c, launch_extra_metrics(w.fsO.F1.p, w.bsO.Bm.p, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
+        }
+        // --- backward (fb_ddpg.py:383)
+        HIPCK(c, launch_l2norm_bwd(w.dBm.p, Lz, w.bsO.y.p, Lz, w.bsO.norms, w.dy.p, Lz, B, z, s));
+        RC(forward_map_bwd(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
+        RC(backward_map_bwd(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, s));
+    }
+
+    if (mask & FBHIP_PHASE_FB_STEP) {           // fb_opt.step() (:384) + soft_update_params x2 (:500-503)
+        HIPCK(c, launch_step_advance(w.st, 0, s));
+        const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
+        HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf,
+                                 hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, s));
+    }
+
+    if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
+        RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
+        HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
+                                      w.Xopi.p + o, w.Xopi.ld, B, a, s));
+        RC(forward_map_fwd(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
+        HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + o, w.Xopi.ld, hp.stddev,
+                                   w.dF1.p, w.dF2.p, w.metrics, B, z, a, s));
+        // data-gradient only, along the action path of forward_net (the reference also computes and discards
+        // every weight gradient of forward_net here)
+        RC(forward_map_bwd_heads_dgrad(c, c->F_p, w.fsO, B, s));
+        RC(run_gemms(c, {P(w.dp.p, 2 * H, 1, c->F_p.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, 2 * H, nullptr, EPI_MASK_RELU,
+                           w.fsO.h.p, 2 * Fd)}, s));
+        RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fd)}, s));
+        HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
+                                    nullptr, nullptr, nullptr, B, H, s));
+        // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
+        RC(run_gemms(c, {P(w.dt1a.p, H, 1, c->F_p.oa.W1 + o, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
+                           EPI_TANH_BWD, w.as.mu.p, La)}, s));
+        RC(actor_bwd(c, c->A_p, c->A_g, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
+    }
+
+    if (mask & FBHIP_PHASE_ACTOR_STEP) {        // actor_opt.step(), fb_ddpg.py:411
+        HIPCK(c, launch_step_advance(w.st, 1, s));
+        const int64_t na = c->L[FBHIP_NET_ACTOR].numel;
+        HIPCK(c, launch_adam_ema(c->a_p, c->a_g, c->a_m, c->a_v, nullptr, na, hp.lr, hp.lr, na, hp.grad_scale, 0.f, w.st,
+                                 1, 0, s));
+    }
+    return FBHIP_OK;
+}
+
+int need_bound(fbhip_ctx* c, bool replay) {
+    if (!c) { g_err = "fbhip: null context"; return FBHIP_E_INVALID; }
+    if (!c->bound) { c->err = g_err = "fbhip: buffers not bound (fbhip_bind_buffers)"; return FBHIP_E_STATE; }
+    if (replay && !c->replay_bound) { c->err = g_err = "fbhip: replay storage not bound (fbhip_replay_bind)"; return FBHIP_E_STATE; }
+    return FBHIP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" {
+
+int fbhip_abi_version(void) { return FBHIP_ABI_VERSION; }
+
+const char* fbhip_last_error(const fbhip_ctx* ctx) { return (ctx && !ctx->err.empty()) ? ctx->err.c_str() : g_err.c_str(); }
+
+int fbhip_device_ok(void) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        g_err = "fbhip: no HIP device";
+        return FBHIP_E_NODEVICE;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_err = std::string("fbhip: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return FBHIP_E_NODEVICE;
+    }
+    return FBHIP_OK;
+}
+
+int64_t fbhip_net_numel(const fbhip_dims* dims, int net) {
+    if (check_dims(dims) != FBHIP_OK || net < 0 || net > 2) return FBHIP_E_INVALID;
+    return build_layout(*dims, net).numel;
+}
+int64_t fbhip_net_param_count(const fbhip_dims* dims, int net) {
+    if (check_dims(dims) != FBHIP_OK || net < 0 || net > 2) return FBHIP_E_INVALID;
+    return build_layout(*dims, net).nparams;
+}
+int fbhip_layout_count(const fbhip_dims* dims, int net) {
+    if (check_dims(dims) != FBHIP_OK || net < 0 || net > 2) return FBHIP_E_INVALID;
+    return (int)build_layout(*dims, net).slots.size();
+}
+int fbhip_layout_entry(const fbhip_dims* dims, int net, int idx, fbhip_tensor_desc* out) {
+    if (check_dims(dims) != FBHIP_OK || net < 0 || net > 2 || !out) return FBHIP_E_INVALID;
+    const NetLayout L = build_layout(*dims, net);
+    if (idx < 0 || idx >= (int)L.slots.size()) { g_err = "fbhip: layout index out of range"; return FBHIP_E_INVALID; }
+    const Slot& s = L.slots[idx];
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", s.name.c_str());
+    out->offset = s.off; out->rows = s.rows; out->cols = s.cols; out->ld = s.ld;
+    return FBHIP_OK;
+}
+size_t fbhip_workspace_bytes(const fbhip_dims* dims) {
+    if (check_dims(dims) != FBHIP_OK) return 0;
+    return carve(*dims, nullptr).total_bytes;
+}
+
+int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
+    if (!out) return FBHIP_E_INVALID;
+    RC(check_dims(dims));
+    fbhip_ctx* c = new fbhip_ctx();
+    c->d = *dims;
+    for (int n = 0; n < 3; ++n) c->L[n] = build_layout(*dims, n);
+    *out = c;
+    return FBHIP_OK;
+}
+
+int fbhip_destroy(fbhip_ctx* ctx) {
+    if (!ctx) return FBHIP_OK;
+    for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
+    delete ctx;
+    return FBHIP_OK;
+}
+
+int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* fb_adam_m, float* fb_adam_v,
+                       float* fb_targets, float* actor_params, float* actor_grads, float* actor_adam_m,
+                       float* actor_adam_v, void* workspace, size_t workspace_bytes) {
+    if (!c) return FBHIP_E_INVALID;
+    if (!fb_params || !fb_grads || !fb_adam_m || !fb_adam_v || !fb_targets || !actor_params || !actor_grads ||
+        !actor_adam_m || !actor_adam_v || !workspace) { c->err = g_err = "fbhip: null buffer"; return FBHIP_E_INVALID; }
+    const size_t need = carve(c->d, nullptr).total_bytes;
+    if (workspace_bytes < need) { c->err = g_err = "fbhip: workspace too small"; return FBHIP_E_INVALID; }
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)fb_params & 15) || ((uintptr_t)fb_grads & 15) ||
+        ((uintptr_t)fb_targets & 15) || ((uintptr_t)actor_params & 15) || ((uintptr_t)actor_grads & 15)) {
+        c->err = g_err = "fbhip: buffers must be 16-byte aligned (workspace 256)";
+        return FBHIP_E_INVALID;
+    }
+    RC(fbhip_device_ok());
+    c->fb_p = fb_params; c->fb_g = fb_grads; c->fb_m = fb_adam_m; c->fb_v = fb_adam_v; c->fb_t = fb_targets;
+    c->a_p = actor_params; c->a_g = actor_grads; c->a_m = actor_adam_m; c->a_v = actor_adam_v;
+    c->w = carve(c->d, workspace);
+    const int64_t nf = c->L[FBHIP_NET_FORWARD].numel;
+    c->F_p = fwd_p(fb_params, c->L[0]); c->F_g = fwd_p(fb_grads, c->L[0]); c->F_t = fwd_p(fb_targets, c->L[0]);
+    c->K_p = bwd_p(fb_params + nf, c->L[1]); c->K_g = bwd_p(fb_grads + nf, c->L[1]); c->K_t = bwd_p(fb_targets + nf, c->L[1]);
+    c->A_p = act_p(actor_params, c->L[2]); c->A_g = act_p(actor_grads, c->L[2]);
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+    HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
+    c->bound = true;
+    return FBHIP_OK;
+}
+
+int fbhip_replay_bind(fbhip_ctx* c, const float* observation, const float* action, const float* discount,
+                      const float* goal, const int32_t* episode_len, const int64_t* cum_len, int32_t n_episodes,
+                      int32_t t1, int32_t fixed_length) {
+    if (!c) return FBHIP_E_INVALID;
+    if (!observation || !action || !discount || !episode_len || n_episodes < 1 || t1 < 2) { c->err = g_err = "fbhip: bad replay storage"; return FBHIP_E_INVALID; }
+    if (c->d.use_goal && !goal) { c->err = g_err = "fbhip: goal storage required when use_goal"; return FBHIP_E_INVALID; }
+    if (!fixed_length && !cum_len) { c->err = g_err = "fbhip: cum_len required for variable-length episodes"; return FBHIP_E_INVALID; }
+    c->rv.observation = observation; c->rv.action = action; c->rv.discount = discount; c->rv.goal = goal;
+    c->rv.episode_len = episode_len; c->rv.cum_len = cum_len; c->rv.n_episodes = n_episodes; c->rv.t1 = t1;
+    c->rv.fixed_length = fixed_length;
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+    c->replay_bound = true;
+    return FBHIP_OK;
+}
+
+int fbhip_set_seed(fbhip_ctx* c, uint64_t seed, uint32_t rank) {
+    if (!c) return FBHIP_E_INVALID;
+    c->seed = seed; c->rank = rank;
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
+    return FBHIP_OK;
+}
+
+int fbhip_set_step_counts(fbhip_ctx* c, int32_t fb_steps, int32_t actor_steps, void* stream) {
+    RC(need_bound(c, false));
+    hipStream_t s = (hipStream_t)stream;
+    StepState h{};
+    HIPCK(c, hipMemcpyAsync(&h, c->w.st, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    h.fb_t = fb_steps; h.actor_t = actor_steps;
+    HIPCK(c, hipMemcpyAsync(c->w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    return FBHIP_OK;
+}
+
+int fbhip_get_step_counts(fbhip_ctx* c, int32_t* host_fb_steps, int32_t* host_actor_steps, void* stream) {
+    RC(need_bound(c, false));
+    hipStream_t s = (hipStream_t)stream;
+    StepState h{};
+    HIPCK(c, hipMemcpyAsync(&h, c->w.st, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    if (host_fb_steps) *host_fb_steps = h.fb_t;
+    if (host_actor_steps) *host_actor_steps = h.actor_t;
+    return FBHIP_OK;
+}
+
+int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inject, int32_t phase_mask,
+                 int32_t use_graph, void* stream) {
+    RC(need_bound(c, (phase_mask & FBHIP_PHASE_SAMPLE) != 0));
+    if (!hp) { c->err = g_err = "fbhip: null hparams"; return FBHIP_E_INVALID; }
+    if (hp->q_loss) { c->err = g_err = "fbhip: q_loss=True is not implemented in the HIP path yet"; return FBHIP_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
+    for (auto& g : c->graphs) {
+        if (g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
+            (!inject || memcmp(&g.inj, inject, sizeof(*inject)) == 0)) {
+            HIPCK(c, hipGraphLaunch(g.exec, s));
+            return FBHIP_OK;
+        }
+    }
+    hipGraph_t graph = nullptr;
+    HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_update(c, *hp, inject, phase_mask, s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIPCK(c, e);
+    GraphEntry ge{};
+    ge.mask = phase_mask; ge.hp = *hp; ge.has_inj = inject != nullptr;
+    if (inject) ge.inj = *inject;
+    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIPCK(c, e);
+    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    c->graphs.push_back(ge);
+    HIPCK(c, hipGraphLaunch(ge.exec, s));
+    return FBHIP_OK;
+}
+
+int fbhip_read_metrics(fbhip_ctx* c, float* host_out, void* stream) {
+    RC(need_bound(c, false));
+    if (!host_out) return FBHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCK(c, hipMemcpyAsync(host_out, c->w.metrics, FBHIP_NUM_METRICS * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    return FBHIP_OK;
+}
+
+int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld) {
+    RC(need_bound(c, false));
+    if (!name || !ptr) return FBHIP_E_INVALID;
+    Ws& w = c->w;
+    const fbhip_dims& d = c->d;
+    const int B = d.batch, o = d.obs_dim, a = d.action_dim, z = d.z_dim;
+    std::map<std::string, Buf> m = {
+        {"Xoa", w.Xoa}, {"Xoz", w.Xoz}, {"Xnoz", w.Xnoz}, {"Xnoa", w.Xnoa}, {"Xopi", w.Xopi}, {"next_goal", w.next_goal},
+        {"backward_input", w.bin}, {"z", w.z}, {"zrand", w.zrand}, {"F1", w.fsO.F1}, {"F2", w.fsO.F2}, {"Bm", w.bsO.Bm},
+        {"y", w.bsO.y}, {"tF1", w.fsT.F1}, {"tF2", w.fsT.F2}, {"tB", w.bsA.Bm}, {"dF1", w.dF1}, {"dF2", w.dF2},
+        {"dBm", w.dBm}, {"dy", w.dy}, {"mu", w.as.mu}, {"d_premu", w.a_dpremu}};
+    Buf b;
+    const std::string n(name);
+    if (m.count(n)) b = m[n];
+    else if (n == "obs") { b = w.Xoz; b.cols = o; }
+    else if (n == "next_obs") { b = w.Xnoz; b.cols = o; }
+    else if (n == "action") { b = w.Xoa; b.p += o; b.cols = a; }
+    else if (n == "next_action") { b = w.Xnoa; b.p += o; b.cols = a; }
+    else if (n == "pi_action") { b = w.Xopi; b.p += o; b.cols = a; }
+    else if (n == "discount") { b.p = w.disc; b.rows = B; b.cols = 1; b.ld = 1; }
+    else if (n == "metrics") { b.p = w.metrics; b.rows = 1; b.cols = FBHIP_NUM_METRICS; b.ld = FBHIP_NUM_METRICS; }
+    else if (n == "z_gauss") { b.p = w.so.z_gauss; b.rows = B; b.cols = z; b.ld = z; }
+    else if (n == "ep_idx") { b.p = (float*)w.so.ep_idx; b.rows = 1; b.cols = B; b.ld = B; }
+    else if (n == "step_idx") { b.p = (float*)w.so.step_idx; b.rows = 1; b.cols = B; b.ld = B; }
+    else if (n == "perm") { b.p = (float*)w.so.perm; b.rows = 1; b.cols = B; b.ld = B; }
+    else if (n == "mix_uniform") { b.p = w.so.mix_uniform; b.rows = 1; b.cols = B; b.ld = B; }
+    else if (n == "eps_next") { b.p = w.so.eps_next; b.rows = B; b.cols = a; b.ld = a; }
+    else if (n == "eps_actor") { b.p = w.so.eps_actor; b.rows = B; b.cols = a; b.ld = a; }
+    else { c->err = g_err = "fbhip: unknown workspace view '" + n + "'"; return FBHIP_E_INVALID; }
+    *ptr = b.p;
+    if (rows) *rows = b.rows;
+    if (cols) *cols = b.cols;
+    if (ld) *ld = b.ld;
+    return FBHIP_OK;
+}
+
+// ---- inference entry points ----------------------------------------------------------------------------------
+int fbhip_actor_forward(fbhip_ctx* c, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z, int32_t rows,
+                        const float* noise, float stddev, float clip, float* action_out, int32_t ld_out, void* stream) {
+    RC(need_bound(c, false));
+    if (!obs || !z || !action_out || rows < 1) return FBHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const fbhip_dims& d = c->d;
+    Ws& w = c->w;
+    const int La = pad4(d.action_dim);
+    for (int r0 = 0; r0 < rows; r0 += d.batch) {
+        const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
+        HIPCK(c, launch_concat2(w.Xoz.p, w.Xoz.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, z + (size_t)r0 * ld_z, ld_z,
+                                d.z_dim, n, s));
+        RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, n, s));
+        HIPCK(c, launch_policy_sample(w.as.premu.p, La, noise ? noise + (size_t)r0 * d.action_dim : nullptr, d.action_dim,
+                                      stddev, clip, nullptr, 0, action_out + (size_t)r0 * ld_out, ld_out, n, d.action_dim, s));
+    }
+    return FBHIP_OK;
+}
+
+int fbhip_backward_map(fbhip_ctx* c, int32_t which, const float* goal, int32_t ld_goal, int32_t rows, float* out,
+                       int32_t ld_out, void* stream) {
+    RC(need_bound(c, false));
+    if (!goal || !out || rows < 1) return FBHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const fbhip_dims& d = c->d;
+    Ws& w = c->w;
+    for (int r0 = 0; r0 < rows; r0 += d.batch) {
+        const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
+        RC(backward_map_fwd(c, which ? c->K_t : c->K_p, goal + (size_t)r0 * ld_goal, ld_goal, w.bsA, n, s));
+        HIPCK(c, launch_concat2(out + (size_t)r0 * ld_out, ld_out, w.bsA.Bm.p, w.bsA.Bm.ld, d.z_dim, nullptr, 0, 0, n, s));
+    }
+    return FBHIP_OK;
+}
+
+int fbhip_forward_map(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z,
+                      const float* action, int32_t ld_act, int32_t rows, float* f1_out, float* f2_out, int32_t ld_out,
+                      void* stream) {
+    RC(need_bound(c, false));
+    if (!obs || !z || !action || !f1_out || !f2_out || rows < 1) return FBHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const fbhip_dims& d = c->d;
+    Ws& w = c->w;
+    for (int r0 = 0; r0 < rows; r0 += d.batch) {
+        const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
+        HIPCK(c, launch_concat2(w.Xoz.p, w.Xoz.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, z + (size_t)r0 * ld_z, ld_z, d.z_dim, n, s));
+        HIPCK(c, launch_concat2(w.Xoa.p, w.Xoa.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, action + (size_t)r0 * ld_act, ld_act, d.action_dim, n, s));
+        RC(forward_map_fwd(c, which ? c->F_t : c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsT, n, s));
+        HIPCK(c, launch_concat2(f1_out + (size_t)r0 * ld_out, ld_out, w.fsT.F1.p, w.fsT.F1.ld, d.z_dim, nullptr, 0, 0, n, s));
+        HIPCK(c, launch_concat2(f2_out + (size_t)r0 * ld_out, ld_out, w.fsT.F2.p, w.fsT.F2.ld, d.z_dim, nullptr, 0, 0, n, s));
+    }
+    return FBHIP_OK;
+}
+
+// ---- individually testable kernels -------------------------------------------------------------------------------
+int fbhip_gemm(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig, float* C,
+               int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* aux, int32_t ldaux,
+               int32_t epi, float* colsum, void* stream) {
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1 || epi < 0 || epi > 4) { g_err = "fbhip_gemm: bad argument"; return FBHIP_E_INVALID; }
+    if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias) { g_err = "fbhip_gemm: bias required"; return FBHIP_E_INVALID; }
+    if ((epi == EPI_MASK_RELU || epi == EPI_TANH_BWD) && !aux) { g_err = "fbhip_gemm: aux required"; return FBHIP_E_INVALID; }
+    return run_gemms(nullptr, {P(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, aux, ldaux, colsum)},
+                     (hipStream_t)stream);
+}
+
+int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
+                   float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t cfg, void* stream) {
+    if (cfg < 0 || cfg >= CFG_COUNT) return FBHIP_E_INVALID;
+    GemmGroup g{};
+    GemmProblem p = P(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K);
+    gemm_problem_finalize(p, cfg);
+    p.tile_start = 0;
+    g.p[0] = p; g.n = 1; g.total_tiles = p.tiles_m * p.tiles_n;
+    fbhip_ctx* none = nullptr;
+    HIPCK(none, launch_gemm_group(g, cfg, (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_ln_tanh_fwd(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
+                      float* stats, int32_t rows, int32_t n, void* stream) {
+    fbhip_ctx* none = nullptr;
+    HIPCK(none, launch_ln_tanh_fwd(x, ldx, gamma, beta, y, ldy, stats, rows, n, (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_ln_tanh_bwd(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x, int32_t ldx,
+                      const float* stats, const float* gamma, float* dx, int32_t lddx, float* dgamma, float* dbeta,
+                      float* partials, int32_t rows, int32_t n, void* stream) {
+    fbhip_ctx* none = nullptr;
+    HIPCK(none, launch_ln_tanh_bwd(dy, lddy, y, ldy, x, ldx, stats, gamma, dx, lddx, dgamma, dbeta, partials, rows, n,
+                                   (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_l2norm_fwd(const float* y, int32_t ldy, float* out, int32_t ldo, float* norms, int32_t rows, int32_t d,
+                     void* stream) {
+    fbhip_ctx* none = nullptr;
+    HIPCK(none, launch_l2norm_fwd(y, ldy, out, ldo, norms, rows, d, sqrtf((float)d), (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_l2norm_bwd(const float* dB, int32_t lddb, const float* y, int32_t ldy, const float* norms, float* dy,
+                     int32_t lddy, int32_t rows, int32_t d, void* stream) {
+    fbhip_ctx* none = nullptr;
+    HIPCK(none, launch_l2norm_bwd(dB, lddb, y, ldy, norms, dy, lddy, rows, d, (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+size_t fbhip_pairwise_scratch_floats(int32_t B, int32_t d) { return pairwise_scratch_floats(B, d); }
+
+int fbhip_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
+                      const float* tB, const float* discount, int32_t B, int32_t d, int32_t ld, float ortho_coef,
+                      float* dF1, float* dF2, float* dB, float* metrics, float* scratch, void* stream) {
+    fbhip_ctx* none = nullptr;
+    if (!scratch) { g_err = "fbhip_pairwise_fb: scratch required"; return FBHIP_E_INVALID; }
+    HIPCK(none, pairwise_prepare(B, d));
+    HIPCK(none, launch_pairwise_fb(F1, F2, Bm, tF1, tF2, tB, discount, B, d, ld, ortho_coef, dF1, dF2, dB, metrics, scratch,
+                                   (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_adam_ema(float* params, const float* grads, float* m, float* v, float* target, int64_t numel, float lr,
+                   int32_t t, float grad_scale, float tau, void* stream) {
+    fbhip_ctx* none = nullptr;
+    HIPCK(none, launch_adam_ema(params, grads, m, v, target, numel, lr, lr, numel, grad_scale, tau, nullptr, 0, t,
+                                (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float* z, int32_t ldz, const float* mu,
+                     int32_t ldmu, const float* action, int32_t lda, float stddev, float* dF1, float* dF2, float* metrics,
+                     int32_t rows, int32_t d, int32_t a, void* stream) {
+    fbhip_ctx* none = nullptr;
+    HIPCK(none, launch_actor_loss(F1, F2, ldf, z, ldz, mu, ldmu, action, lda, stddev, dF1, dF2, metrics, rows, d, a,
+                                  (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Internal declarations shared by the gfx950 kernels and the C-ABI translation unit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace fbhip {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// epilogue kinds of the grouped GEMM (mirrors include/fbhip.h::fbhip_gemm)
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK_RELU = 3, EPI_TANH_BWD = 4 };
+
+// One GEMM of a grouped launch: C[M,N] = epi(sum_k A(m,k) * B(n,k)).
+struct GemmProblem {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* aux;
+    float* colsum;
+    int M, N, K;
+    int lda, ldb, ldc, ldaux;
+    int a_kcontig, b_kcontig;
+    int a_vec, b_vec;        // 16-byte aligned base + ld % 4 == 0 -> float4 global loads
+    int epi;
+    int tiles_m, tiles_n, tile_start;
+};
+
+constexpr int MAX_GROUP = 8;
+struct GemmGroup {
+    GemmProblem p[MAX_GROUP];
+    int n;
+    int total_tiles;
+};
+
+// tile configurations: <waves along M, waves along N, waves along K>, each wave owns one 32x32 MFMA tile
+enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4x1x1 = 4, CFG_COUNT };
+
+hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
+int pick_gemm_cfg(int M, int N, int K);
+void gemm_problem_finalize(GemmProblem& p, int cfg);   // fills a_vec/b_vec/tiles_*
+
+// ---- row-wise ops ------------------------------------------------------------------------------------
+hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
+                              float* stats, int rows, int n, hipStream_t s);
+hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx,
+                              const float* stats, const float* gamma, float* dx, int lddx,
+                              float* dgamma, float* dbeta, float* partials, int rows, int n, hipStream_t s);
+constexpr int LN_BWD_ROWS_PER_BLOCK = 8;
+hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float* norms, int rows, int d,
+                             float scale, hipStream_t s);
+// policy head: mu = tanh(pre); action = clampST(mu + clip(noise*std))   (utils.py:171-185)
+hipError_t launch_policy_sample(const float* pre, int ldp, const float* noise, int ldn, float stddev, float clip,
+                                float* mu, int ldmu, float* action, int lda, int rows, int a, hipStream_t s);
+// actor loss (fb_ddpg.py:400-406): Q = min(F1.z, F2.z); loss = -mean Q; dF_i = -z/B * w_i
+hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz,
+                             const float* mu, int ldmu, const float* action, int lda, float stddev,
+                             float* dF1, float* dF2, float* metrics, int rows, int d, int a, hipStream_t s);
+
+// ---- pairwise FB loss ----------------------------------------------------------------------------------
+size_t pairwise_scratch_floats(int B, int d);
+hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1,
+                              const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
+                              float ortho_coef, float* dF1, float* dF2, float* dB, float* metrics,
+                              float* scratch, hipStream_t s);
+// dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB))      (F.normalize backward)
+hipError_t launch_l2norm_bwd(const float* dB, int lddb, const float* y, int ldy, const float* norms,
+                             float* dy, int lddy, int rows, int d, hipStream_t s);
+
+// ---- optimiser -------------------------------------------------------------------------------------------
+struct StepState {          // device-resident, advanced in-graph
+    int fb_t;               // Adam step counts (1-based after the first step)
+    int actor_t;
+    unsigned int update_count;   // RNG counter: number of update() calls so far
+    int pad;
+    double fb_bc1;          // 1 - beta1^t          (fp64 like torch's python-side scalars)
+    double fb_bc2_sqrt;     // sqrt(1 - beta2^t)
+    double actor_bc1;
+    double actor_bc2_sqrt;
+};
+hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z, int ld, int rows, int d,
+                                const float* cov, int ldc, float* metrics, hipStream_t s);
+hipError_t launch_step_advance(StepState* st, int which /*0 fb, 1 actor, 2 rng*/, hipStream_t s);
+hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel,
+                           float lr, float lr2, int64_t split, float grad_scale, float tau,
+                           const StepState* st, int which, int t_explicit, hipStream_t s);
+
+// ---- sampler -----------------------------------------------------------------------------------------------
+struct ReplayView {
+    const float* observation; const float* action; const float* discount; const float* goal;
+    const int32_t* episode_len; const int64_t* cum_len;
+    int n_episodes, t1, fixed_length;
+};
+struct SampleOut {          // all device pointers into the workspace
+    int32_t* ep_idx; int32_t* step_idx; int32_t* perm; float* mix_uniform;
+    float* z_gauss; float* eps_next; float* eps_actor;
+};
+hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a,
+                       uint64_t seed, uint32_t rank, const StepState* st, unsigned long long* perm_keys,
+                       hipStream_t s);
+struct GatherArgs {
+    ReplayView rv;
+    const int32_t* ep_idx; const int32_t* step_idx; const int32_t* perm;
+    float* Xoa; int ld_oa;      // [obs | action]
+    float* Xoz; int ld_oz;      // [obs | z]          (z filled later)
+    float* Xnoz; int ld_noz;    // [next_obs | z]
+    float* Xnoa; int ld_noa;    // [next_obs | next_action]  (action filled later)
+    float* Xopi; int ld_opi;    // [obs | pi action]         (action filled later)
+    float* next_goal; int ld_ng;    // only when use_goal
+    float* bin; int ld_bin;     // backward_input[perm]
+    float* disc;
+    int B, o, a, g, use_goal; float gamma;
+};
+hipError_t launch_gather(const GatherArgs& ga, hipStream_t s);
+// z[i] = mix ? sqrt(d)*normalize(Bmix[i]) : zrand[i]; scattered into the concat buffers
+hipError_t launch_mix_z(const float* zrand, const float* Bmix, int ldz, const float* mix_uniform, float mix_ratio,
+                        float* z, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
+                        hipStream_t s);
+
+hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, const float* B, int ldb, int nb,
+                          int rows, hipStream_t s);
+hipError_t pairwise_prepare(int B, int d);     // one-time kernel attribute setup (outside graph capture)
+
+inline int pad4(int x) { return (x + 3) & ~3; }
+
+}  // namespace fbhip

@@ -1,0 +1,256 @@
+// Grouped fp32 GEMM for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//
+// Covers every dense contraction of the FB-DDPG step:
+//   forward   Y[M,N]  = X[M,K]  . W[N,K]^T (+bias, relu)      a_kcontig=1 b_kcontig=1   (nn.Linear, fb_modules.py:60-78)
+//   dgrad     dX[M,K] = dY[M,N] . W[N,K]   (* relu mask)       a_kcontig=1 b_kcontig=0
+//   wgrad     dW[N,K] = dY[M,N]^T . X[M,K] (+ bias grad)       a_kcontig=0 b_kcontig=0
+// One launch runs up to MAX_GROUP independent problems (e.g. the two trunks of a ForwardMap, the F1/F2
+// heads), so small layers share the 256 CUs instead of serialising.
+//
+// Structure: 256 threads = 4 waves; each wave owns ONE 32x32 accumulator (16 VGPRs) -- the 32x32x2 f32 MFMA
+// has issue interval == dependent latency == 64 cycles, so a single accumulator chain per SIMD already runs the
+// matrix pipe back-to-back.  Waves are arranged WM x WN x WK: WK > 1 splits the K range inside the workgroup
+// (partial tiles are reduced through LDS) so skinny outputs (N = z_dim, N = action_dim, N = feature_dim) still
+// put four waves on every CU.  Operand tiles are staged global -> registers -> LDS as [k][row] (row stride
+// odd => conflict-free ds_read_b32 for both operands), double-buffered with one barrier per K step; the global
+// loads of step t+1 are issued before the MFMAs of step t.
+#include "common.h"
+
+namespace fbhip {
+
+template <int ROWS, int BKT, int Q>
+__device__ __forceinline__ void load_tile(float4 (&v)[Q], const float* __restrict__ src, int ld, int kcontig,
+                                          int vec, int row0, int nrows, int k0, int K, int tid) {
+    if (kcontig) {
+        constexpr int QK = BKT / 4;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const int q = tid + i * 256;
+            const int r = q / QK, kq = q % QK;
+            const int gr = row0 + r, gk = k0 + 4 * kq;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < nrows && gk < K) {
+                const float* ptr = src + (size_t)gr * ld + gk;
+                if (vec && gk + 3 < K) {
+                    x = *reinterpret_cast<const float4*>(ptr);
+                } else {
+                    x.x = ptr[0];
+                    if (gk + 1 < K) x.y = ptr[1];
+                    if (gk + 2 < K) x.z = ptr[2];
+                    if (gk + 3 < K) x.w = ptr[3];
+                }
+            }
+            v[i] = x;
+        }
+    } else {
+        constexpr int QR = ROWS / 4;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const int q = tid + i * 256;
+            const int k = q / QR, rq = q % QR;
+            const int gk = k0 + k, gr = row0 + 4 * rq;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gk < K && gr < nrows) {
+                const float* ptr = src + (size_t)gk * ld + gr;
+                if (vec && gr + 3 < nrows) {
+                    x = *reinterpret_cast<const float4*>(ptr);
+                } else {
+                    x.x = ptr[0];
+                    if (gr + 1 < nrows) x.y = ptr[1];
+                    if (gr + 2 < nrows) x.z = ptr[2];
+                    if (gr + 3 < nrows) x.w = ptr[3];
+                }
+            }
+            v[i] = x;
+        }
+    }
+}
+
+template <int ROWS, int BKT, int Q, int LD>
+__device__ __forceinline__ void store_tile(const float4 (&v)[Q], float* __restrict__ s, int kcontig, int tid) {
+    if (kcontig) {
+        constexpr int QK = BKT / 4;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const int q = tid + i * 256;
+            const int r = q / QK, kq = q % QK;
+            float* d = s + (4 * kq) * LD + r;
+            d[0] = v[i].x;
+            d[LD] = v[i].y;
+            d[2 * LD] = v[i].z;
+            d[3 * LD] = v[i].w;
+        }
+    } else {
+        constexpr int QR = ROWS / 4;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const int q = tid + i * 256;
+            const int k = q / QR, rq = q % QR;
+            float* d = s + k * LD + 4 * rq;
+            d[0] = v[i].x;
+            d[1] = v[i].y;
+            d[2] = v[i].z;
+            d[3] = v[i].w;
+        }
+    }
+}
+
+template <int WM, int WN, int WK, int BK>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, BKT = BK * WK;
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    constexpr int STAGE = BKT * (LDA_S + LDB_S);
+    constexpr int QA = BM * BKT / 1024, QB = BN * BKT / 1024;
+    static_assert(WM * WN * WK == 4, "four waves per workgroup");
+    static_assert((BM * BKT) % 1024 == 0 && (BN * BKT) % 1024 == 0, "tile must split into float4 per thread");
+    static_assert((WK - 1) * WM * WN * 17 * 64 <= 2 * STAGE, "split-K reduction scratch must fit");
+    __shared__ float smem[2 * STAGE];
+
+    // XCD-aware bijective remap: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so
+    // neighbours (same A row-panel, adjacent B panels) share that XCD's L2.
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+        if (i < g.n && lid >= g.p[i].tile_start) pi = i;
+    const GemmProblem& p = g.p[pi];
+    const int t = lid - p.tile_start;
+    const int tn = t % p.tiles_n, tm = t / p.tiles_n;
+    const int M = p.M, N = p.N, K = p.K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wk = wid / (WM * WN), wrem = wid % (WM * WN);
+    const int wm = wrem / WN, wn = wrem % WN;
+
+    const float* __restrict__ A = p.A;
+    const float* __restrict__ Bp = p.B;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float csum = 0.f;
+
+    float4 ra[QA], rb[QB];
+    const int nt = (K + BKT - 1) / BKT;
+    load_tile<BM, BKT, QA>(ra, A, p.lda, p.a_kcontig, p.a_vec, row0, M, 0, K, tid);
+    load_tile<BN, BKT, QB>(rb, Bp, p.ldb, p.b_kcontig, p.b_vec, col0, N, 0, K, tid);
+    store_tile<BM, BKT, QA, LDA_S>(ra, smem, p.a_kcontig, tid);
+    store_tile<BN, BKT, QB, LDB_S>(rb, smem + BKT * LDA_S, p.b_kcontig, tid);
+    __syncthreads();
+
+    for (int it = 0; it < nt; ++it) {
+        const float* sA = smem + (it & 1) * STAGE;
+        const float* sB = sA + BKT * LDA_S;
+        const bool more = (it + 1 < nt);
+        if (more) {
+            load_tile<BM, BKT, QA>(ra, A, p.lda, p.a_kcontig, p.a_vec, row0, M, (it + 1) * BKT, K, tid);
+            load_tile<BN, BKT, QB>(rb, Bp, p.ldb, p.b_kcontig, p.b_vec, col0, N, (it + 1) * BKT, K, tid);
+        }
+        const float* a = sA + (wk * BK + h) * LDA_S + wm * 32 + l31;
+        const float* b = sB + (wk * BK + h) * LDB_S + wn * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float av = a[kk * LDA_S];
+            const float bv = b[kk * LDB_S];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            csum += av;
+        }
+        if (more) {
+            float* dA = smem + ((it + 1) & 1) * STAGE;
+            store_tile<BM, BKT, QA, LDA_S>(ra, dA, p.a_kcontig, tid);
+            store_tile<BN, BKT, QB, LDB_S>(rb, dA + BKT * LDA_S, p.b_kcontig, tid);
+        }
+        __syncthreads();
+    }
+
+    if constexpr (WK > 1) {
+        // reduce the WK partial tiles (and the partial column sums) through LDS; wave group wk == 0 finishes
+        float* red = smem;
+        if (wk > 0) {
+            float* dst = red + ((wk - 1) * (WM * WN) + wrem) * (17 * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[i * 64] = acc[i];
+            dst[16 * 64] = csum;
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int j = 0; j < WK - 1; ++j) {
+            const float* srcp = red + (j * (WM * WN) + wrem) * (17 * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += srcp[i * 64];
+            csum += srcp[16 * 64];
+        }
+    }
+
+    if (p.colsum != nullptr && tn == 0 && wn == 0) {
+        const float tot = csum + __shfl_xor(csum, 32);
+        const int r = row0 + wm * 32 + l31;
+        if (h == 0 && r < M) p.colsum[r] = tot;
+    }
+
+    const int col = col0 + wn * 32 + l31;
+    if (col >= N) return;
+    const int epi = p.epi;
+    const float bias = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? p.bias[col] : 0.f;
+    float* __restrict__ C = p.C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) {
+            float v = acc[r];
+            if (epi == EPI_BIAS) {
+                v += bias;
+            } else if (epi == EPI_BIAS_RELU) {
+                v = fmaxf(v + bias, 0.f);
+            } else if (epi == EPI_MASK_RELU) {
+                v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
+            } else if (epi == EPI_TANH_BWD) {
+                const float y = p.aux[(size_t)row * p.ldaux + col];
+                v = v * (1.f - y * y);
+            }
+            C[(size_t)row * p.ldc + col] = v;
+        }
+    }
+}
+
+static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4};
+static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1};
+
+void gemm_problem_finalize(GemmProblem& p, int cfg) {
+    const int BM = 32 * kCfgWM[cfg], BN = 32 * kCfgWN[cfg];
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    p.a_vec = (((uintptr_t)p.A & 15) == 0 && (p.lda & 3) == 0) ? 1 : 0;
+    p.b_vec = (((uintptr_t)p.B & 15) == 0 && (p.ldb & 3) == 0) ? 1 : 0;
+}
+
+int pick_gemm_cfg(int M, int N, int K) {
+    const long tiles32 = (long)((M + 31) / 32) * ((N + 31) / 32);
+    if (K <= 64) return (N <= 32) ? CFG_4x1x1 : CFG_2x2x1;      // nothing to split
+    if (tiles32 >= 768) return CFG_2x2x1;
+    if (tiles32 >= 320) return (N >= M) ? CFG_1x2x2 : CFG_2x1x2;
+    return CFG_1x1x4;
+}
+
+hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
+    if (g.total_tiles <= 0) return hipSuccess;
+    dim3 grid(g.total_tiles), block(256);
+    switch (cfg) {
+        case CFG_2x2x1: hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 32>), grid, block, 0, stream, g); break;
+        case CFG_2x1x2: hipLaunchKernelGGL((gemm_kernel<2, 1, 2, 32>), grid, block, 0, stream, g); break;
+        case CFG_1x2x2: hipLaunchKernelGGL((gemm_kernel<1, 2, 2, 32>), grid, block, 0, stream, g); break;
+        case CFG_1x1x4: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 16>), grid, block, 0, stream, g); break;
+        case CFG_4x1x1: hipLaunchKernelGGL((gemm_kernel<4, 1, 1, 32>), grid, block, 0, stream, g); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace fbhip

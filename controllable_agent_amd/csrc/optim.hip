@@ -1,0 +1,142 @@
+// Fused Adam + soft-target EMA over a flat fp32 segment, and the tiny in-graph step-state kernel.
+//   torch.optim.Adam defaults (fb_ddpg.py:146-151): betas (0.9, 0.999), eps 1e-8, no weight decay:
+//     m <- m + (1-b1)(g - m);  v <- b2 v + (1-b2) g g;  p <- p - (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+//   utils.soft_update_params (utils.py:66-69):  target <- tau p + (1-tau) target
+// The reference issues 28 x (lerp, mul, addcmul, sqrt, div, add, addcdiv) + 28 x 4 EMA launches per FB step;
+// here it is ONE pass over {p, g, m, v, target}: 5 reads + 4 writes of 16 B per lane.  Fusing the EMA into the
+// FB Adam pass is legal because nothing between fb_opt.step() and soft_update_params reads a target net or
+// writes forward_net/backward_net.
+#include "common.h"
+#include "fbhip.h"
+
+namespace fbhip {
+
+__global__ void step_advance_kernel(StepState* st, int which) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (which == 2) {
+        st->update_count += 1u;
+        return;
+    }
+    int t;
+    if (which == 0) { st->fb_t += 1; t = st->fb_t; } else { st->actor_t += 1; t = st->actor_t; }
+    const double bc1 = 1.0 - pow(0.9, (double)t);
+    const double bc2s = sqrt(1.0 - pow(0.999, (double)t));
+    if (which == 0) { st->fb_bc1 = bc1; st->fb_bc2_sqrt = bc2s; } else { st->actor_bc1 = bc1; st->actor_bc2_sqrt = bc2s; }
+}
+
+hipError_t launch_step_advance(StepState* st, int which, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, st, which);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                       float4* __restrict__ m, float4* __restrict__ v,
+                                                       float4* __restrict__ tgt, int64_t nquad, float lr, float lr2,
+                                                       int64_t split_quad, float grad_scale, float tau,
+                                                       const StepState* __restrict__ st, int which, int t_explicit) {
+    double bc1, bc2s;
+    if (st != nullptr) {
+        bc1 = which == 0 ? st->fb_bc1 : st->actor_bc1;
+        bc2s = which == 0 ? st->fb_bc2_sqrt : st->actor_bc2_sqrt;
+    } else {
+        bc1 = 1.0 - pow(0.9, (double)t_explicit);
+        bc2s = sqrt(1.0 - pow(0.999, (double)t_explicit));
+    }
+    const float ss1 = (float)((double)lr / bc1), ss2 = (float)((double)lr2 / bc1);
+    const float bc2f = (float)bc2s;
+    const float w1 = (float)(1.0 - 0.9), w2 = (float)(1.0 - 0.999), b2 = 0.999f, eps = 1e-8f;
+    const float omt = (float)(1.0 - (double)tau);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquad; i += stride) {
+        const float ss = i < split_quad ? ss1 : ss2;
+        float4 gg = g[i], mm = m[i], vv = v[i], pp = p[i];
+#define ADAM1(c)                                                         \
+        {                                                                \
+            const float gr = gg.c * grad_scale;                          \
+            mm.c = mm.c + w1 * (gr - mm.c);                              \
+            vv.c = vv.c * b2 + (w2 * gr) * gr;                           \
+            const float den = sqrtf(vv.c) / bc2f + eps;                  \
+            pp.c = pp.c - ss * (mm.c / den);                             \
+        }
+        ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+        m[i] = mm; v[i] = vv; p[i] = pp;
+        if (tgt != nullptr) {
+            float4 tt = tgt[i];
+            tt.x = tau * pp.x + omt * tt.x; tt.y = tau * pp.y + omt * tt.y;
+            tt.z = tau * pp.z + omt * tt.z; tt.w = tau * pp.w + omt * tt.w;
+            tgt[i] = tt;
+        }
+    }
+}
+
+hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel, float lr,
+                           float lr2, int64_t split, float grad_scale, float tau, const StepState* st, int which,
+                           int t_explicit, hipStream_t s) {
+    if (numel <= 0) return hipSuccess;
+    if ((numel & 3) || (split & 3)) return hipErrorInvalidValue;
+    const int64_t nquad = numel / 4;
+    int blocks = (int)((nquad + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m,
+                       (float4*)v, (float4*)target, nquad, lr, lr2, split / 4, grad_scale, tau, st, which, t_explicit);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Extra metrics of fb_ddpg.py:356-377 that are not by-products of the pairwise kernel: F1.mean(), B.mean(),
+// mean row norms of B and z, and max|.| / Frobenius of (B^T B / batch - I).  One workgroup; metric-only path.
+__global__ void __launch_bounds__(1024) extra_metrics_kernel(const float* __restrict__ F1, const float* __restrict__ Bm,
+                                                             const float* __restrict__ z, int ld, int rows, int d,
+                                                             const float* __restrict__ cov /*[d,d] = B^T B*/,
+                                                             int ldc, float* __restrict__ metrics) {
+    __shared__ double red[16][6];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double sF = 0, sB = 0, sBn = 0, sZn = 0, sL2 = 0, mx = 0;
+    for (int r = wid; r < rows; r += 16) {
+        float f = 0.f, b = 0.f, b2 = 0.f, z2 = 0.f;
+        for (int j = lane; j < d; j += 64) {
+            const float bv = Bm[(size_t)r * ld + j], zv = z[(size_t)r * ld + j];
+            f += F1[(size_t)r * ld + j]; b += bv; b2 += bv * bv; z2 += zv * zv;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            f += __shfl_xor(f, o); b += __shfl_xor(b, o); b2 += __shfl_xor(b2, o); z2 += __shfl_xor(z2, o);
+        }
+        sF += f; sB += b; sBn += sqrtf(b2); sZn += sqrtf(z2);
+    }
+    for (int e = tid; e < d * d; e += 1024) {
+        const int i = e / d, j = e % d;
+        const float v = cov[(size_t)i * ldc + j] / (float)rows - (i == j ? 1.f : 0.f);
+        sL2 += (double)v * v;
+        mx = fmax(mx, (double)fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sL2 += __shfl_xor(sL2, o);
+        mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0) { red[wid][0] = sF; red[wid][1] = sB; red[wid][2] = sBn; red[wid][3] = sZn; red[wid][4] = sL2; red[wid][5] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        double a[6] = {0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 16; ++w) {
+            for (int k = 0; k < 5; ++k) a[k] += red[w][k];
+            a[5] = fmax(a[5], red[w][5]);
+        }
+        metrics[FBHIP_M_F1] = (float)(a[0] / ((double)rows * d));
+        metrics[FBHIP_M_B] = (float)(a[1] / ((double)rows * d));
+        metrics[FBHIP_M_B_NORM] = (float)(a[2] / rows);
+        metrics[FBHIP_M_Z_NORM] = (float)(a[3] / rows);
+        metrics[FBHIP_M_ORTH_L2] = (float)(sqrt(a[4]) / sqrt((double)d));
+        metrics[FBHIP_M_ORTH_LINF] = (float)a[5];
+    }
+}
+
+hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z, int ld, int rows, int d,
+                                const float* cov, int ldc, float* metrics, hipStream_t s) {
+    hipLaunchKernelGGL(extra_metrics_kernel, dim3(1), dim3(1024), 0, s, F1, Bm, z, ld, rows, d, cov, ldc, metrics);
+    return hipGetLastError();
+}
+
+}  // namespace fbhip

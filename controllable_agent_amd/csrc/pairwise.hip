@@ -1,0 +1,375 @@
+// Pairwise forward-backward loss for gfx950: fb_ddpg.py:313-348 (target_M, M1, M2, off-diagonal contrastive
+// FB loss, diagonal term, orthonormality loss) AND its gradient wrt F1, F2, B (fb_loss.backward(), :383) in one
+// pass that never materialises a [B,B] matrix.  Closed-form gradients: SURVEY.md appendix C.
+//
+// The reference builds five [B,B] matrices and indexes them with a boolean off-diagonal mask
+// (aten::nonzero + index_put_ backward = ~50 % of its CPU step).  Here the batch x batch grid is cut into
+// 32x32 tiles; each tile is a handful of v_mfma_f32_32x32x2_f32 products over K = z_dim, the mask is the
+// arithmetic predicate (s != t), and the tile's gradient contribution is contracted back immediately.
+//
+// Layout trick: a 32x32 MFMA accumulator holds tile T[r][c] with lane = column c and registers = rows r, which
+// is exactly the A-operand layout of a product T^T . X contracting over the tile's ROWS -- so "sum over rows"
+// needs no shuffle or LDS transpose.  Every workgroup therefore fixes a row-block I (32 batch rows) as the
+// tile COLUMNS and walks blocks J as tile ROWS; everything it accumulates is indexed by I and stays in
+// registers across the J loop:
+//   role 1 (waves 0,1; I plays s, J plays t):  T = B[J] . F_i[I]^T  = M_i[s,t]^T  -> dF_i[I] += G_i^T-contract . B[J]
+//   role 2 (waves 2,3; I plays t, J plays s):  P = F_i[J] . B[I]^T  = M_i[s,t]    -> dB[I]  += G_i  -contract . F_i[J]
+//   cov    (waves 2/3 alternate):              C = B[J] . B[I]^T (symmetric)      -> dB[I]  += 2 c_o H-contract . B[J]
+// I-side operands live in registers as MFMA B-fragments for the whole kernel; J-side tiles are staged in LDS and
+// shared by the four waves.  Partial results over J-chunks go to a scratch buffer and are folded in a fixed
+// order by pairwise_reduce_kernel (deterministic; no atomics).  Scalar sums are wave-shuffle reduced.
+#include "common.h"
+#include "fbhip.h"
+
+namespace fbhip {
+
+namespace {
+
+constexpr int PW_SLOTS = 4;        // dF1, dF2, dB (wave 2), dB (wave 3)
+constexpr int PW_SCAL = 12;        // scalar partials per workgroup
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+struct PwArgs {
+    const float* F1; const float* F2; const float* Bm; const float* tF1; const float* tF2; const float* tB;
+    const float* discount;
+    int B, d, ld;
+    float ortho2;              // 2 * ortho_coef
+    int jpc;                   // J tiles per chunk
+    int njt;                   // number of J tiles (ceil(B/32))
+    float* partial;            // [nchunks][PW_SLOTS][Bp][DP]
+    float* scal;               // [nblocks][PW_SCAL]
+    int Bp;
+};
+
+// stage a [32 x d] row block of X (rows row0..row0+31, zero filled outside [0,B) x [0,d)) into LDS [32][LD]
+template <int LD>
+__device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ X, int ld, int row0,
+                                           int B, int d, int tid) {
+    constexpr int W = LD - 1;
+    for (int e = tid; e < 32 * W; e += 256) {
+        const int r = e / W, n = e % W;
+        const int gr = row0 + r;
+        s[r * LD + n] = (gr < B && n < d) ? X[(size_t)gr * ld + n] : 0.f;
+    }
+}
+
+// acc(32x32) = rowsJ (LDS, [32][LD]) . fragI^T over KS k-steps
+template <int KS, int LD>
+__device__ __forceinline__ floatx16 tile_mm(const float* __restrict__ sJ, const float (&fragI)[KS], int l31, int h) {
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* a = sJ + l31 * LD + h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * ks], fragI[ks], acc, 0, 0, 0);
+    return acc;
+}
+
+// out[nt] += G^T-contract . X[J]:  out[c][n] += sum_r G[r][c] * X[r][n]
+template <int NT, int LD>
+__device__ __forceinline__ void contract_rows(floatx16 (&out)[NT], const floatx16& G, const float* __restrict__ sX,
+                                              int l31, int h) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const float* b = sX + acc_row(reg, h) * LD + l31;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) out[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G[reg], b[32 * nt], out[nt], 0, 0, 0);
+    }
+}
+
+template <int KS, int LD>
+__device__ __forceinline__ void load_frag(float (&f)[KS], const float* __restrict__ sI, int l31, int h) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) f[ks] = sI[l31 * LD + 2 * ks + h];
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
+    constexpr int NT = (2 * KS + 31) / 32;
+    constexpr int W = (2 * KS > 32 * NT ? 2 * KS : 32 * NT);
+    constexpr int LD = W + 1;                       // odd => conflict-free for both access patterns
+    extern __shared__ float lds[];                  // 6 x [32][LD] + gamma[32]
+    float* sBm = lds;
+    float* stB = sBm + 32 * LD;
+    float* sF1 = stB + 32 * LD;
+    float* sF2 = sF1 + 32 * LD;
+    float* stF1 = sF2 + 32 * LD;
+    float* stF2 = stF1 + 32 * LD;
+    float* sGam = stF2 + 32 * LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int I0 = blockIdx.x * 32, chunk = blockIdx.y;
+    const int B = p.B, d = p.d;
+    const float n_off = (float)B * (float)(B - 1);
+    const float inv_noff = 1.0f / n_off, inv_b = 1.0f / (float)B;
+
+    // ---- I-side fragments (registers, whole kernel) ----------------------------------------------------
+    stage_rows<LD>(sBm, p.Bm, p.ld, I0, B, d, tid);
+    stage_rows<LD>(stB, p.tB, p.ld, I0, B, d, tid);
+    stage_rows<LD>(sF1, p.F1, p.ld, I0, B, d, tid);
+    stage_rows<LD>(sF2, p.F2, p.ld, I0, B, d, tid);
+    stage_rows<LD>(stF1, p.tF1, p.ld, I0, B, d, tid);
+    stage_rows<LD>(stF2, p.tF2, p.ld, I0, B, d, tid);
+    __syncthreads();
+    float fa[KS], fb[KS], fc[KS];
+    if (wid < 2) {                   // role 1: F_i[I], tF1[I], tF2[I]
+        load_frag<KS, LD>(fa, wid == 0 ? sF1 : sF2, l31, h);
+        load_frag<KS, LD>(fb, stF1, l31, h);
+        load_frag<KS, LD>(fc, stF2, l31, h);
+    } else {                         // role 2: B[I], tB[I]
+        load_frag<KS, LD>(fa, sBm, l31, h);
+        load_frag<KS, LD>(fb, stB, l31, h);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fc[ks] = 0.f;
+    }
+    const int gcol = I0 + l31;                              // batch index of this lane's tile column
+    const float gam_col = (gcol < B) ? p.discount[gcol] : 0.f;
+    __syncthreads();
+
+    floatx16 out[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[nt][i] = 0.f;
+    float s_sq = 0.f, s_diag = 0.f, s_all = 0.f, s_tall = 0.f, s_csq = 0.f, s_cdiag = 0.f;
+
+    const int jt_begin = chunk * p.jpc;
+    const int jt_end = min(jt_begin + p.jpc, p.njt);
+#pragma unroll 1
+    for (int jt = jt_begin; jt < jt_end; ++jt) {
+        const int J0 = jt * 32;
+        stage_rows<LD>(sBm, p.Bm, p.ld, J0, B, d, tid);
+        stage_rows<LD>(stB, p.tB, p.ld, J0, B, d, tid);
+        stage_rows<LD>(sF1, p.F1, p.ld, J0, B, d, tid);
+        stage_rows<LD>(sF2, p.F2, p.ld, J0, B, d, tid);
+        stage_rows<LD>(stF1, p.tF1, p.ld, J0, B, d, tid);
+        stage_rows<LD>(stF2, p.tF2, p.ld, J0, B, d, tid);
+        if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
+        __syncthreads();
+
+        if (wid < 2) {
+            // tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
+            floatx16 tm = tile_mm<KS, LD>(stB, fb, l31, h);
+            {
+                const floatx16 t2 = tile_mm<KS, LD>(stB, fc, l31, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tm[i] = fminf(tm[i], t2[i]);
+            }
+            floatx16 G = tile_mm<KS, LD>(sBm, fa, l31, h);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int grow = J0 + acc_row(reg, h);
+                const float m = G[reg], t = tm[reg];
+                const float dlt = m - gam_col * t;                 // discount is indexed by s = column here
+                const bool diag = (grow == gcol);
+                s_all += m;
+                s_tall += t;
+                if (diag) {
+                    s_diag += m;
+                    G[reg] = (gcol < B) ? -inv_b : 0.f;
+                } else {
+                    s_sq += dlt * dlt;
+                    G[reg] = dlt * inv_noff;
+                }
+            }
+            contract_rows<NT, LD>(out, G, sBm, l31, h);            // dF_i[I] += G^T-contract . B[J]
+        } else {
+            // tile rows = s (J), cols = t (I):  P[r][c] = M_i[s = J0+r][t = I0+c]
+            floatx16 tm = tile_mm<KS, LD>(stF1, fb, l31, h);
+            {
+                const floatx16 t2 = tile_mm<KS, LD>(stF2, fb, l31, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tm[i] = fminf(tm[i], t2[i]);
+            }
+            const float* sFi = (wid == 2) ? sF1 : sF2;
+            floatx16 G = tile_mm<KS, LD>(sFi, fa, l31, h);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = acc_row(reg, h);
+                const int grow = J0 + r;
+                const float dlt = G[reg] - sGam[r] * tm[reg];      // discount is indexed by s = row here
+                const bool diag = (grow == gcol);
+                G[reg] = diag ? ((gcol < B) ? -inv_b : 0.f) : dlt * inv_noff;
+            }
+            contract_rows<NT, LD>(out, G, sFi, l31, h);            // dB[I] += G-contract . F_i[J]
+            if ((jt & 1) == (wid & 1)) {
+                // covariance tile C[r][c] = B[J0+r] . B[I0+c]  (fb_ddpg.py:344-348)
+                floatx16 C = tile_mm<KS, LD>(sBm, fa, l31, h);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int grow = J0 + acc_row(reg, h);
+                    const float c = C[reg];
+                    const bool diag = (grow == gcol);
+                    if (diag) {
+                        s_cdiag += c;
+                        C[reg] = (gcol < B) ? -p.ortho2 * inv_b : 0.f;
+                    } else {
+                        s_csq += c * c;
+                        C[reg] = p.ortho2 * c * inv_noff;
+                    }
+                }
+                // L_orth = mean_offdiag C^2 - 2 mean_diag C;  dL/dC = Hm = 2C/N_off (off-diag), -2/B (diag);
+                // C = B B^T  =>  dB = ortho * (Hm + Hm^T) B = ortho * 2 * Hm . B.  With ortho2 = 2*ortho the tile
+                // coefficient is ortho2 * Hm = 2 * (ortho2*C/N_off) resp. 2 * (-ortho2/B):
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) C[reg] *= 2.0f;
+                contract_rows<NT, LD>(out, C, sBm, l31, h);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- write partial outputs ---------------------------------------------------------------------------
+    constexpr int DP = 32 * NT;
+    float* dst = p.partial + (((size_t)chunk * PW_SLOTS + wid) * p.Bp + I0) * DP;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) dst[(size_t)acc_row(reg, h) * DP + nt * 32 + l31] = out[nt][reg];
+
+    float* sc = p.scal + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PW_SCAL;
+    s_sq = wsum(s_sq); s_diag = wsum(s_diag); s_all = wsum(s_all); s_tall = wsum(s_tall);
+    s_csq = wsum(s_csq); s_cdiag = wsum(s_cdiag);
+    if (lane == 0) {
+        if (wid == 0) { sc[0] = s_sq; sc[1] = s_diag; sc[2] = s_all; sc[3] = s_tall; }
+        if (wid == 1) { sc[4] = s_sq; sc[5] = s_diag; }
+        if (wid == 2) { sc[6] = s_csq; sc[7] = s_cdiag; }
+        if (wid == 3) { sc[8] = s_csq; sc[9] = s_cdiag; }
+    }
+}
+
+__global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __restrict__ partial,
+                                                              const float* __restrict__ scal, int nchunks,
+                                                              int nblocks, int B, int Bp, int d, int DP, int ld,
+                                                              float ortho_coef, float* __restrict__ dF1,
+                                                              float* __restrict__ dF2, float* __restrict__ dB,
+                                                              float* __restrict__ metrics) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < B * d) {
+        const int r = idx / d, n = idx % d;
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const float* base = partial + ((size_t)ch * PW_SLOTS * Bp + r) * DP + n;
+            a += base[0];
+            b += base[(size_t)Bp * DP];
+            c += base[(size_t)2 * Bp * DP] + base[(size_t)3 * Bp * DP];
+        }
+        dF1[(size_t)r * ld + n] = a;
+        dF2[(size_t)r * ld + n] = b;
+        dB[(size_t)r * ld + n] = c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // wave 0 of workgroup 0: lane k < 10 folds scalar slot k over all workgroups (fixed order, fp64)
+        double s = 0.0;
+        if (threadIdx.x < 10)
+            for (int bk = 0; bk < nblocks; ++bk) s += (double)scal[(size_t)bk * PW_SCAL + threadIdx.x];
+        double tot[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) tot[k] = __shfl(s, k);
+        if (threadIdx.x == 0 && metrics != nullptr) {
+            const double noff = (double)B * (double)(B - 1), bb = (double)B;
+            const double fb_off = 0.5 * (tot[0] + tot[4]) / noff;
+            const double fb_diag = -(tot[1] + tot[5]) / bb;
+            const double orth_off = (tot[6] + tot[8]) / noff;
+            const double orth_diag = -2.0 * (tot[7] + tot[9]) / bb;
+            metrics[FBHIP_M_FB_OFFDIAG] = (float)fb_off;
+            metrics[FBHIP_M_FB_DIAG] = (float)fb_diag;
+            metrics[FBHIP_M_ORTH_LOSS_OFFDIAG] = (float)orth_off;
+            metrics[FBHIP_M_ORTH_LOSS_DIAG] = (float)orth_diag;
+            metrics[FBHIP_M_ORTH_LOSS] = (float)(orth_off + orth_diag);
+            metrics[FBHIP_M_FB_LOSS] = (float)(fb_off + fb_diag + (double)ortho_coef * (orth_off + orth_diag));
+            metrics[FBHIP_M_M1] = (float)(tot[2] / (bb * bb));
+            metrics[FBHIP_M_TARGET_M] = (float)(tot[3] / (bb * bb));
+        }
+    }
+}
+
+struct PwPlan { int ks, nt, ld, dp, njt, nchunks, jpc, Bp; size_t lds_bytes; };
+
+PwPlan make_plan(int B, int d) {
+    static const int opts[] = {4, 8, 16, 25, 32, 50, 64};
+    PwPlan pl{};
+    pl.ks = -1;
+    for (int o : opts) if (2 * o >= d) { pl.ks = o; break; }
+    if (pl.ks < 0) return pl;
+    pl.nt = (2 * pl.ks + 31) / 32;
+    const int w = (2 * pl.ks > 32 * pl.nt) ? 2 * pl.ks : 32 * pl.nt;
+    pl.ld = w + 1;
+    pl.dp = 32 * pl.nt;
+    pl.njt = (B + 31) / 32;
+    pl.Bp = pl.njt * 32;
+    // aim for >= 256 workgroups (one per CU): nI * nchunks
+    int nchunks = (256 + pl.njt - 1) / pl.njt;
+    if (nchunks > pl.njt) nchunks = pl.njt;
+    if (nchunks < 1) nchunks = 1;
+    pl.jpc = (pl.njt + nchunks - 1) / nchunks;
+    pl.nchunks = (pl.njt + pl.jpc - 1) / pl.jpc;
+    pl.lds_bytes = (size_t)(6 * 32 * pl.ld + 32) * sizeof(float);
+    return pl;
+}
+
+}  // namespace
+
+size_t pairwise_scratch_floats(int B, int d) {
+    const PwPlan pl = make_plan(B, d);
+    if (pl.ks < 0) return 0;
+    return (size_t)pl.nchunks * PW_SLOTS * pl.Bp * pl.dp + (size_t)pl.nchunks * pl.njt * PW_SCAL;
+}
+
+hipError_t pairwise_prepare(int B, int d) {
+    const PwPlan pl = make_plan(B, d);
+    if (pl.ks < 0) return hipErrorInvalidValue;
+    if (pl.lds_bytes <= 48 * 1024) return hipSuccess;
+    const int bytes = (int)pl.lds_bytes;
+#define PW_ATTR(KS) return hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+    switch (pl.ks) {
+        case 25: PW_ATTR(25);
+        case 32: PW_ATTR(32);
+        case 50: PW_ATTR(50);
+        case 64: PW_ATTR(64);
+        default: return hipSuccess;
+    }
+#undef PW_ATTR
+}
+
+hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
+                              const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
+                              float* dF1, float* dF2, float* dB, float* metrics, float* scratch, hipStream_t s) {
+    const PwPlan pl = make_plan(B, d);
+    if (pl.ks < 0 || B < 2) return hipErrorInvalidValue;
+    PwArgs a;
+    a.F1 = F1; a.F2 = F2; a.Bm = Bm; a.tF1 = tF1; a.tF2 = tF2; a.tB = tB; a.discount = discount;
+    a.B = B; a.d = d; a.ld = ld; a.ortho2 = 2.0f * ortho_coef; a.jpc = pl.jpc; a.njt = pl.njt;
+    a.partial = scratch;
+    a.scal = scratch + (size_t)pl.nchunks * PW_SLOTS * pl.Bp * pl.dp;
+    a.Bp = pl.Bp;
+    dim3 grid(pl.njt, pl.nchunks), block(256);
+    hipError_t e = hipSuccess;
+#define PW_LAUNCH(KS) hipLaunchKernelGGL((pairwise_kernel<KS>), grid, block, pl.lds_bytes, s, a)
+    switch (pl.ks) {
+        case 4: PW_LAUNCH(4); break;
+        case 8: PW_LAUNCH(8); break;
+        case 16: PW_LAUNCH(16); break;
+        case 25: PW_LAUNCH(25); break;
+        case 32: PW_LAUNCH(32); break;
+        case 50: PW_LAUNCH(50); break;
+        case 64: PW_LAUNCH(64); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef PW_LAUNCH
+    if (e != hipSuccess) return e;
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int total = B * d;
+    hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.scal,
+                       pl.nchunks, pl.nchunks * pl.njt, B, pl.Bp, d, pl.dp, ld, ortho_coef, dF1, dF2, dB, metrics);
+    return hipGetLastError();
+}
+
+}  // namespace fbhip

@@ -1,0 +1,406 @@
+// Row-wise kernels of the FB-DDPG step for gfx950: one 64-lane wavefront per row, wave-shuffle reductions.
+//   ln_tanh_fwd / ln_tanh_bwd : the "ntanh" non-linearity  LayerNorm(eps=1e-5, affine) + Tanh (fb_modules.py:49-50)
+//   l2norm_fwd / l2norm_bwd   : sqrt(d) * F.normalize(x, dim=1)  (fb_modules.py:229, fb_ddpg.py:226,484)
+//   policy_sample             : mu = tanh(.) and TruncatedNormal.sample with straight-through clamp (utils.py:171-185)
+//   actor_loss                : Q = min(F1.z, F2.z), loss = -mean Q and dF_i (fb_ddpg.py:400-406)
+#include "common.h"
+
+namespace fbhip {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// load 4 consecutive floats starting at element n0 of a row; elements >= n read as 0
+__device__ __forceinline__ float4 ld4(const float* __restrict__ row, int n0, int n, bool vec) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 < n) {
+        if (vec && n0 + 3 < n) {
+            x = *reinterpret_cast<const float4*>(row + n0);
+        } else {
+            x.x = row[n0];
+            if (n0 + 1 < n) x.y = row[n0 + 1];
+            if (n0 + 2 < n) x.z = row[n0 + 2];
+            if (n0 + 3 < n) x.w = row[n0 + 3];
+        }
+    }
+    return x;
+}
+__device__ __forceinline__ void st4(float* __restrict__ row, int n0, int n, bool vec, float4 x) {
+    if (n0 < n) {
+        if (vec && n0 + 3 < n) {
+            *reinterpret_cast<float4*>(row + n0) = x;
+        } else {
+            row[n0] = x.x;
+            if (n0 + 1 < n) row[n0 + 1] = x.y;
+            if (n0 + 2 < n) row[n0 + 2] = x.z;
+            if (n0 + 3 < n) row[n0 + 3] = x.w;
+        }
+    }
+}
+__device__ __forceinline__ float4 mask4(float4 x, int n0, int n) {
+    if (n0 >= n) x.x = 0.f;
+    if (n0 + 1 >= n) x.y = 0.f;
+    if (n0 + 2 >= n) x.z = 0.f;
+    if (n0 + 3 >= n) x.w = 0.f;
+    return x;
+}
+static inline bool aligned16(const void* p, int ld) { return (((uintptr_t)p & 15) == 0) && ((ld & 3) == 0); }
+
+// ------------------------------------------------------------------------------------------------------
+template <int MAXQ>
+__global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          int ldy, float* __restrict__ stats, int rows, int n,
+                                                          int vx, int vy, int vp) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[MAXQ];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        v[i] = ld4(xr, 4 * (lane + 64 * i), n, vx);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int n0 = 4 * (lane + 64 * i);
+        float4 c = mask4(make_float4(v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean), n0, n);
+        q += (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
+    }
+    const float var = wave_sum(q) / (float)n;            // biased, like nn.LayerNorm
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    float* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int n0 = 4 * (lane + 64 * i);
+        if (n0 < n) {
+            const float4 g = ld4(gamma, n0, n, vp), b = ld4(beta, n0, n, vp);
+            float4 o;
+            o.x = tanhf((v[i].x - mean) * rstd * g.x + b.x);
+            o.y = tanhf((v[i].y - mean) * rstd * g.y + b.y);
+            o.z = tanhf((v[i].z - mean) * rstd * g.z + b.z);
+            o.w = tanhf((v[i].w - mean) * rstd * g.w + b.w);
+            st4(yr, n0, n, vy, o);
+        }
+    }
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
+                              float* stats, int rows, int n, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (n > 2048) return hipErrorInvalidValue;
+    const int vx = aligned16(x, ldx), vy = aligned16(y, ldy), vp = aligned16(gamma, 4) && aligned16(beta, 4);
+    dim3 grid((rows + 3) / 4), block(256);
+    const int q = (n + 255) / 256;
+#define LN_FWD(Q) hipLaunchKernelGGL((ln_tanh_fwd_kernel<Q>), grid, block, 0, s, x, ldx, gamma, beta, y, ldy, stats, rows, n, vx, vy, vp)
+    if (q <= 1) LN_FWD(1); else if (q <= 2) LN_FWD(2); else if (q <= 3) LN_FWD(3); else if (q <= 4) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward of y = tanh(gamma * xhat + beta):  du = dy (1 - y^2); g = du * gamma;
+// dx = rstd (g - mean(g) - xhat mean(g xhat));  dgamma = sum_rows du xhat;  dbeta = sum_rows du.
+// Each workgroup owns LN_BWD_ROWS_PER_BLOCK rows (2 per wave) and emits one partial row of (dgamma, dbeta);
+// a second tiny kernel folds the partial rows in a fixed order (deterministic, no atomics).
+template <int MAXQ>
+__global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const float* __restrict__ dy, int lddy,
+                                                          const float* __restrict__ y, int ldy,
+                                                          const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma, float* __restrict__ dx,
+                                                          int lddx, float* __restrict__ partials, int rows, int n,
+                                                          int vdy, int vy, int vx, int vdx, int vp) {
+    extern __shared__ float lds[];          // [4 waves][n] (used twice: dgamma then dbeta)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float4 pg[MAXQ], pb[MAXQ];
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) pg[i] = pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_n = 1.0f / (float)n;
+#pragma unroll 1
+    for (int rr = 0; rr < LN_BWD_ROWS_PER_BLOCK / 4; ++rr) {
+        const int row = blockIdx.x * LN_BWD_ROWS_PER_BLOCK + rr * 4 + wid;
+        if (row >= rows) break;
+        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+        const float* dyr = dy + (size_t)row * lddy;
+        const float* yr = y + (size_t)row * ldy;
+        const float* xr = x + (size_t)row * ldx;
+        float4 g[MAXQ], xh[MAXQ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int n0 = 4 * (lane + 64 * i);
+            const float4 d = ld4(dyr, n0, n, vdy), yy = ld4(yr, n0, n, vy), xx = ld4(xr, n0, n, vx);
+            const float4 gm = ld4(gamma, n0, n, vp);
+            float4 du, h;
+            du.x = d.x * (1.f - yy.x * yy.x); du.y = d.y * (1.f - yy.y * yy.y);
+            du.z = d.z * (1.f - yy.z * yy.z); du.w = d.w * (1.f - yy.w * yy.w);
+            h = mask4(make_float4((xx.x - mean) * rstd, (xx.y - mean) * rstd, (xx.z - mean) * rstd,
+                                  (xx.w - mean) * rstd), n0, n);
+            xh[i] = h;
+            g[i] = make_float4(du.x * gm.x, du.y * gm.y, du.z * gm.z, du.w * gm.w);
+            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+            s2 += (g[i].x * h.x + g[i].y * h.y) + (g[i].z * h.z + g[i].w * h.w);
+            pg[i].x += du.x * h.x; pg[i].y += du.y * h.y; pg[i].z += du.z * h.z; pg[i].w += du.w * h.w;
+            pb[i].x += du.x; pb[i].y += du.y; pb[i].z += du.z; pb[i].w += du.w;
+        }
+        const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+        float* dxr = dx + (size_t)row * lddx;
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int n0 = 4 * (lane + 64 * i);
+            float4 o;
+            o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
+            o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+            o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
+            o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+            st4(dxr, n0, n, vdx, o);
+        }
+    }
+    if (partials == nullptr) return;
+    float* out = partials + (size_t)blockIdx.x * 2 * n;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int n0 = 4 * (lane + 64 * i);
+            const float4 v = pass == 0 ? pg[i] : pb[i];
+            if (n0 < n) lds[wid * n + n0] = v.x;
+            if (n0 + 1 < n) lds[wid * n + n0 + 1] = v.y;
+            if (n0 + 2 < n) lds[wid * n + n0 + 2] = v.z;
+            if (n0 + 3 < n) lds[wid * n + n0 + 3] = v.w;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 256)
+            out[pass * n + j] = (lds[j] + lds[n + j]) + (lds[2 * n + j] + lds[3 * n + j]);
+    }
+}
+
+__global__ void __launch_bounds__(256) ln_colreduce_kernel(const float* __restrict__ partials, int nb, int n,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 2 * n) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partials[(size_t)b * 2 * n + j];
+    if (j < n) dgamma[j] = s; else dbeta[j - n] = s;
+}
+
+hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx,
+                              const float* stats, const float* gamma, float* dx, int lddx, float* dgamma,
+                              float* dbeta, float* partials, int rows, int n, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (n > 2048) return hipErrorInvalidValue;
+    const bool want = dgamma != nullptr && dbeta != nullptr;
+    if (want && partials == nullptr) return hipErrorInvalidValue;
+    const int nb = (rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK;
+    const int vdy = aligned16(dy, lddy), vy = aligned16(y, ldy), vx = aligned16(x, ldx), vdx = aligned16(dx, lddx);
+    const int vp = aligned16(gamma, 4);
+    float* part = want ? partials : nullptr;
+    dim3 grid(nb), block(256);
+    const size_t shmem = (size_t)4 * n * sizeof(float);
+    const int q = (n + 255) / 256;
+#define LN_BWD(Q) hipLaunchKernelGGL((ln_tanh_bwd_kernel<Q>), grid, block, shmem, s, dy, lddy, y, ldy, x, ldx, stats, gamma, dx, lddx, part, rows, n, vdy, vy, vx, vdx, vp)
+    if (q <= 1) LN_BWD(1); else if (q <= 2) LN_BWD(2); else if (q <= 3) LN_BWD(3); else if (q <= 4) LN_BWD(4); else LN_BWD(8);
+#undef LN_BWD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !want) return e;
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, s, partials, nb, n, dgamma, dbeta);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+constexpr int L2_MAXE = 4;      // d <= 256
+__global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict__ y, int ldy, float* __restrict__ out,
+                                                         int ldo, float* __restrict__ norms, int rows, int d,
+                                                         float scale) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* yr = y + (size_t)row * ldy;
+    float v[L2_MAXE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < L2_MAXE; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = j < d ? yr[j] : 0.f;
+        s += v[i] * v[i];
+    }
+    const float nrm = sqrtf(wave_sum(s));
+    const float den = fmaxf(nrm, 1e-12f);                 // F.normalize eps
+    float* o = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < L2_MAXE; ++i) {
+        const int j = lane + 64 * i;
+        if (j < d) o[j] = scale * (v[i] / den);
+    }
+    if (norms != nullptr && lane == 0) norms[row] = nrm;
+}
+
+hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float* norms, int rows, int d,
+                             float scale, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (d > 64 * L2_MAXE) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, ldy, out, ldo, norms, rows, d, scale);
+    return hipGetLastError();
+}
+
+// dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB)),  yhat = y/||y||
+__global__ void __launch_bounds__(256) l2norm_bwd_kernel(const float* __restrict__ dB, int lddb,
+                                                         const float* __restrict__ y, int ldy,
+                                                         const float* __restrict__ norms, float* __restrict__ dy,
+                                                         int lddy, int rows, int d, float scale) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float nrm = fmaxf(norms[row], 1e-12f);
+    const float inv = 1.0f / nrm;
+    float yh[L2_MAXE], g[L2_MAXE];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < L2_MAXE; ++i) {
+        const int j = lane + 64 * i;
+        yh[i] = j < d ? y[(size_t)row * ldy + j] * inv : 0.f;
+        g[i] = j < d ? dB[(size_t)row * lddb + j] : 0.f;
+        dot += yh[i] * g[i];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < L2_MAXE; ++i) {
+        const int j = lane + 64 * i;
+        if (j < d) dy[(size_t)row * lddy + j] = scale * inv * (g[i] - yh[i] * dot);
+    }
+}
+
+hipError_t launch_l2norm_bwd(const float* dB, int lddb, const float* y, int ldy, const float* norms, float* dy,
+                             int lddy, int rows, int d, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (d > 64 * L2_MAXE) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dB, lddb, y, ldy, norms, dy, lddy,
+                       rows, d, sqrtf((float)d));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) policy_sample_kernel(const float* __restrict__ pre, int ldp,
+                                                            const float* __restrict__ noise, int ldn, float stddev,
+                                                            float clip, float* __restrict__ mu, int ldmu,
+                                                            float* __restrict__ action, int lda, int rows, int a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * a) return;
+    const int r = idx / a, c = idx % a;
+    const float m = tanhf(pre[(size_t)r * ldp + c]);
+    if (mu != nullptr) mu[(size_t)r * ldmu + c] = m;
+    float act = m;
+    if (noise != nullptr) {
+        float e = noise[(size_t)r * ldn + c] * stddev;
+        if (clip >= 0.f) e = fminf(fmaxf(e, -clip), clip);
+        const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
+        act = fminf(fmaxf(m + e, lo), hi);
+    }
+    if (action != nullptr) action[(size_t)r * lda + c] = act;
+}
+
+hipError_t launch_policy_sample(const float* pre, int ldp, const float* noise, int ldn, float stddev, float clip,
+                                float* mu, int ldmu, float* action, int lda, int rows, int a, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(policy_sample_kernel, dim3((rows * a + 255) / 256), dim3(256), 0, s, pre, ldp, noise, ldn,
+                       stddev, clip, mu, ldmu, action, lda, rows, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// One workgroup of 16 waves; wave w walks rows w, w+16, ...  Deterministic: per-wave partial sums are folded
+// in wave order by thread 0.  metrics: ACTOR_LOSS, Q, ACTOR_LOGPROB (indices from include/fbhip.h).
+__global__ void __launch_bounds__(1024) actor_loss_kernel(const float* __restrict__ F1, const float* __restrict__ F2,
+                                                          int ldf, const float* __restrict__ z, int ldz,
+                                                          const float* __restrict__ mu, int ldmu,
+                                                          const float* __restrict__ act,
+                                                          int lda, float stddev, float* __restrict__ dF1,
+                                                          float* __restrict__ dF2, float* __restrict__ metrics,
+                                                          int rows, int d, int a, int m_loss, int m_q, int m_lp) {
+    __shared__ double part[16][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float inv_b = 1.0f / (float)rows;
+    double qs = 0.0, lps = 0.0;
+    const float log_std = logf(stddev), log_s2pi = 0.91893853320467274178f;
+    for (int row = wid; row < rows; row += 16) {
+        float zz[L2_MAXE], q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < L2_MAXE; ++i) {
+            const int j = lane + 64 * i;
+            zz[i] = j < d ? z[(size_t)row * ldz + j] : 0.f;
+            if (j < d) {
+                q1 += F1[(size_t)row * ldf + j] * zz[i];
+                q2 += F2[(size_t)row * ldf + j] * zz[i];
+            }
+        }
+        q1 = wave_sum(q1);
+        q2 = wave_sum(q2);
+        // torch.min(Q1, Q2) backward: all of the gradient to the strict arg-min, split evenly on exact ties
+        const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f), w2 = 1.f - w1;
+#pragma unroll
+        for (int i = 0; i < L2_MAXE; ++i) {
+            const int j = lane + 64 * i;
+            if (j < d) {
+                dF1[(size_t)row * ldf + j] = -zz[i] * inv_b * w1;
+                dF2[(size_t)row * ldf + j] = -zz[i] * inv_b * w2;
+            }
+        }
+        float lp = 0.f;
+        if (lane < a) {
+            const float df = act[(size_t)row * lda + lane] - mu[(size_t)row * ldmu + lane];
+            lp = -(df * df) / (2.f * stddev * stddev) - log_std - log_s2pi;
+        }
+        lp = wave_sum(lp);
+        qs += (double)fminf(q1, q2);
+        lps += (double)lp;
+    }
+    if (lane == 0) { part[wid][0] = qs; part[wid][1] = lps; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double q = 0.0, l = 0.0;
+        for (int w = 0; w < 16; ++w) { q += part[w][0]; l += part[w][1]; }
+        metrics[m_loss] = (float)(-q / rows);
+        metrics[m_q] = (float)(q / rows);
+        metrics[m_lp] = (float)(l / rows);
+    }
+}
+
+hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz, const float* mu,
+                             int ldmu, const float* action, int lda, float stddev, float* dF1, float* dF2,
+                             float* metrics, int rows, int d, int a, hipStream_t s) {
+    if (d > 64 * L2_MAXE || a > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, s, F1, F2, ldf, z, ldz, mu, ldmu, action, lda,
+                       stddev, dF1, dF2, metrics, rows, d, a, 15, 16, 17);
+    return hipGetLastError();
+}
+
+// dst[r] = [A[r, :na] | B[r, :nb]]  -- builds an [obs|z] / [obs|action] panel for the inference entry points
+__global__ void __launch_bounds__(256) concat2_kernel(float* __restrict__ dst, int ld, const float* __restrict__ A,
+                                                      int lda, int na, const float* __restrict__ Bsrc, int ldb, int nb,
+                                                      int rows) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    for (int j = lane; j < na; j += 64) dst[(size_t)r * ld + j] = A[(size_t)r * lda + j];
+    if (Bsrc != nullptr)
+        for (int j = lane; j < nb; j += 64) dst[(size_t)r * ld + na + j] = Bsrc[(size_t)r * ldb + j];
+}
+
+hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, const float* B, int ldb, int nb,
+                          int rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(concat2_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dst, ld, A, lda, na, B, ldb, nb, rows);
+    return hipGetLastError();
+}
+
+}  // namespace fbhip

@@ -1,0 +1,198 @@
+// Device-resident replay sampler for gfx950: the index draw, row gather, z sampling and z mixing of
+//   ReplayBuffer.sample        (in_memory_replay_buffer.py:139-190)
+//   EpisodeBatch.to(device)    (replay_buffer.py:50-63)  -- eliminated: the storage already lives in HBM
+//   FBDDPGAgent.sample_z       (fb_ddpg.py:224-232)
+//   perm / mix of update()     (fb_ddpg.py:460-485)
+// Storage is episode-major float32[n_episodes, T+1, dim] exactly like ReplayBuffer._storage, so obs and next_obs
+// of a transition are two ADJACENT rows (one contiguous 2*o-float read).  The gather writes straight into the
+// concatenated [obs|action], [obs|z], [next_obs|z] ... input panels of the first-layer GEMMs, so torch.cat
+// (fb_modules.py:114,190-191) never happens.  Random numbers: Philox4x32-10, counter = (index, stream,
+// update_count), key = (seed, rank) -- reproducible and independent of launch geometry.
+#include "common.h"
+
+namespace fbhip {
+
+namespace {
+
+struct U4 { unsigned x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1)
+__device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& n0, float& n1) {
+    const float r = sqrtf(-2.0f * logf(u01(a)));
+    const float th = 6.283185307179586f * u01(b);
+    n0 = r * cosf(th);
+    n1 = r * sinf(th);
+}
+
+enum { STREAM_INDEX = 0, STREAM_PERM = 1, STREAM_MIX = 2, STREAM_Z = 3, STREAM_EPS_NEXT = 4, STREAM_EPS_ACTOR = 5 };
+
+__global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, int B, int d, int a, unsigned k0,
+                                                   unsigned k1, const StepState* __restrict__ st,
+                                                   unsigned long long* __restrict__ perm_keys) {
+    const unsigned cnt = st->update_count;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B) {
+        const U4 r = philox4x32_10((unsigned)i, STREAM_INDEX, cnt, 0u, k0, k1);
+        int ep, step;
+        if (rv.fixed_length) {
+            // np.random.randint(0, len(self)) then randint(0, eps_len) + 1   (in_memory_replay_buffer.py:147,155)
+            ep = (int)(((unsigned long long)r.x * (unsigned)rv.n_episodes) >> 32);
+            const int len = rv.episode_len[ep];
+            step = 1 + (int)(((unsigned long long)r.y * (unsigned)len) >> 32);
+        } else {
+            // np.random.choice(p = len / sum len) then a uniform step == a uniform draw over all transitions
+            // (in_memory_replay_buffer.py:149-155)
+            const unsigned long long total = (unsigned long long)rv.cum_len[rv.n_episodes];
+            const unsigned long long r64 = ((unsigned long long)r.x << 32) | r.y;
+            const unsigned long long tix = __umul64hi(r64, total);
+            int lo = 0, hi = rv.n_episodes;            // find ep with cum[ep] <= tix < cum[ep+1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((unsigned long long)rv.cum_len[mid] <= tix) lo = mid; else hi = mid;
+            }
+            ep = lo;
+            step = 1 + (int)(tix - (unsigned long long)rv.cum_len[lo]);
+        }
+        so.ep_idx[i] = ep;
+        so.step_idx[i] = step;
+        const U4 q = philox4x32_10((unsigned)i, STREAM_PERM, cnt, 0u, k0, k1);
+        perm_keys[i] = ((unsigned long long)q.x << 32) | (unsigned)i;       // torch.randperm (fb_ddpg.py:467)
+        so.mix_uniform[i] = u01(philox4x32_10((unsigned)i, STREAM_MIX, cnt, 0u, k0, k1).x);   // fb_ddpg.py:471
+    }
+    // gaussians: 4 per Philox call
+    const int nz = B * d, na = B * a;
+    for (int q4 = i; 4 * q4 < nz; q4 += gridDim.x * 256) {
+        const U4 r = philox4x32_10((unsigned)q4, STREAM_Z, cnt, 0u, k0, k1);
+        float n[4];
+        box_muller(r.x, r.y, n[0], n[1]);
+        box_muller(r.z, r.w, n[2], n[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * q4 + j < nz) so.z_gauss[4 * q4 + j] = n[j];
+    }
+    for (int q4 = i; 4 * q4 < na; q4 += gridDim.x * 256) {
+        const U4 r = philox4x32_10((unsigned)q4, STREAM_EPS_NEXT, cnt, 0u, k0, k1);
+        const U4 t = philox4x32_10((unsigned)q4, STREAM_EPS_ACTOR, cnt, 0u, k0, k1);
+        float n[4], m[4];
+        box_muller(r.x, r.y, n[0], n[1]); box_muller(r.z, r.w, n[2], n[3]);
+        box_muller(t.x, t.y, m[0], m[1]); box_muller(t.z, t.w, m[2], m[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * q4 + j < na) { so.eps_next[4 * q4 + j] = n[j]; so.eps_actor[4 * q4 + j] = m[j]; }
+    }
+}
+
+// random permutation = argsort of B random keys: single-workgroup bitonic sort in LDS (B <= 8192)
+__global__ void __launch_bounds__(1024) perm_sort_kernel(const unsigned long long* __restrict__ keys, int B, int n2,
+                                                         int32_t* __restrict__ perm) {
+    extern __shared__ unsigned long long sk[];
+    for (int i = threadIdx.x; i < n2; i += 1024) sk[i] = i < B ? keys[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long x = sk[i], y = sk[ixj];
+                    const bool up = ((i & k) == 0);
+                    if ((x > y) == up) { sk[i] = y; sk[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < B; i += 1024) perm[i] = (int32_t)(sk[i] & 0xffffffffull);
+}
+
+__device__ __forceinline__ void copy_row(float* __restrict__ dst, const float* __restrict__ src, int n, int lane) {
+    for (int j = lane; j < n; j += 64) dst[j] = src[j];
+}
+
+// one wavefront per sampled transition
+__global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= g.B) return;
+    const int e = g.ep_idx[i], s = g.step_idx[i];
+    const size_t t = (size_t)e * g.rv.t1 + s;                         // row of the "next" step
+    const float* obs = g.rv.observation + (t - 1) * g.o;              // observation[ep, step-1]
+    const float* nobs = obs + g.o;                                    // observation[ep, step] (adjacent row)
+    const float* act = g.rv.action + t * g.a;                         // action[ep, step]
+    for (int j = lane; j < g.o; j += 64) {
+        const float ov = obs[j], nv = nobs[j];
+        g.Xoa[(size_t)i * g.ld_oa + j] = ov;
+        g.Xoz[(size_t)i * g.ld_oz + j] = ov;
+        g.Xopi[(size_t)i * g.ld_opi + j] = ov;
+        g.Xnoz[(size_t)i * g.ld_noz + j] = nv;
+        g.Xnoa[(size_t)i * g.ld_noa + j] = nv;
+    }
+    copy_row(g.Xoa + (size_t)i * g.ld_oa + g.o, act, g.a, lane);
+    if (lane == 0) g.disc[i] = g.gamma * g.rv.discount[t];            // discount * storage['discount'] (:171)
+    if (g.use_goal) copy_row(g.next_goal + (size_t)i * g.ld_ng, g.rv.goal + t * g.g, g.g, lane);
+    // backward_input[perm] (fb_ddpg.py:460-468): row i of the permuted panel is transition perm[i]
+    const int pi = g.perm[i];
+    const size_t tp = (size_t)g.ep_idx[pi] * g.rv.t1 + g.step_idx[pi] - 1;
+    const float* bsrc = g.use_goal ? g.rv.goal + tp * g.g : g.rv.observation + tp * g.o;
+    copy_row(g.bin + (size_t)i * g.ld_bin, bsrc, g.g, lane);
+}
+
+// z = mix ? sqrt(d) * normalize(B(backward_input)) : z_rand, scattered into every panel that carries z
+__global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ zrand, const float* __restrict__ Bmix,
+                                                    int ldz, const float* __restrict__ mixu, float mix_ratio,
+                                                    float* __restrict__ z, float* __restrict__ Xoz, int ld_oz,
+                                                    float* __restrict__ Xnoz, int ld_noz, int o, int B, int d) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const bool mix = (mix_ratio > 0.f) && (mixu[i] < mix_ratio);
+    float s = 0.f;
+    for (int j = lane; j < d; j += 64) { const float v = Bmix[(size_t)i * ldz + j]; s += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float den = fmaxf(sqrtf(s), 1e-12f), sc = sqrtf((float)d);
+    for (int j = lane; j < d; j += 64) {
+        const float v = mix ? sc * (Bmix[(size_t)i * ldz + j] / den) : zrand[(size_t)i * ldz + j];
+        z[(size_t)i * ldz + j] = v;
+        Xoz[(size_t)i * ld_oz + o + j] = v;
+        Xnoz[(size_t)i * ld_noz + o + j] = v;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a, uint64_t seed, uint32_t rank,
+                       const StepState* st, unsigned long long* perm_keys, hipStream_t s) {
+    if (B > 8192) return hipErrorInvalidValue;
+    const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
+    int blocks = (B * d / 4 + 255) / 256;
+    if (blocks < (B + 255) / 256) blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(draw_kernel, dim3(blocks), dim3(256), 0, s, rv, so, B, d, a, k0, k1, st, perm_keys);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int n2 = 1;
+    while (n2 < B) n2 <<= 1;
+    hipLaunchKernelGGL(perm_sort_kernel, dim3(1), dim3(1024), (size_t)n2 * 8, s, perm_keys, B, n2, so.perm);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const GatherArgs& ga, hipStream_t s) {
+    hipLaunchKernelGGL(gather_kernel, dim3((ga.B + 3) / 4), dim3(256), 0, s, ga);
+    return hipGetLastError();
+}
+
+hipError_t launch_mix_z(const float* zrand, const float* Bmix, int ldz, const float* mix_uniform, float mix_ratio,
+                        float* z, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d, hipStream_t s) {
+    hipLaunchKernelGGL(mix_z_kernel, dim3((B + 3) / 4), dim3(256), 0, s, zrand, Bmix, ldz, mix_uniform, mix_ratio, z,
+                       Xoz, ld_oz, Xnoz, ld_noz, o, B, d);
+    return hipGetLastError();
+}
+
+}  // namespace fbhip

@@ -1,0 +1,124 @@
+"""Torch-tensor front-ends of the individually callable gfx950 kernels in libfbhip.so.
+
+Each function takes CUDA(=HIP) float32 tensors, passes raw device pointers + leading dimensions over the
+C ABI (include/fbhip.h) and launches on torch's current stream.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import typing as tp
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dtype == torch.float32 and t.is_cuda, "float32 device tensor expected"
+    if t.dim() == 1:
+        return t.shape[0]
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D tensor expected"
+    return t.stride(0)
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcontig: bool = True,
+         bias: tp.Optional[torch.Tensor] = None, aux: tp.Optional[torch.Tensor] = None, epi: int = _lib.EPI_NONE,
+         want_colsum: bool = False, out: tp.Optional[torch.Tensor] = None, cfg: tp.Optional[int] = None):
+    """C[M,N] = epi(sum_k A(m,k) B(n,k)).  a_kcontig: A is [M,K] (else [K,M]); b_kcontig: B is [N,K] (else [K,N])."""
+    _lib.require_device()
+    M, K = (A.shape if a_kcontig else A.shape[::-1])
+    N, K2 = (B.shape if b_kcontig else B.shape[::-1])
+    assert K == K2, (A.shape, B.shape)
+    Cm = out if out is not None else torch.empty((M, N), device=A.device, dtype=torch.float32)
+    colsum = torch.zeros(M, device=A.device) if want_colsum else None
+    lib = _lib.load()
+    if cfg is not None:
+        check(lib.fbhip_gemm_cfg(ptr(A), _ld(A), int(a_kcontig), ptr(B), _ld(B), int(b_kcontig), ptr(Cm), _ld(Cm),
+                                 M, N, K, cfg, stream_ptr()))
+        return Cm
+    check(lib.fbhip_gemm(ptr(A), _ld(A), int(a_kcontig), ptr(B), _ld(B), int(b_kcontig), ptr(Cm), _ld(Cm), M, N, K,
+                         ptr(bias), ptr(aux), 0 if aux is None else _ld(aux), epi, ptr(colsum), stream_ptr()))
+    return (Cm, colsum) if want_colsum else Cm
+
+
+def ln_tanh_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """y = tanh(LayerNorm(x)), stats[rows,2] = (mean, rstd)   (fb_modules.py:49-50)."""
+    _lib.require_device()
+    rows, n = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((rows, 2), device=x.device)
+    check(_lib.load().fbhip_ln_tanh_fwd(ptr(x), _ld(x), ptr(gamma), ptr(beta), ptr(y), _ld(y), ptr(stats), rows, n,
+                                        stream_ptr()))
+    return y, stats
+
+
+def ln_tanh_bwd(dy, y, x, stats, gamma, want_param_grads: bool = True):
+    _lib.require_device()
+    rows, n = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(n, device=x.device) if want_param_grads else None
+    db = torch.empty(n, device=x.device) if want_param_grads else None
+    part = torch.empty(((rows + 7) // 8) * 2 * n, device=x.device) if want_param_grads else None
+    check(_lib.load().fbhip_ln_tanh_bwd(ptr(dy), _ld(dy), ptr(y), _ld(y), ptr(x), _ld(x), ptr(stats), ptr(gamma), ptr(dx),
+                                        _ld(dx), ptr(dg), ptr(db), ptr(part), rows, n, stream_ptr()))
+    return dx, dg, db
+
+
+def l2norm_fwd(y: torch.Tensor):
+    """sqrt(d) * F.normalize(y, dim=1) and the row norms."""
+    _lib.require_device()
+    rows, d = y.shape
+    out = torch.empty_like(y)
+    norms = torch.empty(rows, device=y.device)
+    check(_lib.load().fbhip_l2norm_fwd(ptr(y), _ld(y), ptr(out), _ld(out), ptr(norms), rows, d, stream_ptr()))
+    return out, norms
+
+
+def l2norm_bwd(dB, y, norms):
+    _lib.require_device()
+    rows, d = y.shape
+    dy = torch.empty_like(y)
+    check(_lib.load().fbhip_l2norm_bwd(ptr(dB), _ld(dB), ptr(y), _ld(y), ptr(norms), ptr(dy), _ld(dy), rows, d,
+                                       stream_ptr()))
+    return dy
+
+
+def pairwise_fb(F1, F2, Bm, tF1, tF2, tB, discount, ortho_coef: float):
+    """FB + orthonormality loss and dF1, dF2, dB (fb_ddpg.py:313-348).  Returns (dF1, dF2, dB, metrics dict)."""
+    _lib.require_device()
+    Bn, d = F1.shape
+    ld = _ld(F1)
+    for t in (F2, Bm, tF1, tF2, tB):
+        assert t.shape == F1.shape and _ld(t) == ld
+    lib = _lib.load()
+    dF1, dF2, dB = torch.empty_like(F1), torch.empty_like(F1), torch.empty_like(F1)
+    metrics = torch.zeros(_lib.NUM_METRICS, device=F1.device)
+    scratch = torch.empty(lib.fbhip_pairwise_scratch_floats(Bn, d), device=F1.device)
+    disc = discount.reshape(-1).contiguous()
+    check(lib.fbhip_pairwise_fb(ptr(F1), ptr(F2), ptr(Bm), ptr(tF1), ptr(tF2), ptr(tB), ptr(disc), Bn, d, ld,
+                                float(ortho_coef), ptr(dF1), ptr(dF2), ptr(dB), ptr(metrics), ptr(scratch), stream_ptr()))
+    m = metrics.cpu()
+    names = ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_diag", "orth_loss_offdiag", "target_M", "M1")
+    return dF1, dF2, dB, {k: float(m[_lib.METRIC_INDEX[k]]) for k in names}
+
+
+def adam_ema(params, grads, m, v, target, lr: float, t: int, grad_scale: float = 1.0, tau: float = 0.0) -> None:
+    """In-place fused Adam (+ EMA into ``target`` when given) over flat tensors (numel % 4 == 0)."""
+    _lib.require_device()
+    check(_lib.load().fbhip_adam_ema(ptr(params), ptr(grads), ptr(m), ptr(v), ptr(target), params.numel(), float(lr),
+                                     int(t), float(grad_scale), float(tau), stream_ptr()))
+
+
+def actor_loss(F1, F2, z, mu, action, stddev: float):
+    _lib.require_device()
+    rows, d = F1.shape
+    a = mu.shape[1]
+    dF1, dF2 = torch.empty_like(F1), torch.empty_like(F1)
+    metrics = torch.zeros(_lib.NUM_METRICS, device=F1.device)
+    check(_lib.load().fbhip_actor_loss(ptr(F1), ptr(F2), _ld(F1), ptr(z), _ld(z), ptr(mu), _ld(mu), ptr(action),
+                                       _ld(action), float(stddev), ptr(dF1), ptr(dF2), ptr(metrics), rows, d, a,
+                                       stream_ptr()))
+    m = metrics.cpu()
+    return dF1, dF2, {k: float(m[_lib.METRIC_INDEX[k]]) for k in ("actor_loss", "q", "actor_logprob")}

@@ -1,0 +1,217 @@
+/*
+ * fbhip.h -- C ABI of libfbhip.so: the MI355X (gfx950) implementation of the FB-DDPG update hot path
+ * of facebookresearch/controllable_agent.
+ *
+ * The reference has no FFI (it is 100 % Python on top of torch ATen ops); what this library replaces is
+ * the *sequence of ATen ops* issued by
+ *     url_benchmark/agent/fb_ddpg.py:427-520   FBDDPGAgent.update            -> fbhip_update
+ *     url_benchmark/agent/fb_ddpg.py:291-387   FBDDPGAgent.update_fb         -> (inside fbhip_update, phase FB)
+ *     url_benchmark/agent/fb_ddpg.py:389-421   FBDDPGAgent.update_actor      -> (inside fbhip_update, phase ACTOR)
+ *     url_benchmark/in_memory_replay_buffer.py:139-190  ReplayBuffer.sample  -> fbhip_replay_bind + sampler stage
+ *     url_benchmark/agent/fb_modules.py:81-230 Actor/ForwardMap/BackwardMap  -> fbhip_actor_forward / fbhip_backward_map / ...
+ *     url_benchmark/utils.py:66-69             soft_update_params            -> fused into fbhip_adam_ema
+ *     torch.optim.Adam (fb_ddpg.py:146-151)                                  -> fbhip_adam_ema
+ * The Python host side (controllable_agent_amd/) binds these with ctypes and mirrors the reference's Agent /
+ * ReplayBuffer plugin surface; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (from torch ``tensor.data_ptr()``) unless named ``host_*``;
+ *   - ``stream`` is a ``hipStream_t`` passed as ``void*`` (``torch.cuda.current_stream().cuda_stream``);
+ *   - the caller (torch) OWNS all memory; the library never allocates or frees device memory for data,
+ *     never synchronises the device behind the caller's back (except the explicitly blocking
+ *     ``fbhip_read_metrics``), and launches everything asynchronously on the caller's stream;
+ *   - every function returns 0 on success or a negative FBHIP_E_* code; the message is available from
+ *     ``fbhip_last_error``; nothing is ever thrown across the ABI;
+ *   - all matrices are float32 row-major with an explicit leading dimension (in floats).
+ */
+#ifndef FBHIP_H
+#define FBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FBHIP_ABI_VERSION 1
+
+enum {
+    FBHIP_OK = 0,
+    FBHIP_E_INVALID = -1,     /* bad argument / unsupported shape */
+    FBHIP_E_HIP = -2,         /* a HIP runtime call failed        */
+    FBHIP_E_STATE = -3,       /* buffers / replay not bound       */
+    FBHIP_E_NODEVICE = -4     /* no gfx950 device visible         */
+};
+
+/* nets (flat-buffer segments); fb_ddpg.py:122-141 */
+enum { FBHIP_NET_FORWARD = 0, FBHIP_NET_BACKWARD = 1, FBHIP_NET_ACTOR = 2 };
+
+/* phases of one update(); a mask selects which are enqueued (multi-GPU inserts all-reduces between them) */
+enum {
+    FBHIP_PHASE_SAMPLE = 1,      /* replay gather + z sampling + z mixing           (fb_ddpg.py:433-491) */
+    FBHIP_PHASE_FB_GRAD = 2,     /* targets, online F/B, pairwise loss, FB backward (fb_ddpg.py:303-383) */
+    FBHIP_PHASE_FB_STEP = 4,     /* fb_opt.step() + both soft_update_params         (fb_ddpg.py:384,500-503) */
+    FBHIP_PHASE_ACTOR_GRAD = 8,  /* actor forward / Q / backward                    (fb_ddpg.py:395-410) */
+    FBHIP_PHASE_ACTOR_STEP = 16, /* actor_opt.step()                                (fb_ddpg.py:411) */
+    FBHIP_PHASE_ALL = 31
+};
+
+typedef struct fbhip_dims {
+    int32_t batch;                 /* B   cfg.batch_size                                 */
+    int32_t obs_dim;               /* o                                                 */
+    int32_t action_dim;            /* a                                                 */
+    int32_t goal_dim;              /* g   == obs_dim when goal_space is None            */
+    int32_t z_dim;                 /* d                                                 */
+    int32_t hidden_dim;            /* H   (1024)                                        */
+    int32_t feature_dim;           /* Fd  (512)                                         */
+    int32_t backward_hidden_dim;   /* Hb  (526)                                         */
+    int32_t use_goal;              /* goal_space is not None: B-net input = goal        */
+} fbhip_dims;
+
+typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82 */
+    float lr;                      /* 1e-4   */
+    float lr_coef;                 /* 1      */
+    float fb_target_tau;           /* 0.01   */
+    float stddev;                  /* utils.schedule(stddev_schedule, step), utils.py:235-255 */
+    float stddev_clip;             /* 0.3    */
+    float ortho_coef;              /* 1.0    */
+    float mix_ratio;               /* 0.5    */
+    float q_loss_coef;             /* 0.01   */
+    float discount;                /* ReplayBuffer._discount (in_memory_replay_buffer.py:171) */
+    float grad_scale;              /* 1/world_size when gradients were sum-all-reduced, else 1 */
+    int32_t q_loss;                /* 0/1    */
+    int32_t want_metrics;          /* compute the full metric set of fb_ddpg.py:356-377 */
+} fbhip_hparams;
+
+/* Injected random draws (parity mode).  NULL struct => draw on device with Philox4x32-10 keyed by
+ * (seed, rank, on-device step counter).  Order = the order the reference draws them. */
+typedef struct fbhip_inject {
+    const int32_t* ep_idx;         /* [B]   in_memory_replay_buffer.py:147-151 */
+    const int32_t* step_idx;       /* [B]   in_memory_replay_buffer.py:155 (1-based)  */
+    const float* z_gauss;          /* [B,d] contiguous; fb_ddpg.py:225 */
+    const int32_t* perm;           /* [B]   fb_ddpg.py:467 */
+    const float* mix_uniform;      /* [B]   fb_ddpg.py:471 */
+    const float* eps_next;         /* [B,a] contiguous; utils.py:178 via fb_ddpg.py:310 */
+    const float* eps_actor;        /* [B,a] contiguous; utils.py:178 via fb_ddpg.py:397 */
+} fbhip_inject;
+
+/* one named tensor inside a flat parameter buffer (names = the reference's state_dict keys) */
+typedef struct fbhip_tensor_desc {
+    char name[48];
+    int64_t offset;                /* floats from the start of the net's segment */
+    int32_t rows, cols, ld;        /* vectors: rows = 1 */
+} fbhip_tensor_desc;
+
+#define FBHIP_NUM_METRICS 32
+/* indices into the device metrics array (fb_ddpg.py:356-377, 413-418) */
+enum {
+    FBHIP_M_TARGET_M = 0, FBHIP_M_M1, FBHIP_M_F1, FBHIP_M_B, FBHIP_M_B_NORM, FBHIP_M_Z_NORM,
+    FBHIP_M_FB_LOSS, FBHIP_M_FB_DIAG, FBHIP_M_FB_OFFDIAG, FBHIP_M_Q_LOSS, FBHIP_M_ORTH_LOSS,
+    FBHIP_M_ORTH_LOSS_DIAG, FBHIP_M_ORTH_LOSS_OFFDIAG, FBHIP_M_ORTH_LINF, FBHIP_M_ORTH_L2,
+    FBHIP_M_ACTOR_LOSS, FBHIP_M_Q, FBHIP_M_ACTOR_LOGPROB, FBHIP_M_COUNT
+};
+
+typedef struct fbhip_ctx fbhip_ctx;
+
+/* ---- library / layout --------------------------------------------------------------------------- */
+int fbhip_abi_version(void);
+const char* fbhip_last_error(const fbhip_ctx* ctx);            /* ctx may be NULL: last global error   */
+int fbhip_device_ok(void);                                     /* 0 iff a gfx950 device is current     */
+
+int64_t fbhip_net_numel(const fbhip_dims* dims, int net);      /* padded floats of one net's segment   */
+int64_t fbhip_net_param_count(const fbhip_dims* dims, int net);/* logical parameter count (reference)  */
+int fbhip_layout_count(const fbhip_dims* dims, int net);
+int fbhip_layout_entry(const fbhip_dims* dims, int net, int idx, fbhip_tensor_desc* out);
+size_t fbhip_workspace_bytes(const fbhip_dims* dims);
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out);
+int fbhip_destroy(fbhip_ctx* ctx);
+/* FB flat buffers hold forward_net ++ backward_net (fb_opt's two param groups, fb_ddpg.py:149-151);
+ * fb_targets holds forward_target_net ++ backward_target_net in the same layout. */
+int fbhip_bind_buffers(fbhip_ctx* ctx,
+                       float* fb_params, float* fb_grads, float* fb_adam_m, float* fb_adam_v, float* fb_targets,
+                       float* actor_params, float* actor_grads, float* actor_adam_m, float* actor_adam_v,
+                       void* workspace, size_t workspace_bytes);
+/* Device-resident replay storage, episode-major float32[n_episodes, t1, dim] exactly like
+ * ReplayBuffer._storage (in_memory_replay_buffer.py:119-125).  goal may be NULL when !use_goal.
+ * episode_len int32[n_episodes]; cum_len int64[n_episodes+1] (exclusive prefix sum; used when lengths vary). */
+int fbhip_replay_bind(fbhip_ctx* ctx, const float* observation, const float* action, const float* discount,
+                      const float* goal, const int32_t* episode_len, const int64_t* cum_len,
+                      int32_t n_episodes, int32_t t1, int32_t fixed_length);
+int fbhip_set_seed(fbhip_ctx* ctx, uint64_t seed, uint32_t rank);
+int fbhip_set_step_counts(fbhip_ctx* ctx, int32_t fb_steps, int32_t actor_steps, void* stream); /* Adam t */
+int fbhip_get_step_counts(fbhip_ctx* ctx, int32_t* host_fb_steps, int32_t* host_actor_steps, void* stream);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* Enqueue the selected phases of one FBDDPGAgent.update() (fb_ddpg.py:427-520).  use_graph != 0 replays a
+ * cached hipGraph of the launch sequence (captured on first use; re-captured when hparams change). */
+int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* inject,
+                 int32_t phase_mask, int32_t use_graph, void* stream);
+/* Blocking: copies the FBHIP_NUM_METRICS device floats to host_out after the stream drains. */
+int fbhip_read_metrics(fbhip_ctx* ctx, float* host_out, void* stream);
+/* Named views into the workspace for tests / host code ("z", "F1", "dF1", "obs", ...). */
+int fbhip_workspace_view(fbhip_ctx* ctx, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld);
+
+/* ---- inference entry points (fb_ddpg.py:177-289) --------------------------------------------------- */
+/* mu = Actor(obs, z).mean for ``rows`` rows (rows <= batch); obs [rows,o] ld=ld_obs, z [rows,d] ld=ld_z,
+ * action_out [rows,a] ld=ld_out.  If noise != NULL: action = TruncatedNormal(mu, stddev).sample() with
+ * noise [rows,a] contiguous (clip < 0 => no clip; utils.py:176-185). */
+int fbhip_actor_forward(fbhip_ctx* ctx, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z,
+                        int32_t rows, const float* noise, float stddev, float clip,
+                        float* action_out, int32_t ld_out, void* stream);
+/* B(goal): which = 0 online backward_net, 1 backward_target_net (fb_modules.py:223-230). out [rows,d]. */
+int fbhip_backward_map(fbhip_ctx* ctx, int32_t which, const float* goal, int32_t ld_goal, int32_t rows,
+                       float* out, int32_t ld_out, void* stream);
+/* F1,F2 = ForwardMap(obs, z, action): which = 0 online, 1 target (fb_modules.py:186-199). */
+int fbhip_forward_map(fbhip_ctx* ctx, int32_t which, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z,
+                      const float* action, int32_t ld_act, int32_t rows,
+                      float* f1_out, float* f2_out, int32_t ld_out, void* stream);
+
+/* ---- individually testable kernels ----------------------------------------------------------------- */
+/* C[M,N] = epi( sum_k A(m,k) * B(n,k) ).  a_kcontig: A(m,k) = A[m*lda+k] else A[k*lda+m]; same for B.
+ * epi: 0 none | 1 +bias[n] | 2 relu(+bias[n]) | 3 acc*(aux>0) | 4 acc*(1-aux^2).
+ * colsum (nullable, [M]) receives sum_k A(m,k) (the bias gradient of a weight-gradient GEMM). */
+int fbhip_gemm(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
+               float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+               const float* bias, const float* aux, int32_t ldaux, int32_t epi, float* colsum, void* stream);
+/* Same GEMM with an explicit tile configuration (0: 2x2x1, 1: 2x1x2, 2: 1x2x2, 3: 1x1x4, 4: 4x1x1 waves along
+ * M x N x K); no epilogue.  For tests and kernel benchmarking. */
+int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
+                   float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t cfg, void* stream);
+/* y = tanh(LayerNorm(x; gamma, beta, eps=1e-5)); stats[rows,2] = (mean, rstd)  (fb_modules.py:49-50) */
+int fbhip_ln_tanh_fwd(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
+                      float* stats, int32_t rows, int32_t n, void* stream);
+/* dx (may alias dy); dgamma/dbeta nullable; partials scratch >= ceil(rows/8)*2*n floats when they are not. */
+int fbhip_ln_tanh_bwd(const float* dy, int32_t lddy, const float* y, int32_t ldy, const float* x, int32_t ldx,
+                      const float* stats, const float* gamma, float* dx, int32_t lddx,
+                      float* dgamma, float* dbeta, float* partials, int32_t rows, int32_t n, void* stream);
+/* out = sqrt(d) * y / max(||y||, 1e-12); norms[rows] nullable (F.normalize, fb_modules.py:229) */
+int fbhip_l2norm_fwd(const float* y, int32_t ldy, float* out, int32_t ldo, float* norms,
+                     int32_t rows, int32_t d, void* stream);
+/* dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB)), yhat = y/||y||  (autograd of the line above) */
+int fbhip_l2norm_bwd(const float* dB, int32_t lddb, const float* y, int32_t ldy, const float* norms, float* dy,
+                     int32_t lddy, int32_t rows, int32_t d, void* stream);
+/* Actor loss (fb_ddpg.py:399-406): Q = min(F1.z, F2.z) row dots, loss = -mean Q, dF_i = -z/B on the arg-min
+ * (1/2 each on exact ties); writes ACTOR_LOSS, Q, ACTOR_LOGPROB into metrics. */
+int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float* z, int32_t ldz, const float* mu,
+                     int32_t ldmu, const float* action, int32_t lda, float stddev, float* dF1, float* dF2, float* metrics,
+                     int32_t rows, int32_t d, int32_t a, void* stream);
+/* Pairwise FB + orthonormality loss and its gradients (fb_ddpg.py:313-348).
+ * All inputs [B,d] with leading dim ld; discount [B].  Outputs dF1,dF2,dB [B,d] (ld), scalars -> metrics
+ * (device float[FBHIP_NUM_METRICS]; writes TARGET_M, M1, FB_LOSS, FB_DIAG, FB_OFFDIAG, ORTH_*).
+ * scratch: >= fbhip_pairwise_scratch_floats(B, d) floats. */
+size_t fbhip_pairwise_scratch_floats(int32_t B, int32_t d);
+int fbhip_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
+                      const float* tB, const float* discount, int32_t B, int32_t d, int32_t ld, float ortho_coef,
+                      float* dF1, float* dF2, float* dB, float* metrics, float* scratch, void* stream);
+/* Fused Adam (+ optional target EMA) over a flat segment: torch.optim.Adam defaults (betas .9/.999, eps 1e-8),
+ * t = 1-based step count; target nullable (utils.py:66-69 fused when given). */
+int fbhip_adam_ema(float* params, const float* grads, float* m, float* v, float* target, int64_t numel,
+                   float lr, int32_t t, float grad_scale, float tau, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FBHIP_H */

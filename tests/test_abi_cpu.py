@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/fbhip.h
+declares, reports the reference's parameter counts, and the product never touches oracle/."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build_lib()
+    from controllable_agent_amd import _lib
+    return _lib
+
+
+def test_header_symbols_all_exported(lib):
+    header = (ROOT / "include" / "fbhip.h").read_text()
+    declared = set(re.findall(r"\b(fbhip_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fbhip_ctx"}
+    l = lib.load()
+    for name in sorted(declared):
+        assert hasattr(l, name), f"{name} declared in include/fbhip.h but not exported by libfbhip.so"
+    assert declared == set(lib.PROTOTYPES), "ctypes prototypes out of sync with include/fbhip.h"
+
+
+def test_parameter_counts_match_reference(lib):
+    """SURVEY.md appendix B (confirmed by instantiating the reference): walker, z_dim=50."""
+    d = lib.Dims(1024, 24, 6, 24, 50, 1024, 512, 526, 0)
+    l = lib.load()
+    assert l.fbhip_net_param_count(C.byref(d), lib.NET_FORWARD) == 3_363_940
+    assert l.fbhip_net_param_count(C.byref(d), lib.NET_BACKWARD) == 317_754
+    assert l.fbhip_net_param_count(C.byref(d), lib.NET_ACTOR) == 2_211_846
+    assert [l.fbhip_layout_count(C.byref(d), n) for n in range(3)] == [20, 8, 16]
+
+
+def test_layout_is_aligned_and_disjoint(lib):
+    l = lib.load()
+    for dims in (lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0), lib.Dims(1024, 78, 12, 2, 100, 1024, 512, 526, 1)):
+        for net in range(3):
+            spans = []
+            for i in range(l.fbhip_layout_count(C.byref(dims), net)):
+                t = lib.TensorDesc()
+                assert l.fbhip_layout_entry(C.byref(dims), net, i, C.byref(t)) == 0
+                assert t.offset % 4 == 0 and t.ld % 4 == 0 and t.ld >= t.cols
+                spans.append((t.offset, t.offset + t.rows * t.ld))
+            spans.sort()
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 <= b0
+            assert spans[-1][1] <= l.fbhip_net_numel(C.byref(dims), net)
+
+
+def test_bad_dims_fail_loudly(lib):
+    l = lib.load()
+    bad = lib.Dims(1024, 24, 6, 24, 50, 1022, 512, 526, 0)       # hidden_dim % 4 != 0
+    assert l.fbhip_net_numel(C.byref(bad), 0) < 0
+    assert b"multiples of 4" in l.fbhip_last_error(None)
+    ctx = C.c_void_p()
+    assert l.fbhip_create(C.byref(bad), C.byref(ctx)) != 0
+
+
+def test_unbound_context_is_an_error_not_a_crash(lib):
+    l = lib.load()
+    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0)
+    ctx = C.c_void_p()
+    assert l.fbhip_create(C.byref(d), C.byref(ctx)) == 0
+    hp = lib.HParams()
+    assert l.fbhip_update(ctx, C.byref(hp), None, lib.PHASE_ALL, 0, None) == -3      # FBHIP_E_STATE
+    assert b"not bound" in l.fbhip_last_error(ctx)
+    assert l.fbhip_destroy(ctx) == 0
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.require_device()
+
+
+def test_product_never_imports_oracle():
+    for f in list((ROOT / "controllable_agent_amd").rglob("*.py")) + list((ROOT / "controllable_agent_amd").rglob("*.hip")):
+        txt = f.read_text()
+        assert "oracle" not in txt.lower().replace("# oracle", ""), f"{f} mentions oracle/"

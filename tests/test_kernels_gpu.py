@@ -1,0 +1,232 @@
+"""Kernel-level parity (GPU): every hand-written gfx950 kernel against an fp64 torch statement of the same op /
+the oracle's closed form.  Tolerances are fp32 round-off class and are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fb_oracle as fo
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from controllable_agent_amd import kernels
+    return kernels
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def _padded(t, ld):
+    """device copy of a 2-D tensor with leading dimension ld (pad columns filled with NaN to catch over-reads)"""
+    buf = torch.full((t.shape[0], ld), float("nan"), device="cuda")
+    buf[:, :t.shape[1]] = t.cuda()
+    return buf[:, :t.shape[1]]
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [
+    # M, N, K  -- layer shapes of the walker / quadruped nets plus ragged edge cases
+    (1024, 1024, 74), (1024, 512, 1024), (1024, 2048, 1024), (1024, 50, 1024), (1024, 6, 1024), (1024, 526, 526),
+    (1024, 1024, 30), (50, 1024, 1024), (526, 24, 1024), (2048, 1024, 1024), (1, 1024, 74), (16, 32, 13), (33, 65, 97),
+    (256, 100, 1024), (7, 3, 5),
+]
+
+
+@pytest.mark.parametrize("M,N,K_", GEMM_SHAPES)
+@pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, False)])
+def test_gemm_layouts(K, M, N, K_, akc, bkc):
+    """forward (NT), dgrad (NN), wgrad (TN) operand layouts; asymmetric random operands; NaN padding."""
+    A = _r(M, K_, seed=1) if akc else _r(K_, M, seed=1)
+    B = _r(N, K_, seed=2) if bkc else _r(K_, N, seed=2)
+    Ad = _padded(A, (A.shape[1] + 3) // 4 * 4 + 4)
+    Bd = _padded(B, (B.shape[1] + 3) // 4 * 4)
+    C = K.gemm(Ad, Bd, a_kcontig=akc, b_kcontig=bkc)
+    Am = A.double() if akc else A.double().T
+    Bm = B.double() if bkc else B.double().T
+    ref = Am @ Bm.T
+    assert C.shape == (M, N)
+    assert rel_err(C.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+def test_gemm_every_tile_config(K, cfg):
+    A, B = _r(200, 300, seed=3), _r(150, 300, seed=4)
+    C = K.gemm(A.cuda(), B.cuda(), cfg=cfg)
+    assert rel_err(C.cpu(), A.double() @ B.double().T) < 2e-6
+
+
+def test_gemm_unaligned_views(K):
+    """column-sliced operands (the actor step reads W1[:, o:o+a]) and odd leading dimensions take the scalar path"""
+    W = _r(64, 37, seed=5).cuda()
+    X = _r(100, 64, seed=6).cuda()
+    C = K.gemm(X, W[:, 5:11], a_kcontig=True, b_kcontig=False)          # [100,64] . [64,6]
+    assert rel_err(C.cpu(), X.cpu().double() @ W[:, 5:11].cpu().double()) < 2e-6
+
+
+def test_gemm_epilogues(K):
+    M, N, Kd = 300, 200, 128
+    A, B, bias, aux = _r(M, Kd, seed=7), _r(N, Kd, seed=8), _r(N, seed=9), _r(M, N, seed=10)
+    ref = A.double() @ B.double().T
+    Ad, Bd = A.cuda(), B.cuda()
+    from controllable_agent_amd import _lib
+    assert rel_err(K.gemm(Ad, Bd, bias=bias.cuda(), epi=_lib.EPI_BIAS).cpu(), ref + bias.double()) < 2e-6
+    assert rel_err(K.gemm(Ad, Bd, bias=bias.cuda(), epi=_lib.EPI_BIAS_RELU).cpu(), torch.relu(ref + bias.double())) < 2e-6
+    assert rel_err(K.gemm(Ad, Bd, aux=aux.cuda(), epi=_lib.EPI_MASK_RELU).cpu(), ref * (aux.double() > 0)) < 2e-6
+    y = torch.tanh(aux)
+    assert rel_err(K.gemm(Ad, Bd, aux=y.cuda(), epi=_lib.EPI_TANH_BWD).cpu(), ref * (1 - y.double() ** 2)) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,Kd", [(1024, 30, 1024), (50, 1024, 1024), (526, 526, 1024), (33, 7, 45)])
+def test_gemm_wgrad_colsum(K, M, N, Kd):
+    """weight-gradient GEMM dW = dY^T X with the fused bias gradient (column sums of dY)."""
+    dY, X = _r(Kd, M, seed=11), _r(Kd, N, seed=12)
+    C, cs = K.gemm(dY.cuda(), X.cuda(), a_kcontig=False, b_kcontig=False, want_colsum=True)
+    assert rel_err(C.cpu(), dY.double().T @ X.double()) < 2e-6
+    assert rel_err(cs.cpu(), dY.double().sum(0)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm + tanh
+@pytest.mark.parametrize("rows,n", [(1024, 1024), (1024, 526), (5, 32), (1, 18), (37, 2048), (16, 700)])
+def test_ln_tanh_fwd_bwd(K, rows, n):
+    x, g, b, dy = _r(rows, n, seed=1, scale=2.0), 1 + 0.1 * _r(n, seed=2), 0.1 * _r(n, seed=3), _r(rows, n, seed=4)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    y_ref = torch.tanh(torch.nn.functional.layer_norm(xd, (n,), gd, bd, 1e-5))
+    y_ref.backward(dy.double())
+    xp = _padded(x, (n + 3) // 4 * 4)
+    y, stats = K.ln_tanh_fwd(xp, g.cuda(), b.cuda())
+    assert rel_err(y.cpu(), y_ref.detach()) < 2e-6
+    assert rel_err(stats[:, 0].cpu(), x.double().mean(1)) < 1e-5 or x.double().mean(1).abs().max() < 1e-3
+    dx, dg, db = K.ln_tanh_bwd(dy.cuda(), y, xp, stats, g.cuda())
+    assert rel_err(dx.cpu(), xd.grad) < 1e-5
+    assert rel_err(dg.cpu(), gd.grad) < 1e-5
+    assert rel_err(db.cpu(), bd.grad) < 1e-5
+    dx2, none_g, none_b = K.ln_tanh_bwd(dy.cuda(), y, xp, stats, g.cuda(), want_param_grads=False)
+    assert none_g is None and torch.equal(dx2, dx)
+
+
+# ------------------------------------------------------------------------------------------------ L2 projection
+@pytest.mark.parametrize("rows,d", [(1024, 50), (1024, 100), (3, 8), (17, 128), (5, 1)])
+def test_l2norm_fwd_bwd(K, rows, d):
+    y, dB = _r(rows, d, seed=1), _r(rows, d, seed=2)
+    yd = y.double().requires_grad_(True)
+    ref = math.sqrt(d) * torch.nn.functional.normalize(yd, dim=1)
+    ref.backward(dB.double())
+    yp = _padded(y, (d + 3) // 4 * 4)
+    out, norms = K.l2norm_fwd(yp)
+    assert rel_err(out.cpu(), ref.detach()) < 1e-6
+    assert rel_err(norms.cpu(), y.double().norm(dim=1)) < 1e-6
+    dy = K.l2norm_bwd(dB.cuda(), yp, norms)
+    assert rel_err(dy.cpu(), yd.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ pairwise FB
+@pytest.mark.parametrize("Bn,d", [(16, 8), (64, 50), (256, 50), (1024, 50), (100, 100), (48, 10), (33, 3), (1024, 100),
+                                  (2048, 100)])
+def test_pairwise_fb_vs_closed_form(K, Bn, d):
+    """K3 against the oracle's fp64 closed form.  Tolerance: scalars rel 2e-5, grads rel-L2 1e-5
+    (fp32 products accumulated over d and over the batch)."""
+    rng = np.random.default_rng(Bn * 1000 + d)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    F1, F2, tF1, tF2 = t(Bn, d), t(Bn, d), t(Bn, d), t(Bn, d)
+    Bm = math.sqrt(d) * torch.nn.functional.normalize(t(Bn, d), dim=1)
+    tB = math.sqrt(d) * torch.nn.functional.normalize(t(Bn, d), dim=1)
+    disc = torch.from_numpy(rng.uniform(0.9, 0.99, (Bn, 1)).astype(np.float32))
+    cf = fo.fb_loss_closed_form(F1, F2, Bm, tF1, tF2, tB, disc, 0.7)
+    ld = (d + 3) // 4 * 4
+    dev = [_padded(x, ld) for x in (F1, F2, Bm, tF1, tF2, tB)]
+    dF1, dF2, dB, m = K.pairwise_fb(*dev, disc.cuda(), 0.7)
+    for k, got in (("dF1", dF1), ("dF2", dF2), ("dB", dB)):
+        assert rel_err(got.cpu(), cf[k]) < 1e-5, k
+    for k in ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_diag", "orth_loss_offdiag"):
+        assert m[k] == pytest.approx(float(cf[k]), rel=2e-5, abs=1e-6), k
+    assert m["target_M"] == pytest.approx(float(cf["target_M_mean"]), rel=1e-4, abs=1e-5)
+    assert m["M1"] == pytest.approx(float(cf["M1_mean"]), rel=1e-4, abs=1e-5)
+
+
+def test_pairwise_fb_vs_masked_autograd(K):
+    """... and against autograd of the reference's masked formulation (fb_ddpg.py:313-348) in fp32."""
+    rng = np.random.default_rng(3)
+    Bn, d = 96, 50
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    F1, F2, tF1, tF2 = t(Bn, d).requires_grad_(True), t(Bn, d).requires_grad_(True), t(Bn, d), t(Bn, d)
+    Bm = (math.sqrt(d) * torch.nn.functional.normalize(t(Bn, d), dim=1)).requires_grad_(True)
+    tB = math.sqrt(d) * torch.nn.functional.normalize(t(Bn, d), dim=1)
+    disc = torch.full((Bn, 1), 0.98)
+    L = fo.fb_loss_terms(F1, F2, Bm, tF1, tF2, tB, disc, 1.0)
+    L["fb_loss"].backward()
+    ld = 52
+    dev = [_padded(x.detach(), ld) for x in (F1, F2, Bm, tF1, tF2, tB)]
+    dF1, dF2, dB, m = K.pairwise_fb(*dev, disc.cuda(), 1.0)
+    assert rel_err(dF1.cpu(), F1.grad) < 1e-5 and rel_err(dF2.cpu(), F2.grad) < 1e-5 and rel_err(dB.cpu(), Bm.grad) < 1e-5
+    assert m["fb_loss"] == pytest.approx(float(L["fb_loss"]), rel=2e-5)
+
+
+def test_pairwise_is_deterministic(K):
+    """fixed-order reductions: two launches give bit-identical gradients and scalars"""
+    rng = np.random.default_rng(9)
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+    args = [t(512, 52)[:, :50] for _ in range(6)]
+    disc = torch.full((512,), 0.99, device="cuda")
+    a = K.pairwise_fb(*args, disc, 1.0)
+    b = K.pairwise_fb(*args, disc, 1.0)
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert a[3] == b[3]
+
+
+# ------------------------------------------------------------------------------------------------ Adam + EMA
+def test_adam_ema_matches_torch_optim(K):
+    n = 4 * 1000 + 4 * 37
+    p0, tgt0 = _r(n, seed=1), _r(n, seed=2)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=3e-4)
+    ref_t = tgt0.clone()
+    p, m, v, tg = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), tgt0.cuda()
+    for step in range(1, 6):
+        g = _r(n, seed=10 + step)
+        ref_p.grad = g.clone()
+        opt.step()
+        with torch.no_grad():
+            ref_t.copy_(0.01 * ref_p + (1 - 0.01) * ref_t)
+        K.adam_ema(p, g.cuda(), m, v, tg, lr=3e-4, t=step, tau=0.01)
+        assert (p.cpu() - ref_p.detach()).abs().max() < 2e-7 * step
+        assert (tg.cpu() - ref_t).abs().max() < 2e-7 * step
+    st = opt.state[ref_p]
+    assert rel_err(m.cpu(), st["exp_avg"]) < 1e-6 and rel_err(v.cpu(), st["exp_avg_sq"]) < 1e-6
+
+
+def test_adam_grad_scale(K):
+    n = 64
+    p, g = _r(n, seed=1).cuda(), _r(n, seed=2).cuda()
+    p2 = p.clone()
+    m, v, m2, v2 = (torch.zeros(n, device="cuda") for _ in range(4))
+    K.adam_ema(p, g * 4, m, v, None, lr=1e-3, t=1, grad_scale=0.25)
+    K.adam_ema(p2, g, m2, v2, None, lr=1e-3, t=1)
+    assert torch.allclose(p, p2, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ actor loss
+def test_actor_loss(K):
+    rng = np.random.default_rng(2)
+    Bn, d, a = 300, 50, 6
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+    F1, F2, z = t(Bn, d).requires_grad_(True), t(Bn, d).requires_grad_(True), t(Bn, d)
+    mu, act = torch.tanh(t(Bn, a)), torch.tanh(t(Bn, a))
+    Q = torch.min(torch.einsum('sd, sd -> s', F1, z), torch.einsum('sd, sd -> s', F2, z))
+    loss = -Q.mean()
+    loss.backward()
+    lp = fo.normal_log_prob(mu, 0.2, act).sum(-1).mean()
+    dF1, dF2, m = K.actor_loss(_padded(F1.detach(), 52), _padded(F2.detach(), 52), _padded(z, 52), _padded(mu, 8),
+                               _padded(act, 8), 0.2)
+    assert rel_err(dF1.cpu(), F1.grad) < 1e-6 and rel_err(dF2.cpu(), F2.grad) < 1e-6
+    assert m["actor_loss"] == pytest.approx(float(loss), rel=1e-5)
+    assert m["q"] == pytest.approx(float(Q.mean()), rel=1e-5)
+    assert m["actor_logprob"] == pytest.approx(float(lp), rel=1e-5)
