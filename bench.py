@@ -1,0 +1,193 @@
+"""bench.py -- FB update-steps/sec of the HIP path on MI355X (BASELINE.json metric, config[1]: walker offline
+replay, batch=1024, z_dim=50), with the roofline of the step and the CPU baseline timed beside it.
+
+    python bench.py [--gpus N --steps K --warmup W]                 # N=1: plain process
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                      # N>1: one rank per GPU over RCCL
+
+One "step" = one FBDDPGAgent.update(): on-device replay sample + FB step + actor step + target EMA, replayed
+as one hipGraph; inputs (the 5000-episode synthetic replay buffer) are resident in HBM before the timed region.
+N>1 is data parallel (SURVEY.md section 8e mode A): every rank owns a replay shard and a 1024-transition
+minibatch, gradients are all-reduced (RCCL) twice per step -> weak scaling; value = N * K / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WALKER = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50, hidden_dim=1024, feature_dim=512,
+              backward_hidden_dim=526, batch_size=1024)
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table
+
+
+def algorithmic_gflop_per_update(o, a, g, d, H, Fd, Hb, B):
+    """minimal algorithm (reference math minus the weight gradients its actor step computes
+    and discards); FLOP = 2 MAC, forward 1x, trained passes 3x."""
+    Ff = (o + a) * H + H * Fd + (o + d) * H + H * Fd + 2 * (2 * Fd * H + H * d)
+    Fa = o * H + H * Fd + (o + d) * H + H * Fd + 2 * Fd * H + H * a
+    Fb = g * Hb + Hb * Hb + Hb * d
+    Fp = 11 * B * d
+    Fdg = 2 * (H * d + 2 * Fd * H) + H * Fd + a * H
+    mac_row = 0.5 * Fb + Fa + Ff + Fb + 3 * Ff + 3 * Fb + 3 * Fa + Ff + Fdg + Fp
+    return 2 * mac_row * B / 1e9
+
+
+def make_replay(n_episodes, T, o, a, device, seed):
+    """Synthetic buffer per BASELINE.md section 4: obs ~ N(0,1), action ~ U(-1,1), stored discount 1."""
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    g = torch.Generator(device=device).manual_seed(seed)
+    rb = DeviceReplayBuffer(n_episodes, discount=0.99, future=0.99, device=device)
+    rb._storage = {
+        "observation": torch.randn((n_episodes, T + 1, o), device=device, generator=g),
+        "action": torch.rand((n_episodes, T + 1, a), device=device, generator=g) * 2 - 1,
+        "reward": torch.rand((n_episodes, T + 1, 1), device=device, generator=g),
+        "discount": torch.ones((n_episodes, T + 1, 1), device=device),
+    }
+    rb._episodes_length = np.full(n_episodes, T, np.int32)
+    rb._idx, rb._full = 0, True
+    rb._touch()
+    return rb
+
+
+def cpu_baseline(seed=1, budget_s=12.0, max_steps=40):
+    """The oracle (our CPU restatement of the reference's update, pinned to it by tests/golden) timed on this
+    box's host cores -- the reference's Python cannot travel to the GPU box.  Bounded sample of the same workload."""
+    from oracle import fb_oracle as fo
+    cfg = fo.OracleConfig(**WALKER)
+    rng = np.random.default_rng(seed)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    n_eps, T = 50, 1000
+    storage, lengths = fo.synthetic_storage(rng, n_eps, T, cfg.obs_dim, cfg.action_dim)
+    agent = fo.OracleAgent(cfg, nets)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one():
+        d = fo.make_draws(rng, cfg, n_eps, lengths)
+        agent.update(fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount), d)
+    for _ in range(2):
+        one()
+    t0, n = time.time(), 0
+    while n < max_steps and time.time() - t0 < budget_s:
+        one()
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "update-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} updates of the same workload (walker dims, batch 1024, z_dim 50, metrics on) with "
+                      f"oracle/fb_oracle.py (torch-CPU fp32 restatement of fb_ddpg.py:427-520, autograd + "
+                      f"boolean-mask loss like the reference), {dt:.1f} s"}
+
+
+def dominant_kernel_probe(stream_iters=50):
+    """HIP-event timing (on the launch stream) of the step's dominant kernel shape: the stacked F1|F2 hidden layer
+    GEMM  p[1024,2048] = h[1024,1024] . W3s^T  through the same fbhip gemm_kernel the update launches."""
+    from controllable_agent_amd import kernels as K
+    M, N, Kd = 1024, 2048, 1024
+    A, B = torch.randn(M, Kd, device="cuda"), torch.randn(N, Kd, device="cuda")
+    C = torch.empty(M, N, device="cuda")
+    for _ in range(5):
+        K.gemm(A, B, out=C)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(stream_iters):
+        K.gemm(A, B, out=C)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / stream_iters
+    return {"kernel": "fbhip::gemm_kernel<2,2,1,32>", "shape": [M, N, Kd], "us": us,
+            "tflops": 2 * M * N * Kd / us / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--episodes", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from controllable_agent_amd.agent import FBHipAgent
+    torch.manual_seed(1)                       # identical initial weights on every rank
+    agent = FBHipAgent(obs_type="states", obs_shape=(WALKER["obs_dim"],), action_shape=(WALKER["action_dim"],),
+                       device=dev, num_expl_steps=0, update_every_steps=1, batch_size=WALKER["batch_size"],
+                       z_dim=WALKER["z_dim"], hidden_dim=WALKER["hidden_dim"], feature_dim=WALKER["feature_dim"],
+                       backward_hidden_dim=WALKER["backward_hidden_dim"], use_tb=False, use_wandb=False, use_hiplog=False)
+    # each rank's shard of the 5000-episode buffer (episodes ep % world == rank  <=>  an independent 5000/world-episode draw)
+    rb = make_replay(max(args.episodes // world, 8), 1000, WALKER["obs_dim"], WALKER["action_dim"], dev, seed=100 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        agent.update(rb, s)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        agent.update(rb, args.warmup + s)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        steps_per_s = args.steps / dt                     # per-rank update rate (== global step rate)
+        value = world * steps_per_s                       # update-steps/s summed over ranks (weak scaling)
+        gflop = algorithmic_gflop_per_update(WALKER["obs_dim"], WALKER["action_dim"], WALKER["goal_dim"], WALKER["z_dim"],
+                                             WALKER["hidden_dim"], WALKER["feature_dim"], WALKER["backward_hidden_dim"],
+                                             WALKER["batch_size"])
+        achieved = gflop * steps_per_s / 1e3              # TFLOP/s per GPU
+        out = {
+            "metric": "FB update-steps/sec (batch=1024, z_dim=50)", "value": value, "unit": "update-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "fb_ddpg offline on walker_walk replay (configs[1]): obs 24, action 6, z_dim 50, "
+                                   "hidden 1024, feature 512, backward hidden 526; batch 1024 per GPU; "
+                                   f"{args.episodes}-episode x 1000-step synthetic RND-style replay resident in HBM; "
+                                   "metrics off in the timed loop (reference default)",
+                       "global_batch": WALKER["batch_size"] * world, "parallelism": f"dp{world}",
+                       "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "what": f"whole update step: {gflop:.2f} algorithmic GFLOP/update (SURVEY.md section 8d) x "
+                                 "measured updates/s, per GPU, vs the exact-fp32 MFMA peak"},
+        }
+        if world == 1:
+            out["roofline"]["dominant_kernel"] = dominant_kernel_probe()
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

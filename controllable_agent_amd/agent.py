@@ -1,0 +1,684 @@
+"""FBHipAgent: the reference's FB-DDPG agent surface on top of libfbhip.so (MI355X / gfx950).
+
+Mirrors ``url_benchmark/agent/fb_ddpg.py`` -- ``FBDDPGAgentConfig`` (:37-82) and ``FBDDPGAgent`` (:89-520):
+same constructor kwargs (so a hydra ``_target_`` pointing here works unchanged), same methods
+(``train, init_from, init_meta, update_meta, act, update, sample_z, infer_meta,
+infer_meta_from_obs_and_rewards, get_goal_meta, compute_z_correl``), same metric keys and gating.
+
+All state lives in flat fp32 device buffers (params / grads / Adam m,v / targets) owned by torch; the nets
+are exposed as ``NetView`` objects (``state_dict()``, ``parameters()``, ``load_state_dict()``) whose tensors
+are strided views into those buffers, so ``init_from``, pickling and checkpoint code keep working.  Every
+arithmetic step of ``update`` / ``act`` / ``infer_meta`` runs in hand-written HIP kernels behind the C ABI
+(include/fbhip.h); there is no eager-PyTorch or CPU fallback.
+"""
+from __future__ import annotations
+
+import collections
+import copy
+import ctypes as C
+import dataclasses
+import logging
+import math
+import re
+import typing as tp
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Dims, HParams, Inject, TensorDesc, check, ptr, stream_ptr
+from .replay import DeviceReplayBuffer, EpisodeBatch
+
+logger = logging.getLogger(__name__)
+MetaDict = tp.Mapping[str, np.ndarray]
+MISSING: tp.Any = "???"
+
+# goals.get_goal_space_dim (goals.py:218-221) instantiates a MuJoCo env just to read a vector length; the
+# lengths are fixed by the goal-space functions (goals.py:54-112), restated here.
+GOAL_SPACE_DIMS: tp.Dict[str, int] = {
+    "simplified_jaco": 3, "simplified_point_mass_maze": 2, "simplified_walker": 3, "walker_pos_speed": 4,
+    "walker_pos_speed_z": 6, "simplified_quadruped": 2, "quad_pos_speed": 7,
+}
+
+
+def register_goal_space(name: str, dim: int) -> None:
+    GOAL_SPACE_DIMS[name] = int(dim)
+
+
+def get_goal_space_dim(name: str) -> int:
+    if name not in GOAL_SPACE_DIMS:
+        raise KeyError(f"unknown goal_space {name!r}: call controllable_agent_amd.agent.register_goal_space(name, dim)")
+    return GOAL_SPACE_DIMS[name]
+
+
+def schedule(schdl: tp.Union[str, float], step: int) -> float:
+    """utils.schedule (utils.py:235-255)"""
+    try:
+        return float(schdl)
+    except ValueError:
+        match = re.match(r'linear\((.+),(.+),(.+)\)', schdl)
+        if match:
+            init, final, duration = [float(g) for g in match.groups()]
+            mix = np.clip(step / duration, 0.0, 1.0)
+            return float((1.0 - mix) * init + mix * final)
+        match = re.match(r'step_linear\((.+),(.+),(.+),(.+),(.+)\)', schdl)
+        if match:
+            init, final1, duration1, final2, duration2 = [float(g) for g in match.groups()]
+            if step <= duration1:
+                mix = np.clip(step / duration1, 0.0, 1.0)
+                return float((1.0 - mix) * init + mix * final1)
+            mix = np.clip((step - duration1) / duration2, 0.0, 1.0)
+            return float((1.0 - mix) * final1 + mix * final2)
+    raise NotImplementedError(schdl)
+
+
+@dataclasses.dataclass
+class FBDDPGAgentConfig:
+    """Field-for-field mirror of fb_ddpg.py:37-82 (omegaconf interpolations become plain required fields)."""
+    _target_: str = "controllable_agent_amd.agent.FBHipAgent"
+    name: str = "fb_ddpg"
+    obs_type: str = MISSING
+    obs_shape: tp.Tuple[int, ...] = MISSING
+    action_shape: tp.Tuple[int, ...] = MISSING
+    device: str = "cuda"
+    lr: float = 1e-4
+    lr_coef: float = 1
+    fb_target_tau: float = 0.01
+    update_every_steps: int = 2
+    use_tb: bool = False
+    use_wandb: bool = False
+    use_hiplog: bool = False
+    num_expl_steps: int = MISSING
+    num_inference_steps: int = 5120
+    hidden_dim: int = 1024
+    backward_hidden_dim: int = 526
+    feature_dim: int = 512
+    z_dim: int = 50
+    stddev_schedule: str = "0.2"
+    stddev_clip: float = 0.3
+    update_z_every_step: int = 300
+    update_z_proba: float = 1.0
+    nstep: int = 1
+    batch_size: int = 1024
+    init_fb: bool = True
+    update_encoder: bool = True
+    goal_space: tp.Optional[str] = None
+    ortho_coef: float = 1.0
+    log_std_bounds: tp.Tuple[float, float] = (-5, 2)
+    temp: float = 1
+    boltzmann: bool = False
+    debug: bool = False
+    future_ratio: float = 0.0
+    mix_ratio: float = 0.5
+    rand_weight: bool = False
+    preprocess: bool = True
+    norm_z: bool = True
+    q_loss: bool = False
+    q_loss_coef: float = 0.01
+    additional_metric: bool = False
+    add_trunk: bool = False
+
+
+# the reference's Linear-layer construction order per net (fb_modules.py:91-105, 165-182, 220); each entry is
+# (state_dict prefix, in_features, out_features) -- drives an RNG-stream-identical orthogonal init
+def _linear_order(net: str, o: int, a: int, g: int, d: int, H: int, Fd: int, Hb: int):
+    if net == "actor":
+        return [("obs_net.0", o, H), ("obs_net.3", H, Fd), ("obs_z_net.0", o + d, H), ("obs_z_net.3", H, Fd),
+                ("policy.0", 2 * Fd, H), ("policy.2", H, a)]
+    if net == "forward_net":
+        return [("obs_action_net.0", o + a, H), ("obs_action_net.3", H, Fd), ("obs_z_net.0", o + d, H),
+                ("obs_z_net.3", H, Fd), ("F1.0", 2 * Fd, H), ("F1.2", H, d), ("F2.0", 2 * Fd, H), ("F2.2", H, d)]
+    return [("B.0", g, Hb), ("B.3", Hb, Hb), ("B.5", Hb, d)]
+
+
+class NetView:
+    """A network stored inside a flat device buffer; quacks like the ``nn.Module`` the reference code expects
+    for parameter access (``state_dict / load_state_dict / parameters / named_parameters / train``)."""
+
+    def __init__(self, name: str, flat: torch.Tensor, layout: tp.List[TensorDesc],
+                 forward: tp.Optional[tp.Callable[[torch.Tensor], torch.Tensor]] = None) -> None:
+        self._name = name
+        self._flat = flat
+        self._forward = forward
+        self.training = True
+        self._views: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
+        for t in layout:
+            n = t.name.decode()
+            seg = flat[t.offset:t.offset + t.rows * t.ld].view(t.rows, t.ld)[:, :t.cols]
+            self._views[n] = seg[0] if (n.endswith("bias") or ".1." in n) else seg      # vectors: 1-D views
+
+    def state_dict(self) -> "collections.OrderedDict[str, torch.Tensor]":
+        return collections.OrderedDict(self._views)
+
+    def named_parameters(self) -> tp.Iterator[tp.Tuple[str, torch.Tensor]]:
+        return iter(self._views.items())
+
+    def parameters(self) -> tp.Iterator[torch.Tensor]:
+        return iter(self._views.values())
+
+    def load_state_dict(self, sd: tp.Mapping[str, tp.Any], strict: bool = True) -> None:
+        missing = set(self._views) - set(sd)
+        extra = set(sd) - set(self._views)
+        if strict and (missing or extra):
+            raise KeyError(f"{self._name}: missing {sorted(missing)}, unexpected {sorted(extra)}")
+        with torch.no_grad():
+            for k, v in self._views.items():
+                if k in sd:
+                    v.copy_(torch.as_tensor(sd[k], dtype=torch.float32))
+
+    def train(self, mode: bool = True) -> "NetView":
+        self.training = mode
+        return self
+
+    def to(self, *a: tp.Any, **k: tp.Any) -> "NetView":
+        return self
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if self._forward is None:
+            raise TypeError(f"{self._name} is not directly callable; use the agent's methods")
+        return self._forward(x)
+
+
+class AdamView:
+    """torch.optim.Adam-shaped handle (``state_dict / load_state_dict / param_groups``) on the flat m / v buffers."""
+
+    def __init__(self, agent: "FBHipAgent", which: str, nets: tp.List[str], lrs: tp.List[float]) -> None:
+        self._agent, self._which, self._nets = agent, which, nets
+        self.param_groups = [dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False) for lr in lrs]
+
+    def _mv(self) -> tp.List[tp.Tuple[torch.Tensor, torch.Tensor]]:
+        out = []
+        for n in self._nets:
+            for (_, m), (_, v) in zip(self._agent._adam_views[n]["m"].items(), self._agent._adam_views[n]["v"].items()):
+                out.append((m, v))
+        return out
+
+    def state_dict(self) -> tp.Dict[str, tp.Any]:
+        fb, ac = self._agent.step_counts()
+        t = fb if self._which == "fb" else ac
+        state = {}
+        if t > 0:
+            for i, (m, v) in enumerate(self._mv()):
+                state[i] = {"step": torch.tensor(float(t)), "exp_avg": m.detach().cpu().clone(),
+                            "exp_avg_sq": v.detach().cpu().clone()}
+        groups, i0 = [], 0
+        for n, g in zip(self._nets, self.param_groups):
+            k = len(self._agent._adam_views[n]["m"])
+            groups.append(dict(g, params=list(range(i0, i0 + k))))
+            i0 += k
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd: tp.Mapping[str, tp.Any]) -> None:
+        state = sd["state"]
+        t = 0
+        with torch.no_grad():
+            for i, (m, v) in enumerate(self._mv()):
+                if i in state:
+                    m.copy_(torch.as_tensor(state[i]["exp_avg"], dtype=torch.float32))
+                    v.copy_(torch.as_tensor(state[i]["exp_avg_sq"], dtype=torch.float32))
+                    t = int(float(state[i]["step"]))
+                else:
+                    m.zero_(), v.zero_()
+        fb, ac = self._agent.step_counts()
+        self._agent.set_step_counts(*( (t, ac) if self._which == "fb" else (fb, t) ))
+        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+            g["lr"] = src.get("lr", g["lr"])
+
+
+class FBHipAgent:
+    # pylint: disable=unused-argument
+    def __init__(self, **kwargs: tp.Any) -> None:
+        cfg = FBDDPGAgentConfig(**kwargs)
+        self.cfg = cfg
+        for f in ("obs_type", "obs_shape", "action_shape", "num_expl_steps"):
+            if getattr(cfg, f) is MISSING or getattr(cfg, f) == "???":
+                raise ValueError(f"FBHipAgent: missing required config field {f!r}")
+        unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
+                       "rand_weight": cfg.rand_weight, "add_trunk": cfg.add_trunk, "preprocess": not cfg.preprocess,
+                       "norm_z": not cfg.norm_z, "future_ratio": cfg.future_ratio > 0, "q_loss": cfg.q_loss,
+                       "nstep": cfg.nstep != 1}
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"FBHipAgent: non-default options not implemented in the HIP path yet: {bad}")
+        assert len(cfg.action_shape) == 1
+        self.action_dim = int(cfg.action_shape[0])
+        self.obs_dim = int(cfg.obs_shape[0])
+        self.solved_meta: tp.Any = None
+        self.actor_success: tp.List[float] = []
+        goal_dim = self.obs_dim
+        if cfg.goal_space is not None:
+            goal_dim = get_goal_space_dim(cfg.goal_space)
+        self.goal_dim = goal_dim
+        if cfg.feature_dim < self.obs_dim:
+            logger.warning(f"feature_dim {cfg.feature_dim} should not be smaller that obs_dim {self.obs_dim}")
+        if cfg.z_dim < goal_dim:
+            logger.warning(f"z_dim {cfg.z_dim} should not be smaller that goal_dim {goal_dim}")
+        self.training = True
+        self._device = torch.device(cfg.device)
+        self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, goal_dim, cfg.z_dim, cfg.hidden_dim,
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None))
+        self._ctx: tp.Optional[C.c_void_p] = None
+        self._replay_token: tp.Optional[tp.Tuple[int, int]] = None
+        self._ext_replay: tp.Optional[DeviceReplayBuffer] = None
+        self._use_graph = True
+        self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self._allocate(self._reference_init())
+        self.train()
+
+    # ------------------------------------------------------------------ construction
+    def _reference_init(self) -> tp.Dict[str, tp.Dict[str, torch.Tensor]]:
+        """Initial weights with the SAME torch RNG consumption as the reference constructor (fb_ddpg.py:119-141:
+        actor, forward_net, backward_net, backward_target_net, forward_target_net; each = nn.Linear default init
+        followed by utils.weight_init: orthogonal weights, zero bias, LayerNorm (1, 0); utils.py:81-93)."""
+        c = self.cfg
+        dims = (self.obs_dim, self.action_dim, self.goal_dim, c.z_dim, c.hidden_dim, c.feature_dim, c.backward_hidden_dim)
+
+        def build(net: str) -> tp.Dict[str, torch.Tensor]:
+            lins = [(p, torch.nn.Linear(i, o)) for p, i, o in _linear_order(net, *dims)]
+            sd: tp.Dict[str, torch.Tensor] = {}
+            for p, lin in lins:
+                torch.nn.init.orthogonal_(lin.weight.data)
+                sd[f"{p}.weight"] = lin.weight.data
+                sd[f"{p}.bias"] = torch.zeros_like(lin.bias.data)
+                if p.endswith(".0") and not p.startswith(("F1", "F2", "policy")):      # followed by LayerNorm
+                    pre = p[:-2]
+                    sd[f"{pre}.1.weight"] = torch.ones(lin.out_features)
+                    sd[f"{pre}.1.bias"] = torch.zeros(lin.out_features)
+            return sd
+
+        nets = {"actor": build("actor"), "forward_net": build("forward_net"), "backward_net": build("backward_net")}
+        build("backward_net")     # backward_target_net: constructed (RNG consumed), then overwritten by a copy
+        build("forward_net")      # forward_target_net
+        return nets
+
+    def _allocate(self, nets: tp.Optional[tp.Dict[str, tp.Dict[str, torch.Tensor]]]) -> None:
+        _lib.require_device()
+        lib = _lib.load()
+        d, dev = self._dims, self._device
+        torch.cuda.set_device(dev)
+        self._numel = [lib.fbhip_net_numel(C.byref(d), n) for n in range(3)]
+        if min(self._numel) < 0:
+            raise ValueError(_lib.last_error())
+        nfb = self._numel[0] + self._numel[1]
+        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
+        self._fb_params, self._fb_grads, self._fb_m, self._fb_v, self._fb_targets = z(nfb), z(nfb), z(nfb), z(nfb), z(nfb)
+        self._actor_params, self._actor_grads, self._actor_m, self._actor_v = (z(self._numel[2]) for _ in range(4))
+        self._workspace = torch.zeros(lib.fbhip_workspace_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+        ctx = C.c_void_p()
+        check(lib.fbhip_create(C.byref(d), C.byref(ctx)))
+        self._ctx = ctx
+        check(lib.fbhip_bind_buffers(ctx, ptr(self._fb_params), ptr(self._fb_grads), ptr(self._fb_m), ptr(self._fb_v),
+                                     ptr(self._fb_targets), ptr(self._actor_params), ptr(self._actor_grads),
+                                     ptr(self._actor_m), ptr(self._actor_v), ptr(self._workspace),
+                                     self._workspace.numel()), ctx)
+        check(lib.fbhip_set_seed(ctx, self._seed, self._rank()), ctx)
+
+        def layout(net: int) -> tp.List[TensorDesc]:
+            out = []
+            for i in range(lib.fbhip_layout_count(C.byref(d), net)):
+                t = TensorDesc()
+                check(lib.fbhip_layout_entry(C.byref(d), net, i, C.byref(t)))
+                out.append(t)
+            return out
+
+        nf = self._numel[0]
+        lay = {n: layout(i) for i, n in enumerate(("forward_net", "backward_net", "actor"))}
+        seg = {"forward_net": slice(0, nf), "backward_net": slice(nf, nfb)}
+        self.forward_net = NetView("forward_net", self._fb_params[seg["forward_net"]], lay["forward_net"])
+        self.backward_net = NetView("backward_net", self._fb_params[seg["backward_net"]], lay["backward_net"],
+                                    forward=lambda x: self._backward_map(x, target=False))
+        self.forward_target_net = NetView("forward_target_net", self._fb_targets[seg["forward_net"]], lay["forward_net"])
+        self.backward_target_net = NetView("backward_target_net", self._fb_targets[seg["backward_net"]],
+                                           lay["backward_net"], forward=lambda x: self._backward_map(x, target=True))
+        self.actor = NetView("actor", self._actor_params, lay["actor"])
+        self.encoder = torch.nn.Identity()      # states only (fb_ddpg.py:108-110)
+        self.aug = torch.nn.Identity()
+        self._grad_views = {"forward_net": NetView("g", self._fb_grads[seg["forward_net"]], lay["forward_net"]),
+                            "backward_net": NetView("g", self._fb_grads[seg["backward_net"]], lay["backward_net"]),
+                            "actor": NetView("g", self._actor_grads, lay["actor"])}
+        self._adam_views = {
+            "forward_net": {"m": NetView("m", self._fb_m[seg["forward_net"]], lay["forward_net"]).state_dict(),
+                            "v": NetView("v", self._fb_v[seg["forward_net"]], lay["forward_net"]).state_dict()},
+            "backward_net": {"m": NetView("m", self._fb_m[seg["backward_net"]], lay["backward_net"]).state_dict(),
+                             "v": NetView("v", self._fb_v[seg["backward_net"]], lay["backward_net"]).state_dict()},
+            "actor": {"m": NetView("m", self._actor_m, lay["actor"]).state_dict(),
+                      "v": NetView("v", self._actor_v, lay["actor"]).state_dict()}}
+        c = self.cfg
+        self.encoder_opt = None
+        self.actor_opt = AdamView(self, "actor", ["actor"], [c.lr])
+        self.fb_opt = AdamView(self, "fb", ["forward_net", "backward_net"], [c.lr, c.lr_coef * c.lr])   # fb_ddpg.py:149-151
+        if nets is not None:
+            self.load_nets(nets)
+
+    def load_nets(self, nets: tp.Mapping[str, tp.Mapping[str, tp.Any]], copy_targets: bool = True) -> None:
+        """Load {net: state_dict} (reference key names); targets start as copies (fb_ddpg.py:140-141)."""
+        for n in ("actor", "forward_net", "backward_net"):
+            if n in nets:
+                getattr(self, n).load_state_dict(nets[n])
+        if copy_targets:
+            self._fb_targets.copy_(self._fb_params)
+        for n in ("forward_target_net", "backward_target_net"):
+            if n in nets:
+                getattr(self, n).load_state_dict(nets[n])
+
+    def _rank(self) -> int:
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    def _world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def __del__(self) -> None:
+        ctx = getattr(self, "_ctx", None)
+        if ctx:
+            try:
+                _lib.load().fbhip_destroy(ctx)
+            except Exception:       # interpreter shutdown
+                pass
+            self._ctx = None
+
+    # ------------------------------------------------------------------ pickling (pretrain.py:437-449 pickles the agent object)
+    def __getstate__(self) -> tp.Dict[str, tp.Any]:
+        fb, ac = self.step_counts()
+        flat = {k: getattr(self, k).detach().cpu() for k in ("_fb_params", "_fb_m", "_fb_v", "_fb_targets",
+                                                              "_actor_params", "_actor_m", "_actor_v")}
+        return dict(cfg=dataclasses.asdict(self.cfg), flat=flat, fb_steps=fb, actor_steps=ac, seed=self._seed,
+                    solved_meta=self.solved_meta, training=self.training, goal_dim=self.goal_dim)
+
+    def __setstate__(self, st: tp.Dict[str, tp.Any]) -> None:
+        cfg = FBDDPGAgentConfig(**st["cfg"])
+        if torch.device(cfg.device).type == "cuda" and not torch.cuda.is_available():
+            raise RuntimeError("FBHipAgent needs an MI355X to be un-pickled (no CPU fallback)")
+        self.cfg = cfg
+        self.action_dim, self.obs_dim, self.goal_dim = int(cfg.action_shape[0]), int(cfg.obs_shape[0]), st["goal_dim"]
+        self.solved_meta, self.actor_success, self.training = st["solved_meta"], [], st["training"]
+        self._device = torch.device(cfg.device)
+        self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, self.goal_dim, cfg.z_dim, cfg.hidden_dim,
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None))
+        self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
+        self._allocate(None)
+        for k, v in st["flat"].items():
+            getattr(self, k).copy_(v)
+        self.set_step_counts(st["fb_steps"], st["actor_steps"])
+
+    # ------------------------------------------------------------------ small surface methods
+    def train(self, training: bool = True) -> None:                      # fb_ddpg.py:161-164
+        self.training = training
+        for net in (self.actor, self.forward_net, self.backward_net):
+            net.train(training)
+
+    def step_counts(self) -> tp.Tuple[int, int]:
+        fb, ac = C.c_int32(), C.c_int32()
+        check(_lib.load().fbhip_get_step_counts(self._ctx, C.byref(fb), C.byref(ac), stream_ptr()), self._ctx)
+        return fb.value, ac.value
+
+    def set_step_counts(self, fb_steps: int, actor_steps: int) -> None:
+        check(_lib.load().fbhip_set_step_counts(self._ctx, int(fb_steps), int(actor_steps), stream_ptr()), self._ctx)
+
+    def init_from(self, other: tp.Any) -> None:                          # fb_ddpg.py:166-175
+        names = ["actor"]
+        if self.cfg.init_fb:
+            names += ["forward_net", "backward_net", "backward_target_net", "forward_target_net"]
+        for name in names:
+            src = getattr(other, name)
+            getattr(self, name).load_state_dict({k: v.detach() for k, v in src.state_dict().items()})
+        for key in ("actor_opt", "fb_opt"):
+            if getattr(other, key, None) is not None:
+                getattr(self, key).load_state_dict(copy.deepcopy(getattr(other, key).state_dict()))
+
+    def sample_z(self, size: int, device: str = "cpu") -> torch.Tensor:  # fb_ddpg.py:224-232 (norm_z=True)
+        gaussian_rdv = torch.randn((size, self.cfg.z_dim), dtype=torch.float32, device=device)
+        gaussian_rdv = torch.nn.functional.normalize(gaussian_rdv, dim=1)
+        return math.sqrt(self.cfg.z_dim) * gaussian_rdv
+
+    def init_meta(self) -> MetaDict:                                      # fb_ddpg.py:234-243
+        if self.solved_meta is not None:
+            return self.solved_meta
+        z = self.sample_z(1).squeeze().numpy()
+        meta: tp.Dict[str, np.ndarray] = collections.OrderedDict()
+        meta["z"] = z
+        return meta
+
+    def update_meta(self, meta: MetaDict, global_step: int, time_step: tp.Any, finetune: bool = False,
+                    replay_loader: tp.Any = None) -> MetaDict:            # fb_ddpg.py:246-256
+        if global_step % self.cfg.update_z_every_step == 0 and np.random.rand() < self.cfg.update_z_proba:
+            return self.init_meta()
+        return meta
+
+    # ------------------------------------------------------------------ inference paths (HIP)
+    def _dev(self, x: tp.Any) -> torch.Tensor:
+        t = torch.as_tensor(x, dtype=torch.float32, device=self._device)
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        return t.contiguous()
+
+    def _backward_map(self, goal: tp.Any, target: bool = False) -> torch.Tensor:
+        """B(goal) with norm_z (fb_modules.py:223-230)"""
+        g = self._dev(goal)
+        assert g.shape[1] == self.goal_dim, (g.shape, self.goal_dim)
+        out = torch.empty((g.shape[0], self.cfg.z_dim), device=self._device)
+        check(_lib.load().fbhip_backward_map(self._ctx, int(target), ptr(g), g.stride(0), g.shape[0], ptr(out),
+                                             out.stride(0), stream_ptr()), self._ctx)
+        return out
+
+    def _forward_map(self, obs: torch.Tensor, z: torch.Tensor, action: torch.Tensor, target: bool = False):
+        f1 = torch.empty((obs.shape[0], self.cfg.z_dim), device=self._device)
+        f2 = torch.empty_like(f1)
+        check(_lib.load().fbhip_forward_map(self._ctx, int(target), ptr(obs), obs.stride(0), ptr(z), z.stride(0),
+                                            ptr(action), action.stride(0), obs.shape[0], ptr(f1), ptr(f2), f1.stride(0),
+                                            stream_ptr()), self._ctx)
+        return f1, f2
+
+    def _actor(self, obs: torch.Tensor, z: torch.Tensor, noise: tp.Optional[torch.Tensor], std: float,
+               clip: tp.Optional[float]) -> torch.Tensor:
+        out = torch.empty((obs.shape[0], self.action_dim), device=self._device)
+        check(_lib.load().fbhip_actor_forward(self._ctx, ptr(obs), obs.stride(0), ptr(z), z.stride(0), obs.shape[0],
+                                              ptr(noise), float(std), -1.0 if clip is None else float(clip), ptr(out),
+                                              out.stride(0), stream_ptr()), self._ctx)
+        return out
+
+    def act(self, obs: tp.Any, meta: MetaDict, step: int, eval_mode: bool) -> np.ndarray:   # fb_ddpg.py:258-281
+        o = self._dev(obs)
+        z = self._dev(meta["z"])
+        stddev = schedule(self.cfg.stddev_schedule, step)
+        if eval_mode:
+            action = self._actor(o, z, None, stddev, None)
+            if self.cfg.additional_metric:
+                f_mean = self._forward_map(o, z, action)
+                f_rand = self._forward_map(o, z, torch.zeros_like(action).uniform_(-1.0, 1.0))
+                qs = [torch.min(*( (f * z).sum(1) for f in fs)) for fs in (f_mean, f_rand)]
+                self.actor_success = (qs[0] > qs[1]).cpu().numpy().tolist()
+        else:
+            noise = torch.randn((1, self.action_dim), device=self._device)
+            action = self._actor(o, z, noise, stddev, None)               # dist.sample() without clip
+            if step < self.cfg.num_expl_steps:
+                action.uniform_(-1.0, 1.0)
+        return action.cpu().numpy()[0]
+
+    def _normalize_z(self, z: torch.Tensor) -> torch.Tensor:
+        from . import kernels
+        return kernels.l2norm_fwd(z.contiguous())[0]
+
+    def get_goal_meta(self, goal_array: np.ndarray) -> MetaDict:          # fb_ddpg.py:177-186
+        z = self._backward_map(np.asarray(goal_array, np.float32))
+        z = self._normalize_z(z)
+        meta: tp.Dict[str, np.ndarray] = collections.OrderedDict()
+        meta["z"] = z.squeeze(0).cpu().numpy()
+        return meta
+
+    def infer_meta(self, replay_loader: tp.Any) -> MetaDict:              # fb_ddpg.py:188-199
+        obs_list, reward_list = [], []
+        batch_size = 0
+        while batch_size < self.cfg.num_inference_steps:
+            batch = replay_loader.sample(self.cfg.batch_size).to(self.cfg.device)
+            obs_list.append(batch.next_goal if self.cfg.goal_space is not None else batch.next_obs)
+            reward_list.append(batch.reward)
+            batch_size += batch.next_obs.size(0)
+        obs, reward = torch.cat(obs_list, 0), torch.cat(reward_list, 0)
+        obs, reward = obs[:self.cfg.num_inference_steps], reward[:self.cfg.num_inference_steps]
+        return self.infer_meta_from_obs_and_rewards(obs, reward)
+
+    def infer_meta_from_obs_and_rewards(self, obs: torch.Tensor, reward: torch.Tensor) -> MetaDict:   # fb_ddpg.py:201-222
+        from . import kernels
+        Bm = self._backward_map(obs)
+        r = self._dev(reward).reshape(-1, 1)
+        z = kernels.gemm(r, Bm, a_kcontig=False, b_kcontig=False)        # reward^T . B   [1, d]
+        z = z / r.shape[0]
+        z = self._normalize_z(z)
+        meta: tp.Dict[str, np.ndarray] = collections.OrderedDict()
+        meta["z"] = z.squeeze().cpu().numpy()
+        return meta
+
+    def compute_z_correl(self, time_step: tp.Any, meta: MetaDict) -> float:   # fb_ddpg.py:283-289
+        goal = time_step.goal if self.cfg.goal_space is not None else time_step.observation
+        b = torch.nn.functional.normalize(self._backward_map(np.asarray(goal, np.float32)), dim=1)
+        z = torch.nn.functional.normalize(self._dev(meta["z"]), dim=1)
+        return float((b * z).sum().item())
+
+    # ------------------------------------------------------------------ the hot path
+    def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float) -> HParams:
+        c = self.cfg
+        return HParams(lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.fb_target_tau,
+                       stddev=schedule(c.stddev_schedule, step), stddev_clip=c.stddev_clip, ortho_coef=c.ortho_coef,
+                       mix_ratio=c.mix_ratio, q_loss_coef=c.q_loss_coef, discount=discount, grad_scale=grad_scale,
+                       q_loss=int(c.q_loss), want_metrics=int(want_metrics))
+
+    def _bind_replay(self, rb: DeviceReplayBuffer) -> None:
+        token = (id(rb), rb._version)
+        if token == self._replay_token:
+            return
+        if rb.device != self._device:
+            raise RuntimeError(f"replay buffer lives on {rb.device}, agent on {self._device}")
+        v = rb.device_view()
+        if self._dims.use_goal and v["goal"] is None:
+            raise RuntimeError("goal_space is set but the replay buffer stores no 'goal'")
+        for name, dim in (("observation", self.obs_dim), ("action", self.action_dim)):
+            if v[name].shape[2] != dim:
+                raise RuntimeError(f"replay '{name}' has dim {v[name].shape[2]}, agent expects {dim}")
+        check(_lib.load().fbhip_replay_bind(self._ctx, ptr(v["observation"]), ptr(v["action"]), ptr(v["discount"]),
+                                            ptr(v["goal"]), ptr(v["episode_len"]), ptr(v["cum_len"]), v["n_episodes"],
+                                            v["t1"], int(v["fixed_length"])), self._ctx)
+        self._replay_view = v           # keeps the tensors alive while bound
+        self._replay_token = token
+
+    def _run_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
+        import torch.distributed as dist
+        lib = _lib.load()
+        inj = C.byref(inject) if inject is not None else None
+        s = stream_ptr()
+        if self._world() == 1:
+            check(lib.fbhip_update(self._ctx, C.byref(hp), inj, _lib.PHASE_ALL, int(use_graph), s), self._ctx)
+            return
+        # data parallel (SURVEY.md section 8e mode A): local batch x batch loss, sum-all-reduce of the two flat
+        # gradient buckets over RCCL/xGMI, 1/world folded into the Adam pass
+        check(lib.fbhip_update(self._ctx, C.byref(hp), inj, _lib.PHASE_SAMPLE | _lib.PHASE_FB_GRAD, int(use_graph), s), self._ctx)
+        dist.all_reduce(self._fb_grads)
+        check(lib.fbhip_update(self._ctx, C.byref(hp), None, _lib.PHASE_FB_STEP | _lib.PHASE_ACTOR_GRAD, int(use_graph), s), self._ctx)
+        dist.all_reduce(self._actor_grads)
+        check(lib.fbhip_update(self._ctx, C.byref(hp), None, _lib.PHASE_ACTOR_STEP, int(use_graph), s), self._ctx)
+
+    def _metrics(self) -> tp.Dict[str, float]:
+        c = self.cfg
+        out: tp.Dict[str, float] = {}
+        if not (c.use_tb or c.use_wandb or c.use_hiplog):
+            return out
+        buf = (C.c_float * _lib.NUM_METRICS)()
+        check(_lib.load().fbhip_read_metrics(self._ctx, buf, stream_ptr()), self._ctx)
+        g = lambda k: float(buf[_lib.METRIC_INDEX[k]])
+        for k in ("target_M", "M1", "F1", "B", "B_norm", "z_norm", "fb_loss", "fb_diag", "fb_offdiag"):
+            out[k] = g(k)
+        if c.q_loss:
+            out["q_loss"] = g("q_loss")
+        for k in ("orth_loss", "orth_loss_diag", "orth_loss_offdiag", "orth_linf", "orth_l2"):
+            out[k] = g(k)
+        out["fb_opt_lr"] = self.fb_opt.param_groups[0]["lr"]
+        if c.use_tb or c.use_wandb:                                        # fb_ddpg.py:413-418
+            out["actor_loss"], out["q"], out["actor_logprob"] = g("actor_loss"), g("q"), g("actor_logprob")
+        return out
+
+    def update(self, replay_loader: tp.Any, step: int) -> tp.Dict[str, float]:      # fb_ddpg.py:427-520
+        if step % self.cfg.update_every_steps != 0:
+            return {}
+        c = self.cfg
+        want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+        if isinstance(replay_loader, DeviceReplayBuffer):
+            self._bind_replay(replay_loader)
+            hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount))
+            self._run_update(hp, None, self._use_graph)
+        else:
+            # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
+            return self.update_from_batch(replay_loader.sample(c.batch_size), step)
+        return self._metrics()
+
+    def update_from_batch(self, batch: tp.Any, step: int, draws: tp.Optional[tp.Mapping[str, tp.Any]] = None,
+                          use_graph: bool = False) -> tp.Dict[str, float]:
+        """One update on an externally sampled batch (``EpisodeBatch``-like: obs, action, next_obs, discount
+        [, goal, next_goal]).  ``draws`` optionally injects the remaining random draws (parity tests):
+        z_gauss [B,d], perm [B], mix_uniform [B], eps_next [B,a], eps_actor [B,a]."""
+        c, dev, Bn = self.cfg, self._device, self.cfg.batch_size
+        f = lambda x: torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32,
+                                      device=dev).reshape(Bn, -1)
+        obs, nobs, act, disc = f(batch.obs), f(batch.next_obs), f(batch.action), f(batch.discount)
+        # a one-transition-per-episode storage [B, 2, dim]: row 0 = (obs, goal), row 1 = (next_obs, action, ...)
+        storage = {"observation": torch.stack([obs, nobs], 1).contiguous(),
+                   "action": torch.stack([torch.zeros_like(act), act], 1).contiguous(),
+                   "discount": torch.stack([torch.ones_like(disc), disc], 1).contiguous()}
+        if c.goal_space is not None:
+            storage["goal"] = torch.stack([f(batch.goal), f(batch.next_goal)], 1).contiguous()
+        rb = DeviceReplayBuffer(Bn, 1.0, 1.0, device=dev)
+        rb._storage = storage
+        rb._episodes_length = np.ones(Bn, np.int32)
+        rb._idx, rb._full = 0, True
+        rb._touch()
+        self._ext_replay = rb
+        self._bind_replay(rb)
+        i32 = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.int32, device=dev).contiguous()
+        keep: tp.List[torch.Tensor] = [i32(np.arange(Bn)), i32(np.ones(Bn))]
+        inj = Inject(ep_idx=ptr(keep[0]), step_idx=ptr(keep[1]))
+        if draws is not None:
+            for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor"):
+                if name in draws and draws[name] is not None:
+                    t = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
+                    keep.append(t)
+                    setattr(inj, name, ptr(t))
+            if draws.get("perm") is not None:
+                keep.append(i32(draws["perm"]))
+                inj.perm = ptr(keep[-1])
+        want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+        hp = self._hparams(step, want, 1.0 / self._world(), 1.0)          # batch.discount is already gamma-scaled
+        self._run_update(hp, inj, use_graph)
+        torch.cuda.current_stream().synchronize()                          # ``keep`` must outlive the launches
+        return self._metrics()
+
+    def update_injected(self, replay_loader: DeviceReplayBuffer, step: int, draws: tp.Mapping[str, tp.Any],
+                        use_graph: bool = False) -> tp.Dict[str, float]:
+        """Parity mode: every random draw of the step is supplied (``ep_idx, step_idx, z_gauss, perm,
+        mix_uniform, eps_next, eps_actor``), exactly as recorded from the reference run."""
+        dev = self._device
+        self._bind_replay(replay_loader)
+        keep = {}
+        inj = Inject()
+        for name in ("ep_idx", "step_idx", "perm"):
+            keep[name] = torch.as_tensor(np.asarray(draws[name]), dtype=torch.int32, device=dev).contiguous()
+            setattr(inj, name, ptr(keep[name]))
+        for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor"):
+            keep[name] = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
+            setattr(inj, name, ptr(keep[name]))
+        self._inject_keep = keep
+        c = self.cfg
+        want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+        hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount))
+        self._run_update(hp, inj, use_graph)
+        return self._metrics()
+
+    def workspace_view(self, name: str) -> torch.Tensor:
+        """A named intermediate of the last update as a tensor view into the workspace (tests / debugging)."""
+        p, rows, cols, ld = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(_lib.load().fbhip_workspace_view(self._ctx, name.encode(), C.byref(p), C.byref(rows), C.byref(cols),
+                                               C.byref(ld)), self._ctx)
+        base = self._workspace.data_ptr()
+        off = p.value - base
+        is_int = name in ("ep_idx", "step_idx", "perm")
+        flat = self._workspace[off:off + 4 * rows.value * ld.value].view(torch.int32 if is_int else torch.float32)
+        return flat.view(rows.value, ld.value)[:, :cols.value]

@@ -439,16 +439,16 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
 
     if (mask & FBHIP_PHASE_SAMPLE) {
         HIPCK(c, launch_step_advance(w.st, 2, s));
+        // every NULL field of ``inj`` is drawn on device; injected fields (parity mode / externally sampled
+        // batches) overwrite the draw
+        const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
+                                  inj->z_gauss && inj->eps_next && inj->eps_actor;
+        if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, w.perm_keys, s));
         if (inj != nullptr) {
-            HIPCK(c, hipMemcpyAsync(w.so.ep_idx, inj->ep_idx, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-            HIPCK(c, hipMemcpyAsync(w.so.step_idx, inj->step_idx, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-            HIPCK(c, hipMemcpyAsync(w.so.perm, inj->perm, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-            HIPCK(c, hipMemcpyAsync(w.so.mix_uniform, inj->mix_uniform, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-            HIPCK(c, hipMemcpyAsync(w.so.z_gauss, inj->z_gauss, (size_t)B * z * 4, hipMemcpyDeviceToDevice, s));
-            HIPCK(c, hipMemcpyAsync(w.so.eps_next, inj->eps_next, (size_t)B * a * 4, hipMemcpyDeviceToDevice, s));
-            HIPCK(c, hipMemcpyAsync(w.so.eps_actor, inj->eps_actor, (size_t)B * a * 4, hipMemcpyDeviceToDevice, s));
-        } else {
-            HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, w.perm_keys, s));
+#define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
+            INJ(ep_idx, B * 4); INJ(step_idx, B * 4); INJ(perm, B * 4); INJ(mix_uniform, B * 4);
+            INJ(z_gauss, (size_t)B * z * 4); INJ(eps_next, (size_t)B * a * 4); INJ(eps_actor, (size_t)B * a * 4);
+#undef INJ
         }
         GatherArgs ga{};
         ga.rv = c->rv; ga.ep_idx = w.so.ep_idx; ga.step_idx = w.so.step_idx; ga.perm = w.so.perm;

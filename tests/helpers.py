@@ -46,3 +46,58 @@ def rel_err(a, b) -> float:
 
 
 LOSS_KEYS = ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_offdiag", "actor_loss", "q")
+
+
+# ------------------------------------------------------------------------------------------------ HIP agent glue
+def agent_kwargs(cfg: fo.OracleConfig, goal_space=None, metrics=True, **extra):
+    kw = dict(obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cuda",
+              num_expl_steps=0, use_tb=metrics, use_wandb=False, use_hiplog=False, goal_space=goal_space,
+              lr=cfg.lr, lr_coef=cfg.lr_coef, fb_target_tau=cfg.fb_target_tau, hidden_dim=cfg.hidden_dim,
+              backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim, z_dim=cfg.z_dim,
+              stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
+              ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
+              update_every_steps=1)
+    kw.update(extra)
+    return kw
+
+
+def make_hip_agent(cfg: fo.OracleConfig, nets, goal_space=None, metrics=True):
+    from controllable_agent_amd.agent import FBHipAgent
+    ag = FBHipAgent(**agent_kwargs(cfg, goal_space, metrics))
+    ag.load_nets({n: {k: v for k, v in p.items()} for n, p in nets.items()})
+    return ag
+
+
+NETS5 = ("actor", "forward_net", "backward_net", "forward_target_net", "backward_target_net")
+
+
+def get_agent_state(agent) -> dict:
+    out = {}
+    for n in NETS5:
+        for k, v in getattr(agent, n).state_dict().items():
+            out[f"{n}/{k}"] = v.detach().cpu().numpy().copy()
+    for n in ("actor", "forward_net", "backward_net"):
+        for mv in ("m", "v"):
+            for k, v in agent._adam_views[n][mv].items():
+                out[f"adam_{mv}/{n}/{k}"] = v.detach().cpu().numpy().copy()
+    return out
+
+
+def set_agent_state(agent, state: dict, fb_steps: int, actor_steps: int) -> None:
+    """state: {'net/param': array, 'adam_m/net/param': array, ...} (the layout of the golden traces)"""
+    for n in NETS5:
+        sd = {k.split("/", 1)[1]: torch.from_numpy(np.asarray(v)) for k, v in state.items() if k.startswith(n + "/")}
+        getattr(agent, n).load_state_dict(sd)
+    for n in ("actor", "forward_net", "backward_net"):
+        for mv in ("m", "v"):
+            for k, view in agent._adam_views[n][mv].items():
+                key = f"adam_{mv}/{n}/{k}"
+                if key in state:
+                    view.copy_(torch.from_numpy(np.asarray(state[key])))
+                else:
+                    view.zero_()
+    agent.set_step_counts(fb_steps, actor_steps)
+
+
+def draws_dict(d: fo.Draws) -> dict:
+    return {f: getattr(d, f) for f in d.__dataclass_fields__}

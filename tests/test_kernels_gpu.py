@@ -124,7 +124,10 @@ def test_l2norm_fwd_bwd(K, rows, d):
     assert rel_err(out.cpu(), ref.detach()) < 1e-6
     assert rel_err(norms.cpu(), y.double().norm(dim=1)) < 1e-6
     dy = K.l2norm_bwd(dB.cuda(), yp, norms)
-    assert rel_err(dy.cpu(), yd.grad) < 1e-5
+    if d == 1:          # the projection of a 1-vector is constant: the true gradient is exactly zero
+        assert dy.abs().max().item() < 1e-6
+    else:
+        assert rel_err(dy.cpu(), yd.grad) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ pairwise FB

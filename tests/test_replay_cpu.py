@@ -1,0 +1,102 @@
+"""Host logic of DeviceReplayBuffer on CPU tensors: the reference's bookkeeping tests
+(url_benchmark/test_in_memory_replay_buffer.py:19-53) plus the sampler KAT recorded from the real ReplayBuffer."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from controllable_agent_amd.replay import DeviceReplayBuffer, EpisodeBatch, TimeStep
+from tests import helpers as H
+
+
+def _fill(rb, lengths, o=4, a=2, goal_dim=None, meta_z=None, storage=None):
+    for e, L in enumerate(lengths):
+        for s in range(L + 1):
+            st = 0 if s == 0 else (2 if s == L else 1)
+            kw = {}
+            if storage is not None:
+                kw = dict(reward=float(storage["reward"][e, s, 0]), discount=float(storage["discount"][e, s, 0]),
+                          observation=storage["observation"][e, s], action=storage["action"][e, s])
+                if "goal" in storage:
+                    kw["goal"] = storage["goal"][e, s]
+            else:
+                kw = dict(reward=0.0, discount=1.0, observation=np.full(o, e, np.float32), action=np.zeros(a, np.float32))
+            ts = TimeStep(step_type=st, physics=np.zeros(2, np.float32), **kw)
+            rb.add(ts, {} if meta_z is None else {"z": meta_z[e, s]})
+
+
+def test_fixed_episode_length_bookkeeping():
+    rb = DeviceReplayBuffer(max_episodes=3, discount=1.0, future=1.0, device="cpu")
+    _fill(rb, [10, 10])
+    assert len(rb) == 2 and not rb._full and rb._is_fixed_episode_length and rb.avg_episode_length == 10
+    _fill(rb, [10, 10])                      # wraps around
+    assert len(rb) == 3 and rb._full and rb._idx == 1
+
+
+def test_variable_episode_length_bookkeeping():
+    rb = DeviceReplayBuffer(max_episodes=4, discount=1.0, future=1.0, max_episode_length=11, device="cpu")
+    _fill(rb, [10, 4, 6])
+    assert not rb._is_fixed_episode_length
+    assert rb.avg_episode_length == round((10 + 4 + 6) / 3)
+    np.testing.assert_array_equal(rb._episodes_length, [10, 4, 6, 0])
+    b = rb.sample(64)
+    assert b.obs.shape == (64, 4) and b.discount.shape == (64, 1)
+
+
+def test_sample_matches_reference_kat(golden_dir):
+    """Same numpy global-RNG seed => the real ReplayBuffer's indices and rows, bit for bit."""
+    z = np.load(golden_dir / "sampler_kat.npz")
+    storage = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("storage/")}
+    rb = DeviceReplayBuffer(max_episodes=6, discount=0.98, future=1.0, max_episode_length=10, device="cpu")
+    _fill(rb, z["lengths"], storage=storage, meta_z=z["meta_z"])
+    assert len(rb) == int(z["rb_len"]) and rb._full == bool(z["rb_full"]) and rb._idx == int(z["rb_idx"])
+    assert rb.avg_episode_length == int(z["avg_episode_length"])
+    np.testing.assert_array_equal(rb._episodes_length, z["rb_episodes_length"])
+    np.random.seed(123)
+    b = rb.sample(64)
+    for k in ("obs", "action", "next_obs", "reward", "discount", "goal", "next_goal"):
+        np.testing.assert_array_equal(getattr(b, k).numpy(), z[k], err_msg=k)
+    np.testing.assert_array_equal(b.meta["z"].numpy(), z["meta_z_out"])
+    assert b.future_obs is None
+
+
+def test_pickle_round_trip_and_from_arrays():
+    rng = np.random.default_rng(0)
+    from oracle import fb_oracle as fo
+    storage, lengths = fo.synthetic_storage(rng, 5, 8, 4, 2, goal_dim=3)
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, 0.99, device="cpu")
+    rb2 = pickle.loads(pickle.dumps(rb))
+    assert len(rb2) == 5 and rb2._discount == 0.99
+    for k in storage:
+        np.testing.assert_array_equal(rb2._storage[k].numpy(), storage[k])
+    v = rb.device_view()
+    assert v["n_episodes"] == 5 and v["t1"] == 9 and v["fixed_length"]
+    np.testing.assert_array_equal(v["cum_len"].numpy(), np.arange(6) * 8)
+    sh = rb.shard(1, 2)
+    assert len(sh) == 2
+    np.testing.assert_array_equal(sh._storage["observation"].numpy(), storage["observation"][[1, 3]])
+
+
+def test_episode_batch_surface():
+    b = EpisodeBatch(obs=np.zeros((3, 2), np.float32), action=np.zeros((3, 1), np.float32),
+                     reward=np.ones((3, 1), np.float32), next_obs=np.zeros((3, 2), np.float32),
+                     discount=np.ones((3, 1), np.float32))
+    t = b.to("cpu")
+    assert isinstance(t.obs, torch.Tensor) and t.goal is None
+    assert float(t.with_no_reward().reward.sum()) == 0.0
+    assert len(t.unpack()) == 5
+
+
+def test_agent_rejects_unsupported_flags_loudly():
+    from controllable_agent_amd.agent import FBHipAgent
+    base = dict(obs_type="states", obs_shape=(4,), action_shape=(2,), num_expl_steps=0)
+    for flag in (dict(boltzmann=True), dict(add_trunk=True), dict(preprocess=False), dict(norm_z=False),
+                 dict(future_ratio=0.5), dict(rand_weight=True), dict(debug=True), dict(obs_type="pixels")):
+        with pytest.raises(NotImplementedError):
+            FBHipAgent(**{**base, **flag})
+    with pytest.raises(ValueError):
+        FBHipAgent(obs_type="states", obs_shape=(4,), action_shape=(2,))            # num_expl_steps missing
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            FBHipAgent(**base)
