@@ -69,14 +69,25 @@ def cpu_baseline(seed=1, budget_s=12.0, max_steps=40):
     n_eps, T = 50, 1000
     storage, lengths = fo.synthetic_storage(rng, n_eps, T, cfg.obs_dim, cfg.action_dim)
     agent = fo.OracleAgent(cfg, nets)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
 
     def one():
         d = fo.make_draws(rng, cfg, n_eps, lengths)
         agent.update(fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount), d)
-    for _ in range(2):
+    # torch-CPU oversubscribes badly when given every hardware thread of a big host (75 s/update at 256 threads):
+    # probe a few thread counts on the cores this process may actually use and keep the fastest
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best = None
+    for nt in sorted({min(avail, n) for n in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
         one()
+        t0 = time.time()
+        one()
+        dt1 = time.time() - t0
+        if best is None or dt1 < best[1]:
+            best = (nt, dt1)
+        if dt1 > 3.0:
+            break
+    torch.set_num_threads(best[0])
     t0, n = time.time(), 0
     while n < max_steps and time.time() - t0 < budget_s:
         one()

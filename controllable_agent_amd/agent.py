@@ -254,7 +254,7 @@ class FBHipAgent:
         if cfg.z_dim < goal_dim:
             logger.warning(f"z_dim {cfg.z_dim} should not be smaller that goal_dim {goal_dim}")
         self.training = True
-        self._device = torch.device(cfg.device)
+        self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, goal_dim, cfg.z_dim, cfg.hidden_dim,
                           cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None))
         self._ctx: tp.Optional[C.c_void_p] = None
@@ -266,6 +266,16 @@ class FBHipAgent:
         self.train()
 
     # ------------------------------------------------------------------ construction
+    @staticmethod
+    def _resolve_device(device: tp.Any) -> torch.device:
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"FBHipAgent runs on an MI355X only (device={device!r}); there is no CPU fallback")
+        _lib.require_device()
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        return dev
+
     def _reference_init(self) -> tp.Dict[str, tp.Dict[str, torch.Tensor]]:
         """Initial weights with the SAME torch RNG consumption as the reference constructor (fb_ddpg.py:119-141:
         actor, forward_net, backward_net, backward_target_net, forward_target_net; each = nn.Linear default init
@@ -296,6 +306,7 @@ class FBHipAgent:
         lib = _lib.load()
         d, dev = self._dims, self._device
         torch.cuda.set_device(dev)
+        self._stream = torch.cuda.Stream(device=dev)      # hipGraph capture is illegal on the legacy default stream
         self._numel = [lib.fbhip_net_numel(C.byref(d), n) for n in range(3)]
         if min(self._numel) < 0:
             raise ValueError(_lib.last_error())
@@ -388,12 +399,10 @@ class FBHipAgent:
 
     def __setstate__(self, st: tp.Dict[str, tp.Any]) -> None:
         cfg = FBDDPGAgentConfig(**st["cfg"])
-        if torch.device(cfg.device).type == "cuda" and not torch.cuda.is_available():
-            raise RuntimeError("FBHipAgent needs an MI355X to be un-pickled (no CPU fallback)")
         self.cfg = cfg
         self.action_dim, self.obs_dim, self.goal_dim = int(cfg.action_shape[0]), int(cfg.obs_shape[0]), st["goal_dim"]
         self.solved_meta, self.actor_success, self.training = st["solved_meta"], [], st["training"]
-        self._device = torch.device(cfg.device)
+        self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, self.goal_dim, cfg.z_dim, cfg.hidden_dim,
                           cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None))
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
@@ -531,9 +540,11 @@ class FBHipAgent:
         return meta
 
     def compute_z_correl(self, time_step: tp.Any, meta: MetaDict) -> float:   # fb_ddpg.py:283-289
+        """NB: the reference writes ``F.normalize(z, 1)`` -- the positional 1 is ``p``, so both vectors are scaled by
+        their L1 norm (dim defaults to 1).  Kept as is for result parity."""
         goal = time_step.goal if self.cfg.goal_space is not None else time_step.observation
-        b = torch.nn.functional.normalize(self._backward_map(np.asarray(goal, np.float32)), dim=1)
-        z = torch.nn.functional.normalize(self._dev(meta["z"]), dim=1)
+        b = torch.nn.functional.normalize(self._backward_map(np.asarray(goal, np.float32)), p=1.0, dim=1)
+        z = torch.nn.functional.normalize(self._dev(meta["z"]), p=1.0, dim=1)
         return float((b * z).sum().item())
 
     # ------------------------------------------------------------------ the hot path
@@ -563,6 +574,18 @@ class FBHipAgent:
         self._replay_token = token
 
     def _run_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
+        cur = torch.cuda.current_stream(self._device)
+        if cur.cuda_stream != 0:
+            self._launch_update(hp, inject, use_graph)
+            return
+        # the caller sits on the legacy default stream, where stream capture is not allowed: run on the agent's own
+        # stream, ordered after / before the caller's work with events (no host synchronisation)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            self._launch_update(hp, inject, use_graph)
+        cur.wait_stream(self._stream)
+
+    def _launch_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         import torch.distributed as dist
         lib = _lib.load()
         inj = C.byref(inject) if inject is not None else None

@@ -47,7 +47,7 @@ def ln_tanh_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     """y = tanh(LayerNorm(x)), stats[rows,2] = (mean, rstd)   (fb_modules.py:49-50)."""
     _lib.require_device()
     rows, n = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty((rows, n), device=x.device)
     stats = torch.empty((rows, 2), device=x.device)
     check(_lib.load().fbhip_ln_tanh_fwd(ptr(x), _ld(x), ptr(gamma), ptr(beta), ptr(y), _ld(y), ptr(stats), rows, n,
                                         stream_ptr()))
@@ -57,7 +57,7 @@ def ln_tanh_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
 def ln_tanh_bwd(dy, y, x, stats, gamma, want_param_grads: bool = True):
     _lib.require_device()
     rows, n = x.shape
-    dx = torch.empty_like(x)
+    dx = torch.empty((rows, n), device=x.device)
     dg = torch.empty(n, device=x.device) if want_param_grads else None
     db = torch.empty(n, device=x.device) if want_param_grads else None
     part = torch.empty(((rows + 7) // 8) * 2 * n, device=x.device) if want_param_grads else None
@@ -70,7 +70,7 @@ def l2norm_fwd(y: torch.Tensor):
     """sqrt(d) * F.normalize(y, dim=1) and the row norms."""
     _lib.require_device()
     rows, d = y.shape
-    out = torch.empty_like(y)
+    out = torch.empty((rows, d), device=y.device)
     norms = torch.empty(rows, device=y.device)
     check(_lib.load().fbhip_l2norm_fwd(ptr(y), _ld(y), ptr(out), _ld(out), ptr(norms), rows, d, stream_ptr()))
     return out, norms
@@ -79,7 +79,7 @@ def l2norm_fwd(y: torch.Tensor):
 def l2norm_bwd(dB, y, norms):
     _lib.require_device()
     rows, d = y.shape
-    dy = torch.empty_like(y)
+    dy = torch.empty((rows, d), device=y.device)
     check(_lib.load().fbhip_l2norm_bwd(ptr(dB), _ld(dB), ptr(y), _ld(y), ptr(norms), ptr(dy), _ld(dy), rows, d,
                                        stream_ptr()))
     return dy
@@ -93,7 +93,8 @@ def pairwise_fb(F1, F2, Bm, tF1, tF2, tB, discount, ortho_coef: float):
     for t in (F2, Bm, tF1, tF2, tB):
         assert t.shape == F1.shape and _ld(t) == ld
     lib = _lib.load()
-    dF1, dF2, dB = torch.empty_like(F1), torch.empty_like(F1), torch.empty_like(F1)
+    # outputs share the inputs' leading dimension (one ``ld`` in the C ABI)
+    dF1, dF2, dB = (torch.empty((Bn, ld), device=F1.device)[:, :d] for _ in range(3))
     metrics = torch.zeros(_lib.NUM_METRICS, device=F1.device)
     scratch = torch.empty(lib.fbhip_pairwise_scratch_floats(Bn, d), device=F1.device)
     disc = discount.reshape(-1).contiguous()
@@ -115,7 +116,7 @@ def actor_loss(F1, F2, z, mu, action, stddev: float):
     _lib.require_device()
     rows, d = F1.shape
     a = mu.shape[1]
-    dF1, dF2 = torch.empty_like(F1), torch.empty_like(F1)
+    dF1, dF2 = (torch.empty((rows, _ld(F1)), device=F1.device)[:, :d] for _ in range(2))
     metrics = torch.zeros(_lib.NUM_METRICS, device=F1.device)
     check(_lib.load().fbhip_actor_loss(ptr(F1), ptr(F2), _ld(F1), ptr(z), _ld(z), ptr(mu), _ld(mu), ptr(action),
                                        _ld(action), float(stddev), ptr(dF1), ptr(dF2), ptr(metrics), rows, d, a,

@@ -93,6 +93,13 @@ class TimeStep:
         return getattr(self, attr)
 
 
+def _resolve(device: tp.Union[str, torch.device]) -> torch.device:
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None and torch.cuda.is_available():
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
 def _fields_of(time_step: tp.Any) -> tp.Iterable[tp.Tuple[str, tp.Any]]:
     if dataclasses.is_dataclass(time_step):
         return [(f.name, getattr(time_step, f.name)) for f in dataclasses.fields(time_step)]
@@ -125,7 +132,7 @@ class DeviceReplayBuffer:
         self._episodes_selection_probability = None
         self._is_fixed_episode_length = True
         self._max_episode_length = max_episode_length
-        self._device = torch.device(device)
+        self._device = _resolve(device)
         self._version = 0            # bumped on every mutation; FBHipAgent re-binds device pointers when it changes
         self._dev_cache: tp.Optional[tp.Dict[str, tp.Any]] = None
 
@@ -157,6 +164,7 @@ class DeviceReplayBuffer:
         dev = torch.device(state.get("_device", "cuda"))
         if dev.type == "cuda" and not torch.cuda.is_available():
             dev = torch.device("cpu")
+        dev = _resolve(dev)
         self.__dict__.update(state)
         self._device = dev
         self._storage = {k: torch.as_tensor(np.asarray(v, dtype=np.float32), device=dev) for k, v in state["_storage"].items()}

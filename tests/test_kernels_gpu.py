@@ -200,8 +200,8 @@ def test_adam_ema_matches_torch_optim(K):
         with torch.no_grad():
             ref_t.copy_(0.01 * ref_p + (1 - 0.01) * ref_t)
         K.adam_ema(p, g.cuda(), m, v, tg, lr=3e-4, t=step, tau=0.01)
-        assert (p.cpu() - ref_p.detach()).abs().max() < 2e-7 * step
-        assert (tg.cpu() - ref_t).abs().max() < 2e-7 * step
+        assert (p.cpu() - ref_p.detach()).abs().max() < 3e-7 * step        # <= 2 ulp at |p| ~ 2 per step
+        assert (tg.cpu() - ref_t).abs().max() < 3e-7 * step
     st = opt.state[ref_p]
     assert rel_err(m.cpu(), st["exp_avg"]) < 1e-6 and rel_err(v.cpu(), st["exp_avg_sq"]) < 1e-6
 
