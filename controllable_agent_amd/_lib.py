@@ -59,6 +59,7 @@ PROTOTYPES = {
     "fbhip_bind_buffers": (C.c_int, [_P] + [_P] * 9 + [_P, _Z]),
     "fbhip_replay_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "fbhip_set_seed": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
+    "fbhip_set_parallel": (C.c_int, [_P, _I]),
     "fbhip_set_step_counts": (C.c_int, [_P, _I, _I, _P]),
     "fbhip_get_step_counts": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
@@ -73,7 +74,7 @@ PROTOTYPES = {
     "fbhip_ln_tanh_bwd": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "fbhip_l2norm_fwd": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _P]),
     "fbhip_l2norm_bwd": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
-    "fbhip_actor_loss": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _I, _I, _I, _P]),
+    "fbhip_actor_loss": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fbhip_pairwise_scratch_floats": (_Z, [_I, _I]),
     "fbhip_pairwise_fb": (C.c_int, [_P] * 7 + [_I, _I, _I, _F] + [_P] * 5 + [_P]),
     "fbhip_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P]),

@@ -125,6 +125,7 @@ struct Ws {
     ASet as;
     Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov;
     float* ln_partials = nullptr;
+    float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
     float* pw_scratch = nullptr;
     size_t total_bytes = 0;
 };
@@ -184,6 +185,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.cov = c.buf(z, z);
     const int nmax = H > Hb ? H : Hb;
     w.ln_partials = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
+    w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
     w.total_bytes = (c.cur + 255) & ~(size_t)255;
     return w;
@@ -249,6 +251,15 @@ struct fbhip_ctx {
     ActP A_p, A_g;
     std::vector<GraphEntry> graphs;
     std::string err;
+    // fork/join plumbing: independent passes of one update run on side streams (captured into the same hipGraph as
+    // parallel branches), ordered by events from this pool
+    static constexpr int NSIDE = 3;
+    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> events;
+    int ev_next = 0;
+    // bit0: net-level forks, bit1: weight-gradient stream, bit3: Adam overlap.  bit2 (a side stream forking to another
+    // side stream) is off: nested forks make hipStreamEndCapture fault on ROCm 7.2 -- every fork starts at the origin stream
+    int parallel = 11;
 };
 
 namespace {
@@ -291,8 +302,10 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     }
     int cfg;
     if (kmax <= 64) cfg = (nmax <= 32) ? CFG_4x1x1 : CFG_2x2x1;
-    else if (tiles32 >= 768) cfg = CFG_2x2x1;
-    else if (tiles32 >= 320) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
+    // aim for >= 2 workgroups per CU (>= 512): a lone wave per SIMD cannot hide LDS / L2 latency behind its one
+    // dependent MFMA chain, so medium outputs split K inside the workgroup instead of using bigger tiles
+    else if (tiles32 >= 2048) cfg = CFG_2x2x1;
+    else if (tiles32 >= 1024) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
     else cfg = CFG_1x1x4;
     size_t i = 0;
     while (i < v.size()) {
@@ -308,6 +321,16 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
         g.total_tiles = start;
         HIPCK(ctx, launch_gemm_group(g, cfg, s));
     }
+    return FBHIP_OK;
+}
+
+// order ``to`` after everything enqueued so far on ``from`` (no-op when they are the same stream)
+int sync_streams(fbhip_ctx* c, hipStream_t from, hipStream_t to) {
+    if (from == to) return FBHIP_OK;
+    if (c->events.empty()) { c->err = g_err = "fbhip: event pool not initialised"; return FBHIP_E_STATE; }
+    hipEvent_t e = c->events[c->ev_next++ % c->events.size()];
+    HIPCK(c, hipEventRecord(e, from));
+    HIPCK(c, hipStreamWaitEvent(to, e, 0));
     return FBHIP_OK;
 }
 
@@ -338,19 +361,23 @@ int forward_map_bwd_heads_dgrad(fbhip_ctx* c, const FwdP& W, FSet& S, int rows, 
                          P(w.dF2.p, Lz, 1, W.W4[1], H, 0, w.dp.p + H, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p + H, 2 * H)}, s);
 }
 
-// full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383)
+// full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383).  The data-gradient chain runs on
+// ``s``; each weight gradient only needs the chain's previous stage, so it is issued on ``sw`` and overlaps the chain.
 int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz, int ldz,
-                    FSet& S, int rows, hipStream_t s) {
+                    FSet& S, int rows, hipStream_t s, hipStream_t sw) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
     Ws& w = c->w;
+    RC(sync_streams(c, s, sw));
     RC(run_gemms(c, {P(w.dF1.p, Lz, 0, S.p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]),
-                     P(w.dF2.p, Lz, 0, S.p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1])}, s));
+                     P(w.dF2.p, Lz, 0, S.p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1])}, sw));
     RC(forward_map_bwd_heads_dgrad(c, W, S, rows, s));
-    RC(run_gemms(c, {P(w.dp.p, 2 * H, 0, S.h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s)}, s));
+    RC(sync_streams(c, s, sw));
+    RC(run_gemms(c, {P(w.dp.p, 2 * H, 0, S.h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s)}, sw));
     RC(run_gemms(c, {P(w.dp.p, 2 * H, 1, W.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, rows, 2 * Fd, 2 * H, nullptr, EPI_MASK_RELU, S.h.p, 2 * Fd)}, s));
+    RC(sync_streams(c, s, sw));
     RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 0, S.t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2),
-                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, s));
+                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, sw));
     RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, W.oa.W2, H, 0, w.dt1a.p, H, rows, H, Fd),
                      P(w.dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w.dt1z.p, H, rows, H, Fd)}, s));
     HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, S.t1a.p, H, S.pre1a.p, H, S.statsA, W.oa.g1, w.dt1a.p, H, G.oa.g1, G.oa.be1,
@@ -359,6 +386,7 @@ int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa,
                                 w.ln_partials, rows, H, s));
     RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1),
                      P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
+    RC(sync_streams(c, sw, s));
     return FBHIP_OK;
 }
 
@@ -375,17 +403,20 @@ int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet&
 }
 
 int backward_map_bwd(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S, const float* dy,
-                     int rows, hipStream_t s) {
+                     int rows, hipStream_t s, hipStream_t sw) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad4(Hb), z = d.z_dim, Lz = pad4(z);
     Ws& w = c->w;
-    RC(run_gemms(c, {P(dy, Lz, 0, S.r2.p, Lb, 0, G.W3, Lb, z, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, s));
+    RC(sync_streams(c, s, sw));
+    RC(run_gemms(c, {P(dy, Lz, 0, S.r2.p, Lb, 0, G.W3, Lb, z, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, sw));
     RC(run_gemms(c, {P(dy, Lz, 1, W.W3, Lb, 0, w.b_dr2.p, Lb, rows, Hb, z, nullptr, EPI_MASK_RELU, S.r2.p, Lb)}, s));
-    RC(run_gemms(c, {P(w.b_dr2.p, Lb, 0, S.t1.p, Lb, 0, G.W2, Lb, Hb, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2)}, s));
+    RC(sync_streams(c, s, sw));
+    RC(run_gemms(c, {P(w.b_dr2.p, Lb, 0, S.t1.p, Lb, 0, G.W2, Lb, Hb, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2)}, sw));
     RC(run_gemms(c, {P(w.b_dr2.p, Lb, 1, W.W2, Lb, 0, w.b_dt1.p, Lb, rows, Hb, Hb)}, s));
     HIPCK(c, launch_ln_tanh_bwd(w.b_dt1.p, Lb, S.t1.p, Lb, S.pre1.p, Lb, S.stats, W.g1, w.b_dt1.p, Lb, G.g1, G.be1,
-                                w.ln_partials, rows, Hb, s));
+                                w.ln_partials_b, rows, Hb, s));
     RC(run_gemms(c, {P(w.b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad4(g), Hb, g, rows, nullptr, EPI_NONE, nullptr, 0, G.b1)}, s));
+    RC(sync_streams(c, sw, s));
     return FBHIP_OK;
 }
 
@@ -406,17 +437,20 @@ int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float
 }
 
 int actor_bwd(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S,
-              int rows, hipStream_t s) {
+              int rows, hipStream_t s, hipStream_t sw) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
     Ws& w = c->w;
     const float* dpm = w.a_dpremu.p;
-    RC(run_gemms(c, {P(dpm, La, 0, S.p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4)}, s));
+    RC(sync_streams(c, s, sw));
+    RC(run_gemms(c, {P(dpm, La, 0, S.p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4)}, sw));
     RC(run_gemms(c, {P(dpm, La, 1, W.W4, H, 0, w.a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, S.p.p, H)}, s));
-    RC(run_gemms(c, {P(w.a_dp.p, H, 0, S.h.p, 2 * Fd, 0, G.W3, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, s));
+    RC(sync_streams(c, s, sw));
+    RC(run_gemms(c, {P(w.a_dp.p, H, 0, S.h.p, 2 * Fd, 0, G.W3, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, sw));
     RC(run_gemms(c, {P(w.a_dp.p, H, 1, W.W3, 2 * Fd, 0, w.dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, S.h.p, 2 * Fd)}, s));
+    RC(sync_streams(c, s, sw));
     RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 0, S.t1o.p, H, 0, G.o.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b2),
-                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, s));
+                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, sw));
     RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, W.o.W2, H, 0, w.dt1a.p, H, rows, H, Fd),
                      P(w.dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w.dt1z.p, H, rows, H, Fd)}, s));
     HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, S.t1o.p, H, S.pre1o.p, H, S.statsO, W.o.g1, w.dt1a.p, H, G.o.g1, G.o.be1,
@@ -425,6 +459,7 @@ int actor_bwd(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int l
                                 w.ln_partials, rows, H, s));
     RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1),
                      P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
+    RC(sync_streams(c, sw, s));
     return FBHIP_OK;
 }
 
@@ -469,16 +504,24 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         }
     }
 
+    // side streams (parallel graph branches); with parallel == false everything collapses onto ``s``
+    hipStream_t sA = (c->parallel & 1) ? c->side[0] : s, sB = (c->parallel & 1) ? c->side[1] : s;
+    hipStream_t sW = (c->parallel & 2) ? c->side[2] : s;
+
     if (mask & FBHIP_PHASE_FB_GRAD) {
-        // --- targets, no grad (fb_ddpg.py:303-315)
+        RC(sync_streams(c, s, sA));
+        RC(sync_streams(c, s, sB));
+        // --- [s] targets, no grad (fb_ddpg.py:303-315): actor -> next_action -> forward_target
         RC(actor_fwd(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, s));
         HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_next, a, hp.stddev, hp.stddev_clip, nullptr, 0,
                                       w.Xnoa.p + o, w.Xnoa.ld, B, a, s));
         RC(forward_map_fwd(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, s));
-        RC(backward_map_fwd(c, c->K_t, next_goal, ld_ng, w.bsA, B, s));
-        // --- online F, B (fb_ddpg.py:318-319)
-        RC(forward_map_fwd(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
-        RC(backward_map_fwd(c, c->K_p, next_goal, ld_ng, w.bsO, B, s));
+        // --- [sA] online F (fb_ddpg.py:318);  [sB] target B then online B (:312, :319)
+        RC(forward_map_fwd(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, sA));
+        RC(backward_map_fwd(c, c->K_t, next_goal, ld_ng, w.bsA, B, sB));
+        RC(backward_map_fwd(c, c->K_p, next_goal, ld_ng, w.bsO, B, sB));
+        RC(sync_streams(c, sA, s));
+        RC(sync_streams(c, sB, s));
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
         HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, w.bsO.Bm.p, w.fsT.F1.p, w.fsT.F2.p, w.bsA.Bm.p, w.disc, B, z,
                                     Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
@@ -486,26 +529,34 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             RC(run_gemms(c, {P(w.bsO.Bm.p, Lz, 0, w.bsO.Bm.p, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, w.bsO.Bm.p, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
         }
-        // --- backward (fb_ddpg.py:383)
-        HIPCK(c, launch_l2norm_bwd(w.dBm.p, Lz, w.bsO.y.p, Lz, w.bsO.norms, w.dy.p, Lz, B, z, s));
-        RC(forward_map_bwd(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
-        RC(backward_map_bwd(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, s));
+        // --- backward (fb_ddpg.py:383): forward_net on [s]+[sW], backward_net on [sA]+[sB]
+        RC(sync_streams(c, s, sA));
+        HIPCK(c, launch_l2norm_bwd(w.dBm.p, Lz, w.bsO.y.p, Lz, w.bsO.norms, w.dy.p, Lz, B, z, sA));
+        RC(backward_map_bwd(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, sA, (c->parallel & 4) ? sB : sA));
+        RC(forward_map_bwd(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s, sW));
+        RC(sync_streams(c, sA, s));
+        RC(sync_streams(c, sB, s));     // every forked stream re-joins the origin stream DIRECTLY (hipStreamEndCapture
+                                        // faults on a branch that is only joined transitively through another branch)
     }
 
+    const bool overlap_adam = (mask & FBHIP_PHASE_FB_STEP) && (mask & FBHIP_PHASE_ACTOR_GRAD) && (c->parallel & 8) && sA != s;
     if (mask & FBHIP_PHASE_FB_STEP) {           // fb_opt.step() (:384) + soft_update_params x2 (:500-503)
-        HIPCK(c, launch_step_advance(w.st, 0, s));
+        hipStream_t sa = overlap_adam ? sA : s; // the actor's own forward does not read forward_net: overlap it
+        RC(sync_streams(c, s, sa));
+        HIPCK(c, launch_step_advance(w.st, 0, sa));
         const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
         HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf,
-                                 hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, s));
+                                 hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, sa));
     }
 
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
         RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
         HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
                                       w.Xopi.p + o, w.Xopi.ld, B, a, s));
+        if (overlap_adam) RC(sync_streams(c, sA, s));          // forward_net (updated) is read from here on
         RC(forward_map_fwd(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
         HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + o, w.Xopi.ld, hp.stddev,
-                                   w.dF1.p, w.dF2.p, w.metrics, B, z, a, s));
+                                   w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, a, s));
         // data-gradient only, along the action path of forward_net (the reference also computes and discards
         // every weight gradient of forward_net here)
         RC(forward_map_bwd_heads_dgrad(c, c->F_p, w.fsO, B, s));
@@ -517,7 +568,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
         RC(run_gemms(c, {P(w.dt1a.p, H, 1, c->F_p.oa.W1 + o, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
                            EPI_TANH_BWD, w.as.mu.p, La)}, s));
-        RC(actor_bwd(c, c->A_p, c->A_g, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
+        RC(actor_bwd(c, c->A_p, c->A_g, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s, sW));
     }
 
     if (mask & FBHIP_PHASE_ACTOR_STEP) {        // actor_opt.step(), fb_ddpg.py:411
@@ -599,6 +650,8 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
 int fbhip_destroy(fbhip_ctx* ctx) {
     if (!ctx) return FBHIP_OK;
     for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& e : ctx->events) (void)hipEventDestroy(e);
+    for (int i = 0; i < fbhip_ctx::NSIDE; ++i) if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
     delete ctx;
     return FBHIP_OK;
 }
@@ -627,6 +680,11 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
+    if (c->events.empty()) {
+        for (int i = 0; i < fbhip_ctx::NSIDE; ++i) HIPCK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        c->events.resize(96);
+        for (auto& e : c->events) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     c->bound = true;
     return FBHIP_OK;
 }
@@ -644,6 +702,14 @@ int fbhip_replay_bind(fbhip_ctx* c, const float* observation, const float* actio
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
     c->replay_bound = true;
+    return FBHIP_OK;
+}
+
+int fbhip_set_parallel(fbhip_ctx* c, int32_t enable) {
+    if (!c) return FBHIP_E_INVALID;
+    c->parallel = enable;
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    c->graphs.clear();
     return FBHIP_OK;
 }
 
@@ -684,6 +750,7 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     if (!hp) { c->err = g_err = "fbhip: null hparams"; return FBHIP_E_INVALID; }
     if (hp->q_loss) { c->err = g_err = "fbhip: q_loss=True is not implemented in the HIP path yet"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
+    c->ev_next = 0;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     for (auto& g : c->graphs) {
         if (g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
@@ -886,9 +953,9 @@ int fbhip_adam_ema(float* params, const float* grads, float* m, float* v, float*
 
 int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float* z, int32_t ldz, const float* mu,
                      int32_t ldmu, const float* action, int32_t lda, float stddev, float* dF1, float* dF2, float* metrics,
-                     int32_t rows, int32_t d, int32_t a, void* stream) {
+                     float* scratch, int32_t rows, int32_t d, int32_t a, void* stream) {
     fbhip_ctx* none = nullptr;
-    HIPCK(none, launch_actor_loss(F1, F2, ldf, z, ldz, mu, ldmu, action, lda, stddev, dF1, dF2, metrics, rows, d, a,
+    HIPCK(none, launch_actor_loss(F1, F2, ldf, z, ldz, mu, ldmu, action, lda, stddev, dF1, dF2, metrics, scratch, rows, d, a,
                                   (hipStream_t)stream));
     return FBHIP_OK;
 }

@@ -56,7 +56,8 @@ hipError_t launch_policy_sample(const float* pre, int ldp, const float* noise, i
 // actor loss (fb_ddpg.py:400-406): Q = min(F1.z, F2.z); loss = -mean Q; dF_i = -z/B * w_i
 hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz,
                              const float* mu, int ldmu, const float* action, int lda, float stddev,
-                             float* dF1, float* dF2, float* metrics, int rows, int d, int a, hipStream_t s);
+                             float* dF1, float* dF2, float* metrics, float* scratch /* >= 2*ceil(rows/4) floats */,
+                             int rows, int d, int a, hipStream_t s);
 
 // ---- pairwise FB loss ----------------------------------------------------------------------------------
 size_t pairwise_scratch_floats(int B, int d);

@@ -66,33 +66,13 @@ __device__ __forceinline__ void load_tile(float4 (&v)[Q], const float* __restric
     }
 }
 
-template <int ROWS, int BKT, int Q, int LD>
-__device__ __forceinline__ void store_tile(const float4 (&v)[Q], float* __restrict__ s, int kcontig, int tid) {
-    if (kcontig) {
-        constexpr int QK = BKT / 4;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            const int q = tid + i * 256;
-            const int r = q / QK, kq = q % QK;
-            float* d = s + (4 * kq) * LD + r;
-            d[0] = v[i].x;
-            d[LD] = v[i].y;
-            d[2 * LD] = v[i].z;
-            d[3 * LD] = v[i].w;
-        }
-    } else {
-        constexpr int QR = ROWS / 4;
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            const int q = tid + i * 256;
-            const int k = q / QR, rq = q % QR;
-            float* d = s + k * LD + 4 * rq;
-            d[0] = v[i].x;
-            d[1] = v[i].y;
-            d[2] = v[i].z;
-            d[3] = v[i].w;
-        }
-    }
+// LDS image is [k][row] for both operands.  A K-contiguous source quad (4 consecutive k of one row) is written
+// transposed (stride LD), a K-strided quad (4 consecutive rows of one k) is written contiguously (stride 1).
+__device__ __forceinline__ void store_quad(float* __restrict__ d, int step, const float4& v) {
+    d[0] = v.x;
+    d[step] = v.y;
+    d[2 * step] = v.z;
+    d[3 * step] = v.w;
 }
 
 template <int WM, int WN, int WK, int BK>
@@ -101,6 +81,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
     constexpr int STAGE = BKT * (LDA_S + LDB_S);
     constexpr int QA = BM * BKT / 1024, QB = BN * BKT / 1024;
+    constexpr int NF = BK / 2;                         // MFMA k-steps per chunk
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
     static_assert((BM * BKT) % 1024 == 0 && (BN * BKT) % 1024 == 0, "tile must split into float4 per thread");
     static_assert((WK - 1) * WM * WN * 17 * 64 <= 2 * STAGE, "split-K reduction scratch must fit");
@@ -130,6 +111,46 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     const float* __restrict__ A = p.A;
     const float* __restrict__ Bp = p.B;
     const int row0 = tm * BM, col0 = tn * BN;
+    const int akc = p.a_kcontig, bkc = p.b_kcontig;
+
+    // ---- per-thread staging geometry (fixed for the whole K loop) ---------------------------------------
+    // quad i of this thread: global element offset at chunk 0, LDS float offset, LDS write stride
+    size_t ga[QA], gb[QB];
+    int sa[QA], sb[QB];
+#pragma unroll
+    for (int i = 0; i < QA; ++i) {
+        const int q = tid + i * 256;
+        if (akc) {
+            const int r = q / (BKT / 4), kq = q % (BKT / 4);
+            ga[i] = (size_t)(row0 + r) * p.lda + 4 * kq;
+            sa[i] = (4 * kq) * LDA_S + r;
+        } else {
+            const int k = q / (BM / 4), rq = q % (BM / 4);
+            ga[i] = (size_t)k * p.lda + row0 + 4 * rq;
+            sa[i] = k * LDA_S + 4 * rq;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < QB; ++i) {
+        const int q = tid + i * 256;
+        if (bkc) {
+            const int r = q / (BKT / 4), kq = q % (BKT / 4);
+            gb[i] = (size_t)(col0 + r) * p.ldb + 4 * kq;
+            sb[i] = (4 * kq) * LDB_S + r;
+        } else {
+            const int k = q / (BN / 4), rq = q % (BN / 4);
+            gb[i] = (size_t)k * p.ldb + col0 + 4 * rq;
+            sb[i] = k * LDB_S + 4 * rq;
+        }
+    }
+    const int step_a = akc ? LDA_S : 1, step_b = bkc ? LDB_S : 1;
+    const size_t adv_a = akc ? (size_t)BKT : (size_t)BKT * p.lda;
+    const size_t adv_b = bkc ? (size_t)BKT : (size_t)BKT * p.ldb;
+    // interior tiles of 16-byte-aligned operands take a branch-free loader for every full K chunk; edge tiles,
+    // unaligned views and the K tail go through the predicated loader (same register image)
+    const bool interior = (row0 + BM <= M) && (col0 + BN <= N) && p.a_vec && p.b_vec;
+    const int nt = (K + BKT - 1) / BKT;
+    const int nfast = interior ? K / BKT : 0;
 
     floatx16 acc;
 #pragma unroll
@@ -137,34 +158,55 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     float csum = 0.f;
 
     float4 ra[QA], rb[QB];
-    const int nt = (K + BKT - 1) / BKT;
-    load_tile<BM, BKT, QA>(ra, A, p.lda, p.a_kcontig, p.a_vec, row0, M, 0, K, tid);
-    load_tile<BN, BKT, QB>(rb, Bp, p.ldb, p.b_kcontig, p.b_vec, col0, N, 0, K, tid);
-    store_tile<BM, BKT, QA, LDA_S>(ra, smem, p.a_kcontig, tid);
-    store_tile<BN, BKT, QB, LDB_S>(rb, smem + BKT * LDA_S, p.b_kcontig, tid);
+    if (nfast > 0) {
+#pragma unroll
+        for (int i = 0; i < QA; ++i) ra[i] = *reinterpret_cast<const float4*>(A + ga[i]);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + gb[i]);
+    } else {
+        load_tile<BM, BKT, QA>(ra, A, p.lda, akc, p.a_vec, row0, M, 0, K, tid);
+        load_tile<BN, BKT, QB>(rb, Bp, p.ldb, bkc, p.b_vec, col0, N, 0, K, tid);
+    }
+#pragma unroll
+    for (int i = 0; i < QA; ++i) store_quad(smem + sa[i], step_a, ra[i]);
+#pragma unroll
+    for (int i = 0; i < QB; ++i) store_quad(smem + BKT * LDA_S + sb[i], step_b, rb[i]);
     __syncthreads();
 
+    const int frag_a = (wk * BK + h) * LDA_S + wm * 32 + l31;
+    const int frag_b = BKT * LDA_S + (wk * BK + h) * LDB_S + wn * 32 + l31;
+
     for (int it = 0; it < nt; ++it) {
-        const float* sA = smem + (it & 1) * STAGE;
-        const float* sB = sA + BKT * LDA_S;
+        const float* st = smem + (it & 1) * STAGE;
         const bool more = (it + 1 < nt);
-        if (more) {
-            load_tile<BM, BKT, QA>(ra, A, p.lda, p.a_kcontig, p.a_vec, row0, M, (it + 1) * BKT, K, tid);
-            load_tile<BN, BKT, QB>(rb, Bp, p.ldb, p.b_kcontig, p.b_vec, col0, N, (it + 1) * BKT, K, tid);
-        }
-        const float* a = sA + (wk * BK + h) * LDA_S + wm * 32 + l31;
-        const float* b = sB + (wk * BK + h) * LDB_S + wn * 32 + l31;
+        if (it + 1 < nfast) {
+            const size_t oa = (size_t)(it + 1) * adv_a, ob = (size_t)(it + 1) * adv_b;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float av = a[kk * LDA_S];
-            const float bv = b[kk * LDB_S];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-            csum += av;
+            for (int i = 0; i < QA; ++i) ra[i] = *reinterpret_cast<const float4*>(A + ga[i] + oa);
+#pragma unroll
+            for (int i = 0; i < QB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
+        } else if (more) {
+            load_tile<BM, BKT, QA>(ra, A, p.lda, akc, p.a_vec, row0, M, (it + 1) * BKT, K, tid);
+            load_tile<BN, BKT, QB>(rb, Bp, p.ldb, bkc, p.b_vec, col0, N, (it + 1) * BKT, K, tid);
+        }
+        // fragments for the whole chunk first (LDS latency overlaps the dependent MFMA chain), then the chain
+        float av[NF], bv[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            av[j] = st[frag_a + 2 * j * LDA_S];
+            bv[j] = st[frag_b + 2 * j * LDB_S];
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+            csum += av[j];
         }
         if (more) {
             float* dA = smem + ((it + 1) & 1) * STAGE;
-            store_tile<BM, BKT, QA, LDA_S>(ra, dA, p.a_kcontig, tid);
-            store_tile<BN, BKT, QB, LDB_S>(rb, dA + BKT * LDA_S, p.b_kcontig, tid);
+#pragma unroll
+            for (int i = 0; i < QA; ++i) store_quad(dA + sa[i], step_a, ra[i]);
+#pragma unroll
+            for (int i = 0; i < QB; ++i) store_quad(dA + BKT * LDA_S + sb[i], step_b, rb[i]);
         }
         __syncthreads();
     }

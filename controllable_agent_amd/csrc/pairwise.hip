@@ -264,14 +264,19 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
         dF2[(size_t)r * ld + n] = b;
         dB[(size_t)r * ld + n] = c;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        // wave 0 of workgroup 0: lane k < 10 folds scalar slot k over all workgroups (fixed order, fp64)
-        double s = 0.0;
-        if (threadIdx.x < 10)
-            for (int bk = 0; bk < nblocks; ++bk) s += (double)scal[(size_t)bk * PW_SCAL + threadIdx.x];
-        double tot[10];
+    if (blockIdx.x == 0) {
+        // workgroup 0: wave w folds scalar slots w, w+4, w+8 over all workgroups -- each lane a strided slice in
+        // fp64, then a fixed xor-shuffle tree (deterministic)
+        __shared__ double tot[12];
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        for (int slot = wid; slot < 10; slot += 4) {
+            double s = 0.0;
+            for (int bk = lane; bk < nblocks; bk += 64) s += (double)scal[(size_t)bk * PW_SCAL + slot];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) tot[k] = __shfl(s, k);
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) tot[slot] = s;
+        }
+        __syncthreads();
         if (threadIdx.x == 0 && metrics != nullptr) {
             const double noff = (double)B * (double)(B - 1), bb = (double)B;
             const double fb_off = 0.5 * (tot[0] + tot[4]) / noff;

@@ -188,13 +188,24 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const float* __restric
     }
 }
 
+// out[j] = sum_b partials[b][j], j < 2n.  Workgroup = 8 row-groups x 32 columns: every thread folds nb/8 partial
+// rows (coalesced 128-byte reads), the 8 group sums are combined in a fixed order through LDS.
 __global__ void __launch_bounds__(256) ln_colreduce_kernel(const float* __restrict__ partials, int nb, int n,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= 2 * n) return;
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partials[(size_t)b * 2 * n + j];
-    if (j < n) dgamma[j] = s; else dbeta[j - n] = s;
+    if (j < 2 * n)
+        for (int b = rg; b < nb; b += 8) s += partials[(size_t)b * 2 * n + j];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && j < 2 * n) {
+        float t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][c];
+        if (j < n) dgamma[j] = t; else dbeta[j - n] = t;
+    }
 }
 
 hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx,
@@ -216,7 +227,7 @@ hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy
 #undef LN_BWD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !want) return e;
-    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, s, partials, nb, n, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * n + 31) / 32), dim3(256), 0, s, partials, nb, n, dgamma, dbeta);
     return hipGetLastError();
 }
 
@@ -319,21 +330,20 @@ hipError_t launch_policy_sample(const float* pre, int ldp, const float* noise, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// One workgroup of 16 waves; wave w walks rows w, w+16, ...  Deterministic: per-wave partial sums are folded
-// in wave order by thread 0.  metrics: ACTOR_LOSS, Q, ACTOR_LOGPROB (indices from include/fbhip.h).
-__global__ void __launch_bounds__(1024) actor_loss_kernel(const float* __restrict__ F1, const float* __restrict__ F2,
-                                                          int ldf, const float* __restrict__ z, int ldz,
-                                                          const float* __restrict__ mu, int ldmu,
-                                                          const float* __restrict__ act,
-                                                          int lda, float stddev, float* __restrict__ dF1,
-                                                          float* __restrict__ dF2, float* __restrict__ metrics,
-                                                          int rows, int d, int a, int m_loss, int m_q, int m_lp) {
-    __shared__ double part[16][2];
+// One wavefront per row (4 rows per workgroup); per-workgroup partial sums of (min Q, log-prob) go to ``part`` and
+// a one-wave finalize kernel folds them in a fixed order (deterministic).  metrics: ACTOR_LOSS, Q, ACTOR_LOGPROB.
+__global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict__ F1, const float* __restrict__ F2,
+                                                         int ldf, const float* __restrict__ z, int ldz,
+                                                         const float* __restrict__ mu, int ldmu,
+                                                         const float* __restrict__ act, int lda, float stddev,
+                                                         float* __restrict__ dF1, float* __restrict__ dF2,
+                                                         float* __restrict__ part, int rows, int d, int a) {
+    __shared__ float red[4][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
     const float inv_b = 1.0f / (float)rows;
-    double qs = 0.0, lps = 0.0;
-    const float log_std = logf(stddev), log_s2pi = 0.91893853320467274178f;
-    for (int row = wid; row < rows; row += 16) {
+    float qmin = 0.f, lp = 0.f;
+    if (row < rows) {
         float zz[L2_MAXE], q1 = 0.f, q2 = 0.f;
 #pragma unroll
         for (int i = 0; i < L2_MAXE; ++i) {
@@ -356,20 +366,29 @@ __global__ void __launch_bounds__(1024) actor_loss_kernel(const float* __restric
                 dF2[(size_t)row * ldf + j] = -zz[i] * inv_b * w2;
             }
         }
-        float lp = 0.f;
         if (lane < a) {
             const float df = act[(size_t)row * lda + lane] - mu[(size_t)row * ldmu + lane];
-            lp = -(df * df) / (2.f * stddev * stddev) - log_std - log_s2pi;
+            lp = -(df * df) / (2.f * stddev * stddev) - logf(stddev) - 0.91893853320467274178f;
         }
         lp = wave_sum(lp);
-        qs += (double)fminf(q1, q2);
-        lps += (double)lp;
+        qmin = fminf(q1, q2);
     }
-    if (lane == 0) { part[wid][0] = qs; part[wid][1] = lps; }
+    if (lane == 0) { red[wid][0] = qmin; red[wid][1] = lp; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double q = 0.0, l = 0.0;
-        for (int w = 0; w < 16; ++w) { q += part[w][0]; l += part[w][1]; }
+        part[2 * blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        part[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+__global__ void __launch_bounds__(64) actor_loss_finalize_kernel(const float* __restrict__ part, int nblk, int rows,
+                                                                 float* __restrict__ metrics, int m_loss, int m_q,
+                                                                 int m_lp) {
+    double q = 0.0, l = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) { q += (double)part[2 * b]; l += (double)part[2 * b + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o); l += __shfl_xor(l, o); }
+    if (threadIdx.x == 0) {
         metrics[m_loss] = (float)(-q / rows);
         metrics[m_q] = (float)(q / rows);
         metrics[m_lp] = (float)(l / rows);
@@ -378,10 +397,14 @@ __global__ void __launch_bounds__(1024) actor_loss_kernel(const float* __restric
 
 hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz, const float* mu,
                              int ldmu, const float* action, int lda, float stddev, float* dF1, float* dF2,
-                             float* metrics, int rows, int d, int a, hipStream_t s) {
-    if (d > 64 * L2_MAXE || a > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(1024), 0, s, F1, F2, ldf, z, ldz, mu, ldmu, action, lda,
-                       stddev, dF1, dF2, metrics, rows, d, a, 15, 16, 17);
+                             float* metrics, float* scratch, int rows, int d, int a, hipStream_t s) {
+    if (d > 64 * L2_MAXE || a > 64 || scratch == nullptr) return hipErrorInvalidValue;
+    const int nblk = (rows + 3) / 4;
+    hipLaunchKernelGGL(actor_loss_kernel, dim3(nblk), dim3(256), 0, s, F1, F2, ldf, z, ldz, mu, ldmu, action, lda,
+                       stddev, dF1, dF2, scratch, rows, d, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17);
     return hipGetLastError();
 }
 

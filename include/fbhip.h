@@ -141,6 +141,9 @@ int fbhip_replay_bind(fbhip_ctx* ctx, const float* observation, const float* act
                       const float* goal, const int32_t* episode_len, const int64_t* cum_len,
                       int32_t n_episodes, int32_t t1, int32_t fixed_length);
 int fbhip_set_seed(fbhip_ctx* ctx, uint64_t seed, uint32_t rank);
+/* enable != 0 (default): independent passes of one update (target vs online nets, weight- vs data-gradient chains)
+ * run on internal side streams / parallel hipGraph branches; 0 serialises everything on the caller's stream. */
+int fbhip_set_parallel(fbhip_ctx* ctx, int32_t enable);
 int fbhip_set_step_counts(fbhip_ctx* ctx, int32_t fb_steps, int32_t actor_steps, void* stream); /* Adam t */
 int fbhip_get_step_counts(fbhip_ctx* ctx, int32_t* host_fb_steps, int32_t* host_actor_steps, void* stream);
 
@@ -194,10 +197,10 @@ int fbhip_l2norm_fwd(const float* y, int32_t ldy, float* out, int32_t ldo, float
 int fbhip_l2norm_bwd(const float* dB, int32_t lddb, const float* y, int32_t ldy, const float* norms, float* dy,
                      int32_t lddy, int32_t rows, int32_t d, void* stream);
 /* Actor loss (fb_ddpg.py:399-406): Q = min(F1.z, F2.z) row dots, loss = -mean Q, dF_i = -z/B on the arg-min
- * (1/2 each on exact ties); writes ACTOR_LOSS, Q, ACTOR_LOGPROB into metrics. */
+ * (1/2 each on exact ties); writes ACTOR_LOSS, Q, ACTOR_LOGPROB into metrics.  scratch: >= 2*ceil(rows/4) floats. */
 int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float* z, int32_t ldz, const float* mu,
                      int32_t ldmu, const float* action, int32_t lda, float stddev, float* dF1, float* dF2, float* metrics,
-                     int32_t rows, int32_t d, int32_t a, void* stream);
+                     float* scratch, int32_t rows, int32_t d, int32_t a, void* stream);
 /* Pairwise FB + orthonormality loss and its gradients (fb_ddpg.py:313-348).
  * All inputs [B,d] with leading dim ld; discount [B].  Outputs dF1,dF2,dB [B,d] (ld), scalars -> metrics
  * (device float[FBHIP_NUM_METRICS]; writes TARGET_M, M1, FB_LOSS, FB_DIAG, FB_OFFDIAG, ORTH_*).
