@@ -304,8 +304,8 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     if (kmax <= 64) cfg = (nmax <= 32) ? CFG_4x1x1 : CFG_2x2x1;
     // aim for >= 2 workgroups per CU (>= 512): a lone wave per SIMD cannot hide LDS / L2 latency behind its one
     // dependent MFMA chain, so medium outputs split K inside the workgroup instead of using bigger tiles
-    else if (tiles32 >= 2048) cfg = CFG_2x2x1;
-    else if (tiles32 >= 1024) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
+    else if (tiles32 >= 1024) cfg = CFG_2x2x1;
+    else if (tiles32 >= 512) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
     else cfg = CFG_1x1x4;
     size_t i = 0;
     while (i < v.size()) {

@@ -16,6 +16,8 @@
 // loads of step t+1 are issued before the MFMAs of step t.
 #include "common.h"
 
+#include <type_traits>
+
 namespace fbhip {
 
 template <int ROWS, int BKT, int Q>
@@ -157,39 +159,38 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float csum = 0.f;
 
-    float4 ra[QA], rb[QB];
-    if (nfast > 0) {
-#pragma unroll
-        for (int i = 0; i < QA; ++i) ra[i] = *reinterpret_cast<const float4*>(A + ga[i]);
-#pragma unroll
-        for (int i = 0; i < QB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + gb[i]);
-    } else {
-        load_tile<BM, BKT, QA>(ra, A, p.lda, akc, p.a_vec, row0, M, 0, K, tid);
-        load_tile<BN, BKT, QB>(rb, Bp, p.ldb, bkc, p.b_vec, col0, N, 0, K, tid);
-    }
-#pragma unroll
-    for (int i = 0; i < QA; ++i) store_quad(smem + sa[i], step_a, ra[i]);
-#pragma unroll
-    for (int i = 0; i < QB; ++i) store_quad(smem + BKT * LDA_S + sb[i], step_b, rb[i]);
-    __syncthreads();
-
     const int frag_a = (wk * BK + h) * LDA_S + wm * 32 + l31;
     const int frag_b = BKT * LDA_S + (wk * BK + h) * LDB_S + wn * 32 + l31;
 
-    for (int it = 0; it < nt; ++it) {
-        const float* st = smem + (it & 1) * STAGE;
-        const bool more = (it + 1 < nt);
-        if (it + 1 < nfast) {
-            const size_t oa = (size_t)(it + 1) * adv_a, ob = (size_t)(it + 1) * adv_b;
+    // global -> register loader for chunk ``ch`` (branch-free for interior tiles, predicated otherwise)
+    auto load_chunk = [&](int ch, float4 (&xa)[QA], float4 (&xb)[QB]) __attribute__((always_inline)) {
+        if (ch < nfast) {
+            const size_t oa = (size_t)ch * adv_a, ob = (size_t)ch * adv_b;
 #pragma unroll
-            for (int i = 0; i < QA; ++i) ra[i] = *reinterpret_cast<const float4*>(A + ga[i] + oa);
+            for (int i = 0; i < QA; ++i) xa[i] = *reinterpret_cast<const float4*>(A + ga[i] + oa);
 #pragma unroll
-            for (int i = 0; i < QB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
-        } else if (more) {
-            load_tile<BM, BKT, QA>(ra, A, p.lda, akc, p.a_vec, row0, M, (it + 1) * BKT, K, tid);
-            load_tile<BN, BKT, QB>(rb, Bp, p.ldb, bkc, p.b_vec, col0, N, (it + 1) * BKT, K, tid);
+            for (int i = 0; i < QB; ++i) xb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
+        } else {
+            load_tile<BM, BKT, QA>(xa, A, p.lda, akc, p.a_vec, row0, M, ch * BKT, K, tid);
+            load_tile<BN, BKT, QB>(xb, Bp, p.ldb, bkc, p.b_vec, col0, N, ch * BKT, K, tid);
         }
-        // fragments for the whole chunk first (LDS latency overlaps the dependent MFMA chain), then the chain
+    };
+    auto store_chunk = [&](int stage, const float4 (&xa)[QA], const float4 (&xb)[QB]) __attribute__((always_inline)) {
+        float* dA = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < QA; ++i) store_quad(dA + sa[i], step_a, xa[i]);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) store_quad(dA + BKT * LDA_S + sb[i], step_b, xb[i]);
+    };
+    auto load_fast = [&](int ch, float4 (&xa)[QA], float4 (&xb)[QB]) __attribute__((always_inline)) {
+        const size_t oa = (size_t)ch * adv_a, ob = (size_t)ch * adv_b;
+#pragma unroll
+        for (int i = 0; i < QA; ++i) xa[i] = *reinterpret_cast<const float4*>(A + ga[i] + oa);
+#pragma unroll
+        for (int i = 0; i < QB; ++i) xb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
+    };
+    auto mfma_chunk = [&](int it) __attribute__((always_inline)) {
+        const float* st = smem + (it & 1) * STAGE;
         float av[NF], bv[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
@@ -201,14 +202,73 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
             csum += av[j];
         }
-        if (more) {
-            float* dA = smem + ((it + 1) & 1) * STAGE;
+        // Pin the issue order of this block: fragment reads run ahead of the MFMA pair that consumes them, so each
+        // s_waitcnt only covers reads issued >= 128 MFMA-cycles earlier (left alone, hipcc issues every ds_read2 right
+        // before its MFMA pair and exposes the full LDS latency on the dependent chain).
+        // (ds_read_b32 pairs are merged into ds_read2_b32: NF DS instructions per chunk.)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);              // DS reads for MFMA pairs 0, 1
 #pragma unroll
-            for (int i = 0; i < QA; ++i) store_quad(dA + sa[i], step_a, ra[i]);
-#pragma unroll
-            for (int i = 0; i < QB; ++i) store_quad(dA + BKT * LDA_S + sb[i], step_b, rb[i]);
+        for (int j = 0; j < NF / 2 - 2; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // MFMA pair j
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // DS reads for pair j + 2
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);              // last two MFMA pairs
+    };
+    // One K step: chunk ``it`` is in LDS stage it&1, chunk it+1 is in flight in (sa_, sb_), chunk it+2 is requested
+    // into (la_, lb_) -- prefetch distance 2, so the L2 / Infinity-Cache round trip spans two MFMA chains.  LOAD/STORE
+    // are compile-time so the steady-state loop is straight-line code and hipcc can emit a COUNTED s_waitcnt vmcnt(n)
+    // that leaves the newest chunk in flight (with run-time branches it falls back to vmcnt(0)).
+    auto k_step = [&](int it, auto do_load, auto do_store, float4 (&la_)[QA], float4 (&lb_)[QB],
+                      const float4 (&sa_)[QA], const float4 (&sb_)[QB]) __attribute__((always_inline)) {
+        if constexpr (decltype(do_load)::value) load_fast(it + 2, la_, lb_);
+        mfma_chunk(it);
+        if constexpr (decltype(do_store)::value) store_chunk((it + 1) & 1, sa_, sb_);
         __syncthreads();
+    };
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+
+    float4 ra0[QA], rb0[QB], ra1[QA], rb1[QB];
+    if (nfast == nt) {
+        // ---- every chunk is interior + aligned: branch-free pipeline
+        load_fast(0, ra0, rb0);
+        if (nt > 1) load_fast(1, ra1, rb1);
+        else {
+#pragma unroll
+            for (int i = 0; i < QA; ++i) ra1[i] = ra0[i];
+#pragma unroll
+            for (int i = 0; i < QB; ++i) rb1[i] = rb0[i];
+        }
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+        int it = 0;
+        for (; it + 3 < nt; it += 2) {
+            k_step(it, T, T, ra0, rb0, ra1, rb1);
+            k_step(it + 1, T, T, ra1, rb1, ra0, rb0);
+        }
+        const int rem = nt - it;                                    // 1, 2 or 3 steps left
+        if (rem == 3) {
+            k_step(it, T, T, ra0, rb0, ra1, rb1);
+            k_step(it + 1, F, T, ra1, rb1, ra0, rb0);
+            k_step(it + 2, F, F, ra0, rb0, ra1, rb1);
+        } else if (rem == 2) {
+            k_step(it, F, T, ra0, rb0, ra1, rb1);
+            k_step(it + 1, F, F, ra1, rb1, ra0, rb0);
+        } else {
+            k_step(it, F, F, ra0, rb0, ra1, rb1);
+        }
+    } else {
+        // ---- edge tiles / unaligned operands / K tail: predicated loader, prefetch distance 1
+        load_chunk(0, ra0, rb0);
+        store_chunk(0, ra0, rb0);
+        __syncthreads();
+        for (int it = 0; it < nt; ++it) {
+            const bool more = it + 1 < nt;
+            if (more) load_chunk(it + 1, ra0, rb0);
+            mfma_chunk(it);
+            if (more) store_chunk((it + 1) & 1, ra0, rb0);
+            __syncthreads();
+        }
     }
 
     if constexpr (WK > 1) {
