@@ -126,6 +126,7 @@ struct Ws {
     Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov;
     float* ln_partials = nullptr;
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
+    float* splitk = nullptr;            // split-K partial slabs, one per stream slot
     float* pw_scratch = nullptr;
     size_t total_bytes = 0;
 };
@@ -187,6 +188,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.ln_partials = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
+    w.splitk = c.f((size_t)(1 + 3) * ((size_t)6 << 20));
     w.total_bytes = (c.cur + 255) & ~(size_t)255;
     return w;
 }
@@ -293,6 +295,17 @@ GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc
     return p;
 }
 
+// scratch for split-K partials: one slab per stream slot (0 = caller's stream, 1.. = side streams), so concurrent
+// branches never share it; standalone fbhip_gemm (ctx == nullptr) never splits
+constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB per slot
+
+float* splitk_slab(fbhip_ctx* c, hipStream_t s) {
+    if (!c || !c->w.splitk) return nullptr;
+    int slot = 0;
+    for (int i = 0; i < fbhip_ctx::NSIDE; ++i) if (s == c->side[i]) slot = i + 1;
+    return c->w.splitk + (size_t)slot * SPLITK_SLAB_FLOATS;
+}
+
 int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     long tiles32 = 0;
     int kmax = 0, nmax = 0, mmax = 0;
@@ -304,22 +317,49 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     if (kmax <= 64) cfg = (nmax <= 32) ? CFG_4x1x1 : CFG_2x2x1;
     // aim for >= 2 workgroups per CU (>= 512): a lone wave per SIMD cannot hide LDS / L2 latency behind its one
     // dependent MFMA chain, so medium outputs split K inside the workgroup instead of using bigger tiles
-    else if (tiles32 >= 1024) cfg = CFG_2x2x1;
-    else if (tiles32 >= 512) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
+    else if (tiles32 >= 2048) cfg = CFG_2x2x1;
+    else if (tiles32 >= 1024) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
     else cfg = CFG_1x1x4;
+    const int bkt = gemm_cfg_bkt(cfg);
+    float* slab = splitk_slab(ctx, s);
     size_t i = 0;
     while (i < v.size()) {
         GemmGroup g{};
-        int start = 0;
+        int start = 0, red = 0;
+        size_t slab_used = 0;
+        // workgroups of this launch without K slicing
+        long base_blocks = 0;
+        for (size_t j = i; j < v.size() && j < i + MAX_GROUP; ++j) {
+            GemmProblem q = v[j];
+            q.kslices = 1;
+            gemm_problem_finalize(q, cfg);
+            base_blocks += (long)q.tiles_m * q.tiles_n;
+        }
         while (i < v.size() && g.n < MAX_GROUP) {
             GemmProblem p = v[i++];
+            p.kslices = 1;
             gemm_problem_finalize(p, cfg);
+            const int kchunks = (p.K + bkt - 1) / bkt;
+            // small outputs: slice K across workgroups until the launch has ~3 workgroups per CU
+            if (slab && base_blocks <= 160 && kchunks >= 4) {
+                int want = (int)((640 + base_blocks - 1) / base_blocks);
+                if (want > kchunks / 2) want = kchunks / 2;
+                const int kper = (kchunks + want - 1) / want;
+                const int ks = (kchunks + kper - 1) / kper;
+                const size_t need = (size_t)ks * p.M * p.N + (size_t)ks * p.M;
+                if (ks > 1 && slab_used + need <= SPLITK_SLAB_FLOATS) {
+                    p.kslices = ks; p.kper = kper; p.partial = slab + slab_used; p.red_start = red;
+                    slab_used += (need + 3) & ~(size_t)3;
+                    red += p.M * p.N + p.M;
+                }
+            }
             p.tile_start = start;
-            start += p.tiles_m * p.tiles_n;
+            start += p.tiles_m * p.tiles_n * p.kslices;
             g.p[g.n++] = p;
         }
         g.total_tiles = start;
         HIPCK(ctx, launch_gemm_group(g, cfg, s));
+        if (red > 0) HIPCK(ctx, launch_splitk_reduce(g, red, s));
     }
     return FBHIP_OK;
 }
@@ -508,6 +548,9 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     hipStream_t sA = (c->parallel & 1) ? c->side[0] : s, sB = (c->parallel & 1) ? c->side[1] : s;
     hipStream_t sW = (c->parallel & 2) ? c->side[2] : s;
 
+    // single-call updates can start the actor's own forward pass early (see below)
+    const bool early_actor = (mask & FBHIP_PHASE_FB_GRAD) && (mask & FBHIP_PHASE_ACTOR_GRAD) && sB != s;
+
     if (mask & FBHIP_PHASE_FB_GRAD) {
         RC(sync_streams(c, s, sA));
         RC(sync_streams(c, s, sB));
@@ -529,10 +572,21 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             RC(run_gemms(c, {P(w.bsO.Bm.p, Lz, 0, w.bsO.Bm.p, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, w.bsO.Bm.p, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
         }
-        // --- backward (fb_ddpg.py:383): forward_net on [s]+[sW], backward_net on [sA]+[sB]
+        // --- backward (fb_ddpg.py:383): forward_net on [s]+[sW], backward_net on [sA]
         RC(sync_streams(c, s, sA));
+        RC(sync_streams(c, s, sB));
         HIPCK(c, launch_l2norm_bwd(w.dBm.p, Lz, w.bsO.y.p, Lz, w.bsO.norms, w.dy.p, Lz, B, z, sA));
         RC(backward_map_bwd(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, sA, (c->parallel & 4) ? sB : sA));
+        if (early_actor) {
+            // [sB] the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights
+            // and (obs, z): it runs here, under the FB backward, instead of after fb_opt.step()
+            RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, sB));
+            HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
+                                          w.Xopi.p + o, w.Xopi.ld, B, a, sB));
+        }
+        // Adam step counts / bias corrections for the optimiser steps of this call, off the critical path
+        if (mask & FBHIP_PHASE_FB_STEP) HIPCK(c, launch_step_advance(w.st, 0, sB));
+        if (early_actor && (mask & FBHIP_PHASE_ACTOR_STEP)) HIPCK(c, launch_step_advance(w.st, 1, sB));
         RC(forward_map_bwd(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s, sW));
         RC(sync_streams(c, sA, s));
         RC(sync_streams(c, sB, s));     // every forked stream re-joins the origin stream DIRECTLY (hipStreamEndCapture
@@ -543,17 +597,20 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     if (mask & FBHIP_PHASE_FB_STEP) {           // fb_opt.step() (:384) + soft_update_params x2 (:500-503)
         hipStream_t sa = overlap_adam ? sA : s; // the actor's own forward does not read forward_net: overlap it
         RC(sync_streams(c, s, sa));
-        HIPCK(c, launch_step_advance(w.st, 0, sa));
+        if (!(mask & FBHIP_PHASE_FB_GRAD)) HIPCK(c, launch_step_advance(w.st, 0, sa));
         const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
         HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf,
                                  hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, sa));
     }
 
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
-        RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
-        HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
-                                      w.Xopi.p + o, w.Xopi.ld, B, a, s));
+        if (!early_actor) {
+            RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
+            HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
+                                          w.Xopi.p + o, w.Xopi.ld, B, a, s));
+        }
         if (overlap_adam) RC(sync_streams(c, sA, s));          // forward_net (updated) is read from here on
+        if ((mask & FBHIP_PHASE_ACTOR_STEP) && !early_actor) HIPCK(c, launch_step_advance(w.st, 1, s));
         RC(forward_map_fwd(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
         HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + o, w.Xopi.ld, hp.stddev,
                                    w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, a, s));
@@ -572,7 +629,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     }
 
     if (mask & FBHIP_PHASE_ACTOR_STEP) {        // actor_opt.step(), fb_ddpg.py:411
-        HIPCK(c, launch_step_advance(w.st, 1, s));
+        if (!(mask & FBHIP_PHASE_ACTOR_GRAD)) HIPCK(c, launch_step_advance(w.st, 1, s));
         const int64_t na = c->L[FBHIP_NET_ACTOR].numel;
         HIPCK(c, launch_adam_ema(c->a_p, c->a_g, c->a_m, c->a_v, nullptr, na, hp.lr, hp.lr, na, hp.grad_scale, 0.f, w.st,
                                  1, 0, s));

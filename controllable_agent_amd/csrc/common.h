@@ -25,6 +25,12 @@ struct GemmProblem {
     int a_vec, b_vec;        // 16-byte aligned base + ld % 4 == 0 -> float4 global loads
     int epi;
     int tiles_m, tiles_n, tile_start;
+    // grid-level split-K (small outputs): slice s handles K chunks [s*kper, (s+1)*kper) and writes raw partial
+    // tiles to partial[s][M][N] (+ partial column sums after them); splitk_reduce folds them in slice order and
+    // applies the epilogue -- deterministic, no atomics.
+    int kslices, kper;       // kper in units of the config's K chunk
+    float* partial;
+    int red_start;           // first element of this problem in the reduce launch
 };
 
 constexpr int MAX_GROUP = 8;
@@ -38,6 +44,8 @@ struct GemmGroup {
 enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4x1x1 = 4, CFG_COUNT };
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
+hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream);
+int gemm_cfg_bkt(int cfg);     // K extent of one chunk of a tile configuration
 int pick_gemm_cfg(int M, int N, int K);
 void gemm_problem_finalize(GemmProblem& p, int cfg);   // fills a_vec/b_vec/tiles_*
 

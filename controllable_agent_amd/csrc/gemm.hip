@@ -101,8 +101,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
         if (i < g.n && lid >= g.p[i].tile_start) pi = i;
     const GemmProblem& p = g.p[pi];
     const int t = lid - p.tile_start;
-    const int tn = t % p.tiles_n, tm = t / p.tiles_n;
-    const int M = p.M, N = p.N, K = p.K;
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int slice = t / tiles_mn, tt = t % tiles_mn;        // slice-major: neighbours share operand panels
+    const int tn = tt % p.tiles_n, tm = tt / p.tiles_n;
+    const int M = p.M, N = p.N;
+    const int kb = slice * p.kper * BKT;                       // this workgroup's K range [kb, K)
+    const int K = min(p.K, kb + p.kper * BKT);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -124,11 +128,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
         const int q = tid + i * 256;
         if (akc) {
             const int r = q / (BKT / 4), kq = q % (BKT / 4);
-            ga[i] = (size_t)(row0 + r) * p.lda + 4 * kq;
+            ga[i] = (size_t)(row0 + r) * p.lda + kb + 4 * kq;
             sa[i] = (4 * kq) * LDA_S + r;
         } else {
             const int k = q / (BM / 4), rq = q % (BM / 4);
-            ga[i] = (size_t)k * p.lda + row0 + 4 * rq;
+            ga[i] = (size_t)(kb + k) * p.lda + row0 + 4 * rq;
             sa[i] = k * LDA_S + 4 * rq;
         }
     }
@@ -137,11 +141,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
         const int q = tid + i * 256;
         if (bkc) {
             const int r = q / (BKT / 4), kq = q % (BKT / 4);
-            gb[i] = (size_t)(col0 + r) * p.ldb + 4 * kq;
+            gb[i] = (size_t)(col0 + r) * p.ldb + kb + 4 * kq;
             sb[i] = (4 * kq) * LDB_S + r;
         } else {
             const int k = q / (BN / 4), rq = q % (BN / 4);
-            gb[i] = (size_t)k * p.ldb + col0 + 4 * rq;
+            gb[i] = (size_t)(kb + k) * p.ldb + col0 + 4 * rq;
             sb[i] = k * LDB_S + 4 * rq;
         }
     }
@@ -151,8 +155,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     // interior tiles of 16-byte-aligned operands take a branch-free loader for every full K chunk; edge tiles,
     // unaligned views and the K tail go through the predicated loader (same register image)
     const bool interior = (row0 + BM <= M) && (col0 + BN <= N) && p.a_vec && p.b_vec;
-    const int nt = (K + BKT - 1) / BKT;
-    const int nfast = interior ? K / BKT : 0;
+    const int nt = (K - kb + BKT - 1) / BKT;                  // chunks of this slice
+    const int nfast = interior ? (K - kb) / BKT : 0;          // ... of which the leading nfast need no predication
 
     floatx16 acc;
 #pragma unroll
@@ -171,8 +175,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
 #pragma unroll
             for (int i = 0; i < QB; ++i) xb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
         } else {
-            load_tile<BM, BKT, QA>(xa, A, p.lda, akc, p.a_vec, row0, M, ch * BKT, K, tid);
-            load_tile<BN, BKT, QB>(xb, Bp, p.ldb, bkc, p.b_vec, col0, N, ch * BKT, K, tid);
+            load_tile<BM, BKT, QA>(xa, A, p.lda, akc, p.a_vec, row0, M, kb + ch * BKT, K, tid);
+            load_tile<BN, BKT, QB>(xb, Bp, p.ldb, bkc, p.b_vec, col0, N, kb + ch * BKT, K, tid);
         }
     };
     auto store_chunk = [&](int stage, const float4 (&xa)[QA], const float4 (&xb)[QB]) __attribute__((always_inline)) {
@@ -229,10 +233,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     constexpr std::false_type F{};
 
     float4 ra0[QA], rb0[QB], ra1[QA], rb1[QB];
-    if (nfast == nt) {
-        // ---- every chunk is interior + aligned: branch-free pipeline
+    if (nfast > 0) {
+        // ---- leading chunks are interior + aligned: branch-free pipeline
+        const int nf = nfast;
         load_fast(0, ra0, rb0);
-        if (nt > 1) load_fast(1, ra1, rb1);
+        if (nf > 1) load_fast(1, ra1, rb1);
         else {
 #pragma unroll
             for (int i = 0; i < QA; ++i) ra1[i] = ra0[i];
@@ -242,11 +247,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
         store_chunk(0, ra0, rb0);
         __syncthreads();
         int it = 0;
-        for (; it + 3 < nt; it += 2) {
+        for (; it + 3 < nf; it += 2) {
             k_step(it, T, T, ra0, rb0, ra1, rb1);
             k_step(it + 1, T, T, ra1, rb1, ra0, rb0);
         }
-        const int rem = nt - it;                                    // 1, 2 or 3 steps left
+        const int rem = nf - it;                                    // 1, 2 or 3 steps left
         if (rem == 3) {
             k_step(it, T, T, ra0, rb0, ra1, rb1);
             k_step(it + 1, F, T, ra1, rb1, ra0, rb0);
@@ -257,8 +262,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
         } else {
             k_step(it, F, F, ra0, rb0, ra1, rb1);
         }
+        if (nt > nf) {                                              // ragged K tail (K % chunk != 0): predicated
+            load_chunk(nf, ra0, rb0);
+            store_chunk(nf & 1, ra0, rb0);
+            __syncthreads();
+            mfma_chunk(nf);
+            __syncthreads();
+        }
     } else {
-        // ---- edge tiles / unaligned operands / K tail: predicated loader, prefetch distance 1
+        // ---- edge tiles / unaligned operands: predicated loader, prefetch distance 1
         load_chunk(0, ra0, rb0);
         store_chunk(0, ra0, rb0);
         __syncthreads();
@@ -289,6 +301,24 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
             for (int i = 0; i < 16; ++i) acc[i] += srcp[i * 64];
             csum += srcp[16 * 64];
         }
+    }
+
+    if (p.kslices > 1) {
+        // raw partial tile (+ partial column sums behind the tiles); splitk_reduce_kernel applies the epilogue
+        float* part = p.partial + (size_t)slice * M * N;
+        if (p.colsum != nullptr && tn == 0 && wn == 0) {
+            const float tot = csum + __shfl_xor(csum, 32);
+            const int r = row0 + wm * 32 + l31;
+            if (h == 0 && r < M) p.partial[(size_t)p.kslices * M * N + (size_t)slice * M + r] = tot;
+        }
+        const int col = col0 + wn * 32 + l31;
+        if (col >= N) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < M) part[(size_t)row * N + col] = acc[r];
+        }
+        return;
     }
 
     if (p.colsum != nullptr && tn == 0 && wn == 0) {
@@ -322,10 +352,57 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     }
 }
 
+// C = epi(sum_slices partial[s]) for every split-K problem of a group; one thread per output element (+ the column
+// sums appended behind the M*N elements of each problem)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    int pi = -1;
+#pragma unroll
+    for (int i = 0; i < MAX_GROUP; ++i)
+        if (i < g.n && g.p[i].kslices > 1 && e >= g.p[i].red_start) pi = i;
+    if (pi < 0) return;
+    const GemmProblem& p = g.p[pi];
+    const int M = p.M, N = p.N, ks = p.kslices;
+    int idx = e - p.red_start;
+    const int mn = M * N;
+    if (idx < mn) {
+        const int row = idx / N, col = idx % N;
+        float v = 0.f;
+        for (int s = 0; s < ks; ++s) v += p.partial[(size_t)s * mn + idx];
+        const int epi = p.epi;
+        if (epi == EPI_BIAS) {
+            v += p.bias[col];
+        } else if (epi == EPI_BIAS_RELU) {
+            v = fmaxf(v + p.bias[col], 0.f);
+        } else if (epi == EPI_MASK_RELU) {
+            v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
+        } else if (epi == EPI_TANH_BWD) {
+            const float y = p.aux[(size_t)row * p.ldaux + col];
+            v = v * (1.f - y * y);
+        }
+        p.C[(size_t)row * p.ldc + col] = v;
+    } else if (p.colsum != nullptr && idx < mn + M) {
+        const int r = idx - mn;
+        float v = 0.f;
+        for (int s = 0; s < ks; ++s) v += p.partial[(size_t)ks * mn + (size_t)s * M + r];
+        p.colsum[r] = v;
+    }
+}
+
+hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream) {
+    if (total_elems <= 0) return hipSuccess;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total_elems + 255) / 256), dim3(256), 0, stream, g);
+    return hipGetLastError();
+}
+
 static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4};
 static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1};
 
+int gemm_cfg_bkt(int cfg) { return cfg == CFG_2x2x1 || cfg == CFG_4x1x1 ? 32 : 64; }
+
 void gemm_problem_finalize(GemmProblem& p, int cfg) {
+    if (p.kslices < 1) { p.kslices = 1; }
+    if (p.kslices == 1) p.kper = (p.K + gemm_cfg_bkt(cfg) - 1) / gemm_cfg_bkt(cfg);
     const int BM = 32 * kCfgWM[cfg], BN = 32 * kCfgWN[cfg];
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;

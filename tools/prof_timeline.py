@@ -1,0 +1,17 @@
+"""Print the kernel timeline of ONE update step (the last complete graph replay) from a rocprofv3 rocpd database."""
+import sqlite3, sys
+db = sys.argv[1]
+con = sqlite3.connect(db)
+rows = con.execute("select name, start, end, stream_id, queue_id from kernels order by start").fetchall()
+# a step starts at every step_advance_kernel that follows an adam kernel (which=2 is first kernel of a step)
+starts = [i for i, r in enumerate(rows) if "step_advance" in r[0] and i > 0 and "adam_ema" in rows[i - 1][0]]
+if len(starts) < 3:
+    print("no step boundary found"); sys.exit(0)
+a, b = starts[-2], starts[-1]
+t0 = rows[a][1]
+print(f"step of {b - a} kernels, span {(rows[b - 1][2] - t0) / 1e3:.1f} us")
+busy = 0
+for r in rows[a:b]:
+    n = r[0].replace("fbhip::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    n = n.split("(")[0][:40]
+    print(f"{(r[1] - t0) / 1e3:9.1f} {(r[2] - r[1]) / 1e3:8.1f}  q{r[4]}  {n}")
