@@ -737,6 +737,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
+    HIPCK(c, gemm_init());
     if (c->events.empty()) {
         for (int i = 0; i < fbhip_ctx::NSIDE; ++i) HIPCK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         c->events.resize(96);
@@ -940,6 +941,7 @@ int fbhip_gemm(const float* A, int32_t lda, int32_t a_kcontig, const float* B, i
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || epi < 0 || epi > 4) { g_err = "fbhip_gemm: bad argument"; return FBHIP_E_INVALID; }
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias) { g_err = "fbhip_gemm: bias required"; return FBHIP_E_INVALID; }
     if ((epi == EPI_MASK_RELU || epi == EPI_TANH_BWD) && !aux) { g_err = "fbhip_gemm: aux required"; return FBHIP_E_INVALID; }
+    { fbhip_ctx* none = nullptr; HIPCK(none, gemm_init()); }
     return run_gemms(nullptr, {P(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, aux, ldaux, colsum)},
                      (hipStream_t)stream);
 }
@@ -953,6 +955,7 @@ int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* 
     p.tile_start = 0;
     g.p[0] = p; g.n = 1; g.total_tiles = p.tiles_m * p.tiles_n;
     fbhip_ctx* none = nullptr;
+    HIPCK(none, gemm_init());
     HIPCK(none, launch_gemm_group(g, cfg, (hipStream_t)stream));
     return FBHIP_OK;
 }

@@ -46,6 +46,7 @@ enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
 hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream);
 int gemm_cfg_bkt(int cfg);     // K extent of one chunk of a tile configuration
+hipError_t gemm_init();        // one-time kernel attribute setup (outside graph capture)
 int pick_gemm_cfg(int M, int N, int K);
 void gemm_problem_finalize(GemmProblem& p, int cfg);   // fills a_vec/b_vec/tiles_*
 

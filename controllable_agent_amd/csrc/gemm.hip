@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     static_assert(WM * WN * WK == 4, "four waves per workgroup");
     static_assert((BM * BKT) % 1024 == 0 && (BN * BKT) % 1024 == 0, "tile must split into float4 per thread");
     static_assert((WK - 1) * WM * WN * 17 * 64 <= 2 * STAGE, "split-K reduction scratch must fit");
-    __shared__ float smem[2 * STAGE];
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 * STAGE floats (dynamic: may exceed 64 KiB)
 
     // XCD-aware bijective remap: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so
     // neighbours (same A row-panel, adjacent B panels) share that XCD's L2.
@@ -398,7 +398,37 @@ hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t
 static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4};
 static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1};
 
-int gemm_cfg_bkt(int cfg) { return cfg == CFG_2x2x1 || cfg == CFG_4x1x1 ? 32 : 64; }
+// <WM, WN, WK, BK> per configuration
+#define FBHIP_CFGS(X) X(CFG_2x2x1, 2, 2, 1, 32) X(CFG_2x1x2, 2, 1, 2, 32) X(CFG_1x2x2, 1, 2, 2, 32) X(CFG_1x1x4, 1, 1, 4, 16) X(CFG_4x1x1, 4, 1, 1, 32)
+
+template <int WM, int WN, int WK, int BK>
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BK * WK) * (32 * WM + 1 + 32 * WN + 1) * sizeof(float); }
+
+int gemm_cfg_bkt(int cfg) {
+    switch (cfg) {
+#define X(id, wm, wn, wk, bk) case id: return bk * wk;
+        FBHIP_CFGS(X)
+#undef X
+        default: return 32;
+    }
+}
+
+// one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)
+hipError_t gemm_init() {
+    static bool done = false;
+    if (done) return hipSuccess;
+#define X(id, wm, wn, wk, bk)                                                                                       \
+    {                                                                                                                \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<wm, wn, wk, bk>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,                               \
+                                           (int)gemm_lds_bytes<wm, wn, wk, bk>());                                   \
+        if (e != hipSuccess) return e;                                                                               \
+    }
+    FBHIP_CFGS(X)
+#undef X
+    done = true;
+    return hipSuccess;
+}
 
 void gemm_problem_finalize(GemmProblem& p, int cfg) {
     if (p.kslices < 1) { p.kslices = 1; }
@@ -422,11 +452,12 @@ hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
     if (g.total_tiles <= 0) return hipSuccess;
     dim3 grid(g.total_tiles), block(256);
     switch (cfg) {
-        case CFG_2x2x1: hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 32>), grid, block, 0, stream, g); break;
-        case CFG_2x1x2: hipLaunchKernelGGL((gemm_kernel<2, 1, 2, 32>), grid, block, 0, stream, g); break;
-        case CFG_1x2x2: hipLaunchKernelGGL((gemm_kernel<1, 2, 2, 32>), grid, block, 0, stream, g); break;
-        case CFG_1x1x4: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 16>), grid, block, 0, stream, g); break;
-        case CFG_4x1x1: hipLaunchKernelGGL((gemm_kernel<4, 1, 1, 32>), grid, block, 0, stream, g); break;
+#define X(id, wm, wn, wk, bk)                                                                                       \
+    case id:                                                                                                         \
+        hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
+        break;
+        FBHIP_CFGS(X)
+#undef X
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
