@@ -586,20 +586,16 @@ class FBHipAgent:
         cur.wait_stream(self._stream)
 
     def _launch_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
-        import torch.distributed as dist
+        from .distributed import dp_update
         lib = _lib.load()
-        inj = C.byref(inject) if inject is not None else None
         s = stream_ptr()
-        if self._world() == 1:
-            check(lib.fbhip_update(self._ctx, C.byref(hp), inj, _lib.PHASE_ALL, int(use_graph), s), self._ctx)
-            return
-        # data parallel (SURVEY.md section 8e mode A): local batch x batch loss, sum-all-reduce of the two flat
-        # gradient buckets over RCCL/xGMI, 1/world folded into the Adam pass
-        check(lib.fbhip_update(self._ctx, C.byref(hp), inj, _lib.PHASE_SAMPLE | _lib.PHASE_FB_GRAD, int(use_graph), s), self._ctx)
-        dist.all_reduce(self._fb_grads)
-        check(lib.fbhip_update(self._ctx, C.byref(hp), None, _lib.PHASE_FB_STEP | _lib.PHASE_ACTOR_GRAD, int(use_graph), s), self._ctx)
-        dist.all_reduce(self._actor_grads)
-        check(lib.fbhip_update(self._ctx, C.byref(hp), None, _lib.PHASE_ACTOR_STEP, int(use_graph), s), self._ctx)
+
+        def run_phases(mask: int) -> None:
+            # injected draws only matter to the SAMPLE phase
+            inj = C.byref(inject) if (inject is not None and mask & _lib.PHASE_SAMPLE) else None
+            check(lib.fbhip_update(self._ctx, C.byref(hp), inj, mask, int(use_graph), s), self._ctx)
+
+        dp_update(run_phases, self._fb_grads, self._actor_grads)
 
     def _metrics(self) -> tp.Dict[str, float]:
         c = self.cfg

@@ -1,0 +1,53 @@
+"""Data-parallel schedule of one FB-DDPG update (mode A).
+
+The reference has no distributed code at all; this is new design for MI355X nodes: one process per GPU,
+``torch.distributed`` (backend "nccl" == RCCL over xGMI), replay episodes sharded ``ep % world == rank``,
+parameters / Adam state / targets replicated.  Every rank computes the FB loss on its OWN batch x batch block and
+the two flat gradient buckets are sum-all-reduced:
+
+    phase SAMPLE | FB_GRAD      -> all_reduce(fb_grads)      (forward_net ++ backward_net, 14.7 MB at walker dims)
+    phase FB_STEP | ACTOR_GRAD  -> all_reduce(actor_grads)   ( 8.9 MB)
+    phase ACTOR_STEP
+
+``1 / world`` is folded into the Adam pass (``grad_scale``), so the optimiser steps are bit-identical on every
+rank and no parameter broadcast is ever needed.  This equals ONE device fed the same ``world`` micro-batches with
+gradient averaging -- not the single-device loss on the concatenated batch (the contrastive off-diagonal mean
+runs over world * B(B-1) pairs instead of (world*B)(world*B - 1)).
+"""
+from __future__ import annotations
+
+import typing as tp
+
+import torch
+
+PHASE_SAMPLE, PHASE_FB_GRAD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP = 1, 2, 4, 8, 16
+PHASE_ALL = 31
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, actor_grads: torch.Tensor) -> None:
+    """Run one update through ``run_phases(mask)``; with world_size > 1 the two gradient buckets are
+    sum-all-reduced between the phases (``run_phases`` applies grad_scale = 1/world in its optimiser steps)."""
+    if world_size() == 1:
+        run_phases(PHASE_ALL)
+        return
+    import torch.distributed as dist
+    run_phases(PHASE_SAMPLE | PHASE_FB_GRAD)
+    dist.all_reduce(fb_grads)
+    run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
+    dist.all_reduce(actor_grads)
+    run_phases(PHASE_ACTOR_STEP)
+
+
+def shard_episodes(n_episodes: int, rank_: int, world: int) -> range:
+    """episode ids owned by ``rank_``: ep % world == rank_"""
+    return range(rank_, n_episodes, world)

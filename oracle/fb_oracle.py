@@ -449,6 +449,55 @@ class OracleAgent:
                 grads_actor={k: d(v) for k, v in gA.items()})
         return metrics
 
+    # -- the same update cut at the optimiser steps (for the data-parallel schedule test) ---------------- #
+    def dp_begin(self, batch: tp.Dict[str, np.ndarray], draws: Draws) -> None:
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+        cfg = self.cfg
+        self._dp = dict(obs=t(batch["obs"]), action=t(batch["action"]), next_obs=t(batch["next_obs"]),
+                        discount=t(batch["discount"]).reshape(-1, 1), draws=draws)
+        self._dp["next_goal"] = t(batch["next_goal"]) if cfg.use_goal else self._dp["next_obs"]
+        bi = t(batch["goal"]) if cfg.use_goal else self._dp["obs"]
+        self._dp["z"] = self.mix_z(sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim), bi, draws)
+
+    def dp_fb_grads(self) -> tp.Tuple[Params, Params]:
+        """gradients of update_fb's loss wrt (forward_net, backward_net)  (fb_ddpg.py:303-383)"""
+        cfg, d = self.cfg, self._dp
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+        with torch.no_grad():
+            mu_n = actor_mu(self.actor, d["next_obs"], d["z"])
+            na = truncated_normal_sample(mu_n, cfg.stddev, cfg.stddev_clip, t(d["draws"].eps_next))
+            tF1, tF2 = forward_map(self.forward_target_net, d["next_obs"], d["z"], na)
+            tB = backward_map(self.backward_target_net, d["next_goal"], cfg.z_dim)
+        fp, bp = self._req(self.forward_net), self._req(self.backward_net)
+        F1, F2 = forward_map(fp, d["obs"], d["z"], d["action"])
+        Bm = backward_map(bp, d["next_goal"], cfg.z_dim)
+        fb_loss_terms(F1, F2, Bm, tF1, tF2, tB, d["discount"], cfg.ortho_coef)["fb_loss"].backward()
+        return {k: v.grad for k, v in fp.items()}, {k: v.grad for k, v in bp.items()}
+
+    def dp_fb_step(self, gF: Params, gB: Params) -> None:
+        self.fb_steps += 1
+        adam_step(self.forward_net, gF, self.adam["forward_net"]["m"], self.adam["forward_net"]["v"], self.fb_steps, self.cfg.lr)
+        adam_step(self.backward_net, gB, self.adam["backward_net"]["m"], self.adam["backward_net"]["v"], self.fb_steps,
+                  self.cfg.lr_coef * self.cfg.lr)
+        # the HIP path fuses the EMA into this pass (legal: nothing in between reads a target net, SURVEY 2.3 T1)
+        soft_update(self.forward_net, self.forward_target_net, self.cfg.fb_target_tau)
+        soft_update(self.backward_net, self.backward_target_net, self.cfg.fb_target_tau)
+
+    def dp_actor_grads(self) -> Params:
+        cfg, d = self.cfg, self._dp
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+        ap = self._req(self.actor)
+        mu = actor_mu(ap, d["obs"], d["z"])
+        act = truncated_normal_sample(mu, cfg.stddev, cfg.stddev_clip, t(d["draws"].eps_actor))
+        aF1, aF2 = forward_map(self.forward_net, d["obs"], d["z"], act)
+        Q = torch.min(torch.einsum('sd, sd -> s', aF1, d["z"]), torch.einsum('sd, sd -> s', aF2, d["z"]))
+        (-Q.mean()).backward()
+        return {k: v.grad for k, v in ap.items()}
+
+    def dp_actor_step(self, gA: Params) -> None:
+        self.actor_steps += 1
+        adam_step(self.actor, gA, self.adam["actor"]["m"], self.adam["actor"]["v"], self.actor_steps, self.cfg.lr)
+
     # -- inference helpers (fb_ddpg.py:258-289, 177-222) ------------------ #
     def act_mean(self, obs: np.ndarray, z: np.ndarray) -> np.ndarray:
         with torch.no_grad():

@@ -1,0 +1,153 @@
+"""world_size-2 gloo test (CPU) of the data-parallel schedule controllable_agent_amd.distributed.dp_update:
+two ranks, each with its own replay shard / micro-batch, must end on exactly the state of ONE process that is fed
+both micro-batches and averages their gradients (mode A).  The compute engine behind the
+schedule is the oracle (the HIP engine needs a GPU); the schedule, bucket plumbing and sharding are the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from controllable_agent_amd import distributed as D
+from controllable_agent_amd.replay import DeviceReplayBuffer
+from oracle import fb_oracle as fo
+
+CFG = dict(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16, backward_hidden_dim=18,
+           batch_size=16, lr=1e-3)
+N_EPS, T, WORLD, STEPS = 8, 12, 2, 3
+
+
+def _setup(seed=7):
+    cfg = fo.OracleConfig(**CFG)
+    rng = np.random.default_rng(seed)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, N_EPS, T, cfg.obs_dim, cfg.action_dim)
+    return cfg, nets, storage, lengths
+
+
+def _flat(grads):
+    keys = sorted(grads)
+    return keys, torch.cat([grads[k].reshape(-1) for k in keys])
+
+
+def _unflat(keys, like, flat):
+    out, o = {}, 0
+    for k in keys:
+        n = like[k].numel()
+        out[k] = flat[o:o + n].reshape(like[k].shape)
+        o += n
+    return out
+
+
+def _shard_batch(cfg, storage, lengths, rank, step):
+    """rank's micro-batch of step ``step``: drawn from ITS shard (episodes ep % world == rank)"""
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cpu").shard(rank, WORLD)
+    sh = {k: v.numpy() for k, v in rb._storage.items()}
+    rng = np.random.default_rng(1000 * step + rank)
+    d = fo.make_draws(rng, cfg, len(rb), rb._episodes_length)
+    return fo.gather_batch(sh, d.ep_idx, d.step_idx, cfg.discount), d
+
+
+def _worker(rank, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    torch.set_num_threads(1)
+    cfg, nets, storage, lengths = _setup()
+    agent = fo.OracleAgent(cfg, nets)
+    assert list(D.shard_episodes(N_EPS, rank, WORLD)) == list(range(rank, N_EPS, WORLD))
+    for step in range(STEPS):
+        batch, draws = _shard_batch(cfg, storage, lengths, rank, step)
+        agent.dp_begin(batch, draws)
+        st = {}
+        # flat gradient buckets, like FBHipAgent._fb_grads / _actor_grads
+        fb_bucket = torch.zeros(sum(v.numel() for n in ("forward_net", "backward_net") for v in getattr(agent, n).values()))
+        ac_bucket = torch.zeros(sum(v.numel() for v in agent.actor.values()))
+
+        def run_phases(mask):
+            if mask & D.PHASE_FB_GRAD:
+                gF, gB = agent.dp_fb_grads()
+                st["kF"], fF = _flat(gF)
+                st["kB"], fB = _flat(gB)
+                st["nF"] = fF.numel()
+                fb_bucket.copy_(torch.cat([fF, fB]))
+            if mask & D.PHASE_FB_STEP:
+                scale = 1.0 / D.world_size()                       # grad_scale folded into the optimiser pass
+                agent.dp_fb_step(_unflat(st["kF"], agent.forward_net, fb_bucket[:st["nF"]] * scale),
+                                 _unflat(st["kB"], agent.backward_net, fb_bucket[st["nF"]:] * scale))
+            if mask & D.PHASE_ACTOR_GRAD:
+                st["kA"], fA = _flat(agent.dp_actor_grads())
+                ac_bucket.copy_(fA)
+            if mask & D.PHASE_ACTOR_STEP:
+                agent.dp_actor_step(_unflat(st["kA"], agent.actor, ac_bucket / D.world_size()))
+
+        D.dp_update(run_phases, fb_bucket, ac_bucket)
+    out_q.put((rank, {k: v.copy() for k, v in agent.state_tensors().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_dp_schedule_equals_gradient_averaging_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(WORLD))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process: both micro-batches, averaged gradients
+    torch.set_num_threads(1)
+    cfg, nets, storage, lengths = _setup()
+    ref = fo.OracleAgent(cfg, nets)
+    twins = [fo.OracleAgent(cfg, nets) for _ in range(WORLD)]             # per-micro-batch gradient evaluators
+    for step in range(STEPS):
+        gFs, gBs, gAs = [], [], []
+        for r, tw in enumerate(twins):
+            for n in ("actor", "forward_net", "backward_net", "forward_target_net", "backward_target_net"):
+                for k, v in getattr(ref, n).items():
+                    getattr(tw, n)[k].copy_(v)
+            tw.dp_begin(*_shard_batch(cfg, storage, lengths, r, step))
+            gF, gB = tw.dp_fb_grads()
+            gFs.append(gF), gBs.append(gB)
+        avg = lambda gs: {k: sum(g[k] for g in gs) / WORLD for k in gs[0]}
+        ref.dp_fb_step(avg(gFs), avg(gBs))
+        for tw in twins:
+            for n in ("forward_net", "backward_net"):
+                for k, v in getattr(ref, n).items():
+                    getattr(tw, n)[k].copy_(v)
+            gAs.append(tw.dp_actor_grads())
+        ref.dp_actor_step(avg(gAs))
+    want = ref.state_tensors()
+    for r in range(WORLD):
+        for k, v in want.items():
+            np.testing.assert_allclose(results[r][k], v, rtol=1e-5, atol=1e-7, err_msg=f"rank {r} {k}")
+    for k in want:                                                        # replicas stay bit-identical
+        np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+
+
+def test_phase_split_oracle_equals_monolithic_update():
+    """the oracle's phase-split statement == its monolithic update() (which is pinned to the reference)"""
+    cfg, nets, storage, lengths = _setup()
+    a, b = fo.OracleAgent(cfg, nets), fo.OracleAgent(cfg, nets)
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        d = fo.make_draws(rng, cfg, N_EPS, lengths)
+        batch = fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount)
+        a.update(batch, d)
+        b.dp_begin(batch, d)
+        b.dp_fb_step(*b.dp_fb_grads())
+        b.dp_actor_step(b.dp_actor_grads())
+    sa, sb = a.state_tensors(), b.state_tensors()
+    for k in sa:
+        np.testing.assert_allclose(sb[k], sa[k], rtol=1e-6, atol=1e-8, err_msg=k)
