@@ -235,8 +235,7 @@ class FBHipAgent:
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
                        "rand_weight": cfg.rand_weight, "add_trunk": cfg.add_trunk, "preprocess": not cfg.preprocess,
-                       "norm_z": not cfg.norm_z, "future_ratio": cfg.future_ratio > 0, "q_loss": cfg.q_loss,
-                       "nstep": cfg.nstep != 1}
+                       "norm_z": not cfg.norm_z, "future_ratio": cfg.future_ratio > 0, "nstep": cfg.nstep != 1}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"FBHipAgent: non-default options not implemented in the HIP path yet: {bad}")

@@ -123,7 +123,7 @@ struct Ws {
     BSet bsA, bsO;
     FSet fsT, fsO;
     ASet as;
-    Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov;
+    Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov, inv_cov, BinvC;
     float* ln_partials = nullptr;
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
     float* splitk = nullptr;            // split-K partial slabs, one per stream slot
@@ -183,7 +183,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
     w.dp = c.buf(B, 2 * H); w.dh = c.buf(B, 2 * Fd); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
     w.b_dr2 = c.buf(B, Hb); w.b_dt1 = c.buf(B, Hb); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
-    w.cov = c.buf(z, z);
+    w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
     w.ln_partials = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
@@ -568,8 +568,15 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
         HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, w.bsO.Bm.p, w.fsT.F1.p, w.fsT.F2.p, w.bsA.Bm.p, w.disc, B, z,
                                     Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
-        if (hp.want_metrics) {                  // fb_ddpg.py:356-377
+        if (hp.want_metrics || hp.q_loss)       // B^T B: metrics (fb_ddpg.py:371) and the q_loss covariance (:334)
             RC(run_gemms(c, {P(w.bsO.Bm.p, Lz, 0, w.bsO.Bm.p, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
+        if (hp.q_loss) {                        // fb_ddpg.py:330-340
+            HIPCK(c, launch_inverse(w.cov.p, w.cov.ld, z, 1.0f / (float)B, w.inv_cov.p, w.inv_cov.ld, s));
+            RC(run_gemms(c, {P(w.bsO.Bm.p, Lz, 1, w.inv_cov.p, w.inv_cov.ld, 0, w.BinvC.p, Lz, B, z, z)}, s));
+            HIPCK(c, launch_qloss(w.fsO.F1.p, w.fsO.F2.p, w.fsT.F1.p, w.fsT.F2.p, w.BinvC.p, w.z.p, Lz, w.disc,
+                                  hp.q_loss_coef, w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, s));
+        }
+        if (hp.want_metrics) {                  // fb_ddpg.py:356-377
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, w.bsO.Bm.p, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
         }
         // --- backward (fb_ddpg.py:383): forward_net on [s]+[sW], backward_net on [sA]
@@ -738,6 +745,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     c->graphs.clear();
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
     HIPCK(c, gemm_init());
+    HIPCK(c, inverse_prepare());
     if (c->events.empty()) {
         for (int i = 0; i < fbhip_ctx::NSIDE; ++i) HIPCK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         c->events.resize(96);
@@ -806,7 +814,6 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
                  int32_t use_graph, void* stream) {
     RC(need_bound(c, (phase_mask & FBHIP_PHASE_SAMPLE) != 0));
     if (!hp) { c->err = g_err = "fbhip: null hparams"; return FBHIP_E_INVALID; }
-    if (hp->q_loss) { c->err = g_err = "fbhip: q_loss=True is not implemented in the HIP path yet"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     c->ev_next = 0;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);

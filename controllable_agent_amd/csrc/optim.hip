@@ -139,4 +139,141 @@ hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// q_loss branch of update_fb (fb_ddpg.py:330-340).
+//   cov = B^T B / batch;  inv_cov = inverse(cov)                       -> inverse_kernel (d x d, one workgroup)
+//   implicit_reward = rowsum((B inv_cov) * z);  next_Q = min(tF1.z, tF2.z);  target_Q = ir + discount * next_Q
+//   q_loss = mse(F1.z, target_Q) + mse(F2.z, target_Q);  dF_i += coef * 2 (F_i.z - target_Q) / batch * z
+// In-place Gauss-Jordan with partial pivoting, fp64 in LDS (the matrix is tiny; fp64 keeps the result at the
+// conditioning of the fp32 input rather than adding a second fp32 round-off on top of torch.inverse's).
+__global__ void __launch_bounds__(256) inverse_kernel(const float* __restrict__ A, int lda, int d, float scale,
+                                                      float* __restrict__ out, int ldo) {
+    extern __shared__ double sm[];
+    double* M = sm;                  // [d][d]
+    double* rowk = M + d * d;        // [d]
+    double* colk = rowk + d;         // [d]
+    int* piv = (int*)(colk + d);     // [d]
+    __shared__ int s_p;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < d * d; e += 256) M[e] = (double)A[(size_t)(e / d) * lda + (e % d)] * (double)scale;
+    __syncthreads();
+    for (int k = 0; k < d; ++k) {
+        if (tid < 64) {              // pivot search by wave 0: argmax_i>=k |M[i][k]| (lowest index on ties)
+            double best = -1.0;
+            int bi = k;
+            for (int i = k + tid; i < d; i += 64) {
+                const double v = fabs(M[i * d + k]);
+                if (v > best) { best = v; bi = i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (tid == 0) { s_p = bi; piv[k] = bi; }
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (p != k)
+            for (int j = tid; j < d; j += 256) { const double t = M[k * d + j]; M[k * d + j] = M[p * d + j]; M[p * d + j] = t; }
+        __syncthreads();
+        const double pv = M[k * d + k];
+        for (int j = tid; j < d; j += 256) {
+            rowk[j] = (j == k) ? 1.0 / pv : M[k * d + j] / pv;
+            colk[j] = (j == k) ? 0.0 : M[j * d + k];
+        }
+        __syncthreads();
+        for (int e = tid; e < d * d; e += 256) {
+            const int i = e / d, j = e % d;
+            if (i == k) M[e] = rowk[j];
+            else if (j == k) M[e] = -colk[i] * rowk[k];
+            else M[e] -= colk[i] * rowk[j];
+        }
+        __syncthreads();
+    }
+    for (int k = d - 1; k >= 0; --k) {               // undo the row exchanges as column exchanges
+        const int p = piv[k];
+        if (p != k)
+            for (int i = tid; i < d; i += 256) { const double t = M[i * d + k]; M[i * d + k] = M[i * d + p]; M[i * d + p] = t; }
+        __syncthreads();
+    }
+    for (int e = tid; e < d * d; e += 256) out[(size_t)(e / d) * ldo + (e % d)] = (float)M[e];
+}
+
+hipError_t launch_inverse(const float* A, int lda, int d, float scale, float* out, int ldo, hipStream_t s) {
+    if (d < 1 || d > 128) return hipErrorInvalidValue;
+    const size_t bytes = ((size_t)d * d + 2 * d) * sizeof(double) + (size_t)d * sizeof(int);
+    hipLaunchKernelGGL(inverse_kernel, dim3(1), dim3(256), bytes, s, A, lda, d, scale, out, ldo);
+    return hipGetLastError();
+}
+
+hipError_t inverse_prepare() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(((size_t)128 * 128 + 256) * sizeof(double) + 128 * sizeof(int)));
+}
+
+// one wavefront per row; partial sums of the two squared errors go to ``part`` (2 floats per workgroup)
+__global__ void __launch_bounds__(256) qloss_kernel(const float* __restrict__ F1, const float* __restrict__ F2,
+                                                    const float* __restrict__ tF1, const float* __restrict__ tF2,
+                                                    const float* __restrict__ BinvC, const float* __restrict__ z,
+                                                    int ld, const float* __restrict__ discount, float coef,
+                                                    float* __restrict__ dF1, float* __restrict__ dF2,
+                                                    float* __restrict__ part, int rows, int d) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = blockIdx.x * 4 + wid;
+    float sq = 0.f;
+    if (row < rows) {
+        float q1 = 0.f, q2 = 0.f, n1 = 0.f, n2 = 0.f, ir = 0.f;
+        for (int j = lane; j < d; j += 64) {
+            const size_t o = (size_t)row * ld + j;
+            const float zz = z[o];
+            q1 += F1[o] * zz; q2 += F2[o] * zz; n1 += tF1[o] * zz; n2 += tF2[o] * zz; ir += BinvC[o] * zz;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            q1 += __shfl_xor(q1, off); q2 += __shfl_xor(q2, off); n1 += __shfl_xor(n1, off);
+            n2 += __shfl_xor(n2, off); ir += __shfl_xor(ir, off);
+        }
+        const float tq = ir + discount[row] * fminf(n1, n2);
+        const float e1 = q1 - tq, e2 = q2 - tq;
+        const float g1 = coef * 2.f * e1 / (float)rows, g2 = coef * 2.f * e2 / (float)rows;
+        for (int j = lane; j < d; j += 64) {
+            const size_t o = (size_t)row * ld + j;
+            const float zz = z[o];
+            dF1[o] += g1 * zz;
+            dF2[o] += g2 * zz;
+        }
+        sq = e1 * e1 + e2 * e2;
+    }
+    if (lane == 0) red[wid] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(64) qloss_finalize_kernel(const float* __restrict__ part, int nblk, int rows,
+                                                            float coef, float* __restrict__ metrics) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) {
+        const float q = (float)(s / rows);
+        metrics[FBHIP_M_Q_LOSS] = q;
+        metrics[FBHIP_M_FB_LOSS] += coef * q;        // fb_loss += q_loss_coef * q_loss (fb_ddpg.py:340)
+    }
+}
+
+hipError_t launch_qloss(const float* F1, const float* F2, const float* tF1, const float* tF2, const float* BinvC,
+                        const float* z, int ld, const float* discount, float coef, float* dF1, float* dF2,
+                        float* metrics, float* scratch, int rows, int d, hipStream_t s) {
+    const int nblk = (rows + 3) / 4;
+    hipLaunchKernelGGL(qloss_kernel, dim3(nblk), dim3(256), 0, s, F1, F2, tF1, tF2, BinvC, z, ld, discount, coef, dF1,
+                       dF2, scratch, rows, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(qloss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, coef, metrics);
+    return hipGetLastError();
+}
+
 }  // namespace fbhip

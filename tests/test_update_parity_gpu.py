@@ -32,7 +32,7 @@ def _param_close(got, ref, lr, name):
     assert frac >= 0.999, f"{name}: only {frac:.5f} of entries within {PARAM_ATOL}"
 
 
-@pytest.mark.parametrize("name,goal_space", [("tiny_trace", None)])
+@pytest.mark.parametrize("name,goal_space", [("tiny_trace", None), ("tiny_goal_trace", "simplified_walker")])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
