@@ -77,17 +77,22 @@ __device__ __forceinline__ void store_quad(float* __restrict__ d, int step, cons
     d[3 * step] = v.w;
 }
 
+// Wave-specialised workgroup of 8 waves: waves 0-3 are CONSUMERS (one 32x32 accumulator each, arranged WM x WN x WK;
+// they only read MFMA fragments from LDS and issue the dependent MFMA chain), waves 4-7 are PRODUCERS (global ->
+// registers -> LDS staging of the next K chunks, prefetch distance 2).  One s_barrier per K chunk couples them.  With
+// symmetric waves the co-resident workgroups fall into lockstep and the matrix pipe idles through every
+// store/barrier/refill phase (PMC: 44-52 % MFMA busy); here the pipe-owning waves have nothing else to do.
 template <int WM, int WN, int WK, int BK>
-__global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
+__global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     constexpr int BM = 32 * WM, BN = 32 * WN, BKT = BK * WK;
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
     constexpr int STAGE = BKT * (LDA_S + LDB_S);
     constexpr int QA = BM * BKT / 1024, QB = BN * BKT / 1024;
     constexpr int NF = BK / 2;                         // MFMA k-steps per chunk
-    static_assert(WM * WN * WK == 4, "four waves per workgroup");
+    static_assert(WM * WN * WK == 4, "four consumer waves per workgroup");
     static_assert((BM * BKT) % 1024 == 0 && (BN * BKT) % 1024 == 0, "tile must split into float4 per thread");
     static_assert((WK - 1) * WM * WN * 17 * 64 <= 2 * STAGE, "split-K reduction scratch must fit");
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 * STAGE floats (dynamic: may exceed 64 KiB)
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 * STAGE floats
 
     // XCD-aware bijective remap: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so
     // neighbours (same A row-panel, adjacent B panels) share that XCD's L2.
@@ -107,93 +112,148 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
     const int M = p.M, N = p.N;
     const int kb = slice * p.kper * BKT;                       // this workgroup's K range [kb, K)
     const int K = min(p.K, kb + p.kper * BKT);
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nt = (K - kb + BKT - 1) / BKT;                  // chunks of this slice
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    if (wid >= 4) {
+        // =========================================================================================== PRODUCERS
+        const int tid = threadIdx.x - 256;
+        const float* __restrict__ A = p.A;
+        const float* __restrict__ Bp = p.B;
+        const int akc = p.a_kcontig, bkc = p.b_kcontig;
+        // per-thread staging geometry: global element offset at chunk 0, LDS float offset, LDS write stride
+        size_t ga[QA], gb[QB];
+        int sa[QA], sb[QB];
+#pragma unroll
+        for (int i = 0; i < QA; ++i) {
+            const int q = tid + i * 256;
+            if (akc) {
+                const int r = q / (BKT / 4), kq = q % (BKT / 4);
+                ga[i] = (size_t)(row0 + r) * p.lda + kb + 4 * kq;
+                sa[i] = (4 * kq) * LDA_S + r;
+            } else {
+                const int k = q / (BM / 4), rq = q % (BM / 4);
+                ga[i] = (size_t)(kb + k) * p.lda + row0 + 4 * rq;
+                sa[i] = k * LDA_S + 4 * rq;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QB; ++i) {
+            const int q = tid + i * 256;
+            if (bkc) {
+                const int r = q / (BKT / 4), kq = q % (BKT / 4);
+                gb[i] = (size_t)(col0 + r) * p.ldb + kb + 4 * kq;
+                sb[i] = (4 * kq) * LDB_S + r;
+            } else {
+                const int k = q / (BN / 4), rq = q % (BN / 4);
+                gb[i] = (size_t)(kb + k) * p.ldb + col0 + 4 * rq;
+                sb[i] = k * LDB_S + 4 * rq;
+            }
+        }
+        const int step_a = akc ? LDA_S : 1, step_b = bkc ? LDB_S : 1;
+        const size_t adv_a = akc ? (size_t)BKT : (size_t)BKT * p.lda;
+        const size_t adv_b = bkc ? (size_t)BKT : (size_t)BKT * p.ldb;
+        // interior tiles of 16-byte-aligned operands take a branch-free loader for every full K chunk; edge tiles,
+        // unaligned views and the K tail go through the predicated loader (same register image)
+        const bool interior = (row0 + BM <= M) && (col0 + BN <= N) && p.a_vec && p.b_vec;
+        const int nfast = interior ? (K - kb) / BKT : 0;
+
+        auto load_fast = [&](int ch, float4 (&xa)[QA], float4 (&xb)[QB]) __attribute__((always_inline)) {
+            const size_t oa = (size_t)ch * adv_a, ob = (size_t)ch * adv_b;
+#pragma unroll
+            for (int i = 0; i < QA; ++i) xa[i] = *reinterpret_cast<const float4*>(A + ga[i] + oa);
+#pragma unroll
+            for (int i = 0; i < QB; ++i) xb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
+        };
+        auto load_slow = [&](int ch, float4 (&xa)[QA], float4 (&xb)[QB]) __attribute__((always_inline)) {
+            load_tile<BM, BKT, QA>(xa, A, p.lda, akc, p.a_vec, row0, M, kb + ch * BKT, K, tid);
+            load_tile<BN, BKT, QB>(xb, Bp, p.ldb, bkc, p.b_vec, col0, N, kb + ch * BKT, K, tid);
+        };
+        auto store_chunk = [&](int stage, const float4 (&xa)[QA], const float4 (&xb)[QB]) __attribute__((always_inline)) {
+            float* dA = smem + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < QA; ++i) store_quad(dA + sa[i], step_a, xa[i]);
+#pragma unroll
+            for (int i = 0; i < QB; ++i) store_quad(dA + BKT * LDA_S + sb[i], step_b, xb[i]);
+        };
+        // producer step ``it``: request chunk it+2 into (la_, lb_), land chunk it+1 (in flight in (sa_, sb_)) in LDS
+        // stage (it+1)&1, then meet the consumers at the barrier.  LOAD/STORE are compile-time so the steady state is
+        // straight-line code and hipcc emits a COUNTED s_waitcnt vmcnt(n) that keeps the newest chunk in flight.
+        auto p_step = [&](int it, auto do_load, auto do_store, float4 (&la_)[QA], float4 (&lb_)[QB],
+                          const float4 (&sa_)[QA], const float4 (&sb_)[QB]) __attribute__((always_inline)) {
+            if constexpr (decltype(do_load)::value) load_fast(it + 2, la_, lb_);
+            if constexpr (decltype(do_store)::value) store_chunk((it + 1) & 1, sa_, sb_);
+            __syncthreads();
+        };
+        constexpr std::true_type T{};
+        constexpr std::false_type F{};
+        float4 ra0[QA], rb0[QB], ra1[QA], rb1[QB];
+        if (nfast > 0) {
+            const int nf = nfast;
+            load_fast(0, ra0, rb0);
+            if (nf > 1) load_fast(1, ra1, rb1);
+            else {
+#pragma unroll
+                for (int i = 0; i < QA; ++i) ra1[i] = ra0[i];
+#pragma unroll
+                for (int i = 0; i < QB; ++i) rb1[i] = rb0[i];
+            }
+            store_chunk(0, ra0, rb0);
+            __syncthreads();                                          // barrier #0: chunk 0 visible
+            int it = 0;
+            for (; it + 3 < nf; it += 2) {
+                p_step(it, T, T, ra0, rb0, ra1, rb1);
+                p_step(it + 1, T, T, ra1, rb1, ra0, rb0);
+            }
+            const int rem = nf - it;                                    // 1, 2 or 3 fast steps left
+            const bool tail = nt > nf;                                  // ragged K tail chunk (index nf)
+            if (rem == 3) {
+                p_step(it, T, T, ra0, rb0, ra1, rb1);
+                p_step(it + 1, F, T, ra1, rb1, ra0, rb0);
+                if (tail) { load_slow(nf, ra1, rb1); p_step(it + 2, F, T, ra0, rb0, ra1, rb1); }
+                else p_step(it + 2, F, F, ra0, rb0, ra1, rb1);
+            } else if (rem == 2) {
+                p_step(it, F, T, ra0, rb0, ra1, rb1);
+                if (tail) { load_slow(nf, ra0, rb0); p_step(it + 1, F, T, ra1, rb1, ra0, rb0); }
+                else p_step(it + 1, F, F, ra1, rb1, ra0, rb0);
+            } else {
+                if (tail) { load_slow(nf, ra1, rb1); p_step(it, F, T, ra0, rb0, ra1, rb1); }
+                else p_step(it, F, F, ra0, rb0, ra1, rb1);
+            }
+            if (tail) __syncthreads();                                  // the consumers' barrier after chunk nf
+        } else {
+            load_slow(0, ra0, rb0);
+            store_chunk(0, ra0, rb0);
+            __syncthreads();
+            for (int it = 0; it < nt; ++it) {
+                if (it + 1 < nt) {
+                    load_slow(it + 1, ra0, rb0);
+                    store_chunk((it + 1) & 1, ra0, rb0);
+                }
+                __syncthreads();
+            }
+        }
+        if constexpr (WK > 1) __syncthreads();                          // stay for the consumers' reduction barrier
+        return;
+    }
+
+    // ============================================================================================== CONSUMERS
     const int l31 = lane & 31, h = lane >> 5;
     const int wk = wid / (WM * WN), wrem = wid % (WM * WN);
     const int wm = wrem / WN, wn = wrem % WN;
-
-    const float* __restrict__ A = p.A;
-    const float* __restrict__ Bp = p.B;
-    const int row0 = tm * BM, col0 = tn * BN;
-    const int akc = p.a_kcontig, bkc = p.b_kcontig;
-
-    // ---- per-thread staging geometry (fixed for the whole K loop) ---------------------------------------
-    // quad i of this thread: global element offset at chunk 0, LDS float offset, LDS write stride
-    size_t ga[QA], gb[QB];
-    int sa[QA], sb[QB];
-#pragma unroll
-    for (int i = 0; i < QA; ++i) {
-        const int q = tid + i * 256;
-        if (akc) {
-            const int r = q / (BKT / 4), kq = q % (BKT / 4);
-            ga[i] = (size_t)(row0 + r) * p.lda + kb + 4 * kq;
-            sa[i] = (4 * kq) * LDA_S + r;
-        } else {
-            const int k = q / (BM / 4), rq = q % (BM / 4);
-            ga[i] = (size_t)(kb + k) * p.lda + row0 + 4 * rq;
-            sa[i] = k * LDA_S + 4 * rq;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < QB; ++i) {
-        const int q = tid + i * 256;
-        if (bkc) {
-            const int r = q / (BKT / 4), kq = q % (BKT / 4);
-            gb[i] = (size_t)(col0 + r) * p.ldb + kb + 4 * kq;
-            sb[i] = (4 * kq) * LDB_S + r;
-        } else {
-            const int k = q / (BN / 4), rq = q % (BN / 4);
-            gb[i] = (size_t)(kb + k) * p.ldb + col0 + 4 * rq;
-            sb[i] = k * LDB_S + 4 * rq;
-        }
-    }
-    const int step_a = akc ? LDA_S : 1, step_b = bkc ? LDB_S : 1;
-    const size_t adv_a = akc ? (size_t)BKT : (size_t)BKT * p.lda;
-    const size_t adv_b = bkc ? (size_t)BKT : (size_t)BKT * p.ldb;
-    // interior tiles of 16-byte-aligned operands take a branch-free loader for every full K chunk; edge tiles,
-    // unaligned views and the K tail go through the predicated loader (same register image)
-    const bool interior = (row0 + BM <= M) && (col0 + BN <= N) && p.a_vec && p.b_vec;
-    const int nt = (K - kb + BKT - 1) / BKT;                  // chunks of this slice
-    const int nfast = interior ? (K - kb) / BKT : 0;          // ... of which the leading nfast need no predication
+    const int frag_a = (wk * BK + h) * LDA_S + wm * 32 + l31;
+    const int frag_b = BKT * LDA_S + (wk * BK + h) * LDB_S + wn * 32 + l31;
 
     floatx16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float csum = 0.f;
 
-    const int frag_a = (wk * BK + h) * LDA_S + wm * 32 + l31;
-    const int frag_b = BKT * LDA_S + (wk * BK + h) * LDB_S + wn * 32 + l31;
-
-    // global -> register loader for chunk ``ch`` (branch-free for interior tiles, predicated otherwise)
-    auto load_chunk = [&](int ch, float4 (&xa)[QA], float4 (&xb)[QB]) __attribute__((always_inline)) {
-        if (ch < nfast) {
-            const size_t oa = (size_t)ch * adv_a, ob = (size_t)ch * adv_b;
-#pragma unroll
-            for (int i = 0; i < QA; ++i) xa[i] = *reinterpret_cast<const float4*>(A + ga[i] + oa);
-#pragma unroll
-            for (int i = 0; i < QB; ++i) xb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
-        } else {
-            load_tile<BM, BKT, QA>(xa, A, p.lda, akc, p.a_vec, row0, M, kb + ch * BKT, K, tid);
-            load_tile<BN, BKT, QB>(xb, Bp, p.ldb, bkc, p.b_vec, col0, N, kb + ch * BKT, K, tid);
-        }
-    };
-    auto store_chunk = [&](int stage, const float4 (&xa)[QA], const float4 (&xb)[QB]) __attribute__((always_inline)) {
-        float* dA = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < QA; ++i) store_quad(dA + sa[i], step_a, xa[i]);
-#pragma unroll
-        for (int i = 0; i < QB; ++i) store_quad(dA + BKT * LDA_S + sb[i], step_b, xb[i]);
-    };
-    auto load_fast = [&](int ch, float4 (&xa)[QA], float4 (&xb)[QB]) __attribute__((always_inline)) {
-        const size_t oa = (size_t)ch * adv_a, ob = (size_t)ch * adv_b;
-#pragma unroll
-        for (int i = 0; i < QA; ++i) xa[i] = *reinterpret_cast<const float4*>(A + ga[i] + oa);
-#pragma unroll
-        for (int i = 0; i < QB; ++i) xb[i] = *reinterpret_cast<const float4*>(Bp + gb[i] + ob);
-    };
-    auto mfma_chunk = [&](int it) __attribute__((always_inline)) {
+    __syncthreads();                                                    // barrier #0
+    for (int it = 0; it < nt; ++it) {
         const float* st = smem + (it & 1) * STAGE;
         float av[NF], bv[NF];
 #pragma unroll
@@ -206,10 +266,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
             csum += av[j];
         }
-        // Pin the issue order of this block: fragment reads run ahead of the MFMA pair that consumes them, so each
-        // s_waitcnt only covers reads issued >= 128 MFMA-cycles earlier (left alone, hipcc issues every ds_read2 right
-        // before its MFMA pair and exposes the full LDS latency on the dependent chain).
-        // (ds_read_b32 pairs are merged into ds_read2_b32: NF DS instructions per chunk.)
+        // Pin the issue order: fragment reads run ahead of the MFMA pair that consumes them, so each s_waitcnt only
+        // covers reads issued >= 128 MFMA-cycles earlier (ds_read_b32 pairs are merged into ds_read2_b32).
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);              // DS reads for MFMA pairs 0, 1
 #pragma unroll
         for (int j = 0; j < NF / 2 - 2; ++j) {
@@ -217,70 +275,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmGroup g) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // DS reads for pair j + 2
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);              // last two MFMA pairs
-    };
-    // One K step: chunk ``it`` is in LDS stage it&1, chunk it+1 is in flight in (sa_, sb_), chunk it+2 is requested
-    // into (la_, lb_) -- prefetch distance 2, so the L2 / Infinity-Cache round trip spans two MFMA chains.  LOAD/STORE
-    // are compile-time so the steady-state loop is straight-line code and hipcc can emit a COUNTED s_waitcnt vmcnt(n)
-    // that leaves the newest chunk in flight (with run-time branches it falls back to vmcnt(0)).
-    auto k_step = [&](int it, auto do_load, auto do_store, float4 (&la_)[QA], float4 (&lb_)[QB],
-                      const float4 (&sa_)[QA], const float4 (&sb_)[QB]) __attribute__((always_inline)) {
-        if constexpr (decltype(do_load)::value) load_fast(it + 2, la_, lb_);
-        mfma_chunk(it);
-        if constexpr (decltype(do_store)::value) store_chunk((it + 1) & 1, sa_, sb_);
         __syncthreads();
-    };
-    constexpr std::true_type T{};
-    constexpr std::false_type F{};
-
-    float4 ra0[QA], rb0[QB], ra1[QA], rb1[QB];
-    if (nfast > 0) {
-        // ---- leading chunks are interior + aligned: branch-free pipeline
-        const int nf = nfast;
-        load_fast(0, ra0, rb0);
-        if (nf > 1) load_fast(1, ra1, rb1);
-        else {
-#pragma unroll
-            for (int i = 0; i < QA; ++i) ra1[i] = ra0[i];
-#pragma unroll
-            for (int i = 0; i < QB; ++i) rb1[i] = rb0[i];
-        }
-        store_chunk(0, ra0, rb0);
-        __syncthreads();
-        int it = 0;
-        for (; it + 3 < nf; it += 2) {
-            k_step(it, T, T, ra0, rb0, ra1, rb1);
-            k_step(it + 1, T, T, ra1, rb1, ra0, rb0);
-        }
-        const int rem = nf - it;                                    // 1, 2 or 3 steps left
-        if (rem == 3) {
-            k_step(it, T, T, ra0, rb0, ra1, rb1);
-            k_step(it + 1, F, T, ra1, rb1, ra0, rb0);
-            k_step(it + 2, F, F, ra0, rb0, ra1, rb1);
-        } else if (rem == 2) {
-            k_step(it, F, T, ra0, rb0, ra1, rb1);
-            k_step(it + 1, F, F, ra1, rb1, ra0, rb0);
-        } else {
-            k_step(it, F, F, ra0, rb0, ra1, rb1);
-        }
-        if (nt > nf) {                                              // ragged K tail (K % chunk != 0): predicated
-            load_chunk(nf, ra0, rb0);
-            store_chunk(nf & 1, ra0, rb0);
-            __syncthreads();
-            mfma_chunk(nf);
-            __syncthreads();
-        }
-    } else {
-        // ---- edge tiles / unaligned operands: predicated loader, prefetch distance 1
-        load_chunk(0, ra0, rb0);
-        store_chunk(0, ra0, rb0);
-        __syncthreads();
-        for (int it = 0; it < nt; ++it) {
-            const bool more = it + 1 < nt;
-            if (more) load_chunk(it + 1, ra0, rb0);
-            mfma_chunk(it);
-            if (more) store_chunk((it + 1) & 1, ra0, rb0);
-            __syncthreads();
-        }
     }
 
     if constexpr (WK > 1) {
@@ -450,7 +445,7 @@ int pick_gemm_cfg(int M, int N, int K) {
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
     if (g.total_tiles <= 0) return hipSuccess;
-    dim3 grid(g.total_tiles), block(256);
+    dim3 grid(g.total_tiles), block(512);
     switch (cfg) {
 #define X(id, wm, wn, wk, bk)                                                                                       \
     case id:                                                                                                         \

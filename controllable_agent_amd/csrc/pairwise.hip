@@ -42,22 +42,58 @@ struct PwArgs {
     float ortho2;              // 2 * ortho_coef
     int jpc;                   // J tiles per chunk
     int njt;                   // number of J tiles (ceil(B/32))
+    int vec;                   // 16-byte aligned panels with ld % 4 == 0 -> float4 loads
     float* partial;            // [nchunks][PW_SLOTS][Bp][DP]
     float* scal;               // [nblocks][PW_SCAL]
     int Bp;
 };
 
-// stage a [32 x d] row block of X (rows row0..row0+31, zero filled outside [0,B) x [0,d)) into LDS [32][LD]
+// Stage the same 32-row block of SIX matrices (zero filled outside [0,B) x [0,d)) into LDS [32][LD] each.  All global
+// loads are issued before the first LDS store (a load->store loop would serialise one memory latency per element).
 template <int LD>
-__device__ __forceinline__ void stage_rows(float* __restrict__ s, const float* __restrict__ X, int ld, int row0,
-                                           int B, int d, int tid) {
-    constexpr int W = LD - 1;
-    for (int e = tid; e < 32 * W; e += 256) {
-        const int r = e / W, n = e % W;
-        const int gr = row0 + r;
-        s[r * LD + n] = (gr < B && n < d) ? X[(size_t)gr * ld + n] : 0.f;
+struct Stage6 {
+    static constexpr int W = LD - 1;                 // multiple of 32
+    static constexpr int QPT = 32 * (W / 4) / 256;   // float4 quads per thread per matrix (2 for W=64, 4 for W=128)
+    float4 v[6][QPT > 0 ? QPT : 1];
+
+    __device__ __forceinline__ void load(const float* const (&X)[6], int ld, int row0, int B, int d, bool vec, int tid) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                const int q = tid + i * 256;
+                const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+                const int gr = row0 + r;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gr < B && n0 < d) {
+                    const float* ptr = X[m] + (size_t)gr * ld + n0;
+                    if (vec && n0 + 3 < ld) {
+                        x = *reinterpret_cast<const float4*>(ptr);          // may read pad columns: masked below
+                    } else {
+                        x.x = ptr[0];
+                        if (n0 + 1 < d) x.y = ptr[1];
+                        if (n0 + 2 < d) x.z = ptr[2];
+                        if (n0 + 3 < d) x.w = ptr[3];
+                    }
+                    if (n0 + 1 >= d) x.y = 0.f;
+                    if (n0 + 2 >= d) x.z = 0.f;
+                    if (n0 + 3 >= d) x.w = 0.f;
+                }
+                v[m][i] = x;
+            }
     }
-}
+    __device__ __forceinline__ void store(float* __restrict__ lds_base, int tid) const {
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+            for (int i = 0; i < QPT; ++i) {
+                const int q = tid + i * 256;
+                const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+                float* dst = lds_base + m * 32 * LD + r * LD + n0;
+                dst[0] = v[m][i].x; dst[1] = v[m][i].y; dst[2] = v[m][i].z; dst[3] = v[m][i].w;
+            }
+    }
+};
 
 // acc(32x32) = rowsJ (LDS, [32][LD]) . fragI^T over KS k-steps
 template <int KS, int LD>
@@ -109,13 +145,14 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
     const float n_off = (float)B * (float)(B - 1);
     const float inv_noff = 1.0f / n_off, inv_b = 1.0f / (float)B;
 
+    // LDS order of the six panels: Bm, tB, F1, F2, tF1, tF2
+    const float* const srcs[6] = {p.Bm, p.tB, p.F1, p.F2, p.tF1, p.tF2};
+    const bool vec = p.vec != 0;
+    Stage6<LD> stg;
+
     // ---- I-side fragments (registers, whole kernel) ----------------------------------------------------
-    stage_rows<LD>(sBm, p.Bm, p.ld, I0, B, d, tid);
-    stage_rows<LD>(stB, p.tB, p.ld, I0, B, d, tid);
-    stage_rows<LD>(sF1, p.F1, p.ld, I0, B, d, tid);
-    stage_rows<LD>(sF2, p.F2, p.ld, I0, B, d, tid);
-    stage_rows<LD>(stF1, p.tF1, p.ld, I0, B, d, tid);
-    stage_rows<LD>(stF2, p.tF2, p.ld, I0, B, d, tid);
+    stg.load(srcs, p.ld, I0, B, d, vec, tid);
+    stg.store(lds, tid);
     __syncthreads();
     float fa[KS], fb[KS], fc[KS];
     if (wid < 2) {                   // role 1: F_i[I], tF1[I], tF2[I]
@@ -144,14 +181,11 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
 #pragma unroll 1
     for (int jt = jt_begin; jt < jt_end; ++jt) {
         const int J0 = jt * 32;
-        stage_rows<LD>(sBm, p.Bm, p.ld, J0, B, d, tid);
-        stage_rows<LD>(stB, p.tB, p.ld, J0, B, d, tid);
-        stage_rows<LD>(sF1, p.F1, p.ld, J0, B, d, tid);
-        stage_rows<LD>(sF2, p.F2, p.ld, J0, B, d, tid);
-        stage_rows<LD>(stF1, p.tF1, p.ld, J0, B, d, tid);
-        stage_rows<LD>(stF2, p.tF2, p.ld, J0, B, d, tid);
+        if (jt == jt_begin) stg.load(srcs, p.ld, J0, B, d, vec, tid);      // later tiles were prefetched below
+        stg.store(lds, tid);
         if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
         __syncthreads();
+        if (jt + 1 < jt_end) stg.load(srcs, p.ld, J0 + 32, B, d, vec, tid); // next J tile in flight under the MFMAs
 
         if (wid < 2) {
             // tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
@@ -351,6 +385,8 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
     PwArgs a;
     a.F1 = F1; a.F2 = F2; a.Bm = Bm; a.tF1 = tF1; a.tF2 = tF2; a.tB = tB; a.discount = discount;
     a.B = B; a.d = d; a.ld = ld; a.ortho2 = 2.0f * ortho_coef; a.jpc = pl.jpc; a.njt = pl.njt;
+    a.vec = ((ld & 3) == 0);
+    for (const float* q : {F1, F2, Bm, tF1, tF2, tB}) if ((uintptr_t)q & 15) a.vec = 0;
     a.partial = scratch;
     a.scal = scratch + (size_t)pl.nchunks * PW_SLOTS * pl.Bp * pl.dp;
     a.Bp = pl.Bp;
