@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -374,22 +375,59 @@ int sync_streams(fbhip_ctx* c, hipStream_t from, hipStream_t to) {
     return FBHIP_OK;
 }
 
+// A pass is a list of stages (each = the launches of one dependency level).  Independent chains are enqueued
+// round-robin, one stage per chain per round: ROCm's graph executor submits nodes roughly in capture order, so a
+// branch captured behind a long chain would start late even though it has no dependency on it.
+using Stage = std::function<int(hipStream_t)>;
+struct Chain { hipStream_t s; std::vector<Stage> st; };
+
+int run_chain(const std::vector<Stage>& st, hipStream_t s) {
+    for (const auto& f : st) RC(f(s));
+    return FBHIP_OK;
+}
+int run_interleaved(std::vector<Chain>& chains) {
+    for (size_t i = 0;; ++i) {
+        bool any = false;
+        for (auto& ch : chains)
+            if (i < ch.st.size()) { RC(ch.st[i](ch.s)); any = true; }
+        if (!any) return FBHIP_OK;
+    }
+}
+
 // ---- network passes --------------------------------------------------------------------------------------
 // ForwardMap.forward (fb_modules.py:186-199); Xa = [obs|action] panel, Xz = [obs|z] panel
-int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
-                    int rows, hipStream_t s) {
+void forward_map_fwd_stages(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
+                            int rows, std::vector<Stage>& out) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
-    RC(run_gemms(c, {P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, S.pre1a.p, H, rows, H, W.oa.k1, W.oa.b1, EPI_BIAS),
-                     P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, S.pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s));
-    HIPCK(c, launch_ln_tanh_fwd(S.pre1a.p, H, W.oa.g1, W.oa.be1, S.t1a.p, H, S.statsA, rows, H, s));
-    HIPCK(c, launch_ln_tanh_fwd(S.pre1z.p, H, W.oz.g1, W.oz.be1, S.t1z.p, H, S.statsZ, rows, H, s));
-    RC(run_gemms(c, {P(S.t1a.p, H, 1, W.oa.W2, H, 1, S.h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU),
-                     P(S.t1z.p, H, 1, W.oz.W2, H, 1, S.h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s));
-    RC(run_gemms(c, {P(S.h.p, 2 * Fd, 1, W.W3s, 2 * Fd, 1, S.p.p, 2 * H, rows, 2 * H, 2 * Fd, W.b3s, EPI_BIAS_RELU)}, s));
-    RC(run_gemms(c, {P(S.p.p, 2 * H, 1, W.W4[0], H, 1, S.F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS),
-                     P(S.p.p + H, 2 * H, 1, W.W4[1], H, 1, S.F2.p, Lz, rows, z, H, W.b4[1], EPI_BIAS)}, s));
-    return FBHIP_OK;
+    FSet* Sp = &S;
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, W.oa.k1, W.oa.b1, EPI_BIAS),
+                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, s));
+        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, s));
+        return (int)FBHIP_OK;
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU),
+                             P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Sp->h.p, 2 * Fd, 1, W.W3s, 2 * Fd, 1, Sp->p.p, 2 * H, rows, 2 * H, 2 * Fd, W.b3s, EPI_BIAS_RELU)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS),
+                             P(Sp->p.p + H, 2 * H, 1, W.W4[1], H, 1, Sp->F2.p, Lz, rows, z, H, W.b4[1], EPI_BIAS)}, s);
+    });
+}
+
+int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
+                    int rows, hipStream_t s) {
+    std::vector<Stage> st;
+    forward_map_fwd_stages(c, W, Xa, lda, Xz, ldz, S, rows, st);
+    return run_chain(st, s);
 }
 
 // dgrad: dp = (dF_i . W4_i) * relu'(p)   (shared by the FB backward and the actor step)
@@ -403,77 +441,138 @@ int forward_map_bwd_heads_dgrad(fbhip_ctx* c, const FwdP& W, FSet& S, int rows, 
 
 // full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383).  The data-gradient chain runs on
 // ``s``; each weight gradient only needs the chain's previous stage, so it is issued on ``sw`` and overlaps the chain.
-int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz, int ldz,
-                    FSet& S, int rows, hipStream_t s, hipStream_t sw) {
+void forward_map_bwd_stages(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz,
+                            int ldz, FSet& S, int rows, hipStream_t sw, std::vector<Stage>& out) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
-    Ws& w = c->w;
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(w.dF1.p, Lz, 0, S.p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]),
-                     P(w.dF2.p, Lz, 0, S.p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1])}, sw));
-    RC(forward_map_bwd_heads_dgrad(c, W, S, rows, s));
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(w.dp.p, 2 * H, 0, S.h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s)}, sw));
-    RC(run_gemms(c, {P(w.dp.p, 2 * H, 1, W.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, rows, 2 * Fd, 2 * H, nullptr, EPI_MASK_RELU, S.h.p, 2 * Fd)}, s));
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 0, S.t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2),
-                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, sw));
-    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, W.oa.W2, H, 0, w.dt1a.p, H, rows, H, Fd),
-                     P(w.dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w.dt1z.p, H, rows, H, Fd)}, s));
-    HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, S.t1a.p, H, S.pre1a.p, H, S.statsA, W.oa.g1, w.dt1a.p, H, G.oa.g1, G.oa.be1,
-                                w.ln_partials, rows, H, s));
-    HIPCK(c, launch_ln_tanh_bwd(w.dt1z.p, H, S.t1z.p, H, S.pre1z.p, H, S.statsZ, W.oz.g1, w.dt1z.p, H, G.oz.g1, G.oz.be1,
-                                w.ln_partials, rows, H, s));
-    RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1),
-                     P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
-    RC(sync_streams(c, sw, s));
-    return FBHIP_OK;
+    Ws* w = &c->w;
+    FSet* Sp = &S;
+    out.push_back([=](hipStream_t s) -> int {
+        RC(sync_streams(c, s, sw));
+        RC(run_gemms(c, {P(w->dF1.p, Lz, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]),
+                         P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1])}, sw));
+        return forward_map_bwd_heads_dgrad(c, W, *Sp, rows, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        RC(sync_streams(c, s, sw));
+        RC(run_gemms(c, {P(w->dp.p, 2 * H, 0, Sp->h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s)}, sw));
+        return run_gemms(c, {P(w->dp.p, 2 * H, 1, W.W3s, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, 2 * H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        RC(sync_streams(c, s, sw));
+        RC(run_gemms(c, {P(w->dh.p, 2 * Fd, 0, Sp->t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2),
+                         P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, sw));
+        return run_gemms(c, {P(w->dh.p, 2 * Fd, 1, W.oa.W2, H, 0, w->dt1a.p, H, rows, H, Fd),
+                             P(w->dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fd)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        HIPCK(c, launch_ln_tanh_bwd(w->dt1a.p, H, Sp->t1a.p, H, Sp->pre1a.p, H, Sp->statsA, W.oa.g1, w->dt1a.p, H, G.oa.g1,
+                                    G.oa.be1, w->ln_partials, rows, H, s));
+        HIPCK(c, launch_ln_tanh_bwd(w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
+                                    G.oz.be1, w->ln_partials, rows, H, s));
+        return (int)FBHIP_OK;
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        RC(run_gemms(c, {P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1),
+                         P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
+        return sync_streams(c, sw, s);
+    });
+}
+
+// full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383).  The data-gradient chain runs on
+// ``s``; each weight gradient only needs the chain's previous stage, so it is issued on ``sw`` and overlaps the chain.
+int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz, int ldz,
+                    FSet& S, int rows, hipStream_t s, hipStream_t sw) {
+    std::vector<Stage> st;
+    forward_map_bwd_stages(c, W, G, Xa, lda, Xz, ldz, S, rows, sw, st);
+    return run_chain(st, s);
 }
 
 // BackwardMap.forward (fb_modules.py:223-230)
-int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, hipStream_t s) {
+void backward_map_fwd_stages(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows,
+                             std::vector<Stage>& out) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad4(Hb), z = d.z_dim, Lz = pad4(z);
-    RC(run_gemms(c, {P(X, ldx, 1, W.W1, pad4(g), 1, S.pre1.p, Lb, rows, Hb, g, W.b1, EPI_BIAS)}, s));
-    HIPCK(c, launch_ln_tanh_fwd(S.pre1.p, Lb, W.g1, W.be1, S.t1.p, Lb, S.stats, rows, Hb, s));
-    RC(run_gemms(c, {P(S.t1.p, Lb, 1, W.W2, Lb, 1, S.r2.p, Lb, rows, Hb, Hb, W.b2, EPI_BIAS_RELU)}, s));
-    RC(run_gemms(c, {P(S.r2.p, Lb, 1, W.W3, Lb, 1, S.y.p, Lz, rows, z, Hb, W.b3, EPI_BIAS)}, s));
-    HIPCK(c, launch_l2norm_fwd(S.y.p, Lz, S.Bm.p, Lz, S.norms, rows, z, sqrtf((float)z), s));
-    return FBHIP_OK;
+    BSet* Sp = &S;
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(X, ldx, 1, W.W1, pad4(g), 1, Sp->pre1.p, Lb, rows, Hb, g, W.b1, EPI_BIAS)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1.p, Lb, W.g1, W.be1, Sp->t1.p, Lb, Sp->stats, rows, Hb, s));
+        return (int)FBHIP_OK;
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Sp->t1.p, Lb, 1, W.W2, Lb, 1, Sp->r2.p, Lb, rows, Hb, Hb, W.b2, EPI_BIAS_RELU)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        RC(run_gemms(c, {P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Hb, W.b3, EPI_BIAS)}, s));
+        HIPCK(c, launch_l2norm_fwd(Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z), s));
+        return (int)FBHIP_OK;
+    });
 }
 
-int backward_map_bwd(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S, const float* dy,
-                     int rows, hipStream_t s, hipStream_t sw) {
+int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, hipStream_t s) {
+    std::vector<Stage> st;
+    backward_map_fwd_stages(c, W, X, ldx, S, rows, st);
+    return run_chain(st, s);
+}
+
+void backward_map_bwd_stages(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S,
+                             const float* dy, int rows, std::vector<Stage>& out) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad4(Hb), z = d.z_dim, Lz = pad4(z);
-    Ws& w = c->w;
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(dy, Lz, 0, S.r2.p, Lb, 0, G.W3, Lb, z, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, sw));
-    RC(run_gemms(c, {P(dy, Lz, 1, W.W3, Lb, 0, w.b_dr2.p, Lb, rows, Hb, z, nullptr, EPI_MASK_RELU, S.r2.p, Lb)}, s));
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(w.b_dr2.p, Lb, 0, S.t1.p, Lb, 0, G.W2, Lb, Hb, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2)}, sw));
-    RC(run_gemms(c, {P(w.b_dr2.p, Lb, 1, W.W2, Lb, 0, w.b_dt1.p, Lb, rows, Hb, Hb)}, s));
-    HIPCK(c, launch_ln_tanh_bwd(w.b_dt1.p, Lb, S.t1.p, Lb, S.pre1.p, Lb, S.stats, W.g1, w.b_dt1.p, Lb, G.g1, G.be1,
-                                w.ln_partials_b, rows, Hb, s));
-    RC(run_gemms(c, {P(w.b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad4(g), Hb, g, rows, nullptr, EPI_NONE, nullptr, 0, G.b1)}, s));
-    RC(sync_streams(c, sw, s));
-    return FBHIP_OK;
+    Ws* w = &c->w;
+    BSet* Sp = &S;
+    out.push_back([=](hipStream_t s) -> int {          // wgrad and dgrad of the head share one launch
+        return run_gemms(c, {P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3),
+                             P(dy, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Hb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(w->b_dr2.p, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Hb, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2),
+                             P(w->b_dr2.p, Lb, 1, W.W2, Lb, 0, w->b_dt1.p, Lb, rows, Hb, Hb)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        HIPCK(c, launch_ln_tanh_bwd(w->b_dt1.p, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, w->b_dt1.p, Lb, G.g1,
+                                    G.be1, w->ln_partials_b, rows, Hb, s));
+        return (int)FBHIP_OK;
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad4(g), Hb, g, rows, nullptr, EPI_NONE, nullptr, 0, G.b1)}, s);
+    });
+}
+
+void actor_fwd_stages(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S,
+                      int rows, std::vector<Stage>& out) {
+    const fbhip_dims& d = c->d;
+    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
+    ASet* Sp = &S;
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, Sp->pre1o.p, H, rows, H, W.o.k1, W.o.b1, EPI_BIAS),
+                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, s));
+        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, s));
+        return (int)FBHIP_OK;
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Sp->t1o.p, H, 1, W.o.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU),
+                             P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Sp->h.p, 2 * Fd, 1, W.W3, 2 * Fd, 1, Sp->p.p, H, rows, H, 2 * Fd, W.b3, EPI_BIAS_RELU)}, s);
+    });
+    out.push_back([=](hipStream_t s) -> int {
+        return run_gemms(c, {P(Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS)}, s);
+    });
 }
 
 // Actor.forward up to the pre-tanh policy output (fb_modules.py:107-121); Xo supplies obs (first o cols)
 int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
               hipStream_t s) {
-    const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
-    RC(run_gemms(c, {P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, S.pre1o.p, H, rows, H, W.o.k1, W.o.b1, EPI_BIAS),
-                     P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, S.pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s));
-    HIPCK(c, launch_ln_tanh_fwd(S.pre1o.p, H, W.o.g1, W.o.be1, S.t1o.p, H, S.statsO, rows, H, s));
-    HIPCK(c, launch_ln_tanh_fwd(S.pre1z.p, H, W.oz.g1, W.oz.be1, S.t1z.p, H, S.statsZ, rows, H, s));
-    RC(run_gemms(c, {P(S.t1o.p, H, 1, W.o.W2, H, 1, S.h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU),
-                     P(S.t1z.p, H, 1, W.oz.W2, H, 1, S.h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s));
-    RC(run_gemms(c, {P(S.h.p, 2 * Fd, 1, W.W3, 2 * Fd, 1, S.p.p, H, rows, H, 2 * Fd, W.b3, EPI_BIAS_RELU)}, s));
-    RC(run_gemms(c, {P(S.p.p, H, 1, W.W4, H, 1, S.premu.p, La, rows, a, H, W.b4, EPI_BIAS)}, s));
-    return FBHIP_OK;
+    std::vector<Stage> st;
+    actor_fwd_stages(c, W, Xo, ldo, Xz, ldz, S, rows, st);
+    return run_chain(st, s);
 }
 
 int actor_bwd(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S,
@@ -554,15 +653,23 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     if (mask & FBHIP_PHASE_FB_GRAD) {
         RC(sync_streams(c, s, sA));
         RC(sync_streams(c, s, sB));
-        // --- [s] targets, no grad (fb_ddpg.py:303-315): actor -> next_action -> forward_target
-        RC(actor_fwd(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, s));
-        HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_next, a, hp.stddev, hp.stddev_clip, nullptr, 0,
-                                      w.Xnoa.p + o, w.Xnoa.ld, B, a, s));
-        RC(forward_map_fwd(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, s));
-        // --- [sA] online F (fb_ddpg.py:318);  [sB] target B then online B (:312, :319)
-        RC(forward_map_fwd(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, sA));
-        RC(backward_map_fwd(c, c->K_t, next_goal, ld_ng, w.bsA, B, sB));
-        RC(backward_map_fwd(c, c->K_p, next_goal, ld_ng, w.bsO, B, sB));
+        {
+            // [s]  targets, no grad (fb_ddpg.py:303-315): actor -> next_action -> forward_target   (critical chain)
+            // [sA] online F (fb_ddpg.py:318)      [sB] target B then online B (:312, :319)
+            std::vector<Chain> ch(3);
+            ch[0].s = s; ch[1].s = sA; ch[2].s = sB;
+            actor_fwd_stages(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0].st);
+            ch[0].st.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_next, a, hp.stddev, hp.stddev_clip, nullptr, 0,
+                                              w.Xnoa.p + o, w.Xnoa.ld, B, a, q));
+                return (int)FBHIP_OK;
+            });
+            forward_map_fwd_stages(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0].st);
+            forward_map_fwd_stages(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1].st);
+            backward_map_fwd_stages(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch[2].st);
+            backward_map_fwd_stages(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch[2].st);
+            RC(run_interleaved(ch));
+        }
         RC(sync_streams(c, sA, s));
         RC(sync_streams(c, sB, s));
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
@@ -579,22 +686,36 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, w.bsO.Bm.p, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
         }
-        // --- backward (fb_ddpg.py:383): forward_net on [s]+[sW], backward_net on [sA]
+        // --- backward (fb_ddpg.py:383): forward_net on [s]+[sW] (critical), backward_net on [sA], and on [sB] the
+        // actor's own forward pass of update_actor (fb_ddpg.py:395-397): it reads only the actor weights and (obs, z),
+        // so it runs under the FB backward instead of after fb_opt.step()
         RC(sync_streams(c, s, sA));
         RC(sync_streams(c, s, sB));
-        HIPCK(c, launch_l2norm_bwd(w.dBm.p, Lz, w.bsO.y.p, Lz, w.bsO.norms, w.dy.p, Lz, B, z, sA));
-        RC(backward_map_bwd(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, sA, (c->parallel & 4) ? sB : sA));
-        if (early_actor) {
-            // [sB] the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights
-            // and (obs, z): it runs here, under the FB backward, instead of after fb_opt.step()
-            RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, sB));
-            HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
-                                          w.Xopi.p + o, w.Xopi.ld, B, a, sB));
+        {
+            std::vector<Chain> ch(3);
+            ch[0].s = s; ch[1].s = sA; ch[2].s = sB;
+            forward_map_bwd_stages(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, sW, ch[0].st);
+            ch[1].st.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_l2norm_bwd(w.dBm.p, Lz, w.bsO.y.p, Lz, w.bsO.norms, w.dy.p, Lz, B, z, q));
+                return (int)FBHIP_OK;
+            });
+            backward_map_bwd_stages(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, ch[1].st);
+            if (early_actor) {
+                actor_fwd_stages(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2].st);
+                ch[2].st.push_back([=, &w](hipStream_t q) -> int {
+                    HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p,
+                                                  La, w.Xopi.p + o, w.Xopi.ld, B, a, q));
+                    return (int)FBHIP_OK;
+                });
+            }
+            // Adam step counts / bias corrections for the optimiser steps of this call, off the critical path
+            ch[2].st.push_back([=, &w](hipStream_t q) -> int {
+                if (mask & FBHIP_PHASE_FB_STEP) HIPCK(c, launch_step_advance(w.st, 0, q));
+                if (early_actor && (mask & FBHIP_PHASE_ACTOR_STEP)) HIPCK(c, launch_step_advance(w.st, 1, q));
+                return (int)FBHIP_OK;
+            });
+            RC(run_interleaved(ch));
         }
-        // Adam step counts / bias corrections for the optimiser steps of this call, off the critical path
-        if (mask & FBHIP_PHASE_FB_STEP) HIPCK(c, launch_step_advance(w.st, 0, sB));
-        if (early_actor && (mask & FBHIP_PHASE_ACTOR_STEP)) HIPCK(c, launch_step_advance(w.st, 1, sB));
-        RC(forward_map_bwd(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s, sW));
         RC(sync_streams(c, sA, s));
         RC(sync_streams(c, sB, s));     // every forked stream re-joins the origin stream DIRECTLY (hipStreamEndCapture
                                         // faults on a branch that is only joined transitively through another branch)
