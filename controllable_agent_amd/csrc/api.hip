@@ -31,23 +31,30 @@ struct NetLayout {
     int64_t nparams = 0;                // logical parameter count
 };
 
+// Internal padding (zero rows / columns that provably stay zero under the update): first-layer
+// input widths are padded to a multiple of 32 and the BackwardMap hidden width (526 by default) to a multiple of 64,
+// so every GEMM tile of those layers is interior and every K chunk full -> the branch-free loader applies.
+inline int pad32(int x) { return (x + 31) & ~31; }
+inline int pad64(int x) { return (x + 63) & ~63; }
+
 struct LayoutBuilder {
     NetLayout L;
     int64_t cur = 0;
-    void mat(const std::string& n, int rows, int cols) {
-        Slot s{n, cur, rows, cols, pad4(cols)};
-        cur += (int64_t)rows * s.ld;
+    // logical [rows x cols]; physical leading dimension ld (>= cols) and phys_rows (>= rows) allocated
+    void mat(const std::string& n, int rows, int cols, int ld = 0, int phys_rows = 0) {
+        Slot s{n, cur, rows, cols, ld > 0 ? ld : pad4(cols)};
+        cur += (int64_t)(phys_rows > 0 ? phys_rows : rows) * s.ld;
         L.by_name[n] = s;
         L.nparams += (int64_t)rows * cols;
     }
-    void vec(const std::string& n, int len) {
-        Slot s{n, cur, 1, len, pad4(len)};
+    void vec(const std::string& n, int len, int phys_len = 0) {
+        Slot s{n, cur, 1, len, phys_len > 0 ? phys_len : pad4(len)};
         cur += s.ld;
         L.by_name[n] = s;
         L.nparams += len;
     }
     void trunk(const std::string& p, int in, int H, int Fd) {     // mlp(in, H, "ntanh", Fd, "irelu"), fb_modules.py:60-78
-        mat(p + ".0.weight", H, in); vec(p + ".0.bias", H);
+        mat(p + ".0.weight", H, in, pad32(in)); vec(p + ".0.bias", H);
         vec(p + ".1.weight", H); vec(p + ".1.bias", H);
         mat(p + ".3.weight", Fd, H); vec(p + ".3.bias", Fd);
     }
@@ -80,9 +87,11 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
         append(order, {"F1.0.weight", "F1.0.bias", "F1.2.weight", "F1.2.bias",
                        "F2.0.weight", "F2.0.bias", "F2.2.weight", "F2.2.bias"});
     } else if (net == FBHIP_NET_BACKWARD) {       // BackwardMap, fb_modules.py:220
-        b.mat("B.0.weight", Hb, g); b.vec("B.0.bias", Hb); b.vec("B.1.weight", Hb); b.vec("B.1.bias", Hb);
-        b.mat("B.3.weight", Hb, Hb); b.vec("B.3.bias", Hb);
-        b.mat("B.5.weight", z, Hb); b.vec("B.5.bias", z);
+        const int HbP = pad64(Hb);
+        b.mat("B.0.weight", Hb, g, pad32(g), HbP); b.vec("B.0.bias", Hb, HbP); b.vec("B.1.weight", Hb, HbP);
+        b.vec("B.1.bias", Hb, HbP);
+        b.mat("B.3.weight", Hb, Hb, HbP, HbP); b.vec("B.3.bias", Hb, HbP);
+        b.mat("B.5.weight", z, Hb, HbP); b.vec("B.5.bias", z);
         order = {"B.0.weight", "B.0.bias", "B.1.weight", "B.1.bias", "B.3.weight", "B.3.bias", "B.5.weight", "B.5.bias"};
     } else {                                      // Actor, fb_modules.py:91-105
         b.trunk("obs_net", o, H, Fd);
@@ -119,7 +128,7 @@ struct Ws {
     float* metrics = nullptr;
     unsigned long long* perm_keys = nullptr;
     SampleOut so{};
-    Buf Xoa, Xoz, Xnoz, Xnoa, Xopi, next_goal, bin, z, zrand;
+    Buf Xoa, Xoz, Xnoz, Xnoa, Xopi, Xo, next_goal, bin, z, zrand;
     float* disc = nullptr;
     BSet bsA, bsO;
     FSet fsT, fsO;
@@ -143,9 +152,9 @@ struct Carver {
         return p;
     }
     float* f(size_t n) { return (float*)take(n * sizeof(float)); }
-    Buf buf(int rows, int cols) {
+    Buf buf(int rows, int cols, int ld = 0) {
         Buf b;
-        b.rows = rows; b.cols = cols; b.ld = pad4(cols);
+        b.rows = rows; b.cols = cols; b.ld = ld > 0 ? ld : pad4(cols);
         b.p = f((size_t)rows * b.ld);
         return b;
     }
@@ -166,11 +175,15 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.so.z_gauss = c.f((size_t)B * z);
     w.so.eps_next = c.f((size_t)B * a);
     w.so.eps_actor = c.f((size_t)B * a);
-    w.Xoa = c.buf(B, o + a); w.Xoz = c.buf(B, o + z); w.Xnoz = c.buf(B, o + z); w.Xnoa = c.buf(B, o + a);
-    w.Xopi = c.buf(B, o + a); w.next_goal = c.buf(B, g); w.bin = c.buf(B, g); w.z = c.buf(B, z); w.zrand = c.buf(B, z);
+    // input panels: widths padded to 32 (pad columns stay zero: the workspace is zero-initialised by the host and
+    // no kernel writes them)
+    w.Xoa = c.buf(B, o + a, pad32(o + a)); w.Xoz = c.buf(B, o + z, pad32(o + z)); w.Xnoz = c.buf(B, o + z, pad32(o + z));
+    w.Xnoa = c.buf(B, o + a, pad32(o + a)); w.Xopi = c.buf(B, o + a, pad32(o + a)); w.Xo = c.buf(B, o, pad32(o));
+    w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.z = c.buf(B, z); w.zrand = c.buf(B, z);
     w.disc = c.f(B);
     for (BSet* s : {&w.bsA, &w.bsO}) {
-        s->pre1 = c.buf(B, Hb); s->t1 = c.buf(B, Hb); s->r2 = c.buf(B, Hb); s->y = c.buf(B, z); s->Bm = c.buf(B, z);
+        s->pre1 = c.buf(B, Hb, pad64(Hb)); s->t1 = c.buf(B, Hb, pad64(Hb)); s->r2 = c.buf(B, Hb, pad64(Hb));
+        s->y = c.buf(B, z); s->Bm = c.buf(B, z);
         s->stats = c.f(2 * (size_t)B); s->norms = c.f(B);
     }
     for (FSet* s : {&w.fsT, &w.fsO}) {
@@ -183,7 +196,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.as.statsO = c.f(2 * (size_t)B); w.as.statsZ = c.f(2 * (size_t)B);
     w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
     w.dp = c.buf(B, 2 * H); w.dh = c.buf(B, 2 * Fd); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
-    w.b_dr2 = c.buf(B, Hb); w.b_dt1 = c.buf(B, Hb); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
+    w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
     w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
     w.ln_partials = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
@@ -402,8 +415,8 @@ void forward_map_fwd_stages(fbhip_ctx* c, const FwdP& W, const float* Xa, int ld
     const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
     FSet* Sp = &S;
     out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, W.oa.k1, W.oa.b1, EPI_BIAS),
-                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s);
+        return run_gemms(c, {P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, W.oa.ld1, W.oa.b1, EPI_BIAS),
+                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
         HIPCK(c, launch_ln_tanh_fwd(Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, s));
@@ -473,8 +486,8 @@ void forward_map_bwd_stages(fbhip_ctx* c, const FwdP& W, const FwdP& G, const fl
         return (int)FBHIP_OK;
     });
     out.push_back([=](hipStream_t s) -> int {
-        RC(run_gemms(c, {P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1),
-                         P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
+        RC(run_gemms(c, {P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1),
+                         P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
         return sync_streams(c, sw, s);
     });
 }
@@ -492,20 +505,25 @@ int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa,
 void backward_map_fwd_stages(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows,
                              std::vector<Stage>& out) {
     const fbhip_dims& d = c->d;
-    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad4(Hb), z = d.z_dim, Lz = pad4(z);
+    // GEMMs run on the padded width Lb = pad64(Hb) (zero weight rows / columns), LayerNorm on the logical Hb
+    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
+    // workspace panels have >= pad32(g) finite columns per row (the weight's pad columns are zero, so whatever sits
+    // there contributes nothing); arbitrary caller tensors are read on their logical width
+    const bool in_ws = (const char*)X >= (const char*)c->w.st && (const char*)X < (const char*)c->w.st + c->w.total_bytes;
+    const int Kg = (in_ws && ldx >= pad32(g)) ? pad32(g) : g;
     BSet* Sp = &S;
     out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(X, ldx, 1, W.W1, pad4(g), 1, Sp->pre1.p, Lb, rows, Hb, g, W.b1, EPI_BIAS)}, s);
+        return run_gemms(c, {P(X, ldx, 1, W.W1, pad32(g), 1, Sp->pre1.p, Lb, rows, Lb, Kg, W.b1, EPI_BIAS)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
         HIPCK(c, launch_ln_tanh_fwd(Sp->pre1.p, Lb, W.g1, W.be1, Sp->t1.p, Lb, Sp->stats, rows, Hb, s));
         return (int)FBHIP_OK;
     });
     out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->t1.p, Lb, 1, W.W2, Lb, 1, Sp->r2.p, Lb, rows, Hb, Hb, W.b2, EPI_BIAS_RELU)}, s);
+        return run_gemms(c, {P(Sp->t1.p, Lb, 1, W.W2, Lb, 1, Sp->r2.p, Lb, rows, Lb, Lb, W.b2, EPI_BIAS_RELU)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
-        RC(run_gemms(c, {P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Hb, W.b3, EPI_BIAS)}, s));
+        RC(run_gemms(c, {P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Lb, W.b3, EPI_BIAS)}, s));
         HIPCK(c, launch_l2norm_fwd(Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z), s));
         return (int)FBHIP_OK;
     });
@@ -520,16 +538,19 @@ int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet&
 void backward_map_bwd_stages(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S,
                              const float* dy, int rows, std::vector<Stage>& out) {
     const fbhip_dims& d = c->d;
-    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad4(Hb), z = d.z_dim, Lz = pad4(z);
+    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
+    // weight gradient of the first layer: X must be a zero-padded panel to use the padded width
+    const bool padded_x = (X == c->w.next_goal.p) || (X == c->w.bin.p);     // zero-padded panels only
+    const int Ng = padded_x ? pad32(g) : g;
     Ws* w = &c->w;
     BSet* Sp = &S;
-    out.push_back([=](hipStream_t s) -> int {          // wgrad and dgrad of the head share one launch
-        return run_gemms(c, {P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3),
-                             P(dy, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Hb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb)}, s);
+    out.push_back([=](hipStream_t s) -> int {
+        RC(run_gemms(c, {P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, s));
+        return run_gemms(c, {P(dy, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(w->b_dr2.p, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Hb, Hb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2),
-                             P(w->b_dr2.p, Lb, 1, W.W2, Lb, 0, w->b_dt1.p, Lb, rows, Hb, Hb)}, s);
+        RC(run_gemms(c, {P(w->b_dr2.p, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Lb, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2)}, s));
+        return run_gemms(c, {P(w->b_dr2.p, Lb, 1, W.W2, Lb, 0, w->b_dt1.p, Lb, rows, Lb, Lb)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
         HIPCK(c, launch_ln_tanh_bwd(w->b_dt1.p, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, w->b_dt1.p, Lb, G.g1,
@@ -537,7 +558,7 @@ void backward_map_bwd_stages(fbhip_ctx* c, const BwdP& W, const BwdP& G, const f
         return (int)FBHIP_OK;
     });
     out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad4(g), Hb, g, rows, nullptr, EPI_NONE, nullptr, 0, G.b1)}, s);
+        return run_gemms(c, {P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad32(g), Lb, Ng, rows, nullptr, EPI_NONE, nullptr, 0, G.b1)}, s);
     });
 }
 
@@ -547,8 +568,8 @@ void actor_fwd_stages(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, con
     const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
     ASet* Sp = &S;
     out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, Sp->pre1o.p, H, rows, H, W.o.k1, W.o.b1, EPI_BIAS),
-                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.k1, W.oz.b1, EPI_BIAS)}, s);
+        return run_gemms(c, {P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, Sp->pre1o.p, H, rows, H, W.o.ld1, W.o.b1, EPI_BIAS),
+                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
         HIPCK(c, launch_ln_tanh_fwd(Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, s));
@@ -596,8 +617,8 @@ int actor_bwd(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int l
                                 w.ln_partials, rows, H, s));
     HIPCK(c, launch_ln_tanh_bwd(w.dt1z.p, H, S.t1z.p, H, S.pre1z.p, H, S.statsZ, W.oz.g1, w.dt1z.p, H, G.oz.g1, G.oz.be1,
                                 w.ln_partials, rows, H, s));
-    RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1),
-                     P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.k1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
+    RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1),
+                     P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
     RC(sync_streams(c, sw, s));
     return FBHIP_OK;
 }
@@ -608,8 +629,9 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     Ws& w = c->w;
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
               Fd = d.feature_dim, Lz = pad4(z), La = pad4(a);
-    const float* next_goal = d.use_goal ? w.next_goal.p : w.Xnoz.p;          // fb_ddpg.py:440-443
-    const int ld_ng = d.use_goal ? w.next_goal.ld : w.Xnoz.ld;
+    // next_goal = batch.next_goal if goal_space else batch.next_obs (fb_ddpg.py:440-443); always its own zero-padded panel
+    const float* next_goal = w.next_goal.p;
+    const int ld_ng = w.next_goal.ld;
 
     if (mask & FBHIP_PHASE_SAMPLE) {
         HIPCK(c, launch_step_advance(w.st, 2, s));
@@ -629,6 +651,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         ga.Xoa = w.Xoa.p; ga.ld_oa = w.Xoa.ld; ga.Xoz = w.Xoz.p; ga.ld_oz = w.Xoz.ld; ga.Xnoz = w.Xnoz.p; ga.ld_noz = w.Xnoz.ld;
         ga.Xnoa = w.Xnoa.p; ga.ld_noa = w.Xnoa.ld; ga.Xopi = w.Xopi.p; ga.ld_opi = w.Xopi.ld;
         ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
+        ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld;
         ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount;
         HIPCK(c, launch_gather(ga, s));
         // sample_z: sqrt(d) * normalize(gauss)   (fb_ddpg.py:224-228)
@@ -701,7 +724,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             });
             backward_map_bwd_stages(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, ch[1].st);
             if (early_actor) {
-                actor_fwd_stages(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2].st);
+                actor_fwd_stages(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2].st);
                 ch[2].st.push_back([=, &w](hipStream_t q) -> int {
                     HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p,
                                                   La, w.Xopi.p + o, w.Xopi.ld, B, a, q));
@@ -733,7 +756,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
 
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
         if (!early_actor) {
-            RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
+            RC(actor_fwd(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
             HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
                                           w.Xopi.p + o, w.Xopi.ld, B, a, s));
         }
@@ -753,7 +776,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
         RC(run_gemms(c, {P(w.dt1a.p, H, 1, c->F_p.oa.W1 + o, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
                            EPI_TANH_BWD, w.as.mu.p, La)}, s));
-        RC(actor_bwd(c, c->A_p, c->A_g, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s, sW));
+        RC(actor_bwd(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s, sW));
     }
 
     if (mask & FBHIP_PHASE_ACTOR_STEP) {        // actor_opt.step(), fb_ddpg.py:411

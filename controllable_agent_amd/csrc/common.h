@@ -122,7 +122,8 @@ struct GatherArgs {
     float* Xnoz; int ld_noz;    // [next_obs | z]
     float* Xnoa; int ld_noa;    // [next_obs | next_action]  (action filled later)
     float* Xopi; int ld_opi;    // [obs | pi action]         (action filled later)
-    float* next_goal; int ld_ng;    // only when use_goal
+    float* Xo; int ld_o;        // [obs] alone (zero padded: operand of the actor's obs_net weight gradient)
+    float* next_goal; int ld_ng;    // goal[ep, step] if use_goal else next_obs
     float* bin; int ld_bin;     // backward_input[perm]
     float* disc;
     int B, o, a, g, use_goal; float gamma;

@@ -132,12 +132,13 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
         g.Xoa[(size_t)i * g.ld_oa + j] = ov;
         g.Xoz[(size_t)i * g.ld_oz + j] = ov;
         g.Xopi[(size_t)i * g.ld_opi + j] = ov;
+        g.Xo[(size_t)i * g.ld_o + j] = ov;
         g.Xnoz[(size_t)i * g.ld_noz + j] = nv;
         g.Xnoa[(size_t)i * g.ld_noa + j] = nv;
     }
     copy_row(g.Xoa + (size_t)i * g.ld_oa + g.o, act, g.a, lane);
     if (lane == 0) g.disc[i] = g.gamma * g.rv.discount[t];            // discount * storage['discount'] (:171)
-    if (g.use_goal) copy_row(g.next_goal + (size_t)i * g.ld_ng, g.rv.goal + t * g.g, g.g, lane);
+    copy_row(g.next_goal + (size_t)i * g.ld_ng, g.use_goal ? g.rv.goal + t * g.g : nobs, g.g, lane);
     // backward_input[perm] (fb_ddpg.py:460-468): row i of the permuted panel is transition perm[i]
     const int pi = g.perm[i];
     const size_t tp = (size_t)g.ep_idx[pi] * g.rv.t1 + g.step_idx[pi] - 1;
