@@ -199,7 +199,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
     w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
-    w.ln_partials = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
+    w.ln_partials = c.f((size_t)2 * ((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);   // two trunks
     w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
     w.splitk = c.f((size_t)(1 + 3) * ((size_t)6 << 20));
@@ -419,8 +419,11 @@ void forward_map_fwd_stages(fbhip_ctx* c, const FwdP& W, const float* Xa, int ld
                              P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
-        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, s));
-        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, s));
+        LnFwdGroup g{};
+        g.n = 2;
+        g.p[0] = LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0};
+        g.p[1] = LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0};
+        HIPCK(c, launch_ln_tanh_fwd_group(g, s));
         return (int)FBHIP_OK;
     });
     out.push_back([=](hipStream_t s) -> int {
@@ -479,10 +482,14 @@ void forward_map_bwd_stages(fbhip_ctx* c, const FwdP& W, const FwdP& G, const fl
                              P(w->dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fd)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
-        HIPCK(c, launch_ln_tanh_bwd(w->dt1a.p, H, Sp->t1a.p, H, Sp->pre1a.p, H, Sp->statsA, W.oa.g1, w->dt1a.p, H, G.oa.g1,
-                                    G.oa.be1, w->ln_partials, rows, H, s));
-        HIPCK(c, launch_ln_tanh_bwd(w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
-                                    G.oz.be1, w->ln_partials, rows, H, s));
+        const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
+        LnBwdGroup g{};
+        g.n = 2;
+        g.p[0] = LnBwdProblem{w->dt1a.p, H, Sp->t1a.p, H, Sp->pre1a.p, H, Sp->statsA, W.oa.g1, w->dt1a.p, H, G.oa.g1, G.oa.be1,
+                              w->ln_partials, rows, H, 0, 0, 0, 0, 0};
+        g.p[1] = LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1, G.oz.be1,
+                              w->ln_partials + half, rows, H, 0, 0, 0, 0, 0};
+        HIPCK(c, launch_ln_tanh_bwd_group(g, s));
         return (int)FBHIP_OK;
     });
     out.push_back([=](hipStream_t s) -> int {
@@ -572,8 +579,11 @@ void actor_fwd_stages(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, con
                              P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS)}, s);
     });
     out.push_back([=](hipStream_t s) -> int {
-        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, s));
-        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, s));
+        LnFwdGroup g{};
+        g.n = 2;
+        g.p[0] = LnFwdProblem{Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, 0, 0, 0};
+        g.p[1] = LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0};
+        HIPCK(c, launch_ln_tanh_fwd_group(g, s));
         return (int)FBHIP_OK;
     });
     out.push_back([=](hipStream_t s) -> int {
@@ -613,10 +623,16 @@ int actor_bwd(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int l
                      P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, sw));
     RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, W.o.W2, H, 0, w.dt1a.p, H, rows, H, Fd),
                      P(w.dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w.dt1z.p, H, rows, H, Fd)}, s));
-    HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, S.t1o.p, H, S.pre1o.p, H, S.statsO, W.o.g1, w.dt1a.p, H, G.o.g1, G.o.be1,
-                                w.ln_partials, rows, H, s));
-    HIPCK(c, launch_ln_tanh_bwd(w.dt1z.p, H, S.t1z.p, H, S.pre1z.p, H, S.statsZ, W.oz.g1, w.dt1z.p, H, G.oz.g1, G.oz.be1,
-                                w.ln_partials, rows, H, s));
+    {
+        const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
+        LnBwdGroup g{};
+        g.n = 2;
+        g.p[0] = LnBwdProblem{w.dt1a.p, H, S.t1o.p, H, S.pre1o.p, H, S.statsO, W.o.g1, w.dt1a.p, H, G.o.g1, G.o.be1,
+                              w.ln_partials, rows, H, 0, 0, 0, 0, 0};
+        g.p[1] = LnBwdProblem{w.dt1z.p, H, S.t1z.p, H, S.pre1z.p, H, S.statsZ, W.oz.g1, w.dt1z.p, H, G.oz.g1, G.oz.be1,
+                              w.ln_partials + half, rows, H, 0, 0, 0, 0, 0};
+        HIPCK(c, launch_ln_tanh_bwd_group(g, s));
+    }
     RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1),
                      P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
     RC(sync_streams(c, sw, s));

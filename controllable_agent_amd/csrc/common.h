@@ -57,6 +57,16 @@ hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy
                               const float* stats, const float* gamma, float* dx, int lddx,
                               float* dgamma, float* dbeta, float* partials, int rows, int n, hipStream_t s);
 constexpr int LN_BWD_ROWS_PER_BLOCK = 8;
+// grouped variants: the two trunks of a net (independent rows, different parameters) share one launch
+struct LnFwdProblem { const float* x; int ldx; const float* gamma; const float* beta; float* y; int ldy; float* stats;
+                      int rows, n, vx, vy, vp; };
+struct LnFwdGroup { LnFwdProblem p[2]; int n; };
+hipError_t launch_ln_tanh_fwd_group(LnFwdGroup g, hipStream_t s);
+struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* stats;
+                      const float* gamma; float* dx; int lddx; float* dgamma; float* dbeta; float* partials;
+                      int rows, n, vdy, vy, vx, vdx, vp; };
+struct LnBwdGroup { LnBwdProblem p[2]; int n; };
+hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s);
 hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float* norms, int rows, int d,
                              float scale, hipStream_t s);
 // policy head: mu = tanh(pre); action = clampST(mu + clip(noise*std))   (utils.py:171-185)

@@ -51,11 +51,11 @@ static inline bool aligned16(const void* p, int ld) { return (((uintptr_t)p & 15
 
 // ------------------------------------------------------------------------------------------------------
 template <int MAXQ>
-__global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const float* __restrict__ x, int ldx,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ y,
-                                                          int ldy, float* __restrict__ stats, int rows, int n,
-                                                          int vx, int vy, int vp) {
+__global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const LnFwdGroup g) {
+    const LnFwdProblem& p = g.p[blockIdx.y];
+    const float* __restrict__ x = p.x;
+    float* __restrict__ y = p.y;
+    const int ldx = p.ldx, ldy = p.ldy, rows = p.rows, n = p.n, vx = p.vx, vy = p.vy, vp = p.vp;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * ldx;
@@ -81,32 +81,47 @@ __global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const float* __restric
     for (int i = 0; i < MAXQ; ++i) {
         const int n0 = 4 * (lane + 64 * i);
         if (n0 < n) {
-            const float4 g = ld4(gamma, n0, n, vp), b = ld4(beta, n0, n, vp);
+            const float4 gm = ld4(p.gamma, n0, n, vp), b = ld4(p.beta, n0, n, vp);
             float4 o;
-            o.x = tanhf((v[i].x - mean) * rstd * g.x + b.x);
-            o.y = tanhf((v[i].y - mean) * rstd * g.y + b.y);
-            o.z = tanhf((v[i].z - mean) * rstd * g.z + b.z);
-            o.w = tanhf((v[i].w - mean) * rstd * g.w + b.w);
+            o.x = tanhf((v[i].x - mean) * rstd * gm.x + b.x);
+            o.y = tanhf((v[i].y - mean) * rstd * gm.y + b.y);
+            o.z = tanhf((v[i].z - mean) * rstd * gm.z + b.z);
+            o.w = tanhf((v[i].w - mean) * rstd * gm.w + b.w);
             st4(yr, n0, n, vy, o);
         }
     }
     if (lane == 0) {
-        stats[2 * row] = mean;
-        stats[2 * row + 1] = rstd;
+        p.stats[2 * row] = mean;
+        p.stats[2 * row + 1] = rstd;
     }
+}
+
+hipError_t launch_ln_tanh_fwd_group(LnFwdGroup g, hipStream_t s) {
+    if (g.n < 1) return hipSuccess;
+    int maxrows = 0, maxn = 0;
+    for (int i = 0; i < g.n; ++i) {
+        LnFwdProblem& p = g.p[i];
+        if (p.n > 2048) return hipErrorInvalidValue;
+        p.vx = aligned16(p.x, p.ldx); p.vy = aligned16(p.y, p.ldy);
+        p.vp = aligned16(p.gamma, 4) && aligned16(p.beta, 4);
+        maxrows = p.rows > maxrows ? p.rows : maxrows;
+        maxn = p.n > maxn ? p.n : maxn;
+    }
+    if (maxrows <= 0) return hipSuccess;
+    dim3 grid((maxrows + 3) / 4, g.n), block(256);
+    const int q = (maxn + 255) / 256;
+#define LN_FWD(Q) hipLaunchKernelGGL((ln_tanh_fwd_kernel<Q>), grid, block, 0, s, g)
+    if (q <= 1) LN_FWD(1); else if (q <= 2) LN_FWD(2); else if (q <= 3) LN_FWD(3); else if (q <= 4) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
+    return hipGetLastError();
 }
 
 hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
                               float* stats, int rows, int n, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    if (n > 2048) return hipErrorInvalidValue;
-    const int vx = aligned16(x, ldx), vy = aligned16(y, ldy), vp = aligned16(gamma, 4) && aligned16(beta, 4);
-    dim3 grid((rows + 3) / 4), block(256);
-    const int q = (n + 255) / 256;
-#define LN_FWD(Q) hipLaunchKernelGGL((ln_tanh_fwd_kernel<Q>), grid, block, 0, s, x, ldx, gamma, beta, y, ldy, stats, rows, n, vx, vy, vp)
-    if (q <= 1) LN_FWD(1); else if (q <= 2) LN_FWD(2); else if (q <= 3) LN_FWD(3); else if (q <= 4) LN_FWD(4); else LN_FWD(8);
-#undef LN_FWD
-    return hipGetLastError();
+    LnFwdGroup g{};
+    g.n = 1;
+    g.p[0] = LnFwdProblem{x, ldx, gamma, beta, y, ldy, stats, rows, n, 0, 0, 0};
+    return launch_ln_tanh_fwd_group(g, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -115,14 +130,13 @@ hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const
 // Each workgroup owns LN_BWD_ROWS_PER_BLOCK rows (2 per wave) and emits one partial row of (dgamma, dbeta);
 // a second tiny kernel folds the partial rows in a fixed order (deterministic, no atomics).
 template <int MAXQ>
-__global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const float* __restrict__ dy, int lddy,
-                                                          const float* __restrict__ y, int ldy,
-                                                          const float* __restrict__ x, int ldx,
-                                                          const float* __restrict__ stats,
-                                                          const float* __restrict__ gamma, float* __restrict__ dx,
-                                                          int lddx, float* __restrict__ partials, int rows, int n,
-                                                          int vdy, int vy, int vx, int vdx, int vp) {
+__global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const LnBwdGroup grp) {
     extern __shared__ float lds[];          // [4 waves][n] (used twice: dgamma then dbeta)
+    const LnBwdProblem& p = grp.p[blockIdx.y];
+    const int rows = p.rows, n = p.n;
+    if (blockIdx.x * LN_BWD_ROWS_PER_BLOCK >= rows) return;
+    const float* __restrict__ gamma = p.gamma;
+    float* __restrict__ partials = p.partials;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float4 pg[MAXQ], pb[MAXQ];
 #pragma unroll
@@ -132,17 +146,17 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const float* __restric
     for (int rr = 0; rr < LN_BWD_ROWS_PER_BLOCK / 4; ++rr) {
         const int row = blockIdx.x * LN_BWD_ROWS_PER_BLOCK + rr * 4 + wid;
         if (row >= rows) break;
-        const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-        const float* dyr = dy + (size_t)row * lddy;
-        const float* yr = y + (size_t)row * ldy;
-        const float* xr = x + (size_t)row * ldx;
+        const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
+        const float* dyr = p.dy + (size_t)row * p.lddy;
+        const float* yr = p.y + (size_t)row * p.ldy;
+        const float* xr = p.x + (size_t)row * p.ldx;
         float4 g[MAXQ], xh[MAXQ];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i) {
             const int n0 = 4 * (lane + 64 * i);
-            const float4 d = ld4(dyr, n0, n, vdy), yy = ld4(yr, n0, n, vy), xx = ld4(xr, n0, n, vx);
-            const float4 gm = ld4(gamma, n0, n, vp);
+            const float4 d = ld4(dyr, n0, n, p.vdy), yy = ld4(yr, n0, n, p.vy), xx = ld4(xr, n0, n, p.vx);
+            const float4 gm = ld4(gamma, n0, n, p.vp);
             float4 du, h;
             du.x = d.x * (1.f - yy.x * yy.x); du.y = d.y * (1.f - yy.y * yy.y);
             du.z = d.z * (1.f - yy.z * yy.z); du.w = d.w * (1.f - yy.w * yy.w);
@@ -156,7 +170,7 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const float* __restric
             pb[i].x += du.x; pb[i].y += du.y; pb[i].z += du.z; pb[i].w += du.w;
         }
         const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
-        float* dxr = dx + (size_t)row * lddx;
+        float* dxr = p.dx + (size_t)row * p.lddx;
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i) {
             const int n0 = 4 * (lane + 64 * i);
@@ -165,7 +179,7 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const float* __restric
             o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
             o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
             o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
-            st4(dxr, n0, n, vdx, o);
+            st4(dxr, n0, n, p.vdx, o);
         }
     }
     if (partials == nullptr) return;
@@ -190,45 +204,64 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const float* __restric
 
 // out[j] = sum_b partials[b][j], j < 2n.  Workgroup = 8 row-groups x 32 columns: every thread folds nb/8 partial
 // rows (coalesced 128-byte reads), the 8 group sums are combined in a fixed order through LDS.
-__global__ void __launch_bounds__(256) ln_colreduce_kernel(const float* __restrict__ partials, int nb, int n,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void __launch_bounds__(256) ln_colreduce_kernel(const LnBwdGroup grp) {
     __shared__ float red[8][32];
+    const LnBwdProblem& p = grp.p[blockIdx.y];
+    if (p.partials == nullptr) return;
+    const int n = p.n, nb = (p.rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK;
     const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + c;
+    if (blockIdx.x * 32 >= 2 * n) return;
     float s = 0.f;
     if (j < 2 * n)
-        for (int b = rg; b < nb; b += 8) s += partials[(size_t)b * 2 * n + j];
+        for (int b = rg; b < nb; b += 8) s += p.partials[(size_t)b * 2 * n + j];
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && j < 2 * n) {
         float t = red[0][c];
 #pragma unroll
         for (int k = 1; k < 8; ++k) t += red[k][c];
-        if (j < n) dgamma[j] = t; else dbeta[j - n] = t;
+        if (j < n) p.dgamma[j] = t; else p.dbeta[j - n] = t;
     }
+}
+
+hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s) {
+    if (g.n < 1) return hipSuccess;
+    int maxrows = 0, maxn = 0;
+    bool any_param = false;
+    for (int i = 0; i < g.n; ++i) {
+        LnBwdProblem& p = g.p[i];
+        if (p.n > 2048) return hipErrorInvalidValue;
+        const bool want = p.dgamma != nullptr && p.dbeta != nullptr;
+        if (want && p.partials == nullptr) return hipErrorInvalidValue;
+        if (!want) p.partials = nullptr;
+        any_param |= want;
+        p.vdy = aligned16(p.dy, p.lddy); p.vy = aligned16(p.y, p.ldy); p.vx = aligned16(p.x, p.ldx);
+        p.vdx = aligned16(p.dx, p.lddx); p.vp = aligned16(p.gamma, 4);
+        maxrows = p.rows > maxrows ? p.rows : maxrows;
+        maxn = p.n > maxn ? p.n : maxn;
+    }
+    if (maxrows <= 0) return hipSuccess;
+    const int nb = (maxrows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK;
+    dim3 grid(nb, g.n), block(256);
+    const size_t shmem = (size_t)4 * maxn * sizeof(float);
+    const int q = (maxn + 255) / 256;
+#define LN_BWD(Q) hipLaunchKernelGGL((ln_tanh_bwd_kernel<Q>), grid, block, shmem, s, g)
+    if (q <= 1) LN_BWD(1); else if (q <= 2) LN_BWD(2); else if (q <= 3) LN_BWD(3); else if (q <= 4) LN_BWD(4); else LN_BWD(8);
+#undef LN_BWD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !any_param) return e;
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * maxn + 31) / 32, g.n), dim3(256), 0, s, g);
+    return hipGetLastError();
 }
 
 hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy, const float* x, int ldx,
                               const float* stats, const float* gamma, float* dx, int lddx, float* dgamma,
                               float* dbeta, float* partials, int rows, int n, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    if (n > 2048) return hipErrorInvalidValue;
-    const bool want = dgamma != nullptr && dbeta != nullptr;
-    if (want && partials == nullptr) return hipErrorInvalidValue;
-    const int nb = (rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK;
-    const int vdy = aligned16(dy, lddy), vy = aligned16(y, ldy), vx = aligned16(x, ldx), vdx = aligned16(dx, lddx);
-    const int vp = aligned16(gamma, 4);
-    float* part = want ? partials : nullptr;
-    dim3 grid(nb), block(256);
-    const size_t shmem = (size_t)4 * n * sizeof(float);
-    const int q = (n + 255) / 256;
-#define LN_BWD(Q) hipLaunchKernelGGL((ln_tanh_bwd_kernel<Q>), grid, block, shmem, s, dy, lddy, y, ldy, x, ldx, stats, gamma, dx, lddx, part, rows, n, vdy, vy, vx, vdx, vp)
-    if (q <= 1) LN_BWD(1); else if (q <= 2) LN_BWD(2); else if (q <= 3) LN_BWD(3); else if (q <= 4) LN_BWD(4); else LN_BWD(8);
-#undef LN_BWD
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !want) return e;
-    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * n + 31) / 32), dim3(256), 0, s, partials, nb, n, dgamma, dbeta);
-    return hipGetLastError();
+    LnBwdGroup g{};
+    g.n = 1;
+    g.p[0] = LnBwdProblem{dy, lddy, y, ldy, x, ldx, stats, gamma, dx, lddx, dgamma, dbeta, partials, rows, n, 0, 0, 0, 0, 0};
+    return launch_ln_tanh_bwd_group(g, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
