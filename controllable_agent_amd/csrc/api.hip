@@ -510,7 +510,7 @@ int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa,
 
 // BackwardMap.forward (fb_modules.py:223-230)
 void backward_map_fwd_stages(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows,
-                             std::vector<Stage>& out) {
+                             std::vector<Stage>& out, bool with_projection = true) {
     const fbhip_dims& d = c->d;
     // GEMMs run on the padded width Lb = pad64(Hb) (zero weight rows / columns), LayerNorm on the logical Hb
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
@@ -531,7 +531,7 @@ void backward_map_fwd_stages(fbhip_ctx* c, const BwdP& W, const float* X, int ld
     });
     out.push_back([=](hipStream_t s) -> int {
         RC(run_gemms(c, {P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Lb, W.b3, EPI_BIAS)}, s));
-        HIPCK(c, launch_l2norm_fwd(Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z), s));
+        if (with_projection) HIPCK(c, launch_l2norm_fwd(Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z), s));
         return (int)FBHIP_OK;
     });
 }
@@ -649,8 +649,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     const float* next_goal = w.next_goal.p;
     const int ld_ng = w.next_goal.ld;
 
-    if (mask & FBHIP_PHASE_SAMPLE) {
-        HIPCK(c, launch_step_advance(w.st, 2, s));
+    if (mask & FBHIP_PHASE_SAMPLE) {            // (the RNG counter is advanced by mix_z_kernel at the end of the phase)
         // every NULL field of ``inj`` is drawn on device; injected fields (parity mode / externally sampled
         // batches) overwrite the draw
         const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
@@ -670,16 +669,15 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld;
         ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount;
         HIPCK(c, launch_gather(ga, s));
-        // sample_z: sqrt(d) * normalize(gauss)   (fb_ddpg.py:224-228)
-        HIPCK(c, launch_l2norm_fwd(w.so.z_gauss, z, w.zrand.p, Lz, nullptr, B, z, sqrtf((float)z), s));
-        if (hp.mix_ratio > 0.f) {               // fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm]))
-            RC(backward_map_fwd(c, c->K_p, w.bin.p, w.bin.ld, w.bsA, B, s));
-            HIPCK(c, launch_mix_z(w.zrand.p, w.bsA.Bm.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, w.Xoz.p, w.Xoz.ld,
-                                  w.Xnoz.p, w.Xnoz.ld, o, B, z, s));
-        } else {
-            HIPCK(c, launch_mix_z(w.zrand.p, w.zrand.p, Lz, w.so.mix_uniform, 0.f, w.z.p, w.Xoz.p, w.Xoz.ld, w.Xnoz.p,
-                                  w.Xnoz.ld, o, B, z, s));
+        // sample_z (fb_ddpg.py:224-228) + z-mix (fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm])))
+        // in one row kernel; the BackwardMap pass stops at its raw mlp output y (the kernel applies both projections)
+        if (hp.mix_ratio > 0.f) {
+            std::vector<Stage> st;
+            backward_map_fwd_stages(c, c->K_p, w.bin.p, w.bin.ld, w.bsA, B, st, /*with_projection=*/false);
+            RC(run_chain(st, s));
         }
+        HIPCK(c, launch_mix_z(w.so.z_gauss, z, w.bsA.y.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
+                              w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, s));
     }
 
     // side streams (parallel graph branches); with parallel == false everything collapses onto ``s``
@@ -780,7 +778,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         if ((mask & FBHIP_PHASE_ACTOR_STEP) && !early_actor) HIPCK(c, launch_step_advance(w.st, 1, s));
         RC(forward_map_fwd(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
         HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + o, w.Xopi.ld, hp.stddev,
-                                   w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, a, s));
+                                   w.dF1.p, w.dF2.p, hp.want_metrics ? w.metrics : nullptr, w.pw_scratch, B, z, a, s));
         // data-gradient only, along the action path of forward_net (the reference also computes and discards
         // every weight gradient of forward_net here)
         RC(forward_map_bwd_heads_dgrad(c, c->F_p, w.fsO, B, s));

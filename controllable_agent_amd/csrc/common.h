@@ -73,6 +73,7 @@ hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float
 hipError_t launch_policy_sample(const float* pre, int ldp, const float* noise, int ldn, float stddev, float clip,
                                 float* mu, int ldmu, float* action, int lda, int rows, int a, hipStream_t s);
 // actor loss (fb_ddpg.py:400-406): Q = min(F1.z, F2.z); loss = -mean Q; dF_i = -z/B * w_i
+// metrics == nullptr skips the (metric-only) finalize launch
 hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz,
                              const float* mu, int ldmu, const float* action, int lda, float stddev,
                              float* dF1, float* dF2, float* metrics, float* scratch /* >= 2*ceil(rows/4) floats */,
@@ -139,11 +140,11 @@ struct GatherArgs {
     int B, o, a, g, use_goal; float gamma;
 };
 hipError_t launch_gather(const GatherArgs& ga, hipStream_t s);
-// z[i] = mix ? sqrt(d)*normalize(Bmix[i]) : zrand[i]; scattered into the concat buffers
-hipError_t launch_mix_z(const float* zrand, const float* Bmix, int ldz, const float* mix_uniform, float mix_ratio,
-                        float* z, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
-                        hipStream_t s);
-
+// z[i] = mix ? sqrt(d) normalize(sqrt(d) normalize(ymix[i])) : sqrt(d) normalize(gauss[i]); scattered into the concat
+// panels; advances the RNG counter when st != nullptr
+hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
+                        float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
+                        StepState* st, hipStream_t s);
 hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, const float* B, int ldb, int nb,
                           int rows, hipStream_t s);
 hipError_t pairwise_prepare(int B, int d);     // one-time kernel attribute setup (outside graph capture)

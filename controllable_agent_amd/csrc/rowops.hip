@@ -436,7 +436,7 @@ hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const fl
     hipLaunchKernelGGL(actor_loss_kernel, dim3(nblk), dim3(256), 0, s, F1, F2, ldf, z, ldz, mu, ldmu, action, lda,
                        stddev, dF1, dF2, scratch, rows, d, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
     hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17);
     return hipGetLastError();
 }

@@ -146,24 +146,56 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
     copy_row(g.bin + (size_t)i * g.ld_bin, bsrc, g.g, lane);
 }
 
-// z = mix ? sqrt(d) * normalize(B(backward_input)) : z_rand, scattered into every panel that carries z
-__global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ zrand, const float* __restrict__ Bmix,
-                                                    int ldz, const float* __restrict__ mixu, float mix_ratio,
-                                                    float* __restrict__ z, float* __restrict__ Xoz, int ld_oz,
-                                                    float* __restrict__ Xnoz, int ld_noz, int o, int B, int d) {
+// z = mix ? sqrt(d) normalize(B(backward_input)) : sqrt(d) normalize(gauss), scattered into every panel that carries z.
+//   sample_z (fb_ddpg.py:224-228) and the z-mix (fb_ddpg.py:470-485) in one pass.  ``ymix`` is the RAW output of the
+//   BackwardMap mlp: the reference normalises it twice (inside BackwardMap.forward, fb_modules.py:229, and again at
+//   fb_ddpg.py:483-484) and so does this kernel, with the same operation order.  Thread 0 also advances the RNG counter
+//   for the next update (every draw of this update has been consumed by now: stream order).
+__global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ gauss, int ldg,
+                                                    const float* __restrict__ ymix, int ldy,
+                                                    const float* __restrict__ mixu, float mix_ratio,
+                                                    float* __restrict__ z, int ldz, float* __restrict__ Xoz, int ld_oz,
+                                                    float* __restrict__ Xnoz, int ld_noz, int o, int B, int d,
+                                                    StepState* __restrict__ st) {
+    if (st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) st->update_count += 1u;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
     const bool mix = (mix_ratio > 0.f) && (mixu[i] < mix_ratio);
+    const float* src = mix ? ymix + (size_t)i * ldy : gauss + (size_t)i * ldg;
+    constexpr int ME = 4;                         // d <= 256
+    float v[ME];
     float s = 0.f;
-    for (int j = lane; j < d; j += 64) { const float v = Bmix[(size_t)i * ldz + j]; s += v * v; }
+#pragma unroll
+    for (int k = 0; k < ME; ++k) {
+        const int j = lane + 64 * k;
+        v[k] = j < d ? src[j] : 0.f;
+        s += v[k] * v[k];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    const float den = fmaxf(sqrtf(s), 1e-12f), sc = sqrtf((float)d);
-    for (int j = lane; j < d; j += 64) {
-        const float v = mix ? sc * (Bmix[(size_t)i * ldz + j] / den) : zrand[(size_t)i * ldz + j];
-        z[(size_t)i * ldz + j] = v;
-        Xoz[(size_t)i * ld_oz + o + j] = v;
-        Xnoz[(size_t)i * ld_noz + o + j] = v;
+    const float sc = sqrtf((float)d);
+    const float den = fmaxf(sqrtf(s), 1e-12f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < ME; ++k) {
+        v[k] = sc * (v[k] / den);                 // first (or, for gaussian rows, only) projection
+        s2 += v[k] * v[k];
+    }
+    if (mix) {                                    // second projection of the mixed rows (fb_ddpg.py:483-484)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+        const float den2 = fmaxf(sqrtf(s2), 1e-12f);
+#pragma unroll
+        for (int k = 0; k < ME; ++k) v[k] = sc * (v[k] / den2);
+    }
+#pragma unroll
+    for (int k = 0; k < ME; ++k) {
+        const int j = lane + 64 * k;
+        if (j < d) {
+            z[(size_t)i * ldz + j] = v[k];
+            Xoz[(size_t)i * ld_oz + o + j] = v[k];
+            Xnoz[(size_t)i * ld_noz + o + j] = v[k];
+        }
     }
 }
 
@@ -189,10 +221,12 @@ hipError_t launch_gather(const GatherArgs& ga, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_mix_z(const float* zrand, const float* Bmix, int ldz, const float* mix_uniform, float mix_ratio,
-                        float* z, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d, hipStream_t s) {
-    hipLaunchKernelGGL(mix_z_kernel, dim3((B + 3) / 4), dim3(256), 0, s, zrand, Bmix, ldz, mix_uniform, mix_ratio, z,
-                       Xoz, ld_oz, Xnoz, ld_noz, o, B, d);
+hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
+                        float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
+                        StepState* st, hipStream_t s) {
+    if (d > 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mix_z_kernel, dim3((B + 3) / 4), dim3(256), 0, s, gauss, ldg, ymix, ldy, mix_uniform, mix_ratio, z,
+                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st);
     return hipGetLastError();
 }
 
