@@ -14,6 +14,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace fbhip;
@@ -335,29 +336,52 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     else if (tiles32 >= 1024) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
     else cfg = CFG_1x1x4;
     const int bkt = gemm_cfg_bkt(cfg);
+    const int BMc = gemm_cfg_bm(cfg), BNc = gemm_cfg_bn(cfg);
     float* slab = splitk_slab(ctx, s);
+    // per-workgroup cost of a problem in K-chunk units; tiles that take the predicated loader (ragged M / N,
+    // unaligned views) cost ~3x per chunk
+    auto cost_of = [&](const GemmProblem& p) {
+        const bool vec = (((uintptr_t)p.A & 15) == 0 && (p.lda & 3) == 0) && (((uintptr_t)p.B & 15) == 0 && (p.ldb & 3) == 0);
+        const long tm = (p.M + BMc - 1) / BMc, tn = (p.N + BNc - 1) / BNc;
+        const long ragged = (p.M % BMc ? tn : 0) + (p.N % BNc ? tm : 0);
+        const bool slow = !vec || 2 * ragged >= tm * tn;
+        return (long)((p.K + bkt - 1) / bkt) * (slow ? 3 : 1);
+    };
+    // longest workgroups first, so that the stragglers of a heterogeneous group start at t = 0 and hide under the
+    // bulk (the hardware dispatches workgroups in launch order)
+    std::stable_sort(v.begin(), v.end(), [&](const GemmProblem& a, const GemmProblem& b) { return cost_of(a) > cost_of(b); });
     size_t i = 0;
     while (i < v.size()) {
         GemmGroup g{};
         int start = 0, red = 0;
         size_t slab_used = 0;
-        // workgroups of this launch without K slicing
-        long base_blocks = 0;
+        // workgroups / total work of this launch without K slicing
+        long base_blocks = 0, work = 0;
         for (size_t j = i; j < v.size() && j < i + MAX_GROUP; ++j) {
             GemmProblem q = v[j];
             q.kslices = 1;
             gemm_problem_finalize(q, cfg);
             base_blocks += (long)q.tiles_m * q.tiles_n;
+            work += (long)q.tiles_m * q.tiles_n * cost_of(q);
         }
+        const long ideal = (work + 511) / 512;          // chunk-units per slot with ~2 workgroups on every CU
         while (i < v.size() && g.n < MAX_GROUP) {
             GemmProblem p = v[i++];
             p.kslices = 1;
             gemm_problem_finalize(p, cfg);
             const int kchunks = (p.K + bkt - 1) / bkt;
-            // small outputs: slice K across workgroups until the launch has ~3 workgroups per CU
-            if (slab && base_blocks <= 160 && kchunks >= 4) {
-                int want = (int)((640 + base_blocks - 1) / base_blocks);
+            int want = 1;
+            if (base_blocks <= 160 && kchunks >= 4) {
+                // small launch: slice K across workgroups until it has ~3 workgroups per CU
+                want = (int)((640 + base_blocks - 1) / base_blocks);
                 if (want > kchunks / 2) want = kchunks / 2;
+            } else if (base_blocks > 160 && cost_of(p) > std::max(ideal, 6L) && kchunks >= 4) {
+                // straggler of a heterogeneous group: slice until one workgroup costs about half the ideal makespan
+                const long pen = cost_of(p) / kchunks;
+                long kper = std::max(2L, (ideal / 2 + pen - 1) / pen);
+                want = (int)((kchunks + kper - 1) / kper);
+            }
+            if (slab && want > 1) {
                 const int kper = (kchunks + want - 1) / want;
                 const int ks = (kchunks + kper - 1) / kper;
                 const size_t need = (size_t)ks * p.M * p.N + (size_t)ks * p.M;
@@ -388,129 +412,137 @@ int sync_streams(fbhip_ctx* c, hipStream_t from, hipStream_t to) {
     return FBHIP_OK;
 }
 
-// A pass is a list of stages (each = the launches of one dependency level).  Independent chains are enqueued
-// round-robin, one stage per chain per round: ROCm's graph executor submits nodes roughly in capture order, so a
-// branch captured behind a long chain would start late even though it has no dependency on it.
-using Stage = std::function<int(hipStream_t)>;
-struct Chain { hipStream_t s; std::vector<Stage> st; };
+// ---- round-based merged scheduling -------------------------------------------------------------------------
+// A pass (one net forward or backward) is a CHAIN of stages; a stage only DECLARES what it needs at its dependency
+// level: GEMM problems, LayerNorm problems, and "post" launches that must follow them.  Independent chains advance in
+// lock-step rounds and everything declared in a round goes out as ONE grouped GEMM launch (+ one grouped LayerNorm
+// launch): e.g. the second layers of actor(next_obs), forward_net(obs) and both backward nets share a launch, and tiny
+// heads ride along the big hidden-layer GEMMs instead of paying a ~6 us launch + pipeline-fill floor each.
+// (Measured on MI355X: running independent chains as parallel hipGraph branches instead buys nothing -- the step
+// costs the SUM of its kernels' standalone times -- so everything is enqueued on the caller's stream.)
+struct Ops {
+    std::vector<GemmProblem> gemms;
+    std::vector<LnFwdProblem> lnf;
+    std::vector<LnBwdProblem> lnb;
+    std::vector<std::function<int(hipStream_t)>> post;
+};
+using Stage = std::function<void(Ops&)>;
+using Chain = std::vector<Stage>;
 
-int run_chain(const std::vector<Stage>& st, hipStream_t s) {
-    for (const auto& f : st) RC(f(s));
+int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
+    if (!o.gemms.empty()) RC(run_gemms(c, o.gemms, s));
+    for (size_t i = 0; i < o.lnf.size(); i += LN_MAX_GROUP) {
+        LnFwdGroup g{};
+        for (size_t j = i; j < o.lnf.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.lnf[j];
+        HIPCK(c, launch_ln_tanh_fwd_group(g, s));
+    }
+    for (size_t i = 0; i < o.lnb.size(); i += LN_MAX_GROUP) {
+        LnBwdGroup g{};
+        for (size_t j = i; j < o.lnb.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.lnb[j];
+        HIPCK(c, launch_ln_tanh_bwd_group(g, s));
+    }
+    for (auto& f : o.post) RC(f(s));
     return FBHIP_OK;
 }
-int run_interleaved(std::vector<Chain>& chains) {
-    for (size_t i = 0;; ++i) {
+
+int run_rounds(fbhip_ctx* c, std::vector<Chain>& chains, hipStream_t s) {
+    for (size_t r = 0;; ++r) {
+        Ops o;
         bool any = false;
         for (auto& ch : chains)
-            if (i < ch.st.size()) { RC(ch.st[i](ch.s)); any = true; }
+            if (r < ch.size()) { ch[r](o); any = true; }
         if (!any) return FBHIP_OK;
+        RC(flush_round(c, o, s));
     }
 }
+int run_chain(fbhip_ctx* c, Chain& ch, hipStream_t s) {
+    std::vector<Chain> v{ch};
+    return run_rounds(c, v, s);
+}
 
-// ---- network passes --------------------------------------------------------------------------------------
+// ---- network passes as chains ---------------------------------------------------------------------------------
 // ForwardMap.forward (fb_modules.py:186-199); Xa = [obs|action] panel, Xz = [obs|z] panel
-void forward_map_fwd_stages(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
-                            int rows, std::vector<Stage>& out) {
+void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
+                           int rows, Chain& out) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
     FSet* Sp = &S;
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, W.oa.ld1, W.oa.b1, EPI_BIAS),
-                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, W.oa.ld1, W.oa.b1, EPI_BIAS));
+        o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        LnFwdGroup g{};
-        g.n = 2;
-        g.p[0] = LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0};
-        g.p[1] = LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0};
-        HIPCK(c, launch_ln_tanh_fwd_group(g, s));
-        return (int)FBHIP_OK;
+    out.push_back([=](Ops& o) {
+        o.lnf.push_back(LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0});
+        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0});
     });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU),
-                             P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU));
+        o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->h.p, 2 * Fd, 1, W.W3s, 2 * Fd, 1, Sp->p.p, 2 * H, rows, 2 * H, 2 * Fd, W.b3s, EPI_BIAS_RELU)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.W3s, 2 * Fd, 1, Sp->p.p, 2 * H, rows, 2 * H, 2 * Fd, W.b3s, EPI_BIAS_RELU));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS),
-                             P(Sp->p.p + H, 2 * H, 1, W.W4[1], H, 1, Sp->F2.p, Lz, rows, z, H, W.b4[1], EPI_BIAS)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS));
+        o.gemms.push_back(P(Sp->p.p + H, 2 * H, 1, W.W4[1], H, 1, Sp->F2.p, Lz, rows, z, H, W.b4[1], EPI_BIAS));
     });
 }
 
 int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
                     int rows, hipStream_t s) {
-    std::vector<Stage> st;
-    forward_map_fwd_stages(c, W, Xa, lda, Xz, ldz, S, rows, st);
-    return run_chain(st, s);
+    Chain ch;
+    forward_map_fwd_chain(c, W, Xa, lda, Xz, ldz, S, rows, ch);
+    return run_chain(c, ch, s);
 }
 
 // dgrad: dp = (dF_i . W4_i) * relu'(p)   (shared by the FB backward and the actor step)
-int forward_map_bwd_heads_dgrad(fbhip_ctx* c, const FwdP& W, FSet& S, int rows, hipStream_t s) {
+void heads_dgrad_ops(fbhip_ctx* c, const FwdP& W, FSet& S, int rows, Ops& o) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z);
     Ws& w = c->w;
-    return run_gemms(c, {P(w.dF1.p, Lz, 1, W.W4[0], H, 0, w.dp.p, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p, 2 * H),
-                         P(w.dF2.p, Lz, 1, W.W4[1], H, 0, w.dp.p + H, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p + H, 2 * H)}, s);
+    o.gemms.push_back(P(w.dF1.p, Lz, 1, W.W4[0], H, 0, w.dp.p, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p, 2 * H));
+    o.gemms.push_back(P(w.dF2.p, Lz, 1, W.W4[1], H, 0, w.dp.p + H, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p + H, 2 * H));
 }
 
-// full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383).  The data-gradient chain runs on
-// ``s``; each weight gradient only needs the chain's previous stage, so it is issued on ``sw`` and overlaps the chain.
-void forward_map_bwd_stages(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz,
-                            int ldz, FSet& S, int rows, hipStream_t sw, std::vector<Stage>& out) {
+// full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383): each stage holds the weight
+// gradient of layer l and the data gradient into layer l-1 (both depend only on the previous stage)
+void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz,
+                           int ldz, FSet& S, int rows, Chain& out) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
     Ws* w = &c->w;
     FSet* Sp = &S;
-    out.push_back([=](hipStream_t s) -> int {
-        RC(sync_streams(c, s, sw));
-        RC(run_gemms(c, {P(w->dF1.p, Lz, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]),
-                         P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1])}, sw));
-        return forward_map_bwd_heads_dgrad(c, W, *Sp, rows, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dF1.p, Lz, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]));
+        o.gemms.push_back(P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
+        heads_dgrad_ops(c, W, *Sp, rows, o);
     });
-    out.push_back([=](hipStream_t s) -> int {
-        RC(sync_streams(c, s, sw));
-        RC(run_gemms(c, {P(w->dp.p, 2 * H, 0, Sp->h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s)}, sw));
-        return run_gemms(c, {P(w->dp.p, 2 * H, 1, W.W3s, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, 2 * H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dp.p, 2 * H, 0, Sp->h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s));
+        o.gemms.push_back(P(w->dp.p, 2 * H, 1, W.W3s, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, 2 * H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        RC(sync_streams(c, s, sw));
-        RC(run_gemms(c, {P(w->dh.p, 2 * Fd, 0, Sp->t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2),
-                         P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, sw));
-        return run_gemms(c, {P(w->dh.p, 2 * Fd, 1, W.oa.W2, H, 0, w->dt1a.p, H, rows, H, Fd),
-                             P(w->dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fd)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dh.p, 2 * Fd, 0, Sp->t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2));
+        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
+        o.gemms.push_back(P(w->dh.p, 2 * Fd, 1, W.oa.W2, H, 0, w->dt1a.p, H, rows, H, Fd));
+        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fd));
     });
-    out.push_back([=](hipStream_t s) -> int {
+    out.push_back([=](Ops& o) {
         const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
-        LnBwdGroup g{};
-        g.n = 2;
-        g.p[0] = LnBwdProblem{w->dt1a.p, H, Sp->t1a.p, H, Sp->pre1a.p, H, Sp->statsA, W.oa.g1, w->dt1a.p, H, G.oa.g1, G.oa.be1,
-                              w->ln_partials, rows, H, 0, 0, 0, 0, 0};
-        g.p[1] = LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1, G.oz.be1,
-                              w->ln_partials + half, rows, H, 0, 0, 0, 0, 0};
-        HIPCK(c, launch_ln_tanh_bwd_group(g, s));
-        return (int)FBHIP_OK;
+        o.lnb.push_back(LnBwdProblem{w->dt1a.p, H, Sp->t1a.p, H, Sp->pre1a.p, H, Sp->statsA, W.oa.g1, w->dt1a.p, H, G.oa.g1,
+                                     G.oa.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0});
+        o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
+                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0});
     });
-    out.push_back([=](hipStream_t s) -> int {
-        RC(run_gemms(c, {P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1),
-                         P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
-        return sync_streams(c, sw, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1));
+        o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
     });
-}
-
-// full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383).  The data-gradient chain runs on
-// ``s``; each weight gradient only needs the chain's previous stage, so it is issued on ``sw`` and overlaps the chain.
-int forward_map_bwd(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz, int ldz,
-                    FSet& S, int rows, hipStream_t s, hipStream_t sw) {
-    std::vector<Stage> st;
-    forward_map_bwd_stages(c, W, G, Xa, lda, Xz, ldz, S, rows, sw, st);
-    return run_chain(st, s);
 }
 
 // BackwardMap.forward (fb_modules.py:223-230)
-void backward_map_fwd_stages(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows,
-                             std::vector<Stage>& out, bool with_projection = true) {
+void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, Chain& out,
+                            bool with_projection = true) {
     const fbhip_dims& d = c->d;
     // GEMMs run on the padded width Lb = pad64(Hb) (zero weight rows / columns), LayerNorm on the logical Hb
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
@@ -519,31 +551,34 @@ void backward_map_fwd_stages(fbhip_ctx* c, const BwdP& W, const float* X, int ld
     const bool in_ws = (const char*)X >= (const char*)c->w.st && (const char*)X < (const char*)c->w.st + c->w.total_bytes;
     const int Kg = (in_ws && ldx >= pad32(g)) ? pad32(g) : g;
     BSet* Sp = &S;
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(X, ldx, 1, W.W1, pad32(g), 1, Sp->pre1.p, Lb, rows, Lb, Kg, W.b1, EPI_BIAS)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(X, ldx, 1, W.W1, pad32(g), 1, Sp->pre1.p, Lb, rows, Lb, Kg, W.b1, EPI_BIAS));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        HIPCK(c, launch_ln_tanh_fwd(Sp->pre1.p, Lb, W.g1, W.be1, Sp->t1.p, Lb, Sp->stats, rows, Hb, s));
-        return (int)FBHIP_OK;
+    out.push_back([=](Ops& o) {
+        o.lnf.push_back(LnFwdProblem{Sp->pre1.p, Lb, W.g1, W.be1, Sp->t1.p, Lb, Sp->stats, rows, Hb, 0, 0, 0});
     });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->t1.p, Lb, 1, W.W2, Lb, 1, Sp->r2.p, Lb, rows, Lb, Lb, W.b2, EPI_BIAS_RELU)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->t1.p, Lb, 1, W.W2, Lb, 1, Sp->r2.p, Lb, rows, Lb, Lb, W.b2, EPI_BIAS_RELU));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        RC(run_gemms(c, {P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Lb, W.b3, EPI_BIAS)}, s));
-        if (with_projection) HIPCK(c, launch_l2norm_fwd(Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z), s));
-        return (int)FBHIP_OK;
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Lb, W.b3, EPI_BIAS));
+        if (with_projection)
+            o.post.push_back([=](hipStream_t s) -> int {
+                HIPCK(c, launch_l2norm_fwd(Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z), s));
+                return (int)FBHIP_OK;
+            });
     });
 }
 
 int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, hipStream_t s) {
-    std::vector<Stage> st;
-    backward_map_fwd_stages(c, W, X, ldx, S, rows, st);
-    return run_chain(st, s);
+    Chain ch;
+    backward_map_fwd_chain(c, W, X, ldx, S, rows, ch);
+    return run_chain(c, ch, s);
 }
 
-void backward_map_bwd_stages(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S,
-                             const float* dy, int rows, std::vector<Stage>& out) {
+// backward of BackwardMap from dB (gradient wrt the projected embedding)
+void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S, int rows,
+                            Chain& out) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
     // weight gradient of the first layer: X must be a zero-padded panel to use the padded width
@@ -551,92 +586,93 @@ void backward_map_bwd_stages(fbhip_ctx* c, const BwdP& W, const BwdP& G, const f
     const int Ng = padded_x ? pad32(g) : g;
     Ws* w = &c->w;
     BSet* Sp = &S;
-    out.push_back([=](hipStream_t s) -> int {
-        RC(run_gemms(c, {P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, s));
-        return run_gemms(c, {P(dy, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb)}, s);
+    out.push_back([=](Ops& o) {                 // dy = d/dy of sqrt(d) normalize(y)   (F.normalize backward)
+        o.post.push_back([=](hipStream_t s) -> int {
+            HIPCK(c, launch_l2norm_bwd(w->dBm.p, Lz, Sp->y.p, Lz, Sp->norms, w->dy.p, Lz, rows, z, s));
+            return (int)FBHIP_OK;
+        });
     });
-    out.push_back([=](hipStream_t s) -> int {
-        RC(run_gemms(c, {P(w->b_dr2.p, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Lb, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2)}, s));
-        return run_gemms(c, {P(w->b_dr2.p, Lb, 1, W.W2, Lb, 0, w->b_dt1.p, Lb, rows, Lb, Lb)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dy.p, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
+        o.gemms.push_back(P(w->dy.p, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        HIPCK(c, launch_ln_tanh_bwd(w->b_dt1.p, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, w->b_dt1.p, Lb, G.g1,
-                                    G.be1, w->ln_partials_b, rows, Hb, s));
-        return (int)FBHIP_OK;
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->b_dr2.p, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Lb, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2));
+        o.gemms.push_back(P(w->b_dr2.p, Lb, 1, W.W2, Lb, 0, w->b_dt1.p, Lb, rows, Lb, Lb));
     });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad32(g), Lb, Ng, rows, nullptr, EPI_NONE, nullptr, 0, G.b1)}, s);
+    out.push_back([=](Ops& o) {
+        o.lnb.push_back(LnBwdProblem{w->b_dt1.p, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, w->b_dt1.p, Lb, G.g1,
+                                     G.be1, w->ln_partials_b, rows, Hb, 0, 0, 0, 0, 0});
     });
-}
-
-void actor_fwd_stages(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S,
-                      int rows, std::vector<Stage>& out) {
-    const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
-    ASet* Sp = &S;
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, Sp->pre1o.p, H, rows, H, W.o.ld1, W.o.b1, EPI_BIAS),
-                             P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS)}, s);
-    });
-    out.push_back([=](hipStream_t s) -> int {
-        LnFwdGroup g{};
-        g.n = 2;
-        g.p[0] = LnFwdProblem{Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, 0, 0, 0};
-        g.p[1] = LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0};
-        HIPCK(c, launch_ln_tanh_fwd_group(g, s));
-        return (int)FBHIP_OK;
-    });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->t1o.p, H, 1, W.o.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU),
-                             P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU)}, s);
-    });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->h.p, 2 * Fd, 1, W.W3, 2 * Fd, 1, Sp->p.p, H, rows, H, 2 * Fd, W.b3, EPI_BIAS_RELU)}, s);
-    });
-    out.push_back([=](hipStream_t s) -> int {
-        return run_gemms(c, {P(Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS)}, s);
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad32(g), Lb, Ng, rows, nullptr, EPI_NONE, nullptr, 0, G.b1));
     });
 }
 
 // Actor.forward up to the pre-tanh policy output (fb_modules.py:107-121); Xo supplies obs (first o cols)
-int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
-              hipStream_t s) {
-    std::vector<Stage> st;
-    actor_fwd_stages(c, W, Xo, ldo, Xz, ldz, S, rows, st);
-    return run_chain(st, s);
-}
-
-int actor_bwd(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S,
-              int rows, hipStream_t s, hipStream_t sw) {
+void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
+                     Chain& out) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
-    Ws& w = c->w;
-    const float* dpm = w.a_dpremu.p;
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(dpm, La, 0, S.p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4)}, sw));
-    RC(run_gemms(c, {P(dpm, La, 1, W.W4, H, 0, w.a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, S.p.p, H)}, s));
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(w.a_dp.p, H, 0, S.h.p, 2 * Fd, 0, G.W3, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3)}, sw));
-    RC(run_gemms(c, {P(w.a_dp.p, H, 1, W.W3, 2 * Fd, 0, w.dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, S.h.p, 2 * Fd)}, s));
-    RC(sync_streams(c, s, sw));
-    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 0, S.t1o.p, H, 0, G.o.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b2),
-                     P(w.dh.p + Fd, 2 * Fd, 0, S.t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2)}, sw));
-    RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, W.o.W2, H, 0, w.dt1a.p, H, rows, H, Fd),
-                     P(w.dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w.dt1z.p, H, rows, H, Fd)}, s));
-    {
+    ASet* Sp = &S;
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, Sp->pre1o.p, H, rows, H, W.o.ld1, W.o.b1, EPI_BIAS));
+        o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
+    });
+    out.push_back([=](Ops& o) {
+        o.lnf.push_back(LnFwdProblem{Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, 0, 0, 0});
+        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0});
+    });
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->t1o.p, H, 1, W.o.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU));
+        o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU));
+    });
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.W3, 2 * Fd, 1, Sp->p.p, H, rows, H, 2 * Fd, W.b3, EPI_BIAS_RELU));
+    });
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS));
+    });
+}
+
+int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
+              hipStream_t s) {
+    Chain ch;
+    actor_fwd_chain(c, W, Xo, ldo, Xz, ldz, S, rows, ch);
+    return run_chain(c, ch, s);
+}
+
+void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz,
+                     ASet& S, int rows, Chain& out) {
+    const fbhip_dims& d = c->d;
+    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
+    Ws* w = &c->w;
+    ASet* Sp = &S;
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->a_dpremu.p, La, 0, Sp->p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
+        o.gemms.push_back(P(w->a_dpremu.p, La, 1, W.W4, H, 0, w->a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, Sp->p.p, H));
+    });
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->a_dp.p, H, 0, Sp->h.p, 2 * Fd, 0, G.W3, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
+        o.gemms.push_back(P(w->a_dp.p, H, 1, W.W3, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
+    });
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dh.p, 2 * Fd, 0, Sp->t1o.p, H, 0, G.o.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b2));
+        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
+        o.gemms.push_back(P(w->dh.p, 2 * Fd, 1, W.o.W2, H, 0, w->dt1a.p, H, rows, H, Fd));
+        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fd));
+    });
+    out.push_back([=](Ops& o) {
         const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
-        LnBwdGroup g{};
-        g.n = 2;
-        g.p[0] = LnBwdProblem{w.dt1a.p, H, S.t1o.p, H, S.pre1o.p, H, S.statsO, W.o.g1, w.dt1a.p, H, G.o.g1, G.o.be1,
-                              w.ln_partials, rows, H, 0, 0, 0, 0, 0};
-        g.p[1] = LnBwdProblem{w.dt1z.p, H, S.t1z.p, H, S.pre1z.p, H, S.statsZ, W.oz.g1, w.dt1z.p, H, G.oz.g1, G.oz.be1,
-                              w.ln_partials + half, rows, H, 0, 0, 0, 0, 0};
-        HIPCK(c, launch_ln_tanh_bwd_group(g, s));
-    }
-    RC(run_gemms(c, {P(w.dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1),
-                     P(w.dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1)}, s));
-    RC(sync_streams(c, sw, s));
-    return FBHIP_OK;
+        o.lnb.push_back(LnBwdProblem{w->dt1a.p, H, Sp->t1o.p, H, Sp->pre1o.p, H, Sp->statsO, W.o.g1, w->dt1a.p, H, G.o.g1,
+                                     G.o.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0});
+        o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
+                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0});
+    });
+    out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1));
+        o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
+    });
 }
 
 // ---- one update(): fb_ddpg.py:427-520 ----------------------------------------------------------------------
@@ -672,43 +708,40 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // sample_z (fb_ddpg.py:224-228) + z-mix (fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm])))
         // in one row kernel; the BackwardMap pass stops at its raw mlp output y (the kernel applies both projections)
         if (hp.mix_ratio > 0.f) {
-            std::vector<Stage> st;
-            backward_map_fwd_stages(c, c->K_p, w.bin.p, w.bin.ld, w.bsA, B, st, /*with_projection=*/false);
-            RC(run_chain(st, s));
+            Chain ch;
+            backward_map_fwd_chain(c, c->K_p, w.bin.p, w.bin.ld, w.bsA, B, ch, /*with_projection=*/false);
+            RC(run_chain(c, ch, s));
         }
         HIPCK(c, launch_mix_z(w.so.z_gauss, z, w.bsA.y.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, s));
     }
 
-    // side streams (parallel graph branches); with parallel == false everything collapses onto ``s``
-    hipStream_t sA = (c->parallel & 1) ? c->side[0] : s, sB = (c->parallel & 1) ? c->side[1] : s;
-    hipStream_t sW = (c->parallel & 2) ? c->side[2] : s;
-
-    // single-call updates can start the actor's own forward pass early (see below)
-    const bool early_actor = (mask & FBHIP_PHASE_FB_GRAD) && (mask & FBHIP_PHASE_ACTOR_GRAD) && sB != s;
-
-    if (mask & FBHIP_PHASE_FB_GRAD) {
-        RC(sync_streams(c, s, sA));
-        RC(sync_streams(c, s, sB));
-        {
-            // [s]  targets, no grad (fb_ddpg.py:303-315): actor -> next_action -> forward_target   (critical chain)
-            // [sA] online F (fb_ddpg.py:318)      [sB] target B then online B (:312, :319)
-            std::vector<Chain> ch(3);
-            ch[0].s = s; ch[1].s = sA; ch[2].s = sB;
-            actor_fwd_stages(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0].st);
-            ch[0].st.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_next, a, hp.stddev, hp.stddev_clip, nullptr, 0,
-                                              w.Xnoa.p + o, w.Xnoa.ld, B, a, q));
+    // single-call updates can run the actor's own forward pass of update_actor (fb_ddpg.py:395-397) under the FB
+    // backward: it reads only the actor weights and (obs, z), not forward_net or the new FB weights
+    const bool early_actor = (mask & FBHIP_PHASE_FB_GRAD) && (mask & FBHIP_PHASE_ACTOR_GRAD);
+    auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst) {
+        return [=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_policy_sample(w.as.premu.p, La, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
+                                              ld_dst, B, a, q));
                 return (int)FBHIP_OK;
             });
-            forward_map_fwd_stages(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0].st);
-            forward_map_fwd_stages(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1].st);
-            backward_map_fwd_stages(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch[2].st);
-            backward_map_fwd_stages(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch[2].st);
-            RC(run_interleaved(ch));
+        };
+    };
+
+    if (mask & FBHIP_PHASE_FB_GRAD) {
+        {
+            // chain A: targets, no grad (fb_ddpg.py:303-315): actor(next_obs) -> next_action -> forward_target
+            // chain B: online F (fb_ddpg.py:318)    chains C, D: target B (:312) and online B (:319)
+            std::vector<Chain> ch(4);
+            actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0]);
+            ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + o, w.Xnoa.ld));
+            forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
+            forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
+            backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch[2]);
+            backward_map_fwd_chain(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch[3]);
+            RC(run_rounds(c, ch, s));
         }
-        RC(sync_streams(c, sA, s));
-        RC(sync_streams(c, sB, s));
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
         HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, w.bsO.Bm.p, w.fsT.F1.p, w.fsT.F2.p, w.bsA.Bm.p, w.disc, B, z,
                                     Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
@@ -723,78 +756,64 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, w.bsO.Bm.p, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
         }
-        // --- backward (fb_ddpg.py:383): forward_net on [s]+[sW] (critical), backward_net on [sA], and on [sB] the
-        // actor's own forward pass of update_actor (fb_ddpg.py:395-397): it reads only the actor weights and (obs, z),
-        // so it runs under the FB backward instead of after fb_opt.step()
-        RC(sync_streams(c, s, sA));
-        RC(sync_streams(c, s, sB));
         {
+            // --- backward (fb_ddpg.py:383): forward_net, backward_net and (early) the actor's own forward pass
             std::vector<Chain> ch(3);
-            ch[0].s = s; ch[1].s = sA; ch[2].s = sB;
-            forward_map_bwd_stages(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, sW, ch[0].st);
-            ch[1].st.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_l2norm_bwd(w.dBm.p, Lz, w.bsO.y.p, Lz, w.bsO.norms, w.dy.p, Lz, B, z, q));
-                return (int)FBHIP_OK;
-            });
-            backward_map_bwd_stages(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, w.dy.p, B, ch[1].st);
+            forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
+            backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1]);
             if (early_actor) {
-                actor_fwd_stages(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2].st);
-                ch[2].st.push_back([=, &w](hipStream_t q) -> int {
-                    HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p,
-                                                  La, w.Xopi.p + o, w.Xopi.ld, B, a, q));
-                    return (int)FBHIP_OK;
-                });
+                actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2]);
+                ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + o, w.Xopi.ld));
             }
-            // Adam step counts / bias corrections for the optimiser steps of this call, off the critical path
-            ch[2].st.push_back([=, &w](hipStream_t q) -> int {
-                if (mask & FBHIP_PHASE_FB_STEP) HIPCK(c, launch_step_advance(w.st, 0, q));
-                if (early_actor && (mask & FBHIP_PHASE_ACTOR_STEP)) HIPCK(c, launch_step_advance(w.st, 1, q));
-                return (int)FBHIP_OK;
-            });
-            RC(run_interleaved(ch));
+            RC(run_rounds(c, ch, s));
         }
-        RC(sync_streams(c, sA, s));
-        RC(sync_streams(c, sB, s));     // every forked stream re-joins the origin stream DIRECTLY (hipStreamEndCapture
-                                        // faults on a branch that is only joined transitively through another branch)
     }
 
-    const bool overlap_adam = (mask & FBHIP_PHASE_FB_STEP) && (mask & FBHIP_PHASE_ACTOR_GRAD) && (c->parallel & 8) && sA != s;
     if (mask & FBHIP_PHASE_FB_STEP) {           // fb_opt.step() (:384) + soft_update_params x2 (:500-503)
-        hipStream_t sa = overlap_adam ? sA : s; // the actor's own forward does not read forward_net: overlap it
-        RC(sync_streams(c, s, sa));
-        if (!(mask & FBHIP_PHASE_FB_GRAD)) HIPCK(c, launch_step_advance(w.st, 0, sa));
+        HIPCK(c, launch_step_advance(w.st, ((mask & FBHIP_PHASE_ACTOR_STEP) ? 3 : 0), s));   // 3 = both optimisers
         const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
         HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf,
-                                 hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, sa));
+                                 hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, s));
     }
 
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
+        Chain ch;
         if (!early_actor) {
-            RC(actor_fwd(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s));
-            HIPCK(c, launch_policy_sample(w.as.premu.p, La, w.so.eps_actor, a, hp.stddev, hp.stddev_clip, w.as.mu.p, La,
-                                          w.Xopi.p + o, w.Xopi.ld, B, a, s));
+            actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
+            ch.push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + o, w.Xopi.ld));
         }
-        if (overlap_adam) RC(sync_streams(c, sA, s));          // forward_net (updated) is read from here on
-        if ((mask & FBHIP_PHASE_ACTOR_STEP) && !early_actor) HIPCK(c, launch_step_advance(w.st, 1, s));
-        RC(forward_map_fwd(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, s));
-        HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + o, w.Xopi.ld, hp.stddev,
-                                   w.dF1.p, w.dF2.p, hp.want_metrics ? w.metrics : nullptr, w.pw_scratch, B, z, a, s));
-        // data-gradient only, along the action path of forward_net (the reference also computes and discards
-        // every weight gradient of forward_net here)
-        RC(forward_map_bwd_heads_dgrad(c, c->F_p, w.fsO, B, s));
-        RC(run_gemms(c, {P(w.dp.p, 2 * H, 1, c->F_p.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, 2 * H, nullptr, EPI_MASK_RELU,
-                           w.fsO.h.p, 2 * Fd)}, s));
-        RC(run_gemms(c, {P(w.dh.p, 2 * Fd, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fd)}, s));
-        HIPCK(c, launch_ln_tanh_bwd(w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
-                                    nullptr, nullptr, nullptr, B, H, s));
+        forward_map_fwd_chain(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch);
+        ch.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + o, w.Xopi.ld,
+                                           hp.stddev, w.dF1.p, w.dF2.p, hp.want_metrics ? w.metrics : nullptr, w.pw_scratch,
+                                           B, z, a, q));
+                return (int)FBHIP_OK;
+            });
+        });
+        // data-gradient only, along the action path of forward_net (the reference also computes and discards every
+        // weight gradient of forward_net here)
+        ch.push_back([=, &w](Ops& o2) { heads_dgrad_ops(c, c->F_p, w.fsO, B, o2); });
+        ch.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.dp.p, 2 * H, 1, c->F_p.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, 2 * H, nullptr, EPI_MASK_RELU,
+                                 w.fsO.h.p, 2 * Fd));
+        });
+        ch.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.dh.p, 2 * Fd, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fd)); });
+        ch.push_back([=, &w](Ops& o2) {
+            o2.lnb.push_back(LnBwdProblem{w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
+                                          nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0});
+        });
         // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
-        RC(run_gemms(c, {P(w.dt1a.p, H, 1, c->F_p.oa.W1 + o, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
-                           EPI_TANH_BWD, w.as.mu.p, La)}, s));
-        RC(actor_bwd(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, s, sW));
+        ch.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + o, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
+                                 EPI_TANH_BWD, w.as.mu.p, La));
+        });
+        actor_bwd_chain(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
+        RC(run_chain(c, ch, s));
     }
 
     if (mask & FBHIP_PHASE_ACTOR_STEP) {        // actor_opt.step(), fb_ddpg.py:411
-        if (!(mask & FBHIP_PHASE_ACTOR_GRAD)) HIPCK(c, launch_step_advance(w.st, 1, s));
+        if (!(mask & FBHIP_PHASE_FB_STEP)) HIPCK(c, launch_step_advance(w.st, 1, s));
         const int64_t na = c->L[FBHIP_NET_ACTOR].numel;
         HIPCK(c, launch_adam_ema(c->a_p, c->a_g, c->a_m, c->a_v, nullptr, na, hp.lr, hp.lr, na, hp.grad_scale, 0.f, w.st,
                                  1, 0, s));

@@ -45,7 +45,9 @@ enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
 hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream);
-int gemm_cfg_bkt(int cfg);     // K extent of one chunk of a tile configuration
+int gemm_cfg_bkt(int cfg);    // K extent of one chunk of a tile configuration
+int gemm_cfg_bm(int cfg);     // tile rows / columns
+int gemm_cfg_bn(int cfg);
 hipError_t gemm_init();        // one-time kernel attribute setup (outside graph capture)
 int pick_gemm_cfg(int M, int N, int K);
 void gemm_problem_finalize(GemmProblem& p, int cfg);   // fills a_vec/b_vec/tiles_*
@@ -60,12 +62,13 @@ constexpr int LN_BWD_ROWS_PER_BLOCK = 8;
 // grouped variants: the two trunks of a net (independent rows, different parameters) share one launch
 struct LnFwdProblem { const float* x; int ldx; const float* gamma; const float* beta; float* y; int ldy; float* stats;
                       int rows, n, vx, vy, vp; };
-struct LnFwdGroup { LnFwdProblem p[2]; int n; };
+constexpr int LN_MAX_GROUP = 6;
+struct LnFwdGroup { LnFwdProblem p[LN_MAX_GROUP]; int n; };
 hipError_t launch_ln_tanh_fwd_group(LnFwdGroup g, hipStream_t s);
 struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* stats;
                       const float* gamma; float* dx; int lddx; float* dgamma; float* dbeta; float* partials;
                       int rows, n, vdy, vy, vx, vdx, vp; };
-struct LnBwdGroup { LnBwdProblem p[2]; int n; };
+struct LnBwdGroup { LnBwdProblem p[LN_MAX_GROUP]; int n; };
 hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s);
 hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float* norms, int rows, int d,
                              float scale, hipStream_t s);

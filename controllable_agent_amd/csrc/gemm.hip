@@ -94,18 +94,19 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     static_assert((WK - 1) * WM * WN * 17 * 64 <= 2 * STAGE, "split-K reduction scratch must fit");
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 * STAGE floats
 
-    // XCD-aware bijective remap: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so
-    // neighbours (same A row-panel, adjacent B panels) share that XCD's L2.
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, qd = nwg >> 3, rm = nwg & 7;
-    const int lid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
-
+    // problem lookup by launch position, then an XCD-aware bijective remap INSIDE the problem: workgroup b runs on
+    // XCD b % 8; each XCD gets a contiguous run of the problem's tiles (neighbours share an A row-panel / adjacent
+    // B panels in that XCD's L2) while every problem of a heterogeneous group still spreads over all 8 XCDs.
+    const int orig = blockIdx.x;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAX_GROUP; ++i)
-        if (i < g.n && lid >= g.p[i].tile_start) pi = i;
+        if (i < g.n && orig >= g.p[i].tile_start) pi = i;
     const GemmProblem& p = g.p[pi];
-    const int t = lid - p.tile_start;
+    const int nwg = p.tiles_m * p.tiles_n * p.kslices;
+    const int jb = orig - p.tile_start;
+    const int xcd = jb & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (jb >> 3);
     const int tiles_mn = p.tiles_m * p.tiles_n;
     const int slice = t / tiles_mn, tt = t % tiles_mn;        // slice-major: neighbours share operand panels
     const int tn = tt % p.tiles_n, tm = tt / p.tiles_n;
@@ -407,6 +408,9 @@ int gemm_cfg_bkt(int cfg) {
         default: return 32;
     }
 }
+
+int gemm_cfg_bm(int cfg) { return 32 * kCfgWM[cfg]; }
+int gemm_cfg_bn(int cfg) { return 32 * kCfgWN[cfg]; }
 
 // one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)
 hipError_t gemm_init() {

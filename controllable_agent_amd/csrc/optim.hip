@@ -17,11 +17,16 @@ __global__ void step_advance_kernel(StepState* st, int which) {
         st->update_count += 1u;
         return;
     }
-    int t;
-    if (which == 0) { st->fb_t += 1; t = st->fb_t; } else { st->actor_t += 1; t = st->actor_t; }
-    const double bc1 = 1.0 - pow(0.9, (double)t);
-    const double bc2s = sqrt(1.0 - pow(0.999, (double)t));
-    if (which == 0) { st->fb_bc1 = bc1; st->fb_bc2_sqrt = bc2s; } else { st->actor_bc1 = bc1; st->actor_bc2_sqrt = bc2s; }
+    if (which == 0 || which == 3) {
+        const int t = ++st->fb_t;
+        st->fb_bc1 = 1.0 - pow(0.9, (double)t);
+        st->fb_bc2_sqrt = sqrt(1.0 - pow(0.999, (double)t));
+    }
+    if (which == 1 || which == 3) {
+        const int t = ++st->actor_t;
+        st->actor_bc1 = 1.0 - pow(0.9, (double)t);
+        st->actor_bc2_sqrt = sqrt(1.0 - pow(0.999, (double)t));
+    }
 }
 
 hipError_t launch_step_advance(StepState* st, int which, hipStream_t s) {

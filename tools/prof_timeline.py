@@ -3,8 +3,8 @@ import sqlite3, sys
 db = sys.argv[1]
 con = sqlite3.connect(db)
 rows = con.execute("select name, start, end, stream_id, queue_id from kernels order by start").fetchall()
-# a step starts at every step_advance_kernel that follows an adam kernel (which=2 is first kernel of a step)
-starts = [i for i, r in enumerate(rows) if "step_advance" in r[0] and i > 0 and "adam_ema" in rows[i - 1][0]]
+# a step starts at the sampler's draw_kernel
+starts = [i for i, r in enumerate(rows) if "draw_kernel" in r[0]]
 if len(starts) < 3:
     print("no step boundary found"); sys.exit(0)
 a, b = starts[-2], starts[-1]
