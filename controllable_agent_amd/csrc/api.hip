@@ -127,11 +127,10 @@ struct ASet { Buf pre1o, t1o, pre1z, t1z, h, p, premu, mu; float* statsO = nullp
 struct Ws {
     StepState* st = nullptr;
     float* metrics = nullptr;
-    unsigned long long* perm_keys = nullptr;
     SampleOut so{};
     Buf Xoa, Xoz, Xnoz, Xnoa, Xopi, Xo, next_goal, bin, z, zrand;
     float* disc = nullptr;
-    BSet bsA, bsO;
+    BSet bsA, bsO, bsM;      // target / online passes on next_goal, z-mix pass on backward_input[perm]
     FSet fsT, fsO;
     ASet as;
     Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov, inv_cov, BinvC;
@@ -168,7 +167,6 @@ Ws carve(const fbhip_dims& d, void* base) {
               Fd = d.feature_dim, Hb = d.backward_hidden_dim;
     w.st = (StepState*)c.take(sizeof(StepState));
     w.metrics = c.f(FBHIP_NUM_METRICS);
-    w.perm_keys = (unsigned long long*)c.take((size_t)B * 8);
     w.so.ep_idx = (int32_t*)c.take((size_t)B * 4);
     w.so.step_idx = (int32_t*)c.take((size_t)B * 4);
     w.so.perm = (int32_t*)c.take((size_t)B * 4);
@@ -182,7 +180,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.Xnoa = c.buf(B, o + a, pad32(o + a)); w.Xopi = c.buf(B, o + a, pad32(o + a)); w.Xo = c.buf(B, o, pad32(o));
     w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.z = c.buf(B, z); w.zrand = c.buf(B, z);
     w.disc = c.f(B);
-    for (BSet* s : {&w.bsA, &w.bsO}) {
+    for (BSet* s : {&w.bsA, &w.bsO, &w.bsM}) {
         s->pre1 = c.buf(B, Hb, pad64(Hb)); s->t1 = c.buf(B, Hb, pad64(Hb)); s->r2 = c.buf(B, Hb, pad64(Hb));
         s->y = c.buf(B, z); s->Bm = c.buf(B, z);
         s->stats = c.f(2 * (size_t)B); s->norms = c.f(B);
@@ -424,6 +422,7 @@ struct Ops {
     std::vector<GemmProblem> gemms;
     std::vector<LnFwdProblem> lnf;
     std::vector<LnBwdProblem> lnb;
+    std::vector<L2Problem> l2n;               // run after this round's GEMMs
     std::vector<std::function<int(hipStream_t)>> post;
 };
 using Stage = std::function<void(Ops&)>;
@@ -440,6 +439,11 @@ int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
         LnBwdGroup g{};
         for (size_t j = i; j < o.lnb.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.lnb[j];
         HIPCK(c, launch_ln_tanh_bwd_group(g, s));
+    }
+    for (size_t i = 0; i < o.l2n.size(); i += LN_MAX_GROUP) {
+        L2Group g{};
+        for (size_t j = i; j < o.l2n.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.l2n[j];
+        HIPCK(c, launch_l2norm_fwd_group(g, s));
     }
     for (auto& f : o.post) RC(f(s));
     return FBHIP_OK;
@@ -562,11 +566,7 @@ void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Lb, W.b3, EPI_BIAS));
-        if (with_projection)
-            o.post.push_back([=](hipStream_t s) -> int {
-                HIPCK(c, launch_l2norm_fwd(Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z), s));
-                return (int)FBHIP_OK;
-            });
+        if (with_projection) o.l2n.push_back(L2Problem{Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z)});
     });
 }
 
@@ -690,7 +690,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // batches) overwrite the draw
         const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
                                   inj->z_gauss && inj->eps_next && inj->eps_actor;
-        if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, w.perm_keys, s));
+        if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, s));
         if (inj != nullptr) {
 #define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
             INJ(ep_idx, B * 4); INJ(step_idx, B * 4); INJ(perm, B * 4); INJ(mix_uniform, B * 4);
@@ -707,12 +707,23 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         HIPCK(c, launch_gather(ga, s));
         // sample_z (fb_ddpg.py:224-228) + z-mix (fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm])))
         // in one row kernel; the BackwardMap pass stops at its raw mlp output y (the kernel applies both projections)
-        if (hp.mix_ratio > 0.f) {
-            Chain ch;
-            backward_map_fwd_chain(c, c->K_p, w.bin.p, w.bin.ld, w.bsA, B, ch, /*with_projection=*/false);
-            RC(run_chain(c, ch, s));
+        // When the FB step follows in the same call, the target / online BackwardMap passes on next_goal (fb_ddpg.py:312,
+        // :319) share these launches: they only need the gathered batch.
+        {
+            std::vector<Chain> ch;
+            if (hp.mix_ratio > 0.f) {
+                ch.emplace_back();
+                backward_map_fwd_chain(c, c->K_p, w.bin.p, w.bin.ld, w.bsM, B, ch.back(), /*with_projection=*/false);
+            }
+            if (mask & FBHIP_PHASE_FB_GRAD) {
+                ch.emplace_back();
+                backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
+                ch.emplace_back();
+                backward_map_fwd_chain(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch.back());
+            }
+            RC(run_rounds(c, ch, s));
         }
-        HIPCK(c, launch_mix_z(w.so.z_gauss, z, w.bsA.y.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
+        HIPCK(c, launch_mix_z(w.so.z_gauss, z, w.bsM.y.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, s));
     }
 
@@ -733,13 +744,18 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         {
             // chain A: targets, no grad (fb_ddpg.py:303-315): actor(next_obs) -> next_action -> forward_target
             // chain B: online F (fb_ddpg.py:318)    chains C, D: target B (:312) and online B (:319)
-            std::vector<Chain> ch(4);
+            // (C, D already ran with the sampler's z-mix pass when this call also covered the SAMPLE phase)
+            std::vector<Chain> ch(2);
             actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0]);
             ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + o, w.Xnoa.ld));
             forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
             forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
-            backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch[2]);
-            backward_map_fwd_chain(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch[3]);
+            if (!(mask & FBHIP_PHASE_SAMPLE)) {
+                ch.emplace_back();
+                backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
+                ch.emplace_back();
+                backward_map_fwd_chain(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch.back());
+            }
             RC(run_rounds(c, ch, s));
         }
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)

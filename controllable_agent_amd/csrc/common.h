@@ -70,6 +70,10 @@ struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const 
                       int rows, n, vdy, vy, vx, vdx, vp; };
 struct LnBwdGroup { LnBwdProblem p[LN_MAX_GROUP]; int n; };
 hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s);
+// out = scale * y / max(||y||, 1e-12) per row (F.normalize, fb_modules.py:229); grouped like the LayerNorm launches
+struct L2Problem { const float* y; int ldy; float* out; int ldo; float* norms; int rows, d; float scale; };
+struct L2Group { L2Problem p[LN_MAX_GROUP]; int n; };
+hipError_t launch_l2norm_fwd_group(const L2Group& g, hipStream_t s);
 hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float* norms, int rows, int d,
                              float scale, hipStream_t s);
 // policy head: mu = tanh(pre); action = clampST(mu + clip(noise*std))   (utils.py:171-185)
@@ -126,7 +130,7 @@ struct SampleOut {          // all device pointers into the workspace
     float* z_gauss; float* eps_next; float* eps_actor;
 };
 hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a,
-                       uint64_t seed, uint32_t rank, const StepState* st, unsigned long long* perm_keys,
+                       uint64_t seed, uint32_t rank, const StepState* st,
                        hipStream_t s);
 struct GatherArgs {
     ReplayView rv;

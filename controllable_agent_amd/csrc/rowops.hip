@@ -266,12 +266,12 @@ hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy
 
 // ------------------------------------------------------------------------------------------------------
 constexpr int L2_MAXE = 4;      // d <= 256
-__global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict__ y, int ldy, float* __restrict__ out,
-                                                         int ldo, float* __restrict__ norms, int rows, int d,
-                                                         float scale) {
+__global__ void __launch_bounds__(256) l2norm_fwd_kernel(const L2Group grp) {
+    const L2Problem& p = grp.p[blockIdx.y];
+    const int rows = p.rows, d = p.d;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* yr = y + (size_t)row * ldy;
+    const float* yr = p.y + (size_t)row * p.ldy;
     float v[L2_MAXE];
     float s = 0.f;
 #pragma unroll
@@ -282,21 +282,32 @@ __global__ void __launch_bounds__(256) l2norm_fwd_kernel(const float* __restrict
     }
     const float nrm = sqrtf(wave_sum(s));
     const float den = fmaxf(nrm, 1e-12f);                 // F.normalize eps
-    float* o = out + (size_t)row * ldo;
+    float* o = p.out + (size_t)row * p.ldo;
 #pragma unroll
     for (int i = 0; i < L2_MAXE; ++i) {
         const int j = lane + 64 * i;
-        if (j < d) o[j] = scale * (v[i] / den);
+        if (j < d) o[j] = p.scale * (v[i] / den);
     }
-    if (norms != nullptr && lane == 0) norms[row] = nrm;
+    if (p.norms != nullptr && lane == 0) p.norms[row] = nrm;
+}
+
+hipError_t launch_l2norm_fwd_group(const L2Group& g, hipStream_t s) {
+    int maxrows = 0;
+    for (int i = 0; i < g.n; ++i) {
+        if (g.p[i].d > 64 * L2_MAXE) return hipErrorInvalidValue;
+        maxrows = g.p[i].rows > maxrows ? g.p[i].rows : maxrows;
+    }
+    if (g.n < 1 || maxrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((maxrows + 3) / 4, g.n), dim3(256), 0, s, g);
+    return hipGetLastError();
 }
 
 hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float* norms, int rows, int d,
                              float scale, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    if (d > 64 * L2_MAXE) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, ldy, out, ldo, norms, rows, d, scale);
-    return hipGetLastError();
+    L2Group g{};
+    g.n = 1;
+    g.p[0] = L2Problem{y, ldy, out, ldo, norms, rows, d, scale};
+    return launch_l2norm_fwd_group(g, s);
 }
 
 // dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB)),  yhat = y/||y||

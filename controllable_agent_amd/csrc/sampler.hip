@@ -39,8 +39,7 @@ __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& n0, fl
 enum { STREAM_INDEX = 0, STREAM_PERM = 1, STREAM_MIX = 2, STREAM_Z = 3, STREAM_EPS_NEXT = 4, STREAM_EPS_ACTOR = 5 };
 
 __global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, int B, int d, int a, unsigned k0,
-                                                   unsigned k1, const StepState* __restrict__ st,
-                                                   unsigned long long* __restrict__ perm_keys) {
+                                                   unsigned k1, const StepState* __restrict__ st) {
     const unsigned cnt = st->update_count;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < B) {
@@ -67,9 +66,29 @@ __global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, 
         }
         so.ep_idx[i] = ep;
         so.step_idx[i] = step;
-        const U4 q = philox4x32_10((unsigned)i, STREAM_PERM, cnt, 0u, k0, k1);
-        perm_keys[i] = ((unsigned long long)q.x << 32) | (unsigned)i;       // torch.randperm (fb_ddpg.py:467)
         so.mix_uniform[i] = u01(philox4x32_10((unsigned)i, STREAM_MIX, cnt, 0u, k0, k1).x);   // fb_ddpg.py:471
+    }
+    // torch.randperm (fb_ddpg.py:467) = argsort of B random keys (Philox word, ties broken by index).  Workgroup b ranks
+    // keys 32b .. 32b+31: it regenerates all B keys in LDS (Philox is counter-based), 8 lanes per key each count the
+    // smaller keys of one residue class, and perm[rank(i)] = i.
+    if (blockIdx.x * 32 < B) {
+        extern __shared__ unsigned sk[];
+        const int n64 = (B + 63) & ~63;                 // padded with sentinels that never count
+        for (int j = threadIdx.x; j < n64; j += 256)
+            sk[j] = j < B ? philox4x32_10((unsigned)j, STREAM_PERM, cnt, 0u, k0, k1).x : 0xffffffffu;
+        __syncthreads();
+        const int part = threadIdx.x & 7, ii = blockIdx.x * 32 + (threadIdx.x >> 3);
+        const unsigned mine = sk[ii < B ? ii : 0];
+        int r = 0;
+        for (int t = 0; t < n64; t += 64) {
+            unsigned h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = sk[t + 8 * u + part];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += (h[u] < mine || (h[u] == mine && t + 8 * u + part < ii)) ? 1 : 0;
+        }
+        r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+        if (ii < B && part == 0) so.perm[r] = ii;
     }
     // gaussians: 4 per Philox call
     const int nz = B * d, na = B * a;
@@ -90,28 +109,6 @@ __global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (4 * q4 + j < na) { so.eps_next[4 * q4 + j] = n[j]; so.eps_actor[4 * q4 + j] = m[j]; }
     }
-}
-
-// random permutation = argsort of B random keys: single-workgroup bitonic sort in LDS (B <= 8192)
-__global__ void __launch_bounds__(1024) perm_sort_kernel(const unsigned long long* __restrict__ keys, int B, int n2,
-                                                         int32_t* __restrict__ perm) {
-    extern __shared__ unsigned long long sk[];
-    for (int i = threadIdx.x; i < n2; i += 1024) sk[i] = i < B ? keys[i] : ~0ull;
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += 1024) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long x = sk[i], y = sk[ixj];
-                    const bool up = ((i & k) == 0);
-                    if ((x > y) == up) { sk[i] = y; sk[ixj] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = threadIdx.x; i < B; i += 1024) perm[i] = (int32_t)(sk[i] & 0xffffffffull);
 }
 
 __device__ __forceinline__ void copy_row(float* __restrict__ dst, const float* __restrict__ src, int n, int lane) {
@@ -202,17 +199,12 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
 }  // namespace
 
 hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a, uint64_t seed, uint32_t rank,
-                       const StepState* st, unsigned long long* perm_keys, hipStream_t s) {
+                       const StepState* st, hipStream_t s) {
     if (B > 8192) return hipErrorInvalidValue;
     const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
     int blocks = (B * d / 4 + 255) / 256;
-    if (blocks < (B + 255) / 256) blocks = (B + 255) / 256;
-    hipLaunchKernelGGL(draw_kernel, dim3(blocks), dim3(256), 0, s, rv, so, B, d, a, k0, k1, st, perm_keys);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    int n2 = 1;
-    while (n2 < B) n2 <<= 1;
-    hipLaunchKernelGGL(perm_sort_kernel, dim3(1), dim3(1024), (size_t)n2 * 8, s, perm_keys, B, n2, so.perm);
+    if (blocks < (B + 31) / 32) blocks = (B + 31) / 32;
+    hipLaunchKernelGGL(draw_kernel, dim3(blocks), dim3(256), (size_t)((B + 63) & ~63) * 4, s, rv, so, B, d, a, k0, k1, st);
     return hipGetLastError();
 }
 
