@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -326,8 +327,19 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
         tiles32 += (long)((p.M + 31) / 32) * ((p.N + 31) / 32);
         kmax = p.K > kmax ? p.K : kmax; nmax = p.N > nmax ? p.N : nmax; mmax = p.M > mmax ? p.M : mmax;
     }
+    bool dma_all = true;
+    long tiles128 = 0;
+    for (auto& p : v) {
+        dma_all = dma_all && gemm_problem_dma_ok(p);
+        tiles128 += (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+    }
     int cfg;
-    if (kmax <= 64) cfg = (nmax <= 32) ? CFG_4x1x1 : CFG_2x2x1;
+    // >= 4 128x64 tiles per CU: the LDS-DMA kernel with two accumulators per wave (25 % fewer operand bytes per FLOP
+    // through the per-CU global->LDS path; 132 vs 122 TFLOP/s at 4096^3).  The step's own launches have 1-2 tiles per CU
+    // and measure faster on the register-staged 64x64 kernel (see gemm.hip).
+    static const long dma128_min = [] { const char* e = getenv("FBHIP_DMA128_MIN_TILES"); return e ? atol(e) : 1024L; }();
+    if (dma_all && kmax > 64 && tiles128 >= dma128_min) cfg = CFG_DMA128;
+    else if (kmax <= 64) cfg = (nmax <= 32) ? CFG_4x1x1 : CFG_2x2x1;
     // aim for >= 2 workgroups per CU (>= 512): a lone wave per SIMD cannot hide LDS / L2 latency behind its one
     // dependent MFMA chain, so medium outputs split K inside the workgroup instead of using bigger tiles
     else if (tiles32 >= 2048) cfg = CFG_2x2x1;

@@ -41,7 +41,8 @@ struct GemmGroup {
 };
 
 // tile configurations: <waves along M, waves along N, waves along K>, each wave owns one 32x32 MFMA tile
-enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4x1x1 = 4, CFG_COUNT };
+enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4x1x1 = 4, CFG_DMA128 = 5, CFG_DMA64 = 6,
+               CFG_COUNT };   // the last two: LDS-DMA kernels (128x64 / 64x64 tiles), need gemm_problem_dma_ok()
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
 hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream);
@@ -50,6 +51,7 @@ int gemm_cfg_bm(int cfg);     // tile rows / columns
 int gemm_cfg_bn(int cfg);
 hipError_t gemm_init();        // one-time kernel attribute setup (outside graph capture)
 int pick_gemm_cfg(int M, int N, int K);
+bool gemm_problem_dma_ok(const GemmProblem& p);        // eligible for the LDS-DMA kernels (CFG_DMA128 requires it)
 void gemm_problem_finalize(GemmProblem& p, int cfg);   // fills a_vec/b_vec/tiles_*
 
 // ---- row-wise ops ------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 // loads of step t+1 are issued before the MFMAs of step t.
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace fbhip {
@@ -75,6 +76,59 @@ __device__ __forceinline__ void store_quad(float* __restrict__ d, int step, cons
     d[step] = v.y;
     d[2 * step] = v.z;
     d[3 * step] = v.w;
+}
+
+// accumulator tile -> C (or the split-K partial slab) with the fused epilogue; acc row = (r&3) + 8(r>>2) + 4h, col = l31
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx16& acc, float csum, int slice, int row0,
+                                              int col0, int wm, int wn, int tn, int l31, int h) {
+    const int M = p.M, N = p.N;
+    if (p.kslices > 1) {
+        // raw partial tile (+ partial column sums behind the tiles); splitk_reduce_kernel applies the epilogue
+        float* part = p.partial + (size_t)slice * M * N;
+        if (p.colsum != nullptr && tn == 0 && wn == 0) {
+            const float tot = csum + __shfl_xor(csum, 32);
+            const int r = row0 + wm * 32 + l31;
+            if (h == 0 && r < M) p.partial[(size_t)p.kslices * M * N + (size_t)slice * M + r] = tot;
+        }
+        const int col = col0 + wn * 32 + l31;
+        if (col >= N) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < M) part[(size_t)row * N + col] = acc[r];
+        }
+        return;
+    }
+
+    if (p.colsum != nullptr && tn == 0 && wn == 0) {
+        const float tot = csum + __shfl_xor(csum, 32);
+        const int r = row0 + wm * 32 + l31;
+        if (h == 0 && r < M) p.colsum[r] = tot;
+    }
+
+    const int col = col0 + wn * 32 + l31;
+    if (col >= N) return;
+    const int epi = p.epi;
+    const float bias = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? p.bias[col] : 0.f;
+    float* __restrict__ C = p.C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) {
+            float v = acc[r];
+            if (epi == EPI_BIAS) {
+                v += bias;
+            } else if (epi == EPI_BIAS_RELU) {
+                v = fmaxf(v + bias, 0.f);
+            } else if (epi == EPI_MASK_RELU) {
+                v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
+            } else if (epi == EPI_TANH_BWD) {
+                const float y = p.aux[(size_t)row * p.ldaux + col];
+                v = v * (1.f - y * y);
+            }
+            C[(size_t)row * p.ldc + col] = v;
+        }
+    }
 }
 
 // Wave-specialised workgroup of 8 waves: waves 0-3 are CONSUMERS (one 32x32 accumulator each, arranged WM x WN x WK;
@@ -299,53 +353,232 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
         }
     }
 
-    if (p.kslices > 1) {
-        // raw partial tile (+ partial column sums behind the tiles); splitk_reduce_kernel applies the epilogue
-        float* part = p.partial + (size_t)slice * M * N;
-        if (p.colsum != nullptr && tn == 0 && wn == 0) {
-            const float tot = csum + __shfl_xor(csum, 32);
-            const int r = row0 + wm * 32 + l31;
-            if (h == 0 && r < M) p.partial[(size_t)p.kslices * M * N + (size_t)slice * M + r] = tot;
-        }
-        const int col = col0 + wn * 32 + l31;
-        if (col >= N) return;
+    gemm_epilogue(p, acc, csum, slice, row0, col0, wm, wn, tn, l31, h);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA kernels: (64 TM) x 64 x 32 tiles, TM = 1 or 2 accumulators per consumer wave.
+//
+// Knock-out measurements on the register-staged kernel above and on this one (tools/gemm_diag.py, 4096^3, MI355X):
+// without any MFMA the staging pipeline alone (global -> LDS of every chunk + fragment reads + barriers) needs 625 us
+// (registers) / 893 us (DMA) against 874 us of pure matrix-pipe time, and it does not get faster when every chunk reads
+// the same (cache-resident) addresses: 64x64 tiles are bound by the per-CU global->LDS path (~16 B/clk/CU), not by MFMA
+// issue, LDS bandwidth, barriers or L2 misses.  The lever is bytes per FLOP: the 128x64 tile moves 25 % fewer, with
+// two INDEPENDENT accumulator chains per wave so one wave per SIMD keeps the matrix pipe busy.
+//
+// Producer waves move global -> LDS with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR round trip, no
+// ds_write pass).  The DMA writes lane-linear (M0 base + 16 B * lane), so the LDS image is chosen by the SOURCE
+// address of each lane:
+//   k-contiguous operand (X[M,K], W[N,K]):  piece = 8 rows x 32 k = 8 FULL 128-byte lines (fragment-shaped
+//       16-row x 64-byte pieces request every line twice and halve the TA/L2 rate): lane l fetches row l%8 and the
+//       16-byte quad (l/8) ^ (piece & 1) of it, so granule position pos of row r holds quad pos ^ ((r>>3) & 1).  A
+//       fragment is ONE ds_read_b128 per lane = 4 consecutive k of its row; with the XOR the 16 rows of a hardware
+//       b128 lane group hit 16 distinct granule slots (conflict-free, 256 B/clk).  Linear destination, swizzled SOURCE,
+//       same involution on the read.
+//   k-strided operand (dY^T, X^T of wgrad): piece = 4 k x 64 rows: lane l fetches k l/16, rows 4(l%16)..+3
+//       -> [k][row] rows of 64 floats, fragments by ds_read_b32 (consecutive lanes = consecutive dwords).
+// MFMA (t, m), t = 0..3, m = 0..3 of a chunk contracts k = 8t + 4h + m (h = lane >> 5) for both operands.
+// A ring of S chunk buffers with ONE barrier per chunk: at barrier i the producers have waited (counted vmcnt) for
+// chunk i+1 and the consumers have retired their fragment reads of chunk i, whose buffer then takes chunk i + S; the
+// consumers read the fragments of chunk i+1 while the MFMAs of chunk i run (two register sets), so the MFMA chains
+// restart right after each barrier.  Requires K % 32 == 0 per slice and 16-byte aligned operands; ragged M / N tiles
+// read clamped (valid) rows whose results the epilogue drops.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most ``chunks`` chunks (P DMAs each) are still in flight
+template <int P, int MAXC>
+__device__ __forceinline__ void wait_chunks(int chunks) {
+    static_assert(MAXC >= 1 && MAXC <= 3 && P * MAXC < 64, "vmcnt is a 6-bit immediate");
+    if (chunks >= 3 && MAXC >= 3) wait_vmcnt<P * (MAXC >= 3 ? 3 : 0)>();
+    else if (chunks >= 2 && MAXC >= 2) wait_vmcnt<P * (MAXC >= 2 ? 2 : 0)>();
+    else if (chunks >= 1) wait_vmcnt<P>();
+    else wait_vmcnt<0>();
+}
+
+template <int TM> struct DmaGeom {
+    static constexpr int BM = 64 * TM, BN = 64, BKT = 32;
+    static constexpr int S = TM == 1 ? 4 : 3;                  // ring depth (chunks)
+    static constexpr int NPW = 4;                              // producer waves (a DMA costs its wave 60-180 issue cycles)
+    static constexpr int STAGE = (BM + BN) * BKT;              // floats per chunk buffer: A tile then B tile
+    static constexpr int BOFF = BM * BKT;
+    static constexpr int PIECES = (BM + BN) / 8;               // 1 KiB DMA pieces per chunk
+    static constexpr int P = PIECES / NPW;                     // per producer wave
+    static constexpr size_t LDS_BYTES = (size_t)S * STAGE * sizeof(float);
+    static constexpr bool PREFETCH = TM == 1;                  // fragments of chunk i+1 read during the MFMAs of chunk i
+};
+
+// fragment offsets (floats) inside an operand tile of R rows
+template <bool KC, int R>
+__device__ __forceinline__ int dma_frag_off(int row, int h) {
+    return KC ? ((row >> 3) * 256 + (row & 7) * 4 + ((h ^ ((row >> 3) & 1)) * 32))
+              : ((h * (R / 64) + (row >> 6)) * 256 + (row & 63));
+}
+template <bool KC, int R>
+__device__ __forceinline__ void dma_read_frag(const float* __restrict__ op, int off, float (&f)[4][4]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < M) part[(size_t)row * N + col] = acc[r];
+    for (int t = 0; t < 4; ++t) {
+        if constexpr (KC) {
+            const float4 v = *reinterpret_cast<const float4*>(op + off + t * 64);
+            f[t][0] = v.x; f[t][1] = v.y; f[t][2] = v.z; f[t][3] = v.w;
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) f[t][m] = op[off + t * 512 * (R / 64) + m * 64];
+        }
+    }
+}
+
+template <int TM, bool AKC, bool BKC>
+__device__ __forceinline__ void dma_consume(const float* __restrict__ smem, int nt, int lane, int wm, int wn,
+                                            floatx16 (&acc)[TM], float (&csum)[TM]) {
+    using G = DmaGeom<TM>;
+    const int l31 = lane & 31, h = lane >> 5;
+    int offa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offa[i] = dma_frag_off<AKC, G::BM>(wm * 32 * TM + 32 * i + l31, h);
+    const int offb = G::BOFF + dma_frag_off<BKC, G::BN>(wn * 32 + l31, h);
+    float a0[TM][4][4], b0[4][4];
+    auto read = [&](int c, float (&a)[TM][4][4], float (&b)[4][4]) __attribute__((always_inline)) {
+        const float* st = smem + (c % G::S) * G::STAGE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) dma_read_frag<AKC, G::BM>(st, offa[i], a[i]);
+        dma_read_frag<BKC, G::BN>(st, offb, b);
+    };
+    auto mfma = [&](const float (&a)[TM][4][4], const float (&b)[4][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t][m], b[t][m], acc[i], 0, 0, 0);
+                    csum[i] += a[i][t][m];
+                }
+    };
+    __syncthreads();                                            // barrier "init": chunk 0 has landed
+    if constexpr (G::PREFETCH) {
+        float a1[TM][4][4], b1[4][4];
+        read(0, a0, b0);
+        for (int it = 0; it < nt; it += 2) {
+            __syncthreads();                                    // barrier it: chunk it+1 has landed, chunk it is in set 0
+            if (it + 1 < nt) read(it + 1, a1, b1);
+            mfma(a0, b0);
+            if (it + 1 >= nt) break;
+            __syncthreads();                                    // barrier it+1
+            if (it + 2 < nt) read(it + 2, a0, b0);
+            mfma(a1, b1);
+        }
+    } else {
+        // two independent accumulator chains per wave and a second workgroup on the CU cover the fragment-read latency;
+        // one register set keeps the kernel at two workgroups per CU
+        for (int it = 0; it < nt; ++it) {
+            read(it, a0, b0);
+            mfma(a0, b0);
+            __syncthreads();                                    // barrier it: reads of chunk it retired
+        }
+    }
+}
+
+template <int TM>
+__global__ void __launch_bounds__(256 + 64 * DmaGeom<TM>::NPW) gemm_dma_kernel(const GemmGroup g) {
+    using G = DmaGeom<TM>;
+    constexpr int BM = G::BM, BN = G::BN, BKT = G::BKT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // S * STAGE floats
+
+    const int orig = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+        if (i < g.n && orig >= g.p[i].tile_start) pi = i;
+    const GemmProblem& p = g.p[pi];
+    const int nwg = p.tiles_m * p.tiles_n * p.kslices;
+    const int jb = orig - p.tile_start;
+    const int xcd = jb & 7, qd = nwg >> 3, rm = nwg & 7;
+    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (jb >> 3);
+    const int tiles_mn = p.tiles_m * p.tiles_n;
+    const int slice = t / tiles_mn, tt = t % tiles_mn;
+    const int tn = tt % p.tiles_n, tm = tt / p.tiles_n;
+    const int M = p.M, N = p.N;
+    const int kb = slice * p.kper * BKT;
+    const int K = min(p.K, kb + p.kper * BKT);
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nt = (K - kb) / BKT;
+
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+
+    if (wid >= 4) {
+        // =========================================================================================== PRODUCERS
+        const int w = wid - 4;                               // pieces w*P .. w*P + P-1 (A pieces first, then B)
+        const float* src[G::P];
+        size_t adv[G::P];
+#pragma unroll
+        for (int q = 0; q < G::P; ++q) {
+            const int pc = w * G::P + q;
+            const bool isA = pc < BM / 8;
+            const int po = isA ? pc : pc - BM / 8;           // piece index inside its operand tile
+            const float* base = isA ? p.A : p.B;
+            const int ld = isA ? p.lda : p.ldb, kc = isA ? p.a_kcontig : p.b_kcontig;
+            const int r0 = isA ? row0 : col0, nr = isA ? M : N, rpk = isA ? BM / 64 : BN / 64;
+            if (kc) {
+                const int r = min(r0 + po * 8 + (lane & 7), nr - 1);
+                src[q] = base + (size_t)r * ld + kb + (((lane >> 3) ^ (po & 1)) * 4);
+                adv[q] = (size_t)BKT;
+            } else {
+                const int r = min(r0 + (po % rpk) * 64 + 4 * (lane & 15), (nr - 1) & ~3);
+                src[q] = base + (size_t)(kb + (po / rpk) * 4 + (lane >> 4)) * ld + r;
+                adv[q] = (size_t)BKT * ld;
+            }
+        }
+        float* const dst = smem + (w * G::P) * 256;           // pieces are 256 floats, A tile then B tile
+        auto issue = [&](int c) __attribute__((always_inline)) {
+            float* d = dst + (c % G::S) * G::STAGE;
+#pragma unroll
+            for (int q = 0; q < G::P; ++q) glds16(src[q] + (size_t)c * adv[q], d + q * 256);
+        };
+        for (int c = 0; c < G::S && c < nt; ++c) issue(c);
+        // barrier "init": chunk 0 landed (up to S - 1 later chunks stay in flight)
+        wait_chunks<G::P, G::S - 1>(nt - 1);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int it = 0; it < nt; ++it) {
+            // barrier it: chunk it+1 must have landed; chunks it+2 .. it+S-1 (those already issued) stay in flight
+            wait_chunks<G::P, G::S - 2>(nt - 2 - it);
+            __builtin_amdgcn_s_barrier();                       // raw: a fence would drain the DMAs
+            asm volatile("" ::: "memory");
+            // the consumers retired their reads of chunk ``it`` before this barrier: its buffer takes chunk it + S
+            if (it + G::S < nt) issue(it + G::S);
         }
         return;
     }
 
-    if (p.colsum != nullptr && tn == 0 && wn == 0) {
-        const float tot = csum + __shfl_xor(csum, 32);
-        const int r = row0 + wm * 32 + l31;
-        if (h == 0 && r < M) p.colsum[r] = tot;
-    }
-
-    const int col = col0 + wn * 32 + l31;
-    if (col >= N) return;
-    const int epi = p.epi;
-    const float bias = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? p.bias[col] : 0.f;
-    float* __restrict__ C = p.C;
+    // ============================================================================================== CONSUMERS
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    floatx16 acc[TM];
+    float csum[TM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < M) {
-            float v = acc[r];
-            if (epi == EPI_BIAS) {
-                v += bias;
-            } else if (epi == EPI_BIAS_RELU) {
-                v = fmaxf(v + bias, 0.f);
-            } else if (epi == EPI_MASK_RELU) {
-                v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
-            } else if (epi == EPI_TANH_BWD) {
-                const float y = p.aux[(size_t)row * p.ldaux + col];
-                v = v * (1.f - y * y);
-            }
-            C[(size_t)row * p.ldc + col] = v;
-        }
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+        csum[i] = 0.f;
     }
+    const int mode = p.a_kcontig * 2 + p.b_kcontig;
+    if (mode == 3) dma_consume<TM, true, true>(smem, nt, lane, wm, wn, acc, csum);
+    else if (mode == 2) dma_consume<TM, true, false>(smem, nt, lane, wm, wn, acc, csum);
+    else if (mode == 0) dma_consume<TM, false, false>(smem, nt, lane, wm, wn, acc, csum);
+    else dma_consume<TM, false, true>(smem, nt, lane, wm, wn, acc, csum);
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        gemm_epilogue(p, acc[i], csum[i], slice, row0 + wm * 32 * TM + 32 * i, col0, 0, wn, tn, l31, h);
 }
 
 // C = epi(sum_slices partial[s]) for every split-K problem of a group; one thread per output element (+ the column
@@ -391,8 +624,8 @@ hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t
     return hipGetLastError();
 }
 
-static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4};
-static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1};
+static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4, 4, 2};     // CFG_DMA128: 128 x 64, CFG_DMA64: 64 x 64 (LDS-DMA kernels)
+static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1, 2, 2};
 
 // <WM, WN, WK, BK> per configuration
 #define FBHIP_CFGS(X) X(CFG_2x2x1, 2, 2, 1, 32) X(CFG_2x1x2, 2, 1, 2, 32) X(CFG_1x2x2, 1, 2, 2, 32) X(CFG_1x1x4, 1, 1, 4, 16) X(CFG_4x1x1, 4, 1, 1, 32)
@@ -425,8 +658,36 @@ hipError_t gemm_init() {
     }
     FBHIP_CFGS(X)
 #undef X
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DmaGeom<1>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)DmaGeom<2>::LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
     done = true;
     return hipSuccess;
+}
+
+// FBHIP_GEMM_DMA=1 also routes the 64x64 configuration through the LDS-DMA kernel.  Measured on the FB-DDPG step
+// (MI355X, 1-2 tiles per CU per launch): register staging 882 updates/s, DMA 64x64 870, DMA 128x64 from 512 tiles 854 --
+// the DMA kernels only win once a launch has >= 4 128x64 tiles per CU (4096^3: 132 vs 122 TFLOP/s), so the default
+// keeps the step on the register-staged kernel and uses CFG_DMA128 for large generic GEMMs only.
+static bool gemm_dma64_enabled() {
+    static const bool on = [] { const char* e = getenv("FBHIP_GEMM_DMA"); return e && e[0] == '1'; }();
+    return on;
+}
+
+// the LDS-DMA kernels need whole 32-deep chunks and 16-byte aligned operands
+bool gemm_problem_dma_ok(const GemmProblem& p) {
+    const bool a_vec = (((uintptr_t)p.A & 15) == 0 && (p.lda & 3) == 0), b_vec = (((uintptr_t)p.B & 15) == 0 && (p.ldb & 3) == 0);
+    return a_vec && b_vec && p.K > 0 && (p.K % 32) == 0 && (p.a_kcontig || p.M >= 4) && (p.b_kcontig || p.N >= 4);
+}
+static bool gemm_group_dma_ok(const GemmGroup& g) {
+    for (int i = 0; i < g.n; ++i)
+        if (!gemm_problem_dma_ok(g.p[i])) return false;
+    return true;
 }
 
 void gemm_problem_finalize(GemmProblem& p, int cfg) {
@@ -450,6 +711,16 @@ int pick_gemm_cfg(int M, int N, int K) {
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
     if (g.total_tiles <= 0) return hipSuccess;
     dim3 grid(g.total_tiles), block(512);
+    if (cfg == CFG_DMA128) {
+        if (!gemm_group_dma_ok(g)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(gemm_dma_kernel<2>, grid, dim3(256 + 64 * DmaGeom<2>::NPW), DmaGeom<2>::LDS_BYTES, stream, g);
+        return hipGetLastError();
+    }
+    if (cfg == CFG_DMA64 && !gemm_group_dma_ok(g)) return hipErrorInvalidValue;
+    if (cfg == CFG_DMA64 || (cfg == CFG_2x2x1 && gemm_dma64_enabled() && gemm_group_dma_ok(g))) {
+        hipLaunchKernelGGL(gemm_dma_kernel<1>, grid, dim3(256 + 64 * DmaGeom<1>::NPW), DmaGeom<1>::LDS_BYTES, stream, g);
+        return hipGetLastError();
+    }
     switch (cfg) {
 #define X(id, wm, wn, wk, bk)                                                                                       \
     case id:                                                                                                         \

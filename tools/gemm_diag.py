@@ -22,18 +22,21 @@ CBAR = "        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);              
 
 
 def variants(src):
+    """Knock-outs of the LDS-DMA kernel (gemm_dma_kernel): results are wrong, timings tell what the stage costs."""
     v = {"base": src}
-    nomfma = src.replace(MFMA, "acc[j % 16] += av[j] * bv[j];")
-    noload = src.replace(LOADA, "for (int i = 0; i < QA; ++i) xa[i] = make_float4((float)ch, 1.f, 2.f, (float)oa);") \
-                .replace(LOADB, "for (int i = 0; i < QB; ++i) xb[i] = make_float4((float)ch, 1.f, 2.f, (float)ob);")
-    nostore = noload.replace(STA, "for (int i = 0; i < QA; ++i) if (xa[i].x == -123.f) dA[sa[i]] = 0.f;") \
-                    .replace(STB, "for (int i = 0; i < QB; ++i) if (xb[i].x == -123.f) dA[sb[i]] = 0.f;")
-    nobar = src.replace(PBAR, PBAR.replace("__syncthreads();", "")).replace(CBAR, CBAR.replace("__syncthreads();", ""))
-    v["nomfma"] = nomfma
-    v["noload"] = noload
-    v["nostore"] = nostore
-    v["nobar"] = nobar
-    v["nomfma_noload"] = noload.replace(MFMA, "acc[j % 16] += av[j] * bv[j];")
+    v["dma_halfload"] = src.replace("            glds16(sa[1] + (size_t)c * adv_a, d + 256);\n", "") \
+                           .replace("            glds16(sb[1] + (size_t)c * adv_b, d + 2048 + 256);\n", "")
+    v["dma_noload"] = src.replace("            glds16(sa[0] + (size_t)c * adv_a, d);\n", "") \
+                         .replace("            glds16(sa[1] + (size_t)c * adv_a, d + 256);\n", "") \
+                         .replace("            glds16(sb[0] + (size_t)c * adv_b, d + 2048);\n", "") \
+                         .replace("            glds16(sb[1] + (size_t)c * adv_b, d + 2048 + 256);\n", "")
+    v["dma_sameaddr"] = src.replace("glds16(sa[0] + (size_t)c * adv_a, d);", "glds16(sa[0], d);") \
+                           .replace("glds16(sa[1] + (size_t)c * adv_a, d + 256);", "glds16(sa[1], d + 256);") \
+                           .replace("glds16(sb[0] + (size_t)c * adv_b, d + 2048);", "glds16(sb[0], d + 2048);") \
+                           .replace("glds16(sb[1] + (size_t)c * adv_b, d + 2048 + 256);", "glds16(sb[1], d + 2048 + 256);")
+    MF = "            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][m], b[t][m], acc, 0, 0, 0);\n            csum += a[t][m];"
+    assert MF in src
+    v["dma_nomfma"] = src.replace(MF, "            acc[(4 * t + m) % 16] += a[t][m] * b[t][m];")
     for k, s in v.items():
         assert k == "base" or s != src, k
     return v
@@ -70,8 +73,8 @@ def timeit(fn, iters=50, warm=10):
     return e0.elapsed_time(e1) / iters * 1e3
 for (M, N, Kd) in ((1024, 2048, 1024), (4096, 4096, 4096), (1024, 1024, 1024)):
     A, B, C = torch.randn(M, Kd, device="cuda"), torch.randn(N, Kd, device="cuda"), torch.empty(M, N, device="cuda")
-    us = timeit(lambda: K.gemm(A, B, out=C, cfg=0), iters=20 if M > 2048 else 50)
-    print(f"  {str((M, N, Kd)):>22} cfg0 {us:9.1f} us {2 * M * N * Kd / us / 1e6:8.2f} TF-equivalent")
+    us = timeit(lambda: K.gemm(A, B, out=C, cfg=6), iters=20 if M > 2048 else 50)
+    print(f"  {str((M, N, Kd)):>22} cfg6 {us:9.1f} us {2 * M * N * Kd / us / 1e6:8.2f} TF-equivalent")
 '''
 
 
