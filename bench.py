@@ -99,6 +99,16 @@ def cpu_baseline(seed=1, budget_s=12.0, max_steps=40):
                       f"boolean-mask loss like the reference), {dt:.1f} s"}
 
 
+def measured_traffic():
+    """HBM-side bytes per update from the last committed PMC passes (profiles/traffic.json, written from
+    tools/pmc_summary.py output); bench.py itself cannot collect PMC counters.  None when no pass is on file."""
+    f = Path(__file__).resolve().parent / "profiles" / "traffic.json"
+    try:
+        return float(json.loads(f.read_text())["hbm_bytes_per_update"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def dominant_kernel_probe(stream_iters=50):
     """HIP-event timing (on the launch stream) of the step's dominant kernel shape: the stacked F1|F2 hidden layer
     GEMM  p[1024,2048] = h[1024,1024] . W3s^T  through the same fbhip gemm_kernel the update launches."""
@@ -186,7 +196,7 @@ def main():
                        "global_batch": WALKER["batch_size"] * world, "parallelism": f"dp{world}",
                        "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(),
                          "what": f"whole update step: {gflop:.2f} algorithmic GFLOP/update (SURVEY.md section 8d) x "
                                  "measured updates/s, per GPU, vs the exact-fp32 MFMA peak"},
         }

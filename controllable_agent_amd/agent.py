@@ -322,9 +322,6 @@ class FBHipAgent:
                                      ptr(self._actor_m), ptr(self._actor_v), ptr(self._workspace),
                                      self._workspace.numel()), ctx)
         check(lib.fbhip_set_seed(ctx, self._seed, self._rank()), ctx)
-        import os
-        if "FBHIP_PARALLEL" in os.environ:       # debugging / profiling: bit mask of fbhip_set_parallel
-            check(lib.fbhip_set_parallel(ctx, int(os.environ["FBHIP_PARALLEL"])), ctx)
 
         def layout(net: int) -> tp.List[TensorDesc]:
             out = []

@@ -137,7 +137,7 @@ struct Ws {
     Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov, inv_cov, BinvC;
     float* ln_partials = nullptr;
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
-    float* splitk = nullptr;            // split-K partial slabs, one per stream slot
+    float* splitk = nullptr;            // split-K partial slab
     float* pw_scratch = nullptr;
     size_t total_bytes = 0;
 };
@@ -202,7 +202,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.ln_partials = c.f((size_t)2 * ((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);   // two trunks
     w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
-    w.splitk = c.f((size_t)(1 + 3) * ((size_t)6 << 20));
+    w.splitk = c.f((size_t)6 << 20);
     w.total_bytes = (c.cur + 255) & ~(size_t)255;
     return w;
 }
@@ -267,15 +267,6 @@ struct fbhip_ctx {
     ActP A_p, A_g;
     std::vector<GraphEntry> graphs;
     std::string err;
-    // fork/join plumbing: independent passes of one update run on side streams (captured into the same hipGraph as
-    // parallel branches), ordered by events from this pool
-    static constexpr int NSIDE = 3;
-    hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> events;
-    int ev_next = 0;
-    // bit0: net-level forks, bit1: weight-gradient stream, bit3: Adam overlap.  bit2 (a side stream forking to another
-    // side stream) is off: nested forks make hipStreamEndCapture fault on ROCm 7.2 -- every fork starts at the origin stream
-    int parallel = 11;
 };
 
 namespace {
@@ -309,16 +300,11 @@ GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc
     return p;
 }
 
-// scratch for split-K partials: one slab per stream slot (0 = caller's stream, 1.. = side streams), so concurrent
-// branches never share it; standalone fbhip_gemm (ctx == nullptr) never splits
-constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB per slot
+// scratch for split-K partials (launches of one update are stream-ordered, so one slab serves them all); standalone
+// fbhip_gemm (ctx == nullptr) never splits
+constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB
 
-float* splitk_slab(fbhip_ctx* c, hipStream_t s) {
-    if (!c || !c->w.splitk) return nullptr;
-    int slot = 0;
-    for (int i = 0; i < fbhip_ctx::NSIDE; ++i) if (s == c->side[i]) slot = i + 1;
-    return c->w.splitk + (size_t)slot * SPLITK_SLAB_FLOATS;
-}
+float* splitk_slab(fbhip_ctx* c) { return (c && c->w.splitk) ? c->w.splitk : nullptr; }
 
 int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     long tiles32 = 0;
@@ -347,7 +333,7 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     else cfg = CFG_1x1x4;
     const int bkt = gemm_cfg_bkt(cfg);
     const int BMc = gemm_cfg_bm(cfg), BNc = gemm_cfg_bn(cfg);
-    float* slab = splitk_slab(ctx, s);
+    float* slab = splitk_slab(ctx);
     // per-workgroup cost of a problem in K-chunk units; tiles that take the predicated loader (ragged M / N,
     // unaligned views) cost ~3x per chunk
     auto cost_of = [&](const GemmProblem& p) {
@@ -409,16 +395,6 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
         HIPCK(ctx, launch_gemm_group(g, cfg, s));
         if (red > 0) HIPCK(ctx, launch_splitk_reduce(g, red, s));
     }
-    return FBHIP_OK;
-}
-
-// order ``to`` after everything enqueued so far on ``from`` (no-op when they are the same stream)
-int sync_streams(fbhip_ctx* c, hipStream_t from, hipStream_t to) {
-    if (from == to) return FBHIP_OK;
-    if (c->events.empty()) { c->err = g_err = "fbhip: event pool not initialised"; return FBHIP_E_STATE; }
-    hipEvent_t e = c->events[c->ev_next++ % c->events.size()];
-    HIPCK(c, hipEventRecord(e, from));
-    HIPCK(c, hipStreamWaitEvent(to, e, 0));
     return FBHIP_OK;
 }
 
@@ -919,8 +895,6 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
 int fbhip_destroy(fbhip_ctx* ctx) {
     if (!ctx) return FBHIP_OK;
     for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (auto& e : ctx->events) (void)hipEventDestroy(e);
-    for (int i = 0; i < fbhip_ctx::NSIDE; ++i) if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
     delete ctx;
     return FBHIP_OK;
 }
@@ -951,11 +925,6 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
     HIPCK(c, gemm_init());
     HIPCK(c, inverse_prepare());
-    if (c->events.empty()) {
-        for (int i = 0; i < fbhip_ctx::NSIDE; ++i) HIPCK(c, hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-        c->events.resize(96);
-        for (auto& e : c->events) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     c->bound = true;
     return FBHIP_OK;
 }
@@ -973,14 +942,6 @@ int fbhip_replay_bind(fbhip_ctx* c, const float* observation, const float* actio
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
     c->replay_bound = true;
-    return FBHIP_OK;
-}
-
-int fbhip_set_parallel(fbhip_ctx* c, int32_t enable) {
-    if (!c) return FBHIP_E_INVALID;
-    c->parallel = enable;
-    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
-    c->graphs.clear();
     return FBHIP_OK;
 }
 
@@ -1020,7 +981,6 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     RC(need_bound(c, (phase_mask & FBHIP_PHASE_SAMPLE) != 0));
     if (!hp) { c->err = g_err = "fbhip: null hparams"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
-    c->ev_next = 0;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     for (auto& g : c->graphs) {
         if (g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&

@@ -141,9 +141,6 @@ int fbhip_replay_bind(fbhip_ctx* ctx, const float* observation, const float* act
                       const float* goal, const int32_t* episode_len, const int64_t* cum_len,
                       int32_t n_episodes, int32_t t1, int32_t fixed_length);
 int fbhip_set_seed(fbhip_ctx* ctx, uint64_t seed, uint32_t rank);
-/* enable != 0 (default): independent passes of one update (target vs online nets, weight- vs data-gradient chains)
- * run on internal side streams / parallel hipGraph branches; 0 serialises everything on the caller's stream. */
-int fbhip_set_parallel(fbhip_ctx* ctx, int32_t enable);
 int fbhip_set_step_counts(fbhip_ctx* ctx, int32_t fb_steps, int32_t actor_steps, void* stream); /* Adam t */
 int fbhip_get_step_counts(fbhip_ctx* ctx, int32_t* host_fb_steps, int32_t* host_actor_steps, void* stream);
 

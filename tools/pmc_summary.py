@@ -1,0 +1,71 @@
+"""Summarise a rocprofv3 ``--pmc ... --output-format csv`` counter_collection file per kernel and per update step.
+
+  python tools/pmc_summary.py <dir-or-csv> [out.txt]
+
+A step = everything from one sampler draw_kernel to the next; the first ``skip`` steps (warm-up, graph capture) are
+dropped.  FETCH_SIZE / WRITE_SIZE are reported in bytes (rocprofv3 reports KiB); the gfx950 correction for wide
+coalesced reads (x2 on FETCH_SIZE, MI355X_MICROARCH.md "HBM") is printed next to the raw value, not applied silently.
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(n):
+    n = n.replace("fbhip::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:48]
+
+
+def main(path, out=None, skip=12):
+    files = [path] if path.endswith(".csv") else sorted(glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True))
+    rows = []
+    for f in files:
+        with open(f, newline="") as fh:
+            rows += list(csv.DictReader(fh))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    # step boundaries by dispatch id of draw_kernel
+    draw_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "draw_kernel" in r["Kernel_Name"]})
+    if len(draw_ids) <= skip + 2:
+        skip = 0
+    lo, hi = (draw_ids[skip], draw_ids[-1]) if draw_ids else (0, 1 << 62)
+    nsteps = max(1, len(draw_ids) - skip - 1)
+    per_kernel = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(set)
+    total = defaultdict(float)
+    for r in rows:
+        d = int(r["Dispatch_Id"])
+        if not (lo <= d < hi):
+            continue
+        k, c, v = short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])
+        per_kernel[k][c] += v
+        calls[k].add(d)
+        total[c] += v
+    counters = sorted(total)
+    scale = {c: (1024.0 if c in ("FETCH_SIZE", "WRITE_SIZE") else 1.0) for c in counters}
+    lines = [f"steps analysed: {nsteps} (dispatches {lo}..{hi}); counters: {', '.join(counters)}",
+             f"{'kernel':<50} {'calls/step':>10} " + " ".join(f"{c + '/step':>28}" for c in counters)]
+    for k in sorted(per_kernel, key=lambda k: -sum(per_kernel[k].values())):
+        lines.append(f"{k:<50} {len(calls[k]) / nsteps:>10.1f} " +
+                     " ".join(f"{per_kernel[k][c] * scale[c] / nsteps:>28.1f}" for c in counters))
+    lines.append(f"{'TOTAL per update step':<50} {'':>10} " + " ".join(f"{total[c] * scale[c] / nsteps:>28.1f}" for c in counters))
+    if "FETCH_SIZE" in total:
+        b = total["FETCH_SIZE"] * 1024.0 / nsteps
+        lines.append(f"FETCH_SIZE per step: {b / 1e6:.2f} MB raw, {2 * b / 1e6:.2f} MB with the gfx950 wide-read correction (x2)")
+    if "WRITE_SIZE" in total:
+        lines.append(f"WRITE_SIZE per step: {total['WRITE_SIZE'] * 1024.0 / nsteps / 1e6:.2f} MB (uncalibrated on gfx950)")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in total:
+        # calibration on this pool: the counter comes back in quad-cycles of ONE XCD, i.e. x32 = SIMD-cycles chip-wide
+        # (check: 15.1 M v_mfma_f32_32x32x2 per update x 64 cycles = 970 M SIMD-cycles)
+        busy = total["SQ_VALU_MFMA_BUSY_CYCLES"] / nsteps
+        lines.append(f"SQ_VALU_MFMA_BUSY_CYCLES per step: {busy / 1e6:.2f} M raw = {32 * busy / 1e6:.0f} M SIMD-cycles (x32: quad-cycles, "
+                     f"one XCD of 8) = {32 * busy / 64 / 1e6:.2f} M fp32 32x32x2 MFMAs")
+    txt = "\n".join(lines)
+    print(txt)
+    if out:
+        open(out, "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
