@@ -435,6 +435,24 @@ class FBHipAgent:
             if getattr(other, key, None) is not None:
                 getattr(self, key).load_state_dict(copy.deepcopy(getattr(other, key).state_dict()))
 
+    @classmethod
+    def from_reference_checkpoint(cls, path: tp.Any, device: tp.Any = "cuda", **overrides: tp.Any) -> "FBHipAgent":
+        """Rebuild an agent from a checkpoint the REFERENCE wrote (``latest.pt`` / ``snapshot_*.pt``: ``torch.save`` of
+        ``{'agent': FBDDPGAgent, ...}``, pretrain.py:437-449) without the reference installed: the pickled config gives
+        the constructor arguments, then ``init_from`` copies the five nets and both Adam states exactly like
+        ``load_checkpoint`` does (pretrain.py:476-478)."""
+        from . import reference_io
+        parts = reference_io.payload_parts(reference_io.load_reference_payload(path))
+        if "agent" not in parts:
+            raise KeyError(f"{path}: no 'agent' in the payload (keys: {sorted(parts)})")
+        ref = parts["agent"]
+        fields = reference_io.reference_agent_config(ref)
+        fields.update(overrides)
+        fields["device"] = device
+        agent = cls(**fields)
+        agent.init_from(ref)
+        return agent
+
     def sample_z(self, size: int, device: str = "cpu") -> torch.Tensor:  # fb_ddpg.py:224-232 (norm_z=True)
         gaussian_rdv = torch.randn((size, self.cfg.z_dim), dtype=torch.float32, device=device)
         gaussian_rdv = torch.nn.functional.normalize(gaussian_rdv, dim=1)

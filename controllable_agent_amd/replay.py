@@ -317,6 +317,27 @@ class DeviceReplayBuffer:
         return rb
 
     @classmethod
+    def from_reference_file(cls, path: tp.Union[str, Path], device: tp.Union[str, torch.device] = "cuda",
+                            discount: tp.Optional[float] = None, future: tp.Optional[float] = None) -> "DeviceReplayBuffer":
+        """Ingest a file the reference wrote with ``torch.save``: a pickled ``ReplayBuffer`` (``replay.pt`` /
+        ``relabeled_replay_*.pt``, train_offline.py:88-90) or a checkpoint dict holding one under ``'replay_loader'``
+        (pretrain.py:437-449) -- without the reference installed (``reference_io``).  Mirrors what
+        ``Workspace.load_checkpoint`` does to the buffer afterwards (pretrain.py:480-489): pending episode dropped,
+        ``_discount`` / ``_future`` taken from the caller's config when given, ``_max_episodes`` = stored episodes."""
+        from . import reference_io
+        parts = reference_io.payload_parts(reference_io.load_reference_payload(path))
+        if "replay_loader" not in parts:
+            raise KeyError(f"{path}: no 'replay_loader' in the payload (keys: {sorted(parts)})")
+        other = parts["replay_loader"]
+        rb = cls.from_reference(other, device=device)
+        if discount is not None:
+            rb._discount = float(discount)
+        if future is not None:
+            rb._future = float(future)
+        rb._max_episodes = int(next(iter(rb._storage.values())).shape[0]) if rb._storage else rb._max_episodes
+        return rb
+
+    @classmethod
     def from_arrays(cls, storage: tp.Mapping[str, np.ndarray], episode_lengths: np.ndarray, discount: float,
                     future: float = 1.0, device: tp.Union[str, torch.device] = "cuda") -> "DeviceReplayBuffer":
         """A full buffer from episode-major arrays ``[n_episodes, T+1, dim]``."""

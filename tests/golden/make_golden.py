@@ -310,6 +310,43 @@ def inference_fixture(R):
     print("[inference_kat] ok")
 
 
+def checkpoint_fixture(R):
+    """A checkpoint exactly as ``Workspace.save_checkpoint`` writes it (pretrain.py:437-449): ``torch.save`` of
+    ``{'agent', 'global_step', 'global_episode', 'replay_loader'}`` holding LIVE reference objects (an ``FBDDPGAgent``
+    after two updates, a filled ``ReplayBuffer``), plus a bare ``torch.save(replay_loader)`` like
+    ``train_offline.py:88-90``.  The ``.pt`` files are data (pickled tensors / arrays + class PATHS, no code);
+    ``ref_checkpoint_expect.npz`` holds what a reader must recover from them."""
+    cfg = tiny_cfg()
+    rng = np.random.default_rng(31)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg.obs_dim, cfg.action_dim, None, None)
+    agent = make_ref_agent(R, cfg)
+    load_nets(agent, nets)
+    rb = fill_ref_buffer(R, storage, lengths, cfg.discount)
+    for s in range(2):
+        with inject(R, fo.make_draws(rng, cfg, 6, lengths), False):
+            agent.update(rb, s)
+    payload = {"agent": agent, "global_step": 7, "global_episode": 3, "replay_loader": rb}
+    with (HERE / "ref_checkpoint_tiny.pt").open("wb") as f:
+        torch.save(payload, f, pickle_protocol=4)
+    with (HERE / "ref_replay_tiny.pt").open("wb") as f:
+        torch.save(rb, f)
+    obs = rng.standard_normal((5, cfg.obs_dim)).astype(np.float32)
+    zs = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((5, cfg.z_dim)).astype(np.float32)), cfg.z_dim).numpy()
+    with torch.no_grad():
+        acts = np.stack([agent.act(obs[i], {"z": zs[i]}, 0, eval_mode=True) for i in range(5)])
+    arrays = {f"state/{k}": v for k, v in ref_state(agent).items()}
+    arrays.update({f"storage/{k}": np.asarray(v) for k, v in rb._storage.items()})
+    arrays.update(lengths=np.asarray(rb._episodes_length), obs=obs, z=zs, act_eval=acts,
+                  fb_steps=np.int64(2), actor_steps=np.int64(2))
+    np.savez_compressed(HERE / "ref_checkpoint_expect.npz", **arrays)
+    (HERE / "ref_checkpoint_expect.json").write_text(json.dumps(
+        {"cfg": {k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, "global_step": 7, "global_episode": 3,
+         "agent_cfg": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(agent.cfg).items()
+                       if isinstance(v, (int, float, str, bool, tuple, type(None)))}}, indent=1))
+    print("[ref_checkpoint] ok")
+
+
 def tiny_cfg(**kw):
     base = dict(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
                 backward_hidden_dim=18, batch_size=16, lr=1e-3)
@@ -337,7 +374,15 @@ def main():
     sampler_fixture(R)
     init_fixture(R)
     inference_fixture(R)
+    checkpoint_fixture(R)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:                      # e.g. ``make_golden.py checkpoint_fixture``: regenerate one fixture only
+        R_ = import_reference()
+        torch.manual_seed(0)
+        np.random.seed(0)
+        for fn in sys.argv[1:]:
+            globals()[fn](R_)
+    else:
+        main()

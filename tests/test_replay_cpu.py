@@ -100,3 +100,51 @@ def test_agent_rejects_unsupported_flags_loudly():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             FBHipAgent(**base)
+
+
+# ------------------------------------------------------------------------------------------------ reference files (n2)
+def test_reference_checkpoint_reads_without_the_reference_installed():
+    """``latest.pt`` as the reference's Workspace.save_checkpoint writes it (pretrain.py:437-449; made by the real
+    reference in tests/golden/make_golden.py::checkpoint_fixture) unpickles through reference_io's placeholder classes:
+    every tensor of the five nets, the Adam moments and the replay storage come back bit-exactly."""
+    import sys
+    from controllable_agent_amd import reference_io as rio
+    assert not any(m == "url_benchmark" or m.startswith("url_benchmark.") for m in sys.modules)
+    import json
+    GOLDEN = H.GOLDEN
+    payload = rio.load_reference_payload(GOLDEN / "ref_checkpoint_tiny.pt")
+    exp = np.load(GOLDEN / "ref_checkpoint_expect.npz")
+    meta = json.loads((GOLDEN / "ref_checkpoint_expect.json").read_text())
+    assert payload["global_step"] == meta["global_step"] and payload["global_episode"] == meta["global_episode"]
+    agent = payload["agent"]
+    assert isinstance(agent, rio.ReferenceObject) and agent._ref_name == "FBDDPGAgent"
+    fields = rio.reference_agent_config(agent)
+    for k, v in meta["agent_cfg"].items():
+        got = fields[k]
+        assert (list(got) if isinstance(got, tuple) else got) == v, k
+    for net in ("actor", "forward_net", "backward_net", "forward_target_net", "backward_target_net"):
+        sd = getattr(agent, net).state_dict()
+        want = [k.split("/", 2)[2] for k in exp.files if k.startswith(f"state/{net}/")]
+        assert list(sd) == want                                  # nn.Module.state_dict() order and names
+        for k, v in sd.items():
+            np.testing.assert_array_equal(v.numpy(), exp[f"state/{net}/{k}"], err_msg=f"{net}/{k}")
+    # torch.optim.Adam unpickles as itself; its state follows parameters() order (fb_ddpg.py:146-151)
+    osd = agent.fb_opt.state_dict()
+    names = ([f"forward_net/{k}" for k in agent.forward_net.state_dict()] +
+             [f"backward_net/{k}" for k in agent.backward_net.state_dict()])
+    assert len(osd["state"]) == len(names)
+    for i, n in enumerate(names):
+        np.testing.assert_array_equal(osd["state"][i]["exp_avg"].numpy(), exp[f"state/adam_m/{n}"], err_msg=n)
+        assert int(osd["state"][i]["step"]) == int(exp["fb_steps"])
+    # the buffer: placeholder -> DeviceReplayBuffer (CPU device here), storage and lengths bit-exact, sampling works
+    for rb in (DeviceReplayBuffer.from_reference(payload["replay_loader"], device="cpu"),
+               DeviceReplayBuffer.from_reference_file(GOLDEN / "ref_replay_tiny.pt", device="cpu", discount=0.9, future=1.0),
+               DeviceReplayBuffer.from_reference_file(GOLDEN / "ref_checkpoint_tiny.pt", device="cpu")):
+        for k in ("observation", "action", "discount", "reward"):
+            np.testing.assert_array_equal(rb._storage[k].numpy(), exp[f"storage/{k}"], err_msg=k)
+        np.testing.assert_array_equal(rb._episodes_length, exp["lengths"])
+        assert len(rb) == exp["storage/observation"].shape[0] and rb._full
+        b = rb.sample(8)
+        assert tuple(b.obs.shape) == (8, exp["storage/observation"].shape[2])
+    assert rb._discount == pytest.approx(0.99)
+    assert DeviceReplayBuffer.from_reference_file(GOLDEN / "ref_replay_tiny.pt", device="cpu", discount=0.9)._discount == 0.9

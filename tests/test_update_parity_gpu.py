@@ -246,3 +246,24 @@ def test_pickle_and_init_from_round_trip():
         np.testing.assert_array_equal(s1[k], s3[k], err_msg=f"init_from {k}")
     rb2 = pickle.loads(pickle.dumps(rb))
     assert len(rb2) == len(rb) and torch.equal(rb2._storage["observation"], rb._storage["observation"])
+
+
+def test_agent_from_reference_checkpoint_file():
+    """A checkpoint written by the REAL reference (pretrain.py:437-449) -> FBHipAgent.from_reference_checkpoint: nets,
+    targets, Adam moments and step counts equal the reference's, and act() reproduces the reference's actions."""
+    from controllable_agent_amd.agent import FBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    exp = np.load(H.GOLDEN / "ref_checkpoint_expect.npz")
+    agent = FBHipAgent.from_reference_checkpoint(H.GOLDEN / "ref_checkpoint_tiny.pt", device="cuda")
+    assert agent.cfg.z_dim == 8 and agent.cfg.batch_size == 16 and str(agent.cfg.device).startswith("cuda")
+    got = H.get_agent_state(agent)
+    for k in exp.files:
+        if k.startswith("state/"):
+            np.testing.assert_array_equal(got[k[len("state/"):]], exp[k], err_msg=k)
+    assert agent.step_counts() == (int(exp["fb_steps"]), int(exp["actor_steps"]))
+    acts = np.stack([agent.act(exp["obs"][i], {"z": exp["z"][i]}, 0, eval_mode=True) for i in range(5)])
+    np.testing.assert_allclose(acts, exp["act_eval"], rtol=2e-5, atol=2e-6)
+    # ... and training continues from it on the buffer stored in the same file
+    rb = DeviceReplayBuffer.from_reference_file(H.GOLDEN / "ref_checkpoint_tiny.pt", device="cuda")
+    m = agent.update(rb, 2)
+    assert np.isfinite(m["fb_loss"]) and agent.step_counts() == (3, 3)
