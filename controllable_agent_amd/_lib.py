@@ -66,6 +66,8 @@ PROTOTYPES = {
     "fbhip_workspace_view": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "fbhip_actor_forward": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _F, _F, _P, _I, _P]),
     "fbhip_backward_map": (C.c_int, [_P, _I, _P, _I, _I, _P, _I, _P]),
+    "fbhip_act": (C.c_int, [_P, _P, _P, _P, _F, _I, _P, _P]),
+    "fbhip_z_correl": (C.c_int, [_P, _P, _P, _P, _P]),
     "fbhip_forward_map": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P]),
     "fbhip_gemm": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "fbhip_gemm_cfg": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),

@@ -505,22 +505,34 @@ class FBHipAgent:
         return out
 
     def act(self, obs: tp.Any, meta: MetaDict, step: int, eval_mode: bool) -> np.ndarray:   # fb_ddpg.py:258-281
+        stddev = schedule(self.cfg.stddev_schedule, step)
+        if not (eval_mode and self.cfg.additional_metric):
+            # batch-1 fast path: host arrays in, host action out, one graph launch (fbhip_act)
+            if not eval_mode and step < self.cfg.num_expl_steps:          # fb_ddpg.py:277-279: uniform exploration
+                return torch.empty(self.action_dim).uniform_(-1.0, 1.0).numpy()
+            return self._act_fast(np.asarray(obs, np.float32).reshape(-1), np.asarray(meta["z"], np.float32).reshape(-1),
+                                  None, stddev, eval_mode)
         o = self._dev(obs)
         z = self._dev(meta["z"])
-        stddev = schedule(self.cfg.stddev_schedule, step)
-        if eval_mode:
-            action = self._actor(o, z, None, stddev, None)
-            if self.cfg.additional_metric:
-                f_mean = self._forward_map(o, z, action)
-                f_rand = self._forward_map(o, z, torch.zeros_like(action).uniform_(-1.0, 1.0))
-                qs = [torch.min(*( (f * z).sum(1) for f in fs)) for fs in (f_mean, f_rand)]
-                self.actor_success = (qs[0] > qs[1]).cpu().numpy().tolist()
-        else:
-            noise = torch.randn((1, self.action_dim), device=self._device)
-            action = self._actor(o, z, noise, stddev, None)               # dist.sample() without clip
-            if step < self.cfg.num_expl_steps:
-                action.uniform_(-1.0, 1.0)
+        action = self._actor(o, z, None, stddev, None)
+        f_mean = self._forward_map(o, z, action)
+        f_rand = self._forward_map(o, z, torch.zeros_like(action).uniform_(-1.0, 1.0))
+        qs = [torch.min(*( (f * z).sum(1) for f in fs)) for fs in (f_mean, f_rand)]
+        self.actor_success = (qs[0] > qs[1]).cpu().numpy().tolist()
         return action.cpu().numpy()[0]
+
+    def _act_fast(self, obs: np.ndarray, z: np.ndarray, noise: tp.Optional[np.ndarray], stddev: float,
+                  eval_mode: bool) -> np.ndarray:
+        if obs.shape[0] != self.obs_dim or z.shape[0] != self.cfg.z_dim:
+            raise ValueError(f"act: expected obs[{self.obs_dim}] and z[{self.cfg.z_dim}], got {obs.shape} / {z.shape}")
+        obs, z = np.ascontiguousarray(obs), np.ascontiguousarray(z)
+        out = np.empty(self.action_dim, np.float32)
+        nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
+        with torch.cuda.stream(self._stream):
+            check(_lib.load().fbhip_act(self._ctx, obs.ctypes.data, z.ctypes.data, None if nz is None else nz.ctypes.data,
+                                        float(stddev), int(bool(eval_mode)), out.ctypes.data,
+                                        self._stream.cuda_stream), self._ctx)
+        return out
 
     def _normalize_z(self, z: torch.Tensor) -> torch.Tensor:
         from . import kernels
@@ -558,11 +570,16 @@ class FBHipAgent:
 
     def compute_z_correl(self, time_step: tp.Any, meta: MetaDict) -> float:   # fb_ddpg.py:283-289
         """NB: the reference writes ``F.normalize(z, 1)`` -- the positional 1 is ``p``, so both vectors are scaled by
-        their L1 norm (dim defaults to 1).  Kept as is for result parity."""
+        their L1 norm (dim defaults to 1).  Kept as is for result parity (fbhip_z_correl)."""
         goal = time_step.goal if self.cfg.goal_space is not None else time_step.observation
-        b = torch.nn.functional.normalize(self._backward_map(np.asarray(goal, np.float32)), p=1.0, dim=1)
-        z = torch.nn.functional.normalize(self._dev(meta["z"]), p=1.0, dim=1)
-        return float((b * z).sum().item())
+        g = np.ascontiguousarray(np.asarray(goal, np.float32).reshape(-1))
+        z = np.ascontiguousarray(np.asarray(meta["z"], np.float32).reshape(-1))
+        if g.shape[0] != self.goal_dim or z.shape[0] != self.cfg.z_dim:
+            raise ValueError(f"compute_z_correl: expected goal[{self.goal_dim}] and z[{self.cfg.z_dim}]")
+        out = np.empty(1, np.float32)
+        check(_lib.load().fbhip_z_correl(self._ctx, g.ctypes.data, z.ctypes.data, out.ctypes.data,
+                                         self._stream.cuda_stream), self._ctx)
+        return float(out[0])
 
     # ------------------------------------------------------------------ the hot path
     def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float) -> HParams:

@@ -139,6 +139,9 @@ struct Ws {
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
     float* splitk = nullptr;            // split-K partial slab
     float* pw_scratch = nullptr;
+    float* act_in = nullptr;            // batch-1 fast path: [obs | z | 0.. | noise] / [goal | 0.. | z] as staged by the host
+    float* act_vec = nullptr;           // its activation vectors
+    float* act_out = nullptr;           // action (a floats) or the z correlation (1 float)
     size_t total_bytes = 0;
 };
 
@@ -160,6 +163,15 @@ struct Carver {
         return b;
     }
 };
+
+// staging layout of the batch-1 entry points (host pinned buffer and device copy are identical):
+//   act:      [obs (o) | z (d) | zeros up to pad32(o+d) | noise (a)]      compute_z_correl: [goal (g) | zeros up to pad32(g) | z (d)]
+size_t act_noise_off(const fbhip_dims& d) { return (size_t)pad32(d.obs_dim + d.z_dim); }
+size_t act_z_off(const fbhip_dims& d) { return (size_t)pad32(d.goal_dim); }
+size_t act_in_floats(const fbhip_dims& d) {
+    const size_t a = act_noise_off(d) + 64, b = act_z_off(d) + (size_t)pad4(d.z_dim);
+    return (a > b ? a : b) + 64;
+}
 
 Ws carve(const fbhip_dims& d, void* base) {
     Ws w;
@@ -203,6 +215,9 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
     w.splitk = c.f((size_t)6 << 20);
+    w.act_in = c.f(act_in_floats(d));
+    w.act_vec = c.f((size_t)4 * 2048 + 256);
+    w.act_out = c.f(64);
     w.total_bytes = (c.cur + 255) & ~(size_t)255;
     return w;
 }
@@ -249,6 +264,7 @@ ActP act_p(float* base, const NetLayout& L) {
 }
 
 struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; };
+struct InferGraph { int kind; int eval_mode; int has_noise; float stddev; hipGraphExec_t exec; };
 
 }  // namespace
 
@@ -266,6 +282,9 @@ struct fbhip_ctx {
     BwdP K_p, K_g, K_t;
     ActP A_p, A_g;
     std::vector<GraphEntry> graphs;
+    std::vector<InferGraph> infer_graphs;    // batch-1 fast path (fbhip_act / fbhip_z_correl)
+    float* h_in = nullptr;                   // pinned host staging, same layout as w.act_in
+    float* h_out = nullptr;                  // pinned: action / correlation
     std::string err;
 };
 
@@ -888,6 +907,14 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
     fbhip_ctx* c = new fbhip_ctx();
     c->d = *dims;
     for (int n = 0; n < 3; ++n) c->L[n] = build_layout(*dims, n);
+    // pinned staging of the batch-1 entry points (a few hundred bytes; host memory, not device memory)
+    if (hipHostMalloc((void**)&c->h_in, act_in_floats(*dims) * sizeof(float), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_out, 64 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();             // no usable device here (e.g. the CPU-only build check): fast path disabled
+        c->h_in = c->h_out = nullptr;
+    } else {
+        memset(c->h_in, 0, act_in_floats(*dims) * sizeof(float));
+    }
     *out = c;
     return FBHIP_OK;
 }
@@ -895,6 +922,9 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
 int fbhip_destroy(fbhip_ctx* ctx) {
     if (!ctx) return FBHIP_OK;
     for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : ctx->infer_graphs) (void)hipGraphExecDestroy(g.exec);
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     delete ctx;
     return FBHIP_OK;
 }
@@ -922,6 +952,8 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     c->A_p = act_p(actor_params, c->L[2]); c->A_g = act_p(actor_grads, c->L[2]);
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
+    for (auto& g : c->infer_graphs) (void)hipGraphExecDestroy(g.exec);
+    c->infer_graphs.clear();
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
     HIPCK(c, gemm_init());
     HIPCK(c, inverse_prepare());
@@ -950,6 +982,8 @@ int fbhip_set_seed(fbhip_ctx* c, uint64_t seed, uint32_t rank) {
     c->seed = seed; c->rank = rank;
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
+    for (auto& g : c->infer_graphs) (void)hipGraphExecDestroy(g.exec);
+    c->infer_graphs.clear();
     return FBHIP_OK;
 }
 
@@ -1053,6 +1087,127 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
 }
 
 // ---- inference entry points ----------------------------------------------------------------------------------
+// ---- batch-1 fast path: one hipGraph = H2D of the staged inputs + 4 launches + D2H of the result ---------------
+namespace {
+
+enum { INFER_ACT = 0, INFER_ZCORREL = 1 };
+
+GemvProblem GV(const float* x, const float* W, int ldw, const float* bias, float* y, int N, int K, bool relu,
+               const float* ln_g = nullptr, const float* ln_b = nullptr, int n_ln = 0) {
+    GemvProblem p{};
+    p.x = x; p.W = W; p.bias = bias; p.y = y; p.ln_g = ln_g; p.ln_b = ln_b;
+    p.N = N; p.K = K; p.ldw = ldw; p.n_ln = n_ln; p.relu = relu ? 1 : 0;
+    return p;
+}
+
+int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int o = d.obs_dim, z = d.z_dim, a = d.action_dim, H = d.hidden_dim, Fd = d.feature_dim;
+    Ws& w = c->w;
+    const ActP& A = c->A_p;
+    float* pre1o = w.act_vec; float* pre1z = pre1o + 2048; float* h = pre1z + 2048; float* pv = h + 2048;
+    const size_t nin = act_noise_off(d) + (has_noise ? a : 0);
+    HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, nin * sizeof(float), hipMemcpyHostToDevice, s));
+    // Actor.forward (fb_modules.py:107-121): obs_net / obs_z_net first layers (the weight's zero pad columns absorb
+    // whatever follows obs / [obs|z] in the staging vector) ...
+    GemvGroup g1{}; g1.n = 2;
+    g1.p[0] = GV(w.act_in, A.o.W1, A.o.ld1, A.o.b1, pre1o, H, A.o.ld1, false);
+    g1.p[1] = GV(w.act_in, A.oz.W1, A.oz.ld1, A.oz.b1, pre1z, H, A.oz.ld1, false);
+    HIPCK(c, launch_gemv_group(g1, s));
+    // ... LayerNorm + tanh as the prologue of the second layers, ReLU ...
+    GemvGroup g2{}; g2.n = 2;
+    g2.p[0] = GV(pre1o, A.o.W2, H, A.o.b2, h, Fd, H, true, A.o.g1, A.o.be1, H);
+    g2.p[1] = GV(pre1z, A.oz.W2, H, A.oz.b2, h + Fd, Fd, H, true, A.oz.g1, A.oz.be1, H);
+    HIPCK(c, launch_gemv_group(g2, s));
+    // ... policy trunk ...
+    GemvGroup g3{}; g3.n = 1;
+    g3.p[0] = GV(h, A.W3, 2 * Fd, A.b3, pv, H, 2 * Fd, true);
+    HIPCK(c, launch_gemv_group(g3, s));
+    // ... head + TruncatedNormal
+    HIPCK(c, launch_act_head(pv, A.W4, H, A.b4, a, H, stddev, eval_mode, has_noise ? w.act_in + act_noise_off(d) : nullptr,
+                             c->seed, c->rank, w.st, w.act_out, s));
+    HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, (size_t)a * sizeof(float), hipMemcpyDeviceToHost, s));
+    (void)o; (void)z;
+    return FBHIP_OK;
+}
+
+int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int g = d.goal_dim, z = d.z_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb);
+    Ws& w = c->w;
+    const BwdP& K = c->K_p;
+    float* pre1 = w.act_vec; float* r2 = pre1 + 2048; float* y = r2 + 2048;
+    HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, (act_z_off(d) + z) * sizeof(float), hipMemcpyHostToDevice, s));
+    // BackwardMap.forward (fb_modules.py:223-230) on the padded layout: pad rows of W1 / W2 are zero
+    GemvGroup g1{}; g1.n = 1;
+    g1.p[0] = GV(w.act_in, K.W1, pad32(g), K.b1, pre1, Lb, pad32(g), false);
+    HIPCK(c, launch_gemv_group(g1, s));
+    GemvGroup g2{}; g2.n = 1;
+    g2.p[0] = GV(pre1, K.W2, Lb, K.b2, r2, Lb, Lb, true, K.g1, K.be1, Hb);
+    HIPCK(c, launch_gemv_group(g2, s));
+    GemvGroup g3{}; g3.n = 1;
+    g3.p[0] = GV(r2, K.W3, Lb, K.b3, y, z, Lb, false);
+    HIPCK(c, launch_gemv_group(g3, s));
+    HIPCK(c, launch_zcorrel(y, w.act_in + act_z_off(d), z, w.act_out, s));
+    HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(float), hipMemcpyDeviceToHost, s));
+    return FBHIP_OK;
+}
+
+// replay (or capture + replay) the graph of one fast-path call, then wait for its result
+int run_infer_graph(fbhip_ctx* c, int kind, float stddev, int eval_mode, bool has_noise, hipStream_t s) {
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : c->infer_graphs)
+        if (g.kind == kind && g.eval_mode == eval_mode && g.has_noise == (int)has_noise && g.stddev == stddev) exec = g.exec;
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = kind == INFER_ACT ? enqueue_act(c, stddev, eval_mode, has_noise, s) : enqueue_zcorrel(c, s);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIPCK(c, e);
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIPCK(c, e);
+        if (c->infer_graphs.size() >= 8) { (void)hipGraphExecDestroy(c->infer_graphs.front().exec); c->infer_graphs.erase(c->infer_graphs.begin()); }
+        c->infer_graphs.push_back(InferGraph{kind, eval_mode, (int)has_noise, stddev, exec});
+    }
+    HIPCK(c, hipGraphLaunch(exec, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    return FBHIP_OK;
+}
+
+}  // namespace
+
+int fbhip_act(fbhip_ctx* c, const float* host_obs, const float* host_z, const float* host_noise, float stddev,
+              int32_t eval_mode, float* host_action_out, void* stream) {
+    RC(need_bound(c, false));
+    if (!host_obs || !host_z || !host_action_out) { c->err = g_err = "fbhip_act: null argument"; return FBHIP_E_INVALID; }
+    if (!c->h_in) { c->err = g_err = "fbhip_act: pinned staging unavailable"; return FBHIP_E_STATE; }
+    if (c->d.hidden_dim > 2048 || 2 * c->d.feature_dim > 2048) { c->err = g_err = "fbhip_act: layer wider than 2048"; return FBHIP_E_INVALID; }
+    const fbhip_dims& d = c->d;
+    memcpy(c->h_in, host_obs, (size_t)d.obs_dim * sizeof(float));
+    memcpy(c->h_in + d.obs_dim, host_z, (size_t)d.z_dim * sizeof(float));
+    for (size_t i = (size_t)d.obs_dim + d.z_dim; i < act_noise_off(d); ++i) c->h_in[i] = 0.f;
+    const bool has_noise = host_noise != nullptr && !eval_mode;
+    if (has_noise) memcpy(c->h_in + act_noise_off(d), host_noise, (size_t)d.action_dim * sizeof(float));
+    RC(run_infer_graph(c, INFER_ACT, stddev, eval_mode ? 1 : 0, has_noise, (hipStream_t)stream));
+    memcpy(host_action_out, c->h_out, (size_t)d.action_dim * sizeof(float));
+    return FBHIP_OK;
+}
+
+int fbhip_z_correl(fbhip_ctx* c, const float* host_goal, const float* host_z, float* host_out, void* stream) {
+    RC(need_bound(c, false));
+    if (!host_goal || !host_z || !host_out) { c->err = g_err = "fbhip_z_correl: null argument"; return FBHIP_E_INVALID; }
+    if (!c->h_in) { c->err = g_err = "fbhip_z_correl: pinned staging unavailable"; return FBHIP_E_STATE; }
+    const fbhip_dims& d = c->d;
+    memcpy(c->h_in, host_goal, (size_t)d.goal_dim * sizeof(float));
+    for (size_t i = (size_t)d.goal_dim; i < act_z_off(d); ++i) c->h_in[i] = 0.f;
+    memcpy(c->h_in + act_z_off(d), host_z, (size_t)d.z_dim * sizeof(float));
+    RC(run_infer_graph(c, INFER_ZCORREL, 0.f, 0, false, (hipStream_t)stream));
+    *host_out = c->h_out[0];
+    return FBHIP_OK;
+}
+
 int fbhip_actor_forward(fbhip_ctx* c, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z, int32_t rows,
                         const float* noise, float stddev, float clip, float* action_out, int32_t ld_out, void* stream) {
     RC(need_bound(c, false));

@@ -103,7 +103,7 @@ struct StepState {          // device-resident, advanced in-graph
     int fb_t;               // Adam step counts (1-based after the first step)
     int actor_t;
     unsigned int update_count;   // RNG counter: number of update() calls so far
-    int pad;
+    unsigned int act_count;      // RNG counter of the batch-1 act() fast path (exploration noise drawn on device)
     double fb_bc1;          // 1 - beta1^t          (fp64 like torch's python-side scalars)
     double fb_bc2_sqrt;     // sqrt(1 - beta2^t)
     double actor_bc1;
@@ -120,6 +120,18 @@ hipError_t launch_step_advance(StepState* st, int which /*0 fb, 1 actor, 2 rng*/
 hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel,
                            float lr, float lr2, int64_t split, float grad_scale, float tau,
                            const StepState* st, int which, int t_explicit, hipStream_t s);
+
+// ---- batch-1 inference (infer.hip) -----------------------------------------------------------------------------
+// y[n] = (relu)( W[n, :K] . f(x) + bias[n] ), f = identity or tanh(LayerNorm(x[:n_ln])) (entries >= n_ln read as 0)
+struct GemvProblem { const float* x; const float* W; const float* bias; float* y; const float* ln_g; const float* ln_b;
+                     int N, K, ldw, n_ln, relu, block_start; };
+constexpr int GEMV_MAX_GROUP = 4;
+struct GemvGroup { GemvProblem p[GEMV_MAX_GROUP]; int n; };
+hipError_t launch_gemv_group(GemvGroup g, hipStream_t s);
+hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
+                           int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
+                           hipStream_t s);
+hipError_t launch_zcorrel(const float* y, const float* z, int d, float* out, hipStream_t s);
 
 // ---- sampler -----------------------------------------------------------------------------------------------
 struct ReplayView {

@@ -169,6 +169,21 @@ int fbhip_forward_map(fbhip_ctx* ctx, int32_t which, const float* obs, int32_t l
                       const float* action, int32_t ld_act, int32_t rows,
                       float* f1_out, float* f2_out, int32_t ld_out, void* stream);
 
+/* ---- batch-1 fast path: what the online loop calls on every environment step (pretrain.py:628-632, 651-652) ----
+ * HOST pointers in, HOST result out; BLOCKING (the caller needs the action to step the environment).  Each call is one
+ * hipGraph launch on ``stream`` (H2D of the staged inputs through pinned memory, 4 kernel launches, D2H of the result)
+ * followed by a stream synchronise.
+ *
+ * fbhip_act: FBDDPGAgent.act (fb_ddpg.py:258-281) for one observation: mu = Actor(obs, z).mean (fb_modules.py:107-121);
+ * eval_mode != 0 -> action = mu, else action = TruncatedNormal(mu, stddev).sample(clip=None) (utils.py:176-185) with
+ * eps = host_noise[a] when given, otherwise drawn on the device (Philox keyed by fbhip_set_seed and an internal counter).
+ * (The reference's ``step < num_expl_steps`` uniform override and ``additional_metric`` stay on the caller's side.) */
+int fbhip_act(fbhip_ctx* ctx, const float* host_obs, const float* host_z, const float* host_noise, float stddev,
+              int32_t eval_mode, float* host_action_out, void* stream);
+/* fbhip_z_correl: FBDDPGAgent.compute_z_correl (fb_ddpg.py:283-289): <normalize(B(goal), p=1), normalize(z, p=1)> with the
+ * online backward_net (the reference's ``F.normalize(z, 1)`` passes 1 as p: L1 normalisation, kept for parity). */
+int fbhip_z_correl(fbhip_ctx* ctx, const float* host_goal, const float* host_z, float* host_out, void* stream);
+
 /* ---- individually testable kernels ----------------------------------------------------------------- */
 /* C[M,N] = epi( sum_k A(m,k) * B(n,k) ).  a_kcontig: A(m,k) = A[m*lda+k] else A[k*lda+m]; same for B.
  * epi: 0 none | 1 +bias[n] | 2 relu(+bias[n]) | 3 acc*(aux>0) | 4 acc*(1-aux^2).

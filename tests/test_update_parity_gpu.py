@@ -3,6 +3,8 @@
   (2) the oracle replaying the same injected draws,
 teacher-forced (tight tolerances) and free-running (the reference's own fp32 drift envelope)."""
 import numpy as np
+import types
+
 import pytest
 import torch
 
@@ -267,3 +269,37 @@ def test_agent_from_reference_checkpoint_file():
     rb = DeviceReplayBuffer.from_reference_file(H.GOLDEN / "ref_checkpoint_tiny.pt", device="cuda")
     m = agent.update(rb, 2)
     assert np.isfinite(m["fb_loss"]) and agent.step_counts() == (3, 3)
+
+
+def test_batch1_fast_path_matches_the_batched_entry_points():
+    """fbhip_act / fbhip_z_correl (GEMV chain in one graph) against the general row-batched inference path and against
+    the distribution the reference samples from (TruncatedNormal.sample(clip=None), utils.py:176-185)."""
+    cfg = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50, batch_size=64)
+    rng = np.random.default_rng(5)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    agent = H.make_hip_agent(cfg, nets)
+    for i in range(4):
+        obs = rng.standard_normal(cfg.obs_dim).astype(np.float32)
+        z = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((1, cfg.z_dim)).astype(np.float32)), cfg.z_dim).numpy()[0]
+        noise = rng.standard_normal(cfg.action_dim).astype(np.float32)
+        o_d, z_d = agent._dev(obs), agent._dev(z)
+        mu_ref = agent._actor(o_d, z_d, None, 0.2, None).cpu().numpy()[0]
+        np.testing.assert_allclose(agent.act(obs, {"z": z}, 0, eval_mode=True), mu_ref, rtol=2e-5, atol=2e-6)
+        a_ref = agent._actor(o_d, z_d, torch.from_numpy(noise[None]).cuda(), 0.2, None).cpu().numpy()[0]
+        np.testing.assert_allclose(agent._act_fast(obs, z, noise, 0.2, False), a_ref, rtol=2e-5, atol=2e-6)
+        b = torch.nn.functional.normalize(agent._backward_map(obs), p=1.0, dim=1)
+        c_ref = float((b * torch.nn.functional.normalize(z_d, p=1.0, dim=1)).sum())
+        c = agent.compute_z_correl(types.SimpleNamespace(observation=obs, goal=None), {"z": z})
+        assert c == pytest.approx(c_ref, rel=2e-5, abs=1e-7)
+    # device-drawn exploration noise: (action - mu) / stddev ~ N(0, 1) while the clamp is inactive; new draw every call
+    std = 0.05
+    mu = agent.act(obs, {"z": z}, 0, eval_mode=True)
+    assert np.abs(mu).max() < 0.8
+    draws = np.stack([agent._act_fast(obs, z, None, std, False) for _ in range(1500)])
+    e = (draws - mu) / std
+    assert abs(e.mean()) < 0.08 and abs(e.std() - 1.0) < 0.06 and len({tuple(r) for r in np.round(draws, 6)}) > 1400
+    assert np.abs(np.corrcoef(e.T) - np.eye(cfg.action_dim)).max() < 0.12
+    # same seed => same exploration sequence
+    a2 = H.make_hip_agent(cfg, nets)
+    assert not np.array_equal(a2._act_fast(obs, z, None, std, False), draws[-1])
+    np.testing.assert_array_equal(a2._act_fast(obs, z, None, std, False), draws[1])
