@@ -37,14 +37,18 @@ def rank() -> int:
 def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, actor_grads: torch.Tensor) -> None:
     """Run one update through ``run_phases(mask)``; with world_size > 1 the two gradient buckets are
     sum-all-reduced between the phases (``run_phases`` applies grad_scale = 1/world in its optimiser steps)."""
-    if world_size() == 1:
+    import os
+    import torch.distributed as dist
+    world = world_size()
+    if world == 1 and os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") != "1":
         run_phases(PHASE_ALL)
         return
-    import torch.distributed as dist
+    # (FBHIP_FORCE_PHASE_SPLIT=1 runs this schedule on a single rank too: tests / 1-GPU rehearsal of the 8-GPU path)
+    reduce = dist.all_reduce if (dist.is_available() and dist.is_initialized()) else (lambda t: None)
     run_phases(PHASE_SAMPLE | PHASE_FB_GRAD)
-    dist.all_reduce(fb_grads)
+    reduce(fb_grads)
     run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
-    dist.all_reduce(actor_grads)
+    reduce(actor_grads)
     run_phases(PHASE_ACTOR_STEP)
 
 

@@ -303,3 +303,26 @@ def test_batch1_fast_path_matches_the_batched_entry_points():
     a2 = H.make_hip_agent(cfg, nets)
     assert not np.array_equal(a2._act_fast(obs, z, None, std, False), draws[-1])
     np.testing.assert_array_equal(a2._act_fast(obs, z, None, std, False), draws[1])
+
+
+def test_phase_split_schedule_equals_single_call(monkeypatch):
+    """The 3-call data-parallel schedule (distributed.dp_update: SAMPLE|FB_GRAD, FB_STEP|ACTOR_GRAD, ACTOR_STEP, each its
+    own hipGraph) against the single-graph update on the same draws.  The launches group differently (the actor's own
+    forward pass cannot ride along the FB backward), so sums may associate differently: fp32 tolerance, not bit-equality."""
+    meta = H.load_meta("tiny_goal_trace")
+    cfg, nets, storage, lengths, rng = H.regenerate_inputs(meta)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a1, a2 = (H.make_hip_agent(cfg, nets, meta["goal_space"]) for _ in range(2))
+    for s in range(3):
+        d = H.draws_dict(fo.make_draws(rng, cfg, meta["n_eps"], lengths))
+        monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+        m1 = a1.update_injected(rb, s, d)
+        monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+        m2 = a2.update_injected(rb, s, d)
+        for k in m1:
+            assert m2[k] == pytest.approx(m1[k], rel=2e-5, abs=1e-6), (s, k)
+    monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+    s1, s2 = H.get_agent_state(a1), H.get_agent_state(a2)
+    assert a1.step_counts() == a2.step_counts() == (3, 3)
+    for k in s1:
+        np.testing.assert_allclose(s2[k], s1[k], rtol=0, atol=3e-6, err_msg=k)
