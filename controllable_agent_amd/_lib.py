@@ -13,7 +13,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libfbhip.so"
 
 NET_FORWARD, NET_BACKWARD, NET_ACTOR = 0, 1, 2
-PHASE_SAMPLE, PHASE_FB_GRAD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ALL = 1, 2, 4, 8, 16, 31
+PHASE_SAMPLE, PHASE_FB_GRAD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD, PHASE_ALL = 1, 2, 4, 8, 16, 32, 63
 NUM_METRICS = 32
 # metric name -> index in the device metrics array (fb_ddpg.py:356-377, 413-418)
 METRIC_INDEX = {n: i for i, n in enumerate(

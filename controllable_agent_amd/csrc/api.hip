@@ -734,9 +734,9 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, s));
     }
 
-    // single-call updates can run the actor's own forward pass of update_actor (fb_ddpg.py:395-397) under the FB
-    // backward: it reads only the actor weights and (obs, z), not forward_net or the new FB weights
-    const bool early_actor = (mask & FBHIP_PHASE_FB_GRAD) && (mask & FBHIP_PHASE_ACTOR_GRAD);
+    // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
+    // forward_net or the new FB weights: in a call that also runs the FB backward it shares that backward's launches
+    const bool early_actor = (mask & FBHIP_PHASE_FB_GRAD) && (mask & FBHIP_PHASE_ACTOR_FWD);
     auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst) {
         return [=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
@@ -801,7 +801,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
 
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
         Chain ch;
-        if (!early_actor) {
+        if ((mask & FBHIP_PHASE_ACTOR_FWD) && !early_actor) {
             actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
             ch.push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + o, w.Xopi.ld));
         }

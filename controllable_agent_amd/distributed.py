@@ -5,7 +5,7 @@ The reference has no distributed code at all; this is new design for MI355X node
 parameters / Adam state / targets replicated.  Every rank computes the FB loss on its OWN batch x batch block and
 the two flat gradient buckets are sum-all-reduced:
 
-    phase SAMPLE | FB_GRAD      -> all_reduce(fb_grads)      (forward_net ++ backward_net, 14.7 MB at walker dims)
+    phase SAMPLE | FB_GRAD | ACTOR_FWD -> all_reduce(fb_grads)  (forward_net ++ backward_net, 14.7 MB at walker dims)
     phase FB_STEP | ACTOR_GRAD  -> all_reduce(actor_grads)   ( 8.9 MB)
     phase ACTOR_STEP
 
@@ -20,8 +20,8 @@ import typing as tp
 
 import torch
 
-PHASE_SAMPLE, PHASE_FB_GRAD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP = 1, 2, 4, 8, 16
-PHASE_ALL = 31
+PHASE_SAMPLE, PHASE_FB_GRAD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD = 1, 2, 4, 8, 16, 32
+PHASE_ALL = 63
 
 
 def world_size() -> int:
@@ -45,7 +45,7 @@ def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, acto
         return
     # (FBHIP_FORCE_PHASE_SPLIT=1 runs this schedule on a single rank too: tests / 1-GPU rehearsal of the 8-GPU path)
     reduce = dist.all_reduce if (dist.is_available() and dist.is_initialized()) else (lambda t: None)
-    run_phases(PHASE_SAMPLE | PHASE_FB_GRAD)
+    run_phases(PHASE_SAMPLE | PHASE_FB_GRAD | PHASE_ACTOR_FWD)     # the actor's forward rides along the FB backward
     reduce(fb_grads)
     run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
     reduce(actor_grads)

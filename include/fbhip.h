@@ -52,9 +52,13 @@ enum {
     FBHIP_PHASE_SAMPLE = 1,      /* replay gather + z sampling + z mixing           (fb_ddpg.py:433-491) */
     FBHIP_PHASE_FB_GRAD = 2,     /* targets, online F/B, pairwise loss, FB backward (fb_ddpg.py:303-383) */
     FBHIP_PHASE_FB_STEP = 4,     /* fb_opt.step() + both soft_update_params         (fb_ddpg.py:384,500-503) */
-    FBHIP_PHASE_ACTOR_GRAD = 8,  /* actor forward / Q / backward                    (fb_ddpg.py:395-410) */
+    FBHIP_PHASE_ACTOR_GRAD = 8,  /* Q through the UPDATED forward_net, actor backward  (fb_ddpg.py:398-410) */
     FBHIP_PHASE_ACTOR_STEP = 16, /* actor_opt.step()                                (fb_ddpg.py:411) */
-    FBHIP_PHASE_ALL = 31
+    /* the actor's own forward pass of update_actor (fb_ddpg.py:395-397): it reads only the actor weights and (obs, z),
+     * so it may run in the same call as FB_GRAD (it then shares the FB backward's launches) -- or with ACTOR_GRAD.
+     * An ACTOR_GRAD call WITHOUT this bit uses the pass of an earlier call on the same batch. */
+    FBHIP_PHASE_ACTOR_FWD = 32,
+    FBHIP_PHASE_ALL = 63
 };
 
 typedef struct fbhip_dims {

@@ -326,3 +326,43 @@ def test_phase_split_schedule_equals_single_call(monkeypatch):
     assert a1.step_counts() == a2.step_counts() == (3, 3)
     for k in s1:
         np.testing.assert_allclose(s2[k], s1[k], rtol=0, atol=3e-6, err_msg=k)
+
+
+def test_online_loop_with_the_hip_agent():
+    """run_online (pretrain.py:559-659 counterpart) end to end on tiny dims: ring buffer fills through add(), updates
+    start after the seed frames at every update_every_steps, act / compute_z_correl run on the batch-1 fast path."""
+    from controllable_agent_amd.replay import DeviceReplayBuffer, TimeStep
+    from controllable_agent_amd.train_online import run_online
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=16)
+    rng = np.random.default_rng(3)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    agent = H.make_hip_agent(cfg, nets)
+    agent.cfg.update_every_steps = 2
+
+    class Env:
+        T, t = 6, 0
+
+        def _ts(self, kind, action):
+            return TimeStep(step_type=kind, reward=0.5, discount=1.0, observation=rng.standard_normal(5).astype(np.float32),
+                            action=np.asarray(action, np.float32), physics=np.zeros(2, np.float32))
+
+        def reset(self):
+            self.t = 0
+            return self._ts(0, np.zeros(3))
+
+        def step(self, action):
+            assert action.shape == (3,) and np.all(np.abs(action) <= 1.0)
+            self.t += 1
+            return self._ts(2 if self.t == self.T else 1, action)
+
+    rb = DeviceReplayBuffer(max_episodes=4, discount=0.98, future=1.0, device="cuda")
+    before = H.get_agent_state(agent)
+    st = run_online(agent, rb, Env(), num_train_frames=40, num_seed_frames=18)
+    assert (st.env_steps, st.episodes) == (40, 6) and st.updates == 11            # steps 18, 20, ..., 38
+    assert agent.step_counts() == (11, 11)
+    assert len(rb) == 4 and rb._full                                              # ring of 4 episodes, 6 collected
+    after = H.get_agent_state(agent)
+    assert any(not np.array_equal(before[k], after[k]) for k in before)
+    assert all(np.isfinite(v).all() for v in after.values())
+    assert abs(st.last_z_correl) <= Env.T + 1e-3 and st.last_episode_reward == pytest.approx(0.5 * Env.T)
