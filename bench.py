@@ -27,6 +27,10 @@ sys.path.insert(0, str(ROOT))
 
 WALKER = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50, hidden_dim=1024, feature_dim=512,
               backward_hidden_dim=526, batch_size=1024)
+# configs[2] (not the bench line: `--workload quadruped` for the record in DESIGN.md): quadruped_walk, goal space
+# simplified_quadruped (g = 2), batch 2048, z_dim 100
+QUADRUPED = dict(obs_dim=78, action_dim=12, goal_dim=2, z_dim=100, hidden_dim=1024, feature_dim=512,
+                 backward_hidden_dim=526, batch_size=2048)
 PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md chip table
 
 
@@ -42,7 +46,7 @@ def algorithmic_gflop_per_update(o, a, g, d, H, Fd, Hb, B):
     return 2 * mac_row * B / 1e9
 
 
-def make_replay(n_episodes, T, o, a, device, seed):
+def make_replay(n_episodes, T, o, a, device, seed, goal_dim=None):
     """Synthetic buffer per BASELINE.md section 4: obs ~ N(0,1), action ~ U(-1,1), stored discount 1."""
     from controllable_agent_amd.replay import DeviceReplayBuffer
     g = torch.Generator(device=device).manual_seed(seed)
@@ -53,6 +57,8 @@ def make_replay(n_episodes, T, o, a, device, seed):
         "reward": torch.rand((n_episodes, T + 1, 1), device=device, generator=g),
         "discount": torch.ones((n_episodes, T + 1, 1), device=device),
     }
+    if goal_dim is not None:
+        rb._storage["goal"] = torch.randn((n_episodes, T + 1, goal_dim), device=device, generator=g)
     rb._episodes_length = np.full(n_episodes, T, np.int32)
     rb._idx, rb._full = 0, True
     rb._touch()
@@ -137,7 +143,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--episodes", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("walker", "quadruped"), default="walker",
+                    help="walker = configs[1], THE bench line; quadruped = configs[2] (no cpu_baseline / kernel probe)")
     args = ap.parse_args()
+    W = WALKER if args.workload == "walker" else QUADRUPED
+    goal_space = None if args.workload == "walker" else "simplified_quadruped"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -152,12 +162,15 @@ def main():
 
     from controllable_agent_amd.agent import FBHipAgent
     torch.manual_seed(1)                       # identical initial weights on every rank
-    agent = FBHipAgent(obs_type="states", obs_shape=(WALKER["obs_dim"],), action_shape=(WALKER["action_dim"],),
-                       device=dev, num_expl_steps=0, update_every_steps=1, batch_size=WALKER["batch_size"],
-                       z_dim=WALKER["z_dim"], hidden_dim=WALKER["hidden_dim"], feature_dim=WALKER["feature_dim"],
-                       backward_hidden_dim=WALKER["backward_hidden_dim"], use_tb=False, use_wandb=False, use_hiplog=False)
+    agent = FBHipAgent(obs_type="states", obs_shape=(W["obs_dim"],), action_shape=(W["action_dim"],),
+                       device=dev, num_expl_steps=0, update_every_steps=1, batch_size=W["batch_size"],
+                       z_dim=W["z_dim"], hidden_dim=W["hidden_dim"], feature_dim=W["feature_dim"],
+                       backward_hidden_dim=W["backward_hidden_dim"], goal_space=goal_space,
+                       use_tb=False, use_wandb=False, use_hiplog=False)
     # each rank's shard of the 5000-episode buffer (episodes ep % world == rank  <=>  an independent 5000/world-episode draw)
-    rb = make_replay(max(args.episodes // world, 8), 1000, WALKER["obs_dim"], WALKER["action_dim"], dev, seed=100 + rank)
+    n_eps = max(args.episodes // world, 8) if args.workload == "walker" else max(min(args.episodes, 1000) // world, 8)
+    rb = make_replay(n_eps, 1000, W["obs_dim"], W["action_dim"], dev, seed=100 + rank,
+                     goal_dim=W["goal_dim"] if goal_space else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -181,26 +194,30 @@ def main():
     if rank == 0:
         steps_per_s = args.steps / dt                     # per-rank update rate (== global step rate)
         value = world * steps_per_s                       # update-steps/s summed over ranks (weak scaling)
-        gflop = algorithmic_gflop_per_update(WALKER["obs_dim"], WALKER["action_dim"], WALKER["goal_dim"], WALKER["z_dim"],
-                                             WALKER["hidden_dim"], WALKER["feature_dim"], WALKER["backward_hidden_dim"],
-                                             WALKER["batch_size"])
+        gflop = algorithmic_gflop_per_update(W["obs_dim"], W["action_dim"], W["goal_dim"], W["z_dim"], W["hidden_dim"],
+                                             W["feature_dim"], W["backward_hidden_dim"], W["batch_size"])
         achieved = gflop * steps_per_s / 1e3              # TFLOP/s per GPU
         out = {
-            "metric": "FB update-steps/sec (batch=1024, z_dim=50)", "value": value, "unit": "update-steps/s",
+            "metric": f"FB update-steps/sec (batch={W['batch_size']}, z_dim={W['z_dim']})", "value": value, "unit": "update-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "fb_ddpg offline on walker_walk replay (configs[1]): obs 24, action 6, z_dim 50, "
-                                   "hidden 1024, feature 512, backward hidden 526; batch 1024 per GPU; "
-                                   f"{args.episodes}-episode x 1000-step synthetic RND-style replay resident in HBM; "
-                                   "metrics off in the timed loop (reference default)",
-                       "global_batch": WALKER["batch_size"] * world, "parallelism": f"dp{world}",
+            "config": {"workload": ("fb_ddpg offline on walker_walk replay (configs[1]): obs 24, action 6, z_dim 50, "
+                                    "hidden 1024, feature 512, backward hidden 526; batch 1024 per GPU; "
+                                    f"{args.episodes}-episode x 1000-step synthetic RND-style replay resident in HBM; "
+                                    "metrics off in the timed loop (reference default)") if args.workload == "walker" else
+                                   ("fb_ddpg offline on quadruped_walk replay (configs[2]): obs 78, action 12, goal space "
+                                    f"simplified_quadruped (g=2), z_dim 100, batch 2048 per GPU; {n_eps}-episode x 1000-step "
+                                    "synthetic replay resident in HBM; metrics off"),
+                       "global_batch": W["batch_size"] * world, "parallelism": f"dp{world}",
                        "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(),
                          "what": f"whole update step: {gflop:.2f} algorithmic GFLOP/update (SURVEY.md section 8d) x "
                                  "measured updates/s, per GPU, vs the exact-fp32 MFMA peak"},
         }
-        if world == 1:
+        if args.workload != "walker":
+            out["roofline"]["traffic"] = None
+        elif world == 1:
             out["roofline"]["dominant_kernel"] = dominant_kernel_probe()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
