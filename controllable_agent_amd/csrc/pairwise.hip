@@ -48,50 +48,70 @@ struct PwArgs {
     int Bp;
 };
 
-// Stage the same 32-row block of SIX matrices (zero filled outside [0,B) x [0,d)) into LDS [32][LD] each.  All global
-// loads are issued before the first LDS store (a load->store loop would serialise one memory latency per element).
-template <int LD>
+// Stage the same 32-row block of SIX matrices (zero filled outside [0,B) x [0,d)) into LDS [32][LD] each.  load() only
+// ISSUES the global loads (branch-free on the aligned path: out-of-range quads read a clamped, valid address), the
+// zero-fill masks are applied in store() -- so the loads of J tile t+1 stay in flight under the MFMAs of tile t and the
+// s_waitcnt lands right before the LDS writes of the next iteration, not behind every load.
+template <int LD, bool VEC>
 struct Stage6 {
     static constexpr int W = LD - 1;                 // multiple of 32
     static constexpr int QPT = 32 * (W / 4) / 256;   // float4 quads per thread per matrix (2 for W=64, 4 for W=128)
     float4 v[6][QPT > 0 ? QPT : 1];
+    int row0_, B_, d_, ld_;
 
-    __device__ __forceinline__ void load(const float* const (&X)[6], int ld, int row0, int B, int d, bool vec, int tid) {
-#pragma unroll
-        for (int m = 0; m < 6; ++m)
+    __device__ __forceinline__ void load(const float* const (&X)[6], int ld, int row0, int B, int d, int tid) {
+        row0_ = row0; B_ = B; d_ = d; ld_ = ld;
+        if constexpr (VEC) {
 #pragma unroll
             for (int i = 0; i < QPT; ++i) {
                 const int q = tid + i * 256;
                 const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
-                const int gr = row0 + r;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gr < B && n0 < d) {
-                    const float* ptr = X[m] + (size_t)gr * ld + n0;
-                    if (vec && n0 + 3 < ld) {
-                        x = *reinterpret_cast<const float4*>(ptr);          // may read pad columns: masked below
-                    } else {
+                const bool ok = (row0 + r < B) && (n0 < ld);                 // ld % 4 == 0: the quad stays inside its row
+                const size_t off = ok ? (size_t)(row0 + r) * ld + n0 : 0;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) v[m][i] = *reinterpret_cast<const float4*>(X[m] + off);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+#pragma unroll
+                for (int i = 0; i < QPT; ++i) {
+                    const int q = tid + i * 256;
+                    const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+                    const int gr = row0 + r;
+                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gr < B && n0 < d) {
+                        const float* ptr = X[m] + (size_t)gr * ld + n0;
                         x.x = ptr[0];
                         if (n0 + 1 < d) x.y = ptr[1];
                         if (n0 + 2 < d) x.z = ptr[2];
                         if (n0 + 3 < d) x.w = ptr[3];
                     }
-                    if (n0 + 1 >= d) x.y = 0.f;
-                    if (n0 + 2 >= d) x.z = 0.f;
-                    if (n0 + 3 >= d) x.w = 0.f;
+                    v[m][i] = x;
                 }
-                v[m][i] = x;
-            }
+        }
     }
-    __device__ __forceinline__ void store(float* __restrict__ lds_base, int tid) const {
+    __device__ __forceinline__ void store(float* __restrict__ lds_base, int tid) {
+        // pin the first use of the loaded registers HERE: without it hipcc hoists the zero-fill selects up to the loads
+        // (before the MFMAs of the previous tile) and waits for every load right where it was issued
 #pragma unroll
         for (int m = 0; m < 6; ++m)
 #pragma unroll
-            for (int i = 0; i < QPT; ++i) {
-                const int q = tid + i * 256;
-                const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+            for (int i = 0; i < QPT; ++i)
+                asm volatile("" : "+v"(v[m][i].x), "+v"(v[m][i].y), "+v"(v[m][i].z), "+v"(v[m][i].w));
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int q = tid + i * 256;
+            const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+            const bool row_ok = row0_ + r < B_;
+            const bool k0 = row_ok && n0 < d_, k1 = row_ok && n0 + 1 < d_, k2 = row_ok && n0 + 2 < d_, k3 = row_ok && n0 + 3 < d_;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
                 float* dst = lds_base + m * 32 * LD + r * LD + n0;
-                dst[0] = v[m][i].x; dst[1] = v[m][i].y; dst[2] = v[m][i].z; dst[3] = v[m][i].w;
+                dst[0] = k0 ? v[m][i].x : 0.f; dst[1] = k1 ? v[m][i].y : 0.f;
+                dst[2] = k2 ? v[m][i].z : 0.f; dst[3] = k3 ? v[m][i].w : 0.f;
             }
+        }
     }
 };
 
@@ -125,7 +145,9 @@ __device__ __forceinline__ void load_frag(float (&f)[KS], const float* __restric
     for (int ks = 0; ks < KS; ++ks) f[ks] = sI[l31 * LD + 2 * ks + h];
 }
 
-template <int KS>
+// VEC: 16-byte aligned panels with ld % 4 == 0 (the product's workspace).  A separate instantiation, not a runtime
+// branch: merging the two loaders' registers makes hipcc wait for the loads right after issuing them.
+template <int KS, bool VEC>
 __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
     constexpr int NT = (2 * KS + 31) / 32;
     constexpr int W = (2 * KS > 32 * NT ? 2 * KS : 32 * NT);
@@ -147,11 +169,10 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
 
     // LDS order of the six panels: Bm, tB, F1, F2, tF1, tF2
     const float* const srcs[6] = {p.Bm, p.tB, p.F1, p.F2, p.tF1, p.tF2};
-    const bool vec = p.vec != 0;
-    Stage6<LD> stg;
+    Stage6<LD, VEC> stg;
 
     // ---- I-side fragments (registers, whole kernel) ----------------------------------------------------
-    stg.load(srcs, p.ld, I0, B, d, vec, tid);
+    stg.load(srcs, p.ld, I0, B, d, tid);
     stg.store(lds, tid);
     __syncthreads();
     float fa[KS], fb[KS], fc[KS];
@@ -181,11 +202,11 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
 #pragma unroll 1
     for (int jt = jt_begin; jt < jt_end; ++jt) {
         const int J0 = jt * 32;
-        if (jt == jt_begin) stg.load(srcs, p.ld, J0, B, d, vec, tid);      // later tiles were prefetched below
+        if (jt == jt_begin) stg.load(srcs, p.ld, J0, B, d, tid);           // later tiles were prefetched below
         stg.store(lds, tid);
         if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
         __syncthreads();
-        if (jt + 1 < jt_end) stg.load(srcs, p.ld, J0 + 32, B, d, vec, tid); // next J tile in flight under the MFMAs
+        if (jt + 1 < jt_end) stg.load(srcs, p.ld, J0 + 32, B, d, tid);      // next J tile in flight under the MFMAs
 
         if (wid < 2) {
             // tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
@@ -366,7 +387,14 @@ hipError_t pairwise_prepare(int B, int d) {
     if (pl.ks < 0) return hipErrorInvalidValue;
     if (pl.lds_bytes <= 48 * 1024) return hipSuccess;
     const int bytes = (int)pl.lds_bytes;
-#define PW_ATTR(KS) return hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+#define PW_ATTR(KS)                                                                                                   \
+    {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS, true>),                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                        \
+        if (e != hipSuccess) return e;                                                                                \
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS, false>),                        \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                \
+    }
     switch (pl.ks) {
         case 25: PW_ATTR(25);
         case 32: PW_ATTR(32);
@@ -392,7 +420,9 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
     a.Bp = pl.Bp;
     dim3 grid(pl.njt, pl.nchunks), block(256);
     hipError_t e = hipSuccess;
-#define PW_LAUNCH(KS) hipLaunchKernelGGL((pairwise_kernel<KS>), grid, block, pl.lds_bytes, s, a)
+#define PW_LAUNCH(KS)                                                                                                 \
+    if (a.vec) hipLaunchKernelGGL((pairwise_kernel<KS, true>), grid, block, pl.lds_bytes, s, a);                       \
+    else hipLaunchKernelGGL((pairwise_kernel<KS, false>), grid, block, pl.lds_bytes, s, a)
     switch (pl.ks) {
         case 4: PW_LAUNCH(4); break;
         case 8: PW_LAUNCH(8); break;
