@@ -30,12 +30,12 @@ class Dims(C.Structure):
 class HParams(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lr", "lr_coef", "fb_target_tau", "stddev", "stddev_clip", "ortho_coef",
                                           "mix_ratio", "q_loss_coef", "discount", "grad_scale")] + \
-               [("q_loss", C.c_int32), ("want_metrics", C.c_int32)]
+               [("q_loss", C.c_int32), ("want_metrics", C.c_int32), ("future_ratio", C.c_float), ("future", C.c_float)]
 
 
 class Inject(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ep_idx", "step_idx", "z_gauss", "perm", "mix_uniform", "eps_next",
-                                           "eps_actor")]
+                                           "eps_actor", "future_idx", "future_uniform")]
 
 
 class TensorDesc(C.Structure):
@@ -96,7 +96,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 1:
+    if lib.fbhip_abi_version() != 2:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

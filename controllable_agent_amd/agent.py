@@ -235,7 +235,7 @@ class FBHipAgent:
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
                        "rand_weight": cfg.rand_weight, "add_trunk": cfg.add_trunk, "preprocess": not cfg.preprocess,
-                       "norm_z": not cfg.norm_z, "future_ratio": cfg.future_ratio > 0, "nstep": cfg.nstep != 1}
+                       "norm_z": not cfg.norm_z, "nstep": cfg.nstep != 1}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"FBHipAgent: non-default options not implemented in the HIP path yet: {bad}")
@@ -582,9 +582,12 @@ class FBHipAgent:
         return float(out[0])
 
     # ------------------------------------------------------------------ the hot path
-    def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float) -> HParams:
+    def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float, future: float = 1.0) -> HParams:
         c = self.cfg
-        return HParams(lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.fb_target_tau,
+        if c.future_ratio > 0 and not future < 1:
+            # the reference asserts ``future_goal is not None`` (fb_ddpg.py:489): only buffers with future < 1 sample it
+            raise ValueError("future_ratio > 0 needs a replay buffer built with future < 1 (hindsight replay)")
+        return HParams(future_ratio=float(c.future_ratio), future=float(future), lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.fb_target_tau,
                        stddev=schedule(c.stddev_schedule, step), stddev_clip=c.stddev_clip, ortho_coef=c.ortho_coef,
                        mix_ratio=c.mix_ratio, q_loss_coef=c.q_loss_coef, discount=discount, grad_scale=grad_scale,
                        q_loss=int(c.q_loss), want_metrics=int(want_metrics))
@@ -657,7 +660,7 @@ class FBHipAgent:
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
         if isinstance(replay_loader, DeviceReplayBuffer):
             self._bind_replay(replay_loader)
-            hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount))
+            hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
             self._run_update(hp, None, self._use_graph)
         else:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
@@ -673,15 +676,25 @@ class FBHipAgent:
         f = lambda x: torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32,
                                       device=dev).reshape(Bn, -1)
         obs, nobs, act, disc = f(batch.obs), f(batch.next_obs), f(batch.action), f(batch.discount)
-        # a one-transition-per-episode storage [B, 2, dim]: row 0 = (obs, goal), row 1 = (next_obs, action, ...)
-        storage = {"observation": torch.stack([obs, nobs], 1).contiguous(),
-                   "action": torch.stack([torch.zeros_like(act), act], 1).contiguous(),
-                   "discount": torch.stack([torch.ones_like(disc), disc], 1).contiguous()}
-        if c.goal_space is not None:
-            storage["goal"] = torch.stack([f(batch.goal), f(batch.next_goal)], 1).contiguous()
-        rb = DeviceReplayBuffer(Bn, 1.0, 1.0, device=dev)
+        hindsight = c.future_ratio > 0
+        # a one-transition-per-episode storage [B, 2 (+1), dim]: row 0 = (obs, goal), row 1 = (next_obs, action, ...),
+        # row 2 = (future_obs, future_goal) when hindsight replay is on
+        rows = lambda *xs: torch.stack(list(xs), 1).contiguous()
+        if hindsight:
+            if batch.future_obs is None or (c.goal_space is not None and batch.future_goal is None):
+                raise ValueError("future_ratio > 0 needs batch.future_obs / future_goal (sample from a buffer with future < 1)")
+            storage = {"observation": rows(obs, nobs, f(batch.future_obs)), "action": rows(torch.zeros_like(act), act, torch.zeros_like(act)),
+                       "discount": rows(torch.ones_like(disc), disc, torch.ones_like(disc))}
+            if c.goal_space is not None:
+                storage["goal"] = rows(f(batch.goal), f(batch.next_goal), f(batch.future_goal))
+        else:
+            storage = {"observation": rows(obs, nobs), "action": rows(torch.zeros_like(act), act),
+                       "discount": rows(torch.ones_like(disc), disc)}
+            if c.goal_space is not None:
+                storage["goal"] = rows(f(batch.goal), f(batch.next_goal))
+        rb = DeviceReplayBuffer(Bn, 1.0, 0.5 if hindsight else 1.0, device=dev)
         rb._storage = storage
-        rb._episodes_length = np.ones(Bn, np.int32)
+        rb._episodes_length = np.full(Bn, 2 if hindsight else 1, np.int32)
         rb._idx, rb._full = 0, True
         rb._touch()
         self._ext_replay = rb
@@ -689,8 +702,11 @@ class FBHipAgent:
         i32 = lambda x: torch.as_tensor(np.asarray(x), dtype=torch.int32, device=dev).contiguous()
         keep: tp.List[torch.Tensor] = [i32(np.arange(Bn)), i32(np.ones(Bn))]
         inj = Inject(ep_idx=ptr(keep[0]), step_idx=ptr(keep[1]))
+        if hindsight:
+            keep.append(i32(np.full(Bn, 3)))                               # future row = storage[:, 2] = [ep, 3 - 1]
+            inj.future_idx = ptr(keep[-1])
         if draws is not None:
-            for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor"):
+            for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor", "future_uniform"):
                 if name in draws and draws[name] is not None:
                     t = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
                     keep.append(t)
@@ -699,7 +715,7 @@ class FBHipAgent:
                 keep.append(i32(draws["perm"]))
                 inj.perm = ptr(keep[-1])
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
-        hp = self._hparams(step, want, 1.0 / self._world(), 1.0)          # batch.discount is already gamma-scaled
+        hp = self._hparams(step, want, 1.0 / self._world(), 1.0, rb._future)   # batch.discount is already gamma-scaled
         self._run_update(hp, inj, use_graph)
         torch.cuda.current_stream().synchronize()                          # ``keep`` must outlive the launches
         return self._metrics()
@@ -718,10 +734,14 @@ class FBHipAgent:
         for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor"):
             keep[name] = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
             setattr(inj, name, ptr(keep[name]))
+        if self.cfg.future_ratio > 0:                                  # hindsight replay draws (fb_ddpg.py:487-491)
+            keep["future_idx"] = torch.as_tensor(np.asarray(draws["future_idx"]), dtype=torch.int32, device=dev).contiguous()
+            keep["future_uniform"] = torch.as_tensor(np.asarray(draws["future_uniform"], dtype=np.float32), device=dev).contiguous()
+            inj.future_idx, inj.future_uniform = ptr(keep["future_idx"]), ptr(keep["future_uniform"])
         self._inject_keep = keep
         c = self.cfg
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
-        hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount))
+        hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
         self._run_update(hp, inj, use_graph)
         return self._metrics()
 
@@ -732,6 +752,6 @@ class FBHipAgent:
                                                C.byref(ld)), self._ctx)
         base = self._workspace.data_ptr()
         off = p.value - base
-        is_int = name in ("ep_idx", "step_idx", "perm")
+        is_int = name in ("ep_idx", "step_idx", "perm", "future_idx")
         flat = self._workspace[off:off + 4 * rows.value * ld.value].view(torch.int32 if is_int else torch.float32)
         return flat.view(rows.value, ld.value)[:, :cols.value]

@@ -129,9 +129,9 @@ struct Ws {
     StepState* st = nullptr;
     float* metrics = nullptr;
     SampleOut so{};
-    Buf Xoa, Xoz, Xnoz, Xnoa, Xopi, Xo, next_goal, bin, z, zrand;
+    Buf Xoa, Xoz, Xnoz, Xnoa, Xopi, Xo, next_goal, bin, fgoal, z, zrand;
     float* disc = nullptr;
-    BSet bsA, bsO, bsM;      // target / online passes on next_goal, z-mix pass on backward_input[perm]
+    BSet bsA, bsO, bsM, bsF; // target / online passes on next_goal, z-mix pass on backward_input[perm], hindsight pass
     FSet fsT, fsO;
     ASet as;
     Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov, inv_cov, BinvC;
@@ -187,13 +187,16 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.so.z_gauss = c.f((size_t)B * z);
     w.so.eps_next = c.f((size_t)B * a);
     w.so.eps_actor = c.f((size_t)B * a);
+    w.so.future_idx = (int32_t*)c.take((size_t)B * 4);
+    w.so.future_uniform = c.f(B);
     // input panels: widths padded to 32 (pad columns stay zero: the workspace is zero-initialised by the host and
     // no kernel writes them)
     w.Xoa = c.buf(B, o + a, pad32(o + a)); w.Xoz = c.buf(B, o + z, pad32(o + z)); w.Xnoz = c.buf(B, o + z, pad32(o + z));
     w.Xnoa = c.buf(B, o + a, pad32(o + a)); w.Xopi = c.buf(B, o + a, pad32(o + a)); w.Xo = c.buf(B, o, pad32(o));
-    w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.z = c.buf(B, z); w.zrand = c.buf(B, z);
+    w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.fgoal = c.buf(B, g, pad32(g));
+    w.z = c.buf(B, z); w.zrand = c.buf(B, z);
     w.disc = c.f(B);
-    for (BSet* s : {&w.bsA, &w.bsO, &w.bsM}) {
+    for (BSet* s : {&w.bsA, &w.bsO, &w.bsM, &w.bsF}) {
         s->pre1 = c.buf(B, Hb, pad64(Hb)); s->t1 = c.buf(B, Hb, pad64(Hb)); s->r2 = c.buf(B, Hb, pad64(Hb));
         s->y = c.buf(B, z); s->Bm = c.buf(B, z);
         s->stats = c.f(2 * (size_t)B); s->norms = c.f(B);
@@ -386,11 +389,12 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
             gemm_problem_finalize(p, cfg);
             const int kchunks = (p.K + bkt - 1) / bkt;
             int want = 1;
-            if (base_blocks <= 160 && kchunks >= 4) {
+            static const long small_split_max = [] { const char* e = getenv("FBHIP_SMALL_SPLIT_MAX_BLOCKS"); return e ? atol(e) : 160L; }();
+            if (base_blocks <= small_split_max && kchunks >= 4) {
                 // small launch: slice K across workgroups until it has ~3 workgroups per CU
                 want = (int)((640 + base_blocks - 1) / base_blocks);
                 if (want > kchunks / 2) want = kchunks / 2;
-            } else if (base_blocks > 160 && cost_of(p) > std::max(ideal, 6L) && kchunks >= 4) {
+            } else if (base_blocks > small_split_max && cost_of(p) > std::max(ideal, 6L) && kchunks >= 4) {
                 // straggler of a heterogeneous group: slice until one workgroup costs about half the ideal makespan
                 const long pen = cost_of(p) / kchunks;
                 long kper = std::max(2L, (ideal / 2 + pen - 1) / pen);
@@ -695,13 +699,17 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     if (mask & FBHIP_PHASE_SAMPLE) {            // (the RNG counter is advanced by mix_z_kernel at the end of the phase)
         // every NULL field of ``inj`` is drawn on device; injected fields (parity mode / externally sampled
         // batches) overwrite the draw
+        const bool hindsight = hp.future_ratio > 0.f;
+        if (hindsight && !(hp.future < 1.f)) { c->err = g_err = "fbhip: future_ratio > 0 needs a replay buffer with future < 1"; return FBHIP_E_INVALID; }
         const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
-                                  inj->z_gauss && inj->eps_next && inj->eps_actor;
-        if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, s));
+                                  inj->z_gauss && inj->eps_next && inj->eps_actor &&
+                                  (!hindsight || (inj->future_idx && inj->future_uniform));
+        if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, hindsight ? hp.future : -1.f, s));
         if (inj != nullptr) {
 #define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
             INJ(ep_idx, B * 4); INJ(step_idx, B * 4); INJ(perm, B * 4); INJ(mix_uniform, B * 4);
             INJ(z_gauss, (size_t)B * z * 4); INJ(eps_next, (size_t)B * a * 4); INJ(eps_actor, (size_t)B * a * 4);
+            if (hindsight) { INJ(future_idx, B * 4); INJ(future_uniform, B * 4); }
 #undef INJ
         }
         GatherArgs ga{};
@@ -710,6 +718,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         ga.Xnoa = w.Xnoa.p; ga.ld_noa = w.Xnoa.ld; ga.Xopi = w.Xopi.p; ga.ld_opi = w.Xopi.ld;
         ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
         ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld;
+        ga.future_idx = hindsight ? w.so.future_idx : nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
         ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount;
         HIPCK(c, launch_gather(ga, s));
         // sample_z (fb_ddpg.py:224-228) + z-mix (fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm])))
@@ -722,6 +731,10 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_p, w.bin.p, w.bin.ld, w.bsM, B, ch.back(), /*with_projection=*/false);
             }
+            if (hindsight) {                    // B(future_goal), fb_ddpg.py:491 (its projection happens in mix_z_kernel)
+                ch.emplace_back();
+                backward_map_fwd_chain(c, c->K_p, w.fgoal.p, w.fgoal.ld, w.bsF, B, ch.back(), /*with_projection=*/false);
+            }
             if (mask & FBHIP_PHASE_FB_GRAD) {
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
@@ -731,7 +744,8 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             RC(run_rounds(c, ch, s));
         }
         HIPCK(c, launch_mix_z(w.so.z_gauss, z, w.bsM.y.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
-                              w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, s));
+                              w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, hindsight ? w.bsF.y.p : nullptr, w.so.future_uniform,
+                              hp.future_ratio, s));
     }
 
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
@@ -1058,7 +1072,7 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, z = d.z_dim;
     std::map<std::string, Buf> m = {
         {"Xoa", w.Xoa}, {"Xoz", w.Xoz}, {"Xnoz", w.Xnoz}, {"Xnoa", w.Xnoa}, {"Xopi", w.Xopi}, {"next_goal", w.next_goal},
-        {"backward_input", w.bin}, {"z", w.z}, {"zrand", w.zrand}, {"F1", w.fsO.F1}, {"F2", w.fsO.F2}, {"Bm", w.bsO.Bm},
+        {"backward_input", w.bin}, {"future_goal", w.fgoal}, {"z", w.z}, {"zrand", w.zrand}, {"F1", w.fsO.F1}, {"F2", w.fsO.F2}, {"Bm", w.bsO.Bm},
         {"y", w.bsO.y}, {"tF1", w.fsT.F1}, {"tF2", w.fsT.F2}, {"tB", w.bsA.Bm}, {"dF1", w.dF1}, {"dF2", w.dF2},
         {"dBm", w.dBm}, {"dy", w.dy}, {"mu", w.as.mu}, {"d_premu", w.a_dpremu}};
     Buf b;
@@ -1076,6 +1090,8 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
     else if (n == "step_idx") { b.p = (float*)w.so.step_idx; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "perm") { b.p = (float*)w.so.perm; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "mix_uniform") { b.p = w.so.mix_uniform; b.rows = 1; b.cols = B; b.ld = B; }
+    else if (n == "future_idx") { b.p = (float*)w.so.future_idx; b.rows = 1; b.cols = B; b.ld = B; }
+    else if (n == "future_uniform") { b.p = w.so.future_uniform; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "eps_next") { b.p = w.so.eps_next; b.rows = B; b.cols = a; b.ld = a; }
     else if (n == "eps_actor") { b.p = w.so.eps_actor; b.rows = B; b.cols = a; b.ld = a; }
     else { c->err = g_err = "fbhip: unknown workspace view '" + n + "'"; return FBHIP_E_INVALID; }

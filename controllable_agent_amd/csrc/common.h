@@ -142,9 +142,11 @@ struct ReplayView {
 struct SampleOut {          // all device pointers into the workspace
     int32_t* ep_idx; int32_t* step_idx; int32_t* perm; float* mix_uniform;
     float* z_gauss; float* eps_next; float* eps_actor;
+    int32_t* future_idx; float* future_uniform;       // hindsight replay (only drawn when future_ratio > 0)
 };
+// future < 0: no hindsight draws; else future_idx = clip(step_idx + Geometric(1 - future), 0, len) and a uniform
 hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a,
-                       uint64_t seed, uint32_t rank, const StepState* st,
+                       uint64_t seed, uint32_t rank, const StepState* st, float future,
                        hipStream_t s);
 struct GatherArgs {
     ReplayView rv;
@@ -157,15 +159,18 @@ struct GatherArgs {
     float* Xo; int ld_o;        // [obs] alone (zero padded: operand of the actor's obs_net weight gradient)
     float* next_goal; int ld_ng;    // goal[ep, step] if use_goal else next_obs
     float* bin; int ld_bin;     // backward_input[perm]
+    const int32_t* future_idx;  // nullable: hindsight replay off
+    float* fgoal; int ld_fg;    // (goal if use_goal else observation)[ep, future_idx - 1]
     float* disc;
     int B, o, a, g, use_goal; float gamma;
 };
 hipError_t launch_gather(const GatherArgs& ga, hipStream_t s);
 // z[i] = mix ? sqrt(d) normalize(sqrt(d) normalize(ymix[i])) : sqrt(d) normalize(gauss[i]); scattered into the concat
 // panels; advances the RNG counter when st != nullptr
+// hindsight rows (future_uniform[i] < future_ratio) take sqrt(d) normalize(yfut[i]) instead (fb_ddpg.py:487-491)
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
-                        StepState* st, hipStream_t s);
+                        StepState* st, const float* yfut, const float* future_uniform, float future_ratio, hipStream_t s);
 hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, const float* B, int ldb, int nb,
                           int rows, hipStream_t s);
 hipError_t pairwise_prepare(int B, int d);     // one-time kernel attribute setup (outside graph capture)

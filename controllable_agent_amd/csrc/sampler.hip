@@ -17,7 +17,7 @@ namespace {
 
 
 __global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, int B, int d, int a, unsigned k0,
-                                                   unsigned k1, const StepState* __restrict__ st) {
+                                                   unsigned k1, const StepState* __restrict__ st, float future) {
     const unsigned cnt = st->update_count;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < B) {
@@ -44,6 +44,21 @@ __global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, 
         }
         so.ep_idx[i] = ep;
         so.step_idx[i] = step;
+        if (future >= 0.f) {
+            // hindsight replay: future_idx = clip(step_idx + Geometric(p = 1 - future), 0, eps_len)
+            // (in_memory_replay_buffer.py:157-161); inverse CDF G = ceil(ln u / ln(1 - p)) >= 1.  Then the selection uniform
+            // of fb_ddpg.py:490.
+            const U4 f = philox4x32_10((unsigned)i, STREAM_FUTURE, cnt, 0u, k0, k1);
+            int geo = 1;
+            if (future > 0.f) {
+                const float gq = ceilf(logf(u01(f.x)) / logf(future));
+                geo = gq < 1.f ? 1 : (gq > 1.0e9f ? 1000000000 : (int)gq);
+            }
+            const int len = rv.episode_len[ep];
+            const long long fi = (long long)step + geo;
+            so.future_idx[i] = (int)(fi > len ? len : fi);
+            so.future_uniform[i] = u01(f.y);
+        }
         so.mix_uniform[i] = u01(philox4x32_10((unsigned)i, STREAM_MIX, cnt, 0u, k0, k1).x);   // fb_ddpg.py:471
     }
     // torch.randperm (fb_ddpg.py:467) = argsort of B random keys (Philox word, ties broken by index).  Workgroup b ranks
@@ -119,6 +134,10 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
     const size_t tp = (size_t)g.ep_idx[pi] * g.rv.t1 + g.step_idx[pi] - 1;
     const float* bsrc = g.use_goal ? g.rv.goal + tp * g.g : g.rv.observation + tp * g.o;
     copy_row(g.bin + (size_t)i * g.ld_bin, bsrc, g.g, lane);
+    if (g.future_idx != nullptr) {   // future_goal / future_obs = storage[ep, future_idx - 1] (in_memory_replay_buffer.py:176-183)
+        const size_t tf = (size_t)e * g.rv.t1 + g.future_idx[i] - 1;
+        copy_row(g.fgoal + (size_t)i * g.ld_fg, g.use_goal ? g.rv.goal + tf * g.g : g.rv.observation + tf * g.o, g.g, lane);
+    }
 }
 
 // z = mix ? sqrt(d) normalize(B(backward_input)) : sqrt(d) normalize(gauss), scattered into every panel that carries z.
@@ -131,12 +150,15 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
                                                     const float* __restrict__ mixu, float mix_ratio,
                                                     float* __restrict__ z, int ldz, float* __restrict__ Xoz, int ld_oz,
                                                     float* __restrict__ Xnoz, int ld_noz, int o, int B, int d,
-                                                    StepState* __restrict__ st) {
+                                                    StepState* __restrict__ st, const float* __restrict__ yfut,
+                                                    const float* __restrict__ futu, float future_ratio) {
     if (st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) st->update_count += 1u;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
-    const bool mix = (mix_ratio > 0.f) && (mixu[i] < mix_ratio);
-    const float* src = mix ? ymix + (size_t)i * ldy : gauss + (size_t)i * ldg;
+    // hindsight rows (fb_ddpg.py:487-491) override the mix: z = B(future_goal), projected ONCE (BackwardMap's own)
+    const bool fut = (future_ratio > 0.f) && (futu[i] < future_ratio);
+    const bool mix = !fut && (mix_ratio > 0.f) && (mixu[i] < mix_ratio);
+    const float* src = fut ? yfut + (size_t)i * ldy : (mix ? ymix + (size_t)i * ldy : gauss + (size_t)i * ldg);
     constexpr int ME = 4;                         // d <= 256
     float v[ME];
     float s = 0.f;
@@ -177,12 +199,12 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
 }  // namespace
 
 hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a, uint64_t seed, uint32_t rank,
-                       const StepState* st, hipStream_t s) {
+                       const StepState* st, float future, hipStream_t s) {
     if (B > 8192) return hipErrorInvalidValue;
     const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
     int blocks = (B * d / 4 + 255) / 256;
     if (blocks < (B + 31) / 32) blocks = (B + 31) / 32;
-    hipLaunchKernelGGL(draw_kernel, dim3(blocks), dim3(256), (size_t)((B + 63) & ~63) * 4, s, rv, so, B, d, a, k0, k1, st);
+    hipLaunchKernelGGL(draw_kernel, dim3(blocks), dim3(256), (size_t)((B + 63) & ~63) * 4, s, rv, so, B, d, a, k0, k1, st, future);
     return hipGetLastError();
 }
 
@@ -193,10 +215,11 @@ hipError_t launch_gather(const GatherArgs& ga, hipStream_t s) {
 
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
-                        StepState* st, hipStream_t s) {
+                        StepState* st, const float* yfut, const float* future_uniform, float future_ratio, hipStream_t s) {
     if (d > 256) return hipErrorInvalidValue;
+    if (future_ratio > 0.f && (!yfut || !future_uniform)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mix_z_kernel, dim3((B + 3) / 4), dim3(256), 0, s, gauss, ldg, ymix, ldy, mix_uniform, mix_ratio, z,
-                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st);
+                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st, yfut, future_uniform, future_ratio);
     return hipGetLastError();
 }
 

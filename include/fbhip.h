@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 1
+#define FBHIP_ABI_VERSION 2
 
 enum {
     FBHIP_OK = 0,
@@ -86,6 +86,9 @@ typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82
     float grad_scale;              /* 1/world_size when gradients were sum-all-reduced, else 1 */
     int32_t q_loss;                /* 0/1    */
     int32_t want_metrics;          /* compute the full metric set of fb_ddpg.py:356-377 */
+    float future_ratio;            /* 0: off.  > 0: hindsight replay z[u < future_ratio] = B(future_goal) (fb_ddpg.py:487-491) */
+    float future;                  /* ReplayBuffer._future (< 1 when future_ratio > 0): future_idx = clip(step_idx +
+                                    * Geometric(1 - future), 0, episode_len) (in_memory_replay_buffer.py:157-161) */
 } fbhip_hparams;
 
 /* Injected random draws (parity mode).  NULL struct => draw on device with Philox4x32-10 keyed by
@@ -98,6 +101,8 @@ typedef struct fbhip_inject {
     const float* mix_uniform;      /* [B]   fb_ddpg.py:471 */
     const float* eps_next;         /* [B,a] contiguous; utils.py:178 via fb_ddpg.py:310 */
     const float* eps_actor;        /* [B,a] contiguous; utils.py:178 via fb_ddpg.py:397 */
+    const int32_t* future_idx;     /* [B]   in_memory_replay_buffer.py:159-160 (1-based, clipped); used if future_ratio > 0 */
+    const float* future_uniform;   /* [B]   fb_ddpg.py:490; used if future_ratio > 0 */
 } fbhip_inject;
 
 /* one named tensor inside a flat parameter buffer (names = the reference's state_dict keys) */

@@ -51,6 +51,8 @@ class OracleConfig:
     q_loss_coef: float = 0.01
     use_goal: bool = False        # goal_space is not None
     discount: float = 0.99        # ReplayBuffer._discount (in_memory_replay_buffer.py:171)
+    future_ratio: float = 0.0     # hindsight replay: z[u < future_ratio] = B(future_goal)  (fb_ddpg.py:487-491)
+    future: float = 1.0           # ReplayBuffer._future; < 1 => future_idx = step + Geometric(1 - future) (:157-161)
 
 
 @dataclasses.dataclass
@@ -63,6 +65,8 @@ class Draws:
     mix_uniform: np.ndarray   # f64 [B]     fb_ddpg.py:471    (np.random.uniform)
     eps_next: np.ndarray      # f32 [B,a]   utils.py:178 inside update_fb (fb_ddpg.py:310)
     eps_actor: np.ndarray     # f32 [B,a]   utils.py:178 inside update_actor (fb_ddpg.py:397)
+    future_idx: tp.Optional[np.ndarray] = None      # int64 [B]  in_memory_replay_buffer.py:157-161 (only if future < 1)
+    future_uniform: tp.Optional[np.ndarray] = None  # f64 [B]    fb_ddpg.py:490 (only if future_ratio > 0)
 
 
 def make_draws(rng: np.random.Generator, cfg: OracleConfig, n_episodes: int,
@@ -78,13 +82,23 @@ def make_draws(rng: np.random.Generator, cfg: OracleConfig, n_episodes: int,
     else:
         ep = rng.choice(np.arange(n_episodes), size=B, p=lens / lens.sum())
     step = rng.integers(0, lens[ep]) + 1
-    return Draws(
+    fut_idx = fut_u = None
+    if cfg.future < 1:                                           # in_memory_replay_buffer.py:157-161
+        fut_idx = np.clip(step + rng.geometric(p=1 - cfg.future, size=B), 0, lens[ep]).astype(np.int64)
+    return _with_future(cfg, rng, fut_idx, Draws(
         ep_idx=ep.astype(np.int64), step_idx=step.astype(np.int64),
         z_gauss=rng.standard_normal((B, cfg.z_dim)).astype(np.float32),
         perm=rng.permutation(B).astype(np.int64),
         mix_uniform=rng.uniform(size=B),
         eps_next=rng.standard_normal((B, cfg.action_dim)).astype(np.float32),
-        eps_actor=rng.standard_normal((B, cfg.action_dim)).astype(np.float32))
+        eps_actor=rng.standard_normal((B, cfg.action_dim)).astype(np.float32)))
+
+
+def _with_future(cfg: OracleConfig, rng: np.random.Generator, fut_idx, d: Draws) -> Draws:
+    d.future_idx = fut_idx
+    if cfg.future_ratio > 0:
+        d.future_uniform = rng.uniform(size=cfg.batch_size)
+    return d
 
 
 # --------------------------------------------------------------------------- #
@@ -212,7 +226,8 @@ def sample_z_from_gauss(gauss: torch.Tensor, z_dim: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 # replay sampling (in_memory_replay_buffer.py:139-190)
 # --------------------------------------------------------------------------- #
-def gather_batch(storage: tp.Dict[str, np.ndarray], ep_idx, step_idx, discount: float) -> tp.Dict[str, np.ndarray]:
+def gather_batch(storage: tp.Dict[str, np.ndarray], ep_idx, step_idx, discount: float,
+                 future_idx=None) -> tp.Dict[str, np.ndarray]:
     """Index arithmetic of ReplayBuffer.sample: obs = observation[ep, step-1],
     action/next_obs/reward/discount at [ep, step]; goal pair likewise (:163-180)."""
     out = {
@@ -226,6 +241,10 @@ def gather_batch(storage: tp.Dict[str, np.ndarray], ep_idx, step_idx, discount: 
     if "goal" in storage:
         out["goal"] = storage["goal"][ep_idx, step_idx - 1]
         out["next_goal"] = storage["goal"][ep_idx, step_idx]
+    if future_idx is not None:                                   # :176-183
+        out["future_obs"] = storage["observation"][ep_idx, future_idx - 1]
+        if "goal" in storage:
+            out["future_goal"] = storage["goal"][ep_idx, future_idx - 1]
     return out
 
 
@@ -337,8 +356,9 @@ class OracleAgent:
     def _req(params: Params) -> Params:
         return {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
 
-    def mix_z(self, z: torch.Tensor, backward_input: torch.Tensor, draws: Draws) -> torch.Tensor:
-        """z-mixing of fb_ddpg.py:467-485 (rand_weight=False, norm_z=True)."""
+    def mix_z(self, z: torch.Tensor, backward_input: torch.Tensor, draws: Draws,
+              future_goal: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+        """z-mixing of fb_ddpg.py:467-485 (rand_weight=False, norm_z=True) and hindsight replay (:487-491)."""
         cfg = self.cfg
         bi = backward_input[torch.from_numpy(draws.perm)]
         if cfg.mix_ratio > 0:
@@ -348,6 +368,13 @@ class OracleAgent:
             mz = math.sqrt(cfg.z_dim) * F.normalize(mz, dim=1)
             z = z.clone()
             z[mix_idxs] = mz
+        if cfg.future_ratio > 0:                                   # fb_ddpg.py:487-491 (after, hence over, the mix)
+            assert future_goal is not None and draws.future_uniform is not None
+            future_idxs = np.where(draws.future_uniform < cfg.future_ratio)[0]
+            with torch.no_grad():
+                fz = backward_map(self.backward_net, future_goal[future_idxs], cfg.z_dim)
+            z = z.clone()
+            z[future_idxs] = fz
         return z
 
     # -- one update ------------------------------------------------------- #
@@ -361,8 +388,11 @@ class OracleAgent:
         if cfg.use_goal:                                           # fb_ddpg.py:441-443, 460-465
             next_goal = t(batch["next_goal"])
             backward_input = t(batch["goal"])
+        future_goal = None
+        if cfg.future_ratio > 0:                                   # fb_ddpg.py:461-465
+            future_goal = t(batch["future_goal"] if cfg.use_goal else batch["future_obs"])
         z = sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim)       # fb_ddpg.py:451
-        z = self.mix_z(z, backward_input, draws)
+        z = self.mix_z(z, backward_input, draws, future_goal)
         metrics: tp.Dict[str, float] = {}
 
         # ---------------- update_fb (fb_ddpg.py:291-387) ---------------- #
@@ -457,7 +487,10 @@ class OracleAgent:
                         discount=t(batch["discount"]).reshape(-1, 1), draws=draws)
         self._dp["next_goal"] = t(batch["next_goal"]) if cfg.use_goal else self._dp["next_obs"]
         bi = t(batch["goal"]) if cfg.use_goal else self._dp["obs"]
-        self._dp["z"] = self.mix_z(sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim), bi, draws)
+        fg = None
+        if cfg.future_ratio > 0:
+            fg = t(batch["future_goal"] if cfg.use_goal else batch["future_obs"])
+        self._dp["z"] = self.mix_z(sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim), bi, draws, fg)
 
     def dp_fb_grads(self) -> tp.Tuple[Params, Params]:
         """gradients of update_fb's loss wrt (forward_net, backward_net)  (fb_ddpg.py:303-383)"""

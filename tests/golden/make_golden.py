@@ -94,7 +94,7 @@ def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
         hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
         z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
         ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
-        update_every_steps=1, **extra)
+        future_ratio=cfg.future_ratio, update_every_steps=1, **extra)
 
 
 def load_nets(agent, nets):
@@ -127,8 +127,8 @@ def fill_ref_buffer(R, storage, lengths, discount, future=0.99, max_len=None, me
 @contextlib.contextmanager
 def inject(R, d: fo.Draws, variable_len: bool):
     """Route every random draw of one ``update()`` to the prepared values."""
-    calls = {"randint": 0}
-    o_randint, o_choice, o_uniform = np.random.randint, np.random.choice, np.random.uniform
+    calls = {"randint": 0, "uniform": 0}
+    o_randint, o_choice, o_uniform, o_geo = np.random.randint, np.random.choice, np.random.uniform, np.random.geometric
     o_randperm, o_randn, o_sn = torch.randperm, torch.randn, R.utils._standard_normal
     eps_queue = [d.eps_next, d.eps_actor]
 
@@ -143,7 +143,11 @@ def inject(R, d: fo.Draws, variable_len: bool):
 
     def uniform(*a, size=None, **kw):
         assert size == len(d.mix_uniform)
-        return d.mix_uniform.copy()
+        calls["uniform"] += 1                  # 1st: mix (fb_ddpg.py:471), 2nd: hindsight replay (:490)
+        return d.mix_uniform.copy() if calls["uniform"] == 1 else d.future_uniform.copy()
+
+    def geometric(p, size=None):               # in_memory_replay_buffer.py:159 (clip at :160 is then a no-op)
+        return (d.future_idx - d.step_idx).copy()
 
     def randperm(n, **kw):
         return torch.from_numpy(d.perm.copy())
@@ -154,12 +158,12 @@ def inject(R, d: fo.Draws, variable_len: bool):
     def standard_normal(shape, dtype, device):
         return torch.from_numpy(eps_queue.pop(0).copy())
 
-    np.random.randint, np.random.choice, np.random.uniform = randint, choice, uniform
+    np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = randint, choice, uniform, geometric
     torch.randperm, torch.randn, R.utils._standard_normal = randperm, randn, standard_normal
     try:
         yield
     finally:
-        np.random.randint, np.random.choice, np.random.uniform = o_randint, o_choice, o_uniform
+        np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = o_randint, o_choice, o_uniform, o_geo
         torch.randperm, torch.randn, R.utils._standard_normal = o_randperm, o_randn, o_sn
     assert not eps_queue, "update() did not consume both action-noise draws"
 
@@ -197,7 +201,7 @@ def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_s
                                             cfg.goal_dim if cfg.use_goal else None, lengths)
     agent = make_ref_agent(R, cfg, goal_space=goal_space)
     load_nets(agent, nets)
-    rb = fill_ref_buffer(R, storage, lengths, cfg.discount, max_len=(T + 1) if variable_len else None)
+    rb = fill_ref_buffer(R, storage, lengths, cfg.discount, future=cfg.future, max_len=(T + 1) if variable_len else None)
     assert rb._is_fixed_episode_length == (not variable_len)
     arrays, meta = {}, {"name": name, "seed": seed, "n_eps": n_eps, "T": T, "n_steps": n_steps,
                         "goal_space": goal_space, "variable_len": variable_len,
@@ -216,7 +220,8 @@ def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_s
         meta["metrics"].append({k: float(v) for k, v in m.items()})
         if full_state:
             for f in d.__dataclass_fields__:
-                arrays[f"draws/{s}/{f}"] = getattr(d, f)
+                if getattr(d, f) is not None:
+                    arrays[f"draws/{s}/{f}"] = getattr(d, f)
             for k, v in ref_state(agent).items():
                 arrays[f"state/{s}/{k}"] = v
         if (s + 1) in checksum_steps:
@@ -226,6 +231,13 @@ def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_s
         np.savez_compressed(HERE / f"{name}.npz", **arrays)
     print(f"[{name}] steps={n_steps} fb_loss={[round(m['fb_loss'], 4) for m in meta['metrics'][:3]]} "
           f"actor_loss={[round(m['actor_loss'], 4) for m in meta['metrics'][:3]]}")
+
+
+def future_fixtures(R):
+    """hindsight replay (fb_ddpg.py:487-491) on buffers with future < 1 (in_memory_replay_buffer.py:157-161)"""
+    trace_fixture(R, "tiny_future_trace", tiny_cfg(future=0.8, future_ratio=0.4), seed=103, n_eps=6, T=12, n_steps=4)
+    trace_fixture(R, "tiny_future_goal_trace", tiny_cfg(goal_dim=3, use_goal=True, future=0.7, future_ratio=0.5, mix_ratio=0.3),
+                  seed=104, n_eps=7, T=11, n_steps=3, goal_space="simplified_walker", variable_len=True)
 
 
 def sampler_fixture(R):
@@ -362,6 +374,7 @@ def main():
     trace_fixture(R, "tiny_goal_trace", tiny_cfg(goal_dim=3, use_goal=True, q_loss=True, lr_coef=0.5, z_dim=10,
                                                  backward_hidden_dim=22, batch_size=24),
                   seed=102, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)
+    future_fixtures(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

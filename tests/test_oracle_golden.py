@@ -25,16 +25,18 @@ def _replay(name, full_state):
         if full_state:
             np.testing.assert_array_equal(z[f"draws/{s}/perm"], d.perm)
             np.testing.assert_array_equal(z[f"draws/{s}/z_gauss"], d.z_gauss)
-        batch = fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount)
+        if full_state and d.future_idx is not None:
+            np.testing.assert_array_equal(z[f"draws/{s}/future_idx"], d.future_idx)
+        batch = fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount, d.future_idx)
         m = agent.update(batch, d)
         out.append((m, agent.state_tensors() if (full_state or str(s + 1) in meta["checksums"]) else None))
     return meta, z, out
 
 
-@pytest.mark.parametrize("name", ["tiny_trace", "tiny_goal_trace"])
+@pytest.mark.parametrize("name", ["tiny_trace", "tiny_goal_trace", "tiny_future_trace", "tiny_future_goal_trace"])
 def test_tiny_traces_full_state(name):
     """Every parameter / target / Adam tensor after every step, tiny dims (incl. goal_space, q_loss,
-    variable episode lengths, lr_coef != 1).  Tolerance: abs 2e-6 on params (fp32, Adam lr 1e-3)."""
+    variable episode lengths, lr_coef != 1, hindsight replay with future_ratio > 0 on future < 1 buffers).  Tolerance: abs 2e-6 on params (fp32, Adam lr 1e-3)."""
     meta, z, out = _replay(name, True)
     for s, (m, state) in enumerate(out):
         for k, v in meta["metrics"][s].items():
