@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--episodes", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with the gloo backend (RCCL refuses two ranks per device): exercises the "
+                         "multi-rank code path of this script on a 1-GPU box; the number it prints is NOT a scaling result")
     ap.add_argument("--workload", choices=("walker", "quadruped"), default="walker",
                     help="walker = configs[1], THE bench line; quadruped = configs[2] (no cpu_baseline / kernel probe)")
     args = ap.parse_args()
@@ -153,12 +156,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from controllable_agent_amd.agent import FBHipAgent
     torch.manual_seed(1)                       # identical initial weights on every rank
@@ -200,7 +208,8 @@ def main():
         out = {
             "metric": f"FB update-steps/sec (batch={W['batch_size']}, z_dim={W['z_dim']})", "value": value, "unit": "update-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic; REHEARSAL: all ranks share cuda:0 over gloo",
             "config": {"workload": ("fb_ddpg offline on walker_walk replay (configs[1]): obs 24, action 6, z_dim 50, "
                                     "hidden 1024, feature 512, backward hidden 526; batch 1024 per GPU; "
                                     f"{args.episodes}-episode x 1000-step synthetic RND-style replay resident in HBM; "

@@ -1,0 +1,81 @@
+"""Two REAL ranks of the HIP data-parallel path on one GPU (both on cuda:0, backend gloo -- RCCL refuses two ranks on
+one device, gloo all-reduces CUDA tensors fine): every rank runs FBHipAgent.update on its own replay shard through
+controllable_agent_amd.distributed.dp_update (3 hipGraphs + 2 gradient all-reduces per step).  Must equal ONE process fed
+both micro-batches with gradient averaging (the oracle, as in tests/test_distributed_cpu.py) and leave the replicas
+bit-identical.  This is the rehearsal of the 8-GPU RCCL run the driver does at round end."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fb_oracle as fo
+from tests import helpers as H
+from tests import test_distributed_cpu as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, port, out_q):
+    import torch.distributed as dist
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    cfg, nets, storage, lengths = T._setup()
+    agent = H.make_hip_agent(cfg, nets)
+    assert agent._world() == T.WORLD and agent._rank() == rank
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    for step in range(T.STEPS):
+        rng = np.random.default_rng(1000 * step + rank)                 # == tests/test_distributed_cpu.py::_shard_batch
+        d = fo.make_draws(rng, cfg, len(rb), rb._episodes_length)
+        agent.update_injected(rb, step, H.draws_dict(d), use_graph=True)
+    torch.cuda.synchronize()
+    out_q.put((rank, H.get_agent_state(agent), agent.step_counts()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_gradient_averaging():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(T.WORLD)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    results = {r: st for r, st, _ in got}
+    assert all(cnt == (T.STEPS, T.STEPS) for _, _, cnt in got)
+    # single process (oracle): both micro-batches, averaged gradients -- same construction as the CPU test
+    torch.set_num_threads(1)
+    cfg, nets, storage, lengths = T._setup()
+    ref = fo.OracleAgent(cfg, nets)
+    twins = [fo.OracleAgent(cfg, nets) for _ in range(T.WORLD)]
+    for step in range(T.STEPS):
+        gFs, gBs, gAs = [], [], []
+        for r, tw in enumerate(twins):
+            for n in H.NETS5:
+                for k, v in getattr(ref, n).items():
+                    getattr(tw, n)[k].copy_(v)
+            tw.dp_begin(*T._shard_batch(cfg, storage, lengths, r, step))
+            gF, gB = tw.dp_fb_grads()
+            gFs.append(gF), gBs.append(gB)
+        avg = lambda gs: {k: sum(g[k] for g in gs) / T.WORLD for k in gs[0]}
+        ref.dp_fb_step(avg(gFs), avg(gBs))
+        for tw in twins:
+            for n in ("forward_net", "backward_net"):
+                for k, v in getattr(ref, n).items():
+                    getattr(tw, n)[k].copy_(v)
+            gAs.append(tw.dp_actor_grads())
+        ref.dp_actor_step(avg(gAs))
+    want = ref.state_tensors()
+    for k in results[0]:                                                  # replicas stay bit-identical
+        np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+    for k, v in want.items():
+        if k.startswith("adam_"):
+            assert H.rel_err(results[0][k], v) < 2e-4, k
+        else:
+            np.testing.assert_allclose(results[0][k], v, rtol=0, atol=3e-6, err_msg=k)
