@@ -52,23 +52,23 @@ def get_goal_space_dim(name: str) -> int:
 
 
 def schedule(schdl: tp.Union[str, float], step: int) -> float:
-    """utils.schedule (utils.py:235-255)"""
+    """``utils.schedule`` (utils.py:235-255): a constant, ``linear(init,final,T)`` or
+    ``step_linear(init,final1,T1,final2,T2)``.  All three are piecewise-linear in ``step`` and constant outside their
+    knots, so one clamped interpolation evaluates them."""
     try:
         return float(schdl)
-    except ValueError:
-        match = re.match(r'linear\((.+),(.+),(.+)\)', schdl)
-        if match:
-            init, final, duration = [float(g) for g in match.groups()]
-            mix = np.clip(step / duration, 0.0, 1.0)
-            return float((1.0 - mix) * init + mix * final)
-        match = re.match(r'step_linear\((.+),(.+),(.+),(.+),(.+)\)', schdl)
-        if match:
-            init, final1, duration1, final2, duration2 = [float(g) for g in match.groups()]
-            if step <= duration1:
-                mix = np.clip(step / duration1, 0.0, 1.0)
-                return float((1.0 - mix) * init + mix * final1)
-            mix = np.clip((step - duration1) / duration2, 0.0, 1.0)
-            return float((1.0 - mix) * final1 + mix * final2)
+    except (TypeError, ValueError):
+        pass
+    m = re.fullmatch(r"\s*(linear|step_linear)\((.*)\)\s*", str(schdl))
+    if m is not None:
+        v = [float(x) for x in m.group(2).split(",")]
+        if m.group(1) == "linear" and len(v) == 3:
+            xs, ys = [0.0, v[2]], [v[0], v[1]]
+        elif m.group(1) == "step_linear" and len(v) == 5:
+            xs, ys = [0.0, v[2], v[2] + v[4]], [v[0], v[1], v[3]]
+        else:
+            raise NotImplementedError(schdl)
+        return float(np.interp(float(step), xs, ys))
     raise NotImplementedError(schdl)
 
 

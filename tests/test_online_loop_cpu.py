@@ -90,3 +90,17 @@ def test_online_loop_call_sequence():
     acts = [e for e in log if e[0] == "act"]
     assert [a[1] for a in acts] == list(range(8)) and acts[3][2] == 0.0 and acts[3][3] == 2.0   # step 3 = first of episode 2
     assert any(k == ["buffer_size", "episode", "episode_reward", "z_correl"] for _, k in seen)
+
+
+def test_schedule_matches_utils_schedule_semantics():
+    """utils.schedule (utils.py:235-255): constants, linear(init,final,T), step_linear(init,f1,T1,f2,T2)."""
+    from controllable_agent_amd.agent import schedule
+    import pytest
+    assert schedule("0.2", 123) == 0.2 and schedule(0.3, 0) == 0.3
+    lin = "linear(1.0,0.1,500)"
+    assert schedule(lin, 0) == 1.0 and schedule(lin, 250) == pytest.approx(0.55) and schedule(lin, 10_000) == pytest.approx(0.1)
+    sl = "step_linear(1.0,0.5,100,0.1,400)"
+    assert schedule(sl, 50) == pytest.approx(0.75) and schedule(sl, 100) == pytest.approx(0.5)
+    assert schedule(sl, 300) == pytest.approx(0.3) and schedule(sl, 9999) == pytest.approx(0.1)
+    with pytest.raises(NotImplementedError):
+        schedule("cosine(1,0,10)", 3)
