@@ -24,7 +24,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK_RELU, EPI_TANH_BWD = range(5)
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
-                                          "feature_dim", "backward_hidden_dim", "use_goal")]
+                                          "feature_dim", "backward_hidden_dim", "use_goal", "norm_z")]
 
 
 class HParams(C.Structure):
@@ -35,7 +35,7 @@ class HParams(C.Structure):
 
 class Inject(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ep_idx", "step_idx", "z_gauss", "perm", "mix_uniform", "eps_next",
-                                           "eps_actor", "future_idx", "future_uniform")]
+                                           "eps_actor", "future_idx", "future_uniform", "z_uniform")]
 
 
 class TensorDesc(C.Structure):
@@ -96,7 +96,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 2:
+    if lib.fbhip_abi_version() != 3:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -235,7 +235,7 @@ class FBHipAgent:
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
                        "rand_weight": cfg.rand_weight, "add_trunk": cfg.add_trunk, "preprocess": not cfg.preprocess,
-                       "norm_z": not cfg.norm_z, "nstep": cfg.nstep != 1}
+                       "nstep": cfg.nstep != 1}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"FBHipAgent: non-default options not implemented in the HIP path yet: {bad}")
@@ -255,7 +255,7 @@ class FBHipAgent:
         self.training = True
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, goal_dim, cfg.z_dim, cfg.hidden_dim,
-                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None))
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.norm_z)))
         self._ctx: tp.Optional[C.c_void_p] = None
         self._replay_token: tp.Optional[tp.Tuple[int, int]] = None
         self._ext_replay: tp.Optional[DeviceReplayBuffer] = None
@@ -403,7 +403,7 @@ class FBHipAgent:
         self.solved_meta, self.actor_success, self.training = st["solved_meta"], [], st["training"]
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, self.goal_dim, cfg.z_dim, cfg.hidden_dim,
-                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None))
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.norm_z)))
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)
         for k, v in st["flat"].items():
@@ -453,10 +453,12 @@ class FBHipAgent:
         agent.init_from(ref)
         return agent
 
-    def sample_z(self, size: int, device: str = "cpu") -> torch.Tensor:  # fb_ddpg.py:224-232 (norm_z=True)
-        gaussian_rdv = torch.randn((size, self.cfg.z_dim), dtype=torch.float32, device=device)
-        gaussian_rdv = torch.nn.functional.normalize(gaussian_rdv, dim=1)
-        return math.sqrt(self.cfg.z_dim) * gaussian_rdv
+    def sample_z(self, size: int, device: str = "cpu") -> torch.Tensor:  # fb_ddpg.py:224-232
+        gaussian_rdv = torch.nn.functional.normalize(
+            torch.randn((size, self.cfg.z_dim), dtype=torch.float32, device=device), dim=1)
+        if self.cfg.norm_z:
+            return math.sqrt(self.cfg.z_dim) * gaussian_rdv
+        return np.sqrt(self.cfg.z_dim) * torch.rand((size, self.cfg.z_dim), dtype=torch.float32, device=device) * gaussian_rdv
 
     def init_meta(self) -> MetaDict:                                      # fb_ddpg.py:234-243
         if self.solved_meta is not None:
@@ -534,7 +536,9 @@ class FBHipAgent:
                                         self._stream.cuda_stream), self._ctx)
         return out
 
-    def _normalize_z(self, z: torch.Tensor) -> torch.Tensor:
+    def _normalize_z(self, z: torch.Tensor) -> torch.Tensor:            # ``if self.cfg.norm_z:`` of fb_ddpg.py:181, :217
+        if not self.cfg.norm_z:
+            return z
         from . import kernels
         return kernels.l2norm_fwd(z.contiguous())[0]
 
@@ -706,7 +710,7 @@ class FBHipAgent:
             keep.append(i32(np.full(Bn, 3)))                               # future row = storage[:, 2] = [ep, 3 - 1]
             inj.future_idx = ptr(keep[-1])
         if draws is not None:
-            for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor", "future_uniform"):
+            for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor", "future_uniform", "z_uniform"):
                 if name in draws and draws[name] is not None:
                     t = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
                     keep.append(t)
@@ -734,6 +738,9 @@ class FBHipAgent:
         for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor"):
             keep[name] = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
             setattr(inj, name, ptr(keep[name]))
+        if not self.cfg.norm_z:                                        # sample_z's uniform factor (fb_ddpg.py:230)
+            keep["z_uniform"] = torch.as_tensor(np.asarray(draws["z_uniform"], dtype=np.float32), device=dev).contiguous()
+            inj.z_uniform = ptr(keep["z_uniform"])
         if self.cfg.future_ratio > 0:                                  # hindsight replay draws (fb_ddpg.py:487-491)
             keep["future_idx"] = torch.as_tensor(np.asarray(draws["future_idx"]), dtype=torch.int32, device=dev).contiguous()
             keep["future_uniform"] = torch.as_tensor(np.asarray(draws["future_uniform"], dtype=np.float32), device=dev).contiguous()

@@ -188,6 +188,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.so.eps_next = c.f((size_t)B * a);
     w.so.eps_actor = c.f((size_t)B * a);
     w.so.future_idx = (int32_t*)c.take((size_t)B * 4);
+    w.so.z_uniform = c.f((size_t)B * z);
     w.so.future_uniform = c.f(B);
     // input panels: widths padded to 32 (pad columns stay zero: the workspace is zero-initialised by the host and
     // no kernel writes them)
@@ -577,7 +578,8 @@ void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->r2.p, Lb, 1, W.W3, Lb, 1, Sp->y.p, Lz, rows, z, Lb, W.b3, EPI_BIAS));
-        if (with_projection) o.l2n.push_back(L2Problem{Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z)});
+        // cfg.norm_z == False: the map's output IS y (fb_modules.py:228-229); callers read ``bm_of(set)``
+        if (with_projection && d.norm_z) o.l2n.push_back(L2Problem{Sp->y.p, Lz, Sp->Bm.p, Lz, Sp->norms, rows, z, sqrtf((float)z)});
     });
 }
 
@@ -597,15 +599,17 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
     const int Ng = padded_x ? pad32(g) : g;
     Ws* w = &c->w;
     BSet* Sp = &S;
+    const float* dy = d.norm_z ? w->dy.p : w->dBm.p;    // no projection: the gradient wrt y is dB itself
     out.push_back([=](Ops& o) {                 // dy = d/dy of sqrt(d) normalize(y)   (F.normalize backward)
+        if (!c->d.norm_z) return;
         o.post.push_back([=](hipStream_t s) -> int {
             HIPCK(c, launch_l2norm_bwd(w->dBm.p, Lz, Sp->y.p, Lz, Sp->norms, w->dy.p, Lz, rows, z, s));
             return (int)FBHIP_OK;
         });
     });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->dy.p, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
-        o.gemms.push_back(P(w->dy.p, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb));
+        o.gemms.push_back(P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
+        o.gemms.push_back(P(dy, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb));
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->b_dr2.p, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Lb, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2));
@@ -703,13 +707,14 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         if (hindsight && !(hp.future < 1.f)) { c->err = g_err = "fbhip: future_ratio > 0 needs a replay buffer with future < 1"; return FBHIP_E_INVALID; }
         const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
                                   inj->z_gauss && inj->eps_next && inj->eps_actor &&
-                                  (!hindsight || (inj->future_idx && inj->future_uniform));
-        if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, hindsight ? hp.future : -1.f, s));
+                                  (!hindsight || (inj->future_idx && inj->future_uniform)) && (d.norm_z || inj->z_uniform);
+        if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, hindsight ? hp.future : -1.f, d.norm_z, s));
         if (inj != nullptr) {
 #define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
             INJ(ep_idx, B * 4); INJ(step_idx, B * 4); INJ(perm, B * 4); INJ(mix_uniform, B * 4);
             INJ(z_gauss, (size_t)B * z * 4); INJ(eps_next, (size_t)B * a * 4); INJ(eps_actor, (size_t)B * a * 4);
             if (hindsight) { INJ(future_idx, B * 4); INJ(future_uniform, B * 4); }
+            if (!d.norm_z) INJ(z_uniform, (size_t)B * z * 4);
 #undef INJ
         }
         GatherArgs ga{};
@@ -745,7 +750,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         }
         HIPCK(c, launch_mix_z(w.so.z_gauss, z, w.bsM.y.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, hindsight ? w.bsF.y.p : nullptr, w.so.future_uniform,
-                              hp.future_ratio, s));
+                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, s));
     }
 
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
@@ -780,18 +785,20 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             RC(run_rounds(c, ch, s));
         }
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
-        HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, w.bsO.Bm.p, w.fsT.F1.p, w.fsT.F2.p, w.bsA.Bm.p, w.disc, B, z,
+        const float* BmO = d.norm_z ? w.bsO.Bm.p : w.bsO.y.p;      // online / target B(next_goal) as the loss sees them
+        const float* BmT = d.norm_z ? w.bsA.Bm.p : w.bsA.y.p;
+        HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, BmO, w.fsT.F1.p, w.fsT.F2.p, BmT, w.disc, B, z,
                                     Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
         if (hp.want_metrics || hp.q_loss)       // B^T B: metrics (fb_ddpg.py:371) and the q_loss covariance (:334)
-            RC(run_gemms(c, {P(w.bsO.Bm.p, Lz, 0, w.bsO.Bm.p, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
+            RC(run_gemms(c, {P(BmO, Lz, 0, BmO, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
         if (hp.q_loss) {                        // fb_ddpg.py:330-340
             HIPCK(c, launch_inverse(w.cov.p, w.cov.ld, z, 1.0f / (float)B, w.inv_cov.p, w.inv_cov.ld, s));
-            RC(run_gemms(c, {P(w.bsO.Bm.p, Lz, 1, w.inv_cov.p, w.inv_cov.ld, 0, w.BinvC.p, Lz, B, z, z)}, s));
+            RC(run_gemms(c, {P(BmO, Lz, 1, w.inv_cov.p, w.inv_cov.ld, 0, w.BinvC.p, Lz, B, z, z)}, s));
             HIPCK(c, launch_qloss(w.fsO.F1.p, w.fsO.F2.p, w.fsT.F1.p, w.fsT.F2.p, w.BinvC.p, w.z.p, Lz, w.disc,
                                   hp.q_loss_coef, w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, s));
         }
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
-            HIPCK(c, launch_extra_metrics(w.fsO.F1.p, w.bsO.Bm.p, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
+            HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
         }
         {
             // --- backward (fb_ddpg.py:383): forward_net, backward_net and (early) the actor's own forward pass
@@ -1072,9 +1079,9 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, z = d.z_dim;
     std::map<std::string, Buf> m = {
         {"Xoa", w.Xoa}, {"Xoz", w.Xoz}, {"Xnoz", w.Xnoz}, {"Xnoa", w.Xnoa}, {"Xopi", w.Xopi}, {"next_goal", w.next_goal},
-        {"backward_input", w.bin}, {"future_goal", w.fgoal}, {"z", w.z}, {"zrand", w.zrand}, {"F1", w.fsO.F1}, {"F2", w.fsO.F2}, {"Bm", w.bsO.Bm},
-        {"y", w.bsO.y}, {"tF1", w.fsT.F1}, {"tF2", w.fsT.F2}, {"tB", w.bsA.Bm}, {"dF1", w.dF1}, {"dF2", w.dF2},
-        {"dBm", w.dBm}, {"dy", w.dy}, {"mu", w.as.mu}, {"d_premu", w.a_dpremu}};
+        {"backward_input", w.bin}, {"future_goal", w.fgoal}, {"z", w.z}, {"zrand", w.zrand}, {"F1", w.fsO.F1}, {"F2", w.fsO.F2}, {"Bm", d.norm_z ? w.bsO.Bm : w.bsO.y},
+        {"y", w.bsO.y}, {"tF1", w.fsT.F1}, {"tF2", w.fsT.F2}, {"tB", d.norm_z ? w.bsA.Bm : w.bsA.y}, {"dF1", w.dF1}, {"dF2", w.dF2},
+        {"dBm", w.dBm}, {"dy", d.norm_z ? w.dy : w.dBm}, {"mu", w.as.mu}, {"d_premu", w.a_dpremu}};
     Buf b;
     const std::string n(name);
     if (m.count(n)) b = m[n];
@@ -1164,7 +1171,7 @@ int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
     GemvGroup g3{}; g3.n = 1;
     g3.p[0] = GV(r2, K.W3, Lb, K.b3, y, z, Lb, false);
     HIPCK(c, launch_gemv_group(g3, s));
-    HIPCK(c, launch_zcorrel(y, w.act_in + act_z_off(d), z, w.act_out, s));
+    HIPCK(c, launch_zcorrel(y, w.act_in + act_z_off(d), z, d.norm_z, w.act_out, s));
     HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(float), hipMemcpyDeviceToHost, s));
     return FBHIP_OK;
 }
@@ -1253,7 +1260,8 @@ int fbhip_backward_map(fbhip_ctx* c, int32_t which, const float* goal, int32_t l
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
         const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
         RC(backward_map_fwd(c, which ? c->K_t : c->K_p, goal + (size_t)r0 * ld_goal, ld_goal, w.bsA, n, s));
-        HIPCK(c, launch_concat2(out + (size_t)r0 * ld_out, ld_out, w.bsA.Bm.p, w.bsA.Bm.ld, d.z_dim, nullptr, 0, 0, n, s));
+        const Buf& bo = d.norm_z ? w.bsA.Bm : w.bsA.y;
+        HIPCK(c, launch_concat2(out + (size_t)r0 * ld_out, ld_out, bo.p, bo.ld, d.z_dim, nullptr, 0, 0, n, s));
     }
     return FBHIP_OK;
 }

@@ -131,7 +131,7 @@ hipError_t launch_gemv_group(GemvGroup g, hipStream_t s);
 hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
                            int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
                            hipStream_t s);
-hipError_t launch_zcorrel(const float* y, const float* z, int d, float* out, hipStream_t s);
+hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s);
 
 // ---- sampler -----------------------------------------------------------------------------------------------
 struct ReplayView {
@@ -143,10 +143,11 @@ struct SampleOut {          // all device pointers into the workspace
     int32_t* ep_idx; int32_t* step_idx; int32_t* perm; float* mix_uniform;
     float* z_gauss; float* eps_next; float* eps_actor;
     int32_t* future_idx; float* future_uniform;       // hindsight replay (only drawn when future_ratio > 0)
+    float* z_uniform;                                 // [B,d] uniform factor of sample_z (only drawn when norm_z == 0)
 };
 // future < 0: no hindsight draws; else future_idx = clip(step_idx + Geometric(1 - future), 0, len) and a uniform
 hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a,
-                       uint64_t seed, uint32_t rank, const StepState* st, float future,
+                       uint64_t seed, uint32_t rank, const StepState* st, float future, int norm_z,
                        hipStream_t s);
 struct GatherArgs {
     ReplayView rv;
@@ -170,7 +171,8 @@ hipError_t launch_gather(const GatherArgs& ga, hipStream_t s);
 // hindsight rows (future_uniform[i] < future_ratio) take sqrt(d) normalize(yfut[i]) instead (fb_ddpg.py:487-491)
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
-                        StepState* st, const float* yfut, const float* future_uniform, float future_ratio, hipStream_t s);
+                        StepState* st, const float* yfut, const float* future_uniform, float future_ratio,
+                        const float* z_uniform /* nullable: norm_z */, hipStream_t s);
 hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, const float* B, int ldb, int nb,
                           int rows, hipStream_t s);
 hipError_t pairwise_prepare(int B, int d);     // one-time kernel attribute setup (outside graph capture)

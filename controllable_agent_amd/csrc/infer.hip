@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) act_head_kernel(const float* __restrict__
 // compute_z_correl's tail (fb_ddpg.py:286-289): b = sqrt(d) y / max(|y|_2, 1e-12) (BackwardMap's own projection), then
 // BOTH vectors divided by their L1 norm (the reference's ``F.normalize(z, 1)``: the positional 1 is p) and dotted.
 __global__ void __launch_bounds__(64) zcorrel_kernel(const float* __restrict__ y, const float* __restrict__ z, int d,
-                                                     float* __restrict__ out) {
+                                                     int project, float* __restrict__ out) {
     const int lane = threadIdx.x;
     float yv[4], zv[4], s2 = 0.f;
 #pragma unroll
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64) zcorrel_kernel(const float* __restrict__ y
         zv[i] = j < d ? z[j] : 0.f;
         s2 += yv[i] * yv[i];
     }
-    const float scale = sqrtf((float)d) / fmaxf(sqrtf(wsum(s2)), 1e-12f);
+    const float scale = project ? sqrtf((float)d) / fmaxf(sqrtf(wsum(s2)), 1e-12f) : 1.0f;   // norm_z == 0: B is unprojected
     float l1b = 0.f, l1z = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -190,9 +190,9 @@ hipError_t launch_act_head(const float* x, const float* W, int ldw, const float*
     return hipGetLastError();
 }
 
-hipError_t launch_zcorrel(const float* y, const float* z, int d, float* out, hipStream_t s) {
+hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s) {
     if (d > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(zcorrel_kernel, dim3(1), dim3(64), 0, s, y, z, d, out);
+    hipLaunchKernelGGL(zcorrel_kernel, dim3(1), dim3(64), 0, s, y, z, d, project, out);
     return hipGetLastError();
 }
 

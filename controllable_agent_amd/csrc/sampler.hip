@@ -17,7 +17,7 @@ namespace {
 
 
 __global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, int B, int d, int a, unsigned k0,
-                                                   unsigned k1, const StepState* __restrict__ st, float future) {
+                                                   unsigned k1, const StepState* __restrict__ st, float future, int norm_z) {
     const unsigned cnt = st->update_count;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < B) {
@@ -92,6 +92,12 @@ __global__ void __launch_bounds__(256) draw_kernel(ReplayView rv, SampleOut so, 
         box_muller(r.z, r.w, n[2], n[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (4 * q4 + j < nz) so.z_gauss[4 * q4 + j] = n[j];
+        if (!norm_z) {                          // torch.rand of sample_z's norm_z == False branch (fb_ddpg.py:230)
+            const U4 u = philox4x32_10((unsigned)q4, STREAM_ZU, cnt, 0u, k0, k1);
+            const float uu[4] = {u01(u.x), u01(u.y), u01(u.z), u01(u.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (4 * q4 + j < nz) so.z_uniform[4 * q4 + j] = uu[j];
+        }
     }
     for (int q4 = i; 4 * q4 < na; q4 += gridDim.x * 256) {
         const U4 r = philox4x32_10((unsigned)q4, STREAM_EPS_NEXT, cnt, 0u, k0, k1);
@@ -151,7 +157,8 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
                                                     float* __restrict__ z, int ldz, float* __restrict__ Xoz, int ld_oz,
                                                     float* __restrict__ Xnoz, int ld_noz, int o, int B, int d,
                                                     StepState* __restrict__ st, const float* __restrict__ yfut,
-                                                    const float* __restrict__ futu, float future_ratio) {
+                                                    const float* __restrict__ futu, float future_ratio,
+                                                    const float* __restrict__ zunif) {
     if (st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) st->update_count += 1u;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
@@ -168,22 +175,35 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
         v[k] = j < d ? src[j] : 0.f;
         s += v[k] * v[k];
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     const float sc = sqrtf((float)d);
-    const float den = fmaxf(sqrtf(s), 1e-12f);
-    float s2 = 0.f;
+    if (zunif == nullptr) {
+        // norm_z: gaussian and hindsight rows are projected once, mixed rows twice (BackwardMap's own + fb_ddpg.py:483-484)
 #pragma unroll
-    for (int k = 0; k < ME; ++k) {
-        v[k] = sc * (v[k] / den);                 // first (or, for gaussian rows, only) projection
-        s2 += v[k] * v[k];
-    }
-    if (mix) {                                    // second projection of the mixed rows (fb_ddpg.py:483-484)
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        const float den = fmaxf(sqrtf(s), 1e-12f);
+        float s2 = 0.f;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
-        const float den2 = fmaxf(sqrtf(s2), 1e-12f);
+        for (int k = 0; k < ME; ++k) {
+            v[k] = sc * (v[k] / den);
+            s2 += v[k] * v[k];
+        }
+        if (mix) {
 #pragma unroll
-        for (int k = 0; k < ME; ++k) v[k] = sc * (v[k] / den2);
+            for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+            const float den2 = fmaxf(sqrtf(s2), 1e-12f);
+#pragma unroll
+            for (int k = 0; k < ME; ++k) v[k] = sc * (v[k] / den2);
+        }
+    } else if (!fut && !mix) {
+        // norm_z == False: z = sqrt(d) * U * g/|g| (fb_ddpg.py:229-231); mixed / hindsight rows are the RAW BackwardMap output
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        const float den = fmaxf(sqrtf(s), 1e-12f);
+#pragma unroll
+        for (int k = 0; k < ME; ++k) {
+            const int j = lane + 64 * k;
+            v[k] = j < d ? sc * zunif[(size_t)i * d + j] * (v[k] / den) : 0.f;
+        }
     }
 #pragma unroll
     for (int k = 0; k < ME; ++k) {
@@ -199,12 +219,12 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
 }  // namespace
 
 hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a, uint64_t seed, uint32_t rank,
-                       const StepState* st, float future, hipStream_t s) {
+                       const StepState* st, float future, int norm_z, hipStream_t s) {
     if (B > 8192) return hipErrorInvalidValue;
     const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
     int blocks = (B * d / 4 + 255) / 256;
     if (blocks < (B + 31) / 32) blocks = (B + 31) / 32;
-    hipLaunchKernelGGL(draw_kernel, dim3(blocks), dim3(256), (size_t)((B + 63) & ~63) * 4, s, rv, so, B, d, a, k0, k1, st, future);
+    hipLaunchKernelGGL(draw_kernel, dim3(blocks), dim3(256), (size_t)((B + 63) & ~63) * 4, s, rv, so, B, d, a, k0, k1, st, future, norm_z);
     return hipGetLastError();
 }
 
@@ -215,11 +235,12 @@ hipError_t launch_gather(const GatherArgs& ga, hipStream_t s) {
 
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
-                        StepState* st, const float* yfut, const float* future_uniform, float future_ratio, hipStream_t s) {
+                        StepState* st, const float* yfut, const float* future_uniform, float future_ratio,
+                        const float* z_uniform, hipStream_t s) {
     if (d > 256) return hipErrorInvalidValue;
     if (future_ratio > 0.f && (!yfut || !future_uniform)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mix_z_kernel, dim3((B + 3) / 4), dim3(256), 0, s, gauss, ldg, ymix, ldy, mix_uniform, mix_ratio, z,
-                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st, yfut, future_uniform, future_ratio);
+                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st, yfut, future_uniform, future_ratio, z_uniform);
     return hipGetLastError();
 }
 

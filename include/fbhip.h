@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 2
+#define FBHIP_ABI_VERSION 3
 
 enum {
     FBHIP_OK = 0,
@@ -71,6 +71,8 @@ typedef struct fbhip_dims {
     int32_t feature_dim;           /* Fd  (512)                                         */
     int32_t backward_hidden_dim;   /* Hb  (526)                                         */
     int32_t use_goal;              /* goal_space is not None: B-net input = goal        */
+    int32_t norm_z;                /* cfg.norm_z (default 1).  0: BackwardMap output unprojected (fb_modules.py:228-229),
+                                    * z = sqrt(d) U g/|g| (fb_ddpg.py:229-231), no re-projection of mixed rows (:483) */
 } fbhip_dims;
 
 typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82 */
@@ -103,6 +105,7 @@ typedef struct fbhip_inject {
     const float* eps_actor;        /* [B,a] contiguous; utils.py:178 via fb_ddpg.py:397 */
     const int32_t* future_idx;     /* [B]   in_memory_replay_buffer.py:159-160 (1-based, clipped); used if future_ratio > 0 */
     const float* future_uniform;   /* [B]   fb_ddpg.py:490; used if future_ratio > 0 */
+    const float* z_uniform;        /* [B,d] contiguous; torch.rand of fb_ddpg.py:230; used if norm_z == 0 */
 } fbhip_inject;
 
 /* one named tensor inside a flat parameter buffer (names = the reference's state_dict keys) */

@@ -53,6 +53,7 @@ class OracleConfig:
     discount: float = 0.99        # ReplayBuffer._discount (in_memory_replay_buffer.py:171)
     future_ratio: float = 0.0     # hindsight replay: z[u < future_ratio] = B(future_goal)  (fb_ddpg.py:487-491)
     future: float = 1.0           # ReplayBuffer._future; < 1 => future_idx = step + Geometric(1 - future) (:157-161)
+    norm_z: bool = True           # False: B unprojected, z = sqrt(d) U g/|g| (fb_ddpg.py:227-231, fb_modules.py:228-229)
 
 
 @dataclasses.dataclass
@@ -67,6 +68,7 @@ class Draws:
     eps_actor: np.ndarray     # f32 [B,a]   utils.py:178 inside update_actor (fb_ddpg.py:397)
     future_idx: tp.Optional[np.ndarray] = None      # int64 [B]  in_memory_replay_buffer.py:157-161 (only if future < 1)
     future_uniform: tp.Optional[np.ndarray] = None  # f64 [B]    fb_ddpg.py:490 (only if future_ratio > 0)
+    z_uniform: tp.Optional[np.ndarray] = None       # f32 [B,d]  fb_ddpg.py:230 (torch.rand, only if not norm_z)
 
 
 def make_draws(rng: np.random.Generator, cfg: OracleConfig, n_episodes: int,
@@ -98,6 +100,8 @@ def _with_future(cfg: OracleConfig, rng: np.random.Generator, fut_idx, d: Draws)
     d.future_idx = fut_idx
     if cfg.future_ratio > 0:
         d.future_uniform = rng.uniform(size=cfg.batch_size)
+    if not cfg.norm_z:
+        d.z_uniform = rng.uniform(size=(cfg.batch_size, cfg.z_dim)).astype(np.float32)
     return d
 
 
@@ -188,9 +192,10 @@ def backward_map_raw(p: Params, goal) -> torch.Tensor:
     return F.linear(h, p["B.5.weight"], p["B.5.bias"])
 
 
-def backward_map(p: Params, goal, z_dim: int) -> torch.Tensor:
-    """BackwardMap.forward with norm_z=True (fb_modules.py:223-230)."""
-    return math.sqrt(z_dim) * F.normalize(backward_map_raw(p, goal), dim=1)
+def backward_map(p: Params, goal, z_dim: int, norm_z: bool = True) -> torch.Tensor:
+    """BackwardMap.forward (fb_modules.py:223-230)."""
+    y = backward_map_raw(p, goal)
+    return math.sqrt(z_dim) * F.normalize(y, dim=1) if norm_z else y
 
 
 def actor_mu(p: Params, obs, z) -> torch.Tensor:
@@ -218,9 +223,10 @@ def normal_log_prob(mu, std: float, x) -> torch.Tensor:
     return -((x - mu) ** 2) / (2 * var) - math.log(std) - math.log(math.sqrt(2 * math.pi))
 
 
-def sample_z_from_gauss(gauss: torch.Tensor, z_dim: int) -> torch.Tensor:
-    """FBDDPGAgent.sample_z with norm_z=True (fb_ddpg.py:224-228)."""
-    return math.sqrt(z_dim) * F.normalize(gauss, dim=1)
+def sample_z_from_gauss(gauss: torch.Tensor, z_dim: int, uniform: tp.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FBDDPGAgent.sample_z (fb_ddpg.py:224-232): ``uniform`` is the torch.rand draw of the norm_z=False branch."""
+    g = F.normalize(gauss, dim=1)
+    return math.sqrt(z_dim) * g if uniform is None else np.sqrt(z_dim) * uniform * g
 
 
 # --------------------------------------------------------------------------- #
@@ -364,15 +370,16 @@ class OracleAgent:
         if cfg.mix_ratio > 0:
             mix_idxs = np.where(draws.mix_uniform < cfg.mix_ratio)[0]
             with torch.no_grad():
-                mz = backward_map(self.backward_net, bi[mix_idxs], cfg.z_dim)
-            mz = math.sqrt(cfg.z_dim) * F.normalize(mz, dim=1)
+                mz = backward_map(self.backward_net, bi[mix_idxs], cfg.z_dim, cfg.norm_z)
+            if cfg.norm_z:                                         # fb_ddpg.py:483-484
+                mz = math.sqrt(cfg.z_dim) * F.normalize(mz, dim=1)
             z = z.clone()
             z[mix_idxs] = mz
         if cfg.future_ratio > 0:                                   # fb_ddpg.py:487-491 (after, hence over, the mix)
             assert future_goal is not None and draws.future_uniform is not None
             future_idxs = np.where(draws.future_uniform < cfg.future_ratio)[0]
             with torch.no_grad():
-                fz = backward_map(self.backward_net, future_goal[future_idxs], cfg.z_dim)
+                fz = backward_map(self.backward_net, future_goal[future_idxs], cfg.z_dim, cfg.norm_z)
             z = z.clone()
             z[future_idxs] = fz
         return z
@@ -391,7 +398,7 @@ class OracleAgent:
         future_goal = None
         if cfg.future_ratio > 0:                                   # fb_ddpg.py:461-465
             future_goal = t(batch["future_goal"] if cfg.use_goal else batch["future_obs"])
-        z = sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim)       # fb_ddpg.py:451
+        z = sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim, None if cfg.norm_z else t(draws.z_uniform))   # fb_ddpg.py:451
         z = self.mix_z(z, backward_input, draws, future_goal)
         metrics: tp.Dict[str, float] = {}
 
@@ -400,11 +407,11 @@ class OracleAgent:
             mu_n = actor_mu(self.actor, next_obs, z)
             next_action = truncated_normal_sample(mu_n, cfg.stddev, cfg.stddev_clip, t(draws.eps_next))
             tF1, tF2 = forward_map(self.forward_target_net, next_obs, z, next_action)
-            tB = backward_map(self.backward_target_net, next_goal, cfg.z_dim)
+            tB = backward_map(self.backward_target_net, next_goal, cfg.z_dim, cfg.norm_z)
         fp, bp = self._req(self.forward_net), self._req(self.backward_net)
         F1, F2 = forward_map(fp, obs, z, action)
         y = backward_map_raw(bp, next_goal)
-        Bm = math.sqrt(cfg.z_dim) * F.normalize(y, dim=1)
+        Bm = math.sqrt(cfg.z_dim) * F.normalize(y, dim=1) if cfg.norm_z else y * 1.0
         if keep:
             for x in (F1, F2, Bm, y):
                 x.retain_grad()
@@ -490,7 +497,8 @@ class OracleAgent:
         fg = None
         if cfg.future_ratio > 0:
             fg = t(batch["future_goal"] if cfg.use_goal else batch["future_obs"])
-        self._dp["z"] = self.mix_z(sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim), bi, draws, fg)
+        self._dp["z"] = self.mix_z(sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim, None if cfg.norm_z else t(draws.z_uniform)),
+                                   bi, draws, fg)
 
     def dp_fb_grads(self) -> tp.Tuple[Params, Params]:
         """gradients of update_fb's loss wrt (forward_net, backward_net)  (fb_ddpg.py:303-383)"""
@@ -500,10 +508,10 @@ class OracleAgent:
             mu_n = actor_mu(self.actor, d["next_obs"], d["z"])
             na = truncated_normal_sample(mu_n, cfg.stddev, cfg.stddev_clip, t(d["draws"].eps_next))
             tF1, tF2 = forward_map(self.forward_target_net, d["next_obs"], d["z"], na)
-            tB = backward_map(self.backward_target_net, d["next_goal"], cfg.z_dim)
+            tB = backward_map(self.backward_target_net, d["next_goal"], cfg.z_dim, cfg.norm_z)
         fp, bp = self._req(self.forward_net), self._req(self.backward_net)
         F1, F2 = forward_map(fp, d["obs"], d["z"], d["action"])
-        Bm = backward_map(bp, d["next_goal"], cfg.z_dim)
+        Bm = backward_map(bp, d["next_goal"], cfg.z_dim, cfg.norm_z)
         fb_loss_terms(F1, F2, Bm, tF1, tF2, tB, d["discount"], cfg.ortho_coef)["fb_loss"].backward()
         return {k: v.grad for k, v in fp.items()}, {k: v.grad for k, v in bp.items()}
 
@@ -540,9 +548,10 @@ class OracleAgent:
     def infer_z(self, goal_obs: torch.Tensor, reward: torch.Tensor) -> np.ndarray:
         """infer_meta_from_obs_and_rewards (fb_ddpg.py:201-222)."""
         with torch.no_grad():
-            Bm = backward_map(self.backward_net, goal_obs, self.cfg.z_dim)
+            Bm = backward_map(self.backward_net, goal_obs, self.cfg.z_dim, self.cfg.norm_z)
         z = torch.matmul(reward.T, Bm) / reward.shape[0]
-        z = math.sqrt(self.cfg.z_dim) * F.normalize(z, dim=1)
+        if self.cfg.norm_z:                                        # fb_ddpg.py:217-218
+            z = math.sqrt(self.cfg.z_dim) * F.normalize(z, dim=1)
         return z.squeeze().numpy()
 
     def state_tensors(self) -> tp.Dict[str, np.ndarray]:

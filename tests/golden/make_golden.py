@@ -94,7 +94,7 @@ def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
         hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
         z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
         ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
-        future_ratio=cfg.future_ratio, update_every_steps=1, **extra)
+        future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, update_every_steps=1, **extra)
 
 
 def load_nets(agent, nets):
@@ -129,7 +129,7 @@ def inject(R, d: fo.Draws, variable_len: bool):
     """Route every random draw of one ``update()`` to the prepared values."""
     calls = {"randint": 0, "uniform": 0}
     o_randint, o_choice, o_uniform, o_geo = np.random.randint, np.random.choice, np.random.uniform, np.random.geometric
-    o_randperm, o_randn, o_sn = torch.randperm, torch.randn, R.utils._standard_normal
+    o_randperm, o_randn, o_sn, o_rand = torch.randperm, torch.randn, R.utils._standard_normal, torch.rand
     eps_queue = [d.eps_next, d.eps_actor]
 
     def randint(low, high=None, size=None, **kw):
@@ -155,16 +155,21 @@ def inject(R, d: fo.Draws, variable_len: bool):
     def randn(*a, **kw):
         return torch.from_numpy(d.z_gauss.copy())
 
+    def rand(*a, **kw):                         # sample_z's uniform factor when norm_z is False (fb_ddpg.py:230)
+        return torch.from_numpy(d.z_uniform.copy())
+
     def standard_normal(shape, dtype, device):
         return torch.from_numpy(eps_queue.pop(0).copy())
 
     np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = randint, choice, uniform, geometric
     torch.randperm, torch.randn, R.utils._standard_normal = randperm, randn, standard_normal
+    if d.z_uniform is not None:
+        torch.rand = rand
     try:
         yield
     finally:
         np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = o_randint, o_choice, o_uniform, o_geo
-        torch.randperm, torch.randn, R.utils._standard_normal = o_randperm, o_randn, o_sn
+        torch.randperm, torch.randn, R.utils._standard_normal, torch.rand = o_randperm, o_randn, o_sn, o_rand
     assert not eps_queue, "update() did not consume both action-noise draws"
 
 
@@ -238,6 +243,11 @@ def future_fixtures(R):
     trace_fixture(R, "tiny_future_trace", tiny_cfg(future=0.8, future_ratio=0.4), seed=103, n_eps=6, T=12, n_steps=4)
     trace_fixture(R, "tiny_future_goal_trace", tiny_cfg(goal_dim=3, use_goal=True, future=0.7, future_ratio=0.5, mix_ratio=0.3),
                   seed=104, n_eps=7, T=11, n_steps=3, goal_space="simplified_walker", variable_len=True)
+
+
+def nonorm_fixture(R):
+    """norm_z=False: BackwardMap unprojected, z = sqrt(d) U g/|g| (fb_ddpg.py:227-231, :483; fb_modules.py:228-229)"""
+    trace_fixture(R, "tiny_nonorm_trace", tiny_cfg(norm_z=False, future=0.8, future_ratio=0.3), seed=105, n_eps=6, T=12, n_steps=4)
 
 
 def sampler_fixture(R):
@@ -375,6 +385,7 @@ def main():
                                                  backward_hidden_dim=22, batch_size=24),
                   seed=102, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)
     future_fixtures(R)
+    nonorm_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -35,7 +35,8 @@ def _param_close(got, ref, lr, name):
 
 
 @pytest.mark.parametrize("name,goal_space", [("tiny_trace", None), ("tiny_goal_trace", "simplified_walker"),
-                                             ("tiny_future_trace", None), ("tiny_future_goal_trace", "simplified_walker")])
+                                             ("tiny_future_trace", None), ("tiny_future_goal_trace", "simplified_walker"),
+                                             ("tiny_nonorm_trace", None)])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
@@ -410,3 +411,36 @@ def test_hindsight_replay_on_device_draws_and_external_batches():
     m = a2.update_from_batch(eb, 0, H.draws_dict(d))
     for k in H.LOSS_KEYS:
         assert m[k] == pytest.approx(om[k], rel=2e-5, abs=2e-6), k
+
+
+def test_norm_z_false_device_draws_and_inference():
+    """cfg.norm_z = False without injected draws: sampled z = sqrt(d) U g/|g| with U ~ U(0,1) per element
+    (fb_ddpg.py:229-231), mixed rows are the RAW BackwardMap output, backward_net(x) / get_goal_meta / compute_z_correl
+    skip the projection (fb_modules.py:228-229, fb_ddpg.py:181,217)."""
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=512, norm_z=False, mix_ratio=0.3)
+    rng = np.random.default_rng(13)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 12, 40, cfg.obs_dim, cfg.action_dim)
+    agent = H.make_hip_agent(cfg, nets)
+    x = rng.standard_normal((7, cfg.obs_dim)).astype(np.float32)
+    raw = fo.backward_map_raw(nets["backward_net"], torch.from_numpy(x))
+    assert H.rel_err(agent.backward_net(torch.from_numpy(x).cuda()).cpu(), raw) < 2e-5
+    np.testing.assert_allclose(agent.get_goal_meta(x[0])["z"], raw[0].numpy(), rtol=2e-5, atol=2e-6)
+    zq = rng.standard_normal(cfg.z_dim).astype(np.float32)
+    want = float((torch.nn.functional.normalize(raw[:1], p=1.0, dim=1) *
+                  torch.nn.functional.normalize(torch.from_numpy(zq)[None], p=1.0, dim=1)).sum())
+    assert agent.compute_z_correl(types.SimpleNamespace(observation=x[0], goal=None), {"z": zq}) == pytest.approx(want, rel=2e-5, abs=1e-7)
+    zs = agent.sample_z(4000)
+    ratio = (zs.norm(dim=1) / np.sqrt(cfg.z_dim)).numpy()            # |U * g/|g|| < 1, not a constant
+    assert ratio.max() < 1.0 and ratio.std() > 0.05
+    rb = _buffer(storage, lengths, cfg.discount)
+    agent.update(rb, 0)
+    z = agent.workspace_view("z").cpu()
+    g = agent.workspace_view("z_gauss").cpu()
+    mixu = agent.workspace_view("mix_uniform").cpu()[0]
+    gauss_rows = mixu >= cfg.mix_ratio
+    u = z[gauss_rows] / (np.sqrt(cfg.z_dim) * torch.nn.functional.normalize(g[gauss_rows], dim=1))
+    assert 0.0 < float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.03
+    bi = agent.workspace_view("backward_input").cpu()
+    assert H.rel_err(z[~gauss_rows], fo.backward_map_raw(nets["backward_net"], bi[~gauss_rows])) < 2e-5
