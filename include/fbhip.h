@@ -141,7 +141,12 @@ size_t fbhip_workspace_bytes(const fbhip_dims* dims);
 int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out);
 int fbhip_destroy(fbhip_ctx* ctx);
 /* FB flat buffers hold forward_net ++ backward_net (fb_opt's two param groups, fb_ddpg.py:149-151);
- * fb_targets holds forward_target_net ++ backward_target_net in the same layout. */
+ * fb_targets holds forward_target_net ++ backward_target_net in the same layout.
+ * ZERO-INITIALISE before binding: (1) every flat buffer -- the physical layout pads matrices (fbhip_tensor_desc.ld >
+ * cols, extra zero rows of backward_net) and the kernels rely on pad weights / gradients / Adam moments being and
+ * staying zero; write parameters through the (offset, rows, cols, ld) views only; (2) the workspace -- it holds the
+ * zero pad columns of the input panels, the device step counters (Adam t, RNG counters: fbhip_set_step_counts) and
+ * the metrics.  The library never allocates, frees or clears these buffers itself. */
 int fbhip_bind_buffers(fbhip_ctx* ctx,
                        float* fb_params, float* fb_grads, float* fb_adam_m, float* fb_adam_v, float* fb_targets,
                        float* actor_params, float* actor_grads, float* actor_adam_m, float* actor_adam_v,
