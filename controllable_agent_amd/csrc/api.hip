@@ -488,8 +488,8 @@ void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda
         o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
     });
     out.push_back([=](Ops& o) {
-        o.lnf.push_back(LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0});
-        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0});
+        o.lnf.push_back(LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0, H});
+        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU));
@@ -546,9 +546,9 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
     out.push_back([=](Ops& o) {
         const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
         o.lnb.push_back(LnBwdProblem{w->dt1a.p, H, Sp->t1a.p, H, Sp->pre1a.p, H, Sp->statsA, W.oa.g1, w->dt1a.p, H, G.oa.g1,
-                                     G.oa.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0});
+                                     G.oa.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0, H});
         o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
-                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0});
+                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1));
@@ -571,7 +571,7 @@ void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx
         o.gemms.push_back(P(X, ldx, 1, W.W1, pad32(g), 1, Sp->pre1.p, Lb, rows, Lb, Kg, W.b1, EPI_BIAS));
     });
     out.push_back([=](Ops& o) {
-        o.lnf.push_back(LnFwdProblem{Sp->pre1.p, Lb, W.g1, W.be1, Sp->t1.p, Lb, Sp->stats, rows, Hb, 0, 0, 0});
+        o.lnf.push_back(LnFwdProblem{Sp->pre1.p, Lb, W.g1, W.be1, Sp->t1.p, Lb, Sp->stats, rows, Hb, 0, 0, 0, pad4(Hb)});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->t1.p, Lb, 1, W.W2, Lb, 1, Sp->r2.p, Lb, rows, Lb, Lb, W.b2, EPI_BIAS_RELU));
@@ -617,7 +617,7 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
     });
     out.push_back([=](Ops& o) {
         o.lnb.push_back(LnBwdProblem{w->b_dt1.p, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, w->b_dt1.p, Lb, G.g1,
-                                     G.be1, w->ln_partials_b, rows, Hb, 0, 0, 0, 0, 0});
+                                     G.be1, w->ln_partials_b, rows, Hb, 0, 0, 0, 0, 0, pad4(Hb)});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad32(g), Lb, Ng, rows, nullptr, EPI_NONE, nullptr, 0, G.b1));
@@ -635,8 +635,8 @@ void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, cons
         o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
     });
     out.push_back([=](Ops& o) {
-        o.lnf.push_back(LnFwdProblem{Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, 0, 0, 0});
-        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0});
+        o.lnf.push_back(LnFwdProblem{Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, 0, 0, 0, H});
+        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->t1o.p, H, 1, W.o.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU));
@@ -680,9 +680,9 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
     out.push_back([=](Ops& o) {
         const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
         o.lnb.push_back(LnBwdProblem{w->dt1a.p, H, Sp->t1o.p, H, Sp->pre1o.p, H, Sp->statsO, W.o.g1, w->dt1a.p, H, G.o.g1,
-                                     G.o.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0});
+                                     G.o.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0, H});
         o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
-                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0});
+                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1));
@@ -845,7 +845,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         ch.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.dh.p, 2 * Fd, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fd)); });
         ch.push_back([=, &w](Ops& o2) {
             o2.lnb.push_back(LnBwdProblem{w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
-                                          nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0});
+                                          nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0, H});
         });
         // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
         ch.push_back([=, &w](Ops& o2) {

@@ -62,14 +62,16 @@ hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy
                               float* dgamma, float* dbeta, float* partials, int rows, int n, hipStream_t s);
 constexpr int LN_BWD_ROWS_PER_BLOCK = 8;
 // grouped variants: the two trunks of a net (independent rows, different parameters) share one launch
+// np (optional, 0 = unknown): a multiple of 4 with n <= np <= every leading dimension and np readable elements in
+// gamma / beta -- lets the kernels use branch-free clamped float4 loads (all of a row's loads in flight at once)
 struct LnFwdProblem { const float* x; int ldx; const float* gamma; const float* beta; float* y; int ldy; float* stats;
-                      int rows, n, vx, vy, vp; };
+                      int rows, n, vx, vy, vp, np; };
 constexpr int LN_MAX_GROUP = 6;
 struct LnFwdGroup { LnFwdProblem p[LN_MAX_GROUP]; int n; };
 hipError_t launch_ln_tanh_fwd_group(LnFwdGroup g, hipStream_t s);
 struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* stats;
                       const float* gamma; float* dx; int lddx; float* dgamma; float* dbeta; float* partials;
-                      int rows, n, vdy, vy, vx, vdx, vp; };
+                      int rows, n, vdy, vy, vx, vdx, vp, np; };
 struct LnBwdGroup { LnBwdProblem p[LN_MAX_GROUP]; int n; };
 hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s);
 // out = scale * y / max(||y||, 1e-12) per row (F.normalize, fb_modules.py:229); grouped like the LayerNorm launches

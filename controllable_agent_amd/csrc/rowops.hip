@@ -47,25 +47,41 @@ __device__ __forceinline__ float4 mask4(float4 x, int n0, int n) {
     if (n0 + 3 >= n) x.w = 0.f;
     return x;
 }
+// branch-free variants for rows whose first ``np`` (multiple of 4) elements are readable: quads at or beyond np read a
+// clamped (valid) address and are zeroed by mask4 -- no control flow between the loads, so they all stay in flight
+__device__ __forceinline__ float4 ld4c(const float* __restrict__ row, int n0, int np) {
+    return *reinterpret_cast<const float4*>(row + (n0 < np ? n0 : np - 4));
+}
+
 static inline bool aligned16(const void* p, int ld) { return (((uintptr_t)p & 15) == 0) && ((ld & 3) == 0); }
 
 // ------------------------------------------------------------------------------------------------------
-template <int MAXQ>
+template <int MAXQ, bool FAST>
 __global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const LnFwdGroup g) {
     const LnFwdProblem& p = g.p[blockIdx.y];
     const float* __restrict__ x = p.x;
     float* __restrict__ y = p.y;
-    const int ldx = p.ldx, ldy = p.ldy, rows = p.rows, n = p.n, vx = p.vx, vy = p.vy, vp = p.vp;
+    const int ldx = p.ldx, ldy = p.ldy, rows = p.rows, n = p.n, vx = p.vx, vy = p.vy, vp = p.vp, np = p.np;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (size_t)row * ldx;
-    float4 v[MAXQ];
+    float4 v[MAXQ], gm[MAXQ], bt[MAXQ];
+    if constexpr (FAST) {
+        // every load of the row (and its gamma / beta) is issued before the first use
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int n0 = 4 * (lane + 64 * i);
+            v[i] = ld4c(xr, n0, np); gm[i] = ld4c(p.gamma, n0, np); bt[i] = ld4c(p.beta, n0, np);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) v[i] = mask4(v[i], 4 * (lane + 64 * i), n);
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) v[i] = ld4(xr, 4 * (lane + 64 * i), n, vx);
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXQ; ++i) {
-        v[i] = ld4(xr, 4 * (lane + 64 * i), n, vx);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
+    for (int i = 0; i < MAXQ; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(s) / (float)n;
     float q = 0.f;
 #pragma unroll
@@ -81,13 +97,18 @@ __global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const LnFwdGroup g) {
     for (int i = 0; i < MAXQ; ++i) {
         const int n0 = 4 * (lane + 64 * i);
         if (n0 < n) {
-            const float4 gm = ld4(p.gamma, n0, n, vp), b = ld4(p.beta, n0, n, vp);
+            if constexpr (!FAST) { gm[i] = ld4(p.gamma, n0, n, vp); bt[i] = ld4(p.beta, n0, n, vp); }
             float4 o;
-            o.x = tanhf((v[i].x - mean) * rstd * gm.x + b.x);
-            o.y = tanhf((v[i].y - mean) * rstd * gm.y + b.y);
-            o.z = tanhf((v[i].z - mean) * rstd * gm.z + b.z);
-            o.w = tanhf((v[i].w - mean) * rstd * gm.w + b.w);
-            st4(yr, n0, n, vy, o);
+            o.x = tanhf((v[i].x - mean) * rstd * gm[i].x + bt[i].x);
+            o.y = tanhf((v[i].y - mean) * rstd * gm[i].y + bt[i].y);
+            o.z = tanhf((v[i].z - mean) * rstd * gm[i].z + bt[i].z);
+            o.w = tanhf((v[i].w - mean) * rstd * gm[i].w + bt[i].w);
+            if constexpr (FAST) {
+                // the quad lies inside [0, np): elements in [n, np) are written as 0 (pad columns stay zero)
+                *reinterpret_cast<float4*>(yr + n0) = mask4(o, n0, n);
+            } else {
+                st4(yr, n0, n, vy, o);
+            }
         }
     }
     if (lane == 0) {
@@ -99,19 +120,23 @@ __global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const LnFwdGroup g) {
 hipError_t launch_ln_tanh_fwd_group(LnFwdGroup g, hipStream_t s) {
     if (g.n < 1) return hipSuccess;
     int maxrows = 0, maxn = 0;
+    bool fast = true;
     for (int i = 0; i < g.n; ++i) {
         LnFwdProblem& p = g.p[i];
         if (p.n > 2048) return hipErrorInvalidValue;
         p.vx = aligned16(p.x, p.ldx); p.vy = aligned16(p.y, p.ldy);
         p.vp = aligned16(p.gamma, 4) && aligned16(p.beta, 4);
+        fast = fast && p.vx && p.vy && p.vp && p.np >= p.n && (p.np & 3) == 0 && p.np >= 4 && p.np <= p.ldx && p.np <= p.ldy;
         maxrows = p.rows > maxrows ? p.rows : maxrows;
         maxn = p.n > maxn ? p.n : maxn;
     }
     if (maxrows <= 0) return hipSuccess;
     dim3 grid((maxrows + 3) / 4, g.n), block(256);
     const int q = (maxn + 255) / 256;
-#define LN_FWD(Q) hipLaunchKernelGGL((ln_tanh_fwd_kernel<Q>), grid, block, 0, s, g)
-    if (q <= 1) LN_FWD(1); else if (q <= 2) LN_FWD(2); else if (q <= 3) LN_FWD(3); else if (q <= 4) LN_FWD(4); else LN_FWD(8);
+#define LN_FWD(Q)                                                                              \
+    if (fast) hipLaunchKernelGGL((ln_tanh_fwd_kernel<Q, true>), grid, block, 0, s, g);         \
+    else hipLaunchKernelGGL((ln_tanh_fwd_kernel<Q, false>), grid, block, 0, s, g)
+    if (q <= 1) { LN_FWD(1); } else if (q <= 2) { LN_FWD(2); } else if (q <= 3) { LN_FWD(3); } else if (q <= 4) { LN_FWD(4); } else { LN_FWD(8); }
 #undef LN_FWD
     return hipGetLastError();
 }
@@ -120,7 +145,7 @@ hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const
                               float* stats, int rows, int n, hipStream_t s) {
     LnFwdGroup g{};
     g.n = 1;
-    g.p[0] = LnFwdProblem{x, ldx, gamma, beta, y, ldy, stats, rows, n, 0, 0, 0};
+    g.p[0] = LnFwdProblem{x, ldx, gamma, beta, y, ldy, stats, rows, n, 0, 0, 0, (n & 3) == 0 ? n : 0};
     return launch_ln_tanh_fwd_group(g, s);
 }
 
@@ -129,7 +154,7 @@ hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const
 // dx = rstd (g - mean(g) - xhat mean(g xhat));  dgamma = sum_rows du xhat;  dbeta = sum_rows du.
 // Each workgroup owns LN_BWD_ROWS_PER_BLOCK rows (2 per wave) and emits one partial row of (dgamma, dbeta);
 // a second tiny kernel folds the partial rows in a fixed order (deterministic, no atomics).
-template <int MAXQ>
+template <int MAXQ, bool FAST>
 __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const LnBwdGroup grp) {
     extern __shared__ float lds[];          // [4 waves][n] (used twice: dgamma then dbeta)
     const LnBwdProblem& p = grp.p[blockIdx.y];
@@ -142,44 +167,108 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const LnBwdGroup grp) 
 #pragma unroll
     for (int i = 0; i < MAXQ; ++i) pg[i] = pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float inv_n = 1.0f / (float)n;
-#pragma unroll 1
-    for (int rr = 0; rr < LN_BWD_ROWS_PER_BLOCK / 4; ++rr) {
-        const int row = blockIdx.x * LN_BWD_ROWS_PER_BLOCK + rr * 4 + wid;
-        if (row >= rows) break;
-        const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
-        const float* dyr = p.dy + (size_t)row * p.lddy;
-        const float* yr = p.y + (size_t)row * p.ldy;
-        const float* xr = p.x + (size_t)row * p.ldx;
-        float4 g[MAXQ], xh[MAXQ];
-        float s1 = 0.f, s2 = 0.f;
+    constexpr int RPW = LN_BWD_ROWS_PER_BLOCK / 4;          // rows per wave
+    if constexpr (FAST) {
+        // all loads of BOTH rows of this wave (3 streams + gamma) are issued before the first use; dx may alias dy
+        // (in place), so the compiler cannot hoist the second row's loads over the first row's stores by itself
+        const int np = p.np;
+        float4 d[RPW][MAXQ], yy[RPW][MAXQ], xx[RPW][MAXQ], gm[MAXQ];
+        float mean[RPW], rstd[RPW];
+        int rowi[RPW];
 #pragma unroll
-        for (int i = 0; i < MAXQ; ++i) {
-            const int n0 = 4 * (lane + 64 * i);
-            const float4 d = ld4(dyr, n0, n, p.vdy), yy = ld4(yr, n0, n, p.vy), xx = ld4(xr, n0, n, p.vx);
-            const float4 gm = ld4(gamma, n0, n, p.vp);
-            float4 du, h;
-            du.x = d.x * (1.f - yy.x * yy.x); du.y = d.y * (1.f - yy.y * yy.y);
-            du.z = d.z * (1.f - yy.z * yy.z); du.w = d.w * (1.f - yy.w * yy.w);
-            h = mask4(make_float4((xx.x - mean) * rstd, (xx.y - mean) * rstd, (xx.z - mean) * rstd,
-                                  (xx.w - mean) * rstd), n0, n);
-            xh[i] = h;
-            g[i] = make_float4(du.x * gm.x, du.y * gm.y, du.z * gm.z, du.w * gm.w);
-            s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
-            s2 += (g[i].x * h.x + g[i].y * h.y) + (g[i].z * h.z + g[i].w * h.w);
-            pg[i].x += du.x * h.x; pg[i].y += du.y * h.y; pg[i].z += du.z * h.z; pg[i].w += du.w * h.w;
-            pb[i].x += du.x; pb[i].y += du.y; pb[i].z += du.z; pb[i].w += du.w;
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = blockIdx.x * LN_BWD_ROWS_PER_BLOCK + rr * 4 + wid;
+            rowi[rr] = row;
+            const int rc = row < rows ? row : rows - 1;     // clamped: results of a row past the end are dropped
+            mean[rr] = p.stats[2 * rc]; rstd[rr] = p.stats[2 * rc + 1];
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                const int n0 = 4 * (lane + 64 * i);
+                d[rr][i] = ld4c(p.dy + (size_t)rc * p.lddy, n0, np);
+                yy[rr][i] = ld4c(p.y + (size_t)rc * p.ldy, n0, np);
+                xx[rr][i] = ld4c(p.x + (size_t)rc * p.ldx, n0, np);
+            }
         }
-        const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
-        float* dxr = p.dx + (size_t)row * p.lddx;
 #pragma unroll
-        for (int i = 0; i < MAXQ; ++i) {
-            const int n0 = 4 * (lane + 64 * i);
-            float4 o;
-            o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
-            o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
-            o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
-            o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
-            st4(dxr, n0, n, p.vdx, o);
+        for (int i = 0; i < MAXQ; ++i) gm[i] = ld4c(gamma, 4 * (lane + 64 * i), np);
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const bool live = rowi[rr] < rows;
+            float4 g[MAXQ], xh[MAXQ];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                const int n0 = 4 * (lane + 64 * i);
+                const float4 dd = mask4(d[rr][i], n0, live ? n : 0), y4 = yy[rr][i], x4 = xx[rr][i];
+                float4 du, h;
+                du.x = dd.x * (1.f - y4.x * y4.x); du.y = dd.y * (1.f - y4.y * y4.y);
+                du.z = dd.z * (1.f - y4.z * y4.z); du.w = dd.w * (1.f - y4.w * y4.w);
+                h = mask4(make_float4((x4.x - mean[rr]) * rstd[rr], (x4.y - mean[rr]) * rstd[rr], (x4.z - mean[rr]) * rstd[rr],
+                                      (x4.w - mean[rr]) * rstd[rr]), n0, n);
+                xh[i] = h;
+                g[i] = make_float4(du.x * gm[i].x, du.y * gm[i].y, du.z * gm[i].z, du.w * gm[i].w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * h.x + g[i].y * h.y) + (g[i].z * h.z + g[i].w * h.w);
+                pg[i].x += du.x * h.x; pg[i].y += du.y * h.y; pg[i].z += du.z * h.z; pg[i].w += du.w * h.w;
+                pb[i].x += du.x; pb[i].y += du.y; pb[i].z += du.z; pb[i].w += du.w;
+            }
+            const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+            if (live) {
+                float* dxr = p.dx + (size_t)rowi[rr] * p.lddx;
+#pragma unroll
+                for (int i = 0; i < MAXQ; ++i) {
+                    const int n0 = 4 * (lane + 64 * i);
+                    if (n0 < n) {
+                        float4 o;
+                        o.x = rstd[rr] * (g[i].x - m1 - xh[i].x * m2);
+                        o.y = rstd[rr] * (g[i].y - m1 - xh[i].y * m2);
+                        o.z = rstd[rr] * (g[i].z - m1 - xh[i].z * m2);
+                        o.w = rstd[rr] * (g[i].w - m1 - xh[i].w * m2);
+                        *reinterpret_cast<float4*>(dxr + n0) = mask4(o, n0, n);     // pad columns [n, np) stay zero
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = blockIdx.x * LN_BWD_ROWS_PER_BLOCK + rr * 4 + wid;
+            if (row >= rows) break;
+            const float mean = p.stats[2 * row], rstd = p.stats[2 * row + 1];
+            const float* dyr = p.dy + (size_t)row * p.lddy;
+            const float* yr = p.y + (size_t)row * p.ldy;
+            const float* xr = p.x + (size_t)row * p.ldx;
+            float4 g[MAXQ], xh[MAXQ];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                const int n0 = 4 * (lane + 64 * i);
+                const float4 d = ld4(dyr, n0, n, p.vdy), yy = ld4(yr, n0, n, p.vy), xx = ld4(xr, n0, n, p.vx);
+                const float4 gm = ld4(gamma, n0, n, p.vp);
+                float4 du, h;
+                du.x = d.x * (1.f - yy.x * yy.x); du.y = d.y * (1.f - yy.y * yy.y);
+                du.z = d.z * (1.f - yy.z * yy.z); du.w = d.w * (1.f - yy.w * yy.w);
+                h = mask4(make_float4((xx.x - mean) * rstd, (xx.y - mean) * rstd, (xx.z - mean) * rstd,
+                                      (xx.w - mean) * rstd), n0, n);
+                xh[i] = h;
+                g[i] = make_float4(du.x * gm.x, du.y * gm.y, du.z * gm.z, du.w * gm.w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * h.x + g[i].y * h.y) + (g[i].z * h.z + g[i].w * h.w);
+                pg[i].x += du.x * h.x; pg[i].y += du.y * h.y; pg[i].z += du.z * h.z; pg[i].w += du.w * h.w;
+                pb[i].x += du.x; pb[i].y += du.y; pb[i].z += du.z; pb[i].w += du.w;
+            }
+            const float m1 = wave_sum(s1) * inv_n, m2 = wave_sum(s2) * inv_n;
+            float* dxr = p.dx + (size_t)row * p.lddx;
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                const int n0 = 4 * (lane + 64 * i);
+                float4 o;
+                o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+                st4(dxr, n0, n, p.vdx, o);
+            }
         }
     }
     if (partials == nullptr) return;
@@ -228,7 +317,7 @@ __global__ void __launch_bounds__(256) ln_colreduce_kernel(const LnBwdGroup grp)
 hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s) {
     if (g.n < 1) return hipSuccess;
     int maxrows = 0, maxn = 0;
-    bool any_param = false;
+    bool any_param = false, fast = true;
     for (int i = 0; i < g.n; ++i) {
         LnBwdProblem& p = g.p[i];
         if (p.n > 2048) return hipErrorInvalidValue;
@@ -238,6 +327,8 @@ hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s) {
         any_param |= want;
         p.vdy = aligned16(p.dy, p.lddy); p.vy = aligned16(p.y, p.ldy); p.vx = aligned16(p.x, p.ldx);
         p.vdx = aligned16(p.dx, p.lddx); p.vp = aligned16(p.gamma, 4);
+        fast = fast && p.vdy && p.vy && p.vx && p.vdx && p.vp && p.np >= p.n && (p.np & 3) == 0 && p.np >= 4 &&
+               p.np <= p.lddy && p.np <= p.ldy && p.np <= p.ldx && p.np <= p.lddx && p.rows >= 1;
         maxrows = p.rows > maxrows ? p.rows : maxrows;
         maxn = p.n > maxn ? p.n : maxn;
     }
@@ -246,8 +337,12 @@ hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s) {
     dim3 grid(nb, g.n), block(256);
     const size_t shmem = (size_t)4 * maxn * sizeof(float);
     const int q = (maxn + 255) / 256;
-#define LN_BWD(Q) hipLaunchKernelGGL((ln_tanh_bwd_kernel<Q>), grid, block, shmem, s, g)
-    if (q <= 1) LN_BWD(1); else if (q <= 2) LN_BWD(2); else if (q <= 3) LN_BWD(3); else if (q <= 4) LN_BWD(4); else LN_BWD(8);
+    if (q > 4) fast = false;                       // the two-rows-in-flight variant is built for n <= 1024
+#define LN_BWD(Q)                                                                                  \
+    if (fast) hipLaunchKernelGGL((ln_tanh_bwd_kernel<Q, true>), grid, block, shmem, s, g);         \
+    else hipLaunchKernelGGL((ln_tanh_bwd_kernel<Q, false>), grid, block, shmem, s, g)
+    if (q <= 1) { LN_BWD(1); } else if (q <= 2) { LN_BWD(2); } else if (q <= 3) { LN_BWD(3); } else if (q <= 4) { LN_BWD(4); }
+    else hipLaunchKernelGGL((ln_tanh_bwd_kernel<8, false>), grid, block, shmem, s, g);
 #undef LN_BWD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !any_param) return e;
@@ -260,7 +355,8 @@ hipError_t launch_ln_tanh_bwd(const float* dy, int lddy, const float* y, int ldy
                               float* dbeta, float* partials, int rows, int n, hipStream_t s) {
     LnBwdGroup g{};
     g.n = 1;
-    g.p[0] = LnBwdProblem{dy, lddy, y, ldy, x, ldx, stats, gamma, dx, lddx, dgamma, dbeta, partials, rows, n, 0, 0, 0, 0, 0};
+    g.p[0] = LnBwdProblem{dy, lddy, y, ldy, x, ldx, stats, gamma, dx, lddx, dgamma, dbeta, partials, rows, n, 0, 0, 0, 0, 0,
+                          (n & 3) == 0 ? n : 0};
     return launch_ln_tanh_bwd_group(g, s);
 }
 
