@@ -355,16 +355,11 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     else if (tiles32 >= 1024) cfg = (nmax > mmax) ? CFG_1x2x2 : CFG_2x1x2;
     else cfg = CFG_1x1x4;
     const int bkt = gemm_cfg_bkt(cfg);
-    const int BMc = gemm_cfg_bm(cfg), BNc = gemm_cfg_bn(cfg);
     float* slab = splitk_slab(ctx);
-    // per-workgroup cost of a problem in K-chunk units; tiles that take the predicated loader (ragged M / N,
-    // unaligned views) cost ~3x per chunk
+    // per-workgroup cost of a problem in K-chunk units; unaligned operands take the predicated loader (~3x per chunk)
     auto cost_of = [&](const GemmProblem& p) {
         const bool vec = (((uintptr_t)p.A & 15) == 0 && (p.lda & 3) == 0) && (((uintptr_t)p.B & 15) == 0 && (p.ldb & 3) == 0);
-        const long tm = (p.M + BMc - 1) / BMc, tn = (p.N + BNc - 1) / BNc;
-        const long ragged = (p.M % BMc ? tn : 0) + (p.N % BNc ? tm : 0);
-        const bool slow = !vec || 2 * ragged >= tm * tn;
-        return (long)((p.K + bkt - 1) / bkt) * (slow ? 3 : 1);
+        return (long)((p.K + bkt - 1) / bkt) * (vec ? 1 : 3);
     };
     // longest workgroups first, so that the stragglers of a heterogeneous group start at t = 0 and hide under the
     // bulk (the hardware dispatches workgroups in launch order)

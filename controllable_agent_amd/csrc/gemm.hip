@@ -185,13 +185,15 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
 #pragma unroll
         for (int i = 0; i < QA; ++i) {
             const int q = tid + i * 256;
+            // rows past the matrix edge read a CLAMPED (valid) address: whatever lands in those LDS rows only reaches
+            // output rows / columns the epilogue drops, so ragged tiles of aligned operands keep the branch-free loader
             if (akc) {
                 const int r = q / (BKT / 4), kq = q % (BKT / 4);
-                ga[i] = (size_t)(row0 + r) * p.lda + kb + 4 * kq;
+                ga[i] = (size_t)min(row0 + r, M - 1) * p.lda + kb + 4 * kq;
                 sa[i] = (4 * kq) * LDA_S + r;
             } else {
                 const int k = q / (BM / 4), rq = q % (BM / 4);
-                ga[i] = (size_t)(kb + k) * p.lda + row0 + 4 * rq;
+                ga[i] = (size_t)(kb + k) * p.lda + min(row0 + 4 * rq, p.lda - 4);
                 sa[i] = k * LDA_S + 4 * rq;
             }
         }
@@ -200,20 +202,21 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
             const int q = tid + i * 256;
             if (bkc) {
                 const int r = q / (BKT / 4), kq = q % (BKT / 4);
-                gb[i] = (size_t)(col0 + r) * p.ldb + kb + 4 * kq;
+                gb[i] = (size_t)min(col0 + r, N - 1) * p.ldb + kb + 4 * kq;
                 sb[i] = (4 * kq) * LDB_S + r;
             } else {
                 const int k = q / (BN / 4), rq = q % (BN / 4);
-                gb[i] = (size_t)(kb + k) * p.ldb + col0 + 4 * rq;
+                gb[i] = (size_t)(kb + k) * p.ldb + min(col0 + 4 * rq, p.ldb - 4);
                 sb[i] = k * LDB_S + 4 * rq;
             }
         }
         const int step_a = akc ? LDA_S : 1, step_b = bkc ? LDB_S : 1;
         const size_t adv_a = akc ? (size_t)BKT : (size_t)BKT * p.lda;
         const size_t adv_b = bkc ? (size_t)BKT : (size_t)BKT * p.ldb;
-        // interior tiles of 16-byte-aligned operands take a branch-free loader for every full K chunk; edge tiles,
-        // unaligned views and the K tail go through the predicated loader (same register image)
-        const bool interior = (row0 + BM <= M) && (col0 + BN <= N) && p.a_vec && p.b_vec;
+        // 16-byte-aligned operands (lda, ldb multiples of 4, >= 4) take the branch-free loader for every full K chunk --
+        // edge tiles included (clamped rows above); unaligned views and the K tail go through the predicated loader
+        // (same register image)
+        const bool interior = p.a_vec && p.b_vec && p.lda >= 4 && p.ldb >= 4;
         const int nfast = interior ? (K - kb) / BKT : 0;
 
         auto load_fast = [&](int ch, float4 (&xa)[QA], float4 (&xb)[QB]) __attribute__((always_inline)) {
