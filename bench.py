@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--episodes", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steps-per-launch", type=int, default=8,
+                    help="consecutive updates handed to one hipGraph launch (FBHipAgent.update_many, as run_offline does "
+                         "between two log lines); 1 = one launch per update.  Ignored (1) when N > 1: the gradient "
+                         "all-reduces sit between the phases of every step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with the gloo backend (RCCL refuses two ranks per device): exercises the "
                          "multi-rank code path of this script on a 1-GPU box; the number it prints is NOT a scaling result")
@@ -186,12 +190,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        agent.update(rb, s)
+    spl = max(1, args.steps_per_launch) if world == 1 else 1
+
+    def run(first_step, n_steps):                 # exactly n_steps updates, spl per graph launch
+        done = 0
+        while done < n_steps:
+            k = min(spl, n_steps - done)
+            if k == 1:
+                agent.update(rb, first_step + done)
+            else:
+                agent.update_many(rb, first_step + done, k)
+            done += k
+
+    run(0, args.warmup)
+    if args.steps % spl and args.steps > spl:    # capture the remainder-sized graph outside the timed region too
+        run(args.warmup, args.steps % spl)
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        agent.update(rb, args.warmup + s)
+    run(args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -217,6 +233,7 @@ def main():
                                    ("fb_ddpg offline on quadruped_walk replay (configs[2]): obs 78, action 12, goal space "
                                     f"simplified_quadruped (g=2), z_dim 100, batch 2048 per GPU; {n_eps}-episode x 1000-step "
                                     "synthetic replay resident in HBM; metrics off"),
+                       "steps_per_graph_launch": spl,
                        "global_batch": W["batch_size"] * world, "parallelism": f"dp{world}",
                        "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

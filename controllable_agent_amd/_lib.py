@@ -62,6 +62,7 @@ PROTOTYPES = {
     "fbhip_set_step_counts": (C.c_int, [_P, _I, _I, _P]),
     "fbhip_get_step_counts": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
+    "fbhip_update_many": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_read_metrics": (C.c_int, [_P, C.POINTER(C.c_float), _P]),
     "fbhip_workspace_view": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "fbhip_actor_forward": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _F, _F, _P, _I, _P]),

@@ -615,15 +615,18 @@ class FBHipAgent:
         self._replay_token = token
 
     def _run_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
+        self._on_update_stream(lambda: self._launch_update(hp, inject, use_graph))
+
+    def _on_update_stream(self, fn: tp.Callable[[], None]) -> None:
         cur = torch.cuda.current_stream(self._device)
         if cur.cuda_stream != 0:
-            self._launch_update(hp, inject, use_graph)
+            fn()
             return
         # the caller sits on the legacy default stream, where stream capture is not allowed: run on the agent's own
         # stream, ordered after / before the caller's work with events (no host synchronisation)
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
-            self._launch_update(hp, inject, use_graph)
+            fn()
         cur.wait_stream(self._stream)
 
     def _launch_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
@@ -669,6 +672,33 @@ class FBHipAgent:
         else:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)
+        return self._metrics()
+
+    def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
+        """``n_steps`` consecutive ``update(replay_loader, step + i)`` calls as ONE graph launch (``fbhip_update_many``):
+        same kernels, same order, same results -- for loops that do nothing between updates (train_offline.py:101-134
+        between two log lines).  Falls back to single updates whenever that would not be equivalent: gradient all-reduce
+        (world > 1), a host-sampling loader, ``update_every_steps != 1``, a time-varying ``stddev_schedule``.
+        Returns the metrics of the LAST step (if metrics are on)."""
+        c = self.cfg
+        stds = {schedule(c.stddev_schedule, step + i) for i in range(n_steps)}
+        if (n_steps < 2 or self._world() > 1 or not isinstance(replay_loader, DeviceReplayBuffer) or
+                c.update_every_steps != 1 or len(stds) != 1 or not self._use_graph):
+            out: tp.Dict[str, float] = {}
+            for i in range(n_steps):
+                out = self.update(replay_loader, step + i)
+            return out
+        want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+        self._bind_replay(replay_loader)
+        hp = self._hparams(step, want, 1.0, float(replay_loader._discount), float(replay_loader._future))
+        done = 0
+        while done < n_steps:
+            n = min(64, n_steps - done)
+
+            def launch(n: int = n) -> None:
+                check(_lib.load().fbhip_update_many(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx)
+            self._on_update_stream(launch)
+            done += n
         return self._metrics()
 
     def update_from_batch(self, batch: tp.Any, step: int, draws: tp.Optional[tp.Mapping[str, tp.Any]] = None,

@@ -267,7 +267,7 @@ ActP act_p(float* base, const NetLayout& L) {
     return a;
 }
 
-struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; };
+struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; };
 struct InferGraph { int kind; int eval_mode; int has_noise; float stddev; hipGraphExec_t exec; };
 
 }  // namespace
@@ -1033,7 +1033,7 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     for (auto& g : c->graphs) {
-        if (g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
+        if (g.n_steps == 1 && g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
             (!inject || memcmp(&g.inj, inject, sizeof(*inject)) == 0)) {
             HIPCK(c, hipGraphLaunch(g.exec, s));
             return FBHIP_OK;
@@ -1046,8 +1046,36 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     HIPCK(c, e);
     GraphEntry ge{};
-    ge.mask = phase_mask; ge.hp = *hp; ge.has_inj = inject != nullptr;
+    ge.mask = phase_mask; ge.hp = *hp; ge.has_inj = inject != nullptr; ge.n_steps = 1;
     if (inject) ge.inj = *inject;
+    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIPCK(c, e);
+    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    c->graphs.push_back(ge);
+    HIPCK(c, hipGraphLaunch(ge.exec, s));
+    return FBHIP_OK;
+}
+
+int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
+    RC(need_bound(c, true));
+    if (!hp || n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    for (auto& g : c->graphs) {
+        if (g.n_steps == n_steps && g.mask == FBHIP_PHASE_ALL && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {
+            HIPCK(c, hipGraphLaunch(g.exec, s));
+            return FBHIP_OK;
+        }
+    }
+    hipGraph_t graph = nullptr;
+    HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = FBHIP_OK;
+    for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ALL, s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIPCK(c, e);
+    GraphEntry ge{};
+    ge.mask = FBHIP_PHASE_ALL; ge.hp = *hp; ge.has_inj = false; ge.n_steps = n_steps;
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCK(c, e);

@@ -166,6 +166,11 @@ int fbhip_get_step_counts(fbhip_ctx* ctx, int32_t* host_fb_steps, int32_t* host_
  * cached hipGraph of the launch sequence (captured on first use; re-captured when hparams change). */
 int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* inject,
                  int32_t phase_mask, int32_t use_graph, void* stream);
+/* n_steps consecutive complete updates (all phases, device-drawn batches) as ONE hipGraph launch: what the offline loop
+ * (train_offline.py:101-134) does between two log lines.  Identical kernels in identical order to n_steps fbhip_update
+ * calls -- the Adam / RNG counters advance on the device -- minus n_steps - 1 graph-launch gaps.  Single-rank only (there
+ * is no place for the gradient all-reduce inside the graph); ``hp`` is constant over the n_steps (1 <= n_steps <= 64). */
+int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
 /* Blocking: copies the FBHIP_NUM_METRICS device floats to host_out after the stream drains. */
 int fbhip_read_metrics(fbhip_ctx* ctx, float* host_out, void* stream);
 /* Named views into the workspace for tests / host code ("z", "F1", "dF1", "obs", ...). */

@@ -444,3 +444,26 @@ def test_norm_z_false_device_draws_and_inference():
     assert 0.0 < float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.03
     bi = agent.workspace_view("backward_input").cpu()
     assert H.rel_err(z[~gauss_rows], fo.backward_map_raw(nets["backward_net"], bi[~gauss_rows])) < 2e-5
+
+
+def test_update_many_equals_consecutive_updates():
+    """fbhip_update_many (n complete updates in one hipGraph) == n fbhip_update launches, bit for bit: same kernels, same
+    order, device-side Adam / RNG counters.  Also through run_offline(steps_per_launch=...)."""
+    from controllable_agent_amd.train_offline import run_offline
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64)
+    rng = np.random.default_rng(21)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a1, a2, a3 = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(3))
+    for s in range(7):
+        a1.update(rb, s)
+    a2.update_many(rb, 0, 4)
+    a2.update_many(rb, 4, 3)
+    run_offline(a3, rb, 7, log_every_steps=5, steps_per_launch=4)           # 4 + 1 (log boundary) + 2
+    s1, s2, s3 = (H.get_agent_state(a) for a in (a1, a2, a3))
+    assert a1.step_counts() == a2.step_counts() == a3.step_counts() == (7, 7)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+        np.testing.assert_array_equal(s1[k], s3[k], err_msg=k)
