@@ -203,8 +203,11 @@ def main():
             done += k
 
     run(0, args.warmup)
-    if args.steps % spl and args.steps > spl:    # capture the remainder-sized graph outside the timed region too
-        run(args.warmup, args.steps % spl)
+    # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
+    # untimed launch of each size (these are additional warm-up steps)
+    sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
+    for sz in sorted(sizes):
+        run(args.warmup, sz)
     barrier()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
