@@ -56,11 +56,22 @@ def main(path, out=None, skip=12):
     if "WRITE_SIZE" in total:
         lines.append(f"WRITE_SIZE per step: {total['WRITE_SIZE'] * 1024.0 / nsteps / 1e6:.2f} MB (uncalibrated on gfx950)")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in total:
-        # calibration on this pool: the counter comes back in quad-cycles of ONE XCD, i.e. x32 = SIMD-cycles chip-wide
-        # (check: 15.1 M v_mfma_f32_32x32x2 per update x 64 cycles = 970 M SIMD-cycles)
+        # SQ_VALU_MFMA_BUSY_CYCLES comes back summed over the chip's 1024 SIMDs in cycles (check: 15.1 M
+        # v_mfma_f32_32x32x2 per update x 64 cycles = 970 M); GRBM_GUI_ACTIVE comes back summed over the 8 XCDs
+        # (check: per launch it is ~8x the kernel-trace duration x 2.4 GHz, PMC runs being ~1.2x slower).
         busy = total["SQ_VALU_MFMA_BUSY_CYCLES"] / nsteps
-        lines.append(f"SQ_VALU_MFMA_BUSY_CYCLES per step: {busy / 1e6:.2f} M raw = {32 * busy / 1e6:.0f} M SIMD-cycles (x32: quad-cycles, "
-                     f"one XCD of 8) = {32 * busy / 64 / 1e6:.2f} M fp32 32x32x2 MFMAs")
+        lines.append(f"SQ_VALU_MFMA_BUSY_CYCLES per step: {busy / 1e6:.1f} M SIMD-cycles = {busy / 64 / 1e6:.2f} M fp32 32x32x2 MFMAs")
+        if "GRBM_GUI_ACTIVE" in total:
+            gsum = bsum = 0.0
+            for k in sorted(per_kernel, key=lambda k: -per_kernel[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)):
+                bz, act = per_kernel[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0), per_kernel[k].get("GRBM_GUI_ACTIVE", 0)
+                if bz > 0 and act > 0:
+                    lines.append(f"  MFMA busy {k:<44} {100.0 * bz / (act / 8 * 1024):6.1f} % of SIMD-cycles while the kernel runs")
+                    if "gemm" in k:
+                        gsum += act; bsum += bz
+            if gsum > 0:
+                lines.append(f"  MFMA busy over all GEMM launches: {100.0 * bsum / (gsum / 8 * 1024):.1f} % (in the PMC run; its kernels "
+                             f"run ~1.2x slower than unprofiled, so the unprofiled figure is higher by about that factor)")
     txt = "\n".join(lines)
     print(txt)
     if out:
