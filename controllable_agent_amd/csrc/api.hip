@@ -343,10 +343,11 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
         tiles128 += (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
     }
     int cfg;
-    // >= 4 128x64 tiles per CU: the LDS-DMA kernel with two accumulators per wave (25 % fewer operand bytes per FLOP
+    // >= 8 128x64 tiles per CU (2048; measured: at 4-6 per CU, quadruped B = 2048, it still loses 1 % to the 64x64 kernel):
+    // the LDS-DMA kernel with two accumulators per wave (25 % fewer operand bytes per FLOP
     // through the per-CU global->LDS path; 132 vs 122 TFLOP/s at 4096^3).  The step's own launches have 1-2 tiles per CU
     // and measure faster on the register-staged 64x64 kernel (see gemm.hip).
-    static const long dma128_min = [] { const char* e = getenv("FBHIP_DMA128_MIN_TILES"); return e ? atol(e) : 1024L; }();
+    static const long dma128_min = [] { const char* e = getenv("FBHIP_DMA128_MIN_TILES"); return e ? atol(e) : 2048L; }();
     if (dma_all && kmax > 64 && tiles128 >= dma128_min) cfg = CFG_DMA128;
     else if (kmax <= 64) cfg = (nmax <= 32) ? CFG_4x1x1 : CFG_2x2x1;
     // aim for >= 2 workgroups per CU (>= 512): a lone wave per SIMD cannot hide LDS / L2 latency behind its one
