@@ -30,12 +30,14 @@ class Dims(C.Structure):
 class HParams(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lr", "lr_coef", "fb_target_tau", "stddev", "stddev_clip", "ortho_coef",
                                           "mix_ratio", "q_loss_coef", "discount", "grad_scale")] + \
-               [("q_loss", C.c_int32), ("want_metrics", C.c_int32), ("future_ratio", C.c_float), ("future", C.c_float)]
+               [("q_loss", C.c_int32), ("want_metrics", C.c_int32), ("future_ratio", C.c_float), ("future", C.c_float),
+                ("rand_weight", C.c_int32)]
 
 
 class Inject(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ep_idx", "step_idx", "z_gauss", "perm", "mix_uniform", "eps_next",
-                                           "eps_actor", "future_idx", "future_uniform", "z_uniform")]
+                                           "eps_actor", "future_idx", "future_uniform", "z_uniform", "rand_weight",
+                                           "rand_weight_u")]
 
 
 class TensorDesc(C.Structure):
@@ -97,7 +99,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 3:
+    if lib.fbhip_abi_version() != 4:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

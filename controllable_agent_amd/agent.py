@@ -234,7 +234,7 @@ class FBHipAgent:
             if getattr(cfg, f) is MISSING or getattr(cfg, f) == "???":
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
-                       "rand_weight": cfg.rand_weight, "add_trunk": cfg.add_trunk, "preprocess": not cfg.preprocess,
+                       "add_trunk": cfg.add_trunk, "preprocess": not cfg.preprocess,
                        "nstep": cfg.nstep != 1}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -591,7 +591,7 @@ class FBHipAgent:
         if c.future_ratio > 0 and not future < 1:
             # the reference asserts ``future_goal is not None`` (fb_ddpg.py:489): only buffers with future < 1 sample it
             raise ValueError("future_ratio > 0 needs a replay buffer built with future < 1 (hindsight replay)")
-        return HParams(future_ratio=float(c.future_ratio), future=float(future), lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.fb_target_tau,
+        return HParams(future_ratio=float(c.future_ratio), future=float(future), rand_weight=int(bool(c.rand_weight)), lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.fb_target_tau,
                        stddev=schedule(c.stddev_schedule, step), stddev_clip=c.stddev_clip, ortho_coef=c.ortho_coef,
                        mix_ratio=c.mix_ratio, q_loss_coef=c.q_loss_coef, discount=discount, grad_scale=grad_scale,
                        q_loss=int(c.q_loss), want_metrics=int(want_metrics))
@@ -740,7 +740,8 @@ class FBHipAgent:
             keep.append(i32(np.full(Bn, 3)))                               # future row = storage[:, 2] = [ep, 3 - 1]
             inj.future_idx = ptr(keep[-1])
         if draws is not None:
-            for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor", "future_uniform", "z_uniform"):
+            for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor", "future_uniform", "z_uniform", "rand_weight",
+                         "rand_weight_u"):
                 if name in draws and draws[name] is not None:
                     t = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
                     keep.append(t)
@@ -768,6 +769,10 @@ class FBHipAgent:
         for name in ("z_gauss", "mix_uniform", "eps_next", "eps_actor"):
             keep[name] = torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous()
             setattr(inj, name, ptr(keep[name]))
+        if self.cfg.rand_weight:                                       # raw weights [B,B] + row scales [B] (fb_ddpg.py:477-479)
+            keep["rand_weight"] = torch.as_tensor(np.asarray(draws["rand_weight"], dtype=np.float32), device=dev).contiguous()
+            keep["rand_weight_u"] = torch.as_tensor(np.asarray(draws["rand_weight_u"], dtype=np.float32), device=dev).contiguous()
+            inj.rand_weight, inj.rand_weight_u = ptr(keep["rand_weight"]), ptr(keep["rand_weight_u"])
         if not self.cfg.norm_z:                                        # sample_z's uniform factor (fb_ddpg.py:230)
             keep["z_uniform"] = torch.as_tensor(np.asarray(draws["z_uniform"], dtype=np.float32), device=dev).contiguous()
             inj.z_uniform = ptr(keep["z_uniform"])

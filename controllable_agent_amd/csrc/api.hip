@@ -139,6 +139,9 @@ struct Ws {
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
     float* splitk = nullptr;            // split-K partial slab
     float* pw_scratch = nullptr;
+    float* rw = nullptr;                // rand_weight: [B, B] mixing weights, [B] row scales, and the mixed rows
+    float* rw_u = nullptr;
+    Buf ymixw;
     float* act_in = nullptr;            // batch-1 fast path: [obs | z | 0.. | noise] / [goal | 0.. | z] as staged by the host
     float* act_vec = nullptr;           // its activation vectors
     float* act_out = nullptr;           // action (a floats) or the z correlation (1 float)
@@ -219,6 +222,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
     w.splitk = c.f((size_t)6 << 20);
+    w.rw = c.f((size_t)B * B); w.rw_u = c.f(B); w.ymixw = c.buf(B, z);
     w.act_in = c.f(act_in_floats(d));
     w.act_vec = c.f((size_t)4 * 2048 + 256);
     w.act_out = c.f(64);
@@ -704,6 +708,8 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
                                   inj->z_gauss && inj->eps_next && inj->eps_actor &&
                                   (!hindsight || (inj->future_idx && inj->future_uniform)) && (d.norm_z || inj->z_uniform);
+        const bool randw = hp.rand_weight != 0 && hp.mix_ratio > 0.f;
+        const bool randw_injected = randw && inj && inj->rand_weight && inj->rand_weight_u;
         if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, hindsight ? hp.future : -1.f, d.norm_z, s));
         if (inj != nullptr) {
 #define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
@@ -711,6 +717,10 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             INJ(z_gauss, (size_t)B * z * 4); INJ(eps_next, (size_t)B * a * 4); INJ(eps_actor, (size_t)B * a * 4);
             if (hindsight) { INJ(future_idx, B * 4); INJ(future_uniform, B * 4); }
             if (!d.norm_z) INJ(z_uniform, (size_t)B * z * 4);
+            if (randw_injected) {
+                HIPCK(c, hipMemcpyAsync(w.rw, inj->rand_weight, (size_t)B * B * 4, hipMemcpyDeviceToDevice, s));
+                HIPCK(c, hipMemcpyAsync(w.rw_u, inj->rand_weight_u, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+            }
 #undef INJ
         }
         GatherArgs ga{};
@@ -728,9 +738,9 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // :319) share these launches: they only need the gathered batch.
         {
             std::vector<Chain> ch;
-            if (hp.mix_ratio > 0.f) {
+            if (hp.mix_ratio > 0.f) {           // rand_weight mixes COMPLETE BackwardMap outputs (projection included)
                 ch.emplace_back();
-                backward_map_fwd_chain(c, c->K_p, w.bin.p, w.bin.ld, w.bsM, B, ch.back(), /*with_projection=*/false);
+                backward_map_fwd_chain(c, c->K_p, w.bin.p, w.bin.ld, w.bsM, B, ch.back(), /*with_projection=*/randw);
             }
             if (hindsight) {                    // B(future_goal), fb_ddpg.py:491 (its projection happens in mix_z_kernel)
                 ch.emplace_back();
@@ -744,9 +754,17 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             }
             RC(run_rounds(c, ch, s));
         }
-        HIPCK(c, launch_mix_z(w.so.z_gauss, z, w.bsM.y.p, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
+        const float* ymix = w.bsM.y.p;
+        if (randw) {
+            // mix_z = (u * normalize(rand[., B])) @ backward_net(backward_input[perm])   (fb_ddpg.py:475-482), all rows
+            HIPCK(c, launch_rand_weight(w.rw, w.rw_u, B, randw_injected ? 0 : 1, c->seed, c->rank, w.st, s));
+            const Buf& bm = d.norm_z ? w.bsM.Bm : w.bsM.y;
+            RC(run_gemms(c, {P(w.rw, B, 1, bm.p, bm.ld, 0, w.ymixw.p, Lz, B, z, B)}, s));
+            ymix = w.ymixw.p;
+        }
+        HIPCK(c, launch_mix_z(w.so.z_gauss, z, ymix, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, hindsight ? w.bsF.y.p : nullptr, w.so.future_uniform,
-                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, s));
+                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, randw ? 1 : 2, s));
     }
 
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
@@ -1121,6 +1139,8 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
     else if (n == "step_idx") { b.p = (float*)w.so.step_idx; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "perm") { b.p = (float*)w.so.perm; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "mix_uniform") { b.p = w.so.mix_uniform; b.rows = 1; b.cols = B; b.ld = B; }
+    else if (n == "rand_weight") { b.p = w.rw; b.rows = B; b.cols = B; b.ld = B; }
+    else if (n == "rand_weight_u") { b.p = w.rw_u; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "future_idx") { b.p = (float*)w.so.future_idx; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "future_uniform") { b.p = w.so.future_uniform; b.rows = 1; b.cols = B; b.ld = B; }
     else if (n == "eps_next") { b.p = w.so.eps_next; b.rows = B; b.cols = a; b.ld = a; }

@@ -174,7 +174,12 @@ hipError_t launch_gather(const GatherArgs& ga, hipStream_t s);
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
                         StepState* st, const float* yfut, const float* future_uniform, float future_ratio,
-                        const float* z_uniform /* nullable: norm_z */, hipStream_t s);
+                        const float* z_uniform /* nullable: norm_z */, int mix_projections /* 2, or 1 with rand_weight */,
+                        hipStream_t s);
+// rand_weight rows (fb_ddpg.py:477-480): W[i, :] = u[i] * raw[i, :] / max(|raw[i, :]|_2, 1e-12), in place.  generate != 0
+// first draws raw[i, j] and u[i] ~ U(0,1) (Philox); else they are the injected values already sitting in W / u.
+hipError_t launch_rand_weight(float* W, float* u, int B, int generate, uint64_t seed, uint32_t rank, const StepState* st,
+                              hipStream_t s);
 hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, const float* B, int ldb, int nb,
                           int rows, hipStream_t s);
 hipError_t pairwise_prepare(int B, int d);     // one-time kernel attribute setup (outside graph capture)

@@ -29,6 +29,7 @@ __device__ __forceinline__ void box_muller(unsigned a, unsigned b, float& n0, fl
 
 // stream ids (second counter word)
 enum { STREAM_INDEX = 0, STREAM_PERM = 1, STREAM_MIX = 2, STREAM_Z = 3, STREAM_EPS_NEXT = 4, STREAM_EPS_ACTOR = 5,
-       STREAM_ACT = 6, STREAM_FUTURE = 7, STREAM_ZU = 8 };
+       STREAM_ACT = 6, STREAM_FUTURE = 7, STREAM_ZU = 8, STREAM_RW = 9,
+       STREAM_RWU = 10 };
 
 }  // namespace fbhip

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
                                                     float* __restrict__ Xnoz, int ld_noz, int o, int B, int d,
                                                     StepState* __restrict__ st, const float* __restrict__ yfut,
                                                     const float* __restrict__ futu, float future_ratio,
-                                                    const float* __restrict__ zunif) {
+                                                    const float* __restrict__ zunif, int mix_proj) {
     if (st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) st->update_count += 1u;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
     }
     const float sc = sqrtf((float)d);
     if (zunif == nullptr) {
-        // norm_z: gaussian and hindsight rows are projected once, mixed rows twice (BackwardMap's own + fb_ddpg.py:483-484)
+        // norm_z: gaussian and hindsight rows are projected once, mixed rows twice (BackwardMap's own + fb_ddpg.py:483-484);
+        // with rand_weight the mixed row is a weighted sum of already projected rows and gets the :483 projection only
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
         const float den = fmaxf(sqrtf(s), 1e-12f);
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
             v[k] = sc * (v[k] / den);
             s2 += v[k] * v[k];
         }
-        if (mix) {
+        if (mix && mix_proj > 1) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
             const float den2 = fmaxf(sqrtf(s2), 1e-12f);
@@ -216,7 +217,51 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
     }
 }
 
+// rand_weight (fb_ddpg.py:477-480): one workgroup per row of the B x B weight matrix
+__global__ void __launch_bounds__(256) rand_weight_kernel(float* __restrict__ W, float* __restrict__ u, int B, int generate,
+                                                         unsigned k0, unsigned k1, const StepState* __restrict__ st) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    float* row = W + (size_t)i * B;
+    const unsigned cnt = st->update_count;
+    float ss = 0.f;
+    for (int q4 = tid; 4 * q4 < B; q4 += 256) {
+        float v[4];
+        if (generate) {
+            const U4 r = philox4x32_10((unsigned)(i * ((B + 3) / 4) + q4), STREAM_RW, cnt, 0u, k0, k1);
+            v[0] = u01(r.x); v[1] = u01(r.y); v[2] = u01(r.z); v[3] = u01(r.w);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = 4 * q4 + j < B ? row[4 * q4 + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * q4 + j < B) { ss += v[j] * v[j]; if (generate) row[4 * q4 + j] = v[j]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    float ui;
+    if (generate) {
+        ui = u01(philox4x32_10((unsigned)i, STREAM_RWU, cnt, 0u, k0, k1).x);
+        if (tid == 0) u[i] = ui;
+    } else {
+        ui = u[i];
+    }
+    const float den = fmaxf(nrm, 1e-12f);                       // F.normalize eps
+    for (int j = tid; j < B; j += 256) row[j] = ui * (row[j] / den);
+}
+
 }  // namespace
+
+hipError_t launch_rand_weight(float* W, float* u, int B, int generate, uint64_t seed, uint32_t rank, const StepState* st,
+                              hipStream_t s) {
+    const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
+    hipLaunchKernelGGL(rand_weight_kernel, dim3(B), dim3(256), 0, s, W, u, B, generate, k0, k1, st);
+    return hipGetLastError();
+}
 
 hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, int a, uint64_t seed, uint32_t rank,
                        const StepState* st, float future, int norm_z, hipStream_t s) {
@@ -236,11 +281,11 @@ hipError_t launch_gather(const GatherArgs& ga, hipStream_t s) {
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
                         StepState* st, const float* yfut, const float* future_uniform, float future_ratio,
-                        const float* z_uniform, hipStream_t s) {
+                        const float* z_uniform, int mix_projections, hipStream_t s) {
     if (d > 256) return hipErrorInvalidValue;
     if (future_ratio > 0.f && (!yfut || !future_uniform)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mix_z_kernel, dim3((B + 3) / 4), dim3(256), 0, s, gauss, ldg, ymix, ldy, mix_uniform, mix_ratio, z,
-                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st, yfut, future_uniform, future_ratio, z_uniform);
+                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st, yfut, future_uniform, future_ratio, z_uniform, mix_projections);
     return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 3
+#define FBHIP_ABI_VERSION 4
 
 enum {
     FBHIP_OK = 0,
@@ -91,6 +91,7 @@ typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82
     float future_ratio;            /* 0: off.  > 0: hindsight replay z[u < future_ratio] = B(future_goal) (fb_ddpg.py:487-491) */
     float future;                  /* ReplayBuffer._future (< 1 when future_ratio > 0): future_idx = clip(step_idx +
                                     * Geometric(1 - future), 0, episode_len) (in_memory_replay_buffer.py:157-161) */
+    int32_t rand_weight;           /* cfg.rand_weight: mixed rows = (u * normalize(rand[B])) @ B(backward_input[perm]) (:475-482) */
 } fbhip_hparams;
 
 /* Injected random draws (parity mode).  NULL struct => draw on device with Philox4x32-10 keyed by
@@ -106,6 +107,8 @@ typedef struct fbhip_inject {
     const int32_t* future_idx;     /* [B]   in_memory_replay_buffer.py:159-160 (1-based, clipped); used if future_ratio > 0 */
     const float* future_uniform;   /* [B]   fb_ddpg.py:490; used if future_ratio > 0 */
     const float* z_uniform;        /* [B,d] contiguous; torch.rand of fb_ddpg.py:230; used if norm_z == 0 */
+    const float* rand_weight;      /* [B,B] contiguous RAW uniforms, row i = batch row i (fb_ddpg.py:477); used if rand_weight */
+    const float* rand_weight_u;    /* [B]   fb_ddpg.py:479; used if rand_weight */
 } fbhip_inject;
 
 /* one named tensor inside a flat parameter buffer (names = the reference's state_dict keys) */

@@ -54,6 +54,7 @@ class OracleConfig:
     future_ratio: float = 0.0     # hindsight replay: z[u < future_ratio] = B(future_goal)  (fb_ddpg.py:487-491)
     future: float = 1.0           # ReplayBuffer._future; < 1 => future_idx = step + Geometric(1 - future) (:157-161)
     norm_z: bool = True           # False: B unprojected, z = sqrt(d) U g/|g| (fb_ddpg.py:227-231, fb_modules.py:228-229)
+    rand_weight: bool = False     # mixed rows = (u * normalize(rand[B])) @ B(backward_input)  (fb_ddpg.py:475-482)
 
 
 @dataclasses.dataclass
@@ -69,6 +70,9 @@ class Draws:
     future_idx: tp.Optional[np.ndarray] = None      # int64 [B]  in_memory_replay_buffer.py:157-161 (only if future < 1)
     future_uniform: tp.Optional[np.ndarray] = None  # f64 [B]    fb_ddpg.py:490 (only if future_ratio > 0)
     z_uniform: tp.Optional[np.ndarray] = None       # f32 [B,d]  fb_ddpg.py:230 (torch.rand, only if not norm_z)
+    rand_weight: tp.Optional[np.ndarray] = None     # f32 [B,B]  fb_ddpg.py:477: row i = the weights of batch row i
+    rand_weight_u: tp.Optional[np.ndarray] = None   # f32 [B]    fb_ddpg.py:479  (both only if cfg.rand_weight; the reference
+                                                    #            draws them for the mixed rows only, in mix_idxs order)
 
 
 def make_draws(rng: np.random.Generator, cfg: OracleConfig, n_episodes: int,
@@ -102,6 +106,9 @@ def _with_future(cfg: OracleConfig, rng: np.random.Generator, fut_idx, d: Draws)
         d.future_uniform = rng.uniform(size=cfg.batch_size)
     if not cfg.norm_z:
         d.z_uniform = rng.uniform(size=(cfg.batch_size, cfg.z_dim)).astype(np.float32)
+    if cfg.rand_weight:
+        d.rand_weight = rng.uniform(size=(cfg.batch_size, cfg.batch_size)).astype(np.float32)
+        d.rand_weight_u = rng.uniform(size=cfg.batch_size).astype(np.float32)
     return d
 
 
@@ -370,7 +377,12 @@ class OracleAgent:
         if cfg.mix_ratio > 0:
             mix_idxs = np.where(draws.mix_uniform < cfg.mix_ratio)[0]
             with torch.no_grad():
-                mz = backward_map(self.backward_net, bi[mix_idxs], cfg.z_dim, cfg.norm_z)
+                if cfg.rand_weight:                                # fb_ddpg.py:475-482
+                    weight = F.normalize(torch.from_numpy(draws.rand_weight[mix_idxs]), dim=1)
+                    weight = torch.from_numpy(draws.rand_weight_u[mix_idxs]).reshape(-1, 1) * weight
+                    mz = torch.matmul(weight, backward_map(self.backward_net, bi, cfg.z_dim, cfg.norm_z))
+                else:
+                    mz = backward_map(self.backward_net, bi[mix_idxs], cfg.z_dim, cfg.norm_z)
             if cfg.norm_z:                                         # fb_ddpg.py:483-484
                 mz = math.sqrt(cfg.z_dim) * F.normalize(mz, dim=1)
             z = z.clone()

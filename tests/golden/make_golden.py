@@ -94,7 +94,7 @@ def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
         hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
         z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
         ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
-        future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, update_every_steps=1, **extra)
+        future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, rand_weight=cfg.rand_weight, update_every_steps=1, **extra)
 
 
 def load_nets(agent, nets):
@@ -125,7 +125,7 @@ def fill_ref_buffer(R, storage, lengths, discount, future=0.99, max_len=None, me
 
 
 @contextlib.contextmanager
-def inject(R, d: fo.Draws, variable_len: bool):
+def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5):
     """Route every random draw of one ``update()`` to the prepared values."""
     calls = {"randint": 0, "uniform": 0}
     o_randint, o_choice, o_uniform, o_geo = np.random.randint, np.random.choice, np.random.uniform, np.random.geometric
@@ -155,15 +155,23 @@ def inject(R, d: fo.Draws, variable_len: bool):
     def randn(*a, **kw):
         return torch.from_numpy(d.z_gauss.copy())
 
-    def rand(*a, **kw):                         # sample_z's uniform factor when norm_z is False (fb_ddpg.py:230)
-        return torch.from_numpy(d.z_uniform.copy())
+    def rand(*a, **kw):
+        shape = tuple(kw.get("size", a[0] if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else a))
+        B = len(d.mix_uniform)
+        if d.z_uniform is not None and shape == d.z_uniform.shape:      # sample_z, norm_z False (fb_ddpg.py:230)
+            return torch.from_numpy(d.z_uniform.copy())
+        mix_idxs = np.where(d.mix_uniform < mix_ratio)[0]               # rand_weight (fb_ddpg.py:477, :479): mixed rows only
+        if shape == (len(mix_idxs), B):
+            return torch.from_numpy(d.rand_weight[mix_idxs].copy())
+        assert shape == (len(mix_idxs), 1), shape
+        return torch.from_numpy(d.rand_weight_u[mix_idxs].copy()).reshape(-1, 1)
 
     def standard_normal(shape, dtype, device):
         return torch.from_numpy(eps_queue.pop(0).copy())
 
     np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = randint, choice, uniform, geometric
     torch.randperm, torch.randn, R.utils._standard_normal = randperm, randn, standard_normal
-    if d.z_uniform is not None:
+    if d.z_uniform is not None or d.rand_weight is not None:
         torch.rand = rand
     try:
         yield
@@ -220,7 +228,7 @@ def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_s
         arrays["lengths"] = lengths
     for s in range(n_steps):
         d = fo.make_draws(rng, cfg, n_eps, lengths)
-        with inject(R, d, variable_len):
+        with inject(R, d, variable_len, cfg.mix_ratio):
             m = agent.update(rb, s)
         meta["metrics"].append({k: float(v) for k, v in m.items()})
         if full_state:
@@ -248,6 +256,13 @@ def future_fixtures(R):
 def nonorm_fixture(R):
     """norm_z=False: BackwardMap unprojected, z = sqrt(d) U g/|g| (fb_ddpg.py:227-231, :483; fb_modules.py:228-229)"""
     trace_fixture(R, "tiny_nonorm_trace", tiny_cfg(norm_z=False, future=0.8, future_ratio=0.3), seed=105, n_eps=6, T=12, n_steps=4)
+
+
+def randweight_fixture(R):
+    """rand_weight=True (fb_ddpg.py:475-482), once with the default projection and once together with norm_z=False"""
+    trace_fixture(R, "tiny_randw_trace", tiny_cfg(rand_weight=True, mix_ratio=0.6), seed=106, n_eps=6, T=12, n_steps=3)
+    trace_fixture(R, "tiny_randw_nonorm_trace", tiny_cfg(rand_weight=True, norm_z=False, goal_dim=3, use_goal=True),
+                  seed=107, n_eps=7, T=11, n_steps=3, goal_space="simplified_walker")
 
 
 def sampler_fixture(R):
@@ -386,6 +401,7 @@ def main():
                   seed=102, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)
     future_fixtures(R)
     nonorm_fixture(R)
+    randweight_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -27,16 +27,17 @@ def _buffer(storage, lengths, discount, future=1.0):
 def _param_close(got, ref, lr, name):
     """Post-Adam parameters.  Adam divides by sqrt(v): an entry whose gradient is O(eps=1e-8) can move by a
     visible fraction of lr for an O(1e-9) gradient difference, so the bound is: every entry within lr/2 (the
-    step is at most ~lr), and all but 0.1 % within PARAM_ATOL."""
+    step is at most ~lr), and all but 0.1 % (at least one entry: the tiny traces have 512-entry tensors) within PARAM_ATOL."""
     diff = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
     assert diff.max() <= 0.5 * lr + 1e-7, f"{name}: max |diff| {diff.max():.3e}"
-    frac = float((diff <= PARAM_ATOL).mean())
-    assert frac >= 0.999, f"{name}: only {frac:.5f} of entries within {PARAM_ATOL}"
+    bad = int((diff > PARAM_ATOL).sum())
+    assert bad <= max(1, diff.size // 1000), f"{name}: {bad} of {diff.size} entries beyond {PARAM_ATOL}"   # 0.1 %, at least one
 
 
 @pytest.mark.parametrize("name,goal_space", [("tiny_trace", None), ("tiny_goal_trace", "simplified_walker"),
                                              ("tiny_future_trace", None), ("tiny_future_goal_trace", "simplified_walker"),
-                                             ("tiny_nonorm_trace", None)])
+                                             ("tiny_nonorm_trace", None), ("tiny_randw_trace", None),
+                                             ("tiny_randw_nonorm_trace", "simplified_walker")])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
@@ -467,3 +468,27 @@ def test_update_many_equals_consecutive_updates():
     for k in s1:
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
         np.testing.assert_array_equal(s1[k], s3[k], err_msg=k)
+
+
+def test_rand_weight_device_draws():
+    """cfg.rand_weight without injected draws: every row of the mixing matrix is u_i * (nonnegative unit vector)
+    (fb_ddpg.py:477-480) and the mixed rows of z are sqrt(d) normalize(W @ B(backward_input[perm]))."""
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=256, rand_weight=True, mix_ratio=0.5)
+    rng = np.random.default_rng(17)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 12, 40, cfg.obs_dim, cfg.action_dim)
+    agent = H.make_hip_agent(cfg, nets)
+    agent.update(_buffer(storage, lengths, cfg.discount), 0)
+    Wm = agent.workspace_view("rand_weight").cpu()
+    u = agent.workspace_view("rand_weight_u").cpu()[0]
+    assert float(Wm.min()) >= 0.0 and 0.0 < float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.08
+    np.testing.assert_allclose(Wm.norm(dim=1).numpy(), u.numpy(), rtol=1e-5)
+    raw = Wm / u[:, None] * (Wm.shape[1] / 3) ** 0.5       # |x|_2 ~ sqrt(B/3) for x ~ U(0,1)^B: recovers x up to that fluctuation
+    assert abs(float(raw.mean()) - 0.5) < 0.02
+    bi = agent.workspace_view("backward_input").cpu()
+    Bmix = fo.backward_map(nets["backward_net"], bi, cfg.z_dim)
+    want = np.sqrt(cfg.z_dim) * torch.nn.functional.normalize(Wm @ Bmix, dim=1)
+    mixed = agent.workspace_view("mix_uniform").cpu()[0] < cfg.mix_ratio
+    z = agent.workspace_view("z").cpu()
+    assert 0.3 < float(mixed.float().mean()) < 0.7 and H.rel_err(z[mixed], want[mixed]) < 2e-5
