@@ -249,3 +249,64 @@ def test_actor_loss(K):
     assert m["actor_loss"] == pytest.approx(float(loss), rel=1e-5)
     assert m["q"] == pytest.approx(float(Q.mean()), rel=1e-5)
     assert m["actor_logprob"] == pytest.approx(float(lp), rel=1e-5)
+
+
+def test_gemm_randomised_shapes_layouts_epilogues(K):
+    """120 random problems: M, N, K in 1..300 (+ a few large), all operand layouts, aligned and unaligned leading
+    dimensions (NaN in every pad element), every epilogue, optional bias-gradient column sums -- against fp64."""
+    from controllable_agent_amd import _lib
+    rng = np.random.default_rng(1234)
+    for it in range(120):
+        big = it % 10 == 0
+        M, N, Kd = (int(rng.integers(1, 1200 if big else 300)) for _ in range(3))
+        akc, bkc = bool(rng.integers(2)), bool(rng.integers(2))
+        epi = int(rng.integers(0, 5))
+        A = _r(M, Kd, seed=1000 + it) if akc else _r(Kd, M, seed=1000 + it)
+        B = _r(N, Kd, seed=2000 + it) if bkc else _r(Kd, N, seed=2000 + it)
+        pad = lambda t: _padded(t, t.shape[1] + int(rng.integers(0, 6)) if rng.integers(2) else (t.shape[1] + 3) // 4 * 4)
+        Ad, Bd = pad(A), pad(B)
+        Am = A.double() if akc else A.double().T
+        Bm = B.double() if bkc else B.double().T
+        ref = Am @ Bm.T
+        kw = {}
+        if epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_RELU):
+            bias = _r(N, seed=3000 + it)
+            kw["bias"] = bias.cuda()
+            ref = ref + bias.double()
+            if epi == _lib.EPI_BIAS_RELU:
+                ref = torch.relu(ref)
+        elif epi in (_lib.EPI_MASK_RELU, _lib.EPI_TANH_BWD):
+            aux = torch.tanh(_r(M, N, seed=4000 + it))
+            kw["aux"] = _padded(aux, N + int(rng.integers(0, 3)))
+            ref = ref * (aux.double() > 0) if epi == _lib.EPI_MASK_RELU else ref * (1 - aux.double() ** 2)
+        want_cs = epi == 0 and not akc and bool(rng.integers(2))
+        out = K.gemm(Ad, Bd, a_kcontig=akc, b_kcontig=bkc, epi=epi, want_colsum=want_cs, **kw)
+        C, cs = out if want_cs else (out, None)
+        tag = f"#{it} M{M} N{N} K{Kd} akc{akc} bkc{bkc} epi{epi} ldA{Ad.stride(0)} ldB{Bd.stride(0)}"
+        assert torch.isfinite(C).all(), tag
+        assert rel_err(C.cpu(), ref) < 3e-6, tag
+        if cs is not None:
+            assert rel_err(cs.cpu(), Am.sum(1)) < 3e-6, tag
+
+
+def test_pairwise_randomised_sizes_and_alignment(K):
+    """random batch sizes (incl. non-multiples of 32), every z_dim class of the kernel and unaligned panels (the
+    predicated staging instantiation) against the fp64 closed form"""
+    rng = np.random.default_rng(77)
+    for it in range(24):
+        Bn = int(rng.integers(2, 200)) if it % 6 else int(rng.integers(500, 1100))
+        d = int(rng.choice([1, 3, 8, 16, 17, 31, 32, 50, 64, 65, 100, 128]))
+        t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+        F1, F2, tF1, tF2 = t(Bn, d), t(Bn, d), t(Bn, d), t(Bn, d)
+        Bm = math.sqrt(d) * torch.nn.functional.normalize(t(Bn, d), dim=1)
+        tB = math.sqrt(d) * torch.nn.functional.normalize(t(Bn, d), dim=1)
+        disc = torch.from_numpy(rng.uniform(0.9, 0.99, (Bn, 1)).astype(np.float32))
+        cf = fo.fb_loss_closed_form(F1, F2, Bm, tF1, tF2, tB, disc, 1.3)
+        ld = (d + 3) // 4 * 4 if it % 2 else d + 1 + int(rng.integers(0, 3))          # aligned / unaligned leading dimension
+        dev = [_padded(x, ld) for x in (F1, F2, Bm, tF1, tF2, tB)]
+        dF1, dF2, dB, m = K.pairwise_fb(*dev, disc.cuda(), 1.3)
+        tag = f"#{it} B{Bn} d{d} ld{ld}"
+        for k, got in (("dF1", dF1), ("dF2", dF2), ("dB", dB)):
+            assert torch.isfinite(got).all() and rel_err(got.cpu(), cf[k]) < 2e-5, (tag, k)
+        for k in ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss"):
+            assert m[k] == pytest.approx(float(cf[k]), rel=5e-5, abs=1e-5), (tag, k)
