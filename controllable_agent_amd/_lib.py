@@ -95,6 +95,10 @@ def load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"or `make -C {LIB_PATH.parent / 'csrc'}`.  controllable_agent_amd has no CPU fallback.")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be the ONE runtime of the process.  If
+    # libfbhip.so is loaded first, the system copy under /opt/rocm/lib gets mapped, torch later maps its own, and
+    # this library then talks to a second, device-less runtime ("no HIP device").
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
