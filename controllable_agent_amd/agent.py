@@ -121,13 +121,16 @@ class FBDDPGAgentConfig:
 
 # the reference's Linear-layer construction order per net (fb_modules.py:91-105, 165-182, 220); each entry is
 # (state_dict prefix, in_features, out_features) -- drives an RNG-stream-identical orthogonal init
-def _linear_order(net: str, o: int, a: int, g: int, d: int, H: int, Fd: int, Hb: int):
+def _linear_order(net: str, o: int, a: int, g: int, d: int, H: int, Fd: int, Hb: int, add_trunk: bool = False):
+    """(name, in, out) of every nn.Linear in module-construction order (fb_modules.py:91-105, 165-182, 220)."""
+    feat = H if add_trunk else 2 * Fd
+    trunk = [("trunk.0", 2 * Fd, H)] if add_trunk else []
     if net == "actor":
-        return [("obs_net.0", o, H), ("obs_net.3", H, Fd), ("obs_z_net.0", o + d, H), ("obs_z_net.3", H, Fd),
-                ("policy.0", 2 * Fd, H), ("policy.2", H, a)]
+        return [("obs_net.0", o, H), ("obs_net.3", H, Fd), ("obs_z_net.0", o + d, H), ("obs_z_net.3", H, Fd)] + trunk + \
+               [("policy.0", feat, H), ("policy.2", H, a)]
     if net == "forward_net":
         return [("obs_action_net.0", o + a, H), ("obs_action_net.3", H, Fd), ("obs_z_net.0", o + d, H),
-                ("obs_z_net.3", H, Fd), ("F1.0", 2 * Fd, H), ("F1.2", H, d), ("F2.0", 2 * Fd, H), ("F2.2", H, d)]
+                ("obs_z_net.3", H, Fd)] + trunk + [("F1.0", feat, H), ("F1.2", H, d), ("F2.0", feat, H), ("F2.2", H, d)]
     return [("B.0", g, Hb), ("B.3", Hb, Hb), ("B.5", Hb, d)]
 
 
@@ -234,7 +237,7 @@ class FBHipAgent:
             if getattr(cfg, f) is MISSING or getattr(cfg, f) == "???":
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
-                       "add_trunk": cfg.add_trunk, "preprocess": not cfg.preprocess,
+                       "preprocess": not cfg.preprocess,
                        "nstep": cfg.nstep != 1}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -255,7 +258,7 @@ class FBHipAgent:
         self.training = True
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, goal_dim, cfg.z_dim, cfg.hidden_dim,
-                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.norm_z)))
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.norm_z)))
         self._ctx: tp.Optional[C.c_void_p] = None
         self._replay_token: tp.Optional[tp.Tuple[int, int]] = None
         self._ext_replay: tp.Optional[DeviceReplayBuffer] = None
@@ -283,13 +286,13 @@ class FBHipAgent:
         dims = (self.obs_dim, self.action_dim, self.goal_dim, c.z_dim, c.hidden_dim, c.feature_dim, c.backward_hidden_dim)
 
         def build(net: str) -> tp.Dict[str, torch.Tensor]:
-            lins = [(p, torch.nn.Linear(i, o)) for p, i, o in _linear_order(net, *dims)]
+            lins = [(p, torch.nn.Linear(i, o)) for p, i, o in _linear_order(net, *dims, add_trunk=bool(c.add_trunk))]
             sd: tp.Dict[str, torch.Tensor] = {}
             for p, lin in lins:
                 torch.nn.init.orthogonal_(lin.weight.data)
                 sd[f"{p}.weight"] = lin.weight.data
                 sd[f"{p}.bias"] = torch.zeros_like(lin.bias.data)
-                if p.endswith(".0") and not p.startswith(("F1", "F2", "policy")):      # followed by LayerNorm
+                if p.endswith(".0") and not p.startswith(("F1", "F2", "policy", "trunk")):      # followed by LayerNorm
                     pre = p[:-2]
                     sd[f"{pre}.1.weight"] = torch.ones(lin.out_features)
                     sd[f"{pre}.1.bias"] = torch.zeros(lin.out_features)
@@ -403,7 +406,7 @@ class FBHipAgent:
         self.solved_meta, self.actor_success, self.training = st["solved_meta"], [], st["training"]
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, self.goal_dim, cfg.z_dim, cfg.hidden_dim,
-                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.norm_z)))
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.norm_z)))
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)
         for k, v in st["flat"].items():

@@ -80,12 +80,15 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
     if (net == FBHIP_NET_FORWARD) {               // ForwardMap, fb_modules.py:165-182
         b.trunk("obs_action_net", o + a, H, Fd);
         b.trunk("obs_z_net", o + z, H, Fd);
-        // F1/F2 first layers are stored back to back so both heads run as ONE [2H x 2Fd] GEMM
-        b.mat("F1.0.weight", H, 2 * Fd); b.mat("F2.0.weight", H, 2 * Fd);
+        const int feat = d.add_trunk ? H : 2 * Fd;   // width of what feeds the heads
+        if (d.add_trunk) { b.mat("trunk.0.weight", H, 2 * Fd); b.vec("trunk.0.bias", H); }
+        // F1/F2 first layers are stored back to back so both heads run as ONE [2H x feat] GEMM
+        b.mat("F1.0.weight", H, feat); b.mat("F2.0.weight", H, feat);
         b.vec("F1.0.bias", H); b.vec("F2.0.bias", H);
         b.mat("F1.2.weight", z, H); b.vec("F1.2.bias", z);
         b.mat("F2.2.weight", z, H); b.vec("F2.2.bias", z);
         append(order, trunk_names("obs_action_net")); append(order, trunk_names("obs_z_net"));
+        if (d.add_trunk) append(order, {"trunk.0.weight", "trunk.0.bias"});
         append(order, {"F1.0.weight", "F1.0.bias", "F1.2.weight", "F1.2.bias",
                        "F2.0.weight", "F2.0.bias", "F2.2.weight", "F2.2.bias"});
     } else if (net == FBHIP_NET_BACKWARD) {       // BackwardMap, fb_modules.py:220
@@ -98,9 +101,11 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
     } else {                                      // Actor, fb_modules.py:91-105
         b.trunk("obs_net", o, H, Fd);
         b.trunk("obs_z_net", o + z, H, Fd);
-        b.mat("policy.0.weight", H, 2 * Fd); b.vec("policy.0.bias", H);
+        if (d.add_trunk) { b.mat("trunk.0.weight", H, 2 * Fd); b.vec("trunk.0.bias", H); }
+        b.mat("policy.0.weight", H, d.add_trunk ? H : 2 * Fd); b.vec("policy.0.bias", H);
         b.mat("policy.2.weight", a, H); b.vec("policy.2.bias", a);
         append(order, trunk_names("obs_net")); append(order, trunk_names("obs_z_net"));
+        if (d.add_trunk) append(order, {"trunk.0.weight", "trunk.0.bias"});
         append(order, {"policy.0.weight", "policy.0.bias", "policy.2.weight", "policy.2.bias"});
     }
     return b.finish(order);
@@ -122,8 +127,8 @@ int check_dims(const fbhip_dims* d) {
 // ------------------------------------------------------------------------------------------------ workspace
 struct Buf { float* p = nullptr; int rows = 0, cols = 0, ld = 0; };
 struct BSet { Buf pre1, t1, r2, y, Bm; float* stats = nullptr; float* norms = nullptr; };
-struct FSet { Buf pre1a, t1a, pre1z, t1z, h, p, F1, F2; float* statsA = nullptr; float* statsZ = nullptr; };
-struct ASet { Buf pre1o, t1o, pre1z, t1z, h, p, premu, mu; float* statsO = nullptr; float* statsZ = nullptr; };
+struct FSet { Buf pre1a, t1a, pre1z, t1z, h, tr, p, F1, F2; float* statsA = nullptr; float* statsZ = nullptr; };
+struct ASet { Buf pre1o, t1o, pre1z, t1z, h, tr, p, premu, mu; float* statsO = nullptr; float* statsZ = nullptr; };
 
 struct Ws {
     StepState* st = nullptr;
@@ -134,7 +139,7 @@ struct Ws {
     BSet bsA, bsO, bsM, bsF; // target / online passes on next_goal, z-mix pass on backward_input[perm], hindsight pass
     FSet fsT, fsO;
     ASet as;
-    Buf dF1, dF2, dBm, dy, dp, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov, inv_cov, BinvC;
+    Buf dF1, dF2, dBm, dy, dp, dtr, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov, inv_cov, BinvC;
     float* ln_partials = nullptr;
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
     float* splitk = nullptr;            // split-K partial slab
@@ -207,14 +212,14 @@ Ws carve(const fbhip_dims& d, void* base) {
     }
     for (FSet* s : {&w.fsT, &w.fsO}) {
         s->pre1a = c.buf(B, H); s->t1a = c.buf(B, H); s->pre1z = c.buf(B, H); s->t1z = c.buf(B, H);
-        s->h = c.buf(B, 2 * Fd); s->p = c.buf(B, 2 * H); s->F1 = c.buf(B, z); s->F2 = c.buf(B, z);
+        s->h = c.buf(B, 2 * Fd); s->tr = c.buf(d.add_trunk ? B : 1, H); s->p = c.buf(B, 2 * H); s->F1 = c.buf(B, z); s->F2 = c.buf(B, z);
         s->statsA = c.f(2 * (size_t)B); s->statsZ = c.f(2 * (size_t)B);
     }
     w.as.pre1o = c.buf(B, H); w.as.t1o = c.buf(B, H); w.as.pre1z = c.buf(B, H); w.as.t1z = c.buf(B, H);
-    w.as.h = c.buf(B, 2 * Fd); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, a); w.as.mu = c.buf(B, a);
+    w.as.h = c.buf(B, 2 * Fd); w.as.tr = c.buf(d.add_trunk ? B : 1, H); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, a); w.as.mu = c.buf(B, a);
     w.as.statsO = c.f(2 * (size_t)B); w.as.statsZ = c.f(2 * (size_t)B);
     w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
-    w.dp = c.buf(B, 2 * H); w.dh = c.buf(B, 2 * Fd); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
+    w.dp = c.buf(B, 2 * H); w.dtr = c.buf(d.add_trunk ? B : 1, H); w.dh = c.buf(B, 2 * Fd); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
     w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
     w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
@@ -224,7 +229,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.splitk = c.f((size_t)6 << 20);
     w.rw = c.f((size_t)B * B); w.rw_u = c.f(B); w.ymixw = c.buf(B, z);
     w.act_in = c.f(act_in_floats(d));
-    w.act_vec = c.f((size_t)4 * 2048 + 256);
+    w.act_vec = c.f((size_t)5 * 2048 + 256);
     w.act_out = c.f(64);
     w.total_bytes = (c.cur + 255) & ~(size_t)255;
     return w;
@@ -232,9 +237,9 @@ Ws carve(const fbhip_dims& d, void* base) {
 
 // ------------------------------------------------------------------------------------------------ weights
 struct TrunkP { float *W1, *b1, *g1, *be1, *W2, *b2; int k1, ld1; };
-struct FwdP { TrunkP oa, oz; float *W3s, *b3s, *W4[2], *b4[2]; };
+struct FwdP { TrunkP oa, oz; float *Wt = nullptr, *bt = nullptr; float *W3s, *b3s, *W4[2], *b4[2]; };   // Wt: add_trunk
 struct BwdP { float *W1, *b1, *g1, *be1, *W2, *b2, *W3, *b3; };
-struct ActP { TrunkP o, oz; float *W3, *b3, *W4, *b4; };
+struct ActP { TrunkP o, oz; float *Wt = nullptr, *bt = nullptr; float *W3, *b3, *W4, *b4; };
 
 TrunkP trunk_p(float* base, const NetLayout& L, const std::string& p) {
     const Slot& w1 = L.by_name.at(p + ".0.weight");
@@ -250,6 +255,7 @@ TrunkP trunk_p(float* base, const NetLayout& L, const std::string& p) {
 FwdP fwd_p(float* base, const NetLayout& L) {
     FwdP f;
     f.oa = trunk_p(base, L, "obs_action_net"); f.oz = trunk_p(base, L, "obs_z_net");
+    if (L.by_name.count("trunk.0.weight")) { f.Wt = base + L.by_name.at("trunk.0.weight").off; f.bt = base + L.by_name.at("trunk.0.bias").off; }
     f.W3s = base + L.by_name.at("F1.0.weight").off; f.b3s = base + L.by_name.at("F1.0.bias").off;
     f.W4[0] = base + L.by_name.at("F1.2.weight").off; f.b4[0] = base + L.by_name.at("F1.2.bias").off;
     f.W4[1] = base + L.by_name.at("F2.2.weight").off; f.b4[1] = base + L.by_name.at("F2.2.bias").off;
@@ -266,6 +272,7 @@ BwdP bwd_p(float* base, const NetLayout& L) {
 ActP act_p(float* base, const NetLayout& L) {
     ActP a;
     a.o = trunk_p(base, L, "obs_net"); a.oz = trunk_p(base, L, "obs_z_net");
+    if (L.by_name.count("trunk.0.weight")) { a.Wt = base + L.by_name.at("trunk.0.weight").off; a.bt = base + L.by_name.at("trunk.0.bias").off; }
     a.W3 = base + L.by_name.at("policy.0.weight").off; a.b3 = base + L.by_name.at("policy.0.bias").off;
     a.W4 = base + L.by_name.at("policy.2.weight").off; a.b4 = base + L.by_name.at("policy.2.bias").off;
     return a;
@@ -495,8 +502,16 @@ void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda
         o.gemms.push_back(P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU));
         o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU));
     });
+    // what feeds the heads: h [2Fd], or with add_trunk relu(trunk(h)) [H]   (fb_modules.py:194-195)
+    const bool trunk = d.add_trunk != 0;
+    const int feat = trunk ? H : 2 * Fd;
+    if (trunk)
+        out.push_back([=](Ops& o) {
+            o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.Wt, 2 * Fd, 1, Sp->tr.p, H, rows, H, 2 * Fd, W.bt, EPI_BIAS_RELU));
+        });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.W3s, 2 * Fd, 1, Sp->p.p, 2 * H, rows, 2 * H, 2 * Fd, W.b3s, EPI_BIAS_RELU));
+        const float* x = trunk ? Sp->tr.p : Sp->h.p;
+        o.gemms.push_back(P(x, feat, 1, W.W3s, feat, 1, Sp->p.p, 2 * H, rows, 2 * H, feat, W.b3s, EPI_BIAS_RELU));
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS));
@@ -533,10 +548,19 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
         o.gemms.push_back(P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
         heads_dgrad_ops(c, W, *Sp, rows, o);
     });
+    const bool trunk = d.add_trunk != 0;
+    const int feat = trunk ? H : 2 * Fd;
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->dp.p, 2 * H, 0, Sp->h.p, 2 * Fd, 0, G.W3s, 2 * Fd, 2 * H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s));
-        o.gemms.push_back(P(w->dp.p, 2 * H, 1, W.W3s, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, 2 * H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
+        const float* x = trunk ? Sp->tr.p : Sp->h.p;          // input of the heads' first layer and its relu mask
+        float* dx = trunk ? w->dtr.p : w->dh.p;
+        o.gemms.push_back(P(w->dp.p, 2 * H, 0, x, feat, 0, G.W3s, feat, 2 * H, feat, rows, nullptr, EPI_NONE, nullptr, 0, G.b3s));
+        o.gemms.push_back(P(w->dp.p, 2 * H, 1, W.W3s, feat, 0, dx, feat, rows, feat, 2 * H, nullptr, EPI_MASK_RELU, x, feat));
     });
+    if (trunk)
+        out.push_back([=](Ops& o) {
+            o.gemms.push_back(P(w->dtr.p, H, 0, Sp->h.p, 2 * Fd, 0, G.Wt, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.bt));
+            o.gemms.push_back(P(w->dtr.p, H, 1, W.Wt, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
+        });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->dh.p, 2 * Fd, 0, Sp->t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2));
         o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
@@ -642,8 +666,14 @@ void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, cons
         o.gemms.push_back(P(Sp->t1o.p, H, 1, W.o.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU));
         o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU));
     });
+    const bool trunk = d.add_trunk != 0;                     // fb_modules.py:116-117
+    const int feat = trunk ? H : 2 * Fd;
+    if (trunk)
+        out.push_back([=](Ops& o) {
+            o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.Wt, 2 * Fd, 1, Sp->tr.p, H, rows, H, 2 * Fd, W.bt, EPI_BIAS_RELU));
+        });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.W3, 2 * Fd, 1, Sp->p.p, H, rows, H, 2 * Fd, W.b3, EPI_BIAS_RELU));
+        o.gemms.push_back(P(trunk ? Sp->tr.p : Sp->h.p, feat, 1, W.W3, feat, 1, Sp->p.p, H, rows, H, feat, W.b3, EPI_BIAS_RELU));
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS));
@@ -667,10 +697,19 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
         o.gemms.push_back(P(w->a_dpremu.p, La, 0, Sp->p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
         o.gemms.push_back(P(w->a_dpremu.p, La, 1, W.W4, H, 0, w->a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, Sp->p.p, H));
     });
+    const bool trunk = d.add_trunk != 0;
+    const int feat = trunk ? H : 2 * Fd;
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->a_dp.p, H, 0, Sp->h.p, 2 * Fd, 0, G.W3, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
-        o.gemms.push_back(P(w->a_dp.p, H, 1, W.W3, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
+        const float* x = trunk ? Sp->tr.p : Sp->h.p;
+        float* dx = trunk ? w->dtr.p : w->dh.p;
+        o.gemms.push_back(P(w->a_dp.p, H, 0, x, feat, 0, G.W3, feat, H, feat, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
+        o.gemms.push_back(P(w->a_dp.p, H, 1, W.W3, feat, 0, dx, feat, rows, feat, H, nullptr, EPI_MASK_RELU, x, feat));
     });
+    if (trunk)
+        out.push_back([=](Ops& o) {
+            o.gemms.push_back(P(w->dtr.p, H, 0, Sp->h.p, 2 * Fd, 0, G.Wt, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.bt));
+            o.gemms.push_back(P(w->dtr.p, H, 1, W.Wt, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
+        });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->dh.p, 2 * Fd, 0, Sp->t1o.p, H, 0, G.o.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b2));
         o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
@@ -852,10 +891,20 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // data-gradient only, along the action path of forward_net (the reference also computes and discards every
         // weight gradient of forward_net here)
         ch.push_back([=, &w](Ops& o2) { heads_dgrad_ops(c, c->F_p, w.fsO, B, o2); });
-        ch.push_back([=, &w](Ops& o2) {
-            o2.gemms.push_back(P(w.dp.p, 2 * H, 1, c->F_p.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, 2 * H, nullptr, EPI_MASK_RELU,
-                                 w.fsO.h.p, 2 * Fd));
-        });
+        if (d.add_trunk) {
+            ch.push_back([=, &w](Ops& o2) {          // d relu(trunk(h)) ...
+                o2.gemms.push_back(P(w.dp.p, 2 * H, 1, c->F_p.W3s, H, 0, w.dtr.p, H, B, H, 2 * H, nullptr, EPI_MASK_RELU, w.fsO.tr.p, H));
+            });
+            ch.push_back([=, &w](Ops& o2) {          // ... then only the obs_action half of h matters
+                o2.gemms.push_back(P(w.dtr.p, H, 1, c->F_p.Wt, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, H, nullptr, EPI_MASK_RELU,
+                                     w.fsO.h.p, 2 * Fd));
+            });
+        } else {
+            ch.push_back([=, &w](Ops& o2) {
+                o2.gemms.push_back(P(w.dp.p, 2 * H, 1, c->F_p.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, 2 * H, nullptr, EPI_MASK_RELU,
+                                     w.fsO.h.p, 2 * Fd));
+            });
+        }
         ch.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.dh.p, 2 * Fd, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fd)); });
         ch.push_back([=, &w](Ops& o2) {
             o2.lnb.push_back(LnBwdProblem{w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
@@ -1186,9 +1235,18 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
     g2.p[0] = GV(pre1o, A.o.W2, H, A.o.b2, h, Fd, H, true, A.o.g1, A.o.be1, H);
     g2.p[1] = GV(pre1z, A.oz.W2, H, A.oz.b2, h + Fd, Fd, H, true, A.oz.g1, A.oz.be1, H);
     HIPCK(c, launch_gemv_group(g2, s));
-    // ... policy trunk ...
+    // ... (add_trunk: one more Linear + ReLU, fb_modules.py:116-117) policy hidden layer ...
+    const float* feat = h;
+    int nfeat = 2 * Fd;
+    if (d.add_trunk) {
+        float* tr = pv + 2048;
+        GemvGroup gt{}; gt.n = 1;
+        gt.p[0] = GV(h, A.Wt, 2 * Fd, A.bt, tr, H, 2 * Fd, true);
+        HIPCK(c, launch_gemv_group(gt, s));
+        feat = tr; nfeat = H;
+    }
     GemvGroup g3{}; g3.n = 1;
-    g3.p[0] = GV(h, A.W3, 2 * Fd, A.b3, pv, H, 2 * Fd, true);
+    g3.p[0] = GV(feat, A.W3, nfeat, A.b3, pv, H, nfeat, true);
     HIPCK(c, launch_gemv_group(g3, s));
     // ... head + TruncatedNormal
     HIPCK(c, launch_act_head(pv, A.W4, H, A.b4, a, H, stddev, eval_mode, has_noise ? w.act_in + act_noise_off(d) : nullptr,

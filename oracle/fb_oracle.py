@@ -55,6 +55,7 @@ class OracleConfig:
     future: float = 1.0           # ReplayBuffer._future; < 1 => future_idx = step + Geometric(1 - future) (:157-161)
     norm_z: bool = True           # False: B unprojected, z = sqrt(d) U g/|g| (fb_ddpg.py:227-231, fb_modules.py:228-229)
     rand_weight: bool = False     # mixed rows = (u * normalize(rand[B])) @ B(backward_input)  (fb_ddpg.py:475-482)
+    add_trunk: bool = False       # extra Linear(2Fd, H)+ReLU "trunk" after the two preprocess nets (fb_modules.py:93-98,168-173)
 
 
 @dataclasses.dataclass
@@ -126,18 +127,26 @@ def forward_map_shapes(cfg: OracleConfig):
     """ForwardMap parameter list in ``parameters()`` order (fb_modules.py:165-182)."""
     o, a, d, H, Fd = cfg.obs_dim, cfg.action_dim, cfg.z_dim, cfg.hidden_dim, cfg.feature_dim
     out = _trunk_shapes("obs_action_net", o + a, H, Fd) + _trunk_shapes("obs_z_net", o + d, H, Fd)
+    feat = 2 * Fd
+    if cfg.add_trunk:                                      # mlp(2 * feature_dim, hidden_dim, "irelu")
+        out += [("trunk.0.weight", (H, 2 * Fd)), ("trunk.0.bias", (H,))]
+        feat = H
     for head in ("F1", "F2"):
-        out += [(f"{head}.0.weight", (H, 2 * Fd)), (f"{head}.0.bias", (H,)),
+        out += [(f"{head}.0.weight", (H, feat)), (f"{head}.0.bias", (H,)),
                 (f"{head}.2.weight", (d, H)), (f"{head}.2.bias", (d,))]
     return out
 
 
 def actor_shapes(cfg: OracleConfig):
-    """Actor parameter list (fb_modules.py:91-105, preprocess=True, add_trunk=False)."""
+    """Actor parameter list (fb_modules.py:91-105, preprocess=True)."""
     o, a, d, H, Fd = cfg.obs_dim, cfg.action_dim, cfg.z_dim, cfg.hidden_dim, cfg.feature_dim
-    return (_trunk_shapes("obs_net", o, H, Fd) + _trunk_shapes("obs_z_net", o + d, H, Fd)
-            + [("policy.0.weight", (H, 2 * Fd)), ("policy.0.bias", (H,)),
-               ("policy.2.weight", (a, H)), ("policy.2.bias", (a,))])
+    out = _trunk_shapes("obs_net", o, H, Fd) + _trunk_shapes("obs_z_net", o + d, H, Fd)
+    feat = 2 * Fd
+    if cfg.add_trunk:
+        out += [("trunk.0.weight", (H, 2 * Fd)), ("trunk.0.bias", (H,))]
+        feat = H
+    return out + [("policy.0.weight", (H, feat)), ("policy.0.bias", (H,)),
+                  ("policy.2.weight", (a, H)), ("policy.2.bias", (a,))]
 
 
 def backward_map_shapes(cfg: OracleConfig):
@@ -184,6 +193,8 @@ def forward_map(p: Params, obs, z, action) -> tp.Tuple[torch.Tensor, torch.Tenso
     obs_action = _trunk(p, "obs_action_net", torch.cat([obs, action], dim=-1))
     obs_z = _trunk(p, "obs_z_net", torch.cat([obs, z], dim=-1))
     h = torch.cat([obs_action, obs_z], dim=-1)
+    if "trunk.0.weight" in p:                              # add_trunk (fb_modules.py:194-195)
+        h = torch.relu(F.linear(h, p["trunk.0.weight"], p["trunk.0.bias"]))
     outs = []
     for head in ("F1", "F2"):
         t = torch.relu(F.linear(h, p[f"{head}.0.weight"], p[f"{head}.0.bias"]))
@@ -210,6 +221,8 @@ def actor_mu(p: Params, obs, z) -> torch.Tensor:
     obs_z = _trunk(p, "obs_z_net", torch.cat([obs, z], dim=-1))
     ob = _trunk(p, "obs_net", obs)
     h = torch.cat([ob, obs_z], dim=-1)
+    if "trunk.0.weight" in p:                              # add_trunk (fb_modules.py:116-117)
+        h = torch.relu(F.linear(h, p["trunk.0.weight"], p["trunk.0.bias"]))
     t = torch.relu(F.linear(h, p["policy.0.weight"], p["policy.0.bias"]))
     return torch.tanh(F.linear(t, p["policy.2.weight"], p["policy.2.bias"]))
 

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
 
 def test_parameter_counts_match_reference(lib):
     """SURVEY.md appendix B (confirmed by instantiating the reference): walker, z_dim=50."""
-    d = lib.Dims(1024, 24, 6, 24, 50, 1024, 512, 526, 0, 1)
+    d = lib.Dims(1024, 24, 6, 24, 50, 1024, 512, 526, 0, 0, 1)
     l = lib.load()
     assert l.fbhip_net_param_count(C.byref(d), lib.NET_FORWARD) == 3_363_940
     assert l.fbhip_net_param_count(C.byref(d), lib.NET_BACKWARD) == 317_754
@@ -39,7 +39,7 @@ def test_parameter_counts_match_reference(lib):
 
 def test_layout_is_aligned_and_disjoint(lib):
     l = lib.load()
-    for dims in (lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 1), lib.Dims(1024, 78, 12, 2, 100, 1024, 512, 526, 1, 1)):
+    for dims in (lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1), lib.Dims(1024, 78, 12, 2, 100, 1024, 512, 526, 1, 0, 1)):
         for net in range(3):
             spans = []
             for i in range(l.fbhip_layout_count(C.byref(dims), net)):
@@ -55,7 +55,7 @@ def test_layout_is_aligned_and_disjoint(lib):
 
 def test_bad_dims_fail_loudly(lib):
     l = lib.load()
-    bad = lib.Dims(1024, 24, 6, 24, 50, 1022, 512, 526, 0, 1)       # hidden_dim % 4 != 0
+    bad = lib.Dims(1024, 24, 6, 24, 50, 1022, 512, 526, 0, 0, 1)       # hidden_dim % 4 != 0
     assert l.fbhip_net_numel(C.byref(bad), 0) < 0
     assert b"multiples of 4" in l.fbhip_last_error(None)
     ctx = C.c_void_p()
@@ -64,7 +64,7 @@ def test_bad_dims_fail_loudly(lib):
 
 def test_unbound_context_is_an_error_not_a_crash(lib):
     l = lib.load()
-    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 1)
+    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1)
     ctx = C.c_void_p()
     assert l.fbhip_create(C.byref(d), C.byref(ctx)) == 0
     hp = lib.HParams()

@@ -37,7 +37,8 @@ def _param_close(got, ref, lr, name):
 @pytest.mark.parametrize("name,goal_space", [("tiny_trace", None), ("tiny_goal_trace", "simplified_walker"),
                                              ("tiny_future_trace", None), ("tiny_future_goal_trace", "simplified_walker"),
                                              ("tiny_nonorm_trace", None), ("tiny_randw_trace", None),
-                                             ("tiny_randw_nonorm_trace", "simplified_walker")])
+                                             ("tiny_randw_nonorm_trace", "simplified_walker"),
+                                             ("tiny_trunk_trace", "simplified_walker")])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
@@ -492,3 +493,23 @@ def test_rand_weight_device_draws():
     mixed = agent.workspace_view("mix_uniform").cpu()[0] < cfg.mix_ratio
     z = agent.workspace_view("z").cpu()
     assert 0.3 < float(mixed.float().mean()) < 0.7 and H.rel_err(z[mixed], want[mixed]) < 2e-5
+
+
+def test_add_trunk_inference_paths():
+    """add_trunk=True: the batched and the batch-1 actor paths and forward_map agree with the oracle's networks."""
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=16, add_trunk=True)
+    rng = np.random.default_rng(23)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    agent = H.make_hip_agent(cfg, nets)
+    assert "trunk.0.weight" in agent.actor.state_dict() and agent.forward_net.state_dict()["F1.0.weight"].shape == (32, 32)
+    obs = rng.standard_normal((6, cfg.obs_dim)).astype(np.float32)
+    z = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((6, cfg.z_dim)).astype(np.float32)), cfg.z_dim)
+    act = torch.from_numpy(rng.uniform(-1, 1, (6, cfg.action_dim)).astype(np.float32))
+    mu = fo.actor_mu(nets["actor"], torch.from_numpy(obs), z)
+    got = agent._actor(torch.from_numpy(obs).cuda(), z.cuda(), None, 0.2, None).cpu()
+    assert H.rel_err(got, mu) < 2e-5
+    np.testing.assert_allclose(agent.act(obs[0], {"z": z[0].numpy()}, 0, eval_mode=True), mu[0].numpy(), rtol=2e-5, atol=2e-6)
+    F1, F2 = fo.forward_map(nets["forward_net"], torch.from_numpy(obs), z, act)
+    g1, g2 = agent._forward_map(torch.from_numpy(obs).cuda(), z.cuda(), act.cuda())
+    assert H.rel_err(g1.cpu(), F1) < 2e-5 and H.rel_err(g2.cpu(), F2) < 2e-5
