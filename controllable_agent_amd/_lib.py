@@ -24,7 +24,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK_RELU, EPI_TANH_BWD = range(5)
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
-                                          "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "norm_z")]
+                                          "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z")]
 
 
 class HParams(C.Structure):
@@ -103,7 +103,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 5:
+    if lib.fbhip_abi_version() != 6:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

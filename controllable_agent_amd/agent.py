@@ -121,8 +121,14 @@ class FBDDPGAgentConfig:
 
 # the reference's Linear-layer construction order per net (fb_modules.py:91-105, 165-182, 220); each entry is
 # (state_dict prefix, in_features, out_features) -- drives an RNG-stream-identical orthogonal init
-def _linear_order(net: str, o: int, a: int, g: int, d: int, H: int, Fd: int, Hb: int, add_trunk: bool = False):
+def _linear_order(net: str, o: int, a: int, g: int, d: int, H: int, Fd: int, Hb: int, add_trunk: bool = False,
+                  preprocess: bool = True):
     """(name, in, out) of every nn.Linear in module-construction order (fb_modules.py:91-105, 165-182, 220)."""
+    if not preprocess and net != "backward_net":       # one trunk on the concatenated input (fb_modules.py:99-103, 174-178)
+        if net == "actor":
+            return [("trunk.0", o + d, H), ("trunk.3", H, H), ("trunk.5", H, H), ("policy.0", H, H), ("policy.2", H, a)]
+        return [("trunk.0", o + d + a, H), ("trunk.3", H, H), ("trunk.5", H, H),
+                ("F1.0", H, H), ("F1.2", H, d), ("F2.0", H, H), ("F2.2", H, d)]
     feat = H if add_trunk else 2 * Fd
     trunk = [("trunk.0", 2 * Fd, H)] if add_trunk else []
     if net == "actor":
@@ -145,13 +151,22 @@ class NetView:
         self._forward = forward
         self.training = True
         self._views: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
+        self._pads: tp.List[torch.Tensor] = []        # the alignment columns right of every matrix (must stay zero)
         for t in layout:
             n = t.name.decode()
-            seg = flat[t.offset:t.offset + t.rows * t.ld].view(t.rows, t.ld)[:, :t.cols]
+            full = flat[t.offset:t.offset + t.rows * t.ld].view(t.rows, t.ld)
+            seg = full[:, :t.cols]
+            if t.ld > t.cols:
+                self._pads.append(full[:, t.cols:])
             self._views[n] = seg[0] if (n.endswith("bias") or ".1." in n) else seg      # vectors: 1-D views
 
     def state_dict(self) -> "collections.OrderedDict[str, torch.Tensor]":
         return collections.OrderedDict(self._views)
+
+    def pad_abs_max(self) -> float:
+        """max |x| over the alignment columns.  The kernels run GEMMs over padded widths and rely on these being zero:
+        anything else means a panel leaked foreign columns into a weight gradient."""
+        return max([float(p.abs().max()) for p in self._pads], default=0.0)
 
     def named_parameters(self) -> tp.Iterator[tp.Tuple[str, torch.Tensor]]:
         return iter(self._views.items())
@@ -237,7 +252,6 @@ class FBHipAgent:
             if getattr(cfg, f) is MISSING or getattr(cfg, f) == "???":
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
-                       "preprocess": not cfg.preprocess,
                        "nstep": cfg.nstep != 1}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -258,7 +272,8 @@ class FBHipAgent:
         self.training = True
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, goal_dim, cfg.z_dim, cfg.hidden_dim,
-                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.norm_z)))
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.preprocess)),
+                          int(bool(cfg.norm_z)))
         self._ctx: tp.Optional[C.c_void_p] = None
         self._replay_token: tp.Optional[tp.Tuple[int, int]] = None
         self._ext_replay: tp.Optional[DeviceReplayBuffer] = None
@@ -286,13 +301,15 @@ class FBHipAgent:
         dims = (self.obs_dim, self.action_dim, self.goal_dim, c.z_dim, c.hidden_dim, c.feature_dim, c.backward_hidden_dim)
 
         def build(net: str) -> tp.Dict[str, torch.Tensor]:
-            lins = [(p, torch.nn.Linear(i, o)) for p, i, o in _linear_order(net, *dims, add_trunk=bool(c.add_trunk))]
+            lins = [(p, torch.nn.Linear(i, o)) for p, i, o in _linear_order(net, *dims, add_trunk=bool(c.add_trunk),
+                                                                               preprocess=bool(c.preprocess))]
             sd: tp.Dict[str, torch.Tensor] = {}
             for p, lin in lins:
                 torch.nn.init.orthogonal_(lin.weight.data)
                 sd[f"{p}.weight"] = lin.weight.data
                 sd[f"{p}.bias"] = torch.zeros_like(lin.bias.data)
-                if p.endswith(".0") and not p.startswith(("F1", "F2", "policy", "trunk")):      # followed by LayerNorm
+                single = not c.preprocess and net != "backward_net"
+                if p.endswith(".0") and not p.startswith(("F1", "F2", "policy") + (() if single else ("trunk",))):  # LayerNorm next
                     pre = p[:-2]
                     sd[f"{pre}.1.weight"] = torch.ones(lin.out_features)
                     sd[f"{pre}.1.bias"] = torch.zeros(lin.out_features)
@@ -406,7 +423,8 @@ class FBHipAgent:
         self.solved_meta, self.actor_success, self.training = st["solved_meta"], [], st["training"]
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, self.goal_dim, cfg.z_dim, cfg.hidden_dim,
-                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.norm_z)))
+                          cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.preprocess)),
+                          int(bool(cfg.norm_z)))
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)
         for k, v in st["flat"].items():

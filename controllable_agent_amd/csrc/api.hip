@@ -67,6 +67,21 @@ struct LayoutBuilder {
     }
 };
 
+// Front-end geometry of ForwardMap / Actor (fb_modules.py:90-103, 165-178).  preprocess (default): TWO LayerNorm branches
+// (in -> H -> Fd) whose outputs are concatenated (2 Fd wide), optionally followed by a Linear(2Fd, H) + ReLU trunk
+// (add_trunk).  preprocess == 0: ONE LayerNorm branch on the concatenated input with Fd := H, always followed by the
+// trunk's last Linear(H, H) + ReLU -- the same pipeline with one branch.
+struct Geom { bool single, trunk; int Fo, hw, feat; };
+Geom geom_of(const fbhip_dims& d) {
+    Geom g;
+    g.single = d.preprocess == 0;
+    g.trunk = g.single || d.add_trunk != 0;
+    g.Fo = g.single ? d.hidden_dim : d.feature_dim;          // a branch's output width
+    g.hw = g.single ? d.hidden_dim : 2 * d.feature_dim;      // concatenated branch outputs
+    g.feat = g.trunk ? d.hidden_dim : g.hw;                  // what feeds the heads / the policy
+    return g;
+}
+
 std::vector<std::string> trunk_names(const std::string& p) {
     return {p + ".0.weight", p + ".0.bias", p + ".1.weight", p + ".1.bias", p + ".3.weight", p + ".3.bias"};
 }
@@ -77,18 +92,27 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
               Hb = d.backward_hidden_dim;
     LayoutBuilder b;
     std::vector<std::string> order;
+    const Geom gm = geom_of(d);
     if (net == FBHIP_NET_FORWARD) {               // ForwardMap, fb_modules.py:165-182
-        b.trunk("obs_action_net", o + a, H, Fd);
-        b.trunk("obs_z_net", o + z, H, Fd);
-        const int feat = d.add_trunk ? H : 2 * Fd;   // width of what feeds the heads
-        if (d.add_trunk) { b.mat("trunk.0.weight", H, 2 * Fd); b.vec("trunk.0.bias", H); }
+        if (gm.single) {                          // trunk = mlp(o + z + a, H, "ntanh", H, "irelu", H, "irelu")
+            b.trunk("trunk", o + z + a, H, H);
+            b.mat("trunk.5.weight", H, H); b.vec("trunk.5.bias", H);
+        } else {
+            b.trunk("obs_action_net", o + a, H, Fd);
+            b.trunk("obs_z_net", o + z, H, Fd);
+            if (d.add_trunk) { b.mat("trunk.0.weight", H, 2 * Fd); b.vec("trunk.0.bias", H); }
+        }
         // F1/F2 first layers are stored back to back so both heads run as ONE [2H x feat] GEMM
-        b.mat("F1.0.weight", H, feat); b.mat("F2.0.weight", H, feat);
+        b.mat("F1.0.weight", H, gm.feat); b.mat("F2.0.weight", H, gm.feat);
         b.vec("F1.0.bias", H); b.vec("F2.0.bias", H);
         b.mat("F1.2.weight", z, H); b.vec("F1.2.bias", z);
         b.mat("F2.2.weight", z, H); b.vec("F2.2.bias", z);
-        append(order, trunk_names("obs_action_net")); append(order, trunk_names("obs_z_net"));
-        if (d.add_trunk) append(order, {"trunk.0.weight", "trunk.0.bias"});
+        if (gm.single) {
+            append(order, trunk_names("trunk")); append(order, {"trunk.5.weight", "trunk.5.bias"});
+        } else {
+            append(order, trunk_names("obs_action_net")); append(order, trunk_names("obs_z_net"));
+            if (d.add_trunk) append(order, {"trunk.0.weight", "trunk.0.bias"});
+        }
         append(order, {"F1.0.weight", "F1.0.bias", "F1.2.weight", "F1.2.bias",
                        "F2.0.weight", "F2.0.bias", "F2.2.weight", "F2.2.bias"});
     } else if (net == FBHIP_NET_BACKWARD) {       // BackwardMap, fb_modules.py:220
@@ -99,13 +123,19 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
         b.mat("B.5.weight", z, Hb, HbP); b.vec("B.5.bias", z);
         order = {"B.0.weight", "B.0.bias", "B.1.weight", "B.1.bias", "B.3.weight", "B.3.bias", "B.5.weight", "B.5.bias"};
     } else {                                      // Actor, fb_modules.py:91-105
-        b.trunk("obs_net", o, H, Fd);
-        b.trunk("obs_z_net", o + z, H, Fd);
-        if (d.add_trunk) { b.mat("trunk.0.weight", H, 2 * Fd); b.vec("trunk.0.bias", H); }
-        b.mat("policy.0.weight", H, d.add_trunk ? H : 2 * Fd); b.vec("policy.0.bias", H);
+        if (gm.single) {                          // trunk = mlp(o + z, H, "ntanh", H, "irelu", H, "irelu")
+            b.trunk("trunk", o + z, H, H);
+            b.mat("trunk.5.weight", H, H); b.vec("trunk.5.bias", H);
+            append(order, trunk_names("trunk")); append(order, {"trunk.5.weight", "trunk.5.bias"});
+        } else {
+            b.trunk("obs_net", o, H, Fd);
+            b.trunk("obs_z_net", o + z, H, Fd);
+            if (d.add_trunk) { b.mat("trunk.0.weight", H, 2 * Fd); b.vec("trunk.0.bias", H); }
+            append(order, trunk_names("obs_net")); append(order, trunk_names("obs_z_net"));
+            if (d.add_trunk) append(order, {"trunk.0.weight", "trunk.0.bias"});
+        }
+        b.mat("policy.0.weight", H, gm.feat); b.vec("policy.0.bias", H);
         b.mat("policy.2.weight", a, H); b.vec("policy.2.bias", a);
-        append(order, trunk_names("obs_net")); append(order, trunk_names("obs_z_net"));
-        if (d.add_trunk) append(order, {"trunk.0.weight", "trunk.0.bias"});
         append(order, {"policy.0.weight", "policy.0.bias", "policy.2.weight", "policy.2.bias"});
     }
     return b.finish(order);
@@ -200,8 +230,19 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.so.future_uniform = c.f(B);
     // input panels: widths padded to 32 (pad columns stay zero: the workspace is zero-initialised by the host and
     // no kernel writes them)
-    w.Xoa = c.buf(B, o + a, pad32(o + a)); w.Xoz = c.buf(B, o + z, pad32(o + z)); w.Xnoz = c.buf(B, o + z, pad32(o + z));
-    w.Xnoa = c.buf(B, o + a, pad32(o + a)); w.Xopi = c.buf(B, o + a, pad32(o + a)); w.Xo = c.buf(B, o, pad32(o));
+    const Geom gm = geom_of(d);
+    if (gm.single) {
+        // preprocess == 0: the ForwardMap panels are [obs | z | action].  The actor keeps its own [obs|z] panels: a GEMM
+        // runs over the weight's padded width, so whatever follows z in a shared panel would leak into the weight
+        // gradient's pad columns and, through Adam, into the pad weights.
+        const int wd = o + z + a;
+        w.Xoa = c.buf(B, wd, pad32(wd)); w.Xnoa = c.buf(B, wd, pad32(wd)); w.Xopi = c.buf(B, wd, pad32(wd));
+        w.Xoz = c.buf(B, o + z, pad32(o + z)); w.Xnoz = c.buf(B, o + z, pad32(o + z));
+    } else {
+        w.Xoa = c.buf(B, o + a, pad32(o + a)); w.Xoz = c.buf(B, o + z, pad32(o + z)); w.Xnoz = c.buf(B, o + z, pad32(o + z));
+        w.Xnoa = c.buf(B, o + a, pad32(o + a)); w.Xopi = c.buf(B, o + a, pad32(o + a));
+    }
+    w.Xo = c.buf(B, o, pad32(o));
     w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.fgoal = c.buf(B, g, pad32(g));
     w.z = c.buf(B, z); w.zrand = c.buf(B, z);
     w.disc = c.f(B);
@@ -212,14 +253,14 @@ Ws carve(const fbhip_dims& d, void* base) {
     }
     for (FSet* s : {&w.fsT, &w.fsO}) {
         s->pre1a = c.buf(B, H); s->t1a = c.buf(B, H); s->pre1z = c.buf(B, H); s->t1z = c.buf(B, H);
-        s->h = c.buf(B, 2 * Fd); s->tr = c.buf(d.add_trunk ? B : 1, H); s->p = c.buf(B, 2 * H); s->F1 = c.buf(B, z); s->F2 = c.buf(B, z);
+        s->h = c.buf(B, gm.hw); s->tr = c.buf(gm.trunk ? B : 1, H); s->p = c.buf(B, 2 * H); s->F1 = c.buf(B, z); s->F2 = c.buf(B, z);
         s->statsA = c.f(2 * (size_t)B); s->statsZ = c.f(2 * (size_t)B);
     }
     w.as.pre1o = c.buf(B, H); w.as.t1o = c.buf(B, H); w.as.pre1z = c.buf(B, H); w.as.t1z = c.buf(B, H);
-    w.as.h = c.buf(B, 2 * Fd); w.as.tr = c.buf(d.add_trunk ? B : 1, H); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, a); w.as.mu = c.buf(B, a);
+    w.as.h = c.buf(B, gm.hw); w.as.tr = c.buf(gm.trunk ? B : 1, H); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, a); w.as.mu = c.buf(B, a);
     w.as.statsO = c.f(2 * (size_t)B); w.as.statsZ = c.f(2 * (size_t)B);
     w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
-    w.dp = c.buf(B, 2 * H); w.dtr = c.buf(d.add_trunk ? B : 1, H); w.dh = c.buf(B, 2 * Fd); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
+    w.dp = c.buf(B, 2 * H); w.dtr = c.buf(gm.trunk ? B : 1, H); w.dh = c.buf(B, gm.hw); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
     w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
     w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
@@ -254,8 +295,13 @@ TrunkP trunk_p(float* base, const NetLayout& L, const std::string& p) {
 }
 FwdP fwd_p(float* base, const NetLayout& L) {
     FwdP f;
-    f.oa = trunk_p(base, L, "obs_action_net"); f.oz = trunk_p(base, L, "obs_z_net");
-    if (L.by_name.count("trunk.0.weight")) { f.Wt = base + L.by_name.at("trunk.0.weight").off; f.bt = base + L.by_name.at("trunk.0.bias").off; }
+    if (L.by_name.count("trunk.5.weight")) {                 // preprocess == 0: the one branch + the trunk's last layer
+        f.oa = trunk_p(base, L, "trunk"); f.oz = f.oa;
+        f.Wt = base + L.by_name.at("trunk.5.weight").off; f.bt = base + L.by_name.at("trunk.5.bias").off;
+    } else {
+        f.oa = trunk_p(base, L, "obs_action_net"); f.oz = trunk_p(base, L, "obs_z_net");
+        if (L.by_name.count("trunk.0.weight")) { f.Wt = base + L.by_name.at("trunk.0.weight").off; f.bt = base + L.by_name.at("trunk.0.bias").off; }
+    }
     f.W3s = base + L.by_name.at("F1.0.weight").off; f.b3s = base + L.by_name.at("F1.0.bias").off;
     f.W4[0] = base + L.by_name.at("F1.2.weight").off; f.b4[0] = base + L.by_name.at("F1.2.bias").off;
     f.W4[1] = base + L.by_name.at("F2.2.weight").off; f.b4[1] = base + L.by_name.at("F2.2.bias").off;
@@ -271,8 +317,13 @@ BwdP bwd_p(float* base, const NetLayout& L) {
 }
 ActP act_p(float* base, const NetLayout& L) {
     ActP a;
-    a.o = trunk_p(base, L, "obs_net"); a.oz = trunk_p(base, L, "obs_z_net");
-    if (L.by_name.count("trunk.0.weight")) { a.Wt = base + L.by_name.at("trunk.0.weight").off; a.bt = base + L.by_name.at("trunk.0.bias").off; }
+    if (L.by_name.count("trunk.5.weight")) {
+        a.o = trunk_p(base, L, "trunk"); a.oz = a.o;
+        a.Wt = base + L.by_name.at("trunk.5.weight").off; a.bt = base + L.by_name.at("trunk.5.bias").off;
+    } else {
+        a.o = trunk_p(base, L, "obs_net"); a.oz = trunk_p(base, L, "obs_z_net");
+        if (L.by_name.count("trunk.0.weight")) { a.Wt = base + L.by_name.at("trunk.0.weight").off; a.bt = base + L.by_name.at("trunk.0.bias").off; }
+    }
     a.W3 = base + L.by_name.at("policy.0.weight").off; a.b3 = base + L.by_name.at("policy.0.bias").off;
     a.W4 = base + L.by_name.at("policy.2.weight").off; a.b4 = base + L.by_name.at("policy.2.bias").off;
     return a;
@@ -488,29 +539,28 @@ int run_chain(fbhip_ctx* c, Chain& ch, hipStream_t s) {
 void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
                            int rows, Chain& out) {
     const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
+    const Geom gm = geom_of(d);
+    const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
     FSet* Sp = &S;
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, W.oa.ld1, W.oa.b1, EPI_BIAS));
-        o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
+        if (!gm.single) o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
     });
     out.push_back([=](Ops& o) {
         o.lnf.push_back(LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0, H});
-        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
+        if (!gm.single) o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.oa.b2, EPI_BIAS_RELU));
-        o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU));
+        o.gemms.push_back(P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, hw, rows, Fo, H, W.oa.b2, EPI_BIAS_RELU));
+        if (!gm.single) o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fo, hw, rows, Fo, H, W.oz.b2, EPI_BIAS_RELU));
     });
-    // what feeds the heads: h [2Fd], or with add_trunk relu(trunk(h)) [H]   (fb_modules.py:194-195)
-    const bool trunk = d.add_trunk != 0;
-    const int feat = trunk ? H : 2 * Fd;
-    if (trunk)
+    // what feeds the heads: h [hw], or with a trunk layer relu(trunk(h)) [H]   (fb_modules.py:194-195)
+    if (gm.trunk)
         out.push_back([=](Ops& o) {
-            o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.Wt, 2 * Fd, 1, Sp->tr.p, H, rows, H, 2 * Fd, W.bt, EPI_BIAS_RELU));
+            o.gemms.push_back(P(Sp->h.p, hw, 1, W.Wt, hw, 1, Sp->tr.p, H, rows, H, hw, W.bt, EPI_BIAS_RELU));
         });
     out.push_back([=](Ops& o) {
-        const float* x = trunk ? Sp->tr.p : Sp->h.p;
+        const float* x = gm.trunk ? Sp->tr.p : Sp->h.p;
         o.gemms.push_back(P(x, feat, 1, W.W3s, feat, 1, Sp->p.p, 2 * H, rows, 2 * H, feat, W.b3s, EPI_BIAS_RELU));
     });
     out.push_back([=](Ops& o) {
@@ -548,8 +598,9 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
         o.gemms.push_back(P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
         heads_dgrad_ops(c, W, *Sp, rows, o);
     });
-    const bool trunk = d.add_trunk != 0;
-    const int feat = trunk ? H : 2 * Fd;
+    const Geom gm = geom_of(d);
+    const int Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
+    const bool trunk = gm.trunk;
     out.push_back([=](Ops& o) {
         const float* x = trunk ? Sp->tr.p : Sp->h.p;          // input of the heads' first layer and its relu mask
         float* dx = trunk ? w->dtr.p : w->dh.p;
@@ -558,25 +609,29 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
     });
     if (trunk)
         out.push_back([=](Ops& o) {
-            o.gemms.push_back(P(w->dtr.p, H, 0, Sp->h.p, 2 * Fd, 0, G.Wt, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.bt));
-            o.gemms.push_back(P(w->dtr.p, H, 1, W.Wt, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
+            o.gemms.push_back(P(w->dtr.p, H, 0, Sp->h.p, hw, 0, G.Wt, hw, H, hw, rows, nullptr, EPI_NONE, nullptr, 0, G.bt));
+            o.gemms.push_back(P(w->dtr.p, H, 1, W.Wt, hw, 0, w->dh.p, hw, rows, hw, H, nullptr, EPI_MASK_RELU, Sp->h.p, hw));
         });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->dh.p, 2 * Fd, 0, Sp->t1a.p, H, 0, G.oa.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2));
-        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
-        o.gemms.push_back(P(w->dh.p, 2 * Fd, 1, W.oa.W2, H, 0, w->dt1a.p, H, rows, H, Fd));
-        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fd));
+        o.gemms.push_back(P(w->dh.p, hw, 0, Sp->t1a.p, H, 0, G.oa.W2, H, Fo, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b2));
+        o.gemms.push_back(P(w->dh.p, hw, 1, W.oa.W2, H, 0, w->dt1a.p, H, rows, H, Fo));
+        if (!gm.single) {
+            o.gemms.push_back(P(w->dh.p + Fo, hw, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fo, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
+            o.gemms.push_back(P(w->dh.p + Fo, hw, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fo));
+        }
     });
     out.push_back([=](Ops& o) {
         const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
         o.lnb.push_back(LnBwdProblem{w->dt1a.p, H, Sp->t1a.p, H, Sp->pre1a.p, H, Sp->statsA, W.oa.g1, w->dt1a.p, H, G.oa.g1,
                                      G.oa.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0, H});
-        o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
-                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
+        if (!gm.single)
+            o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
+                                         G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1));
-        o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
+        if (!gm.single)
+            o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
     });
 }
 
@@ -652,28 +707,30 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
 void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
                      Chain& out) {
     const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
+    const Geom gm = geom_of(d);
+    const int H = d.hidden_dim, a = d.action_dim, La = pad4(a), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
+    // preprocess == 0: the one branch reads [obs|z] (the Xz panel)
+    const float* X1 = gm.single ? Xz : Xo;
+    const int ld1 = gm.single ? ldz : ldo;
     ASet* Sp = &S;
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(Xo, ldo, 1, W.o.W1, W.o.ld1, 1, Sp->pre1o.p, H, rows, H, W.o.ld1, W.o.b1, EPI_BIAS));
-        o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
+        o.gemms.push_back(P(X1, ld1, 1, W.o.W1, W.o.ld1, 1, Sp->pre1o.p, H, rows, H, W.o.ld1, W.o.b1, EPI_BIAS));
+        if (!gm.single) o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
     });
     out.push_back([=](Ops& o) {
         o.lnf.push_back(LnFwdProblem{Sp->pre1o.p, H, W.o.g1, W.o.be1, Sp->t1o.p, H, Sp->statsO, rows, H, 0, 0, 0, H});
-        o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
+        if (!gm.single) o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(Sp->t1o.p, H, 1, W.o.W2, H, 1, Sp->h.p, 2 * Fd, rows, Fd, H, W.o.b2, EPI_BIAS_RELU));
-        o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fd, 2 * Fd, rows, Fd, H, W.oz.b2, EPI_BIAS_RELU));
+        o.gemms.push_back(P(Sp->t1o.p, H, 1, W.o.W2, H, 1, Sp->h.p, hw, rows, Fo, H, W.o.b2, EPI_BIAS_RELU));
+        if (!gm.single) o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fo, hw, rows, Fo, H, W.oz.b2, EPI_BIAS_RELU));
     });
-    const bool trunk = d.add_trunk != 0;                     // fb_modules.py:116-117
-    const int feat = trunk ? H : 2 * Fd;
-    if (trunk)
+    if (gm.trunk)                                            // fb_modules.py:116-117
         out.push_back([=](Ops& o) {
-            o.gemms.push_back(P(Sp->h.p, 2 * Fd, 1, W.Wt, 2 * Fd, 1, Sp->tr.p, H, rows, H, 2 * Fd, W.bt, EPI_BIAS_RELU));
+            o.gemms.push_back(P(Sp->h.p, hw, 1, W.Wt, hw, 1, Sp->tr.p, H, rows, H, hw, W.bt, EPI_BIAS_RELU));
         });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(trunk ? Sp->tr.p : Sp->h.p, feat, 1, W.W3, feat, 1, Sp->p.p, H, rows, H, feat, W.b3, EPI_BIAS_RELU));
+        o.gemms.push_back(P(gm.trunk ? Sp->tr.p : Sp->h.p, feat, 1, W.W3, feat, 1, Sp->p.p, H, rows, H, feat, W.b3, EPI_BIAS_RELU));
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS));
@@ -697,8 +754,11 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
         o.gemms.push_back(P(w->a_dpremu.p, La, 0, Sp->p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
         o.gemms.push_back(P(w->a_dpremu.p, La, 1, W.W4, H, 0, w->a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, Sp->p.p, H));
     });
-    const bool trunk = d.add_trunk != 0;
-    const int feat = trunk ? H : 2 * Fd;
+    const Geom gm = geom_of(d);
+    const int Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
+    const bool trunk = gm.trunk;
+    const float* X1 = gm.single ? Xz : Xo;                   // preprocess == 0: the one branch reads [obs|z]
+    const int ld1 = gm.single ? ldz : ldo;
     out.push_back([=](Ops& o) {
         const float* x = trunk ? Sp->tr.p : Sp->h.p;
         float* dx = trunk ? w->dtr.p : w->dh.p;
@@ -707,25 +767,29 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
     });
     if (trunk)
         out.push_back([=](Ops& o) {
-            o.gemms.push_back(P(w->dtr.p, H, 0, Sp->h.p, 2 * Fd, 0, G.Wt, 2 * Fd, H, 2 * Fd, rows, nullptr, EPI_NONE, nullptr, 0, G.bt));
-            o.gemms.push_back(P(w->dtr.p, H, 1, W.Wt, 2 * Fd, 0, w->dh.p, 2 * Fd, rows, 2 * Fd, H, nullptr, EPI_MASK_RELU, Sp->h.p, 2 * Fd));
+            o.gemms.push_back(P(w->dtr.p, H, 0, Sp->h.p, hw, 0, G.Wt, hw, H, hw, rows, nullptr, EPI_NONE, nullptr, 0, G.bt));
+            o.gemms.push_back(P(w->dtr.p, H, 1, W.Wt, hw, 0, w->dh.p, hw, rows, hw, H, nullptr, EPI_MASK_RELU, Sp->h.p, hw));
         });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->dh.p, 2 * Fd, 0, Sp->t1o.p, H, 0, G.o.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b2));
-        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fd, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
-        o.gemms.push_back(P(w->dh.p, 2 * Fd, 1, W.o.W2, H, 0, w->dt1a.p, H, rows, H, Fd));
-        o.gemms.push_back(P(w->dh.p + Fd, 2 * Fd, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fd));
+        o.gemms.push_back(P(w->dh.p, hw, 0, Sp->t1o.p, H, 0, G.o.W2, H, Fo, H, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b2));
+        o.gemms.push_back(P(w->dh.p, hw, 1, W.o.W2, H, 0, w->dt1a.p, H, rows, H, Fo));
+        if (!gm.single) {
+            o.gemms.push_back(P(w->dh.p + Fo, hw, 0, Sp->t1z.p, H, 0, G.oz.W2, H, Fo, H, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b2));
+            o.gemms.push_back(P(w->dh.p + Fo, hw, 1, W.oz.W2, H, 0, w->dt1z.p, H, rows, H, Fo));
+        }
     });
     out.push_back([=](Ops& o) {
         const size_t half = (size_t)((rows + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * H;
         o.lnb.push_back(LnBwdProblem{w->dt1a.p, H, Sp->t1o.p, H, Sp->pre1o.p, H, Sp->statsO, W.o.g1, w->dt1a.p, H, G.o.g1,
                                      G.o.be1, w->ln_partials, rows, H, 0, 0, 0, 0, 0, H});
-        o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
-                                     G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
+        if (!gm.single)
+            o.lnb.push_back(LnBwdProblem{w->dt1z.p, H, Sp->t1z.p, H, Sp->pre1z.p, H, Sp->statsZ, W.oz.g1, w->dt1z.p, H, G.oz.g1,
+                                         G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->dt1a.p, H, 0, Xo, ldo, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1));
-        o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
+        o.gemms.push_back(P(w->dt1a.p, H, 0, X1, ld1, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1));
+        if (!gm.single)
+            o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
     });
 }
 
@@ -734,7 +798,10 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     const fbhip_dims& d = c->d;
     Ws& w = c->w;
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
-              Fd = d.feature_dim, Lz = pad4(z), La = pad4(a);
+              Lz = pad4(z), La = pad4(a);
+    const Geom gm = geom_of(d);
+    const int Fo = gm.Fo, hw = gm.hw;
+    const int aoff = gm.single ? o + z : o;      // column of the action inside the ForwardMap input panels
     // next_goal = batch.next_goal if goal_space else batch.next_obs (fb_ddpg.py:440-443); always its own zero-padded panel
     const float* next_goal = w.next_goal.p;
     const int ld_ng = w.next_goal.ld;
@@ -769,7 +836,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
         ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld;
         ga.future_idx = hindsight ? w.so.future_idx : nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
-        ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount;
+        ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount; ga.aoff = aoff;
         HIPCK(c, launch_gather(ga, s));
         // sample_z (fb_ddpg.py:224-228) + z-mix (fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm])))
         // in one row kernel; the BackwardMap pass stops at its raw mlp output y (the kernel applies both projections)
@@ -801,9 +868,12 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             RC(run_gemms(c, {P(w.rw, B, 1, bm.p, bm.ld, 0, w.ymixw.p, Lz, B, z, B)}, s));
             ymix = w.ymixw.p;
         }
+        ZPanels zx{};                            // preprocess == 0: z also sits inside the three ForwardMap panels
+        if (gm.single) zx = ZPanels{{w.Xoa.p, w.Xnoa.p, w.Xopi.p}, {w.Xoa.ld, w.Xnoa.ld, w.Xopi.ld}};
         HIPCK(c, launch_mix_z(w.so.z_gauss, z, ymix, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, hindsight ? w.bsF.y.p : nullptr, w.so.future_uniform,
-                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, randw ? 1 : 2, s));
+                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, randw ? 1 : 2,
+                              zx, s));
     }
 
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
@@ -826,7 +896,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             // (C, D already ran with the sampler's z-mix pass when this call also covered the SAMPLE phase)
             std::vector<Chain> ch(2);
             actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0]);
-            ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + o, w.Xnoa.ld));
+            ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld));
             forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
             forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
             if (!(mask & FBHIP_PHASE_SAMPLE)) {
@@ -860,7 +930,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1]);
             if (early_actor) {
                 actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2]);
-                ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + o, w.Xopi.ld));
+                ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
             }
             RC(run_rounds(c, ch, s));
         }
@@ -877,12 +947,12 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         Chain ch;
         if ((mask & FBHIP_PHASE_ACTOR_FWD) && !early_actor) {
             actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
-            ch.push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + o, w.Xopi.ld));
+            ch.push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
         }
         forward_map_fwd_chain(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch);
         ch.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + o, w.Xopi.ld,
+                HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + aoff, w.Xopi.ld,
                                            hp.stddev, w.dF1.p, w.dF2.p, hp.want_metrics ? w.metrics : nullptr, w.pw_scratch,
                                            B, z, a, q));
                 return (int)FBHIP_OK;
@@ -891,28 +961,27 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         // data-gradient only, along the action path of forward_net (the reference also computes and discards every
         // weight gradient of forward_net here)
         ch.push_back([=, &w](Ops& o2) { heads_dgrad_ops(c, c->F_p, w.fsO, B, o2); });
-        if (d.add_trunk) {
+        // (only the branch that sees the action matters: the first Fo columns of h)
+        if (gm.trunk) {
             ch.push_back([=, &w](Ops& o2) {          // d relu(trunk(h)) ...
                 o2.gemms.push_back(P(w.dp.p, 2 * H, 1, c->F_p.W3s, H, 0, w.dtr.p, H, B, H, 2 * H, nullptr, EPI_MASK_RELU, w.fsO.tr.p, H));
             });
-            ch.push_back([=, &w](Ops& o2) {          // ... then only the obs_action half of h matters
-                o2.gemms.push_back(P(w.dtr.p, H, 1, c->F_p.Wt, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, H, nullptr, EPI_MASK_RELU,
-                                     w.fsO.h.p, 2 * Fd));
+            ch.push_back([=, &w](Ops& o2) {
+                o2.gemms.push_back(P(w.dtr.p, H, 1, c->F_p.Wt, hw, 0, w.dh.p, hw, B, Fo, H, nullptr, EPI_MASK_RELU, w.fsO.h.p, hw));
             });
         } else {
             ch.push_back([=, &w](Ops& o2) {
-                o2.gemms.push_back(P(w.dp.p, 2 * H, 1, c->F_p.W3s, 2 * Fd, 0, w.dh.p, 2 * Fd, B, Fd, 2 * H, nullptr, EPI_MASK_RELU,
-                                     w.fsO.h.p, 2 * Fd));
+                o2.gemms.push_back(P(w.dp.p, 2 * H, 1, c->F_p.W3s, hw, 0, w.dh.p, hw, B, Fo, 2 * H, nullptr, EPI_MASK_RELU, w.fsO.h.p, hw));
             });
         }
-        ch.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.dh.p, 2 * Fd, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fd)); });
+        ch.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.dh.p, hw, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fo)); });
         ch.push_back([=, &w](Ops& o2) {
             o2.lnb.push_back(LnBwdProblem{w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
                                           nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0, H});
         });
         // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
         ch.push_back([=, &w](Ops& o2) {
-            o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + o, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
+            o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
                                  EPI_TANH_BWD, w.as.mu.p, La));
         });
         actor_bwd_chain(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
@@ -1168,6 +1237,7 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
     Ws& w = c->w;
     const fbhip_dims& d = c->d;
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, z = d.z_dim;
+    const int aoff = geom_of(d).single ? o + z : o;
     std::map<std::string, Buf> m = {
         {"Xoa", w.Xoa}, {"Xoz", w.Xoz}, {"Xnoz", w.Xnoz}, {"Xnoa", w.Xnoa}, {"Xopi", w.Xopi}, {"next_goal", w.next_goal},
         {"backward_input", w.bin}, {"future_goal", w.fgoal}, {"z", w.z}, {"zrand", w.zrand}, {"F1", w.fsO.F1}, {"F2", w.fsO.F2}, {"Bm", d.norm_z ? w.bsO.Bm : w.bsO.y},
@@ -1178,9 +1248,9 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
     if (m.count(n)) b = m[n];
     else if (n == "obs") { b = w.Xoz; b.cols = o; }
     else if (n == "next_obs") { b = w.Xnoz; b.cols = o; }
-    else if (n == "action") { b = w.Xoa; b.p += o; b.cols = a; }
-    else if (n == "next_action") { b = w.Xnoa; b.p += o; b.cols = a; }
-    else if (n == "pi_action") { b = w.Xopi; b.p += o; b.cols = a; }
+    else if (n == "action") { b = w.Xoa; b.p += aoff; b.cols = a; }
+    else if (n == "next_action") { b = w.Xnoa; b.p += aoff; b.cols = a; }
+    else if (n == "pi_action") { b = w.Xopi; b.p += aoff; b.cols = a; }
     else if (n == "discount") { b.p = w.disc; b.rows = B; b.cols = 1; b.ld = 1; }
     else if (n == "metrics") { b.p = w.metrics; b.rows = 1; b.cols = FBHIP_NUM_METRICS; b.ld = FBHIP_NUM_METRICS; }
     else if (n == "z_gauss") { b.p = w.so.z_gauss; b.rows = B; b.cols = z; b.ld = z; }
@@ -1218,30 +1288,31 @@ GemvProblem GV(const float* x, const float* W, int ldw, const float* bias, float
 
 int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipStream_t s) {
     const fbhip_dims& d = c->d;
-    const int o = d.obs_dim, z = d.z_dim, a = d.action_dim, H = d.hidden_dim, Fd = d.feature_dim;
+    const int o = d.obs_dim, z = d.z_dim, a = d.action_dim, H = d.hidden_dim;
     Ws& w = c->w;
     const ActP& A = c->A_p;
     float* pre1o = w.act_vec; float* pre1z = pre1o + 2048; float* h = pre1z + 2048; float* pv = h + 2048;
     const size_t nin = act_noise_off(d) + (has_noise ? a : 0);
     HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, nin * sizeof(float), hipMemcpyHostToDevice, s));
-    // Actor.forward (fb_modules.py:107-121): obs_net / obs_z_net first layers (the weight's zero pad columns absorb
-    // whatever follows obs / [obs|z] in the staging vector) ...
-    GemvGroup g1{}; g1.n = 2;
+    // Actor.forward (fb_modules.py:107-121): first layers (the weight's zero pad columns absorb whatever follows
+    // obs / [obs|z] in the staging vector); preprocess == 0 has ONE branch on [obs|z] ...
+    const Geom gm = geom_of(d);
+    GemvGroup g1{}; g1.n = gm.single ? 1 : 2;
     g1.p[0] = GV(w.act_in, A.o.W1, A.o.ld1, A.o.b1, pre1o, H, A.o.ld1, false);
     g1.p[1] = GV(w.act_in, A.oz.W1, A.oz.ld1, A.oz.b1, pre1z, H, A.oz.ld1, false);
     HIPCK(c, launch_gemv_group(g1, s));
     // ... LayerNorm + tanh as the prologue of the second layers, ReLU ...
-    GemvGroup g2{}; g2.n = 2;
-    g2.p[0] = GV(pre1o, A.o.W2, H, A.o.b2, h, Fd, H, true, A.o.g1, A.o.be1, H);
-    g2.p[1] = GV(pre1z, A.oz.W2, H, A.oz.b2, h + Fd, Fd, H, true, A.oz.g1, A.oz.be1, H);
+    GemvGroup g2{}; g2.n = gm.single ? 1 : 2;
+    g2.p[0] = GV(pre1o, A.o.W2, H, A.o.b2, h, gm.Fo, H, true, A.o.g1, A.o.be1, H);
+    g2.p[1] = GV(pre1z, A.oz.W2, H, A.oz.b2, h + gm.Fo, gm.Fo, H, true, A.oz.g1, A.oz.be1, H);
     HIPCK(c, launch_gemv_group(g2, s));
-    // ... (add_trunk: one more Linear + ReLU, fb_modules.py:116-117) policy hidden layer ...
+    // ... (trunk layer: one more Linear + ReLU, fb_modules.py:116-117) policy hidden layer ...
     const float* feat = h;
-    int nfeat = 2 * Fd;
-    if (d.add_trunk) {
+    int nfeat = gm.hw;
+    if (gm.trunk) {
         float* tr = pv + 2048;
         GemvGroup gt{}; gt.n = 1;
-        gt.p[0] = GV(h, A.Wt, 2 * Fd, A.bt, tr, H, 2 * Fd, true);
+        gt.p[0] = GV(h, A.Wt, gm.hw, A.bt, tr, H, gm.hw, true);
         HIPCK(c, launch_gemv_group(gt, s));
         feat = tr; nfeat = H;
     }
@@ -1308,7 +1379,7 @@ int fbhip_act(fbhip_ctx* c, const float* host_obs, const float* host_z, const fl
     RC(need_bound(c, false));
     if (!host_obs || !host_z || !host_action_out) { c->err = g_err = "fbhip_act: null argument"; return FBHIP_E_INVALID; }
     if (!c->h_in) { c->err = g_err = "fbhip_act: pinned staging unavailable"; return FBHIP_E_STATE; }
-    if (c->d.hidden_dim > 2048 || 2 * c->d.feature_dim > 2048) { c->err = g_err = "fbhip_act: layer wider than 2048"; return FBHIP_E_INVALID; }
+    if (c->d.hidden_dim > 2048 || geom_of(c->d).hw > 2048) { c->err = g_err = "fbhip_act: layer wider than 2048"; return FBHIP_E_INVALID; }
     const fbhip_dims& d = c->d;
     memcpy(c->h_in, host_obs, (size_t)d.obs_dim * sizeof(float));
     memcpy(c->h_in + d.obs_dim, host_z, (size_t)d.z_dim * sizeof(float));
@@ -1378,8 +1449,13 @@ int fbhip_forward_map(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld_
     Ws& w = c->w;
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
         const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
-        HIPCK(c, launch_concat2(w.Xoz.p, w.Xoz.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, z + (size_t)r0 * ld_z, ld_z, d.z_dim, n, s));
-        HIPCK(c, launch_concat2(w.Xoa.p, w.Xoa.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, action + (size_t)r0 * ld_act, ld_act, d.action_dim, n, s));
+        if (geom_of(d).single) {                 // one panel [obs | z | action]
+            HIPCK(c, launch_concat2(w.Xoa.p, w.Xoa.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, z + (size_t)r0 * ld_z, ld_z, d.z_dim, n, s));
+            HIPCK(c, launch_concat2(w.Xoa.p + d.obs_dim + d.z_dim, w.Xoa.ld, action + (size_t)r0 * ld_act, ld_act, d.action_dim, nullptr, 0, 0, n, s));
+        } else {
+            HIPCK(c, launch_concat2(w.Xoz.p, w.Xoz.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, z + (size_t)r0 * ld_z, ld_z, d.z_dim, n, s));
+            HIPCK(c, launch_concat2(w.Xoa.p, w.Xoa.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, action + (size_t)r0 * ld_act, ld_act, d.action_dim, n, s));
+        }
         RC(forward_map_fwd(c, which ? c->F_t : c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsT, n, s));
         HIPCK(c, launch_concat2(f1_out + (size_t)r0 * ld_out, ld_out, w.fsT.F1.p, w.fsT.F1.ld, d.z_dim, nullptr, 0, 0, n, s));
         HIPCK(c, launch_concat2(f2_out + (size_t)r0 * ld_out, ld_out, w.fsT.F2.p, w.fsT.F2.ld, d.z_dim, nullptr, 0, 0, n, s));

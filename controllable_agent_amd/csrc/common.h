@@ -166,16 +166,18 @@ struct GatherArgs {
     float* fgoal; int ld_fg;    // (goal if use_goal else observation)[ep, future_idx - 1]
     float* disc;
     int B, o, a, g, use_goal; float gamma;
+    int aoff;                   // column of the action inside Xoa (o, or o + z for the [obs|z|action] panels of preprocess == 0)
 };
 hipError_t launch_gather(const GatherArgs& ga, hipStream_t s);
 // z[i] = mix ? sqrt(d) normalize(sqrt(d) normalize(ymix[i])) : sqrt(d) normalize(gauss[i]); scattered into the concat
 // panels; advances the RNG counter when st != nullptr
 // hindsight rows (future_uniform[i] < future_ratio) take sqrt(d) normalize(yfut[i]) instead (fb_ddpg.py:487-491)
+struct ZPanels { float* p[3]; int ld[3]; };
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
                         StepState* st, const float* yfut, const float* future_uniform, float future_ratio,
                         const float* z_uniform /* nullable: norm_z */, int mix_projections /* 2, or 1 with rand_weight */,
-                        hipStream_t s);
+                        ZPanels extra /* further panels that carry z at column o (entries may be null) */, hipStream_t s);
 // rand_weight rows (fb_ddpg.py:477-480): W[i, :] = u[i] * raw[i, :] / max(|raw[i, :]|_2, 1e-12), in place.  generate != 0
 // first draws raw[i, j] and u[i] ~ U(0,1) (Philox); else they are the injected values already sitting in W / u.
 hipError_t launch_rand_weight(float* W, float* u, int B, int generate, uint64_t seed, uint32_t rank, const StepState* st,

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
         g.Xnoz[(size_t)i * g.ld_noz + j] = nv;
         g.Xnoa[(size_t)i * g.ld_noa + j] = nv;
     }
-    copy_row(g.Xoa + (size_t)i * g.ld_oa + g.o, act, g.a, lane);
+    copy_row(g.Xoa + (size_t)i * g.ld_oa + g.aoff, act, g.a, lane);
     if (lane == 0) g.disc[i] = g.gamma * g.rv.discount[t];            // discount * storage['discount'] (:171)
     copy_row(g.next_goal + (size_t)i * g.ld_ng, g.use_goal ? g.rv.goal + t * g.g : nobs, g.g, lane);
     // backward_input[perm] (fb_ddpg.py:460-468): row i of the permuted panel is transition perm[i]
@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
                                                     float* __restrict__ Xnoz, int ld_noz, int o, int B, int d,
                                                     StepState* __restrict__ st, const float* __restrict__ yfut,
                                                     const float* __restrict__ futu, float future_ratio,
-                                                    const float* __restrict__ zunif, int mix_proj) {
+                                                    const float* __restrict__ zunif, int mix_proj,
+                                                    const ZPanels zx) {
     if (st != nullptr && blockIdx.x == 0 && threadIdx.x == 0) st->update_count += 1u;
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
@@ -213,6 +214,9 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
             z[(size_t)i * ldz + j] = v[k];
             Xoz[(size_t)i * ld_oz + o + j] = v[k];
             Xnoz[(size_t)i * ld_noz + o + j] = v[k];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (zx.p[q] != nullptr) zx.p[q][(size_t)i * zx.ld[q] + o + j] = v[k];
         }
     }
 }
@@ -281,11 +285,11 @@ hipError_t launch_gather(const GatherArgs& ga, hipStream_t s) {
 hipError_t launch_mix_z(const float* gauss, int ldg, const float* ymix, int ldy, const float* mix_uniform, float mix_ratio,
                         float* z, int ldz, float* Xoz, int ld_oz, float* Xnoz, int ld_noz, int o, int B, int d,
                         StepState* st, const float* yfut, const float* future_uniform, float future_ratio,
-                        const float* z_uniform, int mix_projections, hipStream_t s) {
+                        const float* z_uniform, int mix_projections, ZPanels extra, hipStream_t s) {
     if (d > 256) return hipErrorInvalidValue;
     if (future_ratio > 0.f && (!yfut || !future_uniform)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mix_z_kernel, dim3((B + 3) / 4), dim3(256), 0, s, gauss, ldg, ymix, ldy, mix_uniform, mix_ratio, z,
-                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st, yfut, future_uniform, future_ratio, z_uniform, mix_projections);
+                       ldz, Xoz, ld_oz, Xnoz, ld_noz, o, B, d, st, yfut, future_uniform, future_ratio, z_uniform, mix_projections, extra);
     return hipGetLastError();
 }
 

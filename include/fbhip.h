@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 5
+#define FBHIP_ABI_VERSION 6
 
 enum {
     FBHIP_OK = 0,
@@ -74,6 +74,9 @@ typedef struct fbhip_dims {
     int32_t add_trunk;             /* cfg.add_trunk (default 0): Linear(2Fd, H) + ReLU "trunk" between the two preprocess nets and
                                     * the F1/F2 heads / the policy head (fb_modules.py:93-98, 168-173); their first layer is
                                     * then [H, H] instead of [H, 2Fd] */
+    int32_t preprocess;            /* cfg.preprocess (default 1).  0: ForwardMap / Actor are ONE trunk mlp(in, H, "ntanh", H, "irelu",
+                                    * H, "irelu") on cat([obs, z, action]) / cat([obs, z]) instead of the two preprocess nets
+                                    * (fb_modules.py:99-103, 174-178); add_trunk is then ignored */
     int32_t norm_z;                /* cfg.norm_z (default 1).  0: BackwardMap output unprojected (fb_modules.py:228-229),
                                     * z = sqrt(d) U g/|g| (fb_ddpg.py:229-231), no re-projection of mixed rows (:483) */
 } fbhip_dims;

@@ -56,6 +56,8 @@ class OracleConfig:
     norm_z: bool = True           # False: B unprojected, z = sqrt(d) U g/|g| (fb_ddpg.py:227-231, fb_modules.py:228-229)
     rand_weight: bool = False     # mixed rows = (u * normalize(rand[B])) @ B(backward_input)  (fb_ddpg.py:475-482)
     add_trunk: bool = False       # extra Linear(2Fd, H)+ReLU "trunk" after the two preprocess nets (fb_modules.py:93-98,168-173)
+    preprocess: bool = True       # False: ONE trunk mlp(in, H, "ntanh", H, "irelu", H, "irelu") on the concatenated input
+                                  # instead of the two preprocess nets (fb_modules.py:99-103, 174-178); add_trunk is then moot
 
 
 @dataclasses.dataclass
@@ -123,14 +125,23 @@ def _trunk_shapes(prefix: str, in_dim: int, hidden: int, feat: int) -> tp.List[t
             (f"{prefix}.3.weight", (feat, hidden)), (f"{prefix}.3.bias", (feat,))]
 
 
+def _single_trunk_shapes(in_dim: int, H: int):
+    # mlp(in, H, "ntanh", H, "irelu", H, "irelu")  (fb_modules.py:100-102, 175-177): Linear, LayerNorm, Tanh, Linear, ReLU, Linear, ReLU
+    return [("trunk.0.weight", (H, in_dim)), ("trunk.0.bias", (H,)), ("trunk.1.weight", (H,)), ("trunk.1.bias", (H,)),
+            ("trunk.3.weight", (H, H)), ("trunk.3.bias", (H,)), ("trunk.5.weight", (H, H)), ("trunk.5.bias", (H,))]
+
+
 def forward_map_shapes(cfg: OracleConfig):
     """ForwardMap parameter list in ``parameters()`` order (fb_modules.py:165-182)."""
     o, a, d, H, Fd = cfg.obs_dim, cfg.action_dim, cfg.z_dim, cfg.hidden_dim, cfg.feature_dim
-    out = _trunk_shapes("obs_action_net", o + a, H, Fd) + _trunk_shapes("obs_z_net", o + d, H, Fd)
-    feat = 2 * Fd
-    if cfg.add_trunk:                                      # mlp(2 * feature_dim, hidden_dim, "irelu")
-        out += [("trunk.0.weight", (H, 2 * Fd)), ("trunk.0.bias", (H,))]
-        feat = H
+    if not cfg.preprocess:
+        out, feat = _single_trunk_shapes(o + d + a, H), H
+    else:
+        out = _trunk_shapes("obs_action_net", o + a, H, Fd) + _trunk_shapes("obs_z_net", o + d, H, Fd)
+        feat = 2 * Fd
+        if cfg.add_trunk:                                      # mlp(2 * feature_dim, hidden_dim, "irelu")
+            out += [("trunk.0.weight", (H, 2 * Fd)), ("trunk.0.bias", (H,))]
+            feat = H
     for head in ("F1", "F2"):
         out += [(f"{head}.0.weight", (H, feat)), (f"{head}.0.bias", (H,)),
                 (f"{head}.2.weight", (d, H)), (f"{head}.2.bias", (d,))]
@@ -138,13 +149,16 @@ def forward_map_shapes(cfg: OracleConfig):
 
 
 def actor_shapes(cfg: OracleConfig):
-    """Actor parameter list (fb_modules.py:91-105, preprocess=True)."""
+    """Actor parameter list (fb_modules.py:91-105)."""
     o, a, d, H, Fd = cfg.obs_dim, cfg.action_dim, cfg.z_dim, cfg.hidden_dim, cfg.feature_dim
-    out = _trunk_shapes("obs_net", o, H, Fd) + _trunk_shapes("obs_z_net", o + d, H, Fd)
-    feat = 2 * Fd
-    if cfg.add_trunk:
-        out += [("trunk.0.weight", (H, 2 * Fd)), ("trunk.0.bias", (H,))]
-        feat = H
+    if not cfg.preprocess:
+        out, feat = _single_trunk_shapes(o + d, H), H
+    else:
+        out = _trunk_shapes("obs_net", o, H, Fd) + _trunk_shapes("obs_z_net", o + d, H, Fd)
+        feat = 2 * Fd
+        if cfg.add_trunk:
+            out += [("trunk.0.weight", (H, 2 * Fd)), ("trunk.0.bias", (H,))]
+            feat = H
     return out + [("policy.0.weight", (H, feat)), ("policy.0.bias", (H,)),
                   ("policy.2.weight", (a, H)), ("policy.2.bias", (a,))]
 
@@ -188,13 +202,23 @@ def _trunk(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
     return torch.relu(F.linear(h, p[f"{prefix}.3.weight"], p[f"{prefix}.3.bias"]))
 
 
+def _single_trunk(p: Params, x: torch.Tensor) -> torch.Tensor:
+    h = F.linear(x, p["trunk.0.weight"], p["trunk.0.bias"])
+    h = torch.tanh(F.layer_norm(h, (h.shape[-1],), p["trunk.1.weight"], p["trunk.1.bias"], LN_EPS))
+    h = torch.relu(F.linear(h, p["trunk.3.weight"], p["trunk.3.bias"]))
+    return torch.relu(F.linear(h, p["trunk.5.weight"], p["trunk.5.bias"]))
+
+
 def forward_map(p: Params, obs, z, action) -> tp.Tuple[torch.Tensor, torch.Tensor]:
     """ForwardMap.forward (fb_modules.py:186-199)."""
-    obs_action = _trunk(p, "obs_action_net", torch.cat([obs, action], dim=-1))
-    obs_z = _trunk(p, "obs_z_net", torch.cat([obs, z], dim=-1))
-    h = torch.cat([obs_action, obs_z], dim=-1)
-    if "trunk.0.weight" in p:                              # add_trunk (fb_modules.py:194-195)
-        h = torch.relu(F.linear(h, p["trunk.0.weight"], p["trunk.0.bias"]))
+    if "trunk.5.weight" in p:                              # preprocess=False: cat([obs, z, action]) -> trunk
+        h = _single_trunk(p, torch.cat([obs, z, action], dim=-1))
+    else:
+        obs_action = _trunk(p, "obs_action_net", torch.cat([obs, action], dim=-1))
+        obs_z = _trunk(p, "obs_z_net", torch.cat([obs, z], dim=-1))
+        h = torch.cat([obs_action, obs_z], dim=-1)
+        if "trunk.0.weight" in p:                          # add_trunk (fb_modules.py:194-195)
+            h = torch.relu(F.linear(h, p["trunk.0.weight"], p["trunk.0.bias"]))
     outs = []
     for head in ("F1", "F2"):
         t = torch.relu(F.linear(h, p[f"{head}.0.weight"], p[f"{head}.0.bias"]))
@@ -218,11 +242,14 @@ def backward_map(p: Params, goal, z_dim: int, norm_z: bool = True) -> torch.Tens
 
 def actor_mu(p: Params, obs, z) -> torch.Tensor:
     """Actor.forward up to mu = tanh(policy(h)) (fb_modules.py:107-122)."""
-    obs_z = _trunk(p, "obs_z_net", torch.cat([obs, z], dim=-1))
-    ob = _trunk(p, "obs_net", obs)
-    h = torch.cat([ob, obs_z], dim=-1)
-    if "trunk.0.weight" in p:                              # add_trunk (fb_modules.py:116-117)
-        h = torch.relu(F.linear(h, p["trunk.0.weight"], p["trunk.0.bias"]))
+    if "trunk.5.weight" in p:                              # preprocess=False: cat([obs, z]) -> trunk
+        h = _single_trunk(p, torch.cat([obs, z], dim=-1))
+    else:
+        obs_z = _trunk(p, "obs_z_net", torch.cat([obs, z], dim=-1))
+        ob = _trunk(p, "obs_net", obs)
+        h = torch.cat([ob, obs_z], dim=-1)
+        if "trunk.0.weight" in p:                          # add_trunk (fb_modules.py:116-117)
+            h = torch.relu(F.linear(h, p["trunk.0.weight"], p["trunk.0.bias"]))
     t = torch.relu(F.linear(h, p["policy.0.weight"], p["policy.0.bias"]))
     return torch.tanh(F.linear(t, p["policy.2.weight"], p["policy.2.bias"]))
 

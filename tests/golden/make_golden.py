@@ -94,8 +94,8 @@ def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
         hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
         z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
         ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
-        future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, rand_weight=cfg.rand_weight, add_trunk=cfg.add_trunk, update_every_steps=1,
-        **extra)
+        future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, rand_weight=cfg.rand_weight, add_trunk=cfg.add_trunk, preprocess=cfg.preprocess,
+        update_every_steps=1, **extra)
 
 
 def load_nets(agent, nets):
@@ -272,6 +272,13 @@ def trunk_fixture(R):
                   n_steps=4, goal_space="simplified_walker")
 
 
+def single_trunk_fixture(R):
+    """preprocess=False (fb_modules.py:99-103, 174-178): one LayerNorm trunk on cat([obs, z, action]) / cat([obs, z])"""
+    trace_fixture(R, "tiny_single_trunk_trace", tiny_cfg(preprocess=False), seed=109, n_eps=6, T=12, n_steps=4)
+    trace_fixture(R, "tiny_single_trunk_goal_trace", tiny_cfg(preprocess=False, goal_dim=3, use_goal=True, z_dim=10, batch_size=24),
+                  seed=110, n_eps=7, T=11, n_steps=3, goal_space="simplified_walker", variable_len=True)
+
+
 def sampler_fixture(R):
     """ReplayBuffer.sample KAT: variable lengths + goal + stored meta z; real numpy RNG, fixed seed."""
     rng = np.random.default_rng(7)
@@ -410,6 +417,7 @@ def main():
     nonorm_fixture(R)
     randweight_fixture(R)
     trunk_fixture(R)
+    single_trunk_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

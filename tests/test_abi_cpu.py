@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
 
 def test_parameter_counts_match_reference(lib):
     """SURVEY.md appendix B (confirmed by instantiating the reference): walker, z_dim=50."""
-    d = lib.Dims(1024, 24, 6, 24, 50, 1024, 512, 526, 0, 0, 1)
+    d = lib.Dims(1024, 24, 6, 24, 50, 1024, 512, 526, 0, 0, 1, 1)
     l = lib.load()
     assert l.fbhip_net_param_count(C.byref(d), lib.NET_FORWARD) == 3_363_940
     assert l.fbhip_net_param_count(C.byref(d), lib.NET_BACKWARD) == 317_754
@@ -39,7 +39,7 @@ def test_parameter_counts_match_reference(lib):
 
 def test_layout_is_aligned_and_disjoint(lib):
     l = lib.load()
-    for dims in (lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1), lib.Dims(1024, 78, 12, 2, 100, 1024, 512, 526, 1, 0, 1)):
+    for dims in (lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1, 1), lib.Dims(1024, 78, 12, 2, 100, 1024, 512, 526, 1, 0, 1, 1)):
         for net in range(3):
             spans = []
             for i in range(l.fbhip_layout_count(C.byref(dims), net)):
@@ -53,9 +53,30 @@ def test_layout_is_aligned_and_disjoint(lib):
             assert spans[-1][1] <= l.fbhip_net_numel(C.byref(dims), net)
 
 
+def test_single_trunk_layout_follows_the_reference_module(lib):
+    """preprocess == 0 (fb_modules.py:99-103, 174-178): one ``trunk`` mlp on the concatenated input, Linear layers at
+    Sequential indices 0, 3, 5 and the LayerNorm at 1 -- names and order of nn.Module.state_dict()."""
+    l = lib.load()
+    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 0, 1)
+    def names(net):
+        out = []
+        for i in range(l.fbhip_layout_count(C.byref(d), net)):
+            t = lib.TensorDesc()
+            assert l.fbhip_layout_entry(C.byref(d), net, i, C.byref(t)) == 0
+            out.append((t.name.decode(), t.rows, t.cols))
+        return out
+    trunk = lambda k: [("trunk.0.weight", 32, k), ("trunk.0.bias", 1, 32), ("trunk.1.weight", 1, 32), ("trunk.1.bias", 1, 32),
+                       ("trunk.3.weight", 32, 32), ("trunk.3.bias", 1, 32), ("trunk.5.weight", 32, 32), ("trunk.5.bias", 1, 32)]
+    assert names(lib.NET_ACTOR) == trunk(13) + [("policy.0.weight", 32, 32), ("policy.0.bias", 1, 32),
+                                                ("policy.2.weight", 3, 32), ("policy.2.bias", 1, 3)]
+    assert names(lib.NET_FORWARD)[:8] == trunk(16)
+    assert [n for n, _, _ in names(lib.NET_FORWARD)[8:]] == [f"{h}.{i}.{w}" for h in ("F1", "F2") for i in (0, 2)
+                                                             for w in ("weight", "bias")]
+
+
 def test_bad_dims_fail_loudly(lib):
     l = lib.load()
-    bad = lib.Dims(1024, 24, 6, 24, 50, 1022, 512, 526, 0, 0, 1)       # hidden_dim % 4 != 0
+    bad = lib.Dims(1024, 24, 6, 24, 50, 1022, 512, 526, 0, 0, 1, 1)       # hidden_dim % 4 != 0
     assert l.fbhip_net_numel(C.byref(bad), 0) < 0
     assert b"multiples of 4" in l.fbhip_last_error(None)
     ctx = C.c_void_p()
@@ -64,7 +85,7 @@ def test_bad_dims_fail_loudly(lib):
 
 def test_unbound_context_is_an_error_not_a_crash(lib):
     l = lib.load()
-    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1)
+    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1, 1)
     ctx = C.c_void_p()
     assert l.fbhip_create(C.byref(d), C.byref(ctx)) == 0
     hp = lib.HParams()

@@ -38,7 +38,9 @@ def _param_close(got, ref, lr, name):
                                              ("tiny_future_trace", None), ("tiny_future_goal_trace", "simplified_walker"),
                                              ("tiny_nonorm_trace", None), ("tiny_randw_trace", None),
                                              ("tiny_randw_nonorm_trace", "simplified_walker"),
-                                             ("tiny_trunk_trace", "simplified_walker")])
+                                             ("tiny_trunk_trace", "simplified_walker"),
+                                             ("tiny_single_trunk_trace", None),
+                                             ("tiny_single_trunk_goal_trace", "simplified_walker")])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
@@ -86,6 +88,10 @@ def test_teacher_forced_against_reference_trace(name, goal_space):
             else:
                 _param_close(v, ref, cfg.lr, f"step {s} {k}")
         assert agent.step_counts() == (s + 1, s + 1)
+        # alignment columns of every weight, gradient and target stay exactly zero (GEMMs run over padded widths)
+        for nv in (agent.forward_net, agent.backward_net, agent.actor, agent.forward_target_net, agent.backward_target_net,
+                   *agent._grad_views.values()):
+            assert nv.pad_abs_max() == 0.0, (s, nv._name)
 
 
 @pytest.mark.parametrize("name,tol", [("walker_b256", 3e-4), ("walker_b1024", 3e-4)])
@@ -495,14 +501,17 @@ def test_rand_weight_device_draws():
     assert 0.3 < float(mixed.float().mean()) < 0.7 and H.rel_err(z[mixed], want[mixed]) < 2e-5
 
 
-def test_add_trunk_inference_paths():
-    """add_trunk=True: the batched and the batch-1 actor paths and forward_map agree with the oracle's networks."""
+@pytest.mark.parametrize("flags", [dict(add_trunk=True), dict(preprocess=False)])
+def test_trunk_inference_paths(flags):
+    """add_trunk=True / preprocess=False: the batched and the batch-1 actor paths and forward_map agree with the
+    oracle's networks."""
     cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
-                          backward_hidden_dim=18, batch_size=16, add_trunk=True)
+                          backward_hidden_dim=18, batch_size=16, **flags)
     rng = np.random.default_rng(23)
     nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
     agent = H.make_hip_agent(cfg, nets)
     assert "trunk.0.weight" in agent.actor.state_dict() and agent.forward_net.state_dict()["F1.0.weight"].shape == (32, 32)
+    assert ("trunk.5.weight" in agent.forward_net.state_dict()) == (not cfg.preprocess)
     obs = rng.standard_normal((6, cfg.obs_dim)).astype(np.float32)
     z = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((6, cfg.z_dim)).astype(np.float32)), cfg.z_dim)
     act = torch.from_numpy(rng.uniform(-1, 1, (6, cfg.action_dim)).astype(np.float32))
