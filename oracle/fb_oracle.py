@@ -58,6 +58,11 @@ class OracleConfig:
     add_trunk: bool = False       # extra Linear(2Fd, H)+ReLU "trunk" after the two preprocess nets (fb_modules.py:93-98,168-173)
     preprocess: bool = True       # False: ONE trunk mlp(in, H, "ntanh", H, "irelu", H, "irelu") on the concatenated input
                                   # instead of the two preprocess nets (fb_modules.py:99-103, 174-178); add_trunk is then moot
+    boltzmann: bool = False       # DiagGaussianActor + SquashedNormal, actor_loss = (temp log_prob - Q).mean()
+                                  # (fb_ddpg.py:118-120, 304-306, 391-393, 406; fb_modules.py:129-151)
+    temp: float = 1.0             # fb_ddpg.py:71
+    log_std_min: float = -5.0     # fb_ddpg.py:70  log_std_bounds
+    log_std_max: float = 2.0
 
 
 @dataclasses.dataclass
@@ -151,6 +156,9 @@ def forward_map_shapes(cfg: OracleConfig):
 def actor_shapes(cfg: OracleConfig):
     """Actor parameter list (fb_modules.py:91-105)."""
     o, a, d, H, Fd = cfg.obs_dim, cfg.action_dim, cfg.z_dim, cfg.hidden_dim, cfg.feature_dim
+    if cfg.boltzmann:             # DiagGaussianActor.policy = mlp(o + d, H, "ntanh", H, "relu", 2a)  (fb_modules.py:138)
+        return [("policy.0.weight", (H, o + d)), ("policy.0.bias", (H,)), ("policy.1.weight", (H,)), ("policy.1.bias", (H,)),
+                ("policy.3.weight", (H, H)), ("policy.3.bias", (H,)), ("policy.5.weight", (2 * a, H)), ("policy.5.bias", (2 * a,))]
     if not cfg.preprocess:
         out, feat = _single_trunk_shapes(o + d, H), H
     else:
@@ -240,8 +248,27 @@ def backward_map(p: Params, goal, z_dim: int, norm_z: bool = True) -> torch.Tens
     return math.sqrt(z_dim) * F.normalize(y, dim=1) if norm_z else y
 
 
+def diag_gaussian(p: Params, obs, z, log_std_min: float = -5.0, log_std_max: float = 2.0):
+    """DiagGaussianActor.forward (fb_modules.py:141-151): (raw policy output [B, 2a], loc, scale) of the SquashedNormal."""
+    pol = _trunk(p, "policy", torch.cat([obs, z], dim=-1))           # Linear, LayerNorm, Tanh, Linear, ReLU
+    pol = F.linear(pol, p["policy.5.weight"], p["policy.5.bias"])
+    mu, log_std = pol.chunk(2, dim=-1)
+    log_std = torch.tanh(log_std)
+    log_std = log_std_min + 0.5 * (log_std_max - log_std_min) * (log_std + 1)
+    return pol, mu, log_std.exp()
+
+
+def squashed_log_prob(mu, std, u) -> torch.Tensor:
+    """SquashedNormal(mu, std).log_prob(tanh(u)) with the TanhTransform's cached pre-image u (utils.py:188-232):
+    Normal.log_prob(u) - 2 (log 2 - u - softplus(-2u)), per element."""
+    base = -((u - mu) ** 2) / (2 * std ** 2) - std.log() - math.log(math.sqrt(2 * math.pi))
+    return base - 2.0 * (math.log(2.0) - u - F.softplus(-2.0 * u))
+
+
 def actor_mu(p: Params, obs, z) -> torch.Tensor:
-    """Actor.forward up to mu = tanh(policy(h)) (fb_modules.py:107-122)."""
+    """Actor.forward up to mu = tanh(policy(h)) (fb_modules.py:107-122); DiagGaussianActor: ``dist.mean`` = tanh(loc)."""
+    if "policy.5.weight" in p:
+        return torch.tanh(diag_gaussian(p, obs, z)[1])
     if "trunk.5.weight" in p:                              # preprocess=False: cat([obs, z]) -> trunk
         h = _single_trunk(p, torch.cat([obs, z], dim=-1))
     else:
@@ -456,8 +483,13 @@ class OracleAgent:
 
         # ---------------- update_fb (fb_ddpg.py:291-387) ---------------- #
         with torch.no_grad():
-            mu_n = actor_mu(self.actor, next_obs, z)
-            next_action = truncated_normal_sample(mu_n, cfg.stddev, cfg.stddev_clip, t(draws.eps_next))
+            if cfg.boltzmann:                                      # fb_ddpg.py:304-306: dist.sample() = tanh(loc + scale eps)
+                _, loc_n, std_n = diag_gaussian(self.actor, next_obs, z, cfg.log_std_min, cfg.log_std_max)
+                mu_n = torch.tanh(loc_n)
+                next_action = torch.tanh(loc_n + std_n * t(draws.eps_next))
+            else:
+                mu_n = actor_mu(self.actor, next_obs, z)
+                next_action = truncated_normal_sample(mu_n, cfg.stddev, cfg.stddev_clip, t(draws.eps_next))
             tF1, tF2 = forward_map(self.forward_target_net, next_obs, z, next_action)
             tB = backward_map(self.backward_target_net, next_goal, cfg.z_dim, cfg.norm_z)
         fp, bp = self._req(self.forward_net), self._req(self.backward_net)
@@ -504,16 +536,24 @@ class OracleAgent:
         # ---------------- update_actor (fb_ddpg.py:389-421) ------------- #
         ap = self._req(self.actor)
         fnew = self._req(self.forward_net)              # reference also tracks (and discards) these grads
-        mu = actor_mu(ap, obs, z)
-        act = truncated_normal_sample(mu, cfg.stddev, cfg.stddev_clip, t(draws.eps_actor))
-        log_prob = normal_log_prob(mu, cfg.stddev, act).sum(-1, keepdim=True)
+        if cfg.boltzmann:                                          # fb_ddpg.py:391-393: rsample of the SquashedNormal
+            premu, loc, std = diag_gaussian(ap, obs, z, cfg.log_std_min, cfg.log_std_max)
+            u = loc + std * t(draws.eps_actor)
+            act = torch.tanh(u)
+            mu = torch.tanh(loc)
+            log_prob = squashed_log_prob(loc, std, u).sum(-1, keepdim=True)
+        else:
+            mu = actor_mu(ap, obs, z)
+            premu = None
+            act = truncated_normal_sample(mu, cfg.stddev, cfg.stddev_clip, t(draws.eps_actor))
+            log_prob = normal_log_prob(mu, cfg.stddev, act).sum(-1, keepdim=True)
         aF1, aF2 = forward_map(fnew, obs, z, act)
         Q1 = torch.einsum('sd, sd -> s', aF1, z)
         Q2 = torch.einsum('sd, sd -> s', aF2, z)
         Q = torch.min(Q1, Q2)
-        actor_loss = -Q.mean()
+        actor_loss = (cfg.temp * log_prob.squeeze(1) - Q).mean() if cfg.boltzmann else -Q.mean()    # fb_ddpg.py:406
         if keep:
-            for x in (aF1, aF2, act, mu):
+            for x in (aF1, aF2, act, mu) + ((premu,) if cfg.boltzmann else ()):
                 x.retain_grad()
         actor_loss.backward()
         gA = {k: v.grad for k, v in ap.items()}
@@ -534,7 +574,9 @@ class OracleAgent:
                 dF1=d(F1.grad), dF2=d(F2.grad), dBm=d(Bm.grad), dy=d(y.grad),
                 grads_forward={k: d(v) for k, v in gF.items()}, grads_backward={k: d(v) for k, v in gB.items()},
                 mu=d(mu), pi_action=d(act), aF1=d(aF1), aF2=d(aF2), daF1=d(aF1.grad), daF2=d(aF2.grad),
-                d_pi_action=d(act.grad), d_mu=d(mu.grad),
+                d_pi_action=d(act.grad), d_mu=None if cfg.boltzmann else d(mu.grad),
+                # gradient at the policy head's raw output: [B, a] pre-tanh (Actor) / [B, 2a] (loc | raw log-std) (DiagGaussianActor)
+                d_premu=d(premu.grad) if cfg.boltzmann else d(mu.grad) * (1 - d(mu) ** 2),
                 grads_actor={k: d(v) for k, v in gA.items()})
         return metrics
 
@@ -580,6 +622,7 @@ class OracleAgent:
         cfg, d = self.cfg, self._dp
         t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
         ap = self._req(self.actor)
+        assert not cfg.boltzmann, "the data-parallel cut of the oracle covers the default actor only"
         mu = actor_mu(ap, d["obs"], d["z"])
         act = truncated_normal_sample(mu, cfg.stddev, cfg.stddev_clip, t(d["draws"].eps_actor))
         aF1, aF2 = forward_map(self.forward_net, d["obs"], d["z"], act)

@@ -95,6 +95,7 @@ def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
         z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
         ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
         future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, rand_weight=cfg.rand_weight, add_trunk=cfg.add_trunk, preprocess=cfg.preprocess,
+        boltzmann=cfg.boltzmann, temp=cfg.temp, log_std_bounds=(cfg.log_std_min, cfg.log_std_max),
         update_every_steps=1, **extra)
 
 
@@ -131,6 +132,8 @@ def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5):
     calls = {"randint": 0, "uniform": 0}
     o_randint, o_choice, o_uniform, o_geo = np.random.randint, np.random.choice, np.random.uniform, np.random.geometric
     o_randperm, o_randn, o_sn, o_rand = torch.randperm, torch.randn, R.utils._standard_normal, torch.rand
+    import torch.distributions.normal as tdn     # boltzmann: Normal.sample -> torch.normal, Normal.rsample -> _standard_normal
+    o_normal, o_tdn_sn = torch.normal, tdn._standard_normal
     eps_queue = [d.eps_next, d.eps_actor]
 
     def randint(low, high=None, size=None, **kw):
@@ -170,8 +173,12 @@ def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5):
     def standard_normal(shape, dtype, device):
         return torch.from_numpy(eps_queue.pop(0).copy())
 
+    def normal(mean, std, *a, **kw):           # torch.distributions.Normal.sample (fb_ddpg.py:306)
+        return mean + std * torch.from_numpy(eps_queue.pop(0).copy())
+
     np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = randint, choice, uniform, geometric
     torch.randperm, torch.randn, R.utils._standard_normal = randperm, randn, standard_normal
+    torch.normal, tdn._standard_normal = normal, standard_normal
     if d.z_uniform is not None or d.rand_weight is not None:
         torch.rand = rand
     try:
@@ -179,6 +186,7 @@ def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5):
     finally:
         np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = o_randint, o_choice, o_uniform, o_geo
         torch.randperm, torch.randn, R.utils._standard_normal, torch.rand = o_randperm, o_randn, o_sn, o_rand
+        torch.normal, tdn._standard_normal = o_normal, o_tdn_sn
     assert not eps_queue, "update() did not consume both action-noise draws"
 
 
@@ -277,6 +285,15 @@ def single_trunk_fixture(R):
     trace_fixture(R, "tiny_single_trunk_trace", tiny_cfg(preprocess=False), seed=109, n_eps=6, T=12, n_steps=4)
     trace_fixture(R, "tiny_single_trunk_goal_trace", tiny_cfg(preprocess=False, goal_dim=3, use_goal=True, z_dim=10, batch_size=24),
                   seed=110, n_eps=7, T=11, n_steps=3, goal_space="simplified_walker", variable_len=True)
+
+
+def boltzmann_fixture(R):
+    """boltzmann=True (fb_ddpg.py:118-120, 304-306, 391-393, 406): DiagGaussianActor + SquashedNormal, entropy-regularised
+    actor loss with temp != 1 and non-default log_std_bounds in the second trace"""
+    trace_fixture(R, "tiny_boltzmann_trace", tiny_cfg(boltzmann=True), seed=111, n_eps=6, T=12, n_steps=4)
+    trace_fixture(R, "tiny_boltzmann_goal_trace", tiny_cfg(boltzmann=True, temp=0.3, log_std_min=-3.0, log_std_max=1.0, goal_dim=3,
+                                                           use_goal=True, z_dim=10, batch_size=24),
+                  seed=112, n_eps=7, T=11, n_steps=3, goal_space="simplified_walker", variable_len=True)
 
 
 def sampler_fixture(R):
@@ -418,6 +435,7 @@ def main():
     randweight_fixture(R)
     trunk_fixture(R)
     single_trunk_fixture(R)
+    boltzmann_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

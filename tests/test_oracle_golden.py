@@ -35,11 +35,12 @@ def _replay(name, full_state):
 
 @pytest.mark.parametrize("name", ["tiny_trace", "tiny_goal_trace", "tiny_future_trace", "tiny_future_goal_trace", "tiny_nonorm_trace",
                                   "tiny_randw_trace", "tiny_randw_nonorm_trace", "tiny_trunk_trace",
-                                  "tiny_single_trunk_trace", "tiny_single_trunk_goal_trace"])
+                                  "tiny_single_trunk_trace", "tiny_single_trunk_goal_trace",
+                                  "tiny_boltzmann_trace", "tiny_boltzmann_goal_trace"])
 def test_tiny_traces_full_state(name):
     """Every parameter / target / Adam tensor after every step, tiny dims (incl. goal_space, q_loss,
     variable episode lengths, lr_coef != 1, hindsight replay with future_ratio > 0 on future < 1 buffers, norm_z=False,
-    rand_weight=True, add_trunk=True, preprocess=False).  Tolerance: abs 2e-6 on params (fp32, Adam lr 1e-3)."""
+    rand_weight=True, add_trunk=True, preprocess=False, boltzmann=True).  Tolerance: abs 2e-6 on params (fp32, Adam lr 1e-3)."""
     meta, z, out = _replay(name, True)
     for s, (m, state) in enumerate(out):
         for k, v in meta["metrics"][s].items():
