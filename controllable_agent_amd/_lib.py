@@ -24,7 +24,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK_RELU, EPI_TANH_BWD = range(5)
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
-                                          "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z")]
+                                          "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z", "boltzmann")]
 
 
 class HParams(C.Structure):
@@ -61,6 +61,7 @@ PROTOTYPES = {
     "fbhip_bind_buffers": (C.c_int, [_P] + [_P] * 9 + [_P, _Z]),
     "fbhip_replay_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "fbhip_set_seed": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
+    "fbhip_set_policy_squash": (C.c_int, [_P, _F, _F, _F]),
     "fbhip_set_step_counts": (C.c_int, [_P, _I, _I, _P]),
     "fbhip_get_step_counts": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
@@ -103,7 +104,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 6:
+    if lib.fbhip_abi_version() != 7:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

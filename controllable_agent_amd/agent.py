@@ -122,8 +122,10 @@ class FBDDPGAgentConfig:
 # the reference's Linear-layer construction order per net (fb_modules.py:91-105, 165-182, 220); each entry is
 # (state_dict prefix, in_features, out_features) -- drives an RNG-stream-identical orthogonal init
 def _linear_order(net: str, o: int, a: int, g: int, d: int, H: int, Fd: int, Hb: int, add_trunk: bool = False,
-                  preprocess: bool = True):
-    """(name, in, out) of every nn.Linear in module-construction order (fb_modules.py:91-105, 165-182, 220)."""
+                  preprocess: bool = True, boltzmann: bool = False):
+    """(name, in, out) of every nn.Linear in module-construction order (fb_modules.py:91-105, 138, 165-182, 220)."""
+    if boltzmann and net == "actor":                   # DiagGaussianActor: mlp(o + d, H, "ntanh", H, "relu", 2a)
+        return [("policy.0", o + d, H), ("policy.3", H, H), ("policy.5", H, 2 * a)]
     if not preprocess and net != "backward_net":       # one trunk on the concatenated input (fb_modules.py:99-103, 174-178)
         if net == "actor":
             return [("trunk.0", o + d, H), ("trunk.3", H, H), ("trunk.5", H, H), ("policy.0", H, H), ("policy.2", H, a)]
@@ -251,7 +253,7 @@ class FBHipAgent:
         for f in ("obs_type", "obs_shape", "action_shape", "num_expl_steps"):
             if getattr(cfg, f) is MISSING or getattr(cfg, f) == "???":
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
-        unsupported = {"obs_type": cfg.obs_type == "pixels", "boltzmann": cfg.boltzmann, "debug": cfg.debug,
+        unsupported = {"obs_type": cfg.obs_type == "pixels", "debug": cfg.debug,
                        "nstep": cfg.nstep != 1}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
@@ -273,7 +275,7 @@ class FBHipAgent:
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, goal_dim, cfg.z_dim, cfg.hidden_dim,
                           cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.preprocess)),
-                          int(bool(cfg.norm_z)))
+                          int(bool(cfg.norm_z)), int(bool(cfg.boltzmann)))
         self._ctx: tp.Optional[C.c_void_p] = None
         self._replay_token: tp.Optional[tp.Tuple[int, int]] = None
         self._ext_replay: tp.Optional[DeviceReplayBuffer] = None
@@ -302,14 +304,16 @@ class FBHipAgent:
 
         def build(net: str) -> tp.Dict[str, torch.Tensor]:
             lins = [(p, torch.nn.Linear(i, o)) for p, i, o in _linear_order(net, *dims, add_trunk=bool(c.add_trunk),
-                                                                               preprocess=bool(c.preprocess))]
+                                                                               preprocess=bool(c.preprocess),
+                                                                               boltzmann=bool(c.boltzmann))]
             sd: tp.Dict[str, torch.Tensor] = {}
             for p, lin in lins:
                 torch.nn.init.orthogonal_(lin.weight.data)
                 sd[f"{p}.weight"] = lin.weight.data
                 sd[f"{p}.bias"] = torch.zeros_like(lin.bias.data)
                 single = not c.preprocess and net != "backward_net"
-                if p.endswith(".0") and not p.startswith(("F1", "F2", "policy") + (() if single else ("trunk",))):  # LayerNorm next
+                no_ln = ("F1", "F2") + (() if single else ("trunk",)) + (() if (c.boltzmann and net == "actor") else ("policy",))
+                if p.endswith(".0") and not p.startswith(no_ln):                              # LayerNorm next
                     pre = p[:-2]
                     sd[f"{pre}.1.weight"] = torch.ones(lin.out_features)
                     sd[f"{pre}.1.bias"] = torch.zeros(lin.out_features)
@@ -342,6 +346,9 @@ class FBHipAgent:
                                      ptr(self._actor_m), ptr(self._actor_v), ptr(self._workspace),
                                      self._workspace.numel()), ctx)
         check(lib.fbhip_set_seed(ctx, self._seed, self._rank()), ctx)
+        if self.cfg.boltzmann:                         # fb_ddpg.py:70-71, 118-120
+            lo, hi = self.cfg.log_std_bounds
+            check(lib.fbhip_set_policy_squash(ctx, float(self.cfg.temp), float(lo), float(hi)), ctx)
 
         def layout(net: int) -> tp.List[TensorDesc]:
             out = []
@@ -424,7 +431,7 @@ class FBHipAgent:
         self._device = self._resolve_device(cfg.device)
         self._dims = Dims(cfg.batch_size, self.obs_dim, self.action_dim, self.goal_dim, cfg.z_dim, cfg.hidden_dim,
                           cfg.feature_dim, cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.preprocess)),
-                          int(bool(cfg.norm_z)))
+                          int(bool(cfg.norm_z)), int(bool(cfg.boltzmann)))
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)
         for k, v in st["flat"].items():

@@ -71,9 +71,10 @@ struct LayoutBuilder {
 // (in -> H -> Fd) whose outputs are concatenated (2 Fd wide), optionally followed by a Linear(2Fd, H) + ReLU trunk
 // (add_trunk).  preprocess == 0: ONE LayerNorm branch on the concatenated input with Fd := H, always followed by the
 // trunk's last Linear(H, H) + ReLU -- the same pipeline with one branch.
-struct Geom { bool single, trunk; int Fo, hw, feat; };
+struct Geom { bool single, trunk, boltz; int Fo, hw, feat; };
 Geom geom_of(const fbhip_dims& d) {
     Geom g;
+    g.boltz = false;
     g.single = d.preprocess == 0;
     g.trunk = g.single || d.add_trunk != 0;
     g.Fo = g.single ? d.hidden_dim : d.feature_dim;          // a branch's output width
@@ -81,6 +82,15 @@ Geom geom_of(const fbhip_dims& d) {
     g.feat = g.trunk ? d.hidden_dim : g.hw;                  // what feeds the heads / the policy
     return g;
 }
+// The actor's own geometry.  boltzmann: DiagGaussianActor (fb_modules.py:129-151) = ONE LayerNorm branch on [obs|z]
+// (H -> H, the "policy" mlp's first two Linears) feeding the [loc | raw log-std] head directly: no trunk layer, no
+// policy hidden layer; preprocess / add_trunk do not apply to it.
+Geom actor_geom_of(const fbhip_dims& d) {
+    Geom g = geom_of(d);
+    if (d.boltzmann) { g.boltz = true; g.single = true; g.trunk = false; g.Fo = g.hw = g.feat = d.hidden_dim; }
+    return g;
+}
+inline int head_width(const fbhip_dims& d) { return d.boltzmann ? 2 * d.action_dim : d.action_dim; }
 
 std::vector<std::string> trunk_names(const std::string& p) {
     return {p + ".0.weight", p + ".0.bias", p + ".1.weight", p + ".1.bias", p + ".3.weight", p + ".3.bias"};
@@ -122,6 +132,10 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
         b.mat("B.3.weight", Hb, Hb, HbP, HbP); b.vec("B.3.bias", Hb, HbP);
         b.mat("B.5.weight", z, Hb, HbP); b.vec("B.5.bias", z);
         order = {"B.0.weight", "B.0.bias", "B.1.weight", "B.1.bias", "B.3.weight", "B.3.bias", "B.5.weight", "B.5.bias"};
+    } else if (d.boltzmann) {                     // DiagGaussianActor.policy = mlp(o + z, H, "ntanh", H, "relu", 2a)
+        b.trunk("policy", o + z, H, H);
+        b.mat("policy.5.weight", 2 * a, H); b.vec("policy.5.bias", 2 * a);
+        append(order, trunk_names("policy")); append(order, {"policy.5.weight", "policy.5.bias"});
     } else {                                      // Actor, fb_modules.py:91-105
         if (gm.single) {                          // trunk = mlp(o + z, H, "ntanh", H, "irelu", H, "irelu")
             b.trunk("trunk", o + z, H, H);
@@ -169,7 +183,7 @@ struct Ws {
     BSet bsA, bsO, bsM, bsF; // target / online passes on next_goal, z-mix pass on backward_input[perm], hindsight pass
     FSet fsT, fsO;
     ASet as;
-    Buf dF1, dF2, dBm, dy, dp, dtr, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, cov, inv_cov, BinvC;
+    Buf dF1, dF2, dBm, dy, dp, dtr, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, a_dact, cov, inv_cov, BinvC;
     float* ln_partials = nullptr;
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
     float* splitk = nullptr;            // split-K partial slab
@@ -257,11 +271,14 @@ Ws carve(const fbhip_dims& d, void* base) {
         s->statsA = c.f(2 * (size_t)B); s->statsZ = c.f(2 * (size_t)B);
     }
     w.as.pre1o = c.buf(B, H); w.as.t1o = c.buf(B, H); w.as.pre1z = c.buf(B, H); w.as.t1z = c.buf(B, H);
-    w.as.h = c.buf(B, gm.hw); w.as.tr = c.buf(gm.trunk ? B : 1, H); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, a); w.as.mu = c.buf(B, a);
+    const Geom ga = actor_geom_of(d);
+    const int Na = head_width(d);
+    w.as.h = c.buf(B, ga.hw); w.as.tr = c.buf(ga.trunk ? B : 1, H); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, Na); w.as.mu = c.buf(B, a);
     w.as.statsO = c.f(2 * (size_t)B); w.as.statsZ = c.f(2 * (size_t)B);
     w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
-    w.dp = c.buf(B, 2 * H); w.dtr = c.buf(gm.trunk ? B : 1, H); w.dh = c.buf(B, gm.hw); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
-    w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, a); w.a_dp = c.buf(B, H);
+    w.dp = c.buf(B, 2 * H); w.dtr = c.buf(gm.trunk ? B : 1, H); w.dh = c.buf(B, gm.hw > ga.hw ? gm.hw : ga.hw); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
+    w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, Na); w.a_dp = c.buf(B, H);
+    w.a_dact = c.buf(B, a);
     w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
     w.ln_partials = c.f((size_t)2 * ((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);   // two trunks
@@ -317,6 +334,12 @@ BwdP bwd_p(float* base, const NetLayout& L) {
 }
 ActP act_p(float* base, const NetLayout& L) {
     ActP a;
+    if (L.by_name.count("policy.5.weight")) {                // DiagGaussianActor
+        a.o = trunk_p(base, L, "policy"); a.oz = a.o;
+        a.W3 = a.b3 = nullptr;
+        a.W4 = base + L.by_name.at("policy.5.weight").off; a.b4 = base + L.by_name.at("policy.5.bias").off;
+        return a;
+    }
     if (L.by_name.count("trunk.5.weight")) {
         a.o = trunk_p(base, L, "trunk"); a.oz = a.o;
         a.Wt = base + L.by_name.at("trunk.5.weight").off; a.bt = base + L.by_name.at("trunk.5.bias").off;
@@ -351,6 +374,7 @@ struct fbhip_ctx {
     std::vector<InferGraph> infer_graphs;    // batch-1 fast path (fbhip_act / fbhip_z_correl)
     float* h_in = nullptr;                   // pinned host staging, same layout as w.act_in
     float* h_out = nullptr;                  // pinned: action / correlation
+    Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
     std::string err;
 };
 
@@ -707,9 +731,9 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
 void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
                      Chain& out) {
     const fbhip_dims& d = c->d;
-    const Geom gm = geom_of(d);
-    const int H = d.hidden_dim, a = d.action_dim, La = pad4(a), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
-    // preprocess == 0: the one branch reads [obs|z] (the Xz panel)
+    const Geom gm = actor_geom_of(d);
+    const int H = d.hidden_dim, a = head_width(d), La = pad4(a), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
+    // preprocess == 0 / boltzmann: the one branch reads [obs|z] (the Xz panel)
     const float* X1 = gm.single ? Xz : Xo;
     const int ld1 = gm.single ? ldz : ldo;
     ASet* Sp = &S;
@@ -729,11 +753,12 @@ void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, cons
         out.push_back([=](Ops& o) {
             o.gemms.push_back(P(Sp->h.p, hw, 1, W.Wt, hw, 1, Sp->tr.p, H, rows, H, hw, W.bt, EPI_BIAS_RELU));
         });
-    out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(gm.trunk ? Sp->tr.p : Sp->h.p, feat, 1, W.W3, feat, 1, Sp->p.p, H, rows, H, feat, W.b3, EPI_BIAS_RELU));
-    });
-    out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS));
+    if (!gm.boltz)
+        out.push_back([=](Ops& o) {
+            o.gemms.push_back(P(gm.trunk ? Sp->tr.p : Sp->h.p, feat, 1, W.W3, feat, 1, Sp->p.p, H, rows, H, feat, W.b3, EPI_BIAS_RELU));
+        });
+    out.push_back([=](Ops& o) {                              // head: mu (a wide) / [loc | raw log-std] (2a wide, from h directly)
+        o.gemms.push_back(P(gm.boltz ? Sp->h.p : Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS));
     });
 }
 
@@ -747,24 +772,26 @@ int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float
 void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz,
                      ASet& S, int rows, Chain& out) {
     const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, Fd = d.feature_dim, a = d.action_dim, La = pad4(a);
+    const int H = d.hidden_dim, a = head_width(d), La = pad4(a);
     Ws* w = &c->w;
     ASet* Sp = &S;
-    out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->a_dpremu.p, La, 0, Sp->p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
-        o.gemms.push_back(P(w->a_dpremu.p, La, 1, W.W4, H, 0, w->a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, Sp->p.p, H));
-    });
-    const Geom gm = geom_of(d);
+    const Geom gm = actor_geom_of(d);
     const int Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
     const bool trunk = gm.trunk;
+    out.push_back([=](Ops& o) {                              // head; boltzmann: straight into d h (there is no policy hidden layer)
+        const float* x = gm.boltz ? Sp->h.p : Sp->p.p;
+        o.gemms.push_back(P(w->a_dpremu.p, La, 0, x, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
+        o.gemms.push_back(P(w->a_dpremu.p, La, 1, W.W4, H, 0, gm.boltz ? w->dh.p : w->a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, x, H));
+    });
     const float* X1 = gm.single ? Xz : Xo;                   // preprocess == 0: the one branch reads [obs|z]
     const int ld1 = gm.single ? ldz : ldo;
-    out.push_back([=](Ops& o) {
-        const float* x = trunk ? Sp->tr.p : Sp->h.p;
-        float* dx = trunk ? w->dtr.p : w->dh.p;
-        o.gemms.push_back(P(w->a_dp.p, H, 0, x, feat, 0, G.W3, feat, H, feat, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
-        o.gemms.push_back(P(w->a_dp.p, H, 1, W.W3, feat, 0, dx, feat, rows, feat, H, nullptr, EPI_MASK_RELU, x, feat));
-    });
+    if (!gm.boltz)
+        out.push_back([=](Ops& o) {
+            const float* x = trunk ? Sp->tr.p : Sp->h.p;
+            float* dx = trunk ? w->dtr.p : w->dh.p;
+            o.gemms.push_back(P(w->a_dp.p, H, 0, x, feat, 0, G.W3, feat, H, feat, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
+            o.gemms.push_back(P(w->a_dp.p, H, 1, W.W3, feat, 0, dx, feat, rows, feat, H, nullptr, EPI_MASK_RELU, x, feat));
+        });
     if (trunk)
         out.push_back([=](Ops& o) {
             o.gemms.push_back(P(w->dtr.p, H, 0, Sp->h.p, hw, 0, G.Wt, hw, H, hw, rows, nullptr, EPI_NONE, nullptr, 0, G.bt));
@@ -802,6 +829,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     const Geom gm = geom_of(d);
     const int Fo = gm.Fo, hw = gm.hw;
     const int aoff = gm.single ? o + z : o;      // column of the action inside the ForwardMap input panels
+    const int Lh = pad4(head_width(d));          // leading dimension of the policy head's output
     // next_goal = batch.next_goal if goal_space else batch.next_obs (fb_ddpg.py:440-443); always its own zero-padded panel
     const float* next_goal = w.next_goal.p;
     const int ld_ng = w.next_goal.ld;
@@ -882,8 +910,8 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst) {
         return [=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_policy_sample(w.as.premu.p, La, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
-                                              ld_dst, B, a, q));
+                HIPCK(c, launch_policy_sample(w.as.premu.p, Lh, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
+                                              ld_dst, B, a, c->sq, q));
                 return (int)FBHIP_OK;
             });
         };
@@ -954,7 +982,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             o2.post.push_back([=, &w](hipStream_t q) -> int {
                 HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + aoff, w.Xopi.ld,
                                            hp.stddev, w.dF1.p, w.dF2.p, hp.want_metrics ? w.metrics : nullptr, w.pw_scratch,
-                                           B, z, a, q));
+                                           B, z, a, q, c->sq, w.as.premu.p, Lh, w.so.eps_actor, a));
                 return (int)FBHIP_OK;
             });
         });
@@ -980,10 +1008,20 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                                           nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0, H});
         });
         // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
-        ch.push_back([=, &w](Ops& o2) {
-            o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
-                                 EPI_TANH_BWD, w.as.mu.p, La));
-        });
+        if (d.boltzmann)                         // ... or through the SquashedNormal's rsample and log_prob (fb_ddpg.py:393-406)
+            ch.push_back([=, &w](Ops& o2) {
+                o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, 0, w.a_dact.p, La, B, a, H));
+                o2.post.push_back([=, &w](hipStream_t q) -> int {
+                    HIPCK(c, launch_squash_head_bwd(w.a_dact.p, La, w.as.premu.p, Lh, w.so.eps_actor, a, w.a_dpremu.p, Lh, B, a,
+                                                    c->sq, q));
+                    return (int)FBHIP_OK;
+                });
+            });
+        else
+            ch.push_back([=, &w](Ops& o2) {
+                o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
+                                     EPI_TANH_BWD, w.as.mu.p, La));
+            });
         actor_bwd_chain(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
         RC(run_chain(c, ch, s));
     }
@@ -1059,6 +1097,7 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
     RC(check_dims(dims));
     fbhip_ctx* c = new fbhip_ctx();
     c->d = *dims;
+    c->sq.on = dims->boltzmann ? 1 : 0;
     for (int n = 0; n < 3; ++n) c->L[n] = build_layout(*dims, n);
     // pinned staging of the batch-1 entry points (a few hundred bytes; host memory, not device memory)
     if (hipHostMalloc((void**)&c->h_in, act_in_floats(*dims) * sizeof(float), hipHostMallocDefault) != hipSuccess ||
@@ -1127,6 +1166,18 @@ int fbhip_replay_bind(fbhip_ctx* c, const float* observation, const float* actio
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
     c->replay_bound = true;
+    return FBHIP_OK;
+}
+
+int fbhip_set_policy_squash(fbhip_ctx* c, float temp, float log_std_min, float log_std_max) {
+    if (!c) return FBHIP_E_INVALID;
+    if (!c->d.boltzmann) { c->err = g_err = "fbhip_set_policy_squash: the context was not created with boltzmann"; return FBHIP_E_STATE; }
+    if (!(log_std_min < log_std_max)) { c->err = g_err = "fbhip_set_policy_squash: empty log_std interval"; return FBHIP_E_INVALID; }
+    c->sq = Squash{1, temp, log_std_min, log_std_max};
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);        // the values are baked into captured launches
+    c->graphs.clear();
+    for (auto& g : c->infer_graphs) (void)hipGraphExecDestroy(g.exec);
+    c->infer_graphs.clear();
     return FBHIP_OK;
 }
 
@@ -1296,7 +1347,7 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
     HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, nin * sizeof(float), hipMemcpyHostToDevice, s));
     // Actor.forward (fb_modules.py:107-121): first layers (the weight's zero pad columns absorb whatever follows
     // obs / [obs|z] in the staging vector); preprocess == 0 has ONE branch on [obs|z] ...
-    const Geom gm = geom_of(d);
+    const Geom gm = actor_geom_of(d);
     GemvGroup g1{}; g1.n = gm.single ? 1 : 2;
     g1.p[0] = GV(w.act_in, A.o.W1, A.o.ld1, A.o.b1, pre1o, H, A.o.ld1, false);
     g1.p[1] = GV(w.act_in, A.oz.W1, A.oz.ld1, A.oz.b1, pre1z, H, A.oz.ld1, false);
@@ -1316,12 +1367,15 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
         HIPCK(c, launch_gemv_group(gt, s));
         feat = tr; nfeat = H;
     }
-    GemvGroup g3{}; g3.n = 1;
-    g3.p[0] = GV(feat, A.W3, nfeat, A.b3, pv, H, nfeat, true);
-    HIPCK(c, launch_gemv_group(g3, s));
-    // ... head + TruncatedNormal
-    HIPCK(c, launch_act_head(pv, A.W4, H, A.b4, a, H, stddev, eval_mode, has_noise ? w.act_in + act_noise_off(d) : nullptr,
-                             c->seed, c->rank, w.st, w.act_out, s));
+    if (!gm.boltz) {
+        GemvGroup g3{}; g3.n = 1;
+        g3.p[0] = GV(feat, A.W3, nfeat, A.b3, pv, H, nfeat, true);
+        HIPCK(c, launch_gemv_group(g3, s));
+        feat = pv;
+    }
+    // ... head + TruncatedNormal / SquashedNormal
+    HIPCK(c, launch_act_head(feat, A.W4, H, A.b4, a, H, stddev, eval_mode, has_noise ? w.act_in + act_noise_off(d) : nullptr,
+                             c->seed, c->rank, w.st, w.act_out, c->sq, s));
     HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, (size_t)a * sizeof(float), hipMemcpyDeviceToHost, s));
     (void)o; (void)z;
     return FBHIP_OK;
@@ -1379,7 +1433,7 @@ int fbhip_act(fbhip_ctx* c, const float* host_obs, const float* host_z, const fl
     RC(need_bound(c, false));
     if (!host_obs || !host_z || !host_action_out) { c->err = g_err = "fbhip_act: null argument"; return FBHIP_E_INVALID; }
     if (!c->h_in) { c->err = g_err = "fbhip_act: pinned staging unavailable"; return FBHIP_E_STATE; }
-    if (c->d.hidden_dim > 2048 || geom_of(c->d).hw > 2048) { c->err = g_err = "fbhip_act: layer wider than 2048"; return FBHIP_E_INVALID; }
+    if (c->d.hidden_dim > 2048 || actor_geom_of(c->d).hw > 2048) { c->err = g_err = "fbhip_act: layer wider than 2048"; return FBHIP_E_INVALID; }
     const fbhip_dims& d = c->d;
     memcpy(c->h_in, host_obs, (size_t)d.obs_dim * sizeof(float));
     memcpy(c->h_in + d.obs_dim, host_z, (size_t)d.z_dim * sizeof(float));
@@ -1411,14 +1465,14 @@ int fbhip_actor_forward(fbhip_ctx* c, const float* obs, int32_t ld_obs, const fl
     hipStream_t s = (hipStream_t)stream;
     const fbhip_dims& d = c->d;
     Ws& w = c->w;
-    const int La = pad4(d.action_dim);
+    const int La = pad4(head_width(d));
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
         const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
         HIPCK(c, launch_concat2(w.Xoz.p, w.Xoz.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, z + (size_t)r0 * ld_z, ld_z,
                                 d.z_dim, n, s));
         RC(actor_fwd(c, c->A_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.as, n, s));
         HIPCK(c, launch_policy_sample(w.as.premu.p, La, noise ? noise + (size_t)r0 * d.action_dim : nullptr, d.action_dim,
-                                      stddev, clip, nullptr, 0, action_out + (size_t)r0 * ld_out, ld_out, n, d.action_dim, s));
+                                      stddev, clip, nullptr, 0, action_out + (size_t)r0 * ld_out, ld_out, n, d.action_dim, c->sq, s));
     }
     return FBHIP_OK;
 }

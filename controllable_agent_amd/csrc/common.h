@@ -81,14 +81,21 @@ hipError_t launch_l2norm_fwd_group(const L2Group& g, hipStream_t s);
 hipError_t launch_l2norm_fwd(const float* y, int ldy, float* out, int ldo, float* norms, int rows, int d,
                              float scale, hipStream_t s);
 // policy head: mu = tanh(pre); action = clampST(mu + clip(noise*std))   (utils.py:171-185)
+// boltzmann (fb_modules.py:129-151, utils.py:188-232): the policy head emits [loc | raw log-std] (2a wide),
+//   log_std = lo + (hi - lo)/2 (tanh(raw) + 1),  action = tanh(loc + exp(log_std) eps)   (SquashedNormal, no clamp)
+struct Squash { int on; float temp, lo, hi; };
 hipError_t launch_policy_sample(const float* pre, int ldp, const float* noise, int ldn, float stddev, float clip,
-                                float* mu, int ldmu, float* action, int lda, int rows, int a, hipStream_t s);
+                                float* mu, int ldmu, float* action, int lda, int rows, int a, Squash sq, hipStream_t s);
+// boltzmann actor loss backward at the policy head (fb_ddpg.py:393, 399, 406): d action [rows,a] -> d [loc | raw] [rows,2a]
+hipError_t launch_squash_head_bwd(const float* dact, int ldd, const float* pre, int ldp, const float* noise, int ldn,
+                                  float* dpre, int ldo, int rows, int a, Squash sq, hipStream_t s);
 // actor loss (fb_ddpg.py:400-406): Q = min(F1.z, F2.z); loss = -mean Q; dF_i = -z/B * w_i
 // metrics == nullptr skips the (metric-only) finalize launch
 hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz,
                              const float* mu, int ldmu, const float* action, int lda, float stddev,
                              float* dF1, float* dF2, float* metrics, float* scratch /* >= 2*ceil(rows/4) floats */,
-                             int rows, int d, int a, hipStream_t s);
+                             int rows, int d, int a, hipStream_t s, Squash sq = Squash{0, 1.f, -5.f, 2.f},
+                             const float* pre = nullptr, int ldp = 0, const float* noise = nullptr, int ldn = 0);
 
 // ---- pairwise FB loss ----------------------------------------------------------------------------------
 size_t pairwise_scratch_floats(int B, int d);
@@ -132,7 +139,7 @@ struct GemvGroup { GemvProblem p[GEMV_MAX_GROUP]; int n; };
 hipError_t launch_gemv_group(GemvGroup g, hipStream_t s);
 hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
                            int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
-                           hipStream_t s);
+                           Squash sq, hipStream_t s);
 hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s);
 
 // ---- sampler -----------------------------------------------------------------------------------------------

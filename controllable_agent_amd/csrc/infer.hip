@@ -98,11 +98,13 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvGroup g) {
 __global__ void __launch_bounds__(256) act_head_kernel(const float* __restrict__ x, const float* __restrict__ W, int ldw,
                                                        const float* __restrict__ bias, int a, int K, float stddev,
                                                        int eval_mode, const float* __restrict__ noise, unsigned k0,
-                                                       unsigned k1, StepState* __restrict__ st, float* __restrict__ out) {
+                                                       unsigned k1, StepState* __restrict__ st, float* __restrict__ out,
+                                                       const Squash sq) {
     __shared__ float pre[64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (int n = wid; n < a; n += 4) {
+    const int nout = sq.on ? 2 * a : a;            // DiagGaussianActor: [loc | raw log-std]
+    for (int n = wid; n < nout; n += 4) {
         const float4* w4 = reinterpret_cast<const float4*>(W + (size_t)n * ldw);
         float acc = 0.f;
         for (int k4 = lane; k4 < K / 4; k4 += 64) {
@@ -127,8 +129,13 @@ __global__ void __launch_bounds__(256) act_head_kernel(const float* __restrict__
                 box_muller(r.x, r.y, n0, n1);
                 e = (n & 1) ? n1 : n0;
             }
-            const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
-            act = fminf(fmaxf(mu + e * stddev, lo), hi);
+            if (sq.on) {                           // SquashedNormal.sample(): tanh(loc + exp(log_std) eps)
+                const float log_std = sq.lo + 0.5f * (sq.hi - sq.lo) * (tanhf(pre[a + n]) + 1.f);
+                act = tanhf(pre[n] + expf(log_std) * e);
+            } else {
+                const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
+                act = fminf(fmaxf(mu + e * stddev, lo), hi);
+            }
         }
         out[n] = act;
     }
@@ -182,11 +189,11 @@ hipError_t launch_gemv_group(GemvGroup g, hipStream_t s) {
 
 hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
                            int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
-                           hipStream_t s) {
-    if (a > 64 || (K & 3) || (ldw & 3)) return hipErrorInvalidValue;
+                           Squash sq, hipStream_t s) {
+    if ((sq.on ? 2 * a : a) > 64 || (K & 3) || (ldw & 3)) return hipErrorInvalidValue;
     const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
     hipLaunchKernelGGL(act_head_kernel, dim3(1), dim3(256), 0, s, x, W, ldw, bias, a, K, stddev, eval_mode, noise, k0, k1, st,
-                       out);
+                       out, sq);
     return hipGetLastError();
 }
 

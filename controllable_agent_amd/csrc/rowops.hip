@@ -445,14 +445,21 @@ hipError_t launch_l2norm_bwd(const float* dB, int lddb, const float* y, int ldy,
 __global__ void __launch_bounds__(256) policy_sample_kernel(const float* __restrict__ pre, int ldp,
                                                             const float* __restrict__ noise, int ldn, float stddev,
                                                             float clip, float* __restrict__ mu, int ldmu,
-                                                            float* __restrict__ action, int lda, int rows, int a) {
+                                                            float* __restrict__ action, int lda, int rows, int a,
+                                                            const Squash sq) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * a) return;
     const int r = idx / a, c = idx % a;
-    const float m = tanhf(pre[(size_t)r * ldp + c]);
+    const float loc = pre[(size_t)r * ldp + c];
+    const float m = tanhf(loc);                    // Actor: mu; DiagGaussianActor: dist.mean = tanh(loc)
     if (mu != nullptr) mu[(size_t)r * ldmu + c] = m;
     float act = m;
-    if (noise != nullptr) {
+    if (sq.on) {
+        if (noise != nullptr) {                    // SquashedNormal.sample / rsample: tanh(loc + scale eps), no clamp
+            const float log_std = sq.lo + 0.5f * (sq.hi - sq.lo) * (tanhf(pre[(size_t)r * ldp + a + c]) + 1.f);
+            act = tanhf(loc + expf(log_std) * noise[(size_t)r * ldn + c]);
+        }
+    } else if (noise != nullptr) {
         float e = noise[(size_t)r * ldn + c] * stddev;
         if (clip >= 0.f) e = fminf(fmaxf(e, -clip), clip);
         const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
@@ -462,10 +469,44 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(const float* __restr
 }
 
 hipError_t launch_policy_sample(const float* pre, int ldp, const float* noise, int ldn, float stddev, float clip,
-                                float* mu, int ldmu, float* action, int lda, int rows, int a, hipStream_t s) {
+                                float* mu, int ldmu, float* action, int lda, int rows, int a, Squash sq, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(policy_sample_kernel, dim3((rows * a + 255) / 256), dim3(256), 0, s, pre, ldp, noise, ldn,
-                       stddev, clip, mu, ldmu, action, lda, rows, a);
+                       stddev, clip, mu, ldmu, action, lda, rows, a, sq);
+    return hipGetLastError();
+}
+
+// torch.nn.functional.softplus (beta 1, threshold 20)
+__device__ __forceinline__ float softplus20(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// Backward of  L = mean_rows( temp * sum_j log_prob_j - Q )  at the DiagGaussianActor head, given dQ-part d action
+// (already scaled by -1/B through dF): with u = loc + std eps (eps constant), action = tanh(u),
+//   log_prob_j = Normal(loc, std).log_prob(u) - 2 (log 2 - u - softplus(-2u))       (utils.py:212-215)
+//   d log_prob / du = 2 tanh(u);  the Normal term is -eps^2/2 - log std: no loc gradient, -1/std wrt std
+// =>  du = dact (1 - tanh(u)^2) + (temp/B) 2 tanh(u);  dloc = du;  dlog_std = du eps std - temp/B;
+//     draw = dlog_std (hi - lo)/2 (1 - tanh(raw)^2)
+__global__ void __launch_bounds__(256) squash_head_bwd_kernel(const float* __restrict__ dact, int ldd,
+                                                              const float* __restrict__ pre, int ldp,
+                                                              const float* __restrict__ noise, int ldn,
+                                                              float* __restrict__ dpre, int ldo, int rows, int a,
+                                                              const Squash sq) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * a) return;
+    const int r = idx / a, c = idx % a;
+    const float loc = pre[(size_t)r * ldp + c], t = tanhf(pre[(size_t)r * ldp + a + c]), e = noise[(size_t)r * ldn + c];
+    const float half = 0.5f * (sq.hi - sq.lo), std = expf(sq.lo + half * (t + 1.f));
+    const float th = tanhf(loc + std * e), tb = sq.temp / (float)rows;
+    const float du = dact[(size_t)r * ldd + c] * (1.f - th * th) + tb * 2.f * th;
+    dpre[(size_t)r * ldo + c] = du;
+    dpre[(size_t)r * ldo + a + c] = (du * e * std - tb) * half * (1.f - t * t);
+}
+
+hipError_t launch_squash_head_bwd(const float* dact, int ldd, const float* pre, int ldp, const float* noise, int ldn,
+                                  float* dpre, int ldo, int rows, int a, Squash sq, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (!sq.on || noise == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(squash_head_bwd_kernel, dim3((rows * a + 255) / 256), dim3(256), 0, s, dact, ldd, pre, ldp, noise,
+                       ldn, dpre, ldo, rows, a, sq);
     return hipGetLastError();
 }
 
@@ -477,7 +518,9 @@ __global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict
                                                          const float* __restrict__ mu, int ldmu,
                                                          const float* __restrict__ act, int lda, float stddev,
                                                          float* __restrict__ dF1, float* __restrict__ dF2,
-                                                         float* __restrict__ part, int rows, int d, int a) {
+                                                         float* __restrict__ part, int rows, int d, int a,
+                                                         const Squash sq, const float* __restrict__ pre, int ldp,
+                                                         const float* __restrict__ noise, int ldn) {
     __shared__ float red[4][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
@@ -506,7 +549,12 @@ __global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict
                 dF2[(size_t)row * ldf + j] = -zz[i] * inv_b * w2;
             }
         }
-        if (lane < a) {
+        if (lane < a && sq.on) {                   // SquashedNormal.log_prob(action) with the cached pre-image (utils.py:212-215)
+            const float loc = pre[(size_t)row * ldp + lane], e = noise[(size_t)row * ldn + lane];
+            const float log_std = sq.lo + 0.5f * (sq.hi - sq.lo) * (tanhf(pre[(size_t)row * ldp + a + lane]) + 1.f);
+            const float u = loc + expf(log_std) * e;
+            lp = -0.5f * e * e - log_std - 0.91893853320467274178f - 2.f * (0.69314718055994530942f - u - softplus20(-2.f * u));
+        } else if (lane < a) {
             const float df = act[(size_t)row * lda + lane] - mu[(size_t)row * ldmu + lane];
             lp = -(df * df) / (2.f * stddev * stddev) - logf(stddev) - 0.91893853320467274178f;
         }
@@ -523,13 +571,13 @@ __global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict
 
 __global__ void __launch_bounds__(64) actor_loss_finalize_kernel(const float* __restrict__ part, int nblk, int rows,
                                                                  float* __restrict__ metrics, int m_loss, int m_q,
-                                                                 int m_lp) {
+                                                                 int m_lp, float temp /* 0: loss = -mean Q */) {
     double q = 0.0, l = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 64) { q += (double)part[2 * b]; l += (double)part[2 * b + 1]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o); l += __shfl_xor(l, o); }
     if (threadIdx.x == 0) {
-        metrics[m_loss] = (float)(-q / rows);
+        metrics[m_loss] = (float)((temp * l - q) / rows);         // fb_ddpg.py:406
         metrics[m_q] = (float)(q / rows);
         metrics[m_lp] = (float)(l / rows);
     }
@@ -537,14 +585,17 @@ __global__ void __launch_bounds__(64) actor_loss_finalize_kernel(const float* __
 
 hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz, const float* mu,
                              int ldmu, const float* action, int lda, float stddev, float* dF1, float* dF2,
-                             float* metrics, float* scratch, int rows, int d, int a, hipStream_t s) {
+                             float* metrics, float* scratch, int rows, int d, int a, hipStream_t s, Squash sq,
+                             const float* pre, int ldp, const float* noise, int ldn) {
     if (d > 64 * L2_MAXE || a > 64 || scratch == nullptr) return hipErrorInvalidValue;
+    if (sq.on && (pre == nullptr || noise == nullptr)) return hipErrorInvalidValue;
     const int nblk = (rows + 3) / 4;
     hipLaunchKernelGGL(actor_loss_kernel, dim3(nblk), dim3(256), 0, s, F1, F2, ldf, z, ldz, mu, ldmu, action, lda,
-                       stddev, dF1, dF2, scratch, rows, d, a);
+                       stddev, dF1, dF2, scratch, rows, d, a, sq, pre, ldp, noise, ldn);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
-    hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17);
+    hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17,
+                       sq.on ? sq.temp : 0.f);
     return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 6
+#define FBHIP_ABI_VERSION 7
 
 enum {
     FBHIP_OK = 0,
@@ -79,6 +79,11 @@ typedef struct fbhip_dims {
                                     * (fb_modules.py:99-103, 174-178); add_trunk is then ignored */
     int32_t norm_z;                /* cfg.norm_z (default 1).  0: BackwardMap output unprojected (fb_modules.py:228-229),
                                     * z = sqrt(d) U g/|g| (fb_ddpg.py:229-231), no re-projection of mixed rows (:483) */
+    int32_t boltzmann;             /* cfg.boltzmann (default 0).  1: the actor is DiagGaussianActor (fb_modules.py:129-151; net
+                                    * layout policy.{0,1,3,5}, head 2a wide) with a SquashedNormal policy (utils.py:188-232):
+                                    * next_action = dist.sample(), update_actor uses dist.rsample() and
+                                    * actor_loss = (temp * log_prob - Q).mean() (fb_ddpg.py:304-306, 391-393, 406);
+                                    * stddev / stddev_clip are ignored; temp and log_std_bounds: fbhip_set_policy_squash */
 } fbhip_dims;
 
 typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82 */
@@ -167,6 +172,9 @@ int fbhip_replay_bind(fbhip_ctx* ctx, const float* observation, const float* act
                       const float* goal, const int32_t* episode_len, const int64_t* cum_len,
                       int32_t n_episodes, int32_t t1, int32_t fixed_length);
 int fbhip_set_seed(fbhip_ctx* ctx, uint64_t seed, uint32_t rank);
+/* boltzmann contexts only: cfg.temp and cfg.log_std_bounds (fb_ddpg.py:70-71; defaults 1, (-5, 2) are in effect until
+ * this is called).  Drops every captured graph (the values are baked into the launches). */
+int fbhip_set_policy_squash(fbhip_ctx* ctx, float temp, float log_std_min, float log_std_max);
 int fbhip_set_step_counts(fbhip_ctx* ctx, int32_t fb_steps, int32_t actor_steps, void* stream); /* Adam t */
 int fbhip_get_step_counts(fbhip_ctx* ctx, int32_t* host_fb_steps, int32_t* host_actor_steps, void* stream);
 

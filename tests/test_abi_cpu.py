@@ -74,6 +74,25 @@ def test_single_trunk_layout_follows_the_reference_module(lib):
                                                              for w in ("weight", "bias")]
 
 
+def test_boltzmann_actor_layout_follows_the_reference_module(lib):
+    """boltzmann: DiagGaussianActor.policy = mlp(o + z, H, "ntanh", H, "relu", 2a) (fb_modules.py:138)."""
+    l = lib.load()
+    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1, 1, 1)
+    got = []
+    for i in range(l.fbhip_layout_count(C.byref(d), lib.NET_ACTOR)):
+        t = lib.TensorDesc()
+        assert l.fbhip_layout_entry(C.byref(d), lib.NET_ACTOR, i, C.byref(t)) == 0
+        got.append((t.name.decode(), t.rows, t.cols))
+    assert got == [("policy.0.weight", 32, 13), ("policy.0.bias", 1, 32), ("policy.1.weight", 1, 32), ("policy.1.bias", 1, 32),
+                   ("policy.3.weight", 32, 32), ("policy.3.bias", 1, 32), ("policy.5.weight", 6, 32), ("policy.5.bias", 1, 6)]
+    assert l.fbhip_net_param_count(C.byref(d), lib.NET_ACTOR) == 32 * 13 + 32 * 3 + 32 * 32 + 32 + 6 * 32 + 6
+    ctx = C.c_void_p()
+    d0 = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1, 1, 0)
+    assert l.fbhip_create(C.byref(d0), C.byref(ctx)) == 0
+    assert l.fbhip_set_policy_squash(ctx, 1.0, -5.0, 2.0) == -3          # not a boltzmann context
+    assert l.fbhip_destroy(ctx) == 0
+
+
 def test_bad_dims_fail_loudly(lib):
     l = lib.load()
     bad = lib.Dims(1024, 24, 6, 24, 50, 1022, 512, 526, 0, 0, 1, 1)       # hidden_dim % 4 != 0

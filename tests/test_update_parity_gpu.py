@@ -40,7 +40,9 @@ def _param_close(got, ref, lr, name):
                                              ("tiny_randw_nonorm_trace", "simplified_walker"),
                                              ("tiny_trunk_trace", "simplified_walker"),
                                              ("tiny_single_trunk_trace", None),
-                                             ("tiny_single_trunk_goal_trace", "simplified_walker")])
+                                             ("tiny_single_trunk_goal_trace", "simplified_walker"),
+                                             ("tiny_boltzmann_trace", None),
+                                             ("tiny_boltzmann_goal_trace", "simplified_walker")])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
@@ -71,7 +73,7 @@ def test_teacher_forced_against_reference_trace(name, goal_space):
                           ("tF2", oracle.last["tF2"]), ("Bm", oracle.last["Bm"]), ("tB", oracle.last["tB"]),
                           ("pi_action", oracle.last["pi_action"]), ("mu", oracle.last["mu"])):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < 2e-5, (s, view)
-        for view, ref in (("dy", oracle.last["dy"]), ("d_premu", oracle.last["d_mu"] * (1 - oracle.last["mu"] ** 2))):
+        for view, ref in (("dy", oracle.last["dy"]), ("d_premu", oracle.last["d_premu"])):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < GRAD_REL_L2, (s, view)
         for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward"), ("actor", "grads_actor")):
             for k, g in agent._grad_views[net].state_dict().items():
@@ -499,6 +501,33 @@ def test_rand_weight_device_draws():
     mixed = agent.workspace_view("mix_uniform").cpu()[0] < cfg.mix_ratio
     z = agent.workspace_view("z").cpu()
     assert 0.3 < float(mixed.float().mean()) < 0.7 and H.rel_err(z[mixed], want[mixed]) < 2e-5
+
+
+def test_boltzmann_inference_paths():
+    """boltzmann=True (DiagGaussianActor + SquashedNormal, fb_modules.py:129-151): eval act = tanh(loc); exploration act =
+    tanh(loc + exp(log_std) eps) without a clamp, batch-1 and batched, with non-default log_std_bounds."""
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=16, boltzmann=True, log_std_min=-2.0, log_std_max=0.5)
+    rng = np.random.default_rng(29)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    agent = H.make_hip_agent(cfg, nets)
+    assert list(agent.actor.state_dict()) == [f"policy.{i}.{w}" for i in (0, 1, 3, 5) for w in ("weight", "bias")]
+    assert agent.actor.state_dict()["policy.5.weight"].shape == (6, 32)
+    obs = torch.from_numpy(rng.standard_normal((6, cfg.obs_dim)).astype(np.float32))
+    z = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((6, cfg.z_dim)).astype(np.float32)), cfg.z_dim)
+    eps = torch.from_numpy(rng.standard_normal((6, cfg.action_dim)).astype(np.float32))
+    _, loc, std = fo.diag_gaussian(nets["actor"], obs, z, cfg.log_std_min, cfg.log_std_max)
+    want_mean, want_sample = torch.tanh(loc), torch.tanh(loc + std * eps)
+    assert H.rel_err(agent._actor(obs.cuda(), z.cuda(), None, 0.2, None).cpu(), want_mean) < 2e-5
+    assert H.rel_err(agent._actor(obs.cuda(), z.cuda(), eps.cuda(), 0.2, 0.3).cpu(), want_sample) < 2e-5    # std / clip ignored
+    for i in range(3):
+        meta = {"z": z[i].numpy()}
+        np.testing.assert_allclose(agent.act(obs[i].numpy(), meta, 0, eval_mode=True), want_mean[i].numpy(), rtol=2e-5, atol=2e-6)
+        got = agent._act_fast(obs[i].numpy(), z[i].numpy(), eps[i].numpy(), 0.2, False)
+        np.testing.assert_allclose(got, want_sample[i].numpy(), rtol=2e-5, atol=2e-6)
+    a1 = agent.act(obs[0].numpy(), {"z": z[0].numpy()}, 0, eval_mode=False)              # device-side Philox noise
+    a2 = agent.act(obs[0].numpy(), {"z": z[0].numpy()}, 1, eval_mode=False)
+    assert np.all(np.abs(a1) < 1) and not np.allclose(a1, a2)
 
 
 @pytest.mark.parametrize("flags", [dict(add_trunk=True), dict(preprocess=False)])
