@@ -150,6 +150,14 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with the gloo backend (RCCL refuses two ranks per device): exercises the "
                          "multi-rank code path of this script on a 1-GPU box; the number it prints is NOT a scaling result")
+    ap.add_argument("--global-batch", action="store_true",
+                    help="data-parallel mode B (FBHipAgent(dp_global_batch=True)): the exact loss of the concatenated "
+                         "world x batch rows (one embedding all-gather per step) instead of per-rank blocks with gradient "
+                         "averaging.  NOT the default bench line")
+    ap.add_argument("--pretend-world", type=int, default=0,
+                    help="with --global-batch on ONE rank: replicate the rank's embeddings N times in the exchange step, so the "
+                         "pairwise kernel runs its share of an N x batch global loss (cost rehearsal of mode B at world N; the "
+                         "loss itself is not meaningful)")
     ap.add_argument("--workload", choices=("walker", "quadruped"), default="walker",
                     help="walker = configs[1], THE bench line; quadruped = configs[2] (no cpu_baseline / kernel probe)")
     args = ap.parse_args()
@@ -172,13 +180,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
 
+    if args.pretend_world > 1:
+        os.environ["FBHIP_PRETEND_WORLD"] = str(args.pretend_world)
     from controllable_agent_amd.agent import FBHipAgent
     torch.manual_seed(1)                       # identical initial weights on every rank
     agent = FBHipAgent(obs_type="states", obs_shape=(W["obs_dim"],), action_shape=(W["action_dim"],),
                        device=dev, num_expl_steps=0, update_every_steps=1, batch_size=W["batch_size"],
                        z_dim=W["z_dim"], hidden_dim=W["hidden_dim"], feature_dim=W["feature_dim"],
                        backward_hidden_dim=W["backward_hidden_dim"], goal_space=goal_space,
-                       use_tb=False, use_wandb=False, use_hiplog=False)
+                       use_tb=False, use_wandb=False, use_hiplog=False, dp_global_batch=args.global_batch)
     # each rank's shard of the 5000-episode buffer (episodes ep % world == rank  <=>  an independent 5000/world-episode draw)
     n_eps = max(args.episodes // world, 8) if args.workload == "walker" else max(min(args.episodes, 1000) // world, 8)
     rb = make_replay(n_eps, 1000, W["obs_dim"], W["action_dim"], dev, seed=100 + rank,
@@ -190,7 +200,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    spl = max(1, args.steps_per_launch) if world == 1 else 1
+    spl = max(1, args.steps_per_launch) if (world == 1 and not args.global_batch) else 1
 
     def run(first_step, n_steps):                 # exactly n_steps updates, spl per graph launch
         done = 0
@@ -236,7 +246,7 @@ def main():
                                    ("fb_ddpg offline on quadruped_walk replay (configs[2]): obs 78, action 12, goal space "
                                     f"simplified_quadruped (g=2), z_dim 100, batch 2048 per GPU; {n_eps}-episode x 1000-step "
                                     "synthetic replay resident in HBM; metrics off"),
-                       "steps_per_graph_launch": spl,
+                       "steps_per_graph_launch": spl, **({"dp_loss": "global batch (mode B)" + (f", pretend world {args.pretend_world}" if args.pretend_world > 1 else "")} if args.global_batch else {}),
                        "global_batch": W["batch_size"] * world, "parallelism": f"dp{world}",
                        "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -13,7 +13,8 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libfbhip.so"
 
 NET_FORWARD, NET_BACKWARD, NET_ACTOR = 0, 1, 2
-PHASE_SAMPLE, PHASE_FB_GRAD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD, PHASE_ALL = 1, 2, 4, 8, 16, 32, 63
+PHASE_SAMPLE, PHASE_FB_FWD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD, PHASE_FB_BWD = 1, 2, 4, 8, 16, 32, 64
+PHASE_FB_GRAD, PHASE_ALL = PHASE_FB_FWD | PHASE_FB_BWD, 127
 NUM_METRICS = 32
 # metric name -> index in the device metrics array (fb_ddpg.py:356-377, 413-418)
 METRIC_INDEX = {n: i for i, n in enumerate(
@@ -66,6 +67,9 @@ PROTOTYPES = {
     "fbhip_get_step_counts": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
     "fbhip_update_many": (C.c_int, [_P, _P, _I, _P]),
+    "fbhip_embeddings_floats": (_Z, [C.POINTER(Dims)]),
+    "fbhip_export_embeddings": (C.c_int, [_P, _P, _P]),
+    "fbhip_bind_global_batch": (C.c_int, [_P, _P, _P, _I, _I]),
     "fbhip_read_metrics": (C.c_int, [_P, C.POINTER(C.c_float), _P]),
     "fbhip_workspace_view": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "fbhip_actor_forward": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _F, _F, _P, _I, _P]),
@@ -104,7 +108,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 7:
+    if lib.fbhip_abi_version() != 8:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

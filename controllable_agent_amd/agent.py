@@ -19,6 +19,7 @@ import ctypes as C
 import dataclasses
 import logging
 import math
+import os
 import re
 import typing as tp
 
@@ -117,6 +118,9 @@ class FBDDPGAgentConfig:
     q_loss_coef: float = 0.01
     additional_metric: bool = False
     add_trunk: bool = False
+    # --- not a reference field: data-parallel loss semantics (distributed.py).  False: every rank's own B x B block with
+    # gradient averaging (mode A).  True: the exact loss of the concatenated world*B batch (mode B, one all-gather more)
+    dp_global_batch: bool = False
 
 
 # the reference's Linear-layer construction order per net (fb_modules.py:91-105, 165-182, 220); each entry is
@@ -662,12 +666,53 @@ class FBHipAgent:
         lib = _lib.load()
         s = stream_ptr()
 
+        global_batch = bool(self.cfg.dp_global_batch)
+        hp_fb = hp
+        if global_batch:                # the FB loss is normalised by the GLOBAL pair counts: its gradients are summed
+            hp_fb = HParams.from_buffer_copy(hp)
+            hp_fb.grad_scale = 1.0
+
         def run_phases(mask: int) -> None:
             # injected draws only matter to the SAMPLE phase
             inj = C.byref(inject) if (inject is not None and mask & _lib.PHASE_SAMPLE) else None
-            check(lib.fbhip_update(self._ctx, C.byref(hp), inj, mask, int(use_graph), s), self._ctx)
+            h = hp_fb if (mask & _lib.PHASE_FB_STEP) else hp
+            check(lib.fbhip_update(self._ctx, C.byref(h), inj, mask, int(use_graph), s), self._ctx)
 
-        dp_update(run_phases, self._fb_grads, self._actor_grads)
+        dp_update(run_phases, self._fb_grads, self._actor_grads, self._exchange_embeddings if global_batch else None)
+
+    def _exchange_embeddings(self) -> None:
+        """Mode B exchange step (distributed.py): all-gather the six embedding panels + discounts of every rank and bind
+        them as the global batch of the next FB_BWD phase.  Buffers are allocated once, so steady-state steps re-use the
+        same pointers (captured graphs stay valid)."""
+        import torch.distributed as dist
+        lib = _lib.load()
+        world, rank = self._world(), self._rank()
+        pretend = int(os.environ.get("FBHIP_PRETEND_WORLD", "0")) if world == 1 else 0      # bench.py --pretend-world
+        if pretend > 1:
+            world = pretend
+        B, Lz = self.cfg.batch_size, (self.cfg.z_dim + 3) // 4 * 4
+        if self.cfg.q_loss:
+            raise NotImplementedError("dp_global_batch: q_loss is not implemented for the global-batch schedule")
+        if world > 1 and B % 32:
+            raise ValueError("dp_global_batch needs batch_size to be a multiple of 32")
+        n = int(lib.fbhip_embeddings_floats(C.byref(self._dims)))
+        assert n == 6 * B * Lz + B
+        if getattr(self, "_gb_send", None) is None or self._gb_recv.shape[0] != world:
+            self._gb_send = torch.empty(n, device=self._device)
+            self._gb_recv = torch.empty((world, n), device=self._device)
+            self._gb_panels = torch.empty((6, world * B, Lz), device=self._device)
+            self._gb_disc = torch.empty(world * B, device=self._device)
+        check(lib.fbhip_export_embeddings(self._ctx, ptr(self._gb_send), stream_ptr()), self._ctx)
+        if pretend > 1 or world == 1:
+            self._gb_recv.copy_(self._gb_send.view(1, -1).expand(world, -1))
+        elif dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self._gb_recv.view(-1), self._gb_send)
+        else:                                             # gloo (tests: several ranks on one GPU)
+            dist.all_gather(list(self._gb_recv.unbind(0)), self._gb_send)
+        # [rank][matrix][row] -> [matrix][rank * B + row]
+        self._gb_panels.view(6, world, B, Lz).copy_(self._gb_recv[:, :6 * B * Lz].view(world, 6, B, Lz).permute(1, 0, 2, 3))
+        self._gb_disc.view(world, B).copy_(self._gb_recv[:, 6 * B * Lz:])
+        check(lib.fbhip_bind_global_batch(self._ctx, ptr(self._gb_panels), ptr(self._gb_disc), world * B, rank * B), self._ctx)
 
     def _metrics(self) -> tp.Dict[str, float]:
         c = self.cfg
@@ -676,6 +721,19 @@ class FBHipAgent:
             return out
         buf = (C.c_float * _lib.NUM_METRICS)()
         check(_lib.load().fbhip_read_metrics(self._ctx, buf, stream_ptr()), self._ctx)
+        if c.dp_global_batch and self._world() > 1:
+            # every rank holds its SHARE of the pairwise terms (global normalisers) and local means of the row-wise
+            # ones: sum the former, average the latter (orth_linf / orth_l2 come from the gathered B: equal everywhere)
+            import torch.distributed as dist
+            t = torch.tensor(list(buf), dtype=torch.float64)
+            share = [_lib.METRIC_INDEX[k] for k in ("target_M", "M1", "fb_loss", "fb_diag", "fb_offdiag", "orth_loss",
+                                                     "orth_loss_diag", "orth_loss_offdiag")]
+            scale = torch.full_like(t, 1.0 / self._world())
+            scale[share] = 1.0
+            t = (t * scale).to(self._device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            for i, v in enumerate(t.tolist()):
+                buf[i] = v
         g = lambda k: float(buf[_lib.METRIC_INDEX[k]])
         for k in ("target_M", "M1", "F1", "B", "B_norm", "z_norm", "fb_loss", "fb_diag", "fb_offdiag"):
             out[k] = g(k)
@@ -710,7 +768,7 @@ class FBHipAgent:
         Returns the metrics of the LAST step (if metrics are on)."""
         c = self.cfg
         stds = {schedule(c.stddev_schedule, step + i) for i in range(n_steps)}
-        if (n_steps < 2 or self._world() > 1 or not isinstance(replay_loader, DeviceReplayBuffer) or
+        if (n_steps < 2 or self._world() > 1 or c.dp_global_batch or not isinstance(replay_loader, DeviceReplayBuffer) or
                 c.update_every_steps != 1 or len(stds) != 1 or not self._use_graph):
             out: tp.Dict[str, float] = {}
             for i in range(n_steps):

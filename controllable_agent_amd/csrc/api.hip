@@ -374,6 +374,9 @@ struct fbhip_ctx {
     std::vector<InferGraph> infer_graphs;    // batch-1 fast path (fbhip_act / fbhip_z_correl)
     float* h_in = nullptr;                   // pinned host staging, same layout as w.act_in
     float* h_out = nullptr;                  // pinned: action / correlation
+    const float* gb_panels = nullptr;        // global-batch data parallel (fbhip_bind_global_batch): [6][gb_rows][Lz]
+    const float* gb_discount = nullptr;      //   F1, F2, B, tF1, tF2, tB of ALL ranks' rows, and their discounts [gb_rows]
+    int gb_rows = 0, gb_off = 0;             //   this rank owns rows [gb_off, gb_off + batch)
     Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
     std::string err;
 };
@@ -880,7 +883,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_p, w.fgoal.p, w.fgoal.ld, w.bsF, B, ch.back(), /*with_projection=*/false);
             }
-            if (mask & FBHIP_PHASE_FB_GRAD) {
+            if (mask & FBHIP_PHASE_FB_FWD) {
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
                 ch.emplace_back();
@@ -906,7 +909,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
 
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
     // forward_net or the new FB weights: in a call that also runs the FB backward it shares that backward's launches
-    const bool early_actor = (mask & FBHIP_PHASE_FB_GRAD) && (mask & FBHIP_PHASE_ACTOR_FWD);
+    const bool early_actor = (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
     auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst) {
         return [=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
@@ -917,7 +920,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         };
     };
 
-    if (mask & FBHIP_PHASE_FB_GRAD) {
+    if (mask & FBHIP_PHASE_FB_FWD) {
         {
             // chain A: targets, no grad (fb_ddpg.py:303-315): actor(next_obs) -> next_action -> forward_target
             // chain B: online F (fb_ddpg.py:318)    chains C, D: target B (:312) and online B (:319)
@@ -935,13 +938,27 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             }
             RC(run_rounds(c, ch, s));
         }
+    }
+    if (mask & FBHIP_PHASE_FB_BWD) {
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
         const float* BmO = d.norm_z ? w.bsO.Bm.p : w.bsO.y.p;      // online / target B(next_goal) as the loss sees them
         const float* BmT = d.norm_z ? w.bsA.Bm.p : w.bsA.y.p;
-        HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, BmO, w.fsT.F1.p, w.fsT.F2.p, BmT, w.disc, B, z,
-                                    Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
-        if (hp.want_metrics || hp.q_loss)       // B^T B: metrics (fb_ddpg.py:371) and the q_loss covariance (:334)
-            RC(run_gemms(c, {P(BmO, Lz, 0, BmO, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
+        const int Bg = c->gb_rows;              // > 0: the loss couples the rows of ALL ranks (global-batch data parallel)
+        if (Bg > 0) {
+            if (hp.q_loss) { c->err = g_err = "fbhip: q_loss is not implemented for the global-batch schedule"; return FBHIP_E_INVALID; }
+            const float* G = c->gb_panels;
+            const size_t ps = (size_t)Bg * Lz;
+            HIPCK(c, launch_pairwise_fb_block(G, G + ps, G + 2 * ps, G + 3 * ps, G + 4 * ps, G + 5 * ps, c->gb_discount, Bg, z,
+                                              Lz, hp.ortho_coef, c->gb_off, B, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics,
+                                              w.pw_scratch, s));
+            if (hp.want_metrics)                // B^T B over the global rows (identical on every rank)
+                RC(run_gemms(c, {P(G + 2 * ps, Lz, 0, G + 2 * ps, Lz, 0, w.cov.p, w.cov.ld, z, z, Bg)}, s));
+        } else {
+            HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, BmO, w.fsT.F1.p, w.fsT.F2.p, BmT, w.disc, B, z,
+                                        Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
+            if (hp.want_metrics || hp.q_loss)   // B^T B: metrics (fb_ddpg.py:371) and the q_loss covariance (:334)
+                RC(run_gemms(c, {P(BmO, Lz, 0, BmO, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
+        }
         if (hp.q_loss) {                        // fb_ddpg.py:330-340
             HIPCK(c, launch_inverse(w.cov.p, w.cov.ld, z, 1.0f / (float)B, w.inv_cov.p, w.inv_cov.ld, s));
             RC(run_gemms(c, {P(BmO, Lz, 1, w.inv_cov.p, w.inv_cov.ld, 0, w.BinvC.p, Lz, B, z, z)}, s));
@@ -949,7 +966,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                                   hp.q_loss_coef, w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, s));
         }
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
-            HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s));
+            HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s, Bg));
         }
         {
             // --- backward (fb_ddpg.py:383): forward_net, backward_net and (early) the actor's own forward pass
@@ -1178,6 +1195,43 @@ int fbhip_set_policy_squash(fbhip_ctx* c, float temp, float log_std_min, float l
     c->graphs.clear();
     for (auto& g : c->infer_graphs) (void)hipGraphExecDestroy(g.exec);
     c->infer_graphs.clear();
+    return FBHIP_OK;
+}
+
+size_t fbhip_embeddings_floats(const fbhip_dims* d) {
+    if (check_dims(d) != FBHIP_OK) return 0;
+    return (size_t)6 * d->batch * pad4(d->z_dim) + (size_t)d->batch;
+}
+
+int fbhip_export_embeddings(fbhip_ctx* c, float* out, void* stream) {
+    RC(need_bound(c, false));
+    if (!out) return FBHIP_E_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const fbhip_dims& d = c->d;
+    Ws& w = c->w;
+    const size_t ps = (size_t)d.batch * pad4(d.z_dim);
+    const float* src[6] = {w.fsO.F1.p, w.fsO.F2.p, d.norm_z ? w.bsO.Bm.p : w.bsO.y.p,
+                           w.fsT.F1.p, w.fsT.F2.p, d.norm_z ? w.bsA.Bm.p : w.bsA.y.p};
+    for (int m = 0; m < 6; ++m)
+        HIPCK(c, hipMemcpyAsync(out + m * ps, src[m], ps * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCK(c, hipMemcpyAsync(out + 6 * ps, w.disc, (size_t)d.batch * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return FBHIP_OK;
+}
+
+int fbhip_bind_global_batch(fbhip_ctx* c, const float* panels, const float* discount, int32_t global_rows,
+                            int32_t row_offset) {
+    if (!c) return FBHIP_E_INVALID;
+    if (global_rows == 0) { panels = discount = nullptr; row_offset = 0; }
+    else if (!panels || !discount || global_rows < c->d.batch || row_offset < 0 || row_offset + c->d.batch > global_rows ||
+             (global_rows != c->d.batch && ((c->d.batch & 31) || (row_offset & 31))) || ((uintptr_t)panels & 15)) {
+        c->err = g_err = "fbhip_bind_global_batch: need 16-byte aligned panels and batch / row_offset multiples of 32 inside global_rows";
+        return FBHIP_E_INVALID;
+    }
+    if (panels != c->gb_panels || discount != c->gb_discount || global_rows != c->gb_rows || row_offset != c->gb_off) {
+        for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);        // the pointers are baked into captured launches
+        c->graphs.clear();
+    }
+    c->gb_panels = panels; c->gb_discount = discount; c->gb_rows = global_rows; c->gb_off = row_offset;
     return FBHIP_OK;
 }
 

@@ -103,6 +103,11 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
                               const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
                               float ortho_coef, float* dF1, float* dF2, float* dB, float* metrics,
                               float* scratch, hipStream_t s);
+// rows [row_off, row_off + rows) of the same loss on B-row panels (global-batch data parallel); outputs are [rows, ld]
+hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1,
+                                    const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
+                                    float ortho_coef, int row_off, int rows, float* dF1, float* dF2, float* dB,
+                                    float* metrics, float* scratch, hipStream_t s);
 // dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB))      (F.normalize backward)
 hipError_t launch_l2norm_bwd(const float* dB, int lddb, const float* y, int ldy, const float* norms,
                              float* dy, int lddy, int rows, int d, hipStream_t s);
@@ -119,7 +124,7 @@ struct StepState {          // device-resident, advanced in-graph
     double actor_bc2_sqrt;
 };
 hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z, int ld, int rows, int d,
-                                const float* cov, int ldc, float* metrics, hipStream_t s);
+                                const float* cov, int ldc, float* metrics, hipStream_t s, int cov_rows = 0 /* 0: rows */);
 hipError_t launch_inverse(const float* A, int lda, int d, float scale, float* out, int ldo, hipStream_t s);
 hipError_t inverse_prepare();
 hipError_t launch_qloss(const float* F1, const float* F2, const float* tF1, const float* tF2, const float* BinvC,

@@ -94,7 +94,7 @@ hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* 
 __global__ void __launch_bounds__(1024) extra_metrics_kernel(const float* __restrict__ F1, const float* __restrict__ Bm,
                                                              const float* __restrict__ z, int ld, int rows, int d,
                                                              const float* __restrict__ cov /*[d,d] = B^T B*/,
-                                                             int ldc, float* __restrict__ metrics) {
+                                                             int ldc, float* __restrict__ metrics, int cov_rows) {
     __shared__ double red[16][6];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     double sF = 0, sB = 0, sBn = 0, sZn = 0, sL2 = 0, mx = 0;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(1024) extra_metrics_kernel(const float* __rest
     }
     for (int e = tid; e < d * d; e += 1024) {
         const int i = e / d, j = e % d;
-        const float v = cov[(size_t)i * ldc + j] / (float)rows - (i == j ? 1.f : 0.f);
+        const float v = cov[(size_t)i * ldc + j] / (float)cov_rows - (i == j ? 1.f : 0.f);
         sL2 += (double)v * v;
         mx = fmax(mx, (double)fabsf(v));
     }
@@ -139,8 +139,9 @@ __global__ void __launch_bounds__(1024) extra_metrics_kernel(const float* __rest
 }
 
 hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z, int ld, int rows, int d,
-                                const float* cov, int ldc, float* metrics, hipStream_t s) {
-    hipLaunchKernelGGL(extra_metrics_kernel, dim3(1), dim3(1024), 0, s, F1, Bm, z, ld, rows, d, cov, ldc, metrics);
+                                const float* cov, int ldc, float* metrics, hipStream_t s, int cov_rows) {
+    hipLaunchKernelGGL(extra_metrics_kernel, dim3(1), dim3(1024), 0, s, F1, Bm, z, ld, rows, d, cov, ldc, metrics,
+                       cov_rows > 0 ? cov_rows : rows);
     return hipGetLastError();
 }
 

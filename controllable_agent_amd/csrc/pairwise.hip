@@ -46,6 +46,8 @@ struct PwArgs {
     float* partial;            // [nchunks][PW_SLOTS][Bp][DP]
     float* scal;               // [nblocks][PW_SCAL]
     int Bp;
+    int i_off;                 // block mode (global-batch data parallel): the workgroups' I rows are [i_off, i_off + 32 gridDim.x)
+                               // of the B-row panels; outputs / partials are indexed by the LOCAL row (I - i_off)
 };
 
 // Stage the same 32-row block of SIX matrices (zero filled outside [0,B) x [0,d)) into LDS [32][LD] each.  load() only
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
     float* sGam = stF2 + 32 * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int I0 = blockIdx.x * 32, chunk = blockIdx.y;
+    const int I0 = blockIdx.x * 32 + p.i_off, chunk = blockIdx.y;
     const int B = p.B, d = p.d;
     const float n_off = (float)B * (float)(B - 1);
     const float inv_noff = 1.0f / n_off, inv_b = 1.0f / (float)B;
@@ -282,7 +284,7 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
 
     // ---- write partial outputs ---------------------------------------------------------------------------
     constexpr int DP = 32 * NT;
-    float* dst = p.partial + (((size_t)chunk * PW_SLOTS + wid) * p.Bp + I0) * DP;
+    float* dst = p.partial + (((size_t)chunk * PW_SLOTS + wid) * p.Bp + (I0 - p.i_off)) * DP;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -302,6 +304,7 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
 __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __restrict__ partial,
                                                               const float* __restrict__ scal, int nchunks,
                                                               int nblocks, int B, int Bp, int d, int DP, int ld,
+                                                              int Bglobal /* normalisers of the metrics */,
                                                               float ortho_coef, float* __restrict__ dF1,
                                                               float* __restrict__ dF2, float* __restrict__ dB,
                                                               float* __restrict__ metrics) {
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
         }
         __syncthreads();
         if (threadIdx.x == 0 && metrics != nullptr) {
-            const double noff = (double)B * (double)(B - 1), bb = (double)B;
+            const double noff = (double)Bglobal * (double)(Bglobal - 1), bb = (double)Bglobal;
             const double fb_off = 0.5 * (tot[0] + tot[4]) / noff;
             const double fb_diag = -(tot[1] + tot[5]) / bb;
             const double orth_off = (tot[6] + tot[8]) / noff;
@@ -350,9 +353,11 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
     }
 }
 
-struct PwPlan { int ks, nt, ld, dp, njt, nchunks, jpc, Bp; size_t lds_bytes; };
+struct PwPlan { int ks, nt, ld, dp, njt, nchunks, jpc, Bp, nI; size_t lds_bytes; };
 
-PwPlan make_plan(int B, int d) {
+// B: rows of the panels (the J extent); rows: the I extent this launch owns (== B for the square single-device loss)
+PwPlan make_plan(int B, int d, int rows = -1) {
+    if (rows < 0) rows = B;
     static const int opts[] = {4, 8, 16, 25, 32, 50, 64};
     PwPlan pl{};
     pl.ks = -1;
@@ -363,9 +368,10 @@ PwPlan make_plan(int B, int d) {
     pl.ld = w + 1;
     pl.dp = 32 * pl.nt;
     pl.njt = (B + 31) / 32;
-    pl.Bp = pl.njt * 32;
+    pl.nI = (rows + 31) / 32;
+    pl.Bp = pl.nI * 32;
     // aim for >= 256 workgroups (one per CU): nI * nchunks
-    int nchunks = (256 + pl.njt - 1) / pl.njt;
+    int nchunks = (256 + pl.nI - 1) / pl.nI;
     if (nchunks > pl.njt) nchunks = pl.njt;
     if (nchunks < 1) nchunks = 1;
     pl.jpc = (pl.njt + nchunks - 1) / nchunks;
@@ -376,10 +382,12 @@ PwPlan make_plan(int B, int d) {
 
 }  // namespace
 
+// upper bound over every world size of the block mode: nchunks <= ceil(256 / nI) whatever the global row count is
 size_t pairwise_scratch_floats(int B, int d) {
     const PwPlan pl = make_plan(B, d);
     if (pl.ks < 0) return 0;
-    return (size_t)pl.nchunks * PW_SLOTS * pl.Bp * pl.dp + (size_t)pl.nchunks * pl.njt * PW_SCAL;
+    const size_t nchunks = (size_t)(256 + pl.nI - 1) / pl.nI;
+    return nchunks * PW_SLOTS * pl.Bp * pl.dp + nchunks * pl.nI * PW_SCAL;
 }
 
 hipError_t pairwise_prepare(int B, int d) {
@@ -408,8 +416,19 @@ hipError_t pairwise_prepare(int B, int d) {
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
                               const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
                               float* dF1, float* dF2, float* dB, float* metrics, float* scratch, hipStream_t s) {
-    const PwPlan pl = make_plan(B, d);
-    if (pl.ks < 0 || B < 2) return hipErrorInvalidValue;
+    return launch_pairwise_fb_block(F1, F2, Bm, tF1, tF2, tB, discount, B, d, ld, ortho_coef, 0, B, dF1, dF2, dB, metrics,
+                                    scratch, s);
+}
+
+// Rows [row_off, row_off + rows) of the loss on B-row panels: dF_i and dB of THOSE rows (each complete: the workgroups walk
+// every J tile of the B rows), and this row block's share of the scalar sums with the B-row normalisers.
+hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
+                                    const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
+                                    int row_off, int rows, float* dF1, float* dF2, float* dB, float* metrics,
+                                    float* scratch, hipStream_t s) {
+    const PwPlan pl = make_plan(B, d, rows);
+    if (pl.ks < 0 || B < 2 || rows < 1 || row_off < 0 || row_off + rows > B) return hipErrorInvalidValue;
+    if (rows != B && ((row_off & 31) || (rows & 31))) return hipErrorInvalidValue;      // whole 32-row blocks
     PwArgs a;
     a.F1 = F1; a.F2 = F2; a.Bm = Bm; a.tF1 = tF1; a.tF2 = tF2; a.tB = tB; a.discount = discount;
     a.B = B; a.d = d; a.ld = ld; a.ortho2 = 2.0f * ortho_coef; a.jpc = pl.jpc; a.njt = pl.njt;
@@ -418,7 +437,8 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
     a.partial = scratch;
     a.scal = scratch + (size_t)pl.nchunks * PW_SLOTS * pl.Bp * pl.dp;
     a.Bp = pl.Bp;
-    dim3 grid(pl.njt, pl.nchunks), block(256);
+    a.i_off = row_off;
+    dim3 grid(pl.nI, pl.nchunks), block(256);
     hipError_t e = hipSuccess;
 #define PW_LAUNCH(KS)                                                                                                 \
     if (a.vec) hipLaunchKernelGGL((pairwise_kernel<KS, true>), grid, block, pl.lds_bytes, s, a);                       \
@@ -437,9 +457,9 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
     if (e != hipSuccess) return e;
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int total = B * d;
+    const int total = rows * d;
     hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.scal,
-                       pl.nchunks, pl.nchunks * pl.njt, B, pl.Bp, d, pl.dp, ld, ortho_coef, dF1, dF2, dB, metrics);
+                       pl.nchunks, pl.nchunks * pl.nI, rows, pl.Bp, d, pl.dp, ld, B, ortho_coef, dF1, dF2, dB, metrics);
     return hipGetLastError();
 }
 

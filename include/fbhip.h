@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 7
+#define FBHIP_ABI_VERSION 8
 
 enum {
     FBHIP_OK = 0,
@@ -50,7 +50,10 @@ enum { FBHIP_NET_FORWARD = 0, FBHIP_NET_BACKWARD = 1, FBHIP_NET_ACTOR = 2 };
 /* phases of one update(); a mask selects which are enqueued (multi-GPU inserts all-reduces between them) */
 enum {
     FBHIP_PHASE_SAMPLE = 1,      /* replay gather + z sampling + z mixing           (fb_ddpg.py:433-491) */
-    FBHIP_PHASE_FB_GRAD = 2,     /* targets, online F/B, pairwise loss, FB backward (fb_ddpg.py:303-383) */
+    FBHIP_PHASE_FB_FWD = 2,      /* targets and online F / B up to the six embeddings F1 F2 B tF1 tF2 tB (fb_ddpg.py:303-319) */
+    FBHIP_PHASE_FB_BWD = 64,     /* pairwise loss + FB backward (fb_ddpg.py:320-383); on the rows bound by
+                                  * fbhip_bind_global_batch when a global batch is bound */
+    FBHIP_PHASE_FB_GRAD = 66,    /* = FB_FWD | FB_BWD */
     FBHIP_PHASE_FB_STEP = 4,     /* fb_opt.step() + both soft_update_params         (fb_ddpg.py:384,500-503) */
     FBHIP_PHASE_ACTOR_GRAD = 8,  /* Q through the UPDATED forward_net, actor backward  (fb_ddpg.py:398-410) */
     FBHIP_PHASE_ACTOR_STEP = 16, /* actor_opt.step()                                (fb_ddpg.py:411) */
@@ -58,7 +61,7 @@ enum {
      * so it may run in the same call as FB_GRAD (it then shares the FB backward's launches) -- or with ACTOR_GRAD.
      * An ACTOR_GRAD call WITHOUT this bit uses the pass of an earlier call on the same batch. */
     FBHIP_PHASE_ACTOR_FWD = 32,
-    FBHIP_PHASE_ALL = 63
+    FBHIP_PHASE_ALL = 127
 };
 
 typedef struct fbhip_dims {
@@ -188,6 +191,19 @@ int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* in
  * calls -- the Adam / RNG counters advance on the device -- minus n_steps - 1 graph-launch gaps.  Single-rank only (there
  * is no place for the gradient all-reduce inside the graph); ``hp`` is constant over the n_steps (1 <= n_steps <= 64). */
 int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
+/* ---- global-batch data parallel (SURVEY section 8e "mode B"): the FB / orthonormality losses couple every row of the batch
+ * with every other row (fb_ddpg.py:313-326, 344-346), so the exact loss of a batch spread over several devices needs one
+ * exchange: after FB_FWD every rank exports its six [batch, pad4(z_dim)] embedding panels + discounts
+ * (fbhip_embeddings_floats floats, order F1 F2 B tF1 tF2 tB discount), the host all-gathers them into
+ * panels [6][global_rows][pad4(z_dim)] and discount [global_rows], binds them, and FB_BWD then evaluates rows
+ * [row_offset, row_offset + batch) of the global_rows x global_rows loss: dF1 dF2 dB of the rank's own rows are complete
+ * (no reduce-scatter), the normalisers are the global ones, so parameter gradients are SUMMED over ranks (grad_scale 1).
+ * Metrics of that phase are the rank's share (pairwise terms) -- sum them over ranks.  global_rows = 0 unbinds.  batch and
+ * row_offset must be multiples of 32; q_loss is not supported in this mode. */
+size_t fbhip_embeddings_floats(const fbhip_dims* dims);
+int fbhip_export_embeddings(fbhip_ctx* ctx, float* out, void* stream);
+int fbhip_bind_global_batch(fbhip_ctx* ctx, const float* panels, const float* discount, int32_t global_rows,
+                            int32_t row_offset);
 /* Blocking: copies the FBHIP_NUM_METRICS device floats to host_out after the stream drains. */
 int fbhip_read_metrics(fbhip_ctx* ctx, float* host_out, void* stream);
 /* Named views into the workspace for tests / host code ("z", "F1", "dF1", "obs", ...). */

@@ -79,3 +79,106 @@ def test_two_ranks_on_one_gpu_equal_gradient_averaging():
             assert H.rel_err(results[0][k], v) < 2e-4, k
         else:
             np.testing.assert_allclose(results[0][k], v, rtol=0, atol=3e-6, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------ mode B: exact global batch
+CFG_B = dict(T.CFG, batch_size=32)
+
+
+def _setup_b():
+    cfg = fo.OracleConfig(**CFG_B)
+    rng = np.random.default_rng(11)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, T.N_EPS, T.T, cfg.obs_dim, cfg.action_dim)
+    return cfg, nets, storage, lengths
+
+
+def _worker_global(rank, port, out_q):
+    import torch.distributed as dist
+    from controllable_agent_amd.agent import FBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    cfg, nets, storage, lengths = _setup_b()
+    agent = FBHipAgent(**H.agent_kwargs(cfg, dp_global_batch=True))
+    agent.load_nets({n: dict(p) for n, p in nets.items()})
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    metrics = []
+    for step in range(T.STEPS):
+        d = fo.make_draws(np.random.default_rng(1000 * step + rank), cfg, len(rb), rb._episodes_length)
+        metrics.append(agent.update_injected(rb, step, H.draws_dict(d), use_graph=True))
+    torch.cuda.synchronize()
+    out_q.put((rank, H.get_agent_state(agent), metrics))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_global_batch_equal_one_device_on_the_concatenated_batch():
+    """dp_global_batch=True (SURVEY 8e mode B): two ranks x 32 rows == ONE oracle update on the 64-row batch made of both
+    ranks' rows (block-diagonal permutation for the z-mix), parameters, Adam state and metrics; replicas bit-identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_worker_global, args=(r, port, q)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(T.WORLD)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    results = {r: st for r, st, _ in got}
+    metrics = {r: m for r, _, m in got}
+    torch.set_num_threads(1)
+    cfg, nets, storage, lengths = _setup_b()
+    ref = fo.OracleAgent(cfg, nets)
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    for step in range(T.STEPS):
+        batches, draws = [], []
+        for r in range(T.WORLD):
+            rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cpu").shard(r, T.WORLD)
+            sh = {k: v.numpy() for k, v in rb._storage.items()}
+            d = fo.make_draws(np.random.default_rng(1000 * step + r), cfg, len(rb), rb._episodes_length)
+            batches.append(fo.gather_batch(sh, d.ep_idx, d.step_idx, cfg.discount))
+            draws.append(d)
+        B = cfg.batch_size
+        cat = lambda f: np.concatenate([getattr(d, f) for d in draws])
+        both = fo.Draws(ep_idx=cat("ep_idx"), step_idx=cat("step_idx"), z_gauss=cat("z_gauss"),
+                        perm=np.concatenate([d.perm + r * B for r, d in enumerate(draws)]), mix_uniform=cat("mix_uniform"),
+                        eps_next=cat("eps_next"), eps_actor=cat("eps_actor"))
+        batch = {k: np.concatenate([b[k] for b in batches]) for k in batches[0] if batches[0][k] is not None}
+        m = ref.update(batch, both)
+        for k in ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_offdiag", "orth_linf", "orth_l2", "M1", "target_M",
+                  "F1", "B", "B_norm", "z_norm", "actor_loss", "q"):
+            for r in range(T.WORLD):
+                assert metrics[r][step][k] == pytest.approx(m[k], rel=5e-5, abs=2e-6), (step, r, k)
+    want = ref.state_tensors()
+    for k in results[0]:
+        np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+    for k, v in want.items():
+        if k.startswith("adam_"):
+            assert H.rel_err(results[0][k], v) < 2e-4, k
+        else:
+            np.testing.assert_allclose(results[0][k], v, rtol=0, atol=3e-6, err_msg=k)
+
+
+def test_global_batch_schedule_on_one_rank_is_the_plain_update():
+    """world 1: the mode-B schedule (export -> bind -> block pairwise over all rows) lands bit-exactly on the default path."""
+    cfg, nets, storage, lengths = T._setup()
+    from controllable_agent_amd.agent import FBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    states = []
+    for flag in (False, True):
+        agent = FBHipAgent(**H.agent_kwargs(cfg, dp_global_batch=flag))
+        agent.load_nets({n: dict(p) for n, p in nets.items()})
+        rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+        ms = []
+        for step in range(3):
+            d = fo.make_draws(np.random.default_rng(77 + step), cfg, len(rb), rb._episodes_length)
+            ms.append(agent.update_injected(rb, step, H.draws_dict(d), use_graph=True))
+        states.append((H.get_agent_state(agent), ms))
+    for k in states[0][0]:
+        np.testing.assert_array_equal(states[0][0][k], states[1][0][k], err_msg=k)
+    for a, b in zip(states[0][1], states[1][1]):
+        for k in a:
+            assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-7), k
