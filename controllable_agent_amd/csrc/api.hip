@@ -363,7 +363,13 @@ struct fbhip_ctx {
     float *fb_p = nullptr, *fb_g = nullptr, *fb_m = nullptr, *fb_v = nullptr, *fb_t = nullptr;
     float *a_p = nullptr, *a_g = nullptr, *a_m = nullptr, *a_v = nullptr;
     bool bound = false, replay_bound = false;
-    Ws w;
+    Ws sets[2];                              // two complete workspace sets: fbhip_update_many alternates them so that step
+    int cur = 0;                             // t+1's sampling and online forward passes can run beside step t's actor phase
+    Ws& W() { return sets[cur]; }            // the set kernels are currently enqueued on
+    const char* ws_lo = nullptr;
+    size_t ws_bytes = 0;
+    hipStream_t side = nullptr;              // second capture branch of fbhip_update_many
+    std::vector<hipEvent_t> events;
     ReplayView rv{};
     uint64_t seed = 0;
     uint32_t rank = 0;
@@ -416,7 +422,7 @@ GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc
 // fbhip_gemm (ctx == nullptr) never splits
 constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB
 
-float* splitk_slab(fbhip_ctx* c) { return (c && c->w.splitk) ? c->w.splitk : nullptr; }
+float* splitk_slab(fbhip_ctx* c) { return (c && c->W().splitk) ? c->W().splitk : nullptr; }
 
 int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     long tiles32 = 0;
@@ -561,6 +567,35 @@ int run_chain(fbhip_ctx* c, Chain& ch, hipStream_t s) {
     return run_rounds(c, v, s);
 }
 
+// A Program is the round list itself: round r holds the stages of every chain that is r levels deep; build_update
+// appends to one, run_program flushes it round by round onto a stream.
+using Round = std::vector<Stage>;
+using Program = std::vector<Round>;
+void prog_parallel(Program& p, std::vector<Chain>& chains) {
+    size_t n = 0;
+    for (auto& ch : chains) n = ch.size() > n ? ch.size() : n;
+    for (size_t r = 0; r < n; ++r) {
+        Round rd;
+        for (auto& ch : chains)
+            if (r < ch.size()) rd.push_back(ch[r]);
+        p.push_back(std::move(rd));
+    }
+}
+void prog_chain(Program& p, Chain& ch) {
+    for (auto& st : ch) p.push_back(Round{st});
+}
+void prog_post(Program& p, std::function<int(hipStream_t)> f) {
+    p.push_back(Round{[f](Ops& o) { o.post.push_back(f); }});
+}
+int run_program(fbhip_ctx* c, Program& p, hipStream_t s) {
+    for (auto& rd : p) {
+        Ops o;
+        for (auto& st : rd) st(o);
+        RC(flush_round(c, o, s));
+    }
+    return FBHIP_OK;
+}
+
 // ---- network passes as chains ---------------------------------------------------------------------------------
 // ForwardMap.forward (fb_modules.py:186-199); Xa = [obs|action] panel, Xz = [obs|z] panel
 void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
@@ -604,10 +639,10 @@ int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const
 }
 
 // dgrad: dp = (dF_i . W4_i) * relu'(p)   (shared by the FB backward and the actor step)
-void heads_dgrad_ops(fbhip_ctx* c, const FwdP& W, FSet& S, int rows, Ops& o) {
+// (runs when a round is flushed: the workspace set comes from the caller, not from the context's current one)
+void heads_dgrad_ops(fbhip_ctx* c, Ws& w, const FwdP& W, FSet& S, int rows, Ops& o) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z);
-    Ws& w = c->w;
     o.gemms.push_back(P(w.dF1.p, Lz, 1, W.W4[0], H, 0, w.dp.p, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p, 2 * H));
     o.gemms.push_back(P(w.dF2.p, Lz, 1, W.W4[1], H, 0, w.dp.p + H, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p + H, 2 * H));
 }
@@ -618,12 +653,12 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
                            int ldz, FSet& S, int rows, Chain& out) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
-    Ws* w = &c->w;
+    Ws* w = &c->W();
     FSet* Sp = &S;
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(w->dF1.p, Lz, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]));
         o.gemms.push_back(P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
-        heads_dgrad_ops(c, W, *Sp, rows, o);
+        heads_dgrad_ops(c, *w, W, *Sp, rows, o);
     });
     const Geom gm = geom_of(d);
     const int Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
@@ -670,7 +705,7 @@ void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
     // workspace panels have >= pad32(g) finite columns per row (the weight's pad columns are zero, so whatever sits
     // there contributes nothing); arbitrary caller tensors are read on their logical width
-    const bool in_ws = (const char*)X >= (const char*)c->w.st && (const char*)X < (const char*)c->w.st + c->w.total_bytes;
+    const bool in_ws = (const char*)X >= c->ws_lo && (const char*)X < c->ws_lo + c->ws_bytes;
     const int Kg = (in_ws && ldx >= pad32(g)) ? pad32(g) : g;
     BSet* Sp = &S;
     out.push_back([=](Ops& o) {
@@ -701,9 +736,9 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
     // weight gradient of the first layer: X must be a zero-padded panel to use the padded width
-    const bool padded_x = (X == c->w.next_goal.p) || (X == c->w.bin.p);     // zero-padded panels only
+    const bool padded_x = (X == c->W().next_goal.p) || (X == c->W().bin.p);     // zero-padded panels only
     const int Ng = padded_x ? pad32(g) : g;
-    Ws* w = &c->w;
+    Ws* w = &c->W();
     BSet* Sp = &S;
     const float* dy = d.norm_z ? w->dy.p : w->dBm.p;    // no projection: the gradient wrt y is dB itself
     out.push_back([=](Ops& o) {                 // dy = d/dy of sqrt(d) normalize(y)   (F.normalize backward)
@@ -776,7 +811,7 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
                      ASet& S, int rows, Chain& out) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, a = head_width(d), La = pad4(a);
-    Ws* w = &c->w;
+    Ws* w = &c->W();
     ASet* Sp = &S;
     const Geom gm = actor_geom_of(d);
     const int Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
@@ -824,9 +859,14 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
 }
 
 // ---- one update(): fb_ddpg.py:427-520 ----------------------------------------------------------------------
-int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s) {
+// flags: how fbhip_update_many cuts FB_FWD when it pipelines consecutive steps
+enum { UPD_SKIP_TARGET_CHAIN = 1,   // FB_FWD without the target chain actor(next_obs) -> next_action -> forward_target (needs the actor step)
+       UPD_SKIP_ONLINE_CHAINS = 2 };// FB_FWD without online F and the B(next_goal) passes (already done with the sampling)
+#define POST_BEGIN prog_post(prog, [=, &w](hipStream_t s) -> int {
+#define POST_END return (int)FBHIP_OK; });
+int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, int flags, Program& prog) {
     const fbhip_dims& d = c->d;
-    Ws& w = c->w;
+    Ws& w = c->W();
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
               Lz = pad4(z), La = pad4(a);
     const Geom gm = geom_of(d);
@@ -847,6 +887,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                                   (!hindsight || (inj->future_idx && inj->future_uniform)) && (d.norm_z || inj->z_uniform);
         const bool randw = hp.rand_weight != 0 && hp.mix_ratio > 0.f;
         const bool randw_injected = randw && inj && inj->rand_weight && inj->rand_weight_u;
+        POST_BEGIN
         if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, hindsight ? hp.future : -1.f, d.norm_z, s));
         if (inj != nullptr) {
 #define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
@@ -869,6 +910,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         ga.future_idx = hindsight ? w.so.future_idx : nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
         ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount; ga.aoff = aoff;
         HIPCK(c, launch_gather(ga, s));
+        POST_END
         // sample_z (fb_ddpg.py:224-228) + z-mix (fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm])))
         // in one row kernel; the BackwardMap pass stops at its raw mlp output y (the kernel applies both projections)
         // When the FB step follows in the same call, the target / online BackwardMap passes on next_goal (fb_ddpg.py:312,
@@ -889,8 +931,9 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch.back());
             }
-            RC(run_rounds(c, ch, s));
+            prog_parallel(prog, ch);
         }
+        POST_BEGIN
         const float* ymix = w.bsM.y.p;
         if (randw) {
             // mix_z = (u * normalize(rand[., B])) @ backward_net(backward_input[perm])   (fb_ddpg.py:475-482), all rows
@@ -905,6 +948,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, hindsight ? w.bsF.y.p : nullptr, w.so.future_uniform,
                               hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, randw ? 1 : 2,
                               zx, s));
+        POST_END
     }
 
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
@@ -926,17 +970,20 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
             // chain B: online F (fb_ddpg.py:318)    chains C, D: target B (:312) and online B (:319)
             // (C, D already ran with the sampler's z-mix pass when this call also covered the SAMPLE phase)
             std::vector<Chain> ch(2);
-            actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0]);
-            ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld));
-            forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
-            forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
-            if (!(mask & FBHIP_PHASE_SAMPLE)) {
+            if (!(flags & UPD_SKIP_TARGET_CHAIN)) {
+                actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0]);
+                ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld));
+                forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
+            }
+            if (!(flags & UPD_SKIP_ONLINE_CHAINS))
+                forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
+            if (!(mask & FBHIP_PHASE_SAMPLE) && !(flags & UPD_SKIP_ONLINE_CHAINS)) {
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch.back());
             }
-            RC(run_rounds(c, ch, s));
+            prog_parallel(prog, ch);
         }
     }
     if (mask & FBHIP_PHASE_FB_BWD) {
@@ -944,8 +991,9 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         const float* BmO = d.norm_z ? w.bsO.Bm.p : w.bsO.y.p;      // online / target B(next_goal) as the loss sees them
         const float* BmT = d.norm_z ? w.bsA.Bm.p : w.bsA.y.p;
         const int Bg = c->gb_rows;              // > 0: the loss couples the rows of ALL ranks (global-batch data parallel)
+        if (Bg > 0 && hp.q_loss) { c->err = g_err = "fbhip: q_loss is not implemented for the global-batch schedule"; return FBHIP_E_INVALID; }
+        POST_BEGIN
         if (Bg > 0) {
-            if (hp.q_loss) { c->err = g_err = "fbhip: q_loss is not implemented for the global-batch schedule"; return FBHIP_E_INVALID; }
             const float* G = c->gb_panels;
             const size_t ps = (size_t)Bg * Lz;
             HIPCK(c, launch_pairwise_fb_block(G, G + ps, G + 2 * ps, G + 3 * ps, G + 4 * ps, G + 5 * ps, c->gb_discount, Bg, z,
@@ -968,6 +1016,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s, Bg));
         }
+        POST_END
         {
             // --- backward (fb_ddpg.py:383): forward_net, backward_net and (early) the actor's own forward pass
             std::vector<Chain> ch(3);
@@ -977,15 +1026,17 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                 actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2]);
                 ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
             }
-            RC(run_rounds(c, ch, s));
+            prog_parallel(prog, ch);
         }
     }
 
     if (mask & FBHIP_PHASE_FB_STEP) {           // fb_opt.step() (:384) + soft_update_params x2 (:500-503)
+        POST_BEGIN
         HIPCK(c, launch_step_advance(w.st, ((mask & FBHIP_PHASE_ACTOR_STEP) ? 3 : 0), s));   // 3 = both optimisers
         const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
         HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf,
                                  hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, s));
+        POST_END
     }
 
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
@@ -1005,7 +1056,7 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
         });
         // data-gradient only, along the action path of forward_net (the reference also computes and discards every
         // weight gradient of forward_net here)
-        ch.push_back([=, &w](Ops& o2) { heads_dgrad_ops(c, c->F_p, w.fsO, B, o2); });
+        ch.push_back([=, &w](Ops& o2) { heads_dgrad_ops(c, w, c->F_p, w.fsO, B, o2); });
         // (only the branch that sees the action matters: the first Fo columns of h)
         if (gm.trunk) {
             ch.push_back([=, &w](Ops& o2) {          // d relu(trunk(h)) ...
@@ -1040,16 +1091,26 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
                                      EPI_TANH_BWD, w.as.mu.p, La));
             });
         actor_bwd_chain(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
-        RC(run_chain(c, ch, s));
+        prog_chain(prog, ch);
     }
 
     if (mask & FBHIP_PHASE_ACTOR_STEP) {        // actor_opt.step(), fb_ddpg.py:411
+        POST_BEGIN
         if (!(mask & FBHIP_PHASE_FB_STEP)) HIPCK(c, launch_step_advance(w.st, 1, s));
         const int64_t na = c->L[FBHIP_NET_ACTOR].numel;
         HIPCK(c, launch_adam_ema(c->a_p, c->a_g, c->a_m, c->a_v, nullptr, na, hp.lr, hp.lr, na, hp.grad_scale, 0.f, w.st,
                                  1, 0, s));
+        POST_END
     }
     return FBHIP_OK;
+}
+#undef POST_BEGIN
+#undef POST_END
+
+int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s, int flags = 0) {
+    Program prog;
+    RC(build_update(c, hp, inj, mask, flags, prog));
+    return run_program(c, prog, s);
 }
 
 int need_bound(fbhip_ctx* c, bool replay) {
@@ -1106,7 +1167,7 @@ int fbhip_layout_entry(const fbhip_dims* dims, int net, int idx, fbhip_tensor_de
 }
 size_t fbhip_workspace_bytes(const fbhip_dims* dims) {
     if (check_dims(dims) != FBHIP_OK) return 0;
-    return carve(*dims, nullptr).total_bytes;
+    return 2 * carve(*dims, nullptr).total_bytes;            // two complete sets (fbhip_update_many pipelines consecutive steps)
 }
 
 int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
@@ -1132,6 +1193,8 @@ int fbhip_destroy(fbhip_ctx* ctx) {
     if (!ctx) return FBHIP_OK;
     for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& g : ctx->infer_graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     delete ctx;
@@ -1144,7 +1207,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     if (!c) return FBHIP_E_INVALID;
     if (!fb_params || !fb_grads || !fb_adam_m || !fb_adam_v || !fb_targets || !actor_params || !actor_grads ||
         !actor_adam_m || !actor_adam_v || !workspace) { c->err = g_err = "fbhip: null buffer"; return FBHIP_E_INVALID; }
-    const size_t need = carve(c->d, nullptr).total_bytes;
+    const size_t one = carve(c->d, nullptr).total_bytes, need = 2 * one;
     if (workspace_bytes < need) { c->err = g_err = "fbhip: workspace too small"; return FBHIP_E_INVALID; }
     if (((uintptr_t)workspace & 255) || ((uintptr_t)fb_params & 15) || ((uintptr_t)fb_grads & 15) ||
         ((uintptr_t)fb_targets & 15) || ((uintptr_t)actor_params & 15) || ((uintptr_t)actor_grads & 15)) {
@@ -1154,7 +1217,13 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     RC(fbhip_device_ok());
     c->fb_p = fb_params; c->fb_g = fb_grads; c->fb_m = fb_adam_m; c->fb_v = fb_adam_v; c->fb_t = fb_targets;
     c->a_p = actor_params; c->a_g = actor_grads; c->a_m = actor_adam_m; c->a_v = actor_adam_v;
-    c->w = carve(c->d, workspace);
+    c->sets[0] = carve(c->d, workspace);
+    c->sets[1] = carve(c->d, (char*)workspace + one);
+    c->cur = 0;
+    // state that is not per-step lives once: optimiser / RNG counters, metrics, the batch-1 staging buffers
+    c->sets[1].st = c->sets[0].st; c->sets[1].metrics = c->sets[0].metrics;
+    c->sets[1].act_in = c->sets[0].act_in; c->sets[1].act_vec = c->sets[0].act_vec; c->sets[1].act_out = c->sets[0].act_out;
+    c->ws_lo = (const char*)workspace; c->ws_bytes = need;
     const int64_t nf = c->L[FBHIP_NET_FORWARD].numel;
     c->F_p = fwd_p(fb_params, c->L[0]); c->F_g = fwd_p(fb_grads, c->L[0]); c->F_t = fwd_p(fb_targets, c->L[0]);
     c->K_p = bwd_p(fb_params + nf, c->L[1]); c->K_g = bwd_p(fb_grads + nf, c->L[1]); c->K_t = bwd_p(fb_targets + nf, c->L[1]);
@@ -1208,7 +1277,7 @@ int fbhip_export_embeddings(fbhip_ctx* c, float* out, void* stream) {
     if (!out) return FBHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const fbhip_dims& d = c->d;
-    Ws& w = c->w;
+    Ws& w = c->W();
     const size_t ps = (size_t)d.batch * pad4(d.z_dim);
     const float* src[6] = {w.fsO.F1.p, w.fsO.F2.p, d.norm_z ? w.bsO.Bm.p : w.bsO.y.p,
                            w.fsT.F1.p, w.fsT.F2.p, d.norm_z ? w.bsA.Bm.p : w.bsA.y.p};
@@ -1249,10 +1318,10 @@ int fbhip_set_step_counts(fbhip_ctx* c, int32_t fb_steps, int32_t actor_steps, v
     RC(need_bound(c, false));
     hipStream_t s = (hipStream_t)stream;
     StepState h{};
-    HIPCK(c, hipMemcpyAsync(&h, c->w.st, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipMemcpyAsync(&h, c->W().st, sizeof(h), hipMemcpyDeviceToHost, s));
     HIPCK(c, hipStreamSynchronize(s));
     h.fb_t = fb_steps; h.actor_t = actor_steps;
-    HIPCK(c, hipMemcpyAsync(c->w.st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIPCK(c, hipMemcpyAsync(c->W().st, &h, sizeof(h), hipMemcpyHostToDevice, s));
     HIPCK(c, hipStreamSynchronize(s));
     return FBHIP_OK;
 }
@@ -1261,7 +1330,7 @@ int fbhip_get_step_counts(fbhip_ctx* c, int32_t* host_fb_steps, int32_t* host_ac
     RC(need_bound(c, false));
     hipStream_t s = (hipStream_t)stream;
     StepState h{};
-    HIPCK(c, hipMemcpyAsync(&h, c->w.st, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipMemcpyAsync(&h, c->W().st, sizeof(h), hipMemcpyDeviceToHost, s));
     HIPCK(c, hipStreamSynchronize(s));
     if (host_fb_steps) *host_fb_steps = h.fb_t;
     if (host_actor_steps) *host_actor_steps = h.actor_t;
@@ -1309,12 +1378,60 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
             return FBHIP_OK;
         }
     }
+    // Software pipeline over the steps.  Step t's actor phase is ONE dependency chain of ~20 small launches; step t+1's
+    // sampling, z mixing, B passes and online ForwardMap pass depend on step t only through its FB optimiser step (new
+    // forward_net / backward_net / targets), which precedes the actor phase.  So they are captured as a second branch
+    // beside the actor phase (own stream, own workspace set) and rejoin before step t+1's target chain, which needs the
+    // new actor.  Kernels, their order inside each step and every operand are unchanged: results are bit-identical to
+    // n_steps single updates (tests/test_update_parity_gpu.py).  Measured (walker, 8 steps per launch): 951 -> 965
+    // updates/s.  (Zipping the two programs round by round into the SAME launches instead was slower, 933/s: one tile
+    // configuration per launch makes the thin GEMMs of one program stragglers of the other's fat ones.)
+    static const bool pipelined = [] { const char* e = getenv("FBHIP_UPDATE_PIPELINE"); return !(e && e[0] == '0'); }();
+    const bool pipe = pipelined && n_steps > 1;
+    if (pipe) {
+        if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        while ((int)c->events.size() < 2 * 64) {
+            hipEvent_t ev;
+            HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            c->events.push_back(ev);
+        }
+    }
     hipGraph_t graph = nullptr;
     HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = FBHIP_OK;
-    for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ALL, s);
+    hipError_t he = hipSuccess;
+    if (!pipe) {
+        for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ALL, s);
+    } else {
+        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD;
+        const int MID = FBHIP_PHASE_FB_FWD | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD | FBHIP_PHASE_FB_STEP;
+        const int TAIL = FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP;
+        const int cur0 = c->cur;
+        rc = enqueue_update(c, *hp, nullptr, HEAD, s, UPD_SKIP_TARGET_CHAIN);
+        for (int i = 0; i < n_steps && rc == FBHIP_OK && he == hipSuccess; ++i) {
+            rc = enqueue_update(c, *hp, nullptr, MID, s, UPD_SKIP_ONLINE_CHAINS);
+            if (rc != FBHIP_OK) break;
+            const bool more = i + 1 < n_steps;
+            if (more) {                          // fork: the next step's head on the twin workspace set
+                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
+                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
+                c->cur ^= 1;
+                rc = enqueue_update(c, *hp, nullptr, HEAD, c->side, UPD_SKIP_TARGET_CHAIN);
+                c->cur ^= 1;
+                if (rc != FBHIP_OK) break;
+            }
+            rc = enqueue_update(c, *hp, nullptr, TAIL, s);
+            if (more) {                          // join, then continue on the set the head filled
+                if ((he = hipEventRecord(c->events[2 * i + 1], c->side)) != hipSuccess) break;
+                if ((he = hipStreamWaitEvent(s, c->events[2 * i + 1], 0)) != hipSuccess) break;
+                c->cur ^= 1;
+            }
+        }
+        c->cur = cur0;
+    }
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (he != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCK(c, he); }
     HIPCK(c, e);
     GraphEntry ge{};
     ge.mask = FBHIP_PHASE_ALL; ge.hp = *hp; ge.has_inj = false; ge.n_steps = n_steps;
@@ -1331,7 +1448,7 @@ int fbhip_read_metrics(fbhip_ctx* c, float* host_out, void* stream) {
     RC(need_bound(c, false));
     if (!host_out) return FBHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    HIPCK(c, hipMemcpyAsync(host_out, c->w.metrics, FBHIP_NUM_METRICS * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipMemcpyAsync(host_out, c->W().metrics, FBHIP_NUM_METRICS * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCK(c, hipStreamSynchronize(s));
     return FBHIP_OK;
 }
@@ -1339,7 +1456,7 @@ int fbhip_read_metrics(fbhip_ctx* c, float* host_out, void* stream) {
 int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld) {
     RC(need_bound(c, false));
     if (!name || !ptr) return FBHIP_E_INVALID;
-    Ws& w = c->w;
+    Ws& w = c->W();
     const fbhip_dims& d = c->d;
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, z = d.z_dim;
     const int aoff = geom_of(d).single ? o + z : o;
@@ -1394,7 +1511,7 @@ GemvProblem GV(const float* x, const float* W, int ldw, const float* bias, float
 int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipStream_t s) {
     const fbhip_dims& d = c->d;
     const int o = d.obs_dim, z = d.z_dim, a = d.action_dim, H = d.hidden_dim;
-    Ws& w = c->w;
+    Ws& w = c->W();
     const ActP& A = c->A_p;
     float* pre1o = w.act_vec; float* pre1z = pre1o + 2048; float* h = pre1z + 2048; float* pv = h + 2048;
     const size_t nin = act_noise_off(d) + (has_noise ? a : 0);
@@ -1438,7 +1555,7 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
 int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, z = d.z_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb);
-    Ws& w = c->w;
+    Ws& w = c->W();
     const BwdP& K = c->K_p;
     float* pre1 = w.act_vec; float* r2 = pre1 + 2048; float* y = r2 + 2048;
     HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, (act_z_off(d) + z) * sizeof(float), hipMemcpyHostToDevice, s));
@@ -1518,7 +1635,7 @@ int fbhip_actor_forward(fbhip_ctx* c, const float* obs, int32_t ld_obs, const fl
     if (!obs || !z || !action_out || rows < 1) return FBHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const fbhip_dims& d = c->d;
-    Ws& w = c->w;
+    Ws& w = c->W();
     const int La = pad4(head_width(d));
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
         const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
@@ -1537,7 +1654,7 @@ int fbhip_backward_map(fbhip_ctx* c, int32_t which, const float* goal, int32_t l
     if (!goal || !out || rows < 1) return FBHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const fbhip_dims& d = c->d;
-    Ws& w = c->w;
+    Ws& w = c->W();
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
         const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
         RC(backward_map_fwd(c, which ? c->K_t : c->K_p, goal + (size_t)r0 * ld_goal, ld_goal, w.bsA, n, s));
@@ -1554,7 +1671,7 @@ int fbhip_forward_map(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld_
     if (!obs || !z || !action || !f1_out || !f2_out || rows < 1) return FBHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const fbhip_dims& d = c->d;
-    Ws& w = c->w;
+    Ws& w = c->W();
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
         const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
         if (geom_of(d).single) {                 // one panel [obs | z | action]
