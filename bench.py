@@ -145,8 +145,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steps-per-launch", type=int, default=8,
                     help="consecutive updates handed to one hipGraph launch (FBHipAgent.update_many, as run_offline does "
-                         "between two log lines); 1 = one launch per update.  Ignored (1) when N > 1: the gradient "
-                         "all-reduces sit between the phases of every step")
+                         "between two log lines); 1 = one launch per update.  With N > 1 the same call pipelines the steps "
+                         "around the gradient all-reduces (the next step's sampling + online forward under the actor all-reduce)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with the gloo backend (RCCL refuses two ranks per device): exercises the "
                          "multi-rank code path of this script on a 1-GPU box; the number it prints is NOT a scaling result")
@@ -200,7 +200,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    spl = max(1, args.steps_per_launch) if (world == 1 and not args.global_batch) else 1
+    spl = max(1, args.steps_per_launch) if not args.global_batch else 1
 
     def run(first_step, n_steps):                 # exactly n_steps updates, spl per graph launch
         done = 0

@@ -13,8 +13,11 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libfbhip.so"
 
 NET_FORWARD, NET_BACKWARD, NET_ACTOR = 0, 1, 2
-PHASE_SAMPLE, PHASE_FB_FWD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD, PHASE_FB_BWD = 1, 2, 4, 8, 16, 32, 64
-PHASE_FB_GRAD, PHASE_ALL = PHASE_FB_FWD | PHASE_FB_BWD, 127
+PHASE_SAMPLE, PHASE_FB_FWD_ONLINE, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD, PHASE_FB_BWD_A = 1, 2, 4, 8, 16, 32, 64
+PHASE_FB_FWD_TARGET, PHASE_FB_BWD_B = 128, 256
+PHASE_FB_BWD = PHASE_FB_BWD_A | PHASE_FB_BWD_B
+PHASE_FB_FWD = PHASE_FB_FWD_ONLINE | PHASE_FB_FWD_TARGET
+PHASE_FB_GRAD, PHASE_ALL = PHASE_FB_FWD | PHASE_FB_BWD, 511
 NUM_METRICS = 32
 # metric name -> index in the device metrics array (fb_ddpg.py:356-377, 413-418)
 METRIC_INDEX = {n: i for i, n in enumerate(
@@ -67,6 +70,8 @@ PROTOTYPES = {
     "fbhip_get_step_counts": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
     "fbhip_update_many": (C.c_int, [_P, _P, _I, _P]),
+    "fbhip_select_workspace_set": (C.c_int, [_P, _I]),
+    "fbhip_fb_early_grad_range": (C.c_int, [C.POINTER(Dims), C.POINTER(_L), C.POINTER(_L)]),
     "fbhip_embeddings_floats": (_Z, [C.POINTER(Dims)]),
     "fbhip_export_embeddings": (C.c_int, [_P, _P, _P]),
     "fbhip_bind_global_batch": (C.c_int, [_P, _P, _P, _I, _I]),
@@ -108,7 +113,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 8:
+    if lib.fbhip_abi_version() != 10:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

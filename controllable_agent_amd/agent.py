@@ -678,7 +678,14 @@ class FBHipAgent:
             h = hp_fb if (mask & _lib.PHASE_FB_STEP) else hp
             check(lib.fbhip_update(self._ctx, C.byref(h), inj, mask, int(use_graph), s), self._ctx)
 
-        dp_update(run_phases, self._fb_grads, self._actor_grads, self._exchange_embeddings if global_batch else None)
+        dp_update(run_phases, self._fb_grads, self._actor_grads, self._exchange_embeddings if global_batch else None,
+                  early=self._early_grad_range())
+
+    def _early_grad_range(self) -> tp.Tuple[int, int]:
+        """(offset, count) of the FB gradient bucket that FB_BWD_A completes (both ForwardMap heads): reduced under FB_BWD_B."""
+        off, cnt = C.c_int64(), C.c_int64()
+        check(_lib.load().fbhip_fb_early_grad_range(C.byref(self._dims), C.byref(off), C.byref(cnt)))
+        return int(off.value), int(cnt.value)
 
     def _exchange_embeddings(self) -> None:
         """Mode B exchange step (distributed.py): all-gather the six embedding panels + discounts of every rank and bind
@@ -763,17 +770,35 @@ class FBHipAgent:
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         """``n_steps`` consecutive ``update(replay_loader, step + i)`` calls as ONE graph launch (``fbhip_update_many``):
         same kernels, same order, same results -- for loops that do nothing between updates (train_offline.py:101-134
-        between two log lines).  Falls back to single updates whenever that would not be equivalent: gradient all-reduce
-        (world > 1), a host-sampling loader, ``update_every_steps != 1``, a time-varying ``stddev_schedule``.
-        Returns the metrics of the LAST step (if metrics are on)."""
+        between two log lines).  With world > 1 the steps are pipelined around the gradient all-reduces instead
+        (``distributed.dp_update_many``).  Falls back to single updates whenever that would not be equivalent: the
+        global-batch schedule, a host-sampling loader, ``update_every_steps != 1``, a time-varying ``stddev_schedule``.
+        Returns the metrics of the LAST step (if metrics are on).  NOTE: step t+1's batch is sampled while step t is still
+        running -- from the same buffer contents; do not use it when transitions are added between updates."""
         c = self.cfg
         stds = {schedule(c.stddev_schedule, step + i) for i in range(n_steps)}
-        if (n_steps < 2 or self._world() > 1 or c.dp_global_batch or not isinstance(replay_loader, DeviceReplayBuffer) or
+        split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
+        if (n_steps < 2 or c.dp_global_batch or not isinstance(replay_loader, DeviceReplayBuffer) or
                 c.update_every_steps != 1 or len(stds) != 1 or not self._use_graph):
             out: tp.Dict[str, float] = {}
             for i in range(n_steps):
                 out = self.update(replay_loader, step + i)
             return out
+        if split:
+            # data parallel: the steps are pipelined around the gradient all-reduces (distributed.dp_update_many)
+            from .distributed import dp_update_many
+            want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+            self._bind_replay(replay_loader)
+            hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
+            lib = _lib.load()
+
+            def launch() -> None:
+                s = stream_ptr()
+                dp_update_many(lambda mask: check(lib.fbhip_update(self._ctx, C.byref(hp), None, mask, 1, s), self._ctx),
+                               lambda which: check(lib.fbhip_select_workspace_set(self._ctx, which), self._ctx),
+                               self._fb_grads, self._actor_grads, n_steps, early=self._early_grad_range())
+            self._on_update_stream(launch)
+            return self._metrics()
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
         self._bind_replay(replay_loader)
         hp = self._hparams(step, want, 1.0, float(replay_loader._discount), float(replay_loader._future))

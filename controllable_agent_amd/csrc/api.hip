@@ -352,7 +352,7 @@ ActP act_p(float* base, const NetLayout& L) {
     return a;
 }
 
-struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; };
+struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; int set; };
 struct InferGraph { int kind; int eval_mode; int has_noise; float stddev; hipGraphExec_t exec; };
 
 }  // namespace
@@ -507,6 +507,14 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
             g.p[g.n++] = p;
         }
         g.total_tiles = start;
+        static const bool log_launches = [] { const char* e = getenv("FBHIP_GEMM_LOG"); return e && e[0] == '1'; }();
+        if (log_launches) {                      // tools/gemm_launch_report.py joins these lines with a kernel trace
+            double fl = 0;
+            for (int q = 0; q < g.n; ++q) fl += 2.0 * g.p[q].M * g.p[q].N * g.p[q].K;
+            fprintf(stderr, "GEMMLOG cfg=%d wgs=%d gflop=%.4f reduce=%d :", cfg, start, fl * 1e-9, red > 0 ? 1 : 0);
+            for (int q = 0; q < g.n; ++q) fprintf(stderr, " %dx%dx%d/%d", g.p[q].M, g.p[q].N, g.p[q].K, g.p[q].kslices);
+            fprintf(stderr, "\n");
+        }
         HIPCK(ctx, launch_gemm_group(g, cfg, s));
         if (red > 0) HIPCK(ctx, launch_splitk_reduce(g, red, s));
     }
@@ -859,12 +867,9 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
 }
 
 // ---- one update(): fb_ddpg.py:427-520 ----------------------------------------------------------------------
-// flags: how fbhip_update_many cuts FB_FWD when it pipelines consecutive steps
-enum { UPD_SKIP_TARGET_CHAIN = 1,   // FB_FWD without the target chain actor(next_obs) -> next_action -> forward_target (needs the actor step)
-       UPD_SKIP_ONLINE_CHAINS = 2 };// FB_FWD without online F and the B(next_goal) passes (already done with the sampling)
 #define POST_BEGIN prog_post(prog, [=, &w](hipStream_t s) -> int {
 #define POST_END return (int)FBHIP_OK; });
-int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, int flags, Program& prog) {
+int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, Program& prog) {
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
@@ -925,7 +930,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_p, w.fgoal.p, w.fgoal.ld, w.bsF, B, ch.back(), /*with_projection=*/false);
             }
-            if (mask & FBHIP_PHASE_FB_FWD) {
+            if (mask & FBHIP_PHASE_FB_FWD_ONLINE) {
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
                 ch.emplace_back();
@@ -953,6 +958,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
     // forward_net or the new FB weights: in a call that also runs the FB backward it shares that backward's launches
+    // (FB_BWD is two bits, see below: pass ACTOR_FWD with both or with neither)
     const bool early_actor = (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
     auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst) {
         return [=, &w](Ops& o2) {
@@ -970,14 +976,14 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             // chain B: online F (fb_ddpg.py:318)    chains C, D: target B (:312) and online B (:319)
             // (C, D already ran with the sampler's z-mix pass when this call also covered the SAMPLE phase)
             std::vector<Chain> ch(2);
-            if (!(flags & UPD_SKIP_TARGET_CHAIN)) {
+            if (mask & FBHIP_PHASE_FB_FWD_TARGET) {
                 actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0]);
                 ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld));
                 forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
             }
-            if (!(flags & UPD_SKIP_ONLINE_CHAINS))
+            if (mask & FBHIP_PHASE_FB_FWD_ONLINE)
                 forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
-            if (!(mask & FBHIP_PHASE_SAMPLE) && !(flags & UPD_SKIP_ONLINE_CHAINS)) {
+            if ((mask & FBHIP_PHASE_FB_FWD_ONLINE) && !(mask & FBHIP_PHASE_SAMPLE)) {
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
                 ch.emplace_back();
@@ -986,7 +992,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             prog_parallel(prog, ch);
         }
     }
-    if (mask & FBHIP_PHASE_FB_BWD) {
+    if (mask & FBHIP_PHASE_FB_BWD_A) {
         // --- pairwise loss + dF1, dF2, dB (fb_ddpg.py:320-348, :383)
         const float* BmO = d.norm_z ? w.bsO.Bm.p : w.bsO.y.p;      // online / target B(next_goal) as the loss sees them
         const float* BmT = d.norm_z ? w.bsA.Bm.p : w.bsA.y.p;
@@ -1017,8 +1023,15 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s, Bg));
         }
         POST_END
+    }
+    if (mask & FBHIP_PHASE_FB_BWD) {
         {
-            // --- backward (fb_ddpg.py:383): forward_net, backward_net and (early) the actor's own forward pass
+            // --- backward (fb_ddpg.py:383): forward_net, backward_net and (early) the actor's own forward pass.
+            // FB_BWD_A stops after the two rounds that finish the gradients of both ForwardMap heads (F{1,2}.{0,2}: 57 % of
+            // the FB bucket at walker dims, fbhip_fb_early_grad_range), FB_BWD_B runs the rest: a data-parallel host starts
+            // the all-reduce of that range in between and hides it under FB_BWD_B.
+            const float* BmO = d.norm_z ? w.bsO.Bm.p : w.bsO.y.p;
+            (void)BmO;
             std::vector<Chain> ch(3);
             forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
             backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1]);
@@ -1026,7 +1039,11 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                 actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2]);
                 ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
             }
-            prog_parallel(prog, ch);
+            Program bw;
+            prog_parallel(bw, ch);
+            const size_t cut = bw.size() < 2 ? bw.size() : 2;
+            if (mask & FBHIP_PHASE_FB_BWD_A) prog.insert(prog.end(), bw.begin(), bw.begin() + cut);
+            if (mask & FBHIP_PHASE_FB_BWD_B) prog.insert(prog.end(), bw.begin() + cut, bw.end());
         }
     }
 
@@ -1107,9 +1124,9 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 #undef POST_BEGIN
 #undef POST_END
 
-int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s, int flags = 0) {
+int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s) {
     Program prog;
-    RC(build_update(c, hp, inj, mask, flags, prog));
+    RC(build_update(c, hp, inj, mask, prog));
     return run_program(c, prog, s);
 }
 
@@ -1344,7 +1361,7 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     for (auto& g : c->graphs) {
-        if (g.n_steps == 1 && g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
+        if (g.n_steps == 1 && g.set == c->cur && g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
             (!inject || memcmp(&g.inj, inject, sizeof(*inject)) == 0)) {
             HIPCK(c, hipGraphLaunch(g.exec, s));
             return FBHIP_OK;
@@ -1357,14 +1374,29 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     HIPCK(c, e);
     GraphEntry ge{};
-    ge.mask = phase_mask; ge.hp = *hp; ge.has_inj = inject != nullptr; ge.n_steps = 1;
+    ge.mask = phase_mask; ge.hp = *hp; ge.has_inj = inject != nullptr; ge.n_steps = 1; ge.set = c->cur;
     if (inject) ge.inj = *inject;
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCK(c, e);
-    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
     HIPCK(c, hipGraphLaunch(ge.exec, s));
+    return FBHIP_OK;
+}
+
+int fbhip_fb_early_grad_range(const fbhip_dims* dims, int64_t* offset, int64_t* count) {
+    if (check_dims(dims) != FBHIP_OK || !offset || !count) return FBHIP_E_INVALID;
+    const NetLayout L = build_layout(*dims, FBHIP_NET_FORWARD);
+    // both heads (F1.0 F2.0 F1.2 F2.2, weights and biases) are laid out last in forward_net
+    *offset = (int64_t)L.by_name.at("F1.0.weight").off;
+    *count = (int64_t)L.numel - *offset;
+    return FBHIP_OK;
+}
+
+int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
+    if (!c || which < 0 || which > 1) return FBHIP_E_INVALID;
+    c->cur = which;
     return FBHIP_OK;
 }
 
@@ -1373,7 +1405,7 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     if (!hp || n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     for (auto& g : c->graphs) {
-        if (g.n_steps == n_steps && g.mask == FBHIP_PHASE_ALL && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {
+        if (g.n_steps == n_steps && g.set == c->cur && g.mask == FBHIP_PHASE_ALL && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {
             HIPCK(c, hipGraphLaunch(g.exec, s));
             return FBHIP_OK;
         }
@@ -1403,20 +1435,20 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     if (!pipe) {
         for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ALL, s);
     } else {
-        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD;
-        const int MID = FBHIP_PHASE_FB_FWD | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD | FBHIP_PHASE_FB_STEP;
+        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
+        const int MID = FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD | FBHIP_PHASE_FB_STEP;   // (both FB_BWD bits)
         const int TAIL = FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP;
         const int cur0 = c->cur;
-        rc = enqueue_update(c, *hp, nullptr, HEAD, s, UPD_SKIP_TARGET_CHAIN);
+        rc = enqueue_update(c, *hp, nullptr, HEAD, s);
         for (int i = 0; i < n_steps && rc == FBHIP_OK && he == hipSuccess; ++i) {
-            rc = enqueue_update(c, *hp, nullptr, MID, s, UPD_SKIP_ONLINE_CHAINS);
+            rc = enqueue_update(c, *hp, nullptr, MID, s);
             if (rc != FBHIP_OK) break;
             const bool more = i + 1 < n_steps;
             if (more) {                          // fork: the next step's head on the twin workspace set
                 if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
                 if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
                 c->cur ^= 1;
-                rc = enqueue_update(c, *hp, nullptr, HEAD, c->side, UPD_SKIP_TARGET_CHAIN);
+                rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
                 c->cur ^= 1;
                 if (rc != FBHIP_OK) break;
             }
@@ -1434,11 +1466,11 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     if (he != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCK(c, he); }
     HIPCK(c, e);
     GraphEntry ge{};
-    ge.mask = FBHIP_PHASE_ALL; ge.hp = *hp; ge.has_inj = false; ge.n_steps = n_steps;
+    ge.mask = FBHIP_PHASE_ALL; ge.hp = *hp; ge.has_inj = false; ge.n_steps = n_steps; ge.set = c->cur;
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCK(c, e);
-    if (c->graphs.size() >= 8) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
     HIPCK(c, hipGraphLaunch(ge.exec, s));
     return FBHIP_OK;

@@ -31,9 +31,12 @@ import typing as tp
 
 import torch
 
-PHASE_SAMPLE, PHASE_FB_FWD, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD, PHASE_FB_BWD = 1, 2, 4, 8, 16, 32, 64
+PHASE_SAMPLE, PHASE_FB_FWD_ONLINE, PHASE_FB_STEP, PHASE_ACTOR_GRAD, PHASE_ACTOR_STEP, PHASE_ACTOR_FWD, PHASE_FB_BWD_A = 1, 2, 4, 8, 16, 32, 64
+PHASE_FB_FWD_TARGET, PHASE_FB_BWD_B = 128, 256
+PHASE_FB_FWD = PHASE_FB_FWD_ONLINE | PHASE_FB_FWD_TARGET
+PHASE_FB_BWD = PHASE_FB_BWD_A | PHASE_FB_BWD_B
 PHASE_FB_GRAD = PHASE_FB_FWD | PHASE_FB_BWD
-PHASE_ALL = 127
+PHASE_ALL = 511
 
 
 def world_size() -> int:
@@ -46,8 +49,37 @@ def rank() -> int:
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _reduce_fb(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, early: tp.Optional[tp.Tuple[int, int]],
+               first_mask: int, live: bool) -> None:
+    """FB backward + the sum-all-reduce of the FB bucket.  With ``early = (offset, count)`` (the gradients that are final after
+    FB_BWD_A: both ForwardMap heads, 57 % of the bucket at walker dims) that range is reduced WHILE the rest of the backward
+    runs; the remainder follows.  ``first_mask``: the phases issued together with FB_BWD_A."""
+    import torch.distributed as dist
+    if not live or early is None:
+        run_phases(first_mask | PHASE_FB_BWD_B)
+        if live:
+            dist.all_reduce(fb_grads)
+        return
+    off, cnt = early
+    run_phases(first_mask)
+    work = dist.all_reduce(fb_grads[off:off + cnt], async_op=True)
+    run_phases(PHASE_FB_BWD_B | (first_mask & PHASE_ACTOR_FWD))
+    work.wait()
+    rest = [t for t in (fb_grads[:off], fb_grads[off + cnt:]) if t.numel() > 0]
+    if len(rest) == 2 and dist.get_backend() == "nccl":
+        # one grouped RCCL launch for the two remaining slices (trunks | backward_net) instead of two latencies
+        from torch.distributed.distributed_c10d import _coalescing_manager
+        with _coalescing_manager(device=fb_grads.device):
+            for t in rest:
+                dist.all_reduce(t)
+    else:
+        for t in rest:
+            dist.all_reduce(t)
+
+
 def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, actor_grads: torch.Tensor,
-              exchange: tp.Optional[tp.Callable[[], None]] = None) -> None:
+              exchange: tp.Optional[tp.Callable[[], None]] = None,
+              early: tp.Optional[tp.Tuple[int, int]] = None) -> None:
     """Run one update through ``run_phases(mask)``; with world_size > 1 the two gradient buckets are
     sum-all-reduced between the phases (``run_phases`` applies grad_scale = 1/world in its optimiser steps).
     ``exchange`` (mode B): called between FB_FWD and FB_BWD; it all-gathers the embeddings and binds the global batch
@@ -69,12 +101,50 @@ def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, acto
         run_phases(PHASE_ALL)
         return
     # (FBHIP_FORCE_PHASE_SPLIT=1 runs this schedule on a single rank too: tests / 1-GPU rehearsal of the 8-GPU path)
-    reduce = dist.all_reduce if (dist.is_available() and dist.is_initialized()) else (lambda t: None)
-    run_phases(PHASE_SAMPLE | PHASE_FB_GRAD | PHASE_ACTOR_FWD)     # the actor's forward rides along the FB backward
-    reduce(fb_grads)
+    live = dist.is_available() and dist.is_initialized()
+    reduce = dist.all_reduce if live else (lambda t: None)
+    # the actor's forward rides along the FB backward
+    _reduce_fb(run_phases, fb_grads, early, PHASE_SAMPLE | PHASE_FB_FWD | PHASE_FB_BWD_A | PHASE_ACTOR_FWD, live)
     run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
     reduce(actor_grads)
     run_phases(PHASE_ACTOR_STEP)
+
+
+def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable[[int], None], fb_grads: torch.Tensor,
+                   actor_grads: torch.Tensor, n_steps: int, early: tp.Optional[tp.Tuple[int, int]] = None) -> None:
+    """``n_steps`` consecutive mode-A updates with the steps software-pipelined: step t+1's sampling, z mixing, B passes and
+    online ForwardMap pass (``SAMPLE | FB_FWD_ONLINE``: they depend on step t only through its FB optimiser step) are
+    launched on the OTHER workspace set while step t's actor-gradient all-reduce is in flight, so that all-reduce is hidden
+    behind useful work instead of idling the GPU (the FB all-reduce still gates the FB step).  Same kernels, operands and
+    order inside each step as ``n_steps`` calls of ``dp_update``: bit-identical results.
+
+        head(0);  for t:  FB_FWD_TARGET|FB_BWD_A|ACTOR_FWD -> all_reduce(fb heads, async) || FB_BWD_B|ACTOR_FWD -> wait
+                          -> all_reduce(fb rest) -> FB_STEP|ACTOR_GRAD
+                          -> all_reduce(actor, async) || head(t+1) -> wait -> ACTOR_STEP
+    """
+    import torch.distributed as dist
+    live = dist.is_available() and dist.is_initialized()
+    head = PHASE_SAMPLE | PHASE_FB_FWD_ONLINE
+    cur = 0
+    select_set(cur)
+    try:
+        run_phases(head)
+        for t in range(n_steps):
+            _reduce_fb(run_phases, fb_grads, early, PHASE_FB_FWD_TARGET | PHASE_FB_BWD_A | PHASE_ACTOR_FWD, live)
+            run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
+            work = dist.all_reduce(actor_grads, async_op=True) if live else None
+            if t + 1 < n_steps:
+                select_set(cur ^ 1)
+                run_phases(head)                     # the next step's head, under the all-reduce
+                select_set(cur)
+            if work is not None:
+                work.wait()                          # nccl: the compute stream waits; gloo: the host does
+            run_phases(PHASE_ACTOR_STEP)
+            if t + 1 < n_steps:
+                cur ^= 1
+                select_set(cur)
+    finally:
+        select_set(0)
 
 
 def shard_episodes(n_episodes: int, rank_: int, world: int) -> range:

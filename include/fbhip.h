@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 8
+#define FBHIP_ABI_VERSION 10
 
 enum {
     FBHIP_OK = 0,
@@ -50,10 +50,16 @@ enum { FBHIP_NET_FORWARD = 0, FBHIP_NET_BACKWARD = 1, FBHIP_NET_ACTOR = 2 };
 /* phases of one update(); a mask selects which are enqueued (multi-GPU inserts all-reduces between them) */
 enum {
     FBHIP_PHASE_SAMPLE = 1,      /* replay gather + z sampling + z mixing           (fb_ddpg.py:433-491) */
-    FBHIP_PHASE_FB_FWD = 2,      /* targets and online F / B up to the six embeddings F1 F2 B tF1 tF2 tB (fb_ddpg.py:303-319) */
-    FBHIP_PHASE_FB_BWD = 64,     /* pairwise loss + FB backward (fb_ddpg.py:320-383); on the rows bound by
-                                  * fbhip_bind_global_batch when a global batch is bound */
-    FBHIP_PHASE_FB_GRAD = 66,    /* = FB_FWD | FB_BWD */
+    FBHIP_PHASE_FB_FWD_ONLINE = 2,   /* online F(obs, z, action) and the online / target B(next_goal) passes (fb_ddpg.py:312, 318-319):
+                                      * need this step's batch and z but NOT the previous actor step */
+    FBHIP_PHASE_FB_FWD_TARGET = 128, /* actor(next_obs) -> next_action -> forward_target (fb_ddpg.py:303-311) */
+    FBHIP_PHASE_FB_FWD = 130,    /* = FB_FWD_ONLINE | FB_FWD_TARGET: everything up to the six embeddings F1 F2 B tF1 tF2 tB */
+    FBHIP_PHASE_FB_BWD_A = 64,   /* pairwise loss (on the rows bound by fbhip_bind_global_batch when a global batch is bound) + the
+                                  * first two backward rounds: they complete the gradients of both ForwardMap heads
+                                  * (fbhip_fb_early_grad_range) */
+    FBHIP_PHASE_FB_BWD_B = 256,  /* the rest of fb_loss.backward() (fb_ddpg.py:383) */
+    FBHIP_PHASE_FB_BWD = 320,    /* = FB_BWD_A | FB_BWD_B.  ACTOR_FWD must accompany both halves or neither */
+    FBHIP_PHASE_FB_GRAD = 450,   /* = FB_FWD | FB_BWD */
     FBHIP_PHASE_FB_STEP = 4,     /* fb_opt.step() + both soft_update_params         (fb_ddpg.py:384,500-503) */
     FBHIP_PHASE_ACTOR_GRAD = 8,  /* Q through the UPDATED forward_net, actor backward  (fb_ddpg.py:398-410) */
     FBHIP_PHASE_ACTOR_STEP = 16, /* actor_opt.step()                                (fb_ddpg.py:411) */
@@ -61,7 +67,7 @@ enum {
      * so it may run in the same call as FB_GRAD (it then shares the FB backward's launches) -- or with ACTOR_GRAD.
      * An ACTOR_GRAD call WITHOUT this bit uses the pass of an earlier call on the same batch. */
     FBHIP_PHASE_ACTOR_FWD = 32,
-    FBHIP_PHASE_ALL = 127
+    FBHIP_PHASE_ALL = 511
 };
 
 typedef struct fbhip_dims {
@@ -191,6 +197,13 @@ int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* in
  * calls -- the Adam / RNG counters advance on the device -- minus n_steps - 1 graph-launch gaps.  Single-rank only (there
  * is no place for the gradient all-reduce inside the graph); ``hp`` is constant over the n_steps (1 <= n_steps <= 64). */
 int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
+/* The workspace holds two complete per-step sets (fbhip_update_many alternates them).  A host that pipelines steps itself
+ * (data parallel: the next step's SAMPLE | FB_FWD_ONLINE under this step's actor all-reduce) selects the set the following
+ * fbhip_update calls work on; phases of one step must all run on the same set.  Default 0. */
+int fbhip_select_workspace_set(fbhip_ctx* ctx, int32_t which);
+/* [offset, offset + count) floats of the FB gradient buffer (forward_net ++ backward_net) that are FINAL after
+ * FBHIP_PHASE_FB_BWD_A: the gradients of F1.0 F2.0 F1.2 F2.2, laid out last in forward_net. */
+int fbhip_fb_early_grad_range(const fbhip_dims* dims, int64_t* offset, int64_t* count);
 /* ---- global-batch data parallel (SURVEY section 8e "mode B"): the FB / orthonormality losses couple every row of the batch
  * with every other row (fb_ddpg.py:313-326, 344-346), so the exact loss of a batch spread over several devices needs one
  * exchange: after FB_FWD every rank exports its six [batch, pad4(z_dim)] embedding panels + discounts

@@ -151,3 +151,26 @@ def test_phase_split_oracle_equals_monolithic_update():
     sa, sb = a.state_tensors(), b.state_tensors()
     for k in sa:
         np.testing.assert_allclose(sb[k], sa[k], rtol=1e-6, atol=1e-8, err_msg=k)
+
+
+def test_dp_update_many_call_order_and_workspace_sets():
+    """Host logic of the pipelined schedule (no process group: the all-reduces are skipped): every step's phases run on ONE
+    workspace set, consecutive steps alternate sets, the next head is issued between ACTOR_GRAD and ACTOR_STEP, and set 0 is
+    restored at the end."""
+    calls, cur = [], [0]
+    D.dp_update_many(lambda mask: calls.append((cur[0], mask)), lambda w: cur.__setitem__(0, w), torch.zeros(1), torch.zeros(1), 3)
+    head = D.PHASE_SAMPLE | D.PHASE_FB_FWD_ONLINE
+    mid = D.PHASE_FB_FWD_TARGET | D.PHASE_FB_BWD | D.PHASE_ACTOR_FWD
+    grad = D.PHASE_FB_STEP | D.PHASE_ACTOR_GRAD
+    assert calls == [(0, head),
+                     (0, mid), (0, grad), (1, head), (0, D.PHASE_ACTOR_STEP),
+                     (1, mid), (1, grad), (0, head), (1, D.PHASE_ACTOR_STEP),
+                     (0, mid), (0, grad), (0, D.PHASE_ACTOR_STEP)]
+    assert cur[0] == 0
+    # every phase bit of an update is issued exactly once per step
+    per_step = [0, 0, 0]
+    step_of = [0, 0, 0, 1, 0, 1, 1, 2, 1, 2, 2, 2]
+    for (_, m), st in zip(calls, step_of):
+        assert per_step[st] & m == 0
+        per_step[st] |= m
+    assert per_step == [D.PHASE_ALL] * 3

@@ -182,3 +182,54 @@ def test_global_batch_schedule_on_one_rank_is_the_plain_update():
     for a, b in zip(states[0][1], states[1][1]):
         for k in a:
             assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-7), k
+
+
+# ------------------------------------------------------------------- pipelined data-parallel steps (dp_update_many)
+def _worker_many(rank, port, out_q):
+    import torch.distributed as dist
+    from controllable_agent_amd.agent import FBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    cfg, nets, storage, lengths = T._setup()
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    states = []
+    for many in (False, True):
+        torch.manual_seed(5)                                   # the agent's Philox key
+        agent = FBHipAgent(**H.agent_kwargs(cfg))
+        agent.load_nets({n: dict(p) for n, p in nets.items()})
+        if many:
+            m = agent.update_many(rb, 0, 5)
+        else:
+            for step in range(5):
+                m = agent.update(rb, step)
+        torch.cuda.synchronize()
+        states.append((H.get_agent_state(agent), m, agent.step_counts()))
+    out_q.put((rank, states))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_dp_steps_equal_single_dp_updates():
+    """world 2: update_many (next step's sampling + online forward launched under the actor all-reduce, twin workspace
+    sets) is bit-identical to the same number of plain data-parallel updates, on every rank, and replicas stay identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_worker_many, args=(r, port, q)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(T.WORLD))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(T.WORLD):
+        (single, m1, c1), (many, m2, c2) = got[r]
+        assert c1 == c2 == (5, 5)
+        for k in single:
+            np.testing.assert_array_equal(single[k], many[k], err_msg=f"rank {r} {k}")
+        for k in m1:
+            assert m1[k] == m2[k], (r, k)
+    for k in got[0][1][0]:
+        np.testing.assert_array_equal(got[0][1][0][k], got[1][1][0][k], err_msg=k)
