@@ -24,12 +24,12 @@ def _buffer(storage, lengths, discount, future=1.0):
     return DeviceReplayBuffer.from_arrays(storage, lengths, discount, future=future, device="cuda")
 
 
-def _param_close(got, ref, lr, name):
+def _param_close(got, ref, lr, name, max_step=0.5):
     """Post-Adam parameters.  Adam divides by sqrt(v): an entry whose gradient is O(eps=1e-8) can move by a
     visible fraction of lr for an O(1e-9) gradient difference, so the bound is: every entry within lr/2 (the
     step is at most ~lr), and all but 0.1 % (at least one entry: the tiny traces have 512-entry tensors) within PARAM_ATOL."""
     diff = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
-    assert diff.max() <= 0.5 * lr + 1e-7, f"{name}: max |diff| {diff.max():.3e}"
+    assert diff.max() <= max_step * lr + 1e-7, f"{name}: max |diff| {diff.max():.3e}"
     bad = int((diff > PARAM_ATOL).sum())
     assert bad <= max(1, diff.size // 1000), f"{name}: {bad} of {diff.size} entries beyond {PARAM_ATOL}"   # 0.1 %, at least one
 
@@ -551,3 +551,45 @@ def test_trunk_inference_paths(flags):
     F1, F2 = fo.forward_map(nets["forward_net"], torch.from_numpy(obs), z, act)
     g1, g2 = agent._forward_map(torch.from_numpy(obs).cuda(), z.cuda(), act.cuda())
     assert H.rel_err(g1.cpu(), F1) < 2e-5 and H.rel_err(g2.cpu(), F2) < 2e-5
+
+
+@pytest.mark.parametrize("dims", [
+    # the smallest sizes the ABI accepts (ragged everywhere: one-column panels, one-wide BackwardMap hidden layer)
+    dict(obs_dim=1, action_dim=1, goal_dim=1, z_dim=2, hidden_dim=4, feature_dim=4, backward_hidden_dim=1, batch_size=2),
+    # odd everything: nothing is a multiple of a tile edge
+    dict(obs_dim=7, action_dim=5, goal_dim=7, z_dim=33, hidden_dim=68, feature_dim=36, backward_hidden_dim=37, batch_size=45),
+    # the documented maxima of the kernels: hidden 2048 (LayerNorm row kernel), z_dim 128 (pairwise kernel)
+    dict(obs_dim=40, action_dim=20, goal_dim=40, z_dim=128, hidden_dim=2048, feature_dim=1024, backward_hidden_dim=2048,
+         batch_size=96),
+])
+def test_one_update_at_the_edges_of_the_supported_dimensions(dims):
+    """One injected update at degenerate, ragged and maximal dimensions: losses, gradients and post-step parameters against
+    the oracle (same tolerances as the teacher-forced traces)."""
+    cfg = fo.OracleConfig(lr=1e-3, **dims)
+    rng = np.random.default_rng(41)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 6, 9, cfg.obs_dim, cfg.action_dim)
+    agent = H.make_hip_agent(cfg, nets)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    oracle = fo.OracleAgent(cfg, nets)
+    draws = fo.make_draws(rng, cfg, 6, lengths)
+    om = oracle.update(fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount), draws, keep=True)
+    m = agent.update_injected(rb, 0, H.draws_dict(draws))
+    for k in H.LOSS_KEYS:
+        assert m[k] == pytest.approx(om[k], rel=5e-5, abs=5e-6), k
+    for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward"), ("actor", "grads_actor")):
+        for k, g in agent._grad_views[net].state_dict().items():
+            ref = oracle.last[key][k]
+            if float(ref.abs().max()) == 0.0:
+                assert float(g.abs().max()) == 0.0, (net, k)
+            else:
+                assert H.rel_err(g.cpu(), ref) < 2 * GRAD_REL_L2, (net, k)
+    state = H.get_agent_state(agent)
+    want = oracle.state_tensors()
+    for k, v in state.items():
+        if not k.startswith("adam_"):
+            # the FIRST Adam step moves every entry by lr g / (|g| + 1e-8) ~ +-lr: an entry whose gradient is rounding noise
+            # (|g| ~ 1e-8 next to typical 1e-3) can get the opposite sign on the two sides, i.e. differ by up to 2 lr
+            _param_close(v, want[k], cfg.lr, k, max_step=2.0)
+    for nv in (agent.forward_net, agent.backward_net, agent.actor, *agent._grad_views.values()):
+        assert nv.pad_abs_max() == 0.0, nv._name
