@@ -257,8 +257,9 @@ class FBHipAgent:
         for f in ("obs_type", "obs_shape", "action_shape", "num_expl_steps"):
             if getattr(cfg, f) is MISSING or getattr(cfg, f) == "???":
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
-        unsupported = {"obs_type": cfg.obs_type == "pixels", "debug": cfg.debug,
-                       "nstep": cfg.nstep != 1}
+        # (``nstep`` is accepted and ignored like in the reference: neither FBDDPGAgent nor the in-memory ReplayBuffer reads
+        # it -- only the file-based loader of url_benchmark/replay_buffer.py:182-259 did)
+        unsupported = {"obs_type": cfg.obs_type == "pixels", "debug": cfg.debug}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"FBHipAgent: non-default options not implemented in the HIP path yet: {bad}")

@@ -91,8 +91,7 @@ def test_episode_batch_surface():
 def test_agent_rejects_unsupported_flags_loudly():
     from controllable_agent_amd.agent import FBHipAgent
     base = dict(obs_type="states", obs_shape=(4,), action_shape=(2,), num_expl_steps=0)
-    for flag in (dict(nstep=3),
-                 dict(debug=True), dict(obs_type="pixels")):
+    for flag in (dict(debug=True), dict(obs_type="pixels")):
         with pytest.raises(NotImplementedError):
             FBHipAgent(**{**base, **flag})
     with pytest.raises(ValueError):
