@@ -699,8 +699,6 @@ class FBHipAgent:
         if pretend > 1:
             world = pretend
         B, Lz = self.cfg.batch_size, (self.cfg.z_dim + 3) // 4 * 4
-        if self.cfg.q_loss:
-            raise NotImplementedError("dp_global_batch: q_loss is not implemented for the global-batch schedule")
         if world > 1 and B % 32:
             raise ValueError("dp_global_batch needs batch_size to be a multiple of 32")
         n = int(lib.fbhip_embeddings_floats(C.byref(self._dims)))
@@ -735,7 +733,7 @@ class FBHipAgent:
             import torch.distributed as dist
             t = torch.tensor(list(buf), dtype=torch.float64)
             share = [_lib.METRIC_INDEX[k] for k in ("target_M", "M1", "fb_loss", "fb_diag", "fb_offdiag", "orth_loss",
-                                                     "orth_loss_diag", "orth_loss_offdiag")]
+                                                     "orth_loss_diag", "orth_loss_offdiag", "q_loss")]
             scale = torch.full_like(t, 1.0 / self._world())
             scale[share] = 1.0
             t = (t * scale).to(self._device if dist.get_backend() == "nccl" else "cpu")

@@ -997,7 +997,6 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         const float* BmO = d.norm_z ? w.bsO.Bm.p : w.bsO.y.p;      // online / target B(next_goal) as the loss sees them
         const float* BmT = d.norm_z ? w.bsA.Bm.p : w.bsA.y.p;
         const int Bg = c->gb_rows;              // > 0: the loss couples the rows of ALL ranks (global-batch data parallel)
-        if (Bg > 0 && hp.q_loss) { c->err = g_err = "fbhip: q_loss is not implemented for the global-batch schedule"; return FBHIP_E_INVALID; }
         POST_BEGIN
         if (Bg > 0) {
             const float* G = c->gb_panels;
@@ -1005,7 +1004,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             HIPCK(c, launch_pairwise_fb_block(G, G + ps, G + 2 * ps, G + 3 * ps, G + 4 * ps, G + 5 * ps, c->gb_discount, Bg, z,
                                               Lz, hp.ortho_coef, c->gb_off, B, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics,
                                               w.pw_scratch, s));
-            if (hp.want_metrics)                // B^T B over the global rows (identical on every rank)
+            if (hp.want_metrics || hp.q_loss)   // B^T B over the global rows (identical on every rank)
                 RC(run_gemms(c, {P(G + 2 * ps, Lz, 0, G + 2 * ps, Lz, 0, w.cov.p, w.cov.ld, z, z, Bg)}, s));
         } else {
             HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, BmO, w.fsT.F1.p, w.fsT.F2.p, BmT, w.disc, B, z,
@@ -1014,10 +1013,10 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                 RC(run_gemms(c, {P(BmO, Lz, 0, BmO, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
         }
         if (hp.q_loss) {                        // fb_ddpg.py:330-340
-            HIPCK(c, launch_inverse(w.cov.p, w.cov.ld, z, 1.0f / (float)B, w.inv_cov.p, w.inv_cov.ld, s));
+            HIPCK(c, launch_inverse(w.cov.p, w.cov.ld, z, 1.0f / (float)(Bg > 0 ? Bg : B), w.inv_cov.p, w.inv_cov.ld, s));
             RC(run_gemms(c, {P(BmO, Lz, 1, w.inv_cov.p, w.inv_cov.ld, 0, w.BinvC.p, Lz, B, z, z)}, s));
             HIPCK(c, launch_qloss(w.fsO.F1.p, w.fsO.F2.p, w.fsT.F1.p, w.fsT.F2.p, w.BinvC.p, w.z.p, Lz, w.disc,
-                                  hp.q_loss_coef, w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, s));
+                                  hp.q_loss_coef, w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, s, Bg));
         }
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s, Bg));

@@ -129,7 +129,8 @@ hipError_t launch_inverse(const float* A, int lda, int d, float scale, float* ou
 hipError_t inverse_prepare();
 hipError_t launch_qloss(const float* F1, const float* F2, const float* tF1, const float* tF2, const float* BinvC,
                         const float* z, int ld, const float* discount, float coef, float* dF1, float* dF2,
-                        float* metrics, float* scratch /* >= ceil(rows/4) floats */, int rows, int d, hipStream_t s);
+                        float* metrics, float* scratch /* >= ceil(rows/4) floats */, int rows, int d, hipStream_t s,
+                        int norm_rows = 0 /* the mean's row count when ``rows`` is a block of a larger batch */);
 hipError_t launch_step_advance(StepState* st, int which /*0 fb, 1 actor, 2 rng*/, hipStream_t s);
 hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel,
                            float lr, float lr2, int64_t split, float grad_scale, float tau,

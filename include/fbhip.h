@@ -211,8 +211,8 @@ int fbhip_fb_early_grad_range(const fbhip_dims* dims, int64_t* offset, int64_t* 
  * panels [6][global_rows][pad4(z_dim)] and discount [global_rows], binds them, and FB_BWD then evaluates rows
  * [row_offset, row_offset + batch) of the global_rows x global_rows loss: dF1 dF2 dB of the rank's own rows are complete
  * (no reduce-scatter), the normalisers are the global ones, so parameter gradients are SUMMED over ranks (grad_scale 1).
- * Metrics of that phase are the rank's share (pairwise terms) -- sum them over ranks.  global_rows = 0 unbinds.  batch and
- * row_offset must be multiples of 32; q_loss is not supported in this mode. */
+ * Metrics of that phase are the rank's share (pairwise terms, q_loss) -- sum them over ranks.  global_rows = 0 unbinds.  batch
+ * and row_offset must be multiples of 32.  q_loss uses the covariance of the gathered B rows. */
 size_t fbhip_embeddings_floats(const fbhip_dims* dims);
 int fbhip_export_embeddings(fbhip_ctx* ctx, float* out, void* stream);
 int fbhip_bind_global_batch(fbhip_ctx* ctx, const float* panels, const float* discount, int32_t global_rows,

@@ -85,21 +85,21 @@ def test_two_ranks_on_one_gpu_equal_gradient_averaging():
 CFG_B = dict(T.CFG, batch_size=32)
 
 
-def _setup_b():
-    cfg = fo.OracleConfig(**CFG_B)
+def _setup_b(q_loss=False):
+    cfg = fo.OracleConfig(**CFG_B, q_loss=q_loss)
     rng = np.random.default_rng(11)
     nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
     storage, lengths = fo.synthetic_storage(rng, T.N_EPS, T.T, cfg.obs_dim, cfg.action_dim)
     return cfg, nets, storage, lengths
 
 
-def _worker_global(rank, port, out_q):
+def _worker_global(rank, port, out_q, q_loss):
     import torch.distributed as dist
     from controllable_agent_amd.agent import FBHipAgent
     from controllable_agent_amd.replay import DeviceReplayBuffer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
-    cfg, nets, storage, lengths = _setup_b()
+    cfg, nets, storage, lengths = _setup_b(q_loss)
     agent = FBHipAgent(**H.agent_kwargs(cfg, dp_global_batch=True))
     agent.load_nets({n: dict(p) for n, p in nets.items()})
     rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
@@ -113,14 +113,16 @@ def _worker_global(rank, port, out_q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_global_batch_equal_one_device_on_the_concatenated_batch():
+@pytest.mark.parametrize("q_loss", [False, True])
+def test_two_ranks_global_batch_equal_one_device_on_the_concatenated_batch(q_loss):
     """dp_global_batch=True (SURVEY 8e mode B): two ranks x 32 rows == ONE oracle update on the 64-row batch made of both
-    ranks' rows (block-diagonal permutation for the z-mix), parameters, Adam state and metrics; replicas bit-identical."""
+    ranks' rows (block-diagonal permutation for the z-mix), parameters, Adam state and metrics; replicas bit-identical.
+    With q_loss the covariance / inverse come from the gathered B rows."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = T._free_port()
-    procs = [ctx.Process(target=_worker_global, args=(r, port, q)) for r in range(T.WORLD)]
+    procs = [ctx.Process(target=_worker_global, args=(r, port, q, q_loss)) for r in range(T.WORLD)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(T.WORLD)]
@@ -130,7 +132,7 @@ def test_two_ranks_global_batch_equal_one_device_on_the_concatenated_batch():
     results = {r: st for r, st, _ in got}
     metrics = {r: m for r, _, m in got}
     torch.set_num_threads(1)
-    cfg, nets, storage, lengths = _setup_b()
+    cfg, nets, storage, lengths = _setup_b(q_loss)
     ref = fo.OracleAgent(cfg, nets)
     from controllable_agent_amd.replay import DeviceReplayBuffer
     for step in range(T.STEPS):
@@ -149,7 +151,7 @@ def test_two_ranks_global_batch_equal_one_device_on_the_concatenated_batch():
         batch = {k: np.concatenate([b[k] for b in batches]) for k in batches[0] if batches[0][k] is not None}
         m = ref.update(batch, both)
         for k in ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_offdiag", "orth_linf", "orth_l2", "M1", "target_M",
-                  "F1", "B", "B_norm", "z_norm", "actor_loss", "q"):
+                  "F1", "B", "B_norm", "z_norm", "actor_loss", "q") + (("q_loss",) if q_loss else ()):
             for r in range(T.WORLD):
                 assert metrics[r][step][k] == pytest.approx(m[k], rel=5e-5, abs=2e-6), (step, r, k)
     want = ref.state_tensors()
