@@ -229,7 +229,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     Ws w;
     Carver c(base);
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
-              Fd = d.feature_dim, Hb = d.backward_hidden_dim;
+              Hb = d.backward_hidden_dim;
     w.st = (StepState*)c.take(sizeof(StepState));
     w.metrics = c.f(FBHIP_NUM_METRICS);
     w.so.ep_idx = (int32_t*)c.take((size_t)B * 4);
@@ -660,7 +660,7 @@ void heads_dgrad_ops(fbhip_ctx* c, Ws& w, const FwdP& W, FSet& S, int rows, Ops&
 void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz,
                            int ldz, FSet& S, int rows, Chain& out) {
     const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, Fd = d.feature_dim, z = d.z_dim, Lz = pad4(z);
+    const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z);
     Ws* w = &c->W();
     FSet* Sp = &S;
     out.push_back([=](Ops& o) {
@@ -1029,8 +1029,6 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             // FB_BWD_A stops after the two rounds that finish the gradients of both ForwardMap heads (F{1,2}.{0,2}: 57 % of
             // the FB bucket at walker dims, fbhip_fb_early_grad_range), FB_BWD_B runs the rest: a data-parallel host starts
             // the all-reduce of that range in between and hides it under FB_BWD_B.
-            const float* BmO = d.norm_z ? w.bsO.Bm.p : w.bsO.y.p;
-            (void)BmO;
             std::vector<Chain> ch(3);
             forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
             backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1]);
