@@ -65,7 +65,7 @@ def make_replay(n_episodes, T, o, a, device, seed, goal_dim=None):
     return rb
 
 
-def cpu_baseline(seed=1, budget_s=12.0, max_steps=40):
+def cpu_baseline(seed=1, budget_s=15.0, max_steps=120):
     """The oracle (our CPU restatement of the reference's update, pinned to it by tests/golden) timed on this
     box's host cores -- the reference's Python cannot travel to the GPU box.  Bounded sample of the same workload."""
     from oracle import fb_oracle as fo
