@@ -91,6 +91,7 @@ PROTOTYPES = {
     "fbhip_actor_loss": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fbhip_pairwise_scratch_floats": (_Z, [_I, _I]),
     "fbhip_pairwise_fb": (C.c_int, [_P] * 7 + [_I, _I, _I, _F] + [_P] * 5 + [_P]),
+    "fbhip_pairwise_fb_block": (C.c_int, [_P] * 7 + [_I, _I, _I, _F, _I, _I] + [_P] * 5 + [_P]),
     "fbhip_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P]),
 }
 
@@ -113,7 +114,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 10:
+    if lib.fbhip_abi_version() != 11:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1786,6 +1786,18 @@ int fbhip_pairwise_fb(const float* F1, const float* F2, const float* Bm, const f
     return FBHIP_OK;
 }
 
+int fbhip_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
+                            const float* tB, const float* discount, int32_t B, int32_t d, int32_t ld, float ortho_coef,
+                            int32_t row_offset, int32_t rows, float* dF1, float* dF2, float* dB, float* metrics,
+                            float* scratch, void* stream) {
+    fbhip_ctx* none = nullptr;
+    if (!scratch) { g_err = "fbhip_pairwise_fb_block: scratch required"; return FBHIP_E_INVALID; }
+    HIPCK(none, pairwise_prepare(B, d));
+    HIPCK(none, launch_pairwise_fb_block(F1, F2, Bm, tF1, tF2, tB, discount, B, d, ld, ortho_coef, row_offset, rows, dF1, dF2,
+                                         dB, metrics, scratch, (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
 int fbhip_adam_ema(float* params, const float* grads, float* m, float* v, float* target, int64_t numel, float lr,
                    int32_t t, float grad_scale, float tau, void* stream) {
     fbhip_ctx* none = nullptr;

@@ -105,6 +105,27 @@ def pairwise_fb(F1, F2, Bm, tF1, tF2, tB, discount, ortho_coef: float):
     return dF1, dF2, dB, {k: float(m[_lib.METRIC_INDEX[k]]) for k in names}
 
 
+def pairwise_fb_block(F1, F2, Bm, tF1, tF2, tB, discount, ortho_coef: float, row_offset: int, rows: int):
+    """Rows [row_offset, row_offset + rows) of ``pairwise_fb`` on the same panels: (dF1, dF2, dB) of those rows and this block's
+    share of the scalars (fbhip_pairwise_fb_block; the global-batch data-parallel schedule)."""
+    _lib.require_device()
+    Bn, d = F1.shape
+    ld = _ld(F1)
+    for t in (F2, Bm, tF1, tF2, tB):
+        assert t.shape == F1.shape and _ld(t) == ld
+    lib = _lib.load()
+    dF1, dF2, dB = (torch.empty((rows, ld), device=F1.device)[:, :d] for _ in range(3))
+    metrics = torch.zeros(_lib.NUM_METRICS, device=F1.device)
+    scratch = torch.empty(lib.fbhip_pairwise_scratch_floats(rows, d), device=F1.device)
+    disc = discount.reshape(-1).contiguous()
+    check(lib.fbhip_pairwise_fb_block(ptr(F1), ptr(F2), ptr(Bm), ptr(tF1), ptr(tF2), ptr(tB), ptr(disc), Bn, d, ld,
+                                      float(ortho_coef), int(row_offset), int(rows), ptr(dF1), ptr(dF2), ptr(dB), ptr(metrics),
+                                      ptr(scratch), stream_ptr()))
+    m = metrics.cpu()
+    names = ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_diag", "orth_loss_offdiag", "target_M", "M1")
+    return dF1, dF2, dB, {k: float(m[_lib.METRIC_INDEX[k]]) for k in names}
+
+
 def adam_ema(params, grads, m, v, target, lr: float, t: int, grad_scale: float = 1.0, tau: float = 0.0) -> None:
     """In-place fused Adam (+ EMA into ``target`` when given) over flat tensors (numel % 4 == 0)."""
     _lib.require_device()

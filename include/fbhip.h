@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 10
+#define FBHIP_ABI_VERSION 11
 
 enum {
     FBHIP_OK = 0,
@@ -289,6 +289,14 @@ size_t fbhip_pairwise_scratch_floats(int32_t B, int32_t d);
 int fbhip_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
                       const float* tB, const float* discount, int32_t B, int32_t d, int32_t ld, float ortho_coef,
                       float* dF1, float* dF2, float* dB, float* metrics, float* scratch, void* stream);
+/* Rows [row_offset, row_offset + rows) of the same loss on the B-row panels (the global-batch data-parallel schedule): dF1 dF2
+ * dB are [rows, d] (ld) and complete for those rows; metrics receive this block's SHARE of the scalars (B-row normalisers),
+ * so the shares of all blocks add up to the values of fbhip_pairwise_fb.  row_offset and rows: multiples of 32 unless rows == B.
+ * scratch: >= fbhip_pairwise_scratch_floats(rows, d) floats. */
+int fbhip_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
+                            const float* tB, const float* discount, int32_t B, int32_t d, int32_t ld, float ortho_coef,
+                            int32_t row_offset, int32_t rows, float* dF1, float* dF2, float* dB, float* metrics,
+                            float* scratch, void* stream);
 /* Fused Adam (+ optional target EMA) over a flat segment: torch.optim.Adam defaults (betas .9/.999, eps 1e-8),
  * t = 1-based step count; target nullable (utils.py:66-69 fused when given). */
 int fbhip_adam_ema(float* params, const float* grads, float* m, float* v, float* target, int64_t numel,

@@ -188,6 +188,31 @@ def test_pairwise_fb_vs_masked_autograd(K):
     assert m["fb_loss"] == pytest.approx(float(L["fb_loss"]), rel=2e-5)
 
 
+@pytest.mark.parametrize("Bn,d,blocks", [(256, 50, 4), (2048, 50, 8), (1024, 100, 2)])
+def test_pairwise_row_blocks_add_up_to_the_square_loss(K, Bn, d, blocks):
+    """Block mode (the global-batch data-parallel schedule): every row block's dF / dB rows equal the square kernel's rows bit for
+    bit where the J-chunking coincides, within fp32 otherwise, and the blocks' scalar shares add up to the square loss."""
+    rng = np.random.default_rng(17)
+    ld = (d + 3) // 4 * 4
+    t = lambda: torch.from_numpy(rng.standard_normal((Bn, ld)).astype(np.float32)).cuda()[:, :d]
+    F1, F2, tF1, tF2 = t(), t(), t(), t()
+    Bm = t(); Bm.copy_(math.sqrt(d) * torch.nn.functional.normalize(Bm, dim=1))
+    tB = t(); tB.copy_(math.sqrt(d) * torch.nn.functional.normalize(tB, dim=1))
+    disc = torch.from_numpy(rng.uniform(0.9, 1.0, Bn).astype(np.float32)).cuda()
+    dF1, dF2, dB, m = K.pairwise_fb(F1, F2, Bm, tF1, tF2, tB, disc, 1.0)
+    rows = Bn // blocks
+    tot = {k: 0.0 for k in m}
+    for b in range(blocks):
+        g1, g2, gb, mb = K.pairwise_fb_block(F1, F2, Bm, tF1, tF2, tB, disc, 1.0, b * rows, rows)
+        sl = slice(b * rows, (b + 1) * rows)
+        assert rel_err(g1.cpu(), dF1[sl].cpu()) < 2e-6 and rel_err(g2.cpu(), dF2[sl].cpu()) < 2e-6
+        assert rel_err(gb.cpu(), dB[sl].cpu()) < 2e-6
+        for k in tot:
+            tot[k] += mb[k]
+    for k in tot:
+        assert tot[k] == pytest.approx(m[k], rel=2e-5, abs=1e-6), k
+
+
 def test_pairwise_is_deterministic(K):
     """fixed-order reductions: two launches give bit-identical gradients and scalars"""
     rng = np.random.default_rng(9)
