@@ -133,7 +133,11 @@ def dominant_kernel_probe(stream_iters=50):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / stream_iters
     return {"kernel": "fbhip::gemm_kernel<2,2,1,32>", "shape": [M, N, Kd], "us": us,
-            "tflops": 2 * M * N * Kd / us / 1e6}
+            "tflops": 2 * M * N * Kd / us / 1e6, "frac_of_peak": 2 * M * N * Kd / us / 1e6 / PEAK_FP32_MFMA_TFLOPS,
+            "note": "the kernel's most expensive single-problem shape in the step, launched alone and timed with HIP events on its "
+                    "launch stream; the same launches inside the step: profiles/*_step_timeline.txt (42-45 us).  The rocprofv3 "
+                    "--stats average of this kernel NAME (profiles/*_kernel_stats.txt, ~37 us) is over all 14 grouped launches "
+                    "per update, whose shapes differ (4.3-8.7 GFLOP, 7-95 us)"}
 
 
 def main():

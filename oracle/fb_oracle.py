@@ -8,6 +8,17 @@ reproduced bit-for-bit on a GPU (SURVEY.md section 7 "hard parts").
 
 Parameters are kept in plain dicts keyed by the reference's ``state_dict``
 names (``obs_action_net.0.weight`` ...), so reference weights load unchanged.
+
+PARITY STATUS: PINNED.  tests/test_oracle_golden.py replays this file against outputs of the REAL reference
+(``url_benchmark.agent.fb_ddpg.FBDDPGAgent`` + ``in_memory_replay_buffer.ReplayBuffer``, imported from /root/reference by
+tests/golden/make_golden.py in the development container; only the vectors are committed): after every step of 13
+tiny-dimension traces every parameter, target, Adam moment and all 18 metrics (default config, goal space + q_loss +
+variable episode lengths, hindsight replay, norm_z=False, rand_weight, add_trunk, preprocess=False, boltzmann), the
+metric curves and parameter checksums of three full-dimension runs, the sampler's index -> row mapping with the real
+numpy RNG, the constructor's weight init under a torch seed, and the inference entry points.
+
+WHO MAY IMPORT THIS: tests/, ``__graft_entry__.smoke()`` (as the checker) and ``bench.py``'s ``cpu_baseline`` leg (as the
+thing timed on the host cores).  The product (controllable_agent_amd/) never does: it has no CPU fallback.
 """
 from __future__ import annotations
 
