@@ -22,7 +22,7 @@ NUM_METRICS = 32
 # metric name -> index in the device metrics array (fb_ddpg.py:356-377, 413-418)
 METRIC_INDEX = {n: i for i, n in enumerate(
     ["target_M", "M1", "F1", "B", "B_norm", "z_norm", "fb_loss", "fb_diag", "fb_offdiag", "q_loss", "orth_loss",
-     "orth_loss_diag", "orth_loss_offdiag", "orth_linf", "orth_l2", "actor_loss", "q", "actor_logprob"])}
+     "orth_loss_diag", "orth_loss_offdiag", "orth_linf", "orth_l2", "actor_loss", "q", "actor_logprob", "q1_success"])}
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK_RELU, EPI_TANH_BWD = range(5)
 
 

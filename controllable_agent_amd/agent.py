@@ -750,6 +750,8 @@ class FBHipAgent:
         out["fb_opt_lr"] = self.fb_opt.param_groups[0]["lr"]
         if c.use_tb or c.use_wandb:                                        # fb_ddpg.py:413-418
             out["actor_loss"], out["q"], out["actor_logprob"] = g("actor_loss"), g("q"), g("actor_logprob")
+            if c.additional_metric:                                        # fb_ddpg.py:403-404, 416-417
+                out["q1_success"] = g("q1_success")
         return out
 
     def update(self, replay_loader: tp.Any, step: int) -> tp.Dict[str, float]:      # fb_ddpg.py:427-520

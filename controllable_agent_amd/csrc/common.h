@@ -93,7 +93,7 @@ hipError_t launch_squash_head_bwd(const float* dact, int ldd, const float* pre, 
 // metrics == nullptr skips the (metric-only) finalize launch
 hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz,
                              const float* mu, int ldmu, const float* action, int lda, float stddev,
-                             float* dF1, float* dF2, float* metrics, float* scratch /* >= 2*ceil(rows/4) floats */,
+                             float* dF1, float* dF2, float* metrics, float* scratch /* >= 3*ceil(rows/4) floats */,
                              int rows, int d, int a, hipStream_t s, Squash sq = Squash{0, 1.f, -5.f, 2.f},
                              const float* pre = nullptr, int ldp = 0, const float* noise = nullptr, int ldn = 0);
 

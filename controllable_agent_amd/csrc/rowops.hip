@@ -4,6 +4,7 @@
 //   policy_sample             : mu = tanh(.) and TruncatedNormal.sample with straight-through clamp (utils.py:171-185)
 //   actor_loss                : Q = min(F1.z, F2.z), loss = -mean Q and dF_i (fb_ddpg.py:400-406)
 #include "common.h"
+#include "fbhip.h"
 
 namespace fbhip {
 
@@ -521,11 +522,11 @@ __global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict
                                                          float* __restrict__ part, int rows, int d, int a,
                                                          const Squash sq, const float* __restrict__ pre, int ldp,
                                                          const float* __restrict__ noise, int ldn) {
-    __shared__ float red[4][2];
+    __shared__ float red[4][3];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
     const float inv_b = 1.0f / (float)rows;
-    float qmin = 0.f, lp = 0.f;
+    float qmin = 0.f, lp = 0.f, q1win = 0.f;
     if (row < rows) {
         float zz[L2_MAXE], q1 = 0.f, q2 = 0.f;
 #pragma unroll
@@ -560,23 +561,26 @@ __global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict
         }
         lp = wave_sum(lp);
         qmin = fminf(q1, q2);
+        q1win = q1 > q2 ? 1.f : 0.f;               // additional_metric: q1_success = (Q1 > Q2).mean()  (fb_ddpg.py:403-404, 417)
     }
-    if (lane == 0) { red[wid][0] = qmin; red[wid][1] = lp; }
+    if (lane == 0) { red[wid][0] = qmin; red[wid][1] = lp; red[wid][2] = q1win; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        part[2 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        part[3 * blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        part[3 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        part[3 * blockIdx.x + 2] = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
     }
 }
 
 __global__ void __launch_bounds__(64) actor_loss_finalize_kernel(const float* __restrict__ part, int nblk, int rows,
                                                                  float* __restrict__ metrics, int m_loss, int m_q,
                                                                  int m_lp, float temp /* 0: loss = -mean Q */) {
-    double q = 0.0, l = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 64) { q += (double)part[2 * b]; l += (double)part[2 * b + 1]; }
+    double q = 0.0, l = 0.0, w = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) { q += (double)part[3 * b]; l += (double)part[3 * b + 1]; w += (double)part[3 * b + 2]; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o); l += __shfl_xor(l, o); }
+    for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o); l += __shfl_xor(l, o); w += __shfl_xor(w, o); }
     if (threadIdx.x == 0) {
+        metrics[FBHIP_M_Q1_SUCCESS] = (float)(w / rows);
         metrics[m_loss] = (float)((temp * l - q) / rows);         // fb_ddpg.py:406
         metrics[m_q] = (float)(q / rows);
         metrics[m_lp] = (float)(l / rows);

@@ -139,9 +139,9 @@ def actor_loss(F1, F2, z, mu, action, stddev: float):
     a = mu.shape[1]
     dF1, dF2 = (torch.empty((rows, _ld(F1)), device=F1.device)[:, :d] for _ in range(2))
     metrics = torch.zeros(_lib.NUM_METRICS, device=F1.device)
-    scratch = torch.empty(2 * ((rows + 3) // 4), device=F1.device)
+    scratch = torch.empty(3 * ((rows + 3) // 4), device=F1.device)
     check(_lib.load().fbhip_actor_loss(ptr(F1), ptr(F2), _ld(F1), ptr(z), _ld(z), ptr(mu), _ld(mu), ptr(action),
                                        _ld(action), float(stddev), ptr(dF1), ptr(dF2), ptr(metrics), ptr(scratch),
                                        rows, d, a, stream_ptr()))
     m = metrics.cpu()
-    return dF1, dF2, {k: float(m[_lib.METRIC_INDEX[k]]) for k in ("actor_loss", "q", "actor_logprob")}
+    return dF1, dF2, {k: float(m[_lib.METRIC_INDEX[k]]) for k in ("actor_loss", "q", "actor_logprob", "q1_success")}

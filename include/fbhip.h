@@ -144,7 +144,9 @@ enum {
     FBHIP_M_TARGET_M = 0, FBHIP_M_M1, FBHIP_M_F1, FBHIP_M_B, FBHIP_M_B_NORM, FBHIP_M_Z_NORM,
     FBHIP_M_FB_LOSS, FBHIP_M_FB_DIAG, FBHIP_M_FB_OFFDIAG, FBHIP_M_Q_LOSS, FBHIP_M_ORTH_LOSS,
     FBHIP_M_ORTH_LOSS_DIAG, FBHIP_M_ORTH_LOSS_OFFDIAG, FBHIP_M_ORTH_LINF, FBHIP_M_ORTH_L2,
-    FBHIP_M_ACTOR_LOSS, FBHIP_M_Q, FBHIP_M_ACTOR_LOGPROB, FBHIP_M_COUNT
+    FBHIP_M_ACTOR_LOSS, FBHIP_M_Q, FBHIP_M_ACTOR_LOGPROB,
+    FBHIP_M_Q1_SUCCESS,            /* (Q1 > Q2).mean() of update_actor, reported when cfg.additional_metric (fb_ddpg.py:403-404, 417) */
+    FBHIP_M_COUNT
 };
 
 typedef struct fbhip_ctx fbhip_ctx;
@@ -277,7 +279,7 @@ int fbhip_l2norm_fwd(const float* y, int32_t ldy, float* out, int32_t ldo, float
 int fbhip_l2norm_bwd(const float* dB, int32_t lddb, const float* y, int32_t ldy, const float* norms, float* dy,
                      int32_t lddy, int32_t rows, int32_t d, void* stream);
 /* Actor loss (fb_ddpg.py:399-406): Q = min(F1.z, F2.z) row dots, loss = -mean Q, dF_i = -z/B on the arg-min
- * (1/2 each on exact ties); writes ACTOR_LOSS, Q, ACTOR_LOGPROB into metrics.  scratch: >= 2*ceil(rows/4) floats. */
+ * (1/2 each on exact ties); writes ACTOR_LOSS, Q, ACTOR_LOGPROB, Q1_SUCCESS into metrics.  scratch: >= 3*ceil(rows/4) floats. */
 int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float* z, int32_t ldz, const float* mu,
                      int32_t ldmu, const float* action, int32_t lda, float stddev, float* dF1, float* dF2, float* metrics,
                      float* scratch, int32_t rows, int32_t d, int32_t a, void* stream);

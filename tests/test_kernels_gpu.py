@@ -274,6 +274,8 @@ def test_actor_loss(K):
     assert m["actor_loss"] == pytest.approx(float(loss), rel=1e-5)
     assert m["q"] == pytest.approx(float(Q.mean()), rel=1e-5)
     assert m["actor_logprob"] == pytest.approx(float(lp), rel=1e-5)
+    Q1, Q2 = torch.einsum('sd, sd -> s', F1, z), torch.einsum('sd, sd -> s', F2, z)
+    assert m["q1_success"] == pytest.approx(float((Q1 > Q2).float().mean()), abs=1e-6)      # additional_metric (fb_ddpg.py:417)
 
 
 def test_gemm_randomised_shapes_layouts_epilogues(K):
