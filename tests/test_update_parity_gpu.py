@@ -479,6 +479,34 @@ def test_update_many_equals_consecutive_updates():
         np.testing.assert_array_equal(s1[k], s3[k], err_msg=k)
 
 
+@pytest.mark.parametrize("flags,goal_space", [
+    (dict(future_ratio=0.4, future=0.8, rand_weight=True), None),
+    (dict(norm_z=False, q_loss=True, goal_dim=3, use_goal=True), "simplified_walker"),
+    (dict(preprocess=False, boltzmann=True, temp=0.5), None),
+    (dict(add_trunk=True), None),
+])
+def test_pipelined_steps_equal_single_updates_for_every_variant(flags, goal_space):
+    """The twin-workspace pipeline of fbhip_update_many (next step's sampling + online forward beside the actor phase) with the
+    config variants that add per-step buffers (hindsight goals, rand_weight matrices, the SquashedNormal head, ...), metrics on:
+    5 pipelined steps == 5 single updates, bit for bit, incl. the last step's metrics."""
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=flags.get("goal_dim", 5), z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64, **{k: v for k, v in flags.items() if k != "goal_dim"})
+    rng = np.random.default_rng(33)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if cfg.use_goal else None)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    a1, a2 = (H.make_hip_agent(cfg, nets, goal_space) for _ in range(2))
+    for s in range(5):
+        m1 = a1.update(rb, s)
+    m2 = a2.update_many(rb, 0, 5)
+    s1, s2 = H.get_agent_state(a1), H.get_agent_state(a2)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+    assert m1.keys() == m2.keys() and len(m1) >= 17
+    for k in m1:
+        assert m1[k] == m2[k], k
+
+
 def test_rand_weight_device_draws():
     """cfg.rand_weight without injected draws: every row of the mixing matrix is u_i * (nonnegative unit vector)
     (fb_ddpg.py:477-480) and the mixed rows of z are sqrt(d) normalize(W @ B(backward_input[perm]))."""
