@@ -770,7 +770,8 @@ class FBHipAgent:
 
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         """``n_steps`` consecutive ``update(replay_loader, step + i)`` calls as ONE graph launch (``fbhip_update_many``):
-        same kernels, same order, same results -- for loops that do nothing between updates (train_offline.py:101-134
+        same kernels, same order, same results (up to the fp32 summation order of a few split-K GEMMs at large dims, see
+        DESIGN.md section 3 "pipelined steps") -- for loops that do nothing between updates (train_offline.py:101-134
         between two log lines).  With world > 1 the steps are pipelined around the gradient all-reduces instead
         (``distributed.dp_update_many``).  Falls back to single updates whenever that would not be equivalent: the
         global-batch schedule, a host-sampling loader, ``update_every_steps != 1``, a time-varying ``stddev_schedule``.

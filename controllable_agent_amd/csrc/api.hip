@@ -1411,8 +1411,10 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     // sampling, z mixing, B passes and online ForwardMap pass depend on step t only through its FB optimiser step (new
     // forward_net / backward_net / targets), which precedes the actor phase.  So they are captured as a second branch
     // beside the actor phase (own stream, own workspace set) and rejoin before step t+1's target chain, which needs the
-    // new actor.  Kernels, their order inside each step and every operand are unchanged: results are bit-identical to
-    // n_steps single updates (tests/test_update_parity_gpu.py).  Measured (walker, 8 steps per launch): 951 -> 965
+    // new actor.  Kernels, their order inside each step and every operand are unchanged.  Results are bit-identical to
+    // n_steps single updates whenever the regrouped launches keep every GEMM's K-slicing (small dims); at walker dims a few
+    // small-output GEMMs of the target chain are sliced differently once they no longer share a launch with the online
+    // chain: fp32 summation order, not math (tests/test_update_parity_gpu.py covers both).  Measured (walker, 8 steps per launch): 951 -> 965
     // updates/s.  (Zipping the two programs round by round into the SAME launches instead was slower, 933/s: one tile
     // configuration per launch makes the thin GEMMs of one program stragglers of the other's fat ones.)
     static const bool pipelined = [] { const char* e = getenv("FBHIP_UPDATE_PIPELINE"); return !(e && e[0] == '0'); }();

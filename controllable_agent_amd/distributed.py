@@ -116,7 +116,8 @@ def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable
     online ForwardMap pass (``SAMPLE | FB_FWD_ONLINE``: they depend on step t only through its FB optimiser step) are
     launched on the OTHER workspace set while step t's actor-gradient all-reduce is in flight, so that all-reduce is hidden
     behind useful work instead of idling the GPU (the FB all-reduce still gates the FB step).  Same kernels, operands and
-    order inside each step as ``n_steps`` calls of ``dp_update``: bit-identical results.
+    order inside each step as ``n_steps`` calls of ``dp_update`` (bit-identical at small dims; at walker dims regrouped
+    launches change a few split-K factors, i.e. fp32 summation order); replicas stay bit-identical to each other.
 
         head(0);  for t:  FB_FWD_TARGET|FB_BWD_A|ACTOR_FWD -> all_reduce(fb heads, async) || FB_BWD_B|ACTOR_FWD -> wait
                           -> all_reduce(fb rest) -> FB_STEP|ACTOR_GRAD

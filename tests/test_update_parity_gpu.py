@@ -507,6 +507,33 @@ def test_pipelined_steps_equal_single_updates_for_every_variant(flags, goal_spac
         assert m1[k] == m2[k], k
 
 
+def test_pipelined_steps_at_walker_dims_match_single_updates_to_rounding():
+    """At full dims the pipelined graph regroups launches (the target chain no longer shares its launches with the online
+    chain), so a few small-output GEMMs get a different K-slicing: same math, different fp32 summation order.  Two
+    device-drawn steps: metrics within 1e-4, 99.9 % of every parameter tensor within 2e-6 (2 % of lr) and none further than
+    the two Adam steps allow.  (The step is that sensitive by construction: torch.min(Q1, Q2) routes a row's whole actor
+    gradient to one head, so ANY change of summation order moves gradients by ~1/B -- two single-update runs that differ only
+    in the split-K policy already differ by 2e-3 rel-L2 in the actor gradients of step 1, tools/chaos_probe.py.)
+    With FBHIP_UPDATE_PIPELINE=0 update_many is bit-identical to single updates at every size (tools/determinism_probe.py)."""
+    cfg = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50, batch_size=1024)
+    rng = np.random.default_rng(5)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 20, 100, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a1, a2 = (H.make_hip_agent(cfg, nets) for _ in range(2))
+    for s in range(2):
+        m1 = a1.update(rb, s)
+    m2 = a2.update_many(rb, 0, 2)
+    for k in H.LOSS_KEYS:
+        assert m2[k] == pytest.approx(m1[k], rel=1e-4, abs=1e-5), k
+    s1, s2 = H.get_agent_state(a1), H.get_agent_state(a2)
+    for k in s1:
+        if not k.startswith("adam_"):
+            diff = np.abs(s1[k].astype(np.float64) - s2[k].astype(np.float64))
+            assert diff.max() <= 2 * 2 * cfg.lr + 1e-7, k
+            assert (diff > 2e-6).sum() <= max(1, diff.size // 1000), k
+
+
 def test_rand_weight_device_draws():
     """cfg.rand_weight without injected draws: every row of the mixing matrix is u_i * (nonnegative unit vector)
     (fb_ddpg.py:477-480) and the mixed rows of z are sqrt(d) normalize(W @ B(backward_input[perm]))."""

@@ -29,3 +29,6 @@ bad = [k for net in ("actor", "forward_net", "backward_net", "forward_target_net
 print(f"{n} updates in {dt:.1f} s ({n / dt:.0f}/s); step counts {agent.step_counts()}; non-finite tensors: {bad}; "
       f"fb_loss {m['fb_loss']:.3f} actor_loss {m['actor_loss']:.3f} B_norm {m['B_norm']:.4f} orth_linf {m['orth_linf']:.4f}")
 assert not bad and agent.step_counts() == (n + 1, n + 1) and np.isfinite(m["fb_loss"])
+# run-to-run determinism of the whole trajectory (graph replays, two-branch pipelining, fixed-order reductions): a checksum
+ck = float(sum(v.double().sum() for net in ("actor", "forward_net", "backward_net") for v in getattr(agent, net).state_dict().values()))
+print(f"checksum {ck!r}")
