@@ -195,9 +195,14 @@ int fbhip_get_step_counts(fbhip_ctx* ctx, int32_t* host_fb_steps, int32_t* host_
 int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* inject,
                  int32_t phase_mask, int32_t use_graph, void* stream);
 /* n_steps consecutive complete updates (all phases, device-drawn batches) as ONE hipGraph launch: what the offline loop
- * (train_offline.py:101-134) does between two log lines.  Identical kernels in identical order to n_steps fbhip_update
- * calls -- the Adam / RNG counters advance on the device -- minus n_steps - 1 graph-launch gaps.  Single-rank only (there
- * is no place for the gradient all-reduce inside the graph); ``hp`` is constant over the n_steps (1 <= n_steps <= 64). */
+ * (train_offline.py:101-134) does between two log lines.  The same kernels on the same operands as n_steps fbhip_update
+ * calls -- the Adam / RNG counters advance on the device -- minus n_steps - 1 graph-launch gaps, with consecutive steps
+ * pipelined: step t+1's SAMPLE | FB_FWD_ONLINE is captured as a second branch beside step t's actor phase, on the other
+ * workspace set (so step t+1's batch is drawn before step t's actor step has finished -- from the same replay contents).
+ * Results equal n_steps single updates bit for bit while no GEMM's K-slicing changes (small dims), to fp32 summation order
+ * otherwise; FBHIP_UPDATE_PIPELINE=0 in the environment disables the pipelining.  Single-rank only (there is no place for
+ * the gradient all-reduce inside the graph); ``hp`` is constant over the n_steps (1 <= n_steps <= 64).
+ * After the call fbhip_workspace_view refers to set 0, which holds the last or the second-to-last step's intermediates. */
 int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
 /* The workspace holds two complete per-step sets (fbhip_update_many alternates them).  A host that pipelines steps itself
  * (data parallel: the next step's SAMPLE | FB_FWD_ONLINE under this step's actor all-reduce) selects the set the following
