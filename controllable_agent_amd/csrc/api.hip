@@ -607,7 +607,7 @@ int run_program(fbhip_ctx* c, Program& p, hipStream_t s) {
 // ---- network passes as chains ---------------------------------------------------------------------------------
 // ForwardMap.forward (fb_modules.py:186-199); Xa = [obs|action] panel, Xz = [obs|z] panel
 void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
-                           int rows, Chain& out) {
+                           int rows, Chain& out, bool with_heads = true) {
     const fbhip_dims& d = c->d;
     const Geom gm = geom_of(d);
     const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
@@ -633,6 +633,7 @@ void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda
         const float* x = gm.trunk ? Sp->tr.p : Sp->h.p;
         o.gemms.push_back(P(x, feat, 1, W.W3s, feat, 1, Sp->p.p, 2 * H, rows, 2 * H, feat, W.b3s, EPI_BIAS_RELU));
     });
+    if (!with_heads) return;                     // the actor phase gets Q from p directly (actor_q_kernel)
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS));
         o.gemms.push_back(P(Sp->p.p + H, 2 * H, 1, W.W4[1], H, 1, Sp->F2.p, Lz, rows, z, H, W.b4[1], EPI_BIAS));
@@ -1059,18 +1060,28 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
             ch.push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
         }
-        forward_map_fwd_chain(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch);
+        // ForwardMap up to the heads' hidden activations p; the heads' outputs F1, F2 are never formed: with V = z . W4
+        // (no dependence on this pass, so it joins the chain's first round) Q_i = p_i . V_i + b4_i . z and the heads'
+        // data gradient is -(w_i / B) V_i * relu'(p_i) -- one row kernel instead of GEMM + reduce + loss + GEMM
+        forward_map_fwd_chain(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch, /*with_heads=*/false);
+        {
+            Stage first = ch.front();
+            ch.front() = [=, &w](Ops& o2) {
+                first(o2);
+                o2.gemms.push_back(P(w.z.p, Lz, 1, c->F_p.W4[0], H, 0, w.dp.p, 2 * H, B, H, z));
+                o2.gemms.push_back(P(w.z.p, Lz, 1, c->F_p.W4[1], H, 0, w.dp.p + H, 2 * H, B, H, z));
+            };
+        }
+        // (data-gradient only along the action path of forward_net: the reference also computes and discards every weight
+        // gradient of forward_net here)
         ch.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_actor_loss(w.fsO.F1.p, w.fsO.F2.p, Lz, w.z.p, Lz, w.as.mu.p, La, w.Xopi.p + aoff, w.Xopi.ld,
-                                           hp.stddev, w.dF1.p, w.dF2.p, hp.want_metrics ? w.metrics : nullptr, w.pw_scratch,
-                                           B, z, a, q, c->sq, w.as.premu.p, Lh, w.so.eps_actor, a));
+                HIPCK(c, launch_actor_q(w.fsO.p.p, 2 * H, w.dp.p, 2 * H, w.z.p, Lz, c->F_p.b4[0], c->F_p.b4[1], w.as.mu.p, La,
+                                        w.Xopi.p + aoff, w.Xopi.ld, hp.stddev, hp.want_metrics ? w.metrics : nullptr,
+                                        w.pw_scratch, B, H, z, a, c->sq, w.as.premu.p, Lh, w.so.eps_actor, a, q));
                 return (int)FBHIP_OK;
             });
         });
-        // data-gradient only, along the action path of forward_net (the reference also computes and discards every
-        // weight gradient of forward_net here)
-        ch.push_back([=, &w](Ops& o2) { heads_dgrad_ops(c, w, c->F_p, w.fsO, B, o2); });
         // (only the branch that sees the action matters: the first Fo columns of h)
         if (gm.trunk) {
             ch.push_back([=, &w](Ops& o2) {          // d relu(trunk(h)) ...

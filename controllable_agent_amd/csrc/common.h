@@ -97,6 +97,13 @@ hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const fl
                              int rows, int d, int a, hipStream_t s, Squash sq = Squash{0, 1.f, -5.f, 2.f},
                              const float* pre = nullptr, int ldp = 0, const float* noise = nullptr, int ldn = 0);
 
+// the update's actor phase: Q and d p straight from the heads' hidden activations p [rows, 2H] and V = z . W4 [rows, 2H]
+// (overwritten with d p); see actor_q_kernel
+hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const float* z, int ldz, const float* b41,
+                          const float* b42, const float* mu, int ldmu, const float* action, int lda, float stddev,
+                          float* metrics, float* scratch /* >= 3*ceil(rows/4) floats */, int rows, int H, int d, int a,
+                          Squash sq, const float* pre, int ldp, const float* noise, int ldn, hipStream_t s);
+
 // ---- pairwise FB loss ----------------------------------------------------------------------------------
 size_t pairwise_scratch_floats(int B, int d);
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1,

@@ -572,6 +572,76 @@ __global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict
     }
 }
 
+// The same loss WITHOUT materialising F1, F2 (the update's actor phase).  With V_i = z . W4_i  ([B,d] x [d,H], a GEMM that
+// needs neither the ForwardMap pass nor the action, so it rides in the phase's first round):
+//   Q_i[s] = F_i[s] . z[s] = (p_i[s] W4_i^T + b4_i) . z[s] = p_i[s] . V_i[s] + b4_i . z[s]
+//   d p_i[s] = (dF_i[s] W4_i) * relu'(p_i) = -(w_i[s] / B) V_i[s] * (p_i[s] > 0)          (dF_i = -z w_i / B)
+// i.e. the heads' output GEMM + its split-K reduce, the loss kernel and the heads' data-gradient GEMM collapse into this
+// one row kernel: one wavefront per row reads p [B, 2H] and V [B, 2H] and overwrites V with d p.
+__global__ void __launch_bounds__(256) actor_q_kernel(const float* __restrict__ P, int ldp_, float* __restrict__ V, int ldv,
+                                                      const float* __restrict__ z, int ldz,
+                                                      const float* __restrict__ b41, const float* __restrict__ b42,
+                                                      const float* __restrict__ mu, int ldmu, const float* __restrict__ act,
+                                                      int lda, float stddev, float* __restrict__ part, int rows, int H, int d,
+                                                      int a, const Squash sq, const float* __restrict__ pre, int ldp,
+                                                      const float* __restrict__ noise, int ldn) {
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    const float inv_b = 1.0f / (float)rows;
+    float qmin = 0.f, lp = 0.f, q1win = 0.f;
+    if (row < rows) {
+        const float4* p1 = reinterpret_cast<const float4*>(P + (size_t)row * ldp_);
+        const float4* p2 = reinterpret_cast<const float4*>(P + (size_t)row * ldp_ + H);
+        float4* v1 = reinterpret_cast<float4*>(V + (size_t)row * ldv);
+        float4* v2 = reinterpret_cast<float4*>(V + (size_t)row * ldv + H);
+        float q1 = 0.f, q2 = 0.f;
+        for (int k = lane; k < H / 4; k += 64) {
+            const float4 a1 = p1[k], c1 = v1[k], a2 = p2[k], c2 = v2[k];
+            q1 += a1.x * c1.x + a1.y * c1.y + a1.z * c1.z + a1.w * c1.w;
+            q2 += a2.x * c2.x + a2.y * c2.y + a2.z * c2.z + a2.w * c2.w;
+        }
+        for (int j = lane; j < d; j += 64) {
+            const float zz = z[(size_t)row * ldz + j];
+            q1 += b41[j] * zz;
+            q2 += b42[j] * zz;
+        }
+        q1 = wave_sum(q1);
+        q2 = wave_sum(q2);
+        // torch.min(Q1, Q2) backward: all of the gradient to the strict arg-min, split evenly on exact ties
+        const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f), w2 = 1.f - w1;
+        const float s1 = -inv_b * w1, s2 = -inv_b * w2;
+        for (int k = lane; k < H / 4; k += 64) {
+            const float4 a1 = p1[k], a2 = p2[k];
+            float4 c1 = v1[k], c2 = v2[k];
+            c1.x = a1.x > 0.f ? s1 * c1.x : 0.f; c1.y = a1.y > 0.f ? s1 * c1.y : 0.f;
+            c1.z = a1.z > 0.f ? s1 * c1.z : 0.f; c1.w = a1.w > 0.f ? s1 * c1.w : 0.f;
+            c2.x = a2.x > 0.f ? s2 * c2.x : 0.f; c2.y = a2.y > 0.f ? s2 * c2.y : 0.f;
+            c2.z = a2.z > 0.f ? s2 * c2.z : 0.f; c2.w = a2.w > 0.f ? s2 * c2.w : 0.f;
+            v1[k] = c1; v2[k] = c2;
+        }
+        if (lane < a && sq.on) {                   // SquashedNormal.log_prob(action) with the cached pre-image (utils.py:212-215)
+            const float loc = pre[(size_t)row * ldp + lane], e = noise[(size_t)row * ldn + lane];
+            const float log_std = sq.lo + 0.5f * (sq.hi - sq.lo) * (tanhf(pre[(size_t)row * ldp + a + lane]) + 1.f);
+            const float u = loc + expf(log_std) * e;
+            lp = -0.5f * e * e - log_std - 0.91893853320467274178f - 2.f * (0.69314718055994530942f - u - softplus20(-2.f * u));
+        } else if (lane < a) {
+            const float df = act[(size_t)row * lda + lane] - mu[(size_t)row * ldmu + lane];
+            lp = -(df * df) / (2.f * stddev * stddev) - logf(stddev) - 0.91893853320467274178f;
+        }
+        lp = wave_sum(lp);
+        qmin = fminf(q1, q2);
+        q1win = q1 > q2 ? 1.f : 0.f;
+    }
+    if (lane == 0) { red[wid][0] = qmin; red[wid][1] = lp; red[wid][2] = q1win; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[3 * blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        part[3 * blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        part[3 * blockIdx.x + 2] = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+    }
+}
+
 __global__ void __launch_bounds__(64) actor_loss_finalize_kernel(const float* __restrict__ part, int nblk, int rows,
                                                                  float* __restrict__ metrics, int m_loss, int m_q,
                                                                  int m_lp, float temp /* 0: loss = -mean Q */) {
@@ -596,6 +666,22 @@ hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const fl
     const int nblk = (rows + 3) / 4;
     hipLaunchKernelGGL(actor_loss_kernel, dim3(nblk), dim3(256), 0, s, F1, F2, ldf, z, ldz, mu, ldmu, action, lda,
                        stddev, dF1, dF2, scratch, rows, d, a, sq, pre, ldp, noise, ldn);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
+    hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17,
+                       sq.on ? sq.temp : 0.f);
+    return hipGetLastError();
+}
+
+hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const float* z, int ldz, const float* b41,
+                          const float* b42, const float* mu, int ldmu, const float* action, int lda, float stddev,
+                          float* metrics, float* scratch, int rows, int H, int d, int a, Squash sq, const float* pre, int ldp,
+                          const float* noise, int ldn, hipStream_t s) {
+    if ((H & 3) || (ldp_ & 3) || (ldv & 3) || a > 64 || scratch == nullptr) return hipErrorInvalidValue;
+    if (sq.on && (pre == nullptr || noise == nullptr)) return hipErrorInvalidValue;
+    const int nblk = (rows + 3) / 4;
+    hipLaunchKernelGGL(actor_q_kernel, dim3(nblk), dim3(256), 0, s, P, ldp_, V, ldv, z, ldz, b41, b42, mu, ldmu, action, lda,
+                       stddev, scratch, rows, H, d, a, sq, pre, ldp, noise, ldn);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
     hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17,
