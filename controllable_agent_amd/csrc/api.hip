@@ -816,8 +816,10 @@ int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float
     return run_chain(c, ch, s);
 }
 
+// head_dgrad_done: a_dp (the policy hidden layer's gradient) was already produced by actor_head_bwd_kernel; the head's
+// weight gradient then joins the next round instead of having a launch of its own
 void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz,
-                     ASet& S, int rows, Chain& out) {
+                     ASet& S, int rows, Chain& out, bool head_dgrad_done = false) {
     const fbhip_dims& d = c->d;
     const int H = d.hidden_dim, a = head_width(d), La = pad4(a);
     Ws* w = &c->W();
@@ -825,17 +827,20 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
     const Geom gm = actor_geom_of(d);
     const int Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
     const bool trunk = gm.trunk;
-    out.push_back([=](Ops& o) {                              // head; boltzmann: straight into d h (there is no policy hidden layer)
-        const float* x = gm.boltz ? Sp->h.p : Sp->p.p;
-        o.gemms.push_back(P(w->a_dpremu.p, La, 0, x, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
-        o.gemms.push_back(P(w->a_dpremu.p, La, 1, W.W4, H, 0, gm.boltz ? w->dh.p : w->a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, x, H));
-    });
+    if (!head_dgrad_done)
+        out.push_back([=](Ops& o) {                          // head; boltzmann: straight into d h (there is no policy hidden layer)
+            const float* x = gm.boltz ? Sp->h.p : Sp->p.p;
+            o.gemms.push_back(P(w->a_dpremu.p, La, 0, x, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
+            o.gemms.push_back(P(w->a_dpremu.p, La, 1, W.W4, H, 0, gm.boltz ? w->dh.p : w->a_dp.p, H, rows, H, a, nullptr, EPI_MASK_RELU, x, H));
+        });
     const float* X1 = gm.single ? Xz : Xo;                   // preprocess == 0: the one branch reads [obs|z]
     const int ld1 = gm.single ? ldz : ldo;
     if (!gm.boltz)
         out.push_back([=](Ops& o) {
             const float* x = trunk ? Sp->tr.p : Sp->h.p;
             float* dx = trunk ? w->dtr.p : w->dh.p;
+            if (head_dgrad_done)
+                o.gemms.push_back(P(w->a_dpremu.p, La, 0, Sp->p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
             o.gemms.push_back(P(w->a_dp.p, H, 0, x, feat, 0, G.W3, feat, H, feat, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
             o.gemms.push_back(P(w->a_dp.p, H, 1, W.W3, feat, 0, dx, feat, rows, feat, H, nullptr, EPI_MASK_RELU, x, feat));
         });
@@ -1101,6 +1106,8 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                                           nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0, H});
         });
         // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
+        static const bool fuse_env = [] { const char* e = getenv("FBHIP_FUSED_ACTOR_HEAD"); return !(e && e[0] == '0'); }();
+        const bool fused_head = fuse_env && !d.boltzmann && actor_head_bwd_ok(H, a);
         if (d.boltzmann)                         // ... or through the SquashedNormal's rsample and log_prob (fb_ddpg.py:393-406)
             ch.push_back([=, &w](Ops& o2) {
                 o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, 0, w.a_dact.p, La, B, a, H));
@@ -1110,12 +1117,20 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                     return (int)FBHIP_OK;
                 });
             });
+        else if (fused_head)
+            ch.push_back([=, &w](Ops& o2) {      // d action -> d premu -> d p in one row kernel (actor_head_bwd_kernel)
+                o2.post.push_back([=, &w](hipStream_t q) -> int {
+                    HIPCK(c, launch_actor_head_bwd(w.dt1a.p, H, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, w.as.mu.p, La, c->A_p.W4, H,
+                                                   w.as.p.p, H, w.a_dpremu.p, La, w.a_dp.p, H, B, H, a, q));
+                    return (int)FBHIP_OK;
+                });
+            });
         else
             ch.push_back([=, &w](Ops& o2) {
                 o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, 0, w.a_dpremu.p, La, B, a, H, nullptr,
                                      EPI_TANH_BWD, w.as.mu.p, La));
             });
-        actor_bwd_chain(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
+        actor_bwd_chain(c, c->A_p, c->A_g, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch, fused_head);
         prog_chain(prog, ch);
     }
 
@@ -1260,6 +1275,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
     HIPCK(c, gemm_init());
     HIPCK(c, inverse_prepare());
+    HIPCK(c, actor_head_bwd_prepare(c->d.hidden_dim, c->d.action_dim));
     c->bound = true;
     return FBHIP_OK;
 }

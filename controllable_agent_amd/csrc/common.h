@@ -104,6 +104,13 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
                           float* metrics, float* scratch /* >= 3*ceil(rows/4) floats */, int rows, int H, int d, int a,
                           Squash sq, const float* pre, int ldp, const float* noise, int ldn, hipStream_t s);
 
+// d action -> d premu -> d p of the actor's policy hidden layer in one row kernel (actor_head_bwd_kernel; a <= 16)
+bool actor_head_bwd_ok(int H, int a);
+hipError_t actor_head_bwd_prepare(int H, int a);   // raises the kernel's dynamic-LDS limit (not inside a stream capture)
+hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, int ldw1, const float* mu, int ldmu,
+                                 const float* W4, int ldw4, const float* P, int ldp_, float* dpremu, int ldd, float* dp,
+                                 int lddp, int rows, int H, int a, hipStream_t s);
+
 // ---- pairwise FB loss ----------------------------------------------------------------------------------
 size_t pairwise_scratch_floats(int B, int d);
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1,

@@ -689,6 +689,85 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The seam between forward_net's data gradient and the actor's backward pass in update_actor, default (TruncatedNormal) actor:
+//   d action = dt1 . W1[:, action columns]      [B,H] x [H,a]     (the last step of forward_net's dgrad, fb_modules.py:190)
+//   d premu  = d action * (1 - mu^2)            straight-through clamp + tanh (utils.py:171-174)
+//   d p      = (d premu . W4) * relu'(p)        [B,a] x [a,H]     (the first step of the actor's dgrad, fb_modules.py:119)
+// Two GEMMs with an a-wide (6) output / contraction, each with a split-K reduce launch, are one wavefront per row here; the
+// two [H, a] / [a, H] weight slices (24 KB each at walker dims) sit in LDS.  a <= 16.
+constexpr int AHB_MAXA = 16;
+__global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __restrict__ dt1, int ldt,
+                                                             const float* __restrict__ W1a, int ldw1,
+                                                             const float* __restrict__ mu, int ldmu,
+                                                             const float* __restrict__ W4, int ldw4,
+                                                             const float* __restrict__ P, int ldp_,
+                                                             float* __restrict__ dpremu, int ldd,
+                                                             float* __restrict__ dp, int lddp, int rows, int H, int a) {
+    extern __shared__ float ahb_lds[];             // [a][H] (W1 action columns, transposed) then [a][H] (W4)
+    float* sW1 = ahb_lds;
+    float* sW4 = ahb_lds + (size_t)a * H;
+    for (int e = threadIdx.x; e < a * H; e += 256) {
+        const int m = e / a, jj = e % a;           // consecutive threads read the a consecutive floats of row m
+        sW1[(size_t)jj * H + m] = W1a[(size_t)m * ldw1 + jj];
+    }
+    for (int e = threadIdx.x; e < a * H; e += 256) sW4[e] = W4[(size_t)(e / H) * ldw4 + (e % H)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    float acc[AHB_MAXA];
+#pragma unroll
+    for (int jj = 0; jj < AHB_MAXA; ++jj) acc[jj] = 0.f;
+    for (int m = lane; m < H; m += 64) {
+        const float g = dt1[(size_t)row * ldt + m];
+#pragma unroll
+        for (int jj = 0; jj < AHB_MAXA; ++jj)
+            if (jj < a) acc[jj] += g * sW1[(size_t)jj * H + m];
+    }
+#pragma unroll
+    for (int jj = 0; jj < AHB_MAXA; ++jj) {
+        if (jj < a) {
+            const float m_ = mu[(size_t)row * ldmu + jj];
+            acc[jj] = wave_sum(acc[jj]) * (1.f - m_ * m_);
+        }
+    }
+    if (lane < a) {
+        float v = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < AHB_MAXA; ++jj) v = (jj == lane) ? acc[jj] : v;
+        dpremu[(size_t)row * ldd + lane] = v;
+    }
+    for (int k = lane; k < H; k += 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < AHB_MAXA; ++jj)
+            if (jj < a) v += acc[jj] * sW4[(size_t)jj * H + k];
+        dp[(size_t)row * lddp + k] = P[(size_t)row * ldp_ + k] > 0.f ? v : 0.f;
+    }
+}
+
+// Measured: with the two slices in <= 48 KB of LDS (walker: a = 6, H = 1024) the fused kernel wins 0.75 % of the update; at
+// quadruped dims (a = 12, B = 2048: 96 KB per workgroup, one workgroup per CU, 512 fills) it LOSES 3 % to the two GEMMs.
+bool actor_head_bwd_ok(int H, int a) { return a <= AHB_MAXA && (size_t)2 * a * H * sizeof(float) <= 48 * 1024; }
+
+hipError_t actor_head_bwd_prepare(int H, int a) {
+    if (!actor_head_bwd_ok(H, a)) return hipSuccess;
+    const size_t bytes = (size_t)2 * a * H * sizeof(float);
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, int ldw1, const float* mu, int ldmu,
+                                 const float* W4, int ldw4, const float* P, int ldp_, float* dpremu, int ldd, float* dp,
+                                 int lddp, int rows, int H, int a, hipStream_t s) {
+    if (!actor_head_bwd_ok(H, a)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(actor_head_bwd_kernel, dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s, dt1, ldt,
+                       W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a);
+    return hipGetLastError();
+}
+
 // dst[r] = [A[r, :na] | B[r, :nb]]  -- builds an [obs|z] / [obs|action] panel for the inference entry points
 __global__ void __launch_bounds__(256) concat2_kernel(float* __restrict__ dst, int ld, const float* __restrict__ A,
                                                       int lda, int na, const float* __restrict__ Bsrc, int ldb, int nb,
