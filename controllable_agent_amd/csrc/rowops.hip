@@ -697,6 +697,9 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
 // Two GEMMs with an a-wide (6) output / contraction, each with a split-K reduce launch, are one wavefront per row here; the
 // two [H, a] / [a, H] weight slices (24 KB each at walker dims) sit in LDS.  a <= 16.
 constexpr int AHB_MAXA = 16;
+// AHB_N: compile-time bound of a (8 / 16): the accumulator loops are fully unrolled and predicated on jj < a, so a 6-wide
+// head must not pay for 16 lanes of them
+template <int AHB_N>
 __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __restrict__ dt1, int ldt,
                                                              const float* __restrict__ W1a, int ldw1,
                                                              const float* __restrict__ mu, int ldmu,
@@ -716,17 +719,17 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
     if (row >= rows) return;
-    float acc[AHB_MAXA];
+    float acc[AHB_N];
 #pragma unroll
-    for (int jj = 0; jj < AHB_MAXA; ++jj) acc[jj] = 0.f;
+    for (int jj = 0; jj < AHB_N; ++jj) acc[jj] = 0.f;
     for (int m = lane; m < H; m += 64) {
         const float g = dt1[(size_t)row * ldt + m];
 #pragma unroll
-        for (int jj = 0; jj < AHB_MAXA; ++jj)
+        for (int jj = 0; jj < AHB_N; ++jj)
             if (jj < a) acc[jj] += g * sW1[(size_t)jj * H + m];
     }
 #pragma unroll
-    for (int jj = 0; jj < AHB_MAXA; ++jj) {
+    for (int jj = 0; jj < AHB_N; ++jj) {
         if (jj < a) {
             const float m_ = mu[(size_t)row * ldmu + jj];
             acc[jj] = wave_sum(acc[jj]) * (1.f - m_ * m_);
@@ -735,13 +738,13 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     if (lane < a) {
         float v = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < AHB_MAXA; ++jj) v = (jj == lane) ? acc[jj] : v;
+        for (int jj = 0; jj < AHB_N; ++jj) v = (jj == lane) ? acc[jj] : v;
         dpremu[(size_t)row * ldd + lane] = v;
     }
     for (int k = lane; k < H; k += 64) {
         float v = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < AHB_MAXA; ++jj)
+        for (int jj = 0; jj < AHB_N; ++jj)
             if (jj < a) v += acc[jj] * sW4[(size_t)jj * H + k];
         dp[(size_t)row * lddp + k] = P[(size_t)row * ldp_ + k] > 0.f ? v : 0.f;
     }
@@ -755,7 +758,10 @@ hipError_t actor_head_bwd_prepare(int H, int a) {
     if (!actor_head_bwd_ok(H, a)) return hipSuccess;
     const size_t bytes = (size_t)2 * a * H * sizeof(float);
     if (bytes <= 48 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel<8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)bytes);
 }
 
@@ -763,8 +769,12 @@ hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, in
                                  const float* W4, int ldw4, const float* P, int ldp_, float* dpremu, int ldd, float* dp,
                                  int lddp, int rows, int H, int a, hipStream_t s) {
     if (!actor_head_bwd_ok(H, a)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(actor_head_bwd_kernel, dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s, dt1, ldt,
-                       W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a);
+    if (a <= 8)
+        hipLaunchKernelGGL(actor_head_bwd_kernel<8>, dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s, dt1,
+                           ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a);
+    else
+        hipLaunchKernelGGL(actor_head_bwd_kernel<16>, dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s, dt1,
+                           ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a);
     return hipGetLastError();
 }
 
