@@ -817,7 +817,7 @@ int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float
 }
 
 // head_dgrad_done: a_dp (the policy hidden layer's gradient) was already produced by actor_head_bwd_kernel; the head's
-// weight gradient then joins the next round instead of having a launch of its own
+// weight gradient then joins the LAST round (the other thin-and-deep weight gradients) instead of having a launch of its own
 void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo, int ldo, const float* Xz, int ldz,
                      ASet& S, int rows, Chain& out, bool head_dgrad_done = false) {
     const fbhip_dims& d = c->d;
@@ -839,8 +839,6 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
         out.push_back([=](Ops& o) {
             const float* x = trunk ? Sp->tr.p : Sp->h.p;
             float* dx = trunk ? w->dtr.p : w->dh.p;
-            if (head_dgrad_done)
-                o.gemms.push_back(P(w->a_dpremu.p, La, 0, Sp->p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
             o.gemms.push_back(P(w->a_dp.p, H, 0, x, feat, 0, G.W3, feat, H, feat, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
             o.gemms.push_back(P(w->a_dp.p, H, 1, W.W3, feat, 0, dx, feat, rows, feat, H, nullptr, EPI_MASK_RELU, x, feat));
         });
@@ -866,6 +864,9 @@ void actor_bwd_chain(fbhip_ctx* c, const ActP& W, const ActP& G, const float* Xo
                                          G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
+        // (the head's weight gradient, thin and deep like the first-layer ones, when actor_head_bwd_kernel made its launch redundant)
+        if (head_dgrad_done)
+            o.gemms.push_back(P(w->a_dpremu.p, La, 0, Sp->p.p, H, 0, G.W4, H, a, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4));
         o.gemms.push_back(P(w->dt1a.p, H, 0, X1, ld1, 0, G.o.W1, G.o.ld1, H, G.o.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.o.b1));
         if (!gm.single)
             o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));

@@ -699,7 +699,9 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
 constexpr int AHB_MAXA = 16;
 // AHB_N: compile-time bound of a (8 / 16): the accumulator loops are fully unrolled and predicated on jj < a, so a 6-wide
 // head must not pay for 16 lanes of them
-template <int AHB_N>
+// AHB_N == a exactly when EXACT (instantiated for 1..8, 12, 16): every per-output loop is straight-line code without
+// predicates; other widths up to 16 take <16, false>, whose loops are predicated on jj < a
+template <int AHB_N, bool EXACT>
 __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __restrict__ dt1, int ldt,
                                                              const float* __restrict__ W1a, int ldw1,
                                                              const float* __restrict__ mu, int ldmu,
@@ -710,28 +712,57 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     extern __shared__ float ahb_lds[];             // [a][H] (W1 action columns, transposed) then [a][H] (W4)
     float* sW1 = ahb_lds;
     float* sW4 = ahb_lds + (size_t)a * H;
-    for (int e = threadIdx.x; e < a * H; e += 256) {
-        const int m = e / a, jj = e % a;           // consecutive threads read the a consecutive floats of row m
-        sW1[(size_t)jj * H + m] = W1a[(size_t)m * ldw1 + jj];
+    // Every global load below is UNCONDITIONAL (clamped index, mask at the use): hipcc otherwise waits for each load right
+    // where a select meets it, and a 24-load fill becomes 24 round trips (measured: 27 us for this kernel).
+    for (int m = threadIdx.x; m < H; m += 256) {
+        float v[AHB_N];
+#pragma unroll
+        for (int jj = 0; jj < AHB_N; ++jj) v[jj] = W1a[(size_t)m * ldw1 + min(jj, a - 1)];
+#pragma unroll
+        for (int jj = 0; jj < AHB_N; ++jj)
+            if (EXACT || jj < a) sW1[(size_t)jj * H + m] = v[jj];
     }
-    for (int e = threadIdx.x; e < a * H; e += 256) sW4[e] = W4[(size_t)(e / H) * ldw4 + (e % H)];
+    {
+        float4 v[AHB_N];
+        const int k4 = min((int)threadIdx.x, H / 4 - 1);           // H / 4 <= 256 is not required: loop below covers the rest
+#pragma unroll
+        for (int jj = 0; jj < AHB_N; ++jj) v[jj] = reinterpret_cast<const float4*>(W4 + (size_t)min(jj, a - 1) * ldw4)[k4];
+        if ((int)threadIdx.x < H / 4) {
+#pragma unroll
+            for (int jj = 0; jj < AHB_N; ++jj)
+                if (EXACT || jj < a) reinterpret_cast<float4*>(sW4 + (size_t)jj * H)[k4] = v[jj];
+        }
+        for (int kk = threadIdx.x + 256; kk < H / 4; kk += 256)
+#pragma unroll
+            for (int jj = 0; jj < AHB_N; ++jj)
+                if (EXACT || jj < a) reinterpret_cast<float4*>(sW4 + (size_t)jj * H)[kk] = reinterpret_cast<const float4*>(W4 + (size_t)jj * ldw4)[kk];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wid;
-    if (row >= rows) return;
+    const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (no early exit: same stores)
+    constexpr int U = 4;                                            // elements per lane per batch of loads
     float acc[AHB_N];
 #pragma unroll
     for (int jj = 0; jj < AHB_N; ++jj) acc[jj] = 0.f;
-    for (int m = lane; m < H; m += 64) {
-        const float g = dt1[(size_t)row * ldt + m];
+    for (int m0 = lane; m0 < H; m0 += 64 * U) {
+        float g[U];
 #pragma unroll
-        for (int jj = 0; jj < AHB_N; ++jj)
-            if (jj < a) acc[jj] += g * sW1[(size_t)jj * H + m];
+        for (int u = 0; u < U; ++u) g[u] = dt1[(size_t)row * ldt + min(m0 + 64 * u, H - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + 64 * u;
+            const float gv = m < H ? g[u] : 0.f;
+            const int mc = min(m, H - 1);
+#pragma unroll
+            for (int jj = 0; jj < AHB_N; ++jj)
+                if (EXACT || jj < a) acc[jj] += gv * sW1[(size_t)jj * H + mc];
+        }
     }
+    const float mu_l = mu[(size_t)row * ldmu + min(lane, a - 1)];
 #pragma unroll
     for (int jj = 0; jj < AHB_N; ++jj) {
-        if (jj < a) {
-            const float m_ = mu[(size_t)row * ldmu + jj];
+        if (EXACT || jj < a) {
+            const float m_ = __shfl(mu_l, jj);
             acc[jj] = wave_sum(acc[jj]) * (1.f - m_ * m_);
         }
     }
@@ -741,40 +772,74 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
         for (int jj = 0; jj < AHB_N; ++jj) v = (jj == lane) ? acc[jj] : v;
         dpremu[(size_t)row * ldd + lane] = v;
     }
-    for (int k = lane; k < H; k += 64) {
-        float v = 0.f;
+    for (int k0 = lane; k0 < H; k0 += 64 * U) {
+        float pv[U];
 #pragma unroll
-        for (int jj = 0; jj < AHB_N; ++jj)
-            if (jj < a) v += acc[jj] * sW4[(size_t)jj * H + k];
-        dp[(size_t)row * lddp + k] = P[(size_t)row * ldp_ + k] > 0.f ? v : 0.f;
+        for (int u = 0; u < U; ++u) pv[u] = P[(size_t)row * ldp_ + min(k0 + 64 * u, H - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u;
+            const int kc = min(k, H - 1);
+            float v = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < AHB_N; ++jj)
+                if (EXACT || jj < a) v += acc[jj] * sW4[(size_t)jj * H + kc];
+            if (k < H) dp[(size_t)row * lddp + k] = pv[u] > 0.f ? v : 0.f;
+        }
     }
 }
 
-// Measured: with the two slices in <= 48 KB of LDS (walker: a = 6, H = 1024) the fused kernel wins 0.75 % of the update; at
-// quadruped dims (a = 12, B = 2048: 96 KB per workgroup, one workgroup per CU, 512 fills) it LOSES 3 % to the two GEMMs.
-bool actor_head_bwd_ok(int H, int a) { return a <= AHB_MAXA && (size_t)2 * a * H * sizeof(float) <= 48 * 1024; }
+bool actor_head_bwd_ok(int H, int a);
+// Measured (same-box A/B): walker (a = 6, H = 1024, 48 KB of LDS) +2.5 % of the update over the two GEMMs + two reduces;
+// quadruped (a = 12, B = 2048, 96 KB: one workgroup per CU) +0.2 %.  An earlier version with runtime-width predicated loops
+// and select-guarded loads took 27 us instead of 12 and LOST at quadruped dims -- hence the exact-width instantiations.
+bool actor_head_bwd_ok(int H, int a) {
+    static const long cap = [] { const char* e = getenv("FBHIP_AHB_LDS_KB"); return (e ? atol(e) : 128L) * 1024; }();
+    return a <= AHB_MAXA && (long)(2 * a * H * sizeof(float)) <= cap;
+}
 
 hipError_t actor_head_bwd_prepare(int H, int a) {
     if (!actor_head_bwd_ok(H, a)) return hipSuccess;
     const size_t bytes = (size_t)2 * a * H * sizeof(float);
     if (bytes <= 48 * 1024) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel<8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes);
+#define AHB_ATTR(NA, EX)                                                                                                 \
+    {                                                                                                                    \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel<NA, EX>),                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                     \
+        if (e != hipSuccess) return e;                                                                                   \
+    }
+    switch (a) {
+        case 7: AHB_ATTR(7, true); break;
+        case 8: AHB_ATTR(8, true); break;
+        case 12: AHB_ATTR(12, true); break;
+        case 16: AHB_ATTR(16, true); break;
+        default: AHB_ATTR(16, false); break;
+    }
+#undef AHB_ATTR
+    return hipSuccess;
 }
 
 hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, int ldw1, const float* mu, int ldmu,
                                  const float* W4, int ldw4, const float* P, int ldp_, float* dpremu, int ldd, float* dp,
                                  int lddp, int rows, int H, int a, hipStream_t s) {
     if (!actor_head_bwd_ok(H, a)) return hipErrorInvalidValue;
-    if (a <= 8)
-        hipLaunchKernelGGL(actor_head_bwd_kernel<8>, dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s, dt1,
-                           ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a);
-    else
-        hipLaunchKernelGGL(actor_head_bwd_kernel<16>, dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s, dt1,
-                           ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a);
+#define AHB_LAUNCH(NA, EX)                                                                                               \
+    hipLaunchKernelGGL((actor_head_bwd_kernel<NA, EX>), dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s,  \
+                       dt1, ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a)
+    switch (a) {
+        case 1: AHB_LAUNCH(1, true); break;
+        case 2: AHB_LAUNCH(2, true); break;
+        case 3: AHB_LAUNCH(3, true); break;
+        case 4: AHB_LAUNCH(4, true); break;
+        case 5: AHB_LAUNCH(5, true); break;
+        case 6: AHB_LAUNCH(6, true); break;
+        case 7: AHB_LAUNCH(7, true); break;
+        case 8: AHB_LAUNCH(8, true); break;
+        case 12: AHB_LAUNCH(12, true); break;
+        case 16: AHB_LAUNCH(16, true); break;
+        default: AHB_LAUNCH(16, false); break;
+    }
+#undef AHB_LAUNCH
     return hipGetLastError();
 }
 
