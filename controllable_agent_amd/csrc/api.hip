@@ -776,7 +776,7 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
 
 // Actor.forward up to the pre-tanh policy output (fb_modules.py:107-121); Xo supplies obs (first o cols)
 void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
-                     Chain& out) {
+                     Chain& out, bool with_head = true) {
     const fbhip_dims& d = c->d;
     const Geom gm = actor_geom_of(d);
     const int H = d.hidden_dim, a = head_width(d), La = pad4(a), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
@@ -804,6 +804,7 @@ void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, cons
         out.push_back([=](Ops& o) {
             o.gemms.push_back(P(gm.trunk ? Sp->tr.p : Sp->h.p, feat, 1, W.W3, feat, 1, Sp->p.p, H, rows, H, feat, W.b3, EPI_BIAS_RELU));
         });
+    if (!with_head) return;                      // the caller runs the head + the sample as one row kernel (policy_head_kernel)
     out.push_back([=](Ops& o) {                              // head: mu (a wide) / [loc | raw log-std] (2a wide, from h directly)
         o.gemms.push_back(P(gm.boltz ? Sp->h.p : Sp->p.p, H, 1, W.W4, H, 1, Sp->premu.p, La, rows, a, H, W.b4, EPI_BIAS));
     });
@@ -967,11 +968,20 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
     // forward_net or the new FB weights: in a call that also runs the FB backward it shares that backward's launches
     // (FB_BWD is two bits, see below: pass ACTOR_FWD with both or with neither)
     const bool early_actor = (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
+    // policy head + sample: one row kernel when the head's width has an instantiation and its weight fits 48 KB of LDS,
+    // else head GEMM (in the chain) + sample
+    static const bool head_env = [] { const char* e = getenv("FBHIP_FUSED_POLICY_HEAD"); return !(e && e[0] == '0'); }();
+    const bool fused_policy = head_env && policy_head_ok(H, head_width(d));
     auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst) {
         return [=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_policy_sample(w.as.premu.p, Lh, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
-                                              ld_dst, B, a, c->sq, q));
+                if (fused_policy)
+                    HIPCK(c, launch_policy_head(d.boltzmann ? w.as.h.p : w.as.p.p, H, c->A_p.W4, H, c->A_p.b4, w.as.premu.p, Lh,
+                                                noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst, ld_dst, B, H, a,
+                                                head_width(d), c->sq, q));
+                else
+                    HIPCK(c, launch_policy_sample(w.as.premu.p, Lh, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
+                                                  ld_dst, B, a, c->sq, q));
                 return (int)FBHIP_OK;
             });
         };
@@ -984,7 +994,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             // (C, D already ran with the sampler's z-mix pass when this call also covered the SAMPLE phase)
             std::vector<Chain> ch(2);
             if (mask & FBHIP_PHASE_FB_FWD_TARGET) {
-                actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0]);
+                actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0], !fused_policy);
                 ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld));
                 forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
             }
@@ -1040,7 +1050,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
             backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1]);
             if (early_actor) {
-                actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2]);
+                actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2], !fused_policy);
                 ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
             }
             Program bw;
@@ -1063,7 +1073,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
         Chain ch;
         if ((mask & FBHIP_PHASE_ACTOR_FWD) && !early_actor) {
-            actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch);
+            actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch, !fused_policy);
             ch.push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
         }
         // ForwardMap up to the heads' hidden activations p; the heads' outputs F1, F2 are never formed: with V = z . W4

@@ -690,6 +690,99 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The policy head as one row kernel: premu = p . W4^T + b4 (NA = a or 2a outputs over K = H), then exactly policy_sample_kernel.
+// Replaces an a-wide GEMM (+ its share of a split-K reduce) and the sample launch; W4 ([NA, H], 24 KB at walker dims) sits in
+// LDS.  NA is a template parameter and every load is unconditional (see actor_head_bwd_kernel).
+template <int NA>
+__global__ void __launch_bounds__(256) policy_head_kernel(const float* __restrict__ P, int ldp_, const float* __restrict__ W4,
+                                                          int ldw4, const float* __restrict__ b4, float* __restrict__ premu,
+                                                          int ldpre, const float* __restrict__ noise, int ldn, float stddev,
+                                                          float clip, float* __restrict__ mu, int ldmu,
+                                                          float* __restrict__ action, int lda, int rows, int H, int a,
+                                                          const Squash sq) {
+    extern __shared__ float ph_lds[];              // [NA][H]
+    for (int k4 = threadIdx.x; k4 < H / 4; k4 += 256) {
+        float4 v[NA];
+#pragma unroll
+        for (int jj = 0; jj < NA; ++jj) v[jj] = reinterpret_cast<const float4*>(W4 + (size_t)jj * ldw4)[k4];
+#pragma unroll
+        for (int jj = 0; jj < NA; ++jj) reinterpret_cast<float4*>(ph_lds + (size_t)jj * H)[k4] = v[jj];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (same stores)
+    constexpr int U = 4;
+    float acc[NA];
+#pragma unroll
+    for (int jj = 0; jj < NA; ++jj) acc[jj] = 0.f;
+    for (int k0 = lane; k0 < H; k0 += 64 * U) {
+        float x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = P[(size_t)row * ldp_ + min(k0 + 64 * u, H - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u;
+            const float xv = k < H ? x[u] : 0.f;
+            const int kc = min(k, H - 1);
+#pragma unroll
+            for (int jj = 0; jj < NA; ++jj) acc[jj] += xv * ph_lds[(size_t)jj * H + kc];
+        }
+    }
+    const float bias_l = b4[min(lane, NA - 1)];
+    const float nz = noise != nullptr ? noise[(size_t)row * ldn + min(lane, a - 1)] : 0.f;
+    float mine = 0.f, mine_raw = 0.f;              // lane j < a keeps pre[j] (and pre[a + j] when the head is 2a wide)
+#pragma unroll
+    for (int jj = 0; jj < NA; ++jj) {
+        const float v = wave_sum(acc[jj]) + __shfl(bias_l, jj);
+        mine = (jj == lane) ? v : mine;
+        mine_raw = (jj == lane + a) ? v : mine_raw;
+    }
+    if (lane < a) {
+        premu[(size_t)row * ldpre + lane] = mine;
+        if (NA > a) premu[(size_t)row * ldpre + a + lane] = mine_raw;
+        const float m = tanhf(mine);               // Actor: mu; DiagGaussianActor: dist.mean = tanh(loc)
+        if (mu != nullptr) mu[(size_t)row * ldmu + lane] = m;
+        float act = m;
+        if (sq.on) {
+            if (noise != nullptr) {
+                const float log_std = sq.lo + 0.5f * (sq.hi - sq.lo) * (tanhf(mine_raw) + 1.f);
+                act = tanhf(mine + expf(log_std) * nz);
+            }
+        } else if (noise != nullptr) {
+            float e = nz * stddev;
+            if (clip >= 0.f) e = fminf(fmaxf(e, -clip), clip);
+            const float lo = (float)(-1.0 + 1e-6), hi = (float)(1.0 - 1e-6);
+            act = fminf(fmaxf(m + e, lo), hi);
+        }
+        if (action != nullptr) action[(size_t)row * lda + lane] = act;
+    }
+}
+
+// exact widths with an instantiation: the walker / quadruped / test actors and their 2a-wide boltzmann heads
+bool policy_head_ok(int H, int na) {
+    const bool inst = na == 3 || na == 6 || na == 12 || na == 24;
+    return inst && (H & 3) == 0 && (size_t)na * H * sizeof(float) <= 48 * 1024;
+}
+
+hipError_t launch_policy_head(const float* P, int ldp_, const float* W4, int ldw4, const float* b4, float* premu, int ldpre,
+                              const float* noise, int ldn, float stddev, float clip, float* mu, int ldmu, float* action,
+                              int lda, int rows, int H, int a, int na, Squash sq, hipStream_t s) {
+    if (!policy_head_ok(H, na) || (na != a && na != 2 * a) || (ldw4 & 3)) return hipErrorInvalidValue;
+#define PH_LAUNCH(NB)                                                                                                     \
+    hipLaunchKernelGGL(policy_head_kernel<NB>, dim3((rows + 3) / 4), dim3(256), (size_t)na * H * sizeof(float), s, P, ldp_, W4,  \
+                       ldw4, b4, premu, ldpre, noise, ldn, stddev, clip, mu, ldmu, action, lda, rows, H, a, sq)
+    switch (na) {
+        case 3: PH_LAUNCH(3); break;
+        case 6: PH_LAUNCH(6); break;
+        case 12: PH_LAUNCH(12); break;
+        case 24: PH_LAUNCH(24); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef PH_LAUNCH
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
 // The seam between forward_net's data gradient and the actor's backward pass in update_actor, default (TruncatedNormal) actor:
 //   d action = dt1 . W1[:, action columns]      [B,H] x [H,a]     (the last step of forward_net's dgrad, fb_modules.py:190)
 //   d premu  = d action * (1 - mu^2)            straight-through clamp + tanh (utils.py:171-174)
