@@ -384,6 +384,7 @@ struct fbhip_ctx {
     const float* gb_discount = nullptr;      //   F1, F2, B, tF1, tF2, tB of ALL ranks' rows, and their discounts [gb_rows]
     int gb_rows = 0, gb_off = 0;             //   this rank owns rows [gb_off, gb_off + batch)
     Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
+    ColReduceJobs cr_pending{};              // LayerNorm column reduces waiting for the next split-K reduce launch (flush_round)
     std::string err;
 };
 
@@ -516,7 +517,11 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
             fprintf(stderr, "\n");
         }
         HIPCK(ctx, launch_gemm_group(g, cfg, s));
-        if (red > 0) HIPCK(ctx, launch_splitk_reduce(g, red, s));
+        if (red > 0) {
+            const bool take = ctx != nullptr && ctx->cr_pending.count > 0;
+            HIPCK(ctx, launch_splitk_reduce(g, red, s, take ? &ctx->cr_pending : nullptr));
+            if (take) ctx->cr_pending.count = 0;
+        }
     }
     return FBHIP_OK;
 }
@@ -539,8 +544,19 @@ struct Ops {
 using Stage = std::function<void(Ops&)>;
 using Chain = std::vector<Stage>;
 
+// the LayerNorm column reduces deferred by the previous round go out now if no split-K reduce launch took them
+int flush_colreduce(fbhip_ctx* c, hipStream_t s) {
+    if (c->cr_pending.count > 0) {
+        GemmGroup none{};
+        HIPCK(c, launch_splitk_reduce(none, 0, s, &c->cr_pending));
+        c->cr_pending.count = 0;
+    }
+    return FBHIP_OK;
+}
+
 int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
     if (!o.gemms.empty()) RC(run_gemms(c, o.gemms, s));
+    RC(flush_colreduce(c, s));
     for (size_t i = 0; i < o.lnf.size(); i += LN_MAX_GROUP) {
         LnFwdGroup g{};
         for (size_t j = i; j < o.lnf.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.lnf[j];
@@ -549,7 +565,8 @@ int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
     for (size_t i = 0; i < o.lnb.size(); i += LN_MAX_GROUP) {
         LnBwdGroup g{};
         for (size_t j = i; j < o.lnb.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.lnb[j];
-        HIPCK(c, launch_ln_tanh_bwd_group(g, s));
+        static const bool defer_cr = [] { const char* e = getenv("FBHIP_DEFER_COLREDUCE"); return !(e && e[0] == '0'); }();
+        HIPCK(c, launch_ln_tanh_bwd_group(g, s, defer_cr ? &c->cr_pending : nullptr));
     }
     for (size_t i = 0; i < o.l2n.size(); i += LN_MAX_GROUP) {
         L2Group g{};
@@ -566,7 +583,7 @@ int run_rounds(fbhip_ctx* c, std::vector<Chain>& chains, hipStream_t s) {
         bool any = false;
         for (auto& ch : chains)
             if (r < ch.size()) { ch[r](o); any = true; }
-        if (!any) return FBHIP_OK;
+        if (!any) return flush_colreduce(c, s);
         RC(flush_round(c, o, s));
     }
 }
@@ -601,7 +618,7 @@ int run_program(fbhip_ctx* c, Program& p, hipStream_t s) {
         for (auto& st : rd) st(o);
         RC(flush_round(c, o, s));
     }
-    return FBHIP_OK;
+    return flush_colreduce(c, s);
 }
 
 // ---- network passes as chains ---------------------------------------------------------------------------------

@@ -45,7 +45,15 @@ enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4
                CFG_COUNT };   // the last two: LDS-DMA kernels (128x64 / 64x64 tiles), need gemm_problem_dma_ok()
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
-hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream);
+// LayerNorm-backward column reduces (d gamma, d beta = sums of per-block partials) that ride in a split-K reduce launch instead
+// of paying for a launch of their own: both are tiny fold-the-partials jobs whose results only the optimiser reads
+constexpr int CR_MAX = 6;
+struct ColReduceJobs {
+    const float* partials[CR_MAX]; float* dgamma[CR_MAX]; float* dbeta[CR_MAX];
+    int rows[CR_MAX], n[CR_MAX], block_start[CR_MAX + 1];
+    int count;
+};
+hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream, const ColReduceJobs* extra = nullptr);
 int gemm_cfg_bkt(int cfg);    // K extent of one chunk of a tile configuration
 int gemm_cfg_bm(int cfg);     // tile rows / columns
 int gemm_cfg_bn(int cfg);
@@ -73,7 +81,9 @@ struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const 
                       const float* gamma; float* dx; int lddx; float* dgamma; float* dbeta; float* partials;
                       int rows, n, vdy, vy, vx, vdx, vp, np; };
 struct LnBwdGroup { LnBwdProblem p[LN_MAX_GROUP]; int n; };
-hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s);
+// defer != nullptr: the column reduce of (d gamma, d beta) is NOT launched; its jobs are appended to *defer for
+// launch_splitk_reduce (bit-identical result: same partials, same fold order)
+hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s, ColReduceJobs* defer = nullptr);
 // out = scale * y / max(||y||, 1e-12) per row (F.normalize, fb_modules.py:229); grouped like the LayerNorm launches
 struct L2Problem { const float* y; int ldy; float* out; int ldo; float* norms; int rows, d; float scale; };
 struct L2Group { L2Problem p[LN_MAX_GROUP]; int n; };

@@ -586,7 +586,32 @@ __global__ void __launch_bounds__(256 + 64 * DmaGeom<TM>::NPW) gemm_dma_kernel(c
 
 // C = epi(sum_slices partial[s]) for every split-K problem of a group; one thread per output element (+ the column
 // sums appended behind the M*N elements of each problem)
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g) {
+// out[j] = sum_b partials[b][j], j < 2n: exactly ln_colreduce_kernel (rowops.hip), addressed by a linear job block index
+__device__ __forceinline__ void colreduce_job(const ColReduceJobs& cr, int b) {
+    __shared__ float red[8][32];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CR_MAX; ++i)
+        if (i < cr.count && b >= cr.block_start[i]) pi = i;
+    const int bx = b - cr.block_start[pi];
+    const int n = cr.n[pi], nb = (cr.rows[pi] + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK;
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int j = bx * 32 + c;
+    float s = 0.f;
+    if (j < 2 * n)
+        for (int q = rg; q < nb; q += 8) s += cr.partials[pi][(size_t)q * 2 * n + j];
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && j < 2 * n) {
+        float t = red[0][c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][c];
+        if (j < n) cr.dgamma[pi][j] = t; else cr.dbeta[pi][j - n] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g, const ColReduceJobs cr, const int red_blocks) {
+    if ((int)blockIdx.x >= red_blocks) { colreduce_job(cr, (int)blockIdx.x - red_blocks); return; }
     const int e = blockIdx.x * 256 + threadIdx.x;
     int pi = -1;
 #pragma unroll
@@ -621,9 +646,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g) {
     }
 }
 
-hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream) {
-    if (total_elems <= 0) return hipSuccess;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((total_elems + 255) / 256), dim3(256), 0, stream, g);
+hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream, const ColReduceJobs* extra) {
+    const int red_blocks = total_elems > 0 ? (total_elems + 255) / 256 : 0;
+    ColReduceJobs cr{};
+    if (extra != nullptr) cr = *extra;
+    const int cr_blocks = cr.count > 0 ? cr.block_start[cr.count] : 0;
+    if (red_blocks + cr_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(red_blocks + cr_blocks), dim3(256), 0, stream, g, cr, red_blocks);
     return hipGetLastError();
 }
 

@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) ln_colreduce_kernel(const LnBwdGroup grp)
     }
 }
 
-hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s) {
+hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s, ColReduceJobs* defer) {
     if (g.n < 1) return hipSuccess;
     int maxrows = 0, maxn = 0;
     bool any_param = false, fast = true;
@@ -347,6 +347,23 @@ hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s) {
 #undef LN_BWD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !any_param) return e;
+    if (defer != nullptr) {                        // hand the column reduces to the next split-K reduce launch
+        int room = CR_MAX - defer->count;
+        int want = 0;
+        for (int i = 0; i < g.n; ++i) want += g.p[i].partials != nullptr ? 1 : 0;
+        if (want <= room) {
+            for (int i = 0; i < g.n; ++i) {
+                const LnBwdProblem& p = g.p[i];
+                if (p.partials == nullptr) continue;
+                const int k = defer->count++;
+                defer->partials[k] = p.partials; defer->dgamma[k] = p.dgamma; defer->dbeta[k] = p.dbeta;
+                defer->rows[k] = p.rows; defer->n[k] = p.n;
+                if (k == 0) defer->block_start[0] = 0;
+                defer->block_start[k + 1] = defer->block_start[k] + (2 * p.n + 31) / 32;
+            }
+            return hipSuccess;
+        }
+    }
     hipLaunchKernelGGL(ln_colreduce_kernel, dim3((2 * maxn + 31) / 32, g.n), dim3(256), 0, s, g);
     return hipGetLastError();
 }
