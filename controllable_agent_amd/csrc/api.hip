@@ -681,11 +681,10 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
     const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z);
     Ws* w = &c->W();
     FSet* Sp = &S;
-    out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->dF1.p, Lz, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]));
-        o.gemms.push_back(P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
-        heads_dgrad_ops(c, *w, W, *Sp, rows, o);
-    });
+    // (the heads' output-layer WEIGHT gradients -- thin, 50 x H over K = rows -- wait for the chain's last round, where the other
+    // thin-and-deep weight gradients are: next to the wide problems of this round they would need a cross-workgroup split-K
+    // and a reduce launch on the critical path; only the optimiser reads them)
+    out.push_back([=](Ops& o) { heads_dgrad_ops(c, *w, W, *Sp, rows, o); });
     const Geom gm = geom_of(d);
     const int Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
     const bool trunk = gm.trunk;
@@ -717,6 +716,8 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
                                          G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(w->dF1.p, Lz, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]));
+        o.gemms.push_back(P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
         o.gemms.push_back(P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1));
         if (!gm.single)
             o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
@@ -1060,9 +1061,9 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
     if (mask & FBHIP_PHASE_FB_BWD) {
         {
             // --- backward (fb_ddpg.py:383): forward_net, backward_net and (early) the actor's own forward pass.
-            // FB_BWD_A stops after the two rounds that finish the gradients of both ForwardMap heads (F{1,2}.{0,2}: 57 % of
-            // the FB bucket at walker dims, fbhip_fb_early_grad_range), FB_BWD_B runs the rest: a data-parallel host starts
-            // the all-reduce of that range in between and hides it under FB_BWD_B.
+            // FB_BWD_A stops after the two rounds that finish the gradients of the ForwardMap heads' hidden layers (F{1,2}.0:
+            // 57 % of the FB bucket at walker dims, fbhip_fb_early_grad_range), FB_BWD_B runs the rest: a data-parallel host
+            // starts the all-reduce of that range in between and hides it under FB_BWD_B.
             std::vector<Chain> ch(3);
             forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
             backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1]);
@@ -1440,9 +1441,10 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
 int fbhip_fb_early_grad_range(const fbhip_dims* dims, int64_t* offset, int64_t* count) {
     if (check_dims(dims) != FBHIP_OK || !offset || !count) return FBHIP_E_INVALID;
     const NetLayout L = build_layout(*dims, FBHIP_NET_FORWARD);
-    // both heads (F1.0 F2.0 F1.2 F2.2, weights and biases) are laid out last in forward_net
+    // the heads' hidden layers (F1.0 F2.0, weights then biases: 2H x feat + 2H, 98 % of the heads' parameters) are laid out
+    // contiguously before the output layers F1.2 F2.2, whose thin weight gradients are produced in the LAST backward round
     *offset = (int64_t)L.by_name.at("F1.0.weight").off;
-    *count = (int64_t)L.numel - *offset;
+    *count = (int64_t)L.by_name.at("F1.2.weight").off - *offset;
     return FBHIP_OK;
 }
 

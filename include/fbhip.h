@@ -55,7 +55,7 @@ enum {
     FBHIP_PHASE_FB_FWD_TARGET = 128, /* actor(next_obs) -> next_action -> forward_target (fb_ddpg.py:303-311) */
     FBHIP_PHASE_FB_FWD = 130,    /* = FB_FWD_ONLINE | FB_FWD_TARGET: everything up to the six embeddings F1 F2 B tF1 tF2 tB */
     FBHIP_PHASE_FB_BWD_A = 64,   /* pairwise loss (on the rows bound by fbhip_bind_global_batch when a global batch is bound) + the
-                                  * first two backward rounds: they complete the gradients of both ForwardMap heads
+                                  * first two backward rounds: they complete the gradients of the ForwardMap heads' hidden layers
                                   * (fbhip_fb_early_grad_range) */
     FBHIP_PHASE_FB_BWD_B = 256,  /* the rest of fb_loss.backward() (fb_ddpg.py:383) */
     FBHIP_PHASE_FB_BWD = 320,    /* = FB_BWD_A | FB_BWD_B.  ACTOR_FWD must accompany both halves or neither */
@@ -209,7 +209,7 @@ int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, 
  * fbhip_update calls work on; phases of one step must all run on the same set.  Default 0. */
 int fbhip_select_workspace_set(fbhip_ctx* ctx, int32_t which);
 /* [offset, offset + count) floats of the FB gradient buffer (forward_net ++ backward_net) that are FINAL after
- * FBHIP_PHASE_FB_BWD_A: the gradients of F1.0 F2.0 F1.2 F2.2, laid out last in forward_net. */
+ * FBHIP_PHASE_FB_BWD_A: the gradients of the ForwardMap heads' hidden layers F1.0 F2.0 (weights and biases, contiguous). */
 int fbhip_fb_early_grad_range(const fbhip_dims* dims, int64_t* offset, int64_t* count);
 /* ---- global-batch data parallel (SURVEY section 8e "mode B"): the FB / orthonormality losses couple every row of the batch
  * with every other row (fb_ddpg.py:313-326, 344-346), so the exact loss of a batch spread over several devices needs one
