@@ -775,8 +775,7 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
             return (int)FBHIP_OK;
         });
     });
-    out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
+    out.push_back([=](Ops& o) {                 // (the output layer's thin weight gradient waits for the last round, see forward_map_bwd_chain)
         o.gemms.push_back(P(dy, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb));
     });
     out.push_back([=](Ops& o) {
@@ -788,6 +787,7 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
                                      G.be1, w->ln_partials_b, rows, Hb, 0, 0, 0, 0, 0, pad4(Hb)});
     });
     out.push_back([=](Ops& o) {
+        o.gemms.push_back(P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
         o.gemms.push_back(P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad32(g), Lb, Ng, rows, nullptr, EPI_NONE, nullptr, 0, G.b1));
     });
 }
