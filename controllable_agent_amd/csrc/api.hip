@@ -180,6 +180,7 @@ struct Ws {
     SampleOut so{};
     Buf Xoa, Xoz, Xnoz, Xnoa, Xopi, Xo, next_goal, bin, fgoal, z, zrand;
     float* disc = nullptr;
+    ASet asT;                // actor(next_obs) of the target chain: its own set, so that the actor's pass on obs can share its rounds
     BSet bsA, bsO, bsM, bsF; // target / online passes on next_goal, z-mix pass on backward_input[perm], hindsight pass
     FSet fsT, fsO;
     ASet as;
@@ -275,6 +276,9 @@ Ws carve(const fbhip_dims& d, void* base) {
     const int Na = head_width(d);
     w.as.h = c.buf(B, ga.hw); w.as.tr = c.buf(ga.trunk ? B : 1, H); w.as.p = c.buf(B, H); w.as.premu = c.buf(B, Na); w.as.mu = c.buf(B, a);
     w.as.statsO = c.f(2 * (size_t)B); w.as.statsZ = c.f(2 * (size_t)B);
+    w.asT.pre1o = c.buf(B, H); w.asT.t1o = c.buf(B, H); w.asT.pre1z = c.buf(B, H); w.asT.t1z = c.buf(B, H);
+    w.asT.h = c.buf(B, ga.hw); w.asT.tr = c.buf(ga.trunk ? B : 1, H); w.asT.p = c.buf(B, H); w.asT.premu = c.buf(B, Na); w.asT.mu = c.buf(B, a);
+    w.asT.statsO = c.f(2 * (size_t)B); w.asT.statsZ = c.f(2 * (size_t)B);
     w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
     w.dp = c.buf(B, 2 * H); w.dtr = c.buf(gm.trunk ? B : 1, H); w.dh = c.buf(B, gm.hw > ga.hw ? gm.hw : ga.hw); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
     w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, Na); w.a_dp = c.buf(B, H);
@@ -985,20 +989,25 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
     // the actor's own forward pass of update_actor (fb_ddpg.py:395-397) reads only the actor weights and (obs, z), not
     // forward_net or the new FB weights: in a call that also runs the FB backward it shares that backward's launches
     // (FB_BWD is two bits, see below: pass ACTOR_FWD with both or with neither)
-    const bool early_actor = (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
+    // ... and when the call also runs the target chain, whose first half is the SAME actor on next_obs, it rides there instead:
+    // layer by layer the two passes are two problems of the same launches (own activation sets: w.as / w.asT)
+    static const bool awt_env = [] { const char* e = getenv("FBHIP_ACTOR_WITH_TARGET"); return !(e && e[0] == '0'); }();
+    const bool actor_with_target = awt_env && (mask & FBHIP_PHASE_FB_FWD_TARGET) && (mask & FBHIP_PHASE_ACTOR_FWD);
+    const bool early_actor = !actor_with_target && (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
     // policy head + sample: one row kernel when the head's width has an instantiation and its weight fits 48 KB of LDS,
     // else head GEMM (in the chain) + sample
     static const bool head_env = [] { const char* e = getenv("FBHIP_FUSED_POLICY_HEAD"); return !(e && e[0] == '0'); }();
     const bool fused_policy = head_env && policy_head_ok(H, head_width(d));
-    auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst) {
-        return [=, &w](Ops& o2) {
-            o2.post.push_back([=, &w](hipStream_t q) -> int {
+    auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst, ASet* set = nullptr) {
+        ASet* S = set ? set : &w.as;
+        return [=](Ops& o2) {
+            o2.post.push_back([=](hipStream_t q) -> int {
                 if (fused_policy)
-                    HIPCK(c, launch_policy_head(d.boltzmann ? w.as.h.p : w.as.p.p, H, c->A_p.W4, H, c->A_p.b4, w.as.premu.p, Lh,
+                    HIPCK(c, launch_policy_head(d.boltzmann ? S->h.p : S->p.p, H, c->A_p.W4, H, c->A_p.b4, S->premu.p, Lh,
                                                 noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst, ld_dst, B, H, a,
                                                 head_width(d), c->sq, q));
                 else
-                    HIPCK(c, launch_policy_sample(w.as.premu.p, Lh, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
+                    HIPCK(c, launch_policy_sample(S->premu.p, Lh, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
                                                   ld_dst, B, a, c->sq, q));
                 return (int)FBHIP_OK;
             });
@@ -1012,12 +1021,17 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             // (C, D already ran with the sampler's z-mix pass when this call also covered the SAMPLE phase)
             std::vector<Chain> ch(2);
             if (mask & FBHIP_PHASE_FB_FWD_TARGET) {
-                actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.as, B, ch[0], !fused_policy);
-                ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld));
+                actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.asT, B, ch[0], !fused_policy);
+                ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
                 forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
             }
             if (mask & FBHIP_PHASE_FB_FWD_ONLINE)
                 forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
+            if (actor_with_target) {             // update_actor's own actor pass (fb_ddpg.py:395-397), see above
+                ch.emplace_back();
+                actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch.back(), !fused_policy);
+                ch.back().push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
+            }
             if ((mask & FBHIP_PHASE_FB_FWD_ONLINE) && !(mask & FBHIP_PHASE_SAMPLE)) {
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_t, next_goal, ld_ng, w.bsA, B, ch.back());
@@ -1090,7 +1104,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 
     if (mask & FBHIP_PHASE_ACTOR_GRAD) {        // update_actor, fb_ddpg.py:389-410
         Chain ch;
-        if ((mask & FBHIP_PHASE_ACTOR_FWD) && !early_actor) {
+        if ((mask & FBHIP_PHASE_ACTOR_FWD) && !early_actor && !actor_with_target) {
             actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch, !fused_policy);
             ch.push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
         }
@@ -1552,7 +1566,9 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
         {"Xoa", w.Xoa}, {"Xoz", w.Xoz}, {"Xnoz", w.Xnoz}, {"Xnoa", w.Xnoa}, {"Xopi", w.Xopi}, {"next_goal", w.next_goal},
         {"backward_input", w.bin}, {"future_goal", w.fgoal}, {"z", w.z}, {"zrand", w.zrand}, {"F1", w.fsO.F1}, {"F2", w.fsO.F2}, {"Bm", d.norm_z ? w.bsO.Bm : w.bsO.y},
         {"y", w.bsO.y}, {"tF1", w.fsT.F1}, {"tF2", w.fsT.F2}, {"tB", d.norm_z ? w.bsA.Bm : w.bsA.y}, {"dF1", w.dF1}, {"dF2", w.dF2},
-        {"dBm", w.dBm}, {"dy", d.norm_z ? w.dy : w.dBm}, {"mu", w.as.mu}, {"d_premu", w.a_dpremu}};
+        {"dBm", w.dBm}, {"dy", d.norm_z ? w.dy : w.dBm}, {"mu", w.as.mu}, {"d_premu", w.a_dpremu},
+        {"dp", w.dp}, {"dh", w.dh}, {"dt1a", w.dt1a}, {"a_dp", w.a_dp}, {"actor_p", w.as.p}, {"actor_h", w.as.h},
+        {"actor_premu", w.as.premu}, {"online_p", w.fsO.p}, {"online_h", w.fsO.h}};
     Buf b;
     const std::string n(name);
     if (m.count(n)) b = m[n];

@@ -63,7 +63,10 @@ def _reduce_fb(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, ear
     off, cnt = early
     run_phases(first_mask)
     work = dist.all_reduce(fb_grads[off:off + cnt], async_op=True)
-    run_phases(PHASE_FB_BWD_B | (first_mask & PHASE_ACTOR_FWD))
+    # (the actor's own forward pass rides with the target chain when the first call carries FB_FWD_TARGET; only when it shares
+    # the FB backward's launches does the second half need the bit too)
+    second = PHASE_ACTOR_FWD if (first_mask & PHASE_ACTOR_FWD) and not (first_mask & PHASE_FB_FWD_TARGET) else 0
+    run_phases(PHASE_FB_BWD_B | second)
     work.wait()
     rest = [t for t in (fb_grads[:off], fb_grads[off + cnt:]) if t.numel() > 0]
     if len(rest) == 2 and dist.get_backend() == "nccl":

@@ -58,14 +58,16 @@ enum {
                                   * first two backward rounds: they complete the gradients of the ForwardMap heads' hidden layers
                                   * (fbhip_fb_early_grad_range) */
     FBHIP_PHASE_FB_BWD_B = 256,  /* the rest of fb_loss.backward() (fb_ddpg.py:383) */
-    FBHIP_PHASE_FB_BWD = 320,    /* = FB_BWD_A | FB_BWD_B.  ACTOR_FWD must accompany both halves or neither */
+    FBHIP_PHASE_FB_BWD = 320,    /* = FB_BWD_A | FB_BWD_B */
     FBHIP_PHASE_FB_GRAD = 450,   /* = FB_FWD | FB_BWD */
     FBHIP_PHASE_FB_STEP = 4,     /* fb_opt.step() + both soft_update_params         (fb_ddpg.py:384,500-503) */
     FBHIP_PHASE_ACTOR_GRAD = 8,  /* Q through the UPDATED forward_net, actor backward  (fb_ddpg.py:398-410) */
     FBHIP_PHASE_ACTOR_STEP = 16, /* actor_opt.step()                                (fb_ddpg.py:411) */
-    /* the actor's own forward pass of update_actor (fb_ddpg.py:395-397): it reads only the actor weights and (obs, z),
-     * so it may run in the same call as FB_GRAD (it then shares the FB backward's launches) -- or with ACTOR_GRAD.
-     * An ACTOR_GRAD call WITHOUT this bit uses the pass of an earlier call on the same batch. */
+    /* the actor's own forward pass of update_actor (fb_ddpg.py:395-397): it reads only the actor weights and (obs, z), so it
+     * runs wherever it is cheapest in the call that carries this bit: with FB_FWD_TARGET (layer by layer in the same launches
+     * as the target chain's actor(next_obs)), else with FB_BWD (sharing the FB backward's launches; pass the bit with both
+     * halves then), else with ACTOR_GRAD.  An ACTOR_GRAD call WITHOUT this bit uses the pass of an earlier call on the same
+     * batch.  Pass it to ONE place per step. */
     FBHIP_PHASE_ACTOR_FWD = 32,
     FBHIP_PHASE_ALL = 511
 };

@@ -623,7 +623,11 @@ def test_one_update_at_the_edges_of_the_supported_dimensions(dims):
     """One injected update at degenerate, ragged and maximal dimensions: losses, gradients and post-step parameters against
     the oracle (same tolerances as the teacher-forced traces)."""
     cfg = fo.OracleConfig(lr=1e-3, **dims)
-    rng = np.random.default_rng(41)
+    # (seed note: with seed 41 the maximal case has ONE ForwardMap activation of 96 x 2048 within 2.3e-7 of the ReLU
+    # threshold; whether it comes out as 0 or +2e-7 depends on the fp32 summation order of the launch it shares, the mask of
+    # one gradient element flips and a whole weight-gradient row moves by 5e-4 -- a discontinuity of the function, found
+    # with tools/edge_probe2.py, not an error of either side.  The seed below keeps every activation clear of the threshold.)
+    rng = np.random.default_rng(43)
     nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
     storage, lengths = fo.synthetic_storage(rng, 6, 9, cfg.obs_dim, cfg.action_dim)
     agent = H.make_hip_agent(cfg, nets)
