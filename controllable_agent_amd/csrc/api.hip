@@ -1144,13 +1144,17 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             });
         }
         ch.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.dh.p, hw, 1, c->F_p.oa.W2, H, 0, w.dt1a.p, H, B, H, Fo)); });
-        ch.push_back([=, &w](Ops& o2) {
-            o2.lnb.push_back(LnBwdProblem{w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
-                                          nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0, H});
-        });
-        // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
         static const bool fuse_env = [] { const char* e = getenv("FBHIP_FUSED_ACTOR_HEAD"); return !(e && e[0] == '0'); }();
         const bool fused_head = fuse_env && !d.boltzmann && actor_head_bwd_ok(H, a);
+        static const bool ln_env = [] { const char* e = getenv("FBHIP_FUSED_ACTOR_HEAD_LN"); return !(e && e[0] == '0'); }();
+        const bool fused_ln = fused_head && ln_env && H <= 2048;      // the LayerNorm+tanh backward of this row chain joins the kernel
+        if (!fused_ln)
+            ch.push_back([=, &w](Ops& o2) {
+                o2.lnb.push_back(LnBwdProblem{w.dt1a.p, H, w.fsO.t1a.p, H, w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1, w.dt1a.p, H,
+                                              nullptr, nullptr, nullptr, B, H, 0, 0, 0, 0, 0, H});
+            });
+        // d action -> d mu (straight-through clamp, utils.py:171-174) -> d pre-tanh
+
         if (d.boltzmann)                         // ... or through the SquashedNormal's rsample and log_prob (fb_ddpg.py:393-406)
             ch.push_back([=, &w](Ops& o2) {
                 o2.gemms.push_back(P(w.dt1a.p, H, 1, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, 0, w.a_dact.p, La, B, a, H));
@@ -1163,8 +1167,13 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         else if (fused_head)
             ch.push_back([=, &w](Ops& o2) {      // d action -> d premu -> d p in one row kernel (actor_head_bwd_kernel)
                 o2.post.push_back([=, &w](hipStream_t q) -> int {
-                    HIPCK(c, launch_actor_head_bwd(w.dt1a.p, H, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, w.as.mu.p, La, c->A_p.W4, H,
-                                                   w.as.p.p, H, w.a_dpremu.p, La, w.a_dp.p, H, B, H, a, q));
+                    if (fused_ln)
+                        HIPCK(c, launch_actor_head_bwd(w.dt1a.p, H, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, w.as.mu.p, La, c->A_p.W4, H,
+                                                       w.as.p.p, H, w.a_dpremu.p, La, w.a_dp.p, H, B, H, a, q, w.fsO.t1a.p, H,
+                                                       w.fsO.pre1a.p, H, w.fsO.statsA, c->F_p.oa.g1));
+                    else
+                        HIPCK(c, launch_actor_head_bwd(w.dt1a.p, H, c->F_p.oa.W1 + aoff, c->F_p.oa.ld1, w.as.mu.p, La, c->A_p.W4, H,
+                                                       w.as.p.p, H, w.a_dpremu.p, La, w.a_dp.p, H, B, H, a, q));
                     return (int)FBHIP_OK;
                 });
             });

@@ -122,9 +122,13 @@ hipError_t launch_policy_head(const float* P, int ldp_, const float* W4, int ldw
 // d action -> d premu -> d p of the actor's policy hidden layer in one row kernel (actor_head_bwd_kernel; a <= 16)
 bool actor_head_bwd_ok(int H, int a);
 hipError_t actor_head_bwd_prepare(int H, int a);   // raises the kernel's dynamic-LDS limit (not inside a stream capture)
+// lnY != nullptr: dt1 is dL/d(tanh output) and the LayerNorm+tanh backward (y = lnY, x = lnX, (mean, rstd) = lnStats, gamma;
+// no parameter gradients) is done by the kernel as well; H <= 2048
 hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, int ldw1, const float* mu, int ldmu,
                                  const float* W4, int ldw4, const float* P, int ldp_, float* dpremu, int ldd, float* dp,
-                                 int lddp, int rows, int H, int a, hipStream_t s);
+                                 int lddp, int rows, int H, int a, hipStream_t s, const float* lnY = nullptr, int ldy = 0,
+                                 const float* lnX = nullptr, int ldx = 0, const float* lnStats = nullptr,
+                                 const float* lnGamma = nullptr);
 
 // ---- pairwise FB loss ----------------------------------------------------------------------------------
 size_t pairwise_scratch_floats(int B, int d);

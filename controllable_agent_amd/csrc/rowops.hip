@@ -811,8 +811,15 @@ constexpr int AHB_MAXA = 16;
 // head must not pay for 16 lanes of them
 // AHB_N == a exactly when EXACT (instantiated for 1..8, 12, 16): every per-output loop is straight-line code without
 // predicates; other widths up to 16 take <16, false>, whose loops are predicated on jj < a
-template <int AHB_N, bool EXACT>
+// LNE > 0: ``dt1`` is dL/d(tanh output) of forward_net's obs_action trunk and the LayerNorm+tanh backward of that row (no
+// parameter gradients: forward_net's are discarded in update_actor) happens here too, LNE = ceil(H / 64) elements per lane --
+// one more launch off the phase's dependency chain.  LNE == 0: ``dt1`` already is the gradient wrt the pre-LayerNorm values.
+template <int AHB_N, bool EXACT, int LNE>
 __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __restrict__ dt1, int ldt,
+                                                             const float* __restrict__ lnY, int ldy,
+                                                             const float* __restrict__ lnX, int ldx,
+                                                             const float* __restrict__ lnStats,
+                                                             const float* __restrict__ lnGamma,
                                                              const float* __restrict__ W1a, int ldw1,
                                                              const float* __restrict__ mu, int ldmu,
                                                              const float* __restrict__ W4, int ldw4,
@@ -854,6 +861,36 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     float acc[AHB_N];
 #pragma unroll
     for (int jj = 0; jj < AHB_N; ++jj) acc[jj] = 0.f;
+    if constexpr (LNE > 0) {
+        // du = dy (1 - y^2); g = du gamma; dx = rstd (g - mean(g) - xhat mean(g xhat))      (ln_tanh_bwd_kernel, same math)
+        const float mean = lnStats[2 * row], rstd = lnStats[2 * row + 1];
+        float dyv[LNE], yv[LNE], xv[LNE], gam[LNE];
+#pragma unroll
+        for (int i = 0; i < LNE; ++i) {
+            const int mc = min(lane + 64 * i, H - 1);
+            dyv[i] = dt1[(size_t)row * ldt + mc]; yv[i] = lnY[(size_t)row * ldy + mc]; xv[i] = lnX[(size_t)row * ldx + mc];
+            gam[i] = lnGamma[mc];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNE; ++i) {
+            const bool in = lane + 64 * i < H;
+            const float du = dyv[i] * (1.f - yv[i] * yv[i]);
+            const float h = in ? (xv[i] - mean) * rstd : 0.f;
+            const float g = in ? du * gam[i] : 0.f;
+            dyv[i] = g; xv[i] = h;                 // reuse the registers: g and xhat
+            s1 += g; s2 += g * h;
+        }
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int i = 0; i < LNE; ++i) {
+            const int m = lane + 64 * i, mc = min(m, H - 1);
+            const float gv = m < H ? rstd * (dyv[i] - m1 - xv[i] * m2) : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < AHB_N; ++jj)
+                if (EXACT || jj < a) acc[jj] += gv * sW1[(size_t)jj * H + mc];
+        }
+    } else {
     for (int m0 = lane; m0 < H; m0 += 64 * U) {
         float g[U];
 #pragma unroll
@@ -867,6 +904,7 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
             for (int jj = 0; jj < AHB_N; ++jj)
                 if (EXACT || jj < a) acc[jj] += gv * sW1[(size_t)jj * H + mc];
         }
+    }
     }
     const float mu_l = mu[(size_t)row * ldmu + min(lane, a - 1)];
 #pragma unroll
@@ -912,12 +950,13 @@ hipError_t actor_head_bwd_prepare(int H, int a) {
     if (!actor_head_bwd_ok(H, a)) return hipSuccess;
     const size_t bytes = (size_t)2 * a * H * sizeof(float);
     if (bytes <= 48 * 1024) return hipSuccess;
-#define AHB_ATTR(NA, EX)                                                                                                 \
+#define AHB_ATTR1(NA, EX, LN)                                                                                            \
     {                                                                                                                    \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel<NA, EX>),                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&actor_head_bwd_kernel<NA, EX, LN>),             \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                     \
         if (e != hipSuccess) return e;                                                                                   \
     }
+#define AHB_ATTR(NA, EX) AHB_ATTR1(NA, EX, 0) AHB_ATTR1(NA, EX, 16) AHB_ATTR1(NA, EX, 32)
     switch (a) {
         case 7: AHB_ATTR(7, true); break;
         case 8: AHB_ATTR(8, true); break;
@@ -926,16 +965,28 @@ hipError_t actor_head_bwd_prepare(int H, int a) {
         default: AHB_ATTR(16, false); break;
     }
 #undef AHB_ATTR
+#undef AHB_ATTR1
     return hipSuccess;
 }
 
 hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, int ldw1, const float* mu, int ldmu,
                                  const float* W4, int ldw4, const float* P, int ldp_, float* dpremu, int ldd, float* dp,
-                                 int lddp, int rows, int H, int a, hipStream_t s) {
+                                 int lddp, int rows, int H, int a, hipStream_t s, const float* lnY, int ldy, const float* lnX,
+                                 int ldx, const float* lnStats, const float* lnGamma) {
     if (!actor_head_bwd_ok(H, a)) return hipErrorInvalidValue;
+    const bool ln = lnY != nullptr;
+    if (ln && (H > 2048 || !lnX || !lnStats || !lnGamma)) return hipErrorInvalidValue;
+    const int lne = !ln ? 0 : (H <= 1024 ? 16 : 32);
+#define AHB_LAUNCH1(NA, EX, LN)                                                                                          \
+    hipLaunchKernelGGL((actor_head_bwd_kernel<NA, EX, LN>), dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), \
+                       s, dt1, ldt, lnY, ldy, lnX, ldx, lnStats, lnGamma, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd,  \
+                       dp, lddp, rows, H, a)
 #define AHB_LAUNCH(NA, EX)                                                                                               \
-    hipLaunchKernelGGL((actor_head_bwd_kernel<NA, EX>), dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), s,  \
-                       dt1, ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a)
+    {                                                                                                                    \
+        if (lne == 0) AHB_LAUNCH1(NA, EX, 0);                                                                            \
+        else if (lne == 16) AHB_LAUNCH1(NA, EX, 16);                                                                     \
+        else AHB_LAUNCH1(NA, EX, 32);                                                                                    \
+    }
     switch (a) {
         case 1: AHB_LAUNCH(1, true); break;
         case 2: AHB_LAUNCH(2, true); break;
@@ -950,6 +1001,7 @@ hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, in
         default: AHB_LAUNCH(16, false); break;
     }
 #undef AHB_LAUNCH
+#undef AHB_LAUNCH1
     return hipGetLastError();
 }
 
