@@ -388,6 +388,7 @@ struct fbhip_ctx {
     const float* gb_discount = nullptr;      //   F1, F2, B, tF1, tF2, tB of ALL ranks' rows, and their discounts [gb_rows]
     int gb_rows = 0, gb_off = 0;             //   this rank owns rows [gb_off, gb_off + batch)
     Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
+    std::function<int(const PolicyHeadJobs&, hipStream_t)> run_policy_heads;   // set by the update that declares Ops::ph
     ColReduceJobs cr_pending{};              // LayerNorm column reduces waiting for the next split-K reduce launch (flush_round)
     std::string err;
 };
@@ -543,6 +544,7 @@ struct Ops {
     std::vector<LnFwdProblem> lnf;
     std::vector<LnBwdProblem> lnb;
     std::vector<L2Problem> l2n;               // run after this round's GEMMs
+    std::vector<PolicyHeadJob> ph;            // fused policy heads of this round (one launch for all of them)
     std::vector<std::function<int(hipStream_t)>> post;
 };
 using Stage = std::function<void(Ops&)>;
@@ -576,6 +578,11 @@ int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
         L2Group g{};
         for (size_t j = i; j < o.l2n.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.l2n[j];
         HIPCK(c, launch_l2norm_fwd_group(g, s));
+    }
+    for (size_t i = 0; i < o.ph.size(); i += PH_MAX_JOBS) {
+        PolicyHeadJobs jobs{};
+        for (size_t j = i; j < o.ph.size() && j < i + PH_MAX_JOBS; ++j) jobs.j[jobs.n++] = o.ph[j];
+        RC(c->run_policy_heads(jobs, s));
     }
     for (auto& f : o.post) RC(f(s));
     return FBHIP_OK;
@@ -998,17 +1005,23 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
     // else head GEMM (in the chain) + sample
     static const bool head_env = [] { const char* e = getenv("FBHIP_FUSED_POLICY_HEAD"); return !(e && e[0] == '0'); }();
     const bool fused_policy = head_env && policy_head_ok(H, head_width(d));
+    if (fused_policy) {
+        const float stddev = hp.stddev, clip = hp.stddev_clip;
+        c->run_policy_heads = [=](const PolicyHeadJobs& jobs, hipStream_t q) -> int {
+            HIPCK(c, launch_policy_head(jobs, c->A_p.W4, H, c->A_p.b4, Lh, a, stddev, clip, La, B, H, a, head_width(d), c->sq, q));
+            return (int)FBHIP_OK;
+        };
+    }
     auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst, ASet* set = nullptr) {
         ASet* S = set ? set : &w.as;
         return [=](Ops& o2) {
+            if (fused_policy) {                  // all heads of a round go out as one launch (flush_round)
+                o2.ph.push_back(PolicyHeadJob{d.boltzmann ? S->h.p : S->p.p, H, S->premu.p, noise, mu, action_dst, ld_dst});
+                return;
+            }
             o2.post.push_back([=](hipStream_t q) -> int {
-                if (fused_policy)
-                    HIPCK(c, launch_policy_head(d.boltzmann ? S->h.p : S->p.p, H, c->A_p.W4, H, c->A_p.b4, S->premu.p, Lh,
-                                                noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst, ld_dst, B, H, a,
-                                                head_width(d), c->sq, q));
-                else
-                    HIPCK(c, launch_policy_sample(S->premu.p, Lh, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
-                                                  ld_dst, B, a, c->sq, q));
+                HIPCK(c, launch_policy_sample(S->premu.p, Lh, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst,
+                                              ld_dst, B, a, c->sq, q));
                 return (int)FBHIP_OK;
             });
         };

@@ -116,9 +116,11 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
 
 // policy head (premu = p . W4^T + b4, na = a or 2a outputs) + policy_sample in one row kernel (policy_head_kernel)
 bool policy_head_ok(int H, int na);
-hipError_t launch_policy_head(const float* P, int ldp_, const float* W4, int ldw4, const float* b4, float* premu, int ldpre,
-                              const float* noise, int ldn, float stddev, float clip, float* mu, int ldmu, float* action,
-                              int lda, int rows, int H, int a, int na, Squash sq, hipStream_t s);
+constexpr int PH_MAX_JOBS = 2;
+struct PolicyHeadJob { const float* P; int ldp; float* premu; const float* noise; float* mu; float* action; int lda; };
+struct PolicyHeadJobs { PolicyHeadJob j[PH_MAX_JOBS]; int n; };
+hipError_t launch_policy_head(const PolicyHeadJobs& jobs, const float* W4, int ldw4, const float* b4, int ldpre, int ldn,
+                              float stddev, float clip, int ldmu, int rows, int H, int a, int na, Squash sq, hipStream_t s);
 // d action -> d premu -> d p of the actor's policy hidden layer in one row kernel (actor_head_bwd_kernel; a <= 16)
 bool actor_head_bwd_ok(int H, int a);
 hipError_t actor_head_bwd_prepare(int H, int a);   // raises the kernel's dynamic-LDS limit (not inside a stream capture)

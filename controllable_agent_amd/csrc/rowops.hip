@@ -710,13 +710,20 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
 // The policy head as one row kernel: premu = p . W4^T + b4 (NA = a or 2a outputs over K = H), then exactly policy_sample_kernel.
 // Replaces an a-wide GEMM (+ its share of a split-K reduce) and the sample launch; W4 ([NA, H], 24 KB at walker dims) sits in
 // LDS.  NA is a template parameter and every load is unconditional (see actor_head_bwd_kernel).
+// Up to PH_MAX_JOBS row sets share the launch (blockIdx.y): the target chain's actor(next_obs) and update_actor's actor(obs)
+// reach their heads in the same round.
 template <int NA>
-__global__ void __launch_bounds__(256) policy_head_kernel(const float* __restrict__ P, int ldp_, const float* __restrict__ W4,
-                                                          int ldw4, const float* __restrict__ b4, float* __restrict__ premu,
-                                                          int ldpre, const float* __restrict__ noise, int ldn, float stddev,
-                                                          float clip, float* __restrict__ mu, int ldmu,
-                                                          float* __restrict__ action, int lda, int rows, int H, int a,
-                                                          const Squash sq) {
+__global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs jobs, const float* __restrict__ W4, int ldw4,
+                                                          const float* __restrict__ b4, int ldpre, int ldn, float stddev,
+                                                          float clip, int ldmu, int rows, int H, int a, const Squash sq) {
+    const PolicyHeadJob& jb = jobs.j[blockIdx.y];
+    const float* __restrict__ P = jb.P;
+    const int ldp_ = jb.ldp;
+    float* __restrict__ premu = jb.premu;
+    const float* __restrict__ noise = jb.noise;
+    float* __restrict__ mu = jb.mu;
+    float* __restrict__ action = jb.action;
+    const int lda = jb.lda;
     extern __shared__ float ph_lds[];              // [NA][H]
     for (int k4 = threadIdx.x; k4 < H / 4; k4 += 256) {
         float4 v[NA];
@@ -781,13 +788,13 @@ bool policy_head_ok(int H, int na) {
     return inst && (H & 3) == 0 && (size_t)na * H * sizeof(float) <= 48 * 1024;
 }
 
-hipError_t launch_policy_head(const float* P, int ldp_, const float* W4, int ldw4, const float* b4, float* premu, int ldpre,
-                              const float* noise, int ldn, float stddev, float clip, float* mu, int ldmu, float* action,
-                              int lda, int rows, int H, int a, int na, Squash sq, hipStream_t s) {
-    if (!policy_head_ok(H, na) || (na != a && na != 2 * a) || (ldw4 & 3)) return hipErrorInvalidValue;
+hipError_t launch_policy_head(const PolicyHeadJobs& jobs, const float* W4, int ldw4, const float* b4, int ldpre, int ldn,
+                              float stddev, float clip, int ldmu, int rows, int H, int a, int na, Squash sq, hipStream_t s) {
+    if (!policy_head_ok(H, na) || (na != a && na != 2 * a) || (ldw4 & 3) || jobs.n < 1 || jobs.n > PH_MAX_JOBS)
+        return hipErrorInvalidValue;
 #define PH_LAUNCH(NB)                                                                                                     \
-    hipLaunchKernelGGL(policy_head_kernel<NB>, dim3((rows + 3) / 4), dim3(256), (size_t)na * H * sizeof(float), s, P, ldp_, W4,  \
-                       ldw4, b4, premu, ldpre, noise, ldn, stddev, clip, mu, ldmu, action, lda, rows, H, a, sq)
+    hipLaunchKernelGGL(policy_head_kernel<NB>, dim3((rows + 3) / 4, jobs.n), dim3(256), (size_t)na * H * sizeof(float), s, jobs,  \
+                       W4, ldw4, b4, ldpre, ldn, stddev, clip, ldmu, rows, H, a, sq)
     switch (na) {
         case 3: PH_LAUNCH(3); break;
         case 6: PH_LAUNCH(6); break;
