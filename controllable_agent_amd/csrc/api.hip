@@ -1000,6 +1000,14 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
     // layer by layer the two passes are two problems of the same launches (own activation sets: w.as / w.asT)
     static const bool awt_env = [] { const char* e = getenv("FBHIP_ACTOR_WITH_TARGET"); return !(e && e[0] == '0'); }();
     const bool actor_with_target = awt_env && (mask & FBHIP_PHASE_FB_FWD_TARGET) && (mask & FBHIP_PHASE_ACTOR_FWD);
+    // The optimiser counters are advanced by the first kernel of the call that precedes the optimiser pass anyway:
+    // pairwise_reduce_kernel for fb_opt (3 = both optimisers when the call also holds the actor step), actor_q_kernel for a
+    // lone actor step; calls that hold only the STEP phase launch step_advance_kernel.
+    static const bool adv_env = [] { const char* e = getenv("FBHIP_FUSED_STEP_ADVANCE"); return !(e && e[0] == '0'); }();
+    const int fb_adv_which = (mask & FBHIP_PHASE_ACTOR_STEP) ? 3 : 0;
+    const bool fb_adv = adv_env && (mask & FBHIP_PHASE_FB_BWD_A) && (mask & FBHIP_PHASE_FB_STEP);
+    const bool actor_adv = adv_env && (mask & FBHIP_PHASE_ACTOR_GRAD) && (mask & FBHIP_PHASE_ACTOR_STEP) &&
+                           !(mask & FBHIP_PHASE_FB_STEP);
     const bool early_actor = !actor_with_target && (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
     // policy head + sample: one row kernel when the head's width has an instantiation and its weight fits 48 KB of LDS,
     // else head GEMM (in the chain) + sample
@@ -1065,12 +1073,13 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             const size_t ps = (size_t)Bg * Lz;
             HIPCK(c, launch_pairwise_fb_block(G, G + ps, G + 2 * ps, G + 3 * ps, G + 4 * ps, G + 5 * ps, c->gb_discount, Bg, z,
                                               Lz, hp.ortho_coef, c->gb_off, B, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics,
-                                              w.pw_scratch, s));
+                                              w.pw_scratch, s, fb_adv ? w.st : nullptr, fb_adv_which));
             if (hp.want_metrics || hp.q_loss)   // B^T B over the global rows (identical on every rank)
                 RC(run_gemms(c, {P(G + 2 * ps, Lz, 0, G + 2 * ps, Lz, 0, w.cov.p, w.cov.ld, z, z, Bg)}, s));
         } else {
             HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, BmO, w.fsT.F1.p, w.fsT.F2.p, BmT, w.disc, B, z,
-                                        Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s));
+                                        Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s,
+                                        fb_adv ? w.st : nullptr, fb_adv_which));
             if (hp.want_metrics || hp.q_loss)   // B^T B: metrics (fb_ddpg.py:371) and the q_loss covariance (:334)
                 RC(run_gemms(c, {P(BmO, Lz, 0, BmO, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
         }
@@ -1108,7 +1117,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 
     if (mask & FBHIP_PHASE_FB_STEP) {           // fb_opt.step() (:384) + soft_update_params x2 (:500-503)
         POST_BEGIN
-        HIPCK(c, launch_step_advance(w.st, ((mask & FBHIP_PHASE_ACTOR_STEP) ? 3 : 0), s));   // 3 = both optimisers
+        if (!fb_adv) HIPCK(c, launch_step_advance(w.st, fb_adv_which, s));   // (else pairwise_reduce_kernel did it)
         const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
         HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf,
                                  hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, s));
@@ -1139,7 +1148,8 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             o2.post.push_back([=, &w](hipStream_t q) -> int {
                 HIPCK(c, launch_actor_q(w.fsO.p.p, 2 * H, w.dp.p, 2 * H, w.z.p, Lz, c->F_p.b4[0], c->F_p.b4[1], w.as.mu.p, La,
                                         w.Xopi.p + aoff, w.Xopi.ld, hp.stddev, hp.want_metrics ? w.metrics : nullptr,
-                                        w.pw_scratch, B, H, z, a, c->sq, w.as.premu.p, Lh, w.so.eps_actor, a, q));
+                                        w.pw_scratch, B, H, z, a, c->sq, w.as.premu.p, Lh, w.so.eps_actor, a, q,
+                                        actor_adv ? w.st : nullptr, 1));
                 return (int)FBHIP_OK;
             });
         });
@@ -1201,7 +1211,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 
     if (mask & FBHIP_PHASE_ACTOR_STEP) {        // actor_opt.step(), fb_ddpg.py:411
         POST_BEGIN
-        if (!(mask & FBHIP_PHASE_FB_STEP)) HIPCK(c, launch_step_advance(w.st, 1, s));
+        if (!(mask & FBHIP_PHASE_FB_STEP) && !actor_adv) HIPCK(c, launch_step_advance(w.st, 1, s));   // (else actor_q_kernel did it)
         const int64_t na = c->L[FBHIP_NET_ACTOR].numel;
         HIPCK(c, launch_adam_ema(c->a_p, c->a_g, c->a_m, c->a_v, nullptr, na, hp.lr, hp.lr, na, hp.grad_scale, 0.f, w.st,
                                  1, 0, s));

@@ -109,10 +109,12 @@ hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const fl
 
 // the update's actor phase: Q and d p straight from the heads' hidden activations p [rows, 2H] and V = z . W4 [rows, 2H]
 // (overwritten with d p); see actor_q_kernel
+struct StepState;
 hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const float* z, int ldz, const float* b41,
                           const float* b42, const float* mu, int ldmu, const float* action, int lda, float stddev,
                           float* metrics, float* scratch /* >= 3*ceil(rows/4) floats */, int rows, int H, int d, int a,
-                          Squash sq, const float* pre, int ldp, const float* noise, int ldn, hipStream_t s);
+                          Squash sq, const float* pre, int ldp, const float* noise, int ldn, hipStream_t s,
+                          StepState* adv = nullptr, int adv_which = 0 /* also does step_advance(adv, adv_which), see there */);
 
 // policy head (premu = p . W4^T + b4, na = a or 2a outputs) + policy_sample in one row kernel (policy_head_kernel)
 bool policy_head_ok(int H, int na);
@@ -137,12 +139,12 @@ size_t pairwise_scratch_floats(int B, int d);
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1,
                               const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
                               float ortho_coef, float* dF1, float* dF2, float* dB, float* metrics,
-                              float* scratch, hipStream_t s);
+                              float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0);
 // rows [row_off, row_off + rows) of the same loss on B-row panels (global-batch data parallel); outputs are [rows, ld]
 hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1,
                                     const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
                                     float ortho_coef, int row_off, int rows, float* dF1, float* dF2, float* dB,
-                                    float* metrics, float* scratch, hipStream_t s);
+                                    float* metrics, float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0);
 // dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB))      (F.normalize backward)
 hipError_t launch_l2norm_bwd(const float* dB, int lddb, const float* y, int ldy, const float* norms,
                              float* dy, int lddy, int rows, int d, hipStream_t s);
@@ -166,6 +168,22 @@ hipError_t launch_qloss(const float* F1, const float* F2, const float* tF1, cons
                         const float* z, int ld, const float* discount, float coef, float* dF1, float* dF2,
                         float* metrics, float* scratch /* >= ceil(rows/4) floats */, int rows, int d, hipStream_t s,
                         int norm_rows = 0 /* the mean's row count when ``rows`` is a block of a larger batch */);
+// Adam step counters + fp64 bias corrections (which: 0 fb, 1 actor, 3 both, 2 rng counter).  A launch of its own
+// (launch_step_advance) or the first thread of a kernel that precedes the optimiser pass in the same stream anyway
+// (pairwise_reduce_kernel, actor_q_kernel: ``adv`` arguments) -- one dispatch less on the dependency chain.
+__device__ inline void step_advance_device(StepState* st, int which) {
+    if (which == 2) { st->update_count += 1u; return; }
+    if (which == 0 || which == 3) {
+        const int t = ++st->fb_t;
+        st->fb_bc1 = 1.0 - pow(0.9, (double)t);
+        st->fb_bc2_sqrt = sqrt(1.0 - pow(0.999, (double)t));
+    }
+    if (which == 1 || which == 3) {
+        const int t = ++st->actor_t;
+        st->actor_bc1 = 1.0 - pow(0.9, (double)t);
+        st->actor_bc2_sqrt = sqrt(1.0 - pow(0.999, (double)t));
+    }
+}
 hipError_t launch_step_advance(StepState* st, int which /*0 fb, 1 actor, 2 rng*/, hipStream_t s);
 hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel,
                            float lr, float lr2, int64_t split, float grad_scale, float tau,

@@ -13,20 +13,7 @@ namespace fbhip {
 
 __global__ void step_advance_kernel(StepState* st, int which) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (which == 2) {
-        st->update_count += 1u;
-        return;
-    }
-    if (which == 0 || which == 3) {
-        const int t = ++st->fb_t;
-        st->fb_bc1 = 1.0 - pow(0.9, (double)t);
-        st->fb_bc2_sqrt = sqrt(1.0 - pow(0.999, (double)t));
-    }
-    if (which == 1 || which == 3) {
-        const int t = ++st->actor_t;
-        st->actor_bc1 = 1.0 - pow(0.9, (double)t);
-        st->actor_bc2_sqrt = sqrt(1.0 - pow(0.999, (double)t));
-    }
+    step_advance_device(st, which);
 }
 
 hipError_t launch_step_advance(StepState* st, int which, hipStream_t s) {

@@ -307,7 +307,8 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
                                                               int Bglobal /* normalisers of the metrics */,
                                                               float ortho_coef, float* __restrict__ dF1,
                                                               float* __restrict__ dF2, float* __restrict__ dB,
-                                                              float* __restrict__ metrics) {
+                                                              float* __restrict__ metrics, StepState* adv, int adv_which) {
+    if (adv != nullptr && blockIdx.x == 0 && threadIdx.x == 255) step_advance_device(adv, adv_which);
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx < B * d) {
         const int r = idx / d, n = idx % d;
@@ -415,9 +416,10 @@ hipError_t pairwise_prepare(int B, int d) {
 
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
                               const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
-                              float* dF1, float* dF2, float* dB, float* metrics, float* scratch, hipStream_t s) {
+                              float* dF1, float* dF2, float* dB, float* metrics, float* scratch, hipStream_t s,
+                              StepState* adv, int adv_which) {
     return launch_pairwise_fb_block(F1, F2, Bm, tF1, tF2, tB, discount, B, d, ld, ortho_coef, 0, B, dF1, dF2, dB, metrics,
-                                    scratch, s);
+                                    scratch, s, adv, adv_which);
 }
 
 // Rows [row_off, row_off + rows) of the loss on B-row panels: dF_i and dB of THOSE rows (each complete: the workgroups walk
@@ -425,7 +427,7 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
 hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
                                     const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
                                     int row_off, int rows, float* dF1, float* dF2, float* dB, float* metrics,
-                                    float* scratch, hipStream_t s) {
+                                    float* scratch, hipStream_t s, StepState* adv, int adv_which) {
     const PwPlan pl = make_plan(B, d, rows);
     if (pl.ks < 0 || B < 2 || rows < 1 || row_off < 0 || row_off + rows > B) return hipErrorInvalidValue;
     if (rows != B && ((row_off & 31) || (rows & 31))) return hipErrorInvalidValue;      // whole 32-row blocks
@@ -459,7 +461,8 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     if (e != hipSuccess) return e;
     const int total = rows * d;
     hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.scal,
-                       pl.nchunks, pl.nchunks * pl.nI, rows, pl.Bp, d, pl.dp, ld, B, ortho_coef, dF1, dF2, dB, metrics);
+                       pl.nchunks, pl.nchunks * pl.nI, rows, pl.Bp, d, pl.dp, ld, B, ortho_coef, dF1, dF2, dB, metrics, adv,
+                       adv_which);
     return hipGetLastError();
 }
 

@@ -601,8 +601,9 @@ __global__ void __launch_bounds__(256) actor_q_kernel(const float* __restrict__ 
                                                       const float* __restrict__ mu, int ldmu, const float* __restrict__ act,
                                                       int lda, float stddev, float* __restrict__ part, int rows, int H, int d,
                                                       int a, const Squash sq, const float* __restrict__ pre, int ldp,
-                                                      const float* __restrict__ noise, int ldn) {
+                                                      const float* __restrict__ noise, int ldn, StepState* adv, int adv_which) {
     __shared__ float red[4][3];
+    if (adv != nullptr && blockIdx.x == 0 && threadIdx.x == 255) step_advance_device(adv, adv_which);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wid;
     const float inv_b = 1.0f / (float)rows;
@@ -693,12 +694,12 @@ hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const fl
 hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const float* z, int ldz, const float* b41,
                           const float* b42, const float* mu, int ldmu, const float* action, int lda, float stddev,
                           float* metrics, float* scratch, int rows, int H, int d, int a, Squash sq, const float* pre, int ldp,
-                          const float* noise, int ldn, hipStream_t s) {
+                          const float* noise, int ldn, hipStream_t s, StepState* adv, int adv_which) {
     if ((H & 3) || (ldp_ & 3) || (ldv & 3) || a > 64 || scratch == nullptr) return hipErrorInvalidValue;
     if (sq.on && (pre == nullptr || noise == nullptr)) return hipErrorInvalidValue;
     const int nblk = (rows + 3) / 4;
     hipLaunchKernelGGL(actor_q_kernel, dim3(nblk), dim3(256), 0, s, P, ldp_, V, ldv, z, ldz, b41, b42, mu, ldmu, action, lda,
-                       stddev, scratch, rows, H, d, a, sq, pre, ldp, noise, ldn);
+                       stddev, scratch, rows, H, d, a, sq, pre, ldp, noise, ldn, adv, adv_which);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
     hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17,
