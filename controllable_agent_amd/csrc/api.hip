@@ -770,7 +770,7 @@ int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet&
 
 // backward of BackwardMap from dB (gradient wrt the projected embedding)
 void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S, int rows,
-                            Chain& out) {
+                            Chain& out, bool dy_done = false) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
     // weight gradient of the first layer: X must be a zero-padded panel to use the padded width
@@ -780,7 +780,7 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
     BSet* Sp = &S;
     const float* dy = d.norm_z ? w->dy.p : w->dBm.p;    // no projection: the gradient wrt y is dB itself
     out.push_back([=](Ops& o) {                 // dy = d/dy of sqrt(d) normalize(y)   (F.normalize backward)
-        if (!c->d.norm_z) return;
+        if (!c->d.norm_z || dy_done) return;     // (the stage stays, empty: the chain's thin last round must meet forward_net's)
         o.post.push_back([=](hipStream_t s) -> int {
             HIPCK(c, launch_l2norm_bwd(w->dBm.p, Lz, Sp->y.p, Lz, Sp->norms, w->dy.p, Lz, rows, z, s));
             return (int)FBHIP_OK;
@@ -1008,6 +1008,10 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
     const bool fb_adv = adv_env && (mask & FBHIP_PHASE_FB_BWD_A) && (mask & FBHIP_PHASE_FB_STEP);
     const bool actor_adv = adv_env && (mask & FBHIP_PHASE_ACTOR_GRAD) && (mask & FBHIP_PHASE_ACTOR_STEP) &&
                            !(mask & FBHIP_PHASE_FB_STEP);
+    // d/dy of B = sqrt(d) y/|y| is a row operation on the loss kernel's own output dB: pairwise_reduce_kernel does it when the
+    // call continues with the backward (the BackwardMap chain then skips its l2norm_bwd launch)
+    static const bool dy_env = [] { const char* e = getenv("FBHIP_FUSED_L2NORM_BWD"); return !(e && e[0] == '0'); }();
+    const bool fused_dy = dy_env && d.norm_z && (mask & FBHIP_PHASE_FB_BWD_A) && pad4(z) == w.bsO.y.ld && z <= 128;
     const bool early_actor = !actor_with_target && (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
     // policy head + sample: one row kernel when the head's width has an instantiation and its weight fits 48 KB of LDS,
     // else head GEMM (in the chain) + sample
@@ -1073,13 +1077,14 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             const size_t ps = (size_t)Bg * Lz;
             HIPCK(c, launch_pairwise_fb_block(G, G + ps, G + 2 * ps, G + 3 * ps, G + 4 * ps, G + 5 * ps, c->gb_discount, Bg, z,
                                               Lz, hp.ortho_coef, c->gb_off, B, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics,
-                                              w.pw_scratch, s, fb_adv ? w.st : nullptr, fb_adv_which));
+                                              w.pw_scratch, s, fb_adv ? w.st : nullptr, fb_adv_which,
+                                              fused_dy ? w.bsO.y.p : nullptr, w.bsO.norms, w.dy.p));
             if (hp.want_metrics || hp.q_loss)   // B^T B over the global rows (identical on every rank)
                 RC(run_gemms(c, {P(G + 2 * ps, Lz, 0, G + 2 * ps, Lz, 0, w.cov.p, w.cov.ld, z, z, Bg)}, s));
         } else {
             HIPCK(c, launch_pairwise_fb(w.fsO.F1.p, w.fsO.F2.p, BmO, w.fsT.F1.p, w.fsT.F2.p, BmT, w.disc, B, z,
                                         Lz, hp.ortho_coef, w.dF1.p, w.dF2.p, w.dBm.p, w.metrics, w.pw_scratch, s,
-                                        fb_adv ? w.st : nullptr, fb_adv_which));
+                                        fb_adv ? w.st : nullptr, fb_adv_which, fused_dy ? w.bsO.y.p : nullptr, w.bsO.norms, w.dy.p));
             if (hp.want_metrics || hp.q_loss)   // B^T B: metrics (fb_ddpg.py:371) and the q_loss covariance (:334)
                 RC(run_gemms(c, {P(BmO, Lz, 0, BmO, Lz, 0, w.cov.p, w.cov.ld, z, z, B)}, s));
         }
@@ -1102,7 +1107,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             // starts the all-reduce of that range in between and hides it under FB_BWD_B.
             std::vector<Chain> ch(3);
             forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
-            backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1]);
+            backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1], fused_dy);
             if (early_actor) {
                 actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2], !fused_policy);
                 ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));

@@ -139,12 +139,15 @@ size_t pairwise_scratch_floats(int B, int d);
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1,
                               const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
                               float ortho_coef, float* dF1, float* dF2, float* dB, float* metrics,
-                              float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0);
+                              float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0,
+                              const float* y = nullptr /* + norms, dy: also the backward of B = sqrt(d) y/|y| (rows [.,ld]) */,
+                              const float* norms = nullptr, float* dy = nullptr);
 // rows [row_off, row_off + rows) of the same loss on B-row panels (global-batch data parallel); outputs are [rows, ld]
 hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1,
                                     const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
                                     float ortho_coef, int row_off, int rows, float* dF1, float* dF2, float* dB,
-                                    float* metrics, float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0);
+                                    float* metrics, float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0, const float* y = nullptr,
+                                    const float* norms = nullptr, float* dy = nullptr);
 // dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB))      (F.normalize backward)
 hipError_t launch_l2norm_bwd(const float* dB, int lddb, const float* y, int ldy, const float* norms,
                              float* dy, int lddy, int rows, int d, hipStream_t s);

@@ -307,21 +307,51 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
                                                               int Bglobal /* normalisers of the metrics */,
                                                               float ortho_coef, float* __restrict__ dF1,
                                                               float* __restrict__ dF2, float* __restrict__ dB,
-                                                              float* __restrict__ metrics, StepState* adv, int adv_which) {
+                                                              float* __restrict__ metrics, StepState* adv, int adv_which,
+                                                              const float* __restrict__ y, const float* __restrict__ norms,
+                                                              float* __restrict__ dy) {
     if (adv != nullptr && blockIdx.x == 0 && threadIdx.x == 255) step_advance_device(adv, adv_which);
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < B * d) {
-        const int r = idx / d, n = idx % d;
-        float a = 0.f, b = 0.f, c = 0.f;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const float* base = partial + ((size_t)ch * PW_SLOTS * Bp + r) * DP + n;
-            a += base[0];
-            b += base[(size_t)Bp * DP];
-            c += base[(size_t)2 * Bp * DP] + base[(size_t)3 * Bp * DP];
+    // one wavefront per row (d <= 128: two elements per lane); with ``y`` the backward of B = sqrt(d) y / |y|
+    // (dy = (sqrt(d)/|y|)(dB - yhat (yhat . dB)), exactly l2norm_bwd_kernel) follows in the same registers
+    {
+        const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (r < B) {
+            float cc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = lane + 64 * i;
+                float a = 0.f, b = 0.f, c = 0.f;
+                if (n < d) {
+                    for (int ch = 0; ch < nchunks; ++ch) {
+                        const float* base = partial + ((size_t)ch * PW_SLOTS * Bp + r) * DP + n;
+                        a += base[0];
+                        b += base[(size_t)Bp * DP];
+                        c += base[(size_t)2 * Bp * DP] + base[(size_t)3 * Bp * DP];
+                    }
+                    dF1[(size_t)r * ld + n] = a;
+                    dF2[(size_t)r * ld + n] = b;
+                    dB[(size_t)r * ld + n] = c;
+                }
+                cc[i] = c;
+            }
+            if (y != nullptr) {
+                const float inv = 1.0f / fmaxf(norms[r], 1e-12f);
+                float yh[2], dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int n = lane + 64 * i;
+                    yh[i] = n < d ? y[(size_t)r * ld + n] * inv : 0.f;
+                    dot += yh[i] * cc[i];
+                }
+                dot = wsum(dot);
+                const float scale = sqrtf((float)d);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int n = lane + 64 * i;
+                    if (n < d) dy[(size_t)r * ld + n] = scale * inv * (cc[i] - yh[i] * dot);
+                }
+            }
         }
-        dF1[(size_t)r * ld + n] = a;
-        dF2[(size_t)r * ld + n] = b;
-        dB[(size_t)r * ld + n] = c;
     }
     if (blockIdx.x == 0) {
         // workgroup 0: wave w folds scalar slots w, w+4, w+8 over all workgroups -- each lane a strided slice in
@@ -417,9 +447,9 @@ hipError_t pairwise_prepare(int B, int d) {
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
                               const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
                               float* dF1, float* dF2, float* dB, float* metrics, float* scratch, hipStream_t s,
-                              StepState* adv, int adv_which) {
+                              StepState* adv, int adv_which, const float* y, const float* norms, float* dy) {
     return launch_pairwise_fb_block(F1, F2, Bm, tF1, tF2, tB, discount, B, d, ld, ortho_coef, 0, B, dF1, dF2, dB, metrics,
-                                    scratch, s, adv, adv_which);
+                                    scratch, s, adv, adv_which, y, norms, dy);
 }
 
 // Rows [row_off, row_off + rows) of the loss on B-row panels: dF_i and dB of THOSE rows (each complete: the workgroups walk
@@ -427,7 +457,8 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
 hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
                                     const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
                                     int row_off, int rows, float* dF1, float* dF2, float* dB, float* metrics,
-                                    float* scratch, hipStream_t s, StepState* adv, int adv_which) {
+                                    float* scratch, hipStream_t s, StepState* adv, int adv_which, const float* y,
+                                    const float* norms, float* dy) {
     const PwPlan pl = make_plan(B, d, rows);
     if (pl.ks < 0 || B < 2 || rows < 1 || row_off < 0 || row_off + rows > B) return hipErrorInvalidValue;
     if (rows != B && ((row_off & 31) || (rows & 31))) return hipErrorInvalidValue;      // whole 32-row blocks
@@ -459,10 +490,10 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     if (e != hipSuccess) return e;
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int total = rows * d;
-    hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a.partial, a.scal,
+    if (d > 128 || (y != nullptr && (norms == nullptr || dy == nullptr))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a.partial, a.scal,
                        pl.nchunks, pl.nchunks * pl.nI, rows, pl.Bp, d, pl.dp, ld, B, ortho_coef, dF1, dF2, dB, metrics, adv,
-                       adv_which);
+                       adv_which, y, norms, dy);
     return hipGetLastError();
 }
 
