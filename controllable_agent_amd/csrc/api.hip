@@ -1063,6 +1063,15 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                 ch.emplace_back();
                 backward_map_fwd_chain(c, c->K_p, next_goal, ld_ng, w.bsO, B, ch.back());
             }
+            // both ForwardMap chains in one call: the online heads' thin output layer (+ its split-K reduce) waits for the round
+            // of the target chain's, five rounds later -- one launch pair instead of two, nothing needs it earlier
+            static const bool align_env = [] { const char* e = getenv("FBHIP_ALIGN_HEADS"); return !(e && e[0] == '0'); }();
+            if (align_env && ch[0].size() > ch[1].size() && !ch[1].empty()) {
+                Stage heads = ch[1].back();
+                ch[1].pop_back();
+                while (ch[1].size() + 1 < ch[0].size()) ch[1].push_back([](Ops&) {});
+                ch[1].push_back(heads);
+            }
             prog_parallel(prog, ch);
         }
     }
