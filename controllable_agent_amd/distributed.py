@@ -39,6 +39,9 @@ PHASE_FB_GRAD = PHASE_FB_FWD | PHASE_FB_BWD
 PHASE_ALL = 511
 
 
+_COALESCE_OK = True
+
+
 def world_size() -> int:
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -69,15 +72,21 @@ def _reduce_fb(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, ear
     run_phases(PHASE_FB_BWD_B | second)
     work.wait()
     rest = [t for t in (fb_grads[:off], fb_grads[off + cnt:]) if t.numel() > 0]
-    if len(rest) == 2 and dist.get_backend() == "nccl":
-        # one grouped RCCL launch for the two remaining slices (trunks | backward_net) instead of two latencies
-        from torch.distributed.distributed_c10d import _coalescing_manager
-        with _coalescing_manager(device=fb_grads.device):
-            for t in rest:
-                dist.all_reduce(t)
-    else:
-        for t in rest:
-            dist.all_reduce(t)
+    global _COALESCE_OK
+    if len(rest) == 2 and _COALESCE_OK and dist.get_backend() == "nccl":
+        # one grouped RCCL launch for the two remaining slices (trunks | backward_net) instead of two latencies.  The context
+        # manager is a private torch API: if it is missing or refuses, fall back to two plain calls for good -- nothing has
+        # been reduced yet when it raises on entry / exit without having issued the group
+        try:
+            from torch.distributed.distributed_c10d import _coalescing_manager
+            with _coalescing_manager(device=fb_grads.device):
+                for t in rest:
+                    dist.all_reduce(t)
+            return
+        except (ImportError, AttributeError, TypeError, ValueError, NotImplementedError):
+            _COALESCE_OK = False
+    for t in rest:
+        dist.all_reduce(t)
 
 
 def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, actor_grads: torch.Tensor,
