@@ -966,6 +966,12 @@ hipError_t actor_head_bwd_prepare(int H, int a) {
     }
 #define AHB_ATTR(NA, EX) AHB_ATTR1(NA, EX, 0) AHB_ATTR1(NA, EX, 16) AHB_ATTR1(NA, EX, 32)
     switch (a) {
+        case 1: AHB_ATTR(1, true); break;
+        case 2: AHB_ATTR(2, true); break;
+        case 3: AHB_ATTR(3, true); break;
+        case 4: AHB_ATTR(4, true); break;
+        case 5: AHB_ATTR(5, true); break;
+        case 6: AHB_ATTR(6, true); break;
         case 7: AHB_ATTR(7, true); break;
         case 8: AHB_ATTR(8, true); break;
         case 12: AHB_ATTR(12, true); break;
