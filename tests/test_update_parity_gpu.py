@@ -2,6 +2,7 @@
   (1) the golden traces recorded from the real reference (tests/golden/*.npz|json), and
   (2) the oracle replaying the same injected draws,
 teacher-forced (tight tolerances) and free-running (the reference's own fp32 drift envelope)."""
+import dataclasses
 import numpy as np
 import types
 
@@ -654,5 +655,71 @@ def test_one_update_at_the_edges_of_the_supported_dimensions(dims):
             # the FIRST Adam step moves every entry by lr g / (|g| + 1e-8) ~ +-lr: an entry whose gradient is rounding noise
             # (|g| ~ 1e-8 next to typical 1e-3) can get the opposite sign on the two sides, i.e. differ by up to 2 lr
             _param_close(v, want[k], cfg.lr, k, max_step=2.0, one_in=250)
+    for nv in (agent.forward_net, agent.backward_net, agent.actor, *agent._grad_views.values()):
+        assert nv.pad_abs_max() == 0.0, nv._name
+
+
+def _random_case(seed):
+    r = np.random.default_rng(seed)
+    use_goal = bool(r.integers(0, 2))
+    cfg = dict(obs_dim=int(r.integers(2, 12)), action_dim=int(r.integers(1, 9)), z_dim=int(r.integers(3, 40)),
+               hidden_dim=4 * int(r.integers(4, 24)), feature_dim=4 * int(r.integers(2, 12)),
+               backward_hidden_dim=int(r.integers(5, 70)), batch_size=int(r.integers(4, 80)),
+               q_loss=bool(r.integers(0, 2)), norm_z=bool(r.integers(0, 4) > 0), add_trunk=bool(r.integers(0, 3) == 0),
+               preprocess=bool(r.integers(0, 3) > 0), boltzmann=bool(r.integers(0, 3) == 0), rand_weight=bool(r.integers(0, 3) == 0),
+               mix_ratio=float(r.choice([0.0, 0.3, 0.5, 1.0])), lr_coef=float(r.choice([1.0, 0.5])), ortho_coef=float(r.choice([1.0, 0.1])),
+               temp=float(r.choice([1.0, 0.2])), lr=1e-3)
+    hindsight = bool(r.integers(0, 3) == 0)
+    if hindsight:
+        cfg.update(future_ratio=0.4, future=0.8)
+    if use_goal:                                   # the two goal spaces get_goal_space_dim knows (goals.py:66-73, 97-103)
+        cfg.update(goal_dim=int(r.choice([2, 3])), use_goal=True)
+    else:
+        cfg["goal_dim"] = cfg["obs_dim"]
+    if cfg["q_loss"]:                              # torch.inverse of B^T B / batch (fb_ddpg.py:334-335) needs full rank: B = W3 h + b has
+        cfg["batch_size"] = max(cfg["batch_size"], 3 * cfg["z_dim"])      # rank <= min(batch, backward_hidden_dim + 1); a singular
+        cfg["backward_hidden_dim"] = max(cfg["backward_hidden_dim"], cfg["z_dim"] + 8)   # covariance inverts to noise on both sides
+    return fo.OracleConfig(**cfg), ({2: "simplified_quadruped", 3: "simplified_walker"}[cfg["goal_dim"]] if use_goal else None)
+
+
+@pytest.mark.parametrize("seed", list(range(300, 400)))
+def test_random_configurations_one_update_against_the_oracle(seed):
+    """A hundred seeded random draws over dimensions and every config switch of the step (goal space, q_loss, norm_z, add_trunk,
+    preprocess, boltzmann, rand_weight, hindsight replay, mix_ratio incl. 0 and 1, lr_coef, ortho_coef, temp): one injected
+    update, losses and every gradient tensor against the oracle.  Combinations no hand-written case covers."""
+    cfg, goal_space = _random_case(seed)
+    rng = np.random.default_rng(1000 + seed)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 6, 9, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if cfg.use_goal else None)
+    draws = fo.make_draws(rng, cfg, 6, lengths)
+    batch = fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount, draws.future_idx)
+    oracle = fo.OracleAgent(cfg, nets)
+    om = oracle.update(batch, draws, keep=True)
+    if cfg.q_loss:
+        Bm = oracle.last["Bm"].double()
+        if float(torch.linalg.cond(Bm.T @ Bm / Bm.shape[0])) > 1e6:    # singular in fp32 (e.g. a 2-d goal through an untrained B):
+            cfg = dataclasses.replace(cfg, q_loss=False)               # torch.inverse returns noise, on the reference too -- the draw
+            oracle = fo.OracleAgent(cfg, nets)                         # is kept, without q_loss
+            om = oracle.update(batch, draws, keep=True)
+    agent = H.make_hip_agent(cfg, nets, goal_space)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    m = agent.update_injected(rb, 0, H.draws_dict(draws))
+    # tolerances: q_loss inverts B^T B / batch (fb_ddpg.py:334-335) -- whatever both sides round differently is amplified by its
+    # condition number (1e2 .. 2e5 in these cases); the actor's gradients are taken AFTER the FB Adam step of the same update,
+    # whose first step moves every weight by +-lr whatever the gradient's size, and through torch.min(Q1, Q2) (one row of a small
+    # batch changing heads moves them by 1/batch), see the chaos calibration in DESIGN.md section 3
+    amp = 1.0
+    if cfg.q_loss:
+        Bm = oracle.last["Bm"].double()
+        amp = max(1.0, float(torch.linalg.cond(Bm.T @ Bm / Bm.shape[0])) / 1e3)
+    for k in H.LOSS_KEYS + (("q_loss",) if cfg.q_loss else ()):
+        assert m[k] == pytest.approx(om[k], rel=min(2e-4 * amp, 5e-2), abs=2e-5), (k, cfg)
+    for net, key, tol in (("forward_net", "grads_forward", 1e-3), ("backward_net", "grads_backward", 1e-3), ("actor", "grads_actor", 5e-2)):
+        for k, g in agent._grad_views[net].state_dict().items():
+            ref = oracle.last[key][k]
+            if float(ref.abs().max()) == 0.0:
+                assert float(g.abs().max()) == 0.0, (net, k, cfg)
+            else:
+                assert H.rel_err(g.cpu(), ref) < min(tol * amp, 0.2), (net, k, H.rel_err(g.cpu(), ref), cfg)
     for nv in (agent.forward_net, agent.backward_net, agent.actor, *agent._grad_views.values()):
         assert nv.pad_abs_max() == 0.0, nv._name
