@@ -29,6 +29,7 @@ HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parents[1]))
 
 from oracle import fb_oracle as fo  # noqa: E402  (helpers for synthetic weights / storage / draws)
+from oracle import discrete_fb_oracle as do  # noqa: E402
 
 
 # --------------------------------------------------------------------------- #
@@ -79,15 +80,17 @@ def import_reference():
     mod("url_benchmark.goals", get_goal_space_dim={"simplified_walker": 3, "simplified_quadruped": 2}.__getitem__)
     import url_benchmark  # noqa: F401
     mod("url_benchmark.agent").__path__ = [str(REF / "url_benchmark/agent")]
-    from url_benchmark.agent import fb_ddpg
+    from url_benchmark.agent import fb_ddpg, discrete_fb
     from url_benchmark.in_memory_replay_buffer import ReplayBuffer
     from url_benchmark import dmc, utils
-    return types.SimpleNamespace(fb_ddpg=fb_ddpg, ReplayBuffer=ReplayBuffer, dmc=dmc, utils=utils, StepType=StepType)
+    return types.SimpleNamespace(fb_ddpg=fb_ddpg, discrete_fb=discrete_fb, ReplayBuffer=ReplayBuffer, dmc=dmc, utils=utils,
+                                 StepType=StepType)
 
 
 # --------------------------------------------------------------------------- #
-def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
-    return R.fb_ddpg.FBDDPGAgent(
+def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, discrete=False, **extra):
+    cls = R.discrete_fb.DiscreteFBAgent if discrete else R.fb_ddpg.FBDDPGAgent
+    return cls(
         obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cpu",
         num_expl_steps=0, use_tb=True, use_wandb=False, use_hiplog=False, update_encoder=True,
         goal_space=goal_space, lr=cfg.lr, lr_coef=cfg.lr_coef, fb_target_tau=cfg.fb_target_tau,
@@ -100,7 +103,7 @@ def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, **extra):
 
 
 def load_nets(agent, nets):
-    for name in ("actor", "forward_net", "backward_net"):
+    for name in nets:
         getattr(agent, name).load_state_dict(nets[name])
     agent.forward_target_net.load_state_dict(agent.forward_net.state_dict())
     agent.backward_target_net.load_state_dict(agent.backward_net.state_dict())
@@ -127,7 +130,7 @@ def fill_ref_buffer(R, storage, lengths, discount, future=0.99, max_len=None, me
 
 
 @contextlib.contextmanager
-def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5):
+def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5, action_noise: bool = True):
     """Route every random draw of one ``update()`` to the prepared values."""
     calls = {"randint": 0, "uniform": 0}
     o_randint, o_choice, o_uniform, o_geo = np.random.randint, np.random.choice, np.random.uniform, np.random.geometric
@@ -187,15 +190,16 @@ def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5):
         np.random.randint, np.random.choice, np.random.uniform, np.random.geometric = o_randint, o_choice, o_uniform, o_geo
         torch.randperm, torch.randn, R.utils._standard_normal, torch.rand = o_randperm, o_randn, o_sn, o_rand
         torch.normal, tdn._standard_normal = o_normal, o_tdn_sn
-    assert not eps_queue, "update() did not consume both action-noise draws"
+    assert not eps_queue or not action_noise, "update() did not consume both action-noise draws"
 
 
 def ref_state(agent):
     out = {}
-    for n in ("actor", "forward_net", "backward_net", "forward_target_net", "backward_target_net"):
+    has_actor = hasattr(agent, "actor")          # DiscreteFBAgent has none
+    for n in (("actor",) if has_actor else ()) + ("forward_net", "backward_net", "forward_target_net", "backward_target_net"):
         for k, v in getattr(agent, n).state_dict().items():
             out[f"{n}/{k}"] = v.detach().numpy().copy()
-    for opt, nets in ((agent.actor_opt, ("actor",)), (agent.fb_opt, ("forward_net", "backward_net"))):
+    for opt, nets in (((agent.actor_opt, ("actor",)),) if has_actor else ()) + ((agent.fb_opt, ("forward_net", "backward_net")),):
         for n in nets:
             for (k, p) in getattr(agent, n).named_parameters():
                 st = opt.state.get(p, None)
@@ -212,21 +216,24 @@ def checksums(state):
 
 # --------------------------------------------------------------------------- #
 def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_space=None, variable_len=False,
-                  full_state=True, checksum_steps=()):
+                  full_state=True, checksum_steps=(), discrete=False):
     rng = np.random.default_rng(seed)
-    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    shapes = do.NET_SHAPES if discrete else fo.NET_SHAPES
+    nets = {n: fo.synthetic_params(rng, shapes[n](cfg)) for n in shapes}
     lengths = None
     if variable_len:
         lengths = rng.integers(max(2, T // 2), T + 1, size=n_eps).astype(np.int32)
         lengths[0] = T
     storage, lengths = fo.synthetic_storage(rng, n_eps, T, cfg.obs_dim, cfg.action_dim,
                                             cfg.goal_dim if cfg.use_goal else None, lengths)
-    agent = make_ref_agent(R, cfg, goal_space=goal_space)
+    if discrete:
+        do.synthetic_actions(rng, storage, cfg.action_dim)
+    agent = make_ref_agent(R, cfg, goal_space=goal_space, discrete=discrete)
     load_nets(agent, nets)
     rb = fill_ref_buffer(R, storage, lengths, cfg.discount, future=cfg.future, max_len=(T + 1) if variable_len else None)
     assert rb._is_fixed_episode_length == (not variable_len)
     arrays, meta = {}, {"name": name, "seed": seed, "n_eps": n_eps, "T": T, "n_steps": n_steps,
-                        "goal_space": goal_space, "variable_len": variable_len,
+                        "goal_space": goal_space, "variable_len": variable_len, "discrete": discrete,
                         "cfg": {k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, "metrics": [], "checksums": {}}
     if full_state:
         for n, p in nets.items():
@@ -237,7 +244,7 @@ def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_s
         arrays["lengths"] = lengths
     for s in range(n_steps):
         d = fo.make_draws(rng, cfg, n_eps, lengths)
-        with inject(R, d, variable_len, cfg.mix_ratio):
+        with inject(R, d, variable_len, cfg.mix_ratio, action_noise=not discrete):
             m = agent.update(rb, s)
         meta["metrics"].append({k: float(v) for k, v in m.items()})
         if full_state:
@@ -252,7 +259,7 @@ def trace_fixture(R, name, cfg: fo.OracleConfig, seed, n_eps, T, n_steps, goal_s
     if full_state:
         np.savez_compressed(HERE / f"{name}.npz", **arrays)
     print(f"[{name}] steps={n_steps} fb_loss={[round(m['fb_loss'], 4) for m in meta['metrics'][:3]]} "
-          f"actor_loss={[round(m['actor_loss'], 4) for m in meta['metrics'][:3]]}")
+          f"actor_loss={[round(m.get('actor_loss', float('nan')), 4) for m in meta['metrics'][:3]]}")
 
 
 def future_fixtures(R):
@@ -294,6 +301,17 @@ def boltzmann_fixture(R):
     trace_fixture(R, "tiny_boltzmann_goal_trace", tiny_cfg(boltzmann=True, temp=0.3, log_std_min=-3.0, log_std_max=1.0, goal_dim=3,
                                                            use_goal=True, z_dim=10, batch_size=24),
                   seed=112, n_eps=7, T=11, n_steps=3, goal_space="simplified_walker", variable_len=True)
+
+
+def discrete_fixture(R):
+    """DiscreteFBAgent.update (discrete_fb.py:277-468): [B, d, A] heads, greedy target column +
+    goal space + hindsight replay + variable lengths; softmax targets (boltzmann, temp) + q_loss (pinv) + norm_z=False"""
+    trace_fixture(R, "tiny_discrete_trace", tiny_cfg(action_dim=4, preprocess=False, goal_dim=3, use_goal=True, future=0.8,
+                                                     future_ratio=0.3, lr_coef=0.5),
+                  seed=120, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True, discrete=True)
+    trace_fixture(R, "tiny_discrete_boltz_trace", tiny_cfg(action_dim=3, preprocess=False, boltzmann=True, temp=0.7, q_loss=True,
+                                                           norm_z=False, batch_size=32, z_dim=6, backward_hidden_dim=20),
+                  seed=121, n_eps=6, T=12, n_steps=4, discrete=True)
 
 
 def sampler_fixture(R):
@@ -436,6 +454,7 @@ def main():
     trunk_fixture(R)
     single_trunk_fixture(R)
     boltzmann_fixture(R)
+    discrete_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from oracle import fb_oracle as fo
+from oracle import discrete_fb_oracle as do
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
@@ -24,7 +25,8 @@ def regenerate_inputs(meta: dict):
     """Recreate (nets, storage, lengths, rng) exactly as tests/golden/make_golden.py::trace_fixture did."""
     cfg = cfg_from_meta(meta)
     rng = np.random.default_rng(meta["seed"])
-    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    shapes = do.NET_SHAPES if meta.get("discrete") else fo.NET_SHAPES
+    nets = {n: fo.synthetic_params(rng, shapes[n](cfg)) for n in shapes}
     lengths = None
     n_eps, T = meta["n_eps"], meta["T"]
     if meta["variable_len"]:
@@ -32,6 +34,8 @@ def regenerate_inputs(meta: dict):
         lengths[0] = T
     storage, lengths = fo.synthetic_storage(rng, n_eps, T, cfg.obs_dim, cfg.action_dim,
                                             cfg.goal_dim if cfg.use_goal else None, lengths)
+    if meta.get("discrete"):
+        do.synthetic_actions(rng, storage, cfg.action_dim)
     return cfg, nets, storage, lengths, rng
 
 

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import fb_oracle as fo
+from oracle import discrete_fb_oracle as do
 from tests import helpers as H
 
 
@@ -18,7 +19,7 @@ def _replay(name, full_state):
                 np.testing.assert_array_equal(z[f"init/{n}/{k}"], v.numpy())
         for k, v in storage.items():
             np.testing.assert_array_equal(z[f"storage/{k}"], v)
-    agent = fo.OracleAgent(cfg, nets)
+    agent = do.DiscreteOracleAgent(cfg, nets) if meta.get("discrete") else fo.OracleAgent(cfg, nets)
     out = []
     for s in range(meta["n_steps"]):
         d = fo.make_draws(rng, cfg, meta["n_eps"], lengths)
@@ -36,11 +37,12 @@ def _replay(name, full_state):
 @pytest.mark.parametrize("name", ["tiny_trace", "tiny_goal_trace", "tiny_future_trace", "tiny_future_goal_trace", "tiny_nonorm_trace",
                                   "tiny_randw_trace", "tiny_randw_nonorm_trace", "tiny_trunk_trace",
                                   "tiny_single_trunk_trace", "tiny_single_trunk_goal_trace",
-                                  "tiny_boltzmann_trace", "tiny_boltzmann_goal_trace"])
+                                  "tiny_boltzmann_trace", "tiny_boltzmann_goal_trace",
+                                  "tiny_discrete_trace", "tiny_discrete_boltz_trace"])
 def test_tiny_traces_full_state(name):
     """Every parameter / target / Adam tensor after every step, tiny dims (incl. goal_space, q_loss,
     variable episode lengths, lr_coef != 1, hindsight replay with future_ratio > 0 on future < 1 buffers, norm_z=False,
-    rand_weight=True, add_trunk=True, preprocess=False, boltzmann=True).  Tolerance: abs 2e-6 on params (fp32, Adam lr 1e-3)."""
+    rand_weight=True, add_trunk=True, preprocess=False, boltzmann=True; the last two: DiscreteFBAgent, oracle/discrete_fb_oracle.py).  Tolerance: abs 2e-6 on params (fp32, Adam lr 1e-3)."""
     meta, z, out = _replay(name, True)
     for s, (m, state) in enumerate(out):
         for k, v in meta["metrics"][s].items():
