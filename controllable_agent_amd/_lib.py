@@ -28,7 +28,8 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK_RELU, EPI_TANH_BWD = range(5)
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
-                                          "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z", "boltzmann")]
+                                          "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z", "boltzmann",
+                                          "discrete")]
 
 
 class HParams(C.Structure):
@@ -82,6 +83,7 @@ PROTOTYPES = {
     "fbhip_act": (C.c_int, [_P, _P, _P, _P, _F, _I, _P, _P]),
     "fbhip_z_correl": (C.c_int, [_P, _P, _P, _P, _P]),
     "fbhip_forward_map": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P]),
+    "fbhip_discrete_act": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
     "fbhip_gemm": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "fbhip_gemm_cfg": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "fbhip_ln_tanh_fwd": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
@@ -114,7 +116,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 11:
+    if lib.fbhip_abi_version() != 12:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

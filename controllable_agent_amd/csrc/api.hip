@@ -75,7 +75,7 @@ struct Geom { bool single, trunk, boltz; int Fo, hw, feat; };
 Geom geom_of(const fbhip_dims& d) {
     Geom g;
     g.boltz = false;
-    g.single = d.preprocess == 0;
+    g.single = d.preprocess == 0 || d.discrete != 0;
     g.trunk = g.single || d.add_trunk != 0;
     g.Fo = g.single ? d.hidden_dim : d.feature_dim;          // a branch's output width
     g.hw = g.single ? d.hidden_dim : 2 * d.feature_dim;      // concatenated branch outputs
@@ -91,6 +91,10 @@ Geom actor_geom_of(const fbhip_dims& d) {
     return g;
 }
 inline int head_width(const fbhip_dims& d) { return d.boltzmann ? 2 * d.action_dim : d.action_dim; }
+// DiscreteFBAgent (dims.discrete, discrete_fb.py:52-101): action_dim is A, the NUMBER of actions.  The ForwardMap has no action
+// input (one trunk on [obs|z]) and its heads emit one embedding per action: z * A outputs, (k, a) at column k * A + a.
+inline int panel_action_cols(const fbhip_dims& d) { return d.discrete ? 0 : d.action_dim; }
+inline int fhead_out(const fbhip_dims& d) { return d.discrete ? d.z_dim * d.action_dim : d.z_dim; }
 
 std::vector<std::string> trunk_names(const std::string& p) {
     return {p + ".0.weight", p + ".0.bias", p + ".1.weight", p + ".1.bias", p + ".3.weight", p + ".3.bias"};
@@ -105,7 +109,7 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
     const Geom gm = geom_of(d);
     if (net == FBHIP_NET_FORWARD) {               // ForwardMap, fb_modules.py:165-182
         if (gm.single) {                          // trunk = mlp(o + z + a, H, "ntanh", H, "irelu", H, "irelu")
-            b.trunk("trunk", o + z + a, H, H);
+            b.trunk("trunk", o + z + panel_action_cols(d), H, H);
             b.mat("trunk.5.weight", H, H); b.vec("trunk.5.bias", H);
         } else {
             b.trunk("obs_action_net", o + a, H, Fd);
@@ -115,8 +119,8 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
         // F1/F2 first layers are stored back to back so both heads run as ONE [2H x feat] GEMM
         b.mat("F1.0.weight", H, gm.feat); b.mat("F2.0.weight", H, gm.feat);
         b.vec("F1.0.bias", H); b.vec("F2.0.bias", H);
-        b.mat("F1.2.weight", z, H); b.vec("F1.2.bias", z);
-        b.mat("F2.2.weight", z, H); b.vec("F2.2.bias", z);
+        b.mat("F1.2.weight", fhead_out(d), H); b.vec("F1.2.bias", fhead_out(d));
+        b.mat("F2.2.weight", fhead_out(d), H); b.vec("F2.2.bias", fhead_out(d));
         if (gm.single) {
             append(order, trunk_names("trunk")); append(order, {"trunk.5.weight", "trunk.5.bias"});
         } else {
@@ -132,6 +136,7 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
         b.mat("B.3.weight", Hb, Hb, HbP, HbP); b.vec("B.3.bias", Hb, HbP);
         b.mat("B.5.weight", z, Hb, HbP); b.vec("B.5.bias", z);
         order = {"B.0.weight", "B.0.bias", "B.1.weight", "B.1.bias", "B.3.weight", "B.3.bias", "B.5.weight", "B.5.bias"};
+    } else if (d.discrete) {                      // DiscreteFBAgent has no actor: empty layout
     } else if (d.boltzmann) {                     // DiagGaussianActor.policy = mlp(o + z, H, "ntanh", H, "relu", 2a)
         b.trunk("policy", o + z, H, H);
         b.mat("policy.5.weight", 2 * a, H); b.vec("policy.5.bias", 2 * a);
@@ -164,6 +169,8 @@ int check_dims(const fbhip_dims* d) {
     if (d->z_dim > 128) { g_err = "fbhip: z_dim > 128 unsupported (pairwise kernel)"; return FBHIP_E_INVALID; }
     if (d->action_dim > 64) { g_err = "fbhip: action_dim > 64 unsupported"; return FBHIP_E_INVALID; }
     if (d->batch > 8192) { g_err = "fbhip: batch > 8192 per GPU unsupported (permutation sort)"; return FBHIP_E_INVALID; }
+    if (d->discrete && d->preprocess) { g_err = "fbhip: discrete needs preprocess == 0 (the reference's discrete ForwardMap.forward only runs without the preprocess nets, discrete_fb.py:91-94)"; return FBHIP_E_INVALID; }
+    if (d->discrete && (int64_t)d->z_dim * d->action_dim > 8192) { g_err = "fbhip: discrete: z_dim * actions > 8192 unsupported"; return FBHIP_E_INVALID; }
     if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
     return FBHIP_OK;
 }
@@ -171,7 +178,7 @@ int check_dims(const fbhip_dims* d) {
 // ------------------------------------------------------------------------------------------------ workspace
 struct Buf { float* p = nullptr; int rows = 0, cols = 0, ld = 0; };
 struct BSet { Buf pre1, t1, r2, y, Bm; float* stats = nullptr; float* norms = nullptr; };
-struct FSet { Buf pre1a, t1a, pre1z, t1z, h, tr, p, F1, F2; float* statsA = nullptr; float* statsZ = nullptr; };
+struct FSet { Buf pre1a, t1a, pre1z, t1z, h, tr, p, F1, F2, Fall1, Fall2; float* statsA = nullptr; float* statsZ = nullptr; };   // Fall: discrete heads' [B, z * A]
 struct ASet { Buf pre1o, t1o, pre1z, t1z, h, tr, p, premu, mu; float* statsO = nullptr; float* statsZ = nullptr; };
 
 struct Ws {
@@ -184,6 +191,10 @@ struct Ws {
     BSet bsA, bsO, bsM, bsF; // target / online passes on next_goal, z-mix pass on backward_input[perm], hindsight pass
     FSet fsT, fsO;
     ASet as;
+    Buf dFall1, dFall2;      // discrete: dF scattered back to the [B, z * A] head outputs
+    float* act_idx = nullptr;           // discrete: the sampled transitions' action indices [B] (as stored: floats)
+    float* nextq = nullptr;             // discrete: next_Q [B] (discrete_fb.py:297, :302), read by the q_loss
+    int32_t* greedy = nullptr;          // discrete: arg-max action per row of the last selection
     Buf dF1, dF2, dBm, dy, dp, dtr, dh, dt1a, dt1z, b_dr2, b_dt1, a_dpremu, a_dp, a_dact, cov, inv_cov, BinvC;
     float* ln_partials = nullptr;
     float* ln_partials_b = nullptr;     // backward_net's own scratch: its backward runs concurrently with forward_net's
@@ -250,7 +261,7 @@ Ws carve(const fbhip_dims& d, void* base) {
         // preprocess == 0: the ForwardMap panels are [obs | z | action].  The actor keeps its own [obs|z] panels: a GEMM
         // runs over the weight's padded width, so whatever follows z in a shared panel would leak into the weight
         // gradient's pad columns and, through Adam, into the pad weights.
-        const int wd = o + z + a;
+        const int wd = o + z + panel_action_cols(d);
         w.Xoa = c.buf(B, wd, pad32(wd)); w.Xnoa = c.buf(B, wd, pad32(wd)); w.Xopi = c.buf(B, wd, pad32(wd));
         w.Xoz = c.buf(B, o + z, pad32(o + z)); w.Xnoz = c.buf(B, o + z, pad32(o + z));
     } else {
@@ -269,6 +280,7 @@ Ws carve(const fbhip_dims& d, void* base) {
     for (FSet* s : {&w.fsT, &w.fsO}) {
         s->pre1a = c.buf(B, H); s->t1a = c.buf(B, H); s->pre1z = c.buf(B, H); s->t1z = c.buf(B, H);
         s->h = c.buf(B, gm.hw); s->tr = c.buf(gm.trunk ? B : 1, H); s->p = c.buf(B, 2 * H); s->F1 = c.buf(B, z); s->F2 = c.buf(B, z);
+        s->Fall1 = c.buf(d.discrete ? B : 1, fhead_out(d)); s->Fall2 = c.buf(d.discrete ? B : 1, fhead_out(d));
         s->statsA = c.f(2 * (size_t)B); s->statsZ = c.f(2 * (size_t)B);
     }
     w.as.pre1o = c.buf(B, H); w.as.t1o = c.buf(B, H); w.as.pre1z = c.buf(B, H); w.as.t1z = c.buf(B, H);
@@ -280,6 +292,8 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.asT.h = c.buf(B, ga.hw); w.asT.tr = c.buf(ga.trunk ? B : 1, H); w.asT.p = c.buf(B, H); w.asT.premu = c.buf(B, Na); w.asT.mu = c.buf(B, a);
     w.asT.statsO = c.f(2 * (size_t)B); w.asT.statsZ = c.f(2 * (size_t)B);
     w.dF1 = c.buf(B, z); w.dF2 = c.buf(B, z); w.dBm = c.buf(B, z); w.dy = c.buf(B, z);
+    w.dFall1 = c.buf(d.discrete ? B : 1, fhead_out(d)); w.dFall2 = c.buf(d.discrete ? B : 1, fhead_out(d));
+    w.act_idx = c.f(B); w.nextq = c.f(B); w.greedy = (int32_t*)c.take((size_t)B * 4);
     w.dp = c.buf(B, 2 * H); w.dtr = c.buf(gm.trunk ? B : 1, H); w.dh = c.buf(B, gm.hw > ga.hw ? gm.hw : ga.hw); w.dt1a = c.buf(B, H); w.dt1z = c.buf(B, H);
     w.b_dr2 = c.buf(B, Hb, pad64(Hb)); w.b_dt1 = c.buf(B, Hb, pad64(Hb)); w.a_dpremu = c.buf(B, Na); w.a_dp = c.buf(B, H);
     w.a_dact = c.buf(B, a);
@@ -634,8 +648,10 @@ int run_program(fbhip_ctx* c, Program& p, hipStream_t s) {
 
 // ---- network passes as chains ---------------------------------------------------------------------------------
 // ForwardMap.forward (fb_modules.py:186-199); Xa = [obs|action] panel, Xz = [obs|z] panel
+// (discrete: disc_mode 1 = target-side selection with z = disc_z, 2 = online-side gather of the sampled actions)
 void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
-                           int rows, Chain& out, bool with_heads = true) {
+                           int rows, Chain& out, bool with_heads = true, int disc_mode = 0, const float* disc_z = nullptr,
+                           int disc_ldz = 0) {
     const fbhip_dims& d = c->d;
     const Geom gm = geom_of(d);
     const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
@@ -662,6 +678,25 @@ void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda
         o.gemms.push_back(P(x, feat, 1, W.W3s, feat, 1, Sp->p.p, 2 * H, rows, 2 * H, feat, W.b3s, EPI_BIAS_RELU));
     });
     if (!with_heads) return;                     // the actor phase gets Q from p directly (actor_q_kernel)
+    if (d.discrete) {                            // heads emit [rows, z * A]; the embedding the loss sees is picked by a row kernel
+        const int zA = fhead_out(d), Lza = pad4(zA), A = d.action_dim;
+        Ws* w = &c->W();
+        const bool target = disc_mode == 1;
+        const int boltz = d.boltzmann;
+        out.push_back([=](Ops& o) {
+            o.gemms.push_back(P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->Fall1.p, Lza, rows, zA, H, W.b4[0], EPI_BIAS));
+            o.gemms.push_back(P(Sp->p.p + H, 2 * H, 1, W.W4[1], H, 1, Sp->Fall2.p, Lza, rows, zA, H, W.b4[1], EPI_BIAS));
+            o.post.push_back([=](hipStream_t s) -> int {
+                if (target)                      // discrete_fb.py:289-303 (also act(): the arg-max index)
+                    HIPCK(c, launch_discrete_select(Sp->Fall1.p, Sp->Fall2.p, Lza, disc_z, disc_ldz, Sp->F1.p, Sp->F2.p, Lz,
+                                                    w->nextq, w->greedy, rows, z, A, boltz, c->sq.temp, s));
+                else                             // discrete_fb.py:309-311
+                    HIPCK(c, launch_discrete_gather(Sp->Fall1.p, Sp->Fall2.p, Lza, w->act_idx, Sp->F1.p, Sp->F2.p, Lz, rows, z, A, s));
+                return (int)FBHIP_OK;
+            });
+        });
+        return;
+    }
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->F1.p, Lz, rows, z, H, W.b4[0], EPI_BIAS));
         o.gemms.push_back(P(Sp->p.p + H, 2 * H, 1, W.W4[1], H, 1, Sp->F2.p, Lz, rows, z, H, W.b4[1], EPI_BIAS));
@@ -679,9 +714,11 @@ int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const
 // (runs when a round is flushed: the workspace set comes from the caller, not from the context's current one)
 void heads_dgrad_ops(fbhip_ctx* c, Ws& w, const FwdP& W, FSet& S, int rows, Ops& o) {
     const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z);
-    o.gemms.push_back(P(w.dF1.p, Lz, 1, W.W4[0], H, 0, w.dp.p, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p, 2 * H));
-    o.gemms.push_back(P(w.dF2.p, Lz, 1, W.W4[1], H, 0, w.dp.p + H, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p + H, 2 * H));
+    const int H = d.hidden_dim, z = fhead_out(d), Lz = pad4(z);
+    const float* g1 = d.discrete ? w.dFall1.p : w.dF1.p;
+    const float* g2 = d.discrete ? w.dFall2.p : w.dF2.p;
+    o.gemms.push_back(P(g1, Lz, 1, W.W4[0], H, 0, w.dp.p, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p, 2 * H));
+    o.gemms.push_back(P(g2, Lz, 1, W.W4[1], H, 0, w.dp.p + H, 2 * H, rows, H, z, nullptr, EPI_MASK_RELU, S.p.p + H, 2 * H));
 }
 
 // full backward of ForwardMap given dF1, dF2 (autograd of fb_ddpg.py:318, :383): each stage holds the weight
@@ -689,7 +726,7 @@ void heads_dgrad_ops(fbhip_ctx* c, Ws& w, const FwdP& W, FSet& S, int rows, Ops&
 void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const float* Xa, int lda, const float* Xz,
                            int ldz, FSet& S, int rows, Chain& out) {
     const fbhip_dims& d = c->d;
-    const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z);
+    const int H = d.hidden_dim;
     Ws* w = &c->W();
     FSet* Sp = &S;
     // (the heads' output-layer WEIGHT gradients -- thin, 50 x H over K = rows -- wait for the chain's last round, where the other
@@ -727,8 +764,11 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
                                          G.oz.be1, w->ln_partials + half, rows, H, 0, 0, 0, 0, 0, H});
     });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->dF1.p, Lz, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]));
-        o.gemms.push_back(P(w->dF2.p, Lz, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, z, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
+        const int zo = fhead_out(c->d), Lzo = pad4(zo);
+        const float* g1 = c->d.discrete ? w->dFall1.p : w->dF1.p;
+        const float* g2 = c->d.discrete ? w->dFall2.p : w->dF2.p;
+        o.gemms.push_back(P(g1, Lzo, 0, Sp->p.p, 2 * H, 0, G.W4[0], H, zo, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[0]));
+        o.gemms.push_back(P(g2, Lzo, 0, Sp->p.p + H, 2 * H, 0, G.W4[1], H, zo, H, rows, nullptr, EPI_NONE, nullptr, 0, G.b4[1]));
         o.gemms.push_back(P(w->dt1a.p, H, 0, Xa, lda, 0, G.oa.W1, G.oa.ld1, H, G.oa.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oa.b1));
         if (!gm.single)
             o.gemms.push_back(P(w->dt1z.p, H, 0, Xz, ldz, 0, G.oz.W1, G.oz.ld1, H, G.oz.ld1, rows, nullptr, EPI_NONE, nullptr, 0, G.oz.b1));
@@ -913,6 +953,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
               Lz = pad4(z), La = pad4(a);
     const Geom gm = geom_of(d);
     const int Fo = gm.Fo, hw = gm.hw;
+    if (d.discrete) mask &= ~(FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP | FBHIP_PHASE_ACTOR_FWD);   // DiscreteFBAgent has no actor
     const int aoff = gm.single ? o + z : o;      // column of the action inside the ForwardMap input panels
     const int Lh = pad4(head_width(d));          // leading dimension of the policy head's output
     // next_goal = batch.next_goal if goal_space else batch.next_obs (fb_ddpg.py:440-443); always its own zero-padded panel
@@ -950,7 +991,8 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
         ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld;
         ga.future_idx = hindsight ? w.so.future_idx : nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
-        ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount; ga.aoff = aoff;
+        ga.B = B; ga.o = o; ga.a = d.discrete ? 1 : a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount; ga.aoff = aoff;
+        ga.act_idx = d.discrete ? w.act_idx : nullptr;
         HIPCK(c, launch_gather(ga, s));
         POST_END
         // sample_z (fb_ddpg.py:224-228) + z-mix (fb_ddpg.py:470-485: z[mix] = sqrt(d) normalize(B(backward_input[perm])))
@@ -1045,12 +1087,16 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             // chain B: online F (fb_ddpg.py:318)    chains C, D: target B (:312) and online B (:319)
             // (C, D already ran with the sampler's z-mix pass when this call also covered the SAMPLE phase)
             std::vector<Chain> ch(2);
-            if (mask & FBHIP_PHASE_FB_FWD_TARGET) {
+            if ((mask & FBHIP_PHASE_FB_FWD_TARGET) && d.discrete)      // discrete_fb.py:289-303: no actor, the greedy / softmax column
+                forward_map_fwd_chain(c, c->F_t, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0], true, 1, w.z.p, Lz);
+            else if (mask & FBHIP_PHASE_FB_FWD_TARGET) {
                 actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.asT, B, ch[0], !fused_policy);
                 ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
                 forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
             }
-            if (mask & FBHIP_PHASE_FB_FWD_ONLINE)
+            if ((mask & FBHIP_PHASE_FB_FWD_ONLINE) && d.discrete)      // discrete_fb.py:309-311
+                forward_map_fwd_chain(c, c->F_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1], true, 2);
+            else if (mask & FBHIP_PHASE_FB_FWD_ONLINE)
                 forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
             if (actor_with_target) {             // update_actor's own actor pass (fb_ddpg.py:395-397), see above
                 ch.emplace_back();
@@ -1101,11 +1147,15 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             HIPCK(c, launch_inverse(w.cov.p, w.cov.ld, z, 1.0f / (float)(Bg > 0 ? Bg : B), w.inv_cov.p, w.inv_cov.ld, s));
             RC(run_gemms(c, {P(BmO, Lz, 1, w.inv_cov.p, w.inv_cov.ld, 0, w.BinvC.p, Lz, B, z, z)}, s));
             HIPCK(c, launch_qloss(w.fsO.F1.p, w.fsO.F2.p, w.fsT.F1.p, w.fsT.F2.p, w.BinvC.p, w.z.p, Lz, w.disc,
-                                  hp.q_loss_coef, w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, s, Bg));
+                                  hp.q_loss_coef, w.dF1.p, w.dF2.p, w.metrics, w.pw_scratch, B, z, s, Bg,
+                                  d.discrete ? w.nextq : nullptr));      // discrete_fb.py:297, :302, :329
         }
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
             HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s, Bg));
         }
+        if (d.discrete && (mask & FBHIP_PHASE_FB_BWD_A))      // backward of the action gather (discrete_fb.py:310)
+            HIPCK(c, launch_discrete_scatter(w.dF1.p, w.dF2.p, Lz, w.act_idx, w.dFall1.p, w.dFall2.p, pad4(fhead_out(d)), B, z,
+                                             d.action_dim, s));
         POST_END
     }
     if (mask & FBHIP_PHASE_FB_BWD) {
@@ -1115,7 +1165,8 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             // 57 % of the FB bucket at walker dims, fbhip_fb_early_grad_range), FB_BWD_B runs the rest: a data-parallel host
             // starts the all-reduce of that range in between and hides it under FB_BWD_B.
             std::vector<Chain> ch(3);
-            forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
+            const Buf& Xa = d.discrete ? w.Xoz : w.Xoa;
+            forward_map_bwd_chain(c, c->F_p, c->F_g, Xa.p, Xa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
             backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1], fused_dy);
             if (early_actor) {
                 actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2], !fused_policy);
@@ -1334,12 +1385,13 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
                        float* fb_targets, float* actor_params, float* actor_grads, float* actor_adam_m,
                        float* actor_adam_v, void* workspace, size_t workspace_bytes) {
     if (!c) return FBHIP_E_INVALID;
-    if (!fb_params || !fb_grads || !fb_adam_m || !fb_adam_v || !fb_targets || !actor_params || !actor_grads ||
-        !actor_adam_m || !actor_adam_v || !workspace) { c->err = g_err = "fbhip: null buffer"; return FBHIP_E_INVALID; }
+    const bool has_actor = c->d.discrete == 0;      // (DiscreteFBAgent: no actor, its four pointers are ignored)
+    if (!fb_params || !fb_grads || !fb_adam_m || !fb_adam_v || !fb_targets || !workspace ||
+        (has_actor && (!actor_params || !actor_grads || !actor_adam_m || !actor_adam_v))) { c->err = g_err = "fbhip: null buffer"; return FBHIP_E_INVALID; }
     const size_t one = carve(c->d, nullptr).total_bytes, need = 2 * one;
     if (workspace_bytes < need) { c->err = g_err = "fbhip: workspace too small"; return FBHIP_E_INVALID; }
     if (((uintptr_t)workspace & 255) || ((uintptr_t)fb_params & 15) || ((uintptr_t)fb_grads & 15) ||
-        ((uintptr_t)fb_targets & 15) || ((uintptr_t)actor_params & 15) || ((uintptr_t)actor_grads & 15)) {
+        ((uintptr_t)fb_targets & 15) || (has_actor && (((uintptr_t)actor_params & 15) || ((uintptr_t)actor_grads & 15)))) {
         c->err = g_err = "fbhip: buffers must be 16-byte aligned (workspace 256)";
         return FBHIP_E_INVALID;
     }
@@ -1356,7 +1408,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     const int64_t nf = c->L[FBHIP_NET_FORWARD].numel;
     c->F_p = fwd_p(fb_params, c->L[0]); c->F_g = fwd_p(fb_grads, c->L[0]); c->F_t = fwd_p(fb_targets, c->L[0]);
     c->K_p = bwd_p(fb_params + nf, c->L[1]); c->K_g = bwd_p(fb_grads + nf, c->L[1]); c->K_t = bwd_p(fb_targets + nf, c->L[1]);
-    c->A_p = act_p(actor_params, c->L[2]); c->A_g = act_p(actor_grads, c->L[2]);
+    if (has_actor) { c->A_p = act_p(actor_params, c->L[2]); c->A_g = act_p(actor_grads, c->L[2]); }
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
     for (auto& g : c->infer_graphs) (void)hipGraphExecDestroy(g.exec);
@@ -1364,7 +1416,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
     HIPCK(c, gemm_init());
     HIPCK(c, inverse_prepare());
-    HIPCK(c, actor_head_bwd_prepare(c->d.hidden_dim, c->d.action_dim));
+    if (has_actor) HIPCK(c, actor_head_bwd_prepare(c->d.hidden_dim, c->d.action_dim));
     c->bound = true;
     return FBHIP_OK;
 }
@@ -1535,7 +1587,7 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     // updates/s.  (Zipping the two programs round by round into the SAME launches instead was slower, 933/s: one tile
     // configuration per launch makes the thin GEMMs of one program stragglers of the other's fat ones.)
     static const bool pipelined = [] { const char* e = getenv("FBHIP_UPDATE_PIPELINE"); return !(e && e[0] == '0'); }();
-    const bool pipe = pipelined && n_steps > 1;
+    const bool pipe = pipelined && n_steps > 1 && !c->d.discrete;   // (no actor phase to overlap with)
     if (pipe) {
         if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         while ((int)c->events.size() < 2 * 64) {
@@ -1753,6 +1805,7 @@ int fbhip_act(fbhip_ctx* c, const float* host_obs, const float* host_z, const fl
               int32_t eval_mode, float* host_action_out, void* stream) {
     RC(need_bound(c, false));
     if (!host_obs || !host_z || !host_action_out) { c->err = g_err = "fbhip_act: null argument"; return FBHIP_E_INVALID; }
+    if (c->d.discrete) { c->err = g_err = "fbhip_act: discrete context has no actor (use fbhip_discrete_act)"; return FBHIP_E_STATE; }
     if (!c->h_in) { c->err = g_err = "fbhip_act: pinned staging unavailable"; return FBHIP_E_STATE; }
     if (c->d.hidden_dim > 2048 || actor_geom_of(c->d).hw > 2048) { c->err = g_err = "fbhip_act: layer wider than 2048"; return FBHIP_E_INVALID; }
     const fbhip_dims& d = c->d;
@@ -1783,6 +1836,7 @@ int fbhip_actor_forward(fbhip_ctx* c, const float* obs, int32_t ld_obs, const fl
                         const float* noise, float stddev, float clip, float* action_out, int32_t ld_out, void* stream) {
     RC(need_bound(c, false));
     if (!obs || !z || !action_out || rows < 1) return FBHIP_E_INVALID;
+    if (c->d.discrete) { c->err = g_err = "fbhip_actor_forward: discrete context has no actor"; return FBHIP_E_STATE; }
     hipStream_t s = (hipStream_t)stream;
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
@@ -1819,6 +1873,7 @@ int fbhip_forward_map(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld_
                       void* stream) {
     RC(need_bound(c, false));
     if (!obs || !z || !action || !f1_out || !f2_out || rows < 1) return FBHIP_E_INVALID;
+    if (c->d.discrete) { c->err = g_err = "fbhip_forward_map: discrete context (use fbhip_discrete_act)"; return FBHIP_E_STATE; }
     hipStream_t s = (hipStream_t)stream;
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
@@ -1834,6 +1889,30 @@ int fbhip_forward_map(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld_
         RC(forward_map_fwd(c, which ? c->F_t : c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsT, n, s));
         HIPCK(c, launch_concat2(f1_out + (size_t)r0 * ld_out, ld_out, w.fsT.F1.p, w.fsT.F1.ld, d.z_dim, nullptr, 0, 0, n, s));
         HIPCK(c, launch_concat2(f2_out + (size_t)r0 * ld_out, ld_out, w.fsT.F2.p, w.fsT.F2.ld, d.z_dim, nullptr, 0, 0, n, s));
+    }
+    return FBHIP_OK;
+}
+
+int fbhip_discrete_act(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z,
+                       int32_t rows, int32_t* action_out, float* next_q_out, float* f1_out, float* f2_out, int32_t ld_out,
+                       void* stream) {
+    RC(need_bound(c, false));
+    if (!obs || !z || rows < 1) return FBHIP_E_INVALID;
+    if (!c->d.discrete) { c->err = g_err = "fbhip_discrete_act: the context was not created with discrete"; return FBHIP_E_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const fbhip_dims& d = c->d;
+    Ws& w = c->W();
+    for (int r0 = 0; r0 < rows; r0 += d.batch) {
+        const int n = rows - r0 < d.batch ? rows - r0 : d.batch;
+        HIPCK(c, launch_concat2(w.Xoz.p, w.Xoz.ld, obs + (size_t)r0 * ld_obs, ld_obs, d.obs_dim, z + (size_t)r0 * ld_z, ld_z, d.z_dim, n, s));
+        Chain ch;
+        forward_map_fwd_chain(c, which ? c->F_t : c->F_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.fsT, n, ch, true, 1,
+                              z + (size_t)r0 * ld_z, ld_z);
+        RC(run_chain(c, ch, s));
+        if (action_out) HIPCK(c, hipMemcpyAsync(action_out + r0, w.greedy, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if (next_q_out) HIPCK(c, hipMemcpyAsync(next_q_out + r0, w.nextq, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if (f1_out) HIPCK(c, launch_concat2(f1_out + (size_t)r0 * ld_out, ld_out, w.fsT.F1.p, w.fsT.F1.ld, d.z_dim, nullptr, 0, 0, n, s));
+        if (f2_out) HIPCK(c, launch_concat2(f2_out + (size_t)r0 * ld_out, ld_out, w.fsT.F2.p, w.fsT.F2.ld, d.z_dim, nullptr, 0, 0, n, s));
     }
     return FBHIP_OK;
 }

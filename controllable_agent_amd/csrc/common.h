@@ -165,12 +165,23 @@ struct StepState {          // device-resident, advanced in-graph
 };
 hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z, int ld, int rows, int d,
                                 const float* cov, int ldc, float* metrics, hipStream_t s, int cov_rows = 0 /* 0: rows */);
+// DiscreteFBAgent heads, [rows, d * A] with (k, a) at column k * A + a (discrete_fb.py:289-311): target-side selection
+// (greedy column or softmax mix, + next_Q and the greedy index), online-side gather of the taken action's column, and the
+// gather's backward
+hipError_t launch_discrete_select(const float* Fall1, const float* Fall2, int ldfa, const float* z, int ldz, float* out1,
+                                  float* out2, int ldo, float* nextq, int32_t* act_out, int rows, int d, int A, int boltz,
+                                  float temp, hipStream_t s);
+hipError_t launch_discrete_gather(const float* Fall1, const float* Fall2, int ldfa, const float* act_idx, float* out1,
+                                  float* out2, int ldo, int rows, int d, int A, hipStream_t s);
+hipError_t launch_discrete_scatter(const float* dF1, const float* dF2, int ldf, const float* act_idx, float* dFall1,
+                                   float* dFall2, int ldfa, int rows, int d, int A, hipStream_t s);
 hipError_t launch_inverse(const float* A, int lda, int d, float scale, float* out, int ldo, hipStream_t s);
 hipError_t inverse_prepare();
 hipError_t launch_qloss(const float* F1, const float* F2, const float* tF1, const float* tF2, const float* BinvC,
                         const float* z, int ld, const float* discount, float coef, float* dF1, float* dF2,
                         float* metrics, float* scratch /* >= ceil(rows/4) floats */, int rows, int d, hipStream_t s,
-                        int norm_rows = 0 /* the mean's row count when ``rows`` is a block of a larger batch */);
+                        int norm_rows = 0 /* the mean's row count when ``rows`` is a block of a larger batch */,
+                        const float* nextq = nullptr /* [rows] next_Q given (DiscreteFBAgent) instead of min(tF1.z, tF2.z) */);
 // Adam step counters + fp64 bias corrections (which: 0 fb, 1 actor, 3 both, 2 rng counter).  A launch of its own
 // (launch_step_advance) or the first thread of a kernel that precedes the optimiser pass in the same stream anyway
 // (pairwise_reduce_kernel, actor_q_kernel: ``adv`` arguments) -- one dispatch less on the dependency chain.
@@ -236,6 +247,8 @@ struct GatherArgs {
     float* disc;
     int B, o, a, g, use_goal; float gamma;
     int aoff;                   // column of the action inside Xoa (o, or o + z for the [obs|z|action] panels of preprocess == 0)
+    float* act_idx;             // DiscreteFBAgent: action[ep, step] is ONE stored float holding the action index -> act_idx[i];
+                                // no action columns in the panels (nullptr otherwise)
 };
 hipError_t launch_gather(const GatherArgs& ga, hipStream_t s);
 // z[i] = mix ? sqrt(d) normalize(sqrt(d) normalize(ymix[i])) : sqrt(d) normalize(gauss[i]); scattered into the concat

@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(256) qloss_kernel(const float* __restrict__ F1
                                                     const float* __restrict__ BinvC, const float* __restrict__ z,
                                                     int ld, const float* __restrict__ discount, float coef,
                                                     float* __restrict__ dF1, float* __restrict__ dF2,
-                                                    float* __restrict__ part, int rows, int d, int norm_rows) {
+                                                    float* __restrict__ part, int rows, int d, int norm_rows,
+                                                    const float* __restrict__ nextq) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = blockIdx.x * 4 + wid;
     float sq = 0.f;
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(256) qloss_kernel(const float* __restrict__ F1
             q1 += __shfl_xor(q1, off); q2 += __shfl_xor(q2, off); n1 += __shfl_xor(n1, off);
             n2 += __shfl_xor(n2, off); ir += __shfl_xor(ir, off);
         }
-        const float tq = ir + discount[row] * fminf(n1, n2);
+        const float tq = ir + discount[row] * (nextq != nullptr ? nextq[row] : fminf(n1, n2));
         const float e1 = q1 - tq, e2 = q2 - tq;
         const float g1 = coef * 2.f * e1 / (float)norm_rows, g2 = coef * 2.f * e2 / (float)norm_rows;
         for (int j = lane; j < d; j += 64) {
@@ -259,11 +260,11 @@ __global__ void __launch_bounds__(64) qloss_finalize_kernel(const float* __restr
 
 hipError_t launch_qloss(const float* F1, const float* F2, const float* tF1, const float* tF2, const float* BinvC,
                         const float* z, int ld, const float* discount, float coef, float* dF1, float* dF2,
-                        float* metrics, float* scratch, int rows, int d, hipStream_t s, int norm_rows) {
+                        float* metrics, float* scratch, int rows, int d, hipStream_t s, int norm_rows, const float* nextq) {
     const int nblk = (rows + 3) / 4;
     if (norm_rows <= 0) norm_rows = rows;        // > rows: these rows are a block of a larger (global) batch
     hipLaunchKernelGGL(qloss_kernel, dim3(nblk), dim3(256), 0, s, F1, F2, tF1, tF2, BinvC, z, ld, discount, coef, dF1,
-                       dF2, scratch, rows, d, norm_rows);
+                       dF2, scratch, rows, d, norm_rows, nextq);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(qloss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, norm_rows, coef, metrics);

@@ -1037,4 +1037,131 @@ hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, c
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// DiscreteFBAgent (discrete_fb.py:277-311): the ForwardMap heads emit one embedding per action, [rows, d * A] with element
+// (k, a) at column k * A + a.  One wavefront per row.
+//   SELECT (target side, :289-303): Q_i[a] = sum_k Fall_i[k, a] z[k];  nq = min(Q_1, Q_2);
+//       greedy:     a* = argmax_a nq (first maximum);  out_i[k] = Fall_i[k, a*];  nextq = nq[a*]
+//       boltzmann:  pi = softmax(nq / temp);  out_i[k] = sum_a pi[a] Fall_i[k, a];  nextq = sum_a pi[a] nq[a]
+//   GATHER (online side, :309-311): out_i[k] = Fall_i[k, action]
+// lanes are (a, part): a = lane % AP (AP = A rounded up to a power of two), the 64 / AP parts split k; a butterfly over
+// the parts leaves the full Q_i[a] on every lane (fixed order: deterministic)
+template <int MODE>        // 0 select, 1 gather
+__global__ void __launch_bounds__(256) discrete_head_kernel(const float* __restrict__ Fall1, const float* __restrict__ Fall2,
+                                                            int ldfa, const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ act_idx, float* __restrict__ out1,
+                                                            float* __restrict__ out2, int ldo, float* __restrict__ nextq,
+                                                            int32_t* __restrict__ act_out, int rows, int d, int A, int AP,
+                                                            int boltz, float inv_temp) {
+    __shared__ float s_pi[4][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = blockIdx.x * 4 + wid;
+    if (row >= rows) return;
+    const float* f1 = Fall1 + (size_t)row * ldfa;
+    const float* f2 = Fall2 + (size_t)row * ldfa;
+    if (MODE == 1) {
+        const int a = (int)act_idx[row];
+        for (int k = lane; k < d; k += 64) {
+            out1[(size_t)row * ldo + k] = f1[k * A + a];
+            out2[(size_t)row * ldo + k] = f2[k * A + a];
+        }
+        return;
+    }
+    const int a = lane & (AP - 1), part = lane / AP, parts = 64 / AP;
+    const int ac = a < A ? a : A - 1;
+    float q1 = 0.f, q2 = 0.f;
+    for (int k = part; k < d; k += parts) {
+        const float zz = z[(size_t)row * ldz + k];
+        q1 += f1[k * A + ac] * zz;
+        q2 += f2[k * A + ac] * zz;
+    }
+    for (int o = AP; o < 64; o <<= 1) { q1 += __shfl_xor(q1, o); q2 += __shfl_xor(q2, o); }
+    const float nq = a < A ? fminf(q1, q2) : -INFINITY;
+    if (!boltz) {
+        float best = nq;
+        int bi = a;
+        for (int o = 1; o < AP; o <<= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        for (int k = lane; k < d; k += 64) {
+            out1[(size_t)row * ldo + k] = f1[k * A + bi];
+            out2[(size_t)row * ldo + k] = f2[k * A + bi];
+        }
+        if (lane == 0) {
+            if (nextq) nextq[row] = best;
+            if (act_out) act_out[row] = bi;
+        }
+        return;
+    }
+    const float xs = a < A ? nq * inv_temp : -INFINITY;
+    float m = xs;
+    for (int o = 1; o < AP; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float e = a < A ? expf(xs - m) : 0.f;
+    float se = e;
+    for (int o = 1; o < AP; o <<= 1) se += __shfl_xor(se, o);
+    const float pi = e / se;
+    float pq = a < A ? pi * nq : 0.f;
+    for (int o = 1; o < AP; o <<= 1) pq += __shfl_xor(pq, o);
+    if (lane < AP) s_pi[wid][lane] = pi;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < d; k += 64) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int b = 0; b < A; ++b) {
+            const float w = s_pi[wid][b];
+            t1 += w * f1[k * A + b];
+            t2 += w * f2[k * A + b];
+        }
+        out1[(size_t)row * ldo + k] = t1;
+        out2[(size_t)row * ldo + k] = t2;
+    }
+    if (lane == 0) {
+        if (nextq) nextq[row] = pq;
+        if (act_out) {                       // (the arg-max is still what ``act`` wants)
+            int bi = 0;
+            for (int b = 1; b < A; ++b) if (s_pi[wid][b] > s_pi[wid][bi]) bi = b;
+            act_out[row] = bi;
+        }
+    }
+}
+
+// backward of the gather (discrete_fb.py:310): d Fall_i[k, a] = (a == action) ? dF_i[k] : 0
+__global__ void __launch_bounds__(256) discrete_scatter_kernel(const float* __restrict__ dF1, const float* __restrict__ dF2,
+                                                               int ldf, const float* __restrict__ act_idx,
+                                                               float* __restrict__ dFall1, float* __restrict__ dFall2,
+                                                               int ldfa, int rows, int d, int A) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int a = (int)act_idx[row];
+    for (int j = lane; j < d * A; j += 64) {
+        const int k = j / A;
+        const bool hit = (j - k * A) == a;
+        dFall1[(size_t)row * ldfa + j] = hit ? dF1[(size_t)row * ldf + k] : 0.f;
+        dFall2[(size_t)row * ldfa + j] = hit ? dF2[(size_t)row * ldf + k] : 0.f;
+    }
+}
+
+hipError_t launch_discrete_select(const float* Fall1, const float* Fall2, int ldfa, const float* z, int ldz, float* out1,
+                                  float* out2, int ldo, float* nextq, int32_t* act_out, int rows, int d, int A, int boltz,
+                                  float temp, hipStream_t s) {
+    if (A < 1 || A > 64) return hipErrorInvalidValue;
+    int AP = 1;
+    while (AP < A) AP <<= 1;
+    hipLaunchKernelGGL(discrete_head_kernel<0>, dim3((rows + 3) / 4), dim3(256), 0, s, Fall1, Fall2, ldfa, z, ldz,
+                       (const float*)nullptr, out1, out2, ldo, nextq, act_out, rows, d, A, AP, boltz, 1.0f / temp);
+    return hipGetLastError();
+}
+hipError_t launch_discrete_gather(const float* Fall1, const float* Fall2, int ldfa, const float* act_idx, float* out1,
+                                  float* out2, int ldo, int rows, int d, int A, hipStream_t s) {
+    hipLaunchKernelGGL(discrete_head_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, s, Fall1, Fall2, ldfa,
+                       (const float*)nullptr, 0, act_idx, out1, out2, ldo, (float*)nullptr, (int32_t*)nullptr, rows, d, A, 1, 0, 1.f);
+    return hipGetLastError();
+}
+hipError_t launch_discrete_scatter(const float* dF1, const float* dF2, int ldf, const float* act_idx, float* dFall1,
+                                   float* dFall2, int ldfa, int rows, int d, int A, hipStream_t s) {
+    hipLaunchKernelGGL(discrete_scatter_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dF1, dF2, ldf, act_idx, dFall1, dFall2,
+                       ldfa, rows, d, A);
+    return hipGetLastError();
+}
+
 }  // namespace fbhip

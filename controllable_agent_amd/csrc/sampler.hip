@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
         g.Xnoz[(size_t)i * g.ld_noz + j] = nv;
         g.Xnoa[(size_t)i * g.ld_noa + j] = nv;
     }
-    copy_row(g.Xoa + (size_t)i * g.ld_oa + g.aoff, act, g.a, lane);
+    if (g.act_idx != nullptr) { if (lane == 0) g.act_idx[i] = act[0]; }
+    else copy_row(g.Xoa + (size_t)i * g.ld_oa + g.aoff, act, g.a, lane);
     if (lane == 0) g.disc[i] = g.gamma * g.rv.discount[t];            // discount * storage['discount'] (:171)
     copy_row(g.next_goal + (size_t)i * g.ld_ng, g.use_goal ? g.rv.goal + t * g.g : nobs, g.g, lane);
     // backward_input[perm] (fb_ddpg.py:460-468): row i of the permuted panel is transition perm[i]

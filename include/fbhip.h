@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 11
+#define FBHIP_ABI_VERSION 12
 
 enum {
     FBHIP_OK = 0,
@@ -95,6 +95,15 @@ typedef struct fbhip_dims {
                                     * next_action = dist.sample(), update_actor uses dist.rsample() and
                                     * actor_loss = (temp * log_prob - Q).mean() (fb_ddpg.py:304-306, 391-393, 406);
                                     * stddev / stddev_clip are ignored; temp and log_std_bounds: fbhip_set_policy_squash */
+    int32_t discrete;              /* 0: FBDDPGAgent.  1: the sibling DiscreteFBAgent (url_benchmark/agent/discrete_fb.py:103-468):
+                                    * action_dim is A, the NUMBER of actions; the replay's ``action`` storage holds ONE float per
+                                    * transition, the action index; ForwardMap = one trunk on cat([obs, z]) (preprocess must be 0,
+                                    * discrete_fb.py:74-83) whose heads F{1,2}.2 emit z_dim * A values, element (k, a) at k * A + a
+                                    * (:100); there is NO actor (its layout is empty, the four actor pointers of fbhip_bind_buffers
+                                    * are ignored, the ACTOR_* phases are no-ops).  Target embedding = the greedy action's column
+                                    * of the target ForwardMap on next_obs, or with ``boltzmann`` the softmax(next_Q / temp) mix
+                                    * (temp: fbhip_set_policy_squash; :289-303); online embedding = the column of the stored action
+                                    * (:309-311); q_loss uses that next_Q (:329).  Greedy actions: fbhip_discrete_act */
 } fbhip_dims;
 
 typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82 */
@@ -245,6 +254,13 @@ int fbhip_backward_map(fbhip_ctx* ctx, int32_t which, const float* goal, int32_t
 int fbhip_forward_map(fbhip_ctx* ctx, int32_t which, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z,
                       const float* action, int32_t ld_act, int32_t rows,
                       float* f1_out, float* f2_out, int32_t ld_out, void* stream);
+/* DiscreteFBAgent (dims.discrete): Q_i[a] = F_i(obs, z)[:, a] . z, action = argmax_a min(Q_1, Q_2)  -- ``act`` without
+ * exploration (discrete_fb.py:263-268) -- for ``rows`` device rows; which = 0 online forward_net, 1 forward_target_net.
+ * Optional outputs (NULL to skip): action_out int32 [rows]; next_q_out [rows] and f1_out / f2_out [rows, d] ld_out = the value
+ * and the embeddings update_fb's target side selects (greedy column, or the softmax mix with ``boltzmann``; :289-303). */
+int fbhip_discrete_act(fbhip_ctx* ctx, int32_t which, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z,
+                       int32_t rows, int32_t* action_out, float* next_q_out, float* f1_out, float* f2_out, int32_t ld_out,
+                       void* stream);
 
 /* ---- batch-1 fast path: what the online loop calls on every environment step (pretrain.py:628-632, 651-652) ----
  * HOST pointers in, HOST result out; BLOCKING (the caller needs the action to step the environment).  Each call is one

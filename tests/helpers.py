@@ -67,9 +67,9 @@ def agent_kwargs(cfg: fo.OracleConfig, goal_space=None, metrics=True, **extra):
     return kw
 
 
-def make_hip_agent(cfg: fo.OracleConfig, nets, goal_space=None, metrics=True):
-    from controllable_agent_amd.agent import FBHipAgent
-    ag = FBHipAgent(**agent_kwargs(cfg, goal_space, metrics))
+def make_hip_agent(cfg: fo.OracleConfig, nets, goal_space=None, metrics=True, discrete=False):
+    from controllable_agent_amd.agent import DiscreteFBHipAgent, FBHipAgent
+    ag = (DiscreteFBHipAgent if discrete else FBHipAgent)(**agent_kwargs(cfg, goal_space, metrics))
     ag.load_nets({n: {k: v for k, v in p.items()} for n, p in nets.items()})
     return ag
 
@@ -79,10 +79,11 @@ NETS5 = ("actor", "forward_net", "backward_net", "forward_target_net", "backward
 
 def get_agent_state(agent) -> dict:
     out = {}
-    for n in NETS5:
+    has_actor = hasattr(agent, "actor")          # DiscreteFBHipAgent has none
+    for n in NETS5[0 if has_actor else 1:]:
         for k, v in getattr(agent, n).state_dict().items():
             out[f"{n}/{k}"] = v.detach().cpu().numpy().copy()
-    for n in ("actor", "forward_net", "backward_net"):
+    for n in ("actor", "forward_net", "backward_net")[0 if has_actor else 1:]:
         for mv in ("m", "v"):
             for k, v in agent._adam_views[n][mv].items():
                 out[f"adam_{mv}/{n}/{k}"] = v.detach().cpu().numpy().copy()
@@ -91,10 +92,11 @@ def get_agent_state(agent) -> dict:
 
 def set_agent_state(agent, state: dict, fb_steps: int, actor_steps: int) -> None:
     """state: {'net/param': array, 'adam_m/net/param': array, ...} (the layout of the golden traces)"""
-    for n in NETS5:
+    has_actor = hasattr(agent, "actor")
+    for n in NETS5[0 if has_actor else 1:]:
         sd = {k.split("/", 1)[1]: torch.from_numpy(np.asarray(v)) for k, v in state.items() if k.startswith(n + "/")}
         getattr(agent, n).load_state_dict(sd)
-    for n in ("actor", "forward_net", "backward_net"):
+    for n in ("actor", "forward_net", "backward_net")[0 if has_actor else 1:]:
         for mv in ("m", "v"):
             for k, view in agent._adam_views[n][mv].items():
                 key = f"adam_{mv}/{n}/{k}"

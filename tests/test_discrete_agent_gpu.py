@@ -1,0 +1,142 @@
+"""the sibling DiscreteFBAgent (url_benchmark/agent/discrete_fb.py) on the same kernels --
+``DiscreteFBHipAgent`` against the traces recorded from the real reference and against oracle/discrete_fb_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import discrete_fb_oracle as do
+from oracle import fb_oracle as fo
+from tests import helpers as H
+from tests.test_update_parity_gpu import GRAD_REL_L2, LOSS_RTOL, _buffer, _param_close
+
+pytestmark = pytest.mark.gpu
+
+DKEYS = ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_offdiag")
+
+
+@pytest.mark.parametrize("name,goal_space", [("tiny_discrete_trace", "simplified_walker"), ("tiny_discrete_boltz_trace", None)])
+def test_teacher_forced_against_reference_trace(name, goal_space):
+    """Each step starts from the REFERENCE's recorded state (DiscreteFBAgent), runs one HIP update with the recorded draws and
+    must land on the reference's next state; embeddings and gradients are compared with the oracle's autograd."""
+    meta = H.load_meta(name)
+    cfg = H.cfg_from_meta(meta)
+    z = np.load(H.GOLDEN / f"{name}.npz")
+    storage = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("storage/")}
+    lengths = z["lengths"]
+    nets = {n: {k.split("/", 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"init/{n}/")}
+            for n in ("forward_net", "backward_net")}
+    agent = H.make_hip_agent(cfg, nets, goal_space, discrete=True)
+    assert not hasattr(agent, "actor")
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    oracle = do.DiscreteOracleAgent(cfg, nets)
+    for s in range(meta["n_steps"]):
+        draws = fo.Draws(**{f: z[f"draws/{s}/{f}"] for f in fo.Draws.__dataclass_fields__ if f"draws/{s}/{f}" in z.files})
+        if s > 0:
+            prev = {k.split("/", 2)[2]: z[k] for k in z.files if k.startswith(f"state/{s - 1}/")}
+            H.set_agent_state(agent, prev, s, 0)
+        om = oracle.update(fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount, draws.future_idx), draws, keep=True)
+        m = agent.update_injected(rb, s, H.draws_dict(draws))
+        assert set(m) == set(meta["metrics"][s]), (sorted(m), sorted(meta["metrics"][s]))
+        for k, v in meta["metrics"][s].items():
+            assert m[k] == pytest.approx(v, rel=LOSS_RTOL if k not in ("M1", "F1", "B", "target_M") else 2e-4, abs=2e-6), (s, k, om[k])
+        for view, key in (("z", "z"), ("F1", "F1"), ("F2", "F2"), ("tF1", "tF1"), ("tF2", "tF2"), ("Bm", "Bm"), ("tB", "tB")):
+            assert H.rel_err(agent.workspace_view(view).cpu(), oracle.last[key]) < 2e-5, (s, view)
+        for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward")):
+            for k, g in agent._grad_views[net].state_dict().items():
+                ref = oracle.last[key][k]
+                if float(ref.abs().max()) == 0.0:
+                    assert float(g.abs().max()) == 0.0, (s, net, k)
+                else:
+                    assert H.rel_err(g.cpu(), ref) < GRAD_REL_L2, (s, net, k)
+        for k, v in H.get_agent_state(agent).items():
+            ref = z[f"state/{s}/{k}"]
+            if k.startswith("adam_"):
+                assert H.rel_err(v, ref) < 2e-4, (s, k)
+            else:
+                _param_close(v, ref, cfg.lr, f"step {s} {k}")
+        assert agent.step_counts()[0] == s + 1
+        for nv in (agent.forward_net, agent.backward_net, agent.forward_target_net, agent.backward_target_net,
+                   agent._grad_views["forward_net"], agent._grad_views["backward_net"]):
+            assert nv.pad_abs_max() == 0.0, (s, nv._name)
+
+
+def _mid_case(seed, **kw):
+    base = dict(obs_dim=17, action_dim=6, goal_dim=17, z_dim=50, hidden_dim=256, feature_dim=64, backward_hidden_dim=130,
+                batch_size=512, lr=1e-4, preprocess=False)
+    base.update(kw)
+    cfg = fo.OracleConfig(**base)
+    rng = np.random.default_rng(seed)
+    nets = {n: fo.synthetic_params(rng, do.NET_SHAPES[n](cfg)) for n in do.NET_SHAPES}
+    storage, lengths = fo.synthetic_storage(rng, 8, 40, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if cfg.use_goal else None)
+    do.synthetic_actions(rng, storage, cfg.action_dim)
+    return cfg, rng, nets, storage, lengths
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(boltzmann=True, temp=2.0, q_loss=True), dict(action_dim=33, z_dim=37, mix_ratio=1.0),
+                                   dict(action_dim=1), dict(action_dim=64, z_dim=100, batch_size=96)])
+def test_free_running_mid_dims_against_the_oracle(flags):
+    """Mid-size networks (H 256, d 50, B 512; A from 1 to 64 incl. non-powers of two), three free-running updates: loss curves
+    against the oracle; gradients of the first step tensor by tensor."""
+    cfg, rng, nets, storage, lengths = _mid_case(130, **flags)
+    agent = H.make_hip_agent(cfg, nets, discrete=True)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    oracle = do.DiscreteOracleAgent(cfg, nets)
+    for s in range(3):
+        draws = fo.make_draws(rng, cfg, 8, lengths)
+        om = oracle.update(fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount, draws.future_idx), draws, keep=(s == 0))
+        m = agent.update_injected(rb, s, H.draws_dict(draws))
+        for k in DKEYS + (("q_loss",) if cfg.q_loss else ()):
+            assert m[k] == pytest.approx(om[k], rel=3e-4 * (1 + s), abs=1e-5), (s, k)
+        if s == 0:
+            for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward")):
+                for k, g in agent._grad_views[net].state_dict().items():
+                    assert H.rel_err(g.cpu(), oracle.last[key][k]) < 5e-3, (net, k)      # (one near-tie of the arg-max over A moves a row: ~1/B)
+
+
+def test_greedy_action_and_target_embedding_against_the_oracle():
+    """``act`` without exploration (discrete_fb.py:263-268) and the embeddings / next_Q update_fb's target side selects."""
+    for boltz in (False, True):
+        cfg, rng, nets, _, _ = _mid_case(131, action_dim=5, boltzmann=boltz, temp=0.5)
+        agent = H.make_hip_agent(cfg, nets, discrete=True)
+        obs = rng.standard_normal((70, cfg.obs_dim)).astype(np.float32)
+        z = (np.sqrt(cfg.z_dim) * torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((70, cfg.z_dim)).astype(np.float32)), dim=1))
+        ref = do.greedy_action(nets["forward_net"], torch.from_numpy(obs), z, cfg.action_dim)
+        got = agent.greedy_action(obs, z).cpu().long()
+        assert (got == ref).float().mean() >= 0.98        # (a tie broken differently by rounding is not an error)
+        assert agent.act(obs[3], {"z": z[3].numpy()}, step=0, eval_mode=True) == int(ref[3])
+        F1a, F2a = do.forward_map(nets["forward_net"], torch.from_numpy(obs), z, cfg.action_dim)
+        nq = torch.min(*[torch.einsum('sda, sd -> sa', Fi, z) for Fi in (F1a, F2a)])
+        if boltz:
+            pi = torch.softmax(nq / cfg.temp, dim=-1)
+            e1, e2, nqv = torch.einsum("sa, sda -> sd", pi, F1a), torch.einsum("sa, sda -> sd", pi, F2a), (pi * nq).sum(1)
+        else:
+            idx = got[:, None].repeat(1, cfg.z_dim)[:, :, None]
+            e1, e2, nqv = F1a.gather(-1, idx).squeeze(-1), F2a.gather(-1, idx).squeeze(-1), nq.gather(1, got[:, None]).squeeze(1)
+        f1, f2, q = agent.target_embedding(obs, z, target=False)
+        assert H.rel_err(f1.cpu(), e1) < 2e-5 and H.rel_err(f2.cpu(), e2) < 2e-5 and H.rel_err(q.cpu(), nqv) < 2e-5
+
+
+def test_device_draws_graph_replay_and_update_many():
+    """No injection: on-device sampling; a captured update equals eager launches bit for bit; ``update_many(n)`` equals n
+    updates; B stays on the sphere; exploration of ``act`` returns valid indices."""
+    cfg, rng, nets, storage, lengths = _mid_case(132, action_dim=4, batch_size=128, hidden_dim=64, z_dim=16)
+    agents = [H.make_hip_agent(cfg, nets, discrete=True) for _ in range(3)]
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    agents[1]._use_graph = False
+    for s in range(4):
+        m0, m1 = agents[0].update(rb, s), agents[1].update(rb, s)
+        assert m0 == m1
+        assert np.isfinite(m0["fb_loss"]) and m0["B_norm"] == pytest.approx(np.sqrt(cfg.z_dim), rel=1e-5)
+    m2 = agents[2].update_many(rb, 0, 4)
+    assert m2 == m0
+    for a, b in zip(H.get_agent_state(agents[0]).values(), H.get_agent_state(agents[2]).values()):
+        np.testing.assert_array_equal(a, b)
+    acts = {agents[0].act(storage["observation"][0, 1], agents[0].init_meta(), step=10, eval_mode=False) for _ in range(40)}
+    assert acts <= set(range(cfg.action_dim))
+
+
+def test_rejects_what_the_reference_cannot_run():
+    cfg, _, nets, _, _ = _mid_case(133)
+    from controllable_agent_amd.agent import DiscreteFBHipAgent
+    with pytest.raises(NotImplementedError):
+        DiscreteFBHipAgent(**H.agent_kwargs(fo.OracleConfig(**{**cfg.__dict__, "preprocess": True})))
