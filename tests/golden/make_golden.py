@@ -364,6 +364,11 @@ def init_fixture(R):
     agent = make_ref_agent(R, big)
     (HERE / "init_seed1_walker.json").write_text(json.dumps(
         {"torch_version": torch.__version__, "checksums": checksums(ref_state(agent))}, indent=1))
+    torch.manual_seed(1)       # the sibling's constructor (discrete_fb.py:131-150): forward_net, backward_net, the two targets
+    agent = make_ref_agent(R, tiny_cfg(action_dim=4, preprocess=False), discrete=True)
+    arrays = {k: v for k, v in ref_state(agent).items()}
+    arrays["torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(HERE / "init_seed1_tiny_discrete.npz", **arrays)
     print("[init] ok")
 
 

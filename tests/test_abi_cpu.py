@@ -93,6 +93,25 @@ def test_boltzmann_actor_layout_follows_the_reference_module(lib):
     assert l.fbhip_destroy(ctx) == 0
 
 
+def test_discrete_layout_follows_the_reference_module(lib):
+    """dims.discrete (discrete_fb.ForwardMap, discrete_fb.py:74-83): trunk on cat([obs, z]) -- no action columns --, heads
+    z_dim * A wide; no actor; preprocess must be 0 like in the reference (its preprocess branch cannot run)."""
+    l = lib.load()
+    d = lib.Dims(16, 5, 4, 5, 8, 32, 16, 18, 0, 0, 0, 1, 0, 1)
+    got = []
+    for i in range(l.fbhip_layout_count(C.byref(d), lib.NET_FORWARD)):
+        t = lib.TensorDesc()
+        assert l.fbhip_layout_entry(C.byref(d), lib.NET_FORWARD, i, C.byref(t)) == 0
+        got.append((t.name.decode(), t.rows, t.cols))
+    assert got == [("trunk.0.weight", 32, 13), ("trunk.0.bias", 1, 32), ("trunk.1.weight", 1, 32), ("trunk.1.bias", 1, 32),
+                   ("trunk.3.weight", 32, 32), ("trunk.3.bias", 1, 32), ("trunk.5.weight", 32, 32), ("trunk.5.bias", 1, 32),
+                   ("F1.0.weight", 32, 32), ("F1.0.bias", 1, 32), ("F1.2.weight", 32, 32), ("F1.2.bias", 1, 32),
+                   ("F2.0.weight", 32, 32), ("F2.0.bias", 1, 32), ("F2.2.weight", 32, 32), ("F2.2.bias", 1, 32)]
+    assert l.fbhip_layout_count(C.byref(d), lib.NET_ACTOR) == 0 and l.fbhip_net_numel(C.byref(d), lib.NET_ACTOR) == 0
+    bad = lib.Dims(16, 5, 4, 5, 8, 32, 16, 18, 0, 0, 1, 1, 0, 1)
+    assert l.fbhip_net_numel(C.byref(bad), 0) < 0 and b"preprocess" in l.fbhip_last_error(None)
+
+
 def test_bad_dims_fail_loudly(lib):
     l = lib.load()
     bad = lib.Dims(1024, 24, 6, 24, 50, 1022, 512, 526, 0, 0, 1, 1)       # hidden_dim % 4 != 0

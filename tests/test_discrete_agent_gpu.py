@@ -140,3 +140,38 @@ def test_rejects_what_the_reference_cannot_run():
     from controllable_agent_amd.agent import DiscreteFBHipAgent
     with pytest.raises(NotImplementedError):
         DiscreteFBHipAgent(**H.agent_kwargs(fo.OracleConfig(**{**cfg.__dict__, "preprocess": True})))
+
+
+def test_constructor_init_matches_reference_seed():
+    """Same torch.manual_seed => the reference constructor's orthogonal init, tensor for tensor (discrete_fb.py:131-150)."""
+    z = np.load(H.GOLDEN / "init_seed1_tiny_discrete.npz")
+    if str(z["torch_version"]) != torch.__version__:
+        pytest.skip("fixture generated with another torch build")
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=4, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16, backward_hidden_dim=18,
+                          batch_size=16, lr=1e-3, preprocess=False)
+    from controllable_agent_amd.agent import DiscreteFBHipAgent
+    torch.manual_seed(1)
+    agent = DiscreteFBHipAgent(**H.agent_kwargs(cfg))
+    state = H.get_agent_state(agent)
+    assert {k for k in state if not k.startswith("adam_")} == {k for k in z.files if k != "torch_version"}
+    for k, v in state.items():
+        if not k.startswith("adam_"):
+            np.testing.assert_allclose(v, z[k], rtol=0, atol=5e-6, err_msg=k)   # LAPACK QR jitter between hosts (thread count)
+
+
+def test_pickle_round_trip_and_init_from():
+    import pickle
+    cfg, rng, nets, storage, lengths = _mid_case(134, action_dim=3, batch_size=64, hidden_dim=32, z_dim=8, backward_hidden_dim=20)
+    a = H.make_hip_agent(cfg, nets, discrete=True)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    a.update(rb, 0)
+    b = pickle.loads(pickle.dumps(a))
+    assert type(b).__name__ == "DiscreteFBHipAgent" and b.step_counts()[0] == 1
+    for (k, x), y in zip(H.get_agent_state(a).items(), H.get_agent_state(b).values()):
+        np.testing.assert_array_equal(x, y, err_msg=k)
+    c = H.make_hip_agent(cfg, {n: {k: torch.zeros_like(v) for k, v in p.items()} for n, p in nets.items()}, discrete=True)
+    c.init_from(a)
+    for n in ("forward_net", "backward_net", "forward_target_net", "backward_target_net"):
+        for (k, x), y in zip(getattr(a, n).state_dict().items(), getattr(c, n).state_dict().values()):
+            assert torch.equal(x, y), (n, k)
+    assert np.isfinite(b.update(rb, 1)["fb_loss"])          # (the device RNG counter is not part of the pickle: fresh draws)
