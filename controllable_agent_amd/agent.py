@@ -687,6 +687,10 @@ class FBHipAgent:
             hp_fb.grad_scale = 1.0
 
         def run_phases(mask: int) -> None:
+            if self._discrete:          # no actor: a schedule's actor-only calls have nothing to enqueue
+                mask &= ~(_lib.PHASE_ACTOR_GRAD | _lib.PHASE_ACTOR_STEP | _lib.PHASE_ACTOR_FWD)
+                if mask == 0:
+                    return
             # injected draws only matter to the SAMPLE phase
             inj = C.byref(inject) if (inject is not None and mask & _lib.PHASE_SAMPLE) else None
             h = hp_fb if (mask & _lib.PHASE_FB_STEP) else hp
@@ -809,7 +813,12 @@ class FBHipAgent:
 
             def launch() -> None:
                 s = stream_ptr()
-                dp_update_many(lambda mask: check(lib.fbhip_update(self._ctx, C.byref(hp), None, mask, 1, s), self._ctx),
+                actor_bits = (_lib.PHASE_ACTOR_GRAD | _lib.PHASE_ACTOR_STEP | _lib.PHASE_ACTOR_FWD) if self._discrete else 0
+
+                def phases(mask: int) -> None:
+                    if mask & ~actor_bits:
+                        check(lib.fbhip_update(self._ctx, C.byref(hp), None, mask & ~actor_bits, 1, s), self._ctx)
+                dp_update_many(phases,
                                lambda which: check(lib.fbhip_select_workspace_set(self._ctx, which), self._ctx),
                                self._fb_grads, self._actor_grads, n_steps, early=self._early_grad_range())
             self._on_update_stream(launch)
@@ -952,8 +961,6 @@ class DiscreteFBHipAgent(FBHipAgent):
         if cfg.dp_global_batch:
             raise NotImplementedError("DiscreteFBHipAgent: dp_global_batch is not wired for the discrete agent")
         super().__init__(**kwargs)
-        if self._world() > 1:
-            raise NotImplementedError("DiscreteFBHipAgent: data-parallel updates are not wired for the discrete agent yet")
 
     def greedy_action(self, obs: tp.Any, z: tp.Any, target: bool = False) -> torch.Tensor:
         """argmax_a min_i F_i(obs, z)[:, :, a] . z for a batch of rows (device int32 tensor), discrete_fb.py:263-268."""

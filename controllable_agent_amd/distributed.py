@@ -114,7 +114,7 @@ def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, acto
         return
     # (FBHIP_FORCE_PHASE_SPLIT=1 runs this schedule on a single rank too: tests / 1-GPU rehearsal of the 8-GPU path)
     live = dist.is_available() and dist.is_initialized()
-    reduce = dist.all_reduce if live else (lambda t: None)
+    reduce = (lambda t: dist.all_reduce(t) if t.numel() > 0 else None) if live else (lambda t: None)   # (DiscreteFBHipAgent: no actor bucket)
     # the actor's forward rides along the FB backward
     _reduce_fb(run_phases, fb_grads, early, PHASE_SAMPLE | PHASE_FB_FWD | PHASE_FB_BWD_A | PHASE_ACTOR_FWD, live)
     run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
@@ -145,7 +145,7 @@ def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable
         for t in range(n_steps):
             _reduce_fb(run_phases, fb_grads, early, PHASE_FB_FWD_TARGET | PHASE_FB_BWD_A | PHASE_ACTOR_FWD, live)
             run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
-            work = dist.all_reduce(actor_grads, async_op=True) if live else None
+            work = dist.all_reduce(actor_grads, async_op=True) if (live and actor_grads.numel() > 0) else None
             if t + 1 < n_steps:
                 select_set(cur ^ 1)
                 run_phases(head)                     # the next step's head, under the all-reduce

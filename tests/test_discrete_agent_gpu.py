@@ -175,3 +175,104 @@ def test_pickle_round_trip_and_init_from():
         for (k, x), y in zip(getattr(a, n).state_dict().items(), getattr(c, n).state_dict().values()):
             assert torch.equal(x, y), (n, k)
     assert np.isfinite(b.update(rb, 1)["fb_loss"])          # (the device RNG counter is not part of the pickle: fresh draws)
+
+
+def test_data_parallel_phase_schedules_equal_the_single_call(monkeypatch):
+    """distributed.dp_update / dp_update_many on ONE rank (FBHIP_FORCE_PHASE_SPLIT=1: the phase-split schedules of the
+    data-parallel path, all-reduces skipped) against the single-graph update: the agent has no actor bucket, the schedule's
+    actor-only calls enqueue nothing."""
+    cfg, rng, nets, storage, lengths = _mid_case(135, action_dim=5, batch_size=64, hidden_dim=64, z_dim=12, backward_hidden_dim=30)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    a1, a2, a3, a4 = (H.make_hip_agent(cfg, nets, discrete=True) for _ in range(4))
+    for s in range(3):
+        d = H.draws_dict(fo.make_draws(rng, cfg, 8, lengths))
+        monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+        m1 = a1.update_injected(rb, s, d)
+        monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+        m2 = a2.update_injected(rb, s, d)
+        for k in m1:
+            assert m2[k] == pytest.approx(m1[k], rel=2e-5, abs=1e-6), (s, k)
+    s1, s2 = H.get_agent_state(a1), H.get_agent_state(a2)
+    for k in s1:
+        np.testing.assert_allclose(s2[k], s1[k], rtol=0, atol=3e-6, err_msg=k)
+    # device draws: the pipelined multi-step schedule (dp_update_many) against single updates -- same seed, same draws
+    monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+    for s in range(4):
+        m3 = a3.update(rb, s)
+    monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+    m4 = a4.update_many(rb, 0, 4)
+    monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+    for k in m3:
+        assert m4[k] == pytest.approx(m3[k], rel=2e-5, abs=1e-6), k
+    s3, s4 = H.get_agent_state(a3), H.get_agent_state(a4)
+    for k in s3:
+        np.testing.assert_allclose(s4[k], s3[k], rtol=0, atol=3e-6, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------ two real ranks (gloo, one GPU)
+def _dp_setup():
+    from tests import test_distributed_cpu as T
+    cfg = fo.OracleConfig(**{**T.CFG, "action_dim": 4, "preprocess": False})
+    rng = np.random.default_rng(17)
+    nets = {n: fo.synthetic_params(rng, do.NET_SHAPES[n](cfg)) for n in do.NET_SHAPES}
+    storage, lengths = fo.synthetic_storage(rng, T.N_EPS, T.T, cfg.obs_dim, cfg.action_dim)
+    do.synthetic_actions(rng, storage, cfg.action_dim)
+    return cfg, nets, storage, lengths
+
+
+def _dp_worker(rank, port, out_q):
+    import os
+    import torch.distributed as dist
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    from tests import test_distributed_cpu as T
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    cfg, nets, storage, lengths = _dp_setup()
+    agent = H.make_hip_agent(cfg, nets, discrete=True)
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    states = []
+    for step in range(T.STEPS):
+        d = fo.make_draws(np.random.default_rng(1000 * step + rank), cfg, len(rb), rb._episodes_length)
+        agent.update_injected(rb, step, H.draws_dict(d), use_graph=True)
+        states.append(H.get_agent_state(agent))
+    torch.cuda.synchronize()
+    out_q.put((rank, states))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_gradient_averaging():
+    """world 2 (gloo, both ranks on cuda:0): replicas stay bit-identical over three steps, and the first step equals the
+    oracle's Adam step on the AVERAGE of the two ranks' gradients (mode A of DESIGN.md section 7, no actor bucket)."""
+    import torch.multiprocessing as mp
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    from tests import test_distributed_cpu as T
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, port, q)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(T.WORLD))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for s in range(T.STEPS):
+        for k in got[0][s]:
+            np.testing.assert_array_equal(got[0][s][k], got[1][s][k], err_msg=f"step {s} {k}")
+    cfg, nets, storage, lengths = _dp_setup()
+    grads = []
+    for r in range(T.WORLD):
+        rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cpu").shard(r, T.WORLD)
+        sh = {k: v.numpy() for k, v in rb._storage.items()}
+        d = fo.make_draws(np.random.default_rng(r), cfg, len(rb), rb._episodes_length)
+        tw = do.DiscreteOracleAgent(cfg, nets)
+        tw.update(fo.gather_batch(sh, d.ep_idx, d.step_idx, cfg.discount), d, keep=True)
+        grads.append((tw.last["grads_forward"], tw.last["grads_backward"]))
+    ref = do.DiscreteOracleAgent(cfg, nets)
+    for i, (n, lr) in enumerate((("forward_net", cfg.lr), ("backward_net", cfg.lr * cfg.lr_coef))):
+        avg = {k: sum(g[i][k] for g in grads) / T.WORLD for k in grads[0][i]}
+        fo.adam_step(getattr(ref, n), avg, ref.adam[n]["m"], ref.adam[n]["v"], 1, lr)
+    for n in ("forward_net", "backward_net"):
+        for k, v in getattr(ref, n).items():
+            np.testing.assert_allclose(got[0][0][f"{n}/{k}"], v.numpy(), rtol=0, atol=3e-6, err_msg=f"{n}/{k}")
