@@ -84,6 +84,7 @@ PROTOTYPES = {
     "fbhip_z_correl": (C.c_int, [_P, _P, _P, _P, _P]),
     "fbhip_forward_map": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P]),
     "fbhip_discrete_act": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
+    "fbhip_discrete_act_host": (C.c_int, [_P, _P, _P, _P, _P]),
     "fbhip_gemm": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "fbhip_gemm_cfg": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "fbhip_ln_tanh_fwd": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _P]),

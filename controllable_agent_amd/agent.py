@@ -981,7 +981,16 @@ class DiscreteFBHipAgent(FBHipAgent):
         return f1, f2, nq
 
     def act(self, obs: tp.Any, meta: MetaDict, step: int, eval_mode: bool) -> tp.Any:      # discrete_fb.py:258-275
-        action = int(self.greedy_action(obs, meta["z"]).cpu()[0])
+        # batch-1 fast path: host arrays in, host index out, one graph launch (fbhip_discrete_act_host)
+        o = np.ascontiguousarray(np.asarray(obs, np.float32).reshape(-1))
+        z = np.ascontiguousarray(np.asarray(meta["z"], np.float32).reshape(-1))
+        if o.shape[0] != self.obs_dim or z.shape[0] != self.cfg.z_dim:
+            raise ValueError(f"act: expected obs[{self.obs_dim}] and z[{self.cfg.z_dim}], got {o.shape} / {z.shape}")
+        out = C.c_int32()
+        with torch.cuda.stream(self._stream):
+            check(_lib.load().fbhip_discrete_act_host(self._ctx, o.ctypes.data, z.ctypes.data, C.byref(out),
+                                                      self._stream.cuda_stream), self._ctx)
+        action = int(out.value)
         if not eval_mode:
             if step < self.cfg.num_expl_steps:
                 action = int(torch.randint(0, self.action_dim, (1,))[0])

@@ -1700,7 +1700,7 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
 // ---- batch-1 fast path: one hipGraph = H2D of the staged inputs + 4 launches + D2H of the result ---------------
 namespace {
 
-enum { INFER_ACT = 0, INFER_ZCORREL = 1 };
+enum { INFER_ACT = 0, INFER_ZCORREL = 1, INFER_DISCRETE_ACT = 2 };
 
 GemvProblem GV(const float* x, const float* W, int ldw, const float* bias, float* y, int N, int K, bool relu,
                const float* ln_g = nullptr, const float* ln_b = nullptr, int n_ln = 0) {
@@ -1754,6 +1754,38 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
     return FBHIP_OK;
 }
 
+// DiscreteFBAgent.act without exploration (discrete_fb.py:258-268) for ONE observation: the GEMV chain of the batch-1 path
+// through forward_net (trunk on [obs|z], heads z * A wide) + the selection row kernel; activations live in row 0 of the
+// target-side ForwardMap set
+int enqueue_discrete_act(fbhip_ctx* c, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    const int o = d.obs_dim, z = d.z_dim, H = d.hidden_dim, zA = fhead_out(d);
+    Ws& w = c->W();
+    const FwdP& F = c->F_p;
+    FSet& S = w.fsT;
+    HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, act_noise_off(d) * sizeof(float), hipMemcpyHostToDevice, s));
+    GemvGroup g1{}; g1.n = 1;
+    g1.p[0] = GV(w.act_in, F.oa.W1, F.oa.ld1, F.oa.b1, S.pre1a.p, H, F.oa.ld1, false);
+    HIPCK(c, launch_gemv_group(g1, s));
+    GemvGroup g2{}; g2.n = 1;
+    g2.p[0] = GV(S.pre1a.p, F.oa.W2, H, F.oa.b2, S.h.p, H, H, true, F.oa.g1, F.oa.be1, H);
+    HIPCK(c, launch_gemv_group(g2, s));
+    GemvGroup g3{}; g3.n = 1;
+    g3.p[0] = GV(S.h.p, F.Wt, H, F.bt, S.tr.p, H, H, true);
+    HIPCK(c, launch_gemv_group(g3, s));
+    GemvGroup g4{}; g4.n = 1;
+    g4.p[0] = GV(S.tr.p, F.W3s, H, F.b3s, S.p.p, 2 * H, H, true);
+    HIPCK(c, launch_gemv_group(g4, s));
+    GemvGroup g5{}; g5.n = 2;
+    g5.p[0] = GV(S.p.p, F.W4[0], H, F.b4[0], S.Fall1.p, zA, H, false);
+    g5.p[1] = GV(S.p.p + H, F.W4[1], H, F.b4[1], S.Fall2.p, zA, H, false);
+    HIPCK(c, launch_gemv_group(g5, s));
+    HIPCK(c, launch_discrete_select(S.Fall1.p, S.Fall2.p, pad4(zA), w.act_in + o, z, S.F1.p, S.F2.p, pad4(z), w.nextq,
+                                    (int32_t*)w.act_out, 1, z, d.action_dim, d.boltzmann, c->sq.temp, s));
+    HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return FBHIP_OK;
+}
+
 int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, z = d.z_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb);
@@ -1784,7 +1816,8 @@ int run_infer_graph(fbhip_ctx* c, int kind, float stddev, int eval_mode, bool ha
     if (!exec) {
         hipGraph_t graph = nullptr;
         HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        const int rc = kind == INFER_ACT ? enqueue_act(c, stddev, eval_mode, has_noise, s) : enqueue_zcorrel(c, s);
+        const int rc = kind == INFER_ACT ? enqueue_act(c, stddev, eval_mode, has_noise, s)
+                       : kind == INFER_DISCRETE_ACT ? enqueue_discrete_act(c, s) : enqueue_zcorrel(c, s);
         hipError_t e = hipStreamEndCapture(s, &graph);
         if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         HIPCK(c, e);
@@ -1816,6 +1849,20 @@ int fbhip_act(fbhip_ctx* c, const float* host_obs, const float* host_z, const fl
     if (has_noise) memcpy(c->h_in + act_noise_off(d), host_noise, (size_t)d.action_dim * sizeof(float));
     RC(run_infer_graph(c, INFER_ACT, stddev, eval_mode ? 1 : 0, has_noise, (hipStream_t)stream));
     memcpy(host_action_out, c->h_out, (size_t)d.action_dim * sizeof(float));
+    return FBHIP_OK;
+}
+
+int fbhip_discrete_act_host(fbhip_ctx* c, const float* host_obs, const float* host_z, int32_t* host_action_out, void* stream) {
+    RC(need_bound(c, false));
+    if (!host_obs || !host_z || !host_action_out) { c->err = g_err = "fbhip_discrete_act_host: null argument"; return FBHIP_E_INVALID; }
+    if (!c->d.discrete) { c->err = g_err = "fbhip_discrete_act_host: the context was not created with discrete"; return FBHIP_E_STATE; }
+    if (!c->h_in) { c->err = g_err = "fbhip_discrete_act_host: pinned staging unavailable"; return FBHIP_E_STATE; }
+    const fbhip_dims& d = c->d;
+    memcpy(c->h_in, host_obs, (size_t)d.obs_dim * sizeof(float));
+    memcpy(c->h_in + d.obs_dim, host_z, (size_t)d.z_dim * sizeof(float));
+    for (size_t i = (size_t)d.obs_dim + d.z_dim; i < act_noise_off(d); ++i) c->h_in[i] = 0.f;
+    RC(run_infer_graph(c, INFER_DISCRETE_ACT, 0.f, 1, false, (hipStream_t)stream));
+    memcpy(host_action_out, c->h_out, sizeof(int32_t));
     return FBHIP_OK;
 }
 

@@ -261,6 +261,9 @@ int fbhip_forward_map(fbhip_ctx* ctx, int32_t which, const float* obs, int32_t l
 int fbhip_discrete_act(fbhip_ctx* ctx, int32_t which, const float* obs, int32_t ld_obs, const float* z, int32_t ld_z,
                        int32_t rows, int32_t* action_out, float* next_q_out, float* f1_out, float* f2_out, int32_t ld_out,
                        void* stream);
+/* The same arg-max for ONE observation on the batch-1 fast path (like fbhip_act: host arrays in, host result out, one hipGraph
+ * launch holding H2D + a GEMV chain + the selection kernel + D2H); blocks until the action index is in *host_action_out. */
+int fbhip_discrete_act_host(fbhip_ctx* ctx, const float* host_obs, const float* host_z, int32_t* host_action_out, void* stream);
 
 /* ---- batch-1 fast path: what the online loop calls on every environment step (pretrain.py:628-632, 651-652) ----
  * HOST pointers in, HOST result out; BLOCKING (the caller needs the action to step the environment).  Each call is one

@@ -103,7 +103,9 @@ def test_greedy_action_and_target_embedding_against_the_oracle():
         ref = do.greedy_action(nets["forward_net"], torch.from_numpy(obs), z, cfg.action_dim)
         got = agent.greedy_action(obs, z).cpu().long()
         assert (got == ref).float().mean() >= 0.98        # (a tie broken differently by rounding is not an error)
-        assert agent.act(obs[3], {"z": z[3].numpy()}, step=0, eval_mode=True) == int(ref[3])
+        # the batch-1 fast path (fbhip_discrete_act_host: GEMV chain in one graph) against the batched entry point
+        fast = [agent.act(obs[i], {"z": z[i].numpy()}, step=0, eval_mode=True) for i in range(70)]
+        assert np.mean(np.asarray(fast) == got.numpy()) >= 0.98 and fast[3] == int(ref[3])
         F1a, F2a = do.forward_map(nets["forward_net"], torch.from_numpy(obs), z, cfg.action_dim)
         nq = torch.min(*[torch.einsum('sda, sd -> sa', Fi, z) for Fi in (F1a, F2a)])
         if boltz:
