@@ -136,7 +136,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx
 // registers -> LDS staging of the next K chunks, prefetch distance 2).  One s_barrier per K chunk couples them.  With
 // symmetric waves the co-resident workgroups fall into lockstep and the matrix pipe idles through every
 // store/barrier/refill phase (PMC: 44-52 % MFMA busy); here the pipe-owning waves have nothing else to do.
-template <int WM, int WN, int WK, int BK>
+// PF3 (FBHIP_GEMM_PF3=1, off by default): the producers keep TWO chunks in flight behind the one being landed (prefetch
+// distance 3, three register sets) instead of one.  The hypothesis was Little's law -- one 16 KB chunk per workgroup in flight
+// = 32 KB per CU against the L2 round trip, and the knock-out runs measured only ~22 B/clk/CU from cache-resident operands.
+// Measured: the ISA is as intended (counted vmcnt(7..11) in the steady loop, 110 VGPRs, still 2 workgroups per CU) and it is
+// SLOWER -- 1024x2048x1024 alone 45-46 us vs 43.8, the step 1000 vs 1094 updates/s (two same-box pairs): more bytes in flight
+// per CU do not raise the global->LDS rate, so the staging path is not latency-bound.  Kept as a switch for that record.
+template <int WM, int WN, int WK, int BK, bool PF3 = false>
 __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     constexpr int BM = 32 * WM, BN = 32 * WN, BKT = BK * WK;
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
@@ -249,7 +255,50 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
         constexpr std::true_type T{};
         constexpr std::false_type F{};
         float4 ra0[QA], rb0[QB], ra1[QA], rb1[QB];
-        if (nfast > 0) {
+        if constexpr (PF3) {
+            if (nfast > 0) {
+                float4 ra2[QA], rb2[QB];
+                const int nf = nfast;
+                load_fast(0, ra0, rb0);
+                if (nf > 1) load_fast(1, ra1, rb1);
+                if (nf > 2) load_fast(2, ra2, rb2);
+                store_chunk(0, ra0, rb0);
+                __syncthreads();                                      // barrier #0: chunk 0 visible
+                int it = 0;
+                // step ``it``: request chunk it+3 into the set chunk ``it`` just left, land chunk it+1, meet the consumers
+                for (; it + 5 < nf; it += 3) {
+                    load_fast(it + 3, ra0, rb0); store_chunk((it + 1) & 1, ra1, rb1); __syncthreads();
+                    load_fast(it + 4, ra1, rb1); store_chunk((it + 2) & 1, ra2, rb2); __syncthreads();
+                    load_fast(it + 5, ra2, rb2); store_chunk((it + 3) & 1, ra0, rb0); __syncthreads();
+                }
+                // the last <= 6 steps (incl. a ragged K tail chunk, index nf): same rotation, conditions at run time
+#define FBHIP_RSTEP(r, LA, LB, SA, SB)                                                                      \
+                if (it + r < nt) {                                                                          \
+                    if (it + r + 3 < nf) load_fast(it + r + 3, LA, LB);                                     \
+                    if (it + r + 1 < nf) store_chunk((it + r + 1) & 1, SA, SB);                             \
+                    else if (it + r + 1 < nt) { load_slow(nf, SA, SB); store_chunk((it + r + 1) & 1, SA, SB); } \
+                    __syncthreads();                                                                        \
+                }
+                FBHIP_RSTEP(0, ra0, rb0, ra1, rb1)
+                FBHIP_RSTEP(1, ra1, rb1, ra2, rb2)
+                FBHIP_RSTEP(2, ra2, rb2, ra0, rb0)
+                FBHIP_RSTEP(3, ra0, rb0, ra1, rb1)
+                FBHIP_RSTEP(4, ra1, rb1, ra2, rb2)
+                FBHIP_RSTEP(5, ra2, rb2, ra0, rb0)
+#undef FBHIP_RSTEP
+            } else {
+                load_slow(0, ra0, rb0);
+                store_chunk(0, ra0, rb0);
+                __syncthreads();
+                for (int it = 0; it < nt; ++it) {
+                    if (it + 1 < nt) {
+                        load_slow(it + 1, ra0, rb0);
+                        store_chunk((it + 1) & 1, ra0, rb0);
+                    }
+                    __syncthreads();
+                }
+            }
+        } else if (nfast > 0) {
             const int nf = nfast;
             load_fast(0, ra0, rb0);
             if (nf > 1) load_fast(1, ra1, rb1);
@@ -687,6 +736,9 @@ hipError_t gemm_init() {
                                            hipFuncAttributeMaxDynamicSharedMemorySize,                               \
                                            (int)gemm_lds_bytes<wm, wn, wk, bk>());                                   \
         if (e != hipSuccess) return e;                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<wm, wn, wk, bk, true>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<wm, wn, wk, bk>());  \
+        if (e != hipSuccess) return e;                                                                               \
     }
     FBHIP_CFGS(X)
 #undef X
@@ -753,10 +805,13 @@ hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
         hipLaunchKernelGGL(gemm_dma_kernel<1>, grid, dim3(256 + 64 * DmaGeom<1>::NPW), DmaGeom<1>::LDS_BYTES, stream, g);
         return hipGetLastError();
     }
+    // FBHIP_GEMM_PF3=1: prefetch distance 3 in the producer waves (see gemm_kernel)
+    static const bool pf3 = [] { const char* e = getenv("FBHIP_GEMM_PF3"); return e && e[0] == '1'; }();
     switch (cfg) {
 #define X(id, wm, wn, wk, bk)                                                                                       \
     case id:                                                                                                         \
-        hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
+        if (pf3) hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk, true>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
+        else hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
         break;
         FBHIP_CFGS(X)
 #undef X
