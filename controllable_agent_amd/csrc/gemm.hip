@@ -708,7 +708,10 @@ hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t
 static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4, 4, 2};     // CFG_DMA128: 128 x 64, CFG_DMA64: 64 x 64 (LDS-DMA kernels)
 static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1, 2, 2};
 
-// <WM, WN, WK, BK> per configuration
+// <WM, WN, WK, BK> per configuration.  (BK = 64 for the 64x64 configuration -- half the barriers per K -- was measured at the
+// end of round 1: 151 VGPRs = one workgroup per CU unless forced to 128 with amdgpu_waves_per_eu(4) (16 dwords of scratch);
+// forced, 1024x2048x1024 alone gains ~2 % (42.7-43.8 vs 43.6-44.5 us) but the step loses 7 % (1015 vs 1093 updates/s): the
+// thin-K launches and the split-K bookkeeping pay for the deeper chunk.)
 #define FBHIP_CFGS(X) X(CFG_2x2x1, 2, 2, 1, 32) X(CFG_2x1x2, 2, 1, 2, 32) X(CFG_1x2x2, 1, 2, 2, 32) X(CFG_1x1x4, 1, 1, 4, 16) X(CFG_4x1x1, 4, 1, 1, 32)
 
 template <int WM, int WN, int WK, int BK>
