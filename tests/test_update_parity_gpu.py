@@ -723,3 +723,36 @@ def test_random_configurations_one_update_against_the_oracle(seed):
                 assert H.rel_err(g.cpu(), ref) < min(tol * amp, 0.2), (net, k, H.rel_err(g.cpu(), ref), cfg)
     for nv in (agent.forward_net, agent.backward_net, agent.actor, *agent._grad_views.values()):
         assert nv.pad_abs_max() == 0.0, nv._name
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fifty_steps_per_seed_against_the_oracle(seed):
+    """seeds {0, 1, 2}, steps 0..49, injected draws.  The oracle free-runs (it is the pinned
+    restatement of the reference, tests/test_oracle_golden.py); before every step the HIP agent is set to the oracle's state,
+    takes the step with the same draws and must report the oracle's metric dict and land on its post-step parameters,
+    targets and Adam state (tiny dims, goal space + q_loss on the odd seed)."""
+    extra = dict(goal_dim=3, use_goal=True, q_loss=True, z_dim=6, batch_size=24) if seed == 1 else {}
+    cfg = fo.OracleConfig(**{**dict(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                                    backward_hidden_dim=18, batch_size=16, lr=1e-3), **extra})
+    rng = np.random.default_rng(seed)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if cfg.use_goal else None)
+    agent = H.make_hip_agent(cfg, nets, "simplified_walker" if cfg.use_goal else None)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    oracle = fo.OracleAgent(cfg, nets)
+    for s in range(50):
+        draws = fo.make_draws(rng, cfg, 6, lengths)
+        if s > 0:
+            H.set_agent_state(agent, oracle.state_tensors(), s, s)
+        om = oracle.update(fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount, draws.future_idx), draws)
+        m = agent.update_injected(rb, s, H.draws_dict(draws))
+        assert set(m) == set(om)
+        for k, v in om.items():
+            tol = LOSS_RTOL if k not in ("M1", "F1", "B", "target_M", "q_loss") else 5e-4
+            assert m[k] == pytest.approx(v, rel=tol, abs=5e-6), (s, k)
+        want = oracle.state_tensors()
+        for k, v in H.get_agent_state(agent).items():
+            if k.startswith("adam_"):
+                assert H.rel_err(v, want[k]) < 5e-4, (s, k)
+            else:
+                _param_close(v, want[k], cfg.lr, f"seed {seed} step {s} {k}")
