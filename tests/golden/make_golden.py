@@ -154,6 +154,8 @@ def inject(R, d: fo.Draws, variable_len: bool, mix_ratio: float = 0.5, action_no
         return d.mix_uniform.copy() if calls["uniform"] == 1 else d.future_uniform.copy()
 
     def geometric(p, size=None):               # in_memory_replay_buffer.py:159 (clip at :160 is then a no-op)
+        if d.future_idx is None:               # a buffer with future < 1 under an agent that ignores future_obs: any draw will do
+            return o_geo(p, size=size)
         return (d.future_idx - d.step_idx).copy()
 
     def randperm(n, **kw):
@@ -435,6 +437,27 @@ def checkpoint_fixture(R):
         {"cfg": {k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, "global_step": 7, "global_episode": 3,
          "agent_cfg": {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(agent.cfg).items()
                        if isinstance(v, (int, float, str, bool, tuple, type(None)))}}, indent=1))
+    # the sibling agent's checkpoint (a pickled DiscreteFBAgent after two updates)
+    cfg = tiny_cfg(action_dim=4, preprocess=False)
+    rng = np.random.default_rng(32)
+    nets = {n: fo.synthetic_params(rng, do.NET_SHAPES[n](cfg)) for n in do.NET_SHAPES}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg.obs_dim, cfg.action_dim, None, None)
+    do.synthetic_actions(rng, storage, cfg.action_dim)
+    agent = make_ref_agent(R, cfg, discrete=True)
+    load_nets(agent, nets)
+    rb = fill_ref_buffer(R, storage, lengths, cfg.discount)
+    for s in range(2):
+        with inject(R, fo.make_draws(rng, cfg, 6, lengths), False, action_noise=False):
+            agent.update(rb, s)
+    with (HERE / "ref_checkpoint_tiny_discrete.pt").open("wb") as f:
+        torch.save({"agent": agent, "global_step": 5, "global_episode": 2, "replay_loader": rb}, f, pickle_protocol=4)
+    obs = rng.standard_normal((9, cfg.obs_dim)).astype(np.float32)
+    zs = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((9, cfg.z_dim)).astype(np.float32)), cfg.z_dim).numpy()
+    with torch.no_grad():
+        acts = np.array([agent.act(obs[i], {"z": zs[i]}, 0, eval_mode=True) for i in range(9)], np.int64)
+    arrays = {f"state/{k}": v for k, v in ref_state(agent).items()}
+    arrays.update(obs=obs, z=zs, act_eval=acts, fb_steps=np.int64(2))
+    np.savez_compressed(HERE / "ref_checkpoint_discrete_expect.npz", **arrays)
     print("[ref_checkpoint] ok")
 
 

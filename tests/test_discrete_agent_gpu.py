@@ -278,3 +278,24 @@ def test_two_ranks_on_one_gpu_equal_gradient_averaging():
     for n in ("forward_net", "backward_net"):
         for k, v in getattr(ref, n).items():
             np.testing.assert_allclose(got[0][0][f"{n}/{k}"], v.numpy(), rtol=0, atol=3e-6, err_msg=f"{n}/{k}")
+
+
+def test_agent_from_reference_checkpoint_file():
+    """A checkpoint written by the REAL reference holding a DiscreteFBAgent -> DiscreteFBHipAgent.from_reference_checkpoint:
+    nets, targets, Adam moments and the step count equal the reference's; act() reproduces the reference's greedy actions;
+    training continues on the buffer stored in the same file."""
+    from controllable_agent_amd.agent import DiscreteFBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    exp = np.load(H.GOLDEN / "ref_checkpoint_discrete_expect.npz")
+    agent = DiscreteFBHipAgent.from_reference_checkpoint(H.GOLDEN / "ref_checkpoint_tiny_discrete.pt", device="cuda")
+    assert agent.cfg.name == "discrete_fb" and agent.cfg.z_dim == 8 and agent.action_dim == 4
+    got = H.get_agent_state(agent)
+    for k in exp.files:
+        if k.startswith("state/"):
+            np.testing.assert_array_equal(got[k[len("state/"):]], exp[k], err_msg=k)
+    assert agent.step_counts()[0] == int(exp["fb_steps"])
+    acts = [agent.act(exp["obs"][i], {"z": exp["z"][i]}, 0, eval_mode=True) for i in range(len(exp["obs"]))]
+    assert acts == exp["act_eval"].tolist()
+    rb = DeviceReplayBuffer.from_reference_file(H.GOLDEN / "ref_checkpoint_tiny_discrete.pt", device="cuda")
+    m = agent.update(rb, 2)
+    assert np.isfinite(m["fb_loss"]) and agent.step_counts()[0] == 3

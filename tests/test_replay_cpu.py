@@ -147,3 +147,25 @@ def test_reference_checkpoint_reads_without_the_reference_installed():
         assert tuple(b.obs.shape) == (8, exp["storage/observation"].shape[2])
     assert rb._discount == pytest.approx(0.99)
     assert DeviceReplayBuffer.from_reference_file(GOLDEN / "ref_replay_tiny.pt", device="cpu", discount=0.9)._discount == 0.9
+
+
+def test_reference_discrete_checkpoint_reads_without_the_reference():
+    """The sibling agent's checkpoint (a pickled ``DiscreteFBAgent``, discrete_fb.py) through the same reader: config fields,
+    the four nets in state_dict() order, the FB Adam moments."""
+    from controllable_agent_amd import reference_io as rio
+    payload = rio.load_reference_payload(H.GOLDEN / "ref_checkpoint_tiny_discrete.pt")
+    exp = np.load(H.GOLDEN / "ref_checkpoint_discrete_expect.npz")
+    agent = payload["agent"]
+    assert isinstance(agent, rio.ReferenceObject) and agent._ref_name == "DiscreteFBAgent" and not hasattr(agent, "actor")
+    fields = rio.reference_agent_config(agent)
+    assert fields["name"] == "discrete_fb" and fields["preprocess"] is False and fields["action_shape"] == (4,) and fields["expl_eps"] == 0.2
+    for net in ("forward_net", "backward_net", "forward_target_net", "backward_target_net"):
+        sd = getattr(agent, net).state_dict()
+        assert list(sd) == [k.split("/", 2)[2] for k in exp.files if k.startswith(f"state/{net}/")]
+        for k, v in sd.items():
+            np.testing.assert_array_equal(v.numpy(), exp[f"state/{net}/{k}"], err_msg=f"{net}/{k}")
+    assert sd["F2.2.weight"].shape == (8 * 4, 32) if net.startswith("forward") else True
+    osd = agent.fb_opt.state_dict()
+    names = [f"forward_net/{k}" for k in agent.forward_net.state_dict()] + [f"backward_net/{k}" for k in agent.backward_net.state_dict()]
+    for i, n in enumerate(names):
+        np.testing.assert_array_equal(osd["state"][i]["exp_avg"].numpy(), exp[f"state/adam_m/{n}"], err_msg=n)
