@@ -299,3 +299,68 @@ def test_agent_from_reference_checkpoint_file():
     rb = DeviceReplayBuffer.from_reference_file(H.GOLDEN / "ref_checkpoint_tiny_discrete.pt", device="cuda")
     m = agent.update(rb, 2)
     assert np.isfinite(m["fb_loss"]) and agent.step_counts()[0] == 3
+
+
+def _random_case(seed):
+    r = np.random.default_rng(seed)
+    use_goal = bool(r.integers(0, 2))
+    cfg = dict(obs_dim=int(r.integers(2, 12)), action_dim=int(r.integers(1, 20)), z_dim=int(r.integers(3, 40)),
+               hidden_dim=4 * int(r.integers(4, 24)), feature_dim=16, backward_hidden_dim=int(r.integers(5, 70)),
+               batch_size=int(r.integers(4, 80)), q_loss=bool(r.integers(0, 2)), norm_z=bool(r.integers(0, 4) > 0),
+               boltzmann=bool(r.integers(0, 2)), rand_weight=bool(r.integers(0, 3) == 0), preprocess=False,
+               mix_ratio=float(r.choice([0.0, 0.3, 0.5, 1.0])), lr_coef=float(r.choice([1.0, 0.5])), ortho_coef=float(r.choice([1.0, 0.1])),
+               temp=float(r.choice([1.0, 0.2, 100.0])), lr=1e-3)
+    if bool(r.integers(0, 3) == 0):
+        cfg.update(future_ratio=0.4, future=0.8)
+    if use_goal:
+        cfg.update(goal_dim=int(r.choice([2, 3])), use_goal=True)
+    else:
+        cfg["goal_dim"] = cfg["obs_dim"]
+    if cfg["q_loss"]:                              # a full-rank covariance for the pseudo-inverse (see the FB-DDPG sweep)
+        cfg["batch_size"] = max(cfg["batch_size"], 3 * cfg["z_dim"])
+        cfg["backward_hidden_dim"] = max(cfg["backward_hidden_dim"], cfg["z_dim"] + 8)
+    return fo.OracleConfig(**cfg), ({2: "simplified_quadruped", 3: "simplified_walker"}[cfg["goal_dim"]] if use_goal else None)
+
+
+@pytest.mark.parametrize("seed", list(range(500, 560)))
+def test_random_configurations_one_update_against_the_oracle(seed):
+    """Sixty seeded random draws over dimensions (A from 1 to 19) and every switch the discrete step has (goal space, q_loss,
+    norm_z, boltzmann + temp, rand_weight, hindsight replay, mix_ratio, lr_coef, ortho_coef): one injected update, losses and
+    every gradient tensor against the oracle."""
+    import dataclasses
+    cfg, goal_space = _random_case(seed)
+    rng = np.random.default_rng(2000 + seed)
+    nets = {n: fo.synthetic_params(rng, do.NET_SHAPES[n](cfg)) for n in do.NET_SHAPES}
+    storage, lengths = fo.synthetic_storage(rng, 6, 9, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if cfg.use_goal else None)
+    do.synthetic_actions(rng, storage, cfg.action_dim)
+    draws = fo.make_draws(rng, cfg, 6, lengths)
+    batch = fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount, draws.future_idx)
+    oracle = do.DiscreteOracleAgent(cfg, nets)
+    om = oracle.update(batch, draws, keep=True)
+    amp = 1.0
+    if cfg.q_loss:
+        Bm = oracle.last["Bm"].double()
+        cond = float(torch.linalg.cond(Bm.T @ Bm / Bm.shape[0]))
+        if cond > 2e5:                             # (where the tolerance below reaches its cap) numerically singular in fp32:
+                                                   # pinv (SVD) here, Gauss-Jordan there -- noise on both sides
+            cfg = dataclasses.replace(cfg, q_loss=False)
+            oracle = do.DiscreteOracleAgent(cfg, nets)
+            om = oracle.update(batch, draws, keep=True)
+        else:
+            amp = max(1.0, cond / 1e3)
+    agent = H.make_hip_agent(cfg, nets, goal_space, discrete=True)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    m = agent.update_injected(rb, 0, H.draws_dict(draws))
+    for k in DKEYS + (("q_loss",) if cfg.q_loss else ()):
+        assert m[k] == pytest.approx(om[k], rel=min(2e-4 * amp, 5e-2), abs=2e-5), (k, cfg)
+    # (a near-tie of the arg-max over A on the target side moves one row of a small batch: tolerance like the actor's in the
+    # FB-DDPG sweep)
+    for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward")):
+        for k, g in agent._grad_views[net].state_dict().items():
+            ref = oracle.last[key][k]
+            if float(ref.abs().max()) == 0.0:
+                assert float(g.abs().max()) == 0.0, (net, k, cfg)
+            else:
+                assert H.rel_err(g.cpu(), ref) < min(1e-3 * amp, 0.2), (net, k, H.rel_err(g.cpu(), ref), cfg)
+    for nv in (agent.forward_net, agent.backward_net, *[agent._grad_views[n] for n in ("forward_net", "backward_net")]):
+        assert nv.pad_abs_max() == 0.0, nv._name
