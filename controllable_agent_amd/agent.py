@@ -998,5 +998,6 @@ class DiscreteFBHipAgent(FBHipAgent):
                 action = int(torch.randint(0, self.action_dim, (1,))[0])
         return action
 
-    def compute_z_correl(self, time_step: tp.Any, meta: MetaDict) -> float:
+    @property
+    def compute_z_correl(self) -> tp.Any:            # DiscreteFBAgent has none (discrete_fb.py): hasattr() must say so
         raise AttributeError("DiscreteFBAgent has no compute_z_correl (discrete_fb.py)")

@@ -364,3 +364,38 @@ def test_random_configurations_one_update_against_the_oracle(seed):
                 assert H.rel_err(g.cpu(), ref) < min(1e-3 * amp, 0.2), (net, k, H.rel_err(g.cpu(), ref), cfg)
     for nv in (agent.forward_net, agent.backward_net, *[agent._grad_views[n] for n in ("forward_net", "backward_net")]):
         assert nv.pad_abs_max() == 0.0, nv._name
+
+
+def test_online_loop_with_the_discrete_agent():
+    """run_online (pretrain.py:559-659 counterpart) with the discrete agent: integer actions from the batch-1 fast path with
+    epsilon-greedy exploration, stored as one float per transition, updates every second step after the seed frames."""
+    from controllable_agent_amd.replay import DeviceReplayBuffer, TimeStep
+    from controllable_agent_amd.train_online import run_online
+    cfg, rng, nets, _, _ = _mid_case(136, action_dim=5, batch_size=16, hidden_dim=32, z_dim=8, backward_hidden_dim=18, obs_dim=5, goal_dim=5)
+    agent = H.make_hip_agent(cfg, nets, discrete=True)
+    agent.cfg.update_every_steps = 2
+    assert not hasattr(agent, "compute_z_correl")
+    seen = set()
+
+    class Env:
+        T, t = 6, 0
+
+        def _ts(self, kind, action):
+            return TimeStep(step_type=kind, reward=0.5, discount=1.0, observation=rng.standard_normal(5).astype(np.float32),
+                            action=np.asarray([action], np.float32), physics=np.zeros(2, np.float32))
+
+        def reset(self):
+            self.t = 0
+            return self._ts(0, 0)
+
+        def step(self, action):
+            assert isinstance(action, int) and 0 <= action < 5
+            seen.add(action)
+            self.t += 1
+            return self._ts(2 if self.t == self.T else 1, action)
+
+    rb = DeviceReplayBuffer(max_episodes=4, discount=0.98, future=1.0, device="cuda")
+    st = run_online(agent, rb, Env(), num_train_frames=60, num_seed_frames=18)
+    assert (st.env_steps, st.updates) == (60, 21) and agent.step_counts()[0] == 21
+    assert len(seen) > 1 and rb._storage["action"].shape[-1] == 1
+    assert all(np.isfinite(v).all() for v in H.get_agent_state(agent).values())
