@@ -559,6 +559,8 @@ struct Ops {
     std::vector<LnBwdProblem> lnb;
     std::vector<L2Problem> l2n;               // run after this round's GEMMs
     std::vector<PolicyHeadJob> ph;            // fused policy heads of this round (one launch for all of them)
+    std::vector<DiscreteHeadJob> dh;          // discrete: the selection / gather row jobs of this round (one launch)
+    int dh_rows = 0, dh_ldz = 0;
     std::vector<std::function<int(hipStream_t)>> post;
 };
 using Stage = std::function<void(Ops&)>;
@@ -597,6 +599,15 @@ int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
         PolicyHeadJobs jobs{};
         for (size_t j = i; j < o.ph.size() && j < i + PH_MAX_JOBS; ++j) jobs.j[jobs.n++] = o.ph[j];
         RC(c->run_policy_heads(jobs, s));
+    }
+    if (!o.dh.empty()) {
+        const fbhip_dims& d = c->d;
+        for (size_t i = 0; i < o.dh.size(); i += 2) {
+            DiscreteHeadJobs jobs{};
+            for (size_t j = i; j < o.dh.size() && j < i + 2; ++j) jobs.j[jobs.n++] = o.dh[j];
+            HIPCK(c, launch_discrete_heads(jobs, pad4(fhead_out(d)), o.dh_ldz, pad4(d.z_dim), o.dh_rows, d.z_dim, d.action_dim,
+                                           d.boltzmann, c->sq.temp, s));
+        }
     }
     for (auto& f : o.post) RC(f(s));
     return FBHIP_OK;
@@ -679,21 +690,21 @@ void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda
     });
     if (!with_heads) return;                     // the actor phase gets Q from p directly (actor_q_kernel)
     if (d.discrete) {                            // heads emit [rows, z * A]; the embedding the loss sees is picked by a row kernel
-        const int zA = fhead_out(d), Lza = pad4(zA), A = d.action_dim;
+        const int zA = fhead_out(d), Lza = pad4(zA);
         Ws* w = &c->W();
         const bool target = disc_mode == 1;
-        const int boltz = d.boltzmann;
         out.push_back([=](Ops& o) {
             o.gemms.push_back(P(Sp->p.p, 2 * H, 1, W.W4[0], H, 1, Sp->Fall1.p, Lza, rows, zA, H, W.b4[0], EPI_BIAS));
             o.gemms.push_back(P(Sp->p.p + H, 2 * H, 1, W.W4[1], H, 1, Sp->Fall2.p, Lza, rows, zA, H, W.b4[1], EPI_BIAS));
-            o.post.push_back([=](hipStream_t s) -> int {
-                if (target)                      // discrete_fb.py:289-303 (also act(): the arg-max index)
-                    HIPCK(c, launch_discrete_select(Sp->Fall1.p, Sp->Fall2.p, Lza, disc_z, disc_ldz, Sp->F1.p, Sp->F2.p, Lz,
-                                                    w->nextq, w->greedy, rows, z, A, boltz, c->sq.temp, s));
-                else                             // discrete_fb.py:309-311
-                    HIPCK(c, launch_discrete_gather(Sp->Fall1.p, Sp->Fall2.p, Lza, w->act_idx, Sp->F1.p, Sp->F2.p, Lz, rows, z, A, s));
-                return (int)FBHIP_OK;
-            });
+            // the row jobs of a round go out as ONE launch (flush_round): target-side selection (discrete_fb.py:289-303; also
+            // act(): the arg-max index) and online-side gather (:309-311)
+            o.dh_rows = rows;
+            if (target) {
+                o.dh_ldz = disc_ldz;
+                o.dh.push_back(DiscreteHeadJob{Sp->Fall1.p, Sp->Fall2.p, disc_z, nullptr, Sp->F1.p, Sp->F2.p, w->nextq, w->greedy, 0});
+            } else {
+                o.dh.push_back(DiscreteHeadJob{Sp->Fall1.p, Sp->Fall2.p, nullptr, w->act_idx, Sp->F1.p, Sp->F2.p, nullptr, nullptr, 1});
+            }
         });
         return;
     }

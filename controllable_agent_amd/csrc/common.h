@@ -168,6 +168,11 @@ hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z
 // DiscreteFBAgent heads, [rows, d * A] with (k, a) at column k * A + a (discrete_fb.py:289-311): target-side selection
 // (greedy column or softmax mix, + next_Q and the greedy index), online-side gather of the taken action's column, and the
 // gather's backward
+struct DiscreteHeadJob { const float* Fall1; const float* Fall2; const float* z; const float* act_idx; float* out1; float* out2;
+                         float* nextq; int32_t* act_out; int gather; };
+struct DiscreteHeadJobs { DiscreteHeadJob j[2]; int n; };
+hipError_t launch_discrete_heads(const DiscreteHeadJobs& jobs, int ldfa, int ldz, int ldo, int rows, int d, int A, int boltz,
+                                 float temp, hipStream_t s);
 hipError_t launch_discrete_select(const float* Fall1, const float* Fall2, int ldfa, const float* z, int ldz, float* out1,
                                   float* out2, int ldo, float* nextq, int32_t* act_out, int rows, int d, int A, int boltz,
                                   float temp, hipStream_t s);

@@ -1046,19 +1046,22 @@ hipError_t launch_concat2(float* dst, int ld, const float* A, int lda, int na, c
 //   GATHER (online side, :309-311): out_i[k] = Fall_i[k, action]
 // lanes are (a, part): a = lane % AP (AP = A rounded up to a power of two), the 64 / AP parts split k; a butterfly over
 // the parts leaves the full Q_i[a] on every lane (fixed order: deterministic)
-template <int MODE>        // 0 select, 1 gather
-__global__ void __launch_bounds__(256) discrete_head_kernel(const float* __restrict__ Fall1, const float* __restrict__ Fall2,
-                                                            int ldfa, const float* __restrict__ z, int ldz,
-                                                            const float* __restrict__ act_idx, float* __restrict__ out1,
-                                                            float* __restrict__ out2, int ldo, float* __restrict__ nextq,
-                                                            int32_t* __restrict__ act_out, int rows, int d, int A, int AP,
-                                                            int boltz, float inv_temp) {
+// (blockIdx.y picks the job: the target-side selection and the online-side gather of one update share a launch)
+__global__ void __launch_bounds__(256) discrete_head_kernel(const DiscreteHeadJobs jobs, int ldfa, int ldz, int ldo, int rows,
+                                                            int d, int A, int AP, int boltz, float inv_temp) {
     __shared__ float s_pi[4][64];
+    const DiscreteHeadJob& jb = jobs.j[blockIdx.y];
+    const float* __restrict__ z = jb.z;
+    const float* __restrict__ act_idx = jb.act_idx;
+    float* __restrict__ out1 = jb.out1;
+    float* __restrict__ out2 = jb.out2;
+    float* __restrict__ nextq = jb.nextq;
+    int32_t* __restrict__ act_out = jb.act_out;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, row = blockIdx.x * 4 + wid;
     if (row >= rows) return;
-    const float* f1 = Fall1 + (size_t)row * ldfa;
-    const float* f2 = Fall2 + (size_t)row * ldfa;
-    if (MODE == 1) {
+    const float* f1 = jb.Fall1 + (size_t)row * ldfa;
+    const float* f2 = jb.Fall2 + (size_t)row * ldfa;
+    if (jb.gather) {
         const int a = (int)act_idx[row];
         for (int k = lane; k < d; k += 64) {
             out1[(size_t)row * ldo + k] = f1[k * A + a];
@@ -1144,18 +1147,26 @@ __global__ void __launch_bounds__(256) discrete_scatter_kernel(const float* __re
 hipError_t launch_discrete_select(const float* Fall1, const float* Fall2, int ldfa, const float* z, int ldz, float* out1,
                                   float* out2, int ldo, float* nextq, int32_t* act_out, int rows, int d, int A, int boltz,
                                   float temp, hipStream_t s) {
-    if (A < 1 || A > 64) return hipErrorInvalidValue;
+    DiscreteHeadJobs jobs{};
+    jobs.n = 1;
+    jobs.j[0] = DiscreteHeadJob{Fall1, Fall2, z, nullptr, out1, out2, nextq, act_out, 0};
+    return launch_discrete_heads(jobs, ldfa, ldz, ldo, rows, d, A, boltz, temp, s);
+}
+hipError_t launch_discrete_heads(const DiscreteHeadJobs& jobs, int ldfa, int ldz, int ldo, int rows, int d, int A, int boltz,
+                                 float temp, hipStream_t s) {
+    if (A < 1 || A > 64 || jobs.n < 1 || jobs.n > 2) return hipErrorInvalidValue;
     int AP = 1;
     while (AP < A) AP <<= 1;
-    hipLaunchKernelGGL(discrete_head_kernel<0>, dim3((rows + 3) / 4), dim3(256), 0, s, Fall1, Fall2, ldfa, z, ldz,
-                       (const float*)nullptr, out1, out2, ldo, nextq, act_out, rows, d, A, AP, boltz, 1.0f / temp);
+    hipLaunchKernelGGL(discrete_head_kernel, dim3((rows + 3) / 4, jobs.n), dim3(256), 0, s, jobs, ldfa, ldz, ldo, rows, d, A, AP,
+                       boltz, 1.0f / temp);
     return hipGetLastError();
 }
 hipError_t launch_discrete_gather(const float* Fall1, const float* Fall2, int ldfa, const float* act_idx, float* out1,
                                   float* out2, int ldo, int rows, int d, int A, hipStream_t s) {
-    hipLaunchKernelGGL(discrete_head_kernel<1>, dim3((rows + 3) / 4), dim3(256), 0, s, Fall1, Fall2, ldfa,
-                       (const float*)nullptr, 0, act_idx, out1, out2, ldo, (float*)nullptr, (int32_t*)nullptr, rows, d, A, 1, 0, 1.f);
-    return hipGetLastError();
+    DiscreteHeadJobs jobs{};
+    jobs.n = 1;
+    jobs.j[0] = DiscreteHeadJob{Fall1, Fall2, nullptr, act_idx, out1, out2, nullptr, nullptr, 1};
+    return launch_discrete_heads(jobs, ldfa, 0, ldo, rows, d, A, 0, 1.f, s);
 }
 hipError_t launch_discrete_scatter(const float* dF1, const float* dF2, int ldf, const float* act_idx, float* dFall1,
                                    float* dFall2, int ldfa, int rows, int d, int A, hipStream_t s) {
