@@ -73,7 +73,8 @@ def _mid_case(seed, **kw):
 
 
 @pytest.mark.parametrize("flags", [dict(), dict(boltzmann=True, temp=2.0, q_loss=True), dict(action_dim=33, z_dim=37, mix_ratio=1.0),
-                                   dict(action_dim=1), dict(action_dim=64, z_dim=100, batch_size=96)])
+                                   dict(action_dim=1), dict(action_dim=64, z_dim=100, batch_size=96),
+                                   dict(obs_dim=24, goal_dim=24, hidden_dim=1024, backward_hidden_dim=526, batch_size=1024)])   # the bench dims
 def test_free_running_mid_dims_against_the_oracle(flags):
     """Mid-size networks (H 256, d 50, B 512; A from 1 to 64 incl. non-powers of two), three free-running updates: loss curves
     against the oracle; gradients of the first step tensor by tensor."""
