@@ -958,8 +958,6 @@ class DiscreteFBHipAgent(FBHipAgent):
         if cfg.preprocess:
             # discrete_fb.ForwardMap.forward (:91-94) reads self.obs_action_net, which its constructor never builds
             raise NotImplementedError("DiscreteFBHipAgent: preprocess=True cannot run in the reference either (discrete_fb.py:91-94)")
-        if cfg.dp_global_batch:
-            raise NotImplementedError("DiscreteFBHipAgent: dp_global_batch is not wired for the discrete agent")
         super().__init__(**kwargs)
 
     def greedy_action(self, obs: tp.Any, z: tp.Any, target: bool = False) -> torch.Tensor:

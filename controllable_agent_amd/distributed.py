@@ -100,7 +100,8 @@ def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, acto
     import torch.distributed as dist
     world = world_size()
     if exchange is not None:
-        reduce = dist.all_reduce if (dist.is_available() and dist.is_initialized()) else (lambda t: None)
+        live_ = dist.is_available() and dist.is_initialized()
+        reduce = (lambda t: dist.all_reduce(t) if t.numel() > 0 else None) if live_ else (lambda t: None)
         run_phases(PHASE_SAMPLE | PHASE_FB_FWD)
         exchange()
         run_phases(PHASE_FB_BWD | PHASE_ACTOR_FWD)

@@ -400,3 +400,86 @@ def test_online_loop_with_the_discrete_agent():
     assert (st.env_steps, st.updates) == (60, 21) and agent.step_counts()[0] == 21
     assert len(seen) > 1 and rb._storage["action"].shape[-1] == 1
     assert all(np.isfinite(v).all() for v in H.get_agent_state(agent).values())
+
+
+# ------------------------------------------------------------------------------------------ mode B: exact global batch
+def _gb_setup(q_loss):
+    from tests import test_distributed_cpu as T
+    cfg = fo.OracleConfig(**{**T.CFG, "action_dim": 4, "preprocess": False, "batch_size": 32, "q_loss": q_loss, "boltzmann": q_loss,
+                             "temp": 0.5})
+    rng = np.random.default_rng(19)
+    nets = {n: fo.synthetic_params(rng, do.NET_SHAPES[n](cfg)) for n in do.NET_SHAPES}
+    storage, lengths = fo.synthetic_storage(rng, T.N_EPS, T.T, cfg.obs_dim, cfg.action_dim)
+    do.synthetic_actions(rng, storage, cfg.action_dim)
+    return cfg, nets, storage, lengths
+
+
+def _gb_worker(rank, port, out_q, q_loss):
+    import os
+    import torch.distributed as dist
+    from controllable_agent_amd.agent import DiscreteFBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    from tests import test_distributed_cpu as T
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    cfg, nets, storage, lengths = _gb_setup(q_loss)
+    agent = DiscreteFBHipAgent(**H.agent_kwargs(cfg, dp_global_batch=True))
+    agent.load_nets({n: dict(p) for n, p in nets.items()})
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    metrics = []
+    for step in range(T.STEPS):
+        d = fo.make_draws(np.random.default_rng(1000 * step + rank), cfg, len(rb), rb._episodes_length)
+        metrics.append(agent.update_injected(rb, step, H.draws_dict(d), use_graph=True))
+    torch.cuda.synchronize()
+    out_q.put((rank, H.get_agent_state(agent), metrics))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("q_loss", [False, True])
+def test_two_ranks_global_batch_equal_one_device_on_the_concatenated_batch(q_loss):
+    """dp_global_batch=True (mode B of DESIGN.md section 7) with the discrete agent: two ranks x 32 rows == ONE oracle update
+    on the 64-row batch of both ranks' rows; the second case adds softmax targets and the q_loss on the gathered B rows."""
+    import torch.multiprocessing as mp
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    from tests import test_distributed_cpu as T
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_gb_worker, args=(r, port, q, q_loss)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(T.WORLD)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    results = {r: st for r, st, _ in got}
+    metrics = {r: m for r, _, m in got}
+    cfg, nets, storage, lengths = _gb_setup(q_loss)
+    ref = do.DiscreteOracleAgent(cfg, nets)
+    for step in range(T.STEPS):
+        batches, draws = [], []
+        for r in range(T.WORLD):
+            rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cpu").shard(r, T.WORLD)
+            sh = {k: v.numpy() for k, v in rb._storage.items()}
+            d = fo.make_draws(np.random.default_rng(1000 * step + r), cfg, len(rb), rb._episodes_length)
+            batches.append(fo.gather_batch(sh, d.ep_idx, d.step_idx, cfg.discount))
+            draws.append(d)
+        B = cfg.batch_size
+        cat = lambda f: np.concatenate([getattr(d, f) for d in draws])
+        both = fo.Draws(ep_idx=cat("ep_idx"), step_idx=cat("step_idx"), z_gauss=cat("z_gauss"),
+                        perm=np.concatenate([d.perm + r * B for r, d in enumerate(draws)]), mix_uniform=cat("mix_uniform"),
+                        eps_next=cat("eps_next"), eps_actor=cat("eps_actor"))
+        batch = {k: np.concatenate([b[k] for b in batches]) for k in batches[0] if batches[0][k] is not None}
+        m = ref.update(batch, both)
+        for k in DKEYS + ("orth_linf", "orth_l2", "M1", "target_M", "F1", "B", "B_norm", "z_norm") + (("q_loss",) if q_loss else ()):
+            for r in range(T.WORLD):
+                assert metrics[r][step][k] == pytest.approx(m[k], rel=5e-5, abs=2e-6), (step, r, k)
+    want = ref.state_tensors()
+    for k in results[0]:
+        np.testing.assert_array_equal(results[0][k], results[1][k], err_msg=k)
+    for k, v in want.items():
+        if k.startswith("adam_"):
+            assert H.rel_err(results[0][k], v) < 2e-4, k
+        else:
+            np.testing.assert_allclose(results[0][k], v, rtol=0, atol=3e-6, err_msg=k)
