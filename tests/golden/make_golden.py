@@ -316,6 +316,17 @@ def discrete_fixture(R):
                   seed=121, n_eps=6, T=12, n_steps=4, discrete=True)
 
 
+def long_curve_fixtures(R):
+    """50 free-running steps at full network dims, metric dict per step + parameter checksums at
+    steps {1, 10, 50}: walker B=256; quadruped with goal_space B=256."""
+    trace_fixture(R, "walker_b256_50", fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50, batch_size=256),
+                  seed=211, n_eps=20, T=100, n_steps=50, full_state=False, checksum_steps=(1, 10, 50))
+    trace_fixture(R, "quadruped_goal_b256_50",
+                  fo.OracleConfig(obs_dim=78, action_dim=12, goal_dim=2, z_dim=100, batch_size=256, use_goal=True),
+                  seed=212, n_eps=12, T=60, n_steps=50, goal_space="simplified_quadruped", full_state=False,
+                  checksum_steps=(1, 10, 50))
+
+
 def sampler_fixture(R):
     """ReplayBuffer.sample KAT: variable lengths + goal + stored meta z; real numpy RNG, fixed seed."""
     rng = np.random.default_rng(7)
@@ -492,6 +503,7 @@ def main():
                   fo.OracleConfig(obs_dim=78, action_dim=12, goal_dim=2, z_dim=100, batch_size=512, use_goal=True),
                   seed=203, n_eps=12, T=60, n_steps=3, goal_space="simplified_quadruped", full_state=False,
                   checksum_steps=(1, 3))
+    long_curve_fixtures(R)
     sampler_fixture(R)
     init_fixture(R)
     inference_fixture(R)

@@ -98,13 +98,16 @@ def test_teacher_forced_against_reference_trace(name, goal_space):
             assert nv.pad_abs_max() == 0.0, (s, nv._name)
 
 
-@pytest.mark.parametrize("name,tol", [("walker_b256", 3e-4), ("walker_b1024", 3e-4)])
+@pytest.mark.parametrize("name,tol", [("walker_b256", 3e-4), ("walker_b1024", 3e-4), ("walker_b256_50", 3e-4),
+                                      ("quadruped_goal_b256_50", 3e-4)])
 def test_free_running_full_dims_against_reference_curves(name, tol):
-    """Full walker dims, free-running from the seed-defined init: FB-loss / actor-loss / Q curves and parameter
-    checksums vs the reference.  Tolerance grows with the step like the reference's own 1-vs-8-thread drift."""
+    """Full network dims, free-running from the seed-defined init: FB-loss / actor-loss / Q curves and parameter
+    checksums vs the reference (the ``_50`` fixtures: 50 steps, checksums at steps 1 / 10 / 50; measured drift of the HIP
+    path at step 49: 2.3e-3 walker, 1.1e-3 quadruped + goal space, tools/curve_probe.py).  Tolerance grows with the step
+    like the reference's own 1-vs-8-thread drift (2.8e-3 at step 39)."""
     meta = H.load_meta(name)
     cfg, nets, storage, lengths, rng = H.regenerate_inputs(meta)
-    agent = H.make_hip_agent(cfg, nets)
+    agent = H.make_hip_agent(cfg, nets, meta["goal_space"])
     rb = _buffer(storage, lengths, cfg.discount)
     for s in range(meta["n_steps"]):
         d = fo.make_draws(rng, cfg, meta["n_eps"], lengths)
@@ -121,7 +124,7 @@ def test_free_running_full_dims_against_reference_curves(name, tol):
         if str(s + 1) in meta["checksums"]:
             ref = meta["checksums"][str(s + 1)]
             for k, (ssum, l2) in H.checksums(H.get_agent_state(agent)).items():
-                assert l2 == pytest.approx(ref[k][1], rel=1e-5), (s, k)
+                assert l2 == pytest.approx(ref[k][1], rel=1e-5 * (1 + s / 4)), (s, k)
 
 
 def test_graph_replay_equals_eager_launches():
