@@ -632,6 +632,13 @@ class FBHipAgent:
         return float(out[0])
 
     # ------------------------------------------------------------------ the hot path
+    def _stddev_is_constant(self) -> bool:
+        try:
+            float(self.cfg.stddev_schedule)
+            return True
+        except (TypeError, ValueError):
+            return False
+
     def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float, future: float = 1.0) -> HParams:
         c = self.cfg
         if c.future_ratio > 0 and not future < 1:
@@ -779,7 +786,9 @@ class FBHipAgent:
         if isinstance(replay_loader, DeviceReplayBuffer):
             self._bind_replay(replay_loader)
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
-            self._run_update(hp, None, self._use_graph)
+            # a captured graph bakes stddev in: with a time-varying stddev_schedule (utils.py:235-255) every step would be a
+            # fresh capture + instantiation (milliseconds), so those configurations run as eager launches instead
+            self._run_update(hp, None, self._use_graph and self._stddev_is_constant())
         else:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)

@@ -759,3 +759,31 @@ def test_fifty_steps_per_seed_against_the_oracle(seed):
                 assert H.rel_err(v, want[k]) < 5e-4, (s, k)
             else:
                 _param_close(v, want[k], cfg.lr, f"seed {seed} step {s} {k}")
+
+
+def test_time_varying_stddev_schedule_runs_eagerly_and_matches_the_oracle():
+    """stddev_schedule='linear(1.0,0.1,10)' (utils.py:235-255): every step has its own stddev, so the update runs as eager
+    launches (no per-step graph capture) and still equals the oracle step by step (teacher-forced)."""
+    from controllable_agent_amd.agent import FBHipAgent, schedule
+    cfg0 = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16, backward_hidden_dim=18,
+                           batch_size=16, lr=1e-3)
+    rng = np.random.default_rng(9)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg0)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg0.obs_dim, cfg0.action_dim)
+    agent = FBHipAgent(**H.agent_kwargs(cfg0, stddev_schedule="linear(1.0,0.1,10)"))
+    agent.load_nets({n: dict(p) for n, p in nets.items()})
+    assert not agent._stddev_is_constant()
+    rb = _buffer(storage, lengths, cfg0.discount)
+    oracle = fo.OracleAgent(cfg0, nets)
+    for s in range(6):
+        import dataclasses
+        oracle.cfg = dataclasses.replace(cfg0, stddev=schedule("linear(1.0,0.1,10)", s))
+        draws = fo.make_draws(rng, cfg0, 6, lengths)
+        if s > 0:
+            H.set_agent_state(agent, oracle.state_tensors(), s, s)
+        om = oracle.update(fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg0.discount), draws)
+        m = agent.update_injected(rb, s, H.draws_dict(draws), use_graph=False)
+        for k in H.LOSS_KEYS + ("actor_logprob",):
+            assert m[k] == pytest.approx(om[k], rel=2e-5, abs=2e-6), (s, k)
+    n_graphs_before = len(agent.update(rb, 6))          # device draws through update(): must not raise, metrics come back
+    assert n_graphs_before > 0
