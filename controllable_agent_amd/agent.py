@@ -821,15 +821,19 @@ class FBHipAgent:
             lib = _lib.load()
 
             def launch() -> None:
-                s = stream_ptr()
                 actor_bits = (_lib.PHASE_ACTOR_GRAD | _lib.PHASE_ACTOR_STEP | _lib.PHASE_ACTOR_FWD) if self._discrete else 0
 
-                def phases(mask: int) -> None:
+                def phases(mask: int) -> None:           # (on torch's CURRENT stream: dp_update_many switches to its side stream)
                     if mask & ~actor_bits:
-                        check(lib.fbhip_update(self._ctx, C.byref(hp), None, mask & ~actor_bits, 1, s), self._ctx)
+                        check(lib.fbhip_update(self._ctx, C.byref(hp), None, mask & ~actor_bits, 1, stream_ptr()), self._ctx)
+                side = None
+                if not self._discrete and os.environ.get("FBHIP_DP_SIDE_STREAM", "1") != "0":
+                    if getattr(self, "_side_stream", None) is None:
+                        self._side_stream = torch.cuda.Stream(device=self._device)
+                    side = self._side_stream
                 dp_update_many(phases,
                                lambda which: check(lib.fbhip_select_workspace_set(self._ctx, which), self._ctx),
-                               self._fb_grads, self._actor_grads, n_steps, early=self._early_grad_range())
+                               self._fb_grads, self._actor_grads, n_steps, early=self._early_grad_range(), side=side)
             self._on_update_stream(launch)
             return self._metrics()
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)

@@ -124,7 +124,8 @@ def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, acto
 
 
 def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable[[int], None], fb_grads: torch.Tensor,
-                   actor_grads: torch.Tensor, n_steps: int, early: tp.Optional[tp.Tuple[int, int]] = None) -> None:
+                   actor_grads: torch.Tensor, n_steps: int, early: tp.Optional[tp.Tuple[int, int]] = None,
+                   side: tp.Optional["torch.cuda.Stream"] = None) -> None:
     """``n_steps`` consecutive mode-A updates with the steps software-pipelined: step t+1's sampling, z mixing, B passes and
     online ForwardMap pass (``SAMPLE | FB_FWD_ONLINE``: they depend on step t only through its FB optimiser step) are
     launched on the OTHER workspace set while step t's actor-gradient all-reduce is in flight, so that all-reduce is hidden
@@ -135,6 +136,11 @@ def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable
         head(0);  for t:  FB_FWD_TARGET|FB_BWD_A|ACTOR_FWD -> all_reduce(fb heads, async) || FB_BWD_B|ACTOR_FWD -> wait
                           -> all_reduce(fb rest) -> FB_STEP|ACTOR_GRAD
                           -> all_reduce(actor, async) || head(t+1) -> wait -> ACTOR_STEP
+
+    With ``side`` (a second CUDA stream; ``run_phases`` must launch on torch's CURRENT stream) the next head starts even
+    earlier, right after the FB optimiser step, on that stream: it then runs beside the actor phase itself (its ~20 dependent
+    small launches leave most of the GPU idle) AND beside the all-reduce, exactly like the single-GPU pipeline of
+    ``fbhip_update_many``:   FB_STEP -> [ side: head(t+1) ]  ||  [ main: ACTOR_GRAD -> all_reduce(actor) -> ACTOR_STEP ] -> join
     """
     import torch.distributed as dist
     live = dist.is_available() and dist.is_initialized()
@@ -145,6 +151,23 @@ def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable
         run_phases(head)
         for t in range(n_steps):
             _reduce_fb(run_phases, fb_grads, early, PHASE_FB_FWD_TARGET | PHASE_FB_BWD_A | PHASE_ACTOR_FWD, live)
+            if side is not None and t + 1 < n_steps:
+                main = torch.cuda.current_stream()
+                run_phases(PHASE_FB_STEP)
+                side.wait_stream(main)                   # fork: the head needs the new FB weights, nothing of the actor phase
+                select_set(cur ^ 1)
+                with torch.cuda.stream(side):
+                    run_phases(head)
+                select_set(cur)
+                run_phases(PHASE_ACTOR_GRAD)
+                work = dist.all_reduce(actor_grads, async_op=True) if (live and actor_grads.numel() > 0) else None
+                if work is not None:
+                    work.wait()
+                run_phases(PHASE_ACTOR_STEP)
+                main.wait_stream(side)                   # join before the next step's target chain
+                cur ^= 1
+                select_set(cur)
+                continue
             run_phases(PHASE_FB_STEP | PHASE_ACTOR_GRAD)
             work = dist.all_reduce(actor_grads, async_op=True) if (live and actor_grads.numel() > 0) else None
             if t + 1 < n_steps:
