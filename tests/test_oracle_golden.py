@@ -59,15 +59,17 @@ def test_full_dim_metric_curves(name, tol):
     reference's own 1-vs-8-thread envelope, not bit equality."""
     meta, _, out = _replay(name, False)
     for s, (m, state) in enumerate(out):
-        for k in H.LOSS_KEYS:
-            assert m[k] == pytest.approx(meta["metrics"][s][k], rel=tol * (1 + s), abs=1e-5), (s, k)
+        scale = max(1.0, abs(meta["metrics"][s]["fb_offdiag"]))     # fb_diag / q / actor_loss are sums of O(1) terms that can
+        for k in H.LOSS_KEYS:                                        # sit near zero: absolute bound at the loss scale
+            assert m[k] == pytest.approx(meta["metrics"][s][k], rel=tol * (1 + s), abs=max(1e-5, tol * (1 + s) * scale)), (s, k)
         assert m["B_norm"] == pytest.approx(np.sqrt(meta["cfg"]["z_dim"]), rel=1e-5)      # SURVEY appendix D
         assert m["orth_loss_diag"] == pytest.approx(-2 * meta["cfg"]["z_dim"], rel=1e-5)
         if state is not None:
             ref = meta["checksums"][str(s + 1)]
             for k, (ssum, l2) in H.checksums(state).items():
-                assert l2 == pytest.approx(ref[k][1], rel=1e-5), (s, k)
-                assert ssum == pytest.approx(ref[k][0], rel=1e-3, abs=1e-3), (s, k)
+                # (bit-identical with the thread count the fixture was made with; other counts drift like BASELINE.md section 2)
+                assert l2 == pytest.approx(ref[k][1], rel=1e-5 * (1 + s / 4)), (s, k)
+                assert ssum == pytest.approx(ref[k][0], rel=1e-3 * (1 + s), abs=1e-3 * (1 + s)), (s, k)
 
 
 def test_sampler_kat():
