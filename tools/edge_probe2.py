@@ -1,3 +1,5 @@
+"""Diagnostic (not part of the product): per-tensor differences of one edge-dimension case against the oracle (which
+activation / gradient first leaves the tolerance).  python tools/edge_probe2.py"""
 import sys, os, subprocess
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
