@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--episodes", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--steps-per-launch", type=int, default=8,
+    ap.add_argument("--steps-per-launch", type=int, default=32,
                     help="consecutive updates handed to one hipGraph launch (FBHipAgent.update_many, as run_offline does "
                          "between two log lines); 1 = one launch per update.  With N > 1 the same call pipelines the steps "
                          "around the gradient all-reduces (the next step's sampling + online forward under the actor all-reduce)")
