@@ -2,7 +2,7 @@
 """Measurement for SURVEY section 8 row n4 (DiscreteFBAgent on the HIP path) -- NOT the bench line (bench.py is).
 
 One step = one ``DiscreteFBHipAgent.update()`` (on-device sample + FB step + EMA; the agent has no actor), replayed as one
-hipGraph, 8 steps per launch.  Dims: the walker networks with a 6-way discrete action (obs 24, A 6, z_dim 50, hidden 1024,
+hipGraph, 32 steps per launch.  Dims: the walker networks with a 6-way discrete action (obs 24, A 6, z_dim 50, hidden 1024,
 backward hidden 526, batch 1024) -- the reference publishes no benchmark configuration for this agent.  Prints one JSON line
 with the same roofline / cpu_baseline objects as bench.py (cpu_baseline = oracle/discrete_fb_oracle.py on the host cores).
 
@@ -51,7 +51,7 @@ def main():
     rb = bench.make_replay(5000, 1000, W["obs_dim"], 1, dev, seed=100)
     rb._storage["action"] = torch.randint(0, args.actions, rb._storage["action"].shape, device=dev).float()
     rb._touch()
-    spl = 8
+    spl = 32
 
     def run(first, n):
         done = 0
