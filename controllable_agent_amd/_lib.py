@@ -27,16 +27,24 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK_RELU, EPI_TANH_BWD = range(5)
 
 
 class Dims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
+    """include/fbhip.h::fbhip_dims; ``struct_size`` (first field) is filled in here, positional arguments start at ``batch``"""
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
                                           "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z", "boltzmann",
                                           "discrete")]
 
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(Dims), *args, **kw)
+
 
 class HParams(C.Structure):
-    _fields_ = [(n, C.c_float) for n in ("lr", "lr_coef", "fb_target_tau", "stddev", "stddev_clip", "ortho_coef",
+    """include/fbhip.h::fbhip_hparams; ``struct_size`` is filled in here"""
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_float) for n in ("lr", "lr_coef", "fb_target_tau", "stddev", "stddev_clip", "ortho_coef",
                                           "mix_ratio", "q_loss_coef", "discount", "grad_scale")] + \
                [("q_loss", C.c_int32), ("want_metrics", C.c_int32), ("future_ratio", C.c_float), ("future", C.c_float),
                 ("rand_weight", C.c_int32)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(HParams), *args, **kw)
 
 
 class Inject(C.Structure):
@@ -117,7 +125,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 12:
+    if lib.fbhip_abi_version() != 13:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -162,6 +162,11 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
 
 int check_dims(const fbhip_dims* d) {
     if (!d) return FBHIP_E_INVALID;
+    if (d->struct_size != sizeof(fbhip_dims)) {
+        g_err = "fbhip: fbhip_dims.struct_size is " + std::to_string(d->struct_size) + ", this library expects " +
+                std::to_string(sizeof(fbhip_dims)) + " (caller built against another include/fbhip.h?)";
+        return FBHIP_E_INVALID;
+    }
     if (d->batch < 2 || d->obs_dim < 1 || d->action_dim < 1 || d->goal_dim < 1 || d->z_dim < 1 ||
         d->hidden_dim < 4 || d->feature_dim < 4 || d->backward_hidden_dim < 1) { g_err = "fbhip: non-positive dimension"; return FBHIP_E_INVALID; }
     if ((d->hidden_dim & 3) || (d->feature_dim & 3)) { g_err = "fbhip: hidden_dim and feature_dim must be multiples of 4"; return FBHIP_E_INVALID; }
@@ -1304,6 +1309,16 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     return run_program(c, prog, s);
 }
 
+int check_hparams(fbhip_ctx* c, const fbhip_hparams* hp) {
+    if (!hp) { c->err = g_err = "fbhip: null hparams"; return FBHIP_E_INVALID; }
+    if (hp->struct_size != sizeof(fbhip_hparams)) {
+        c->err = g_err = "fbhip: fbhip_hparams.struct_size is " + std::to_string(hp->struct_size) + ", this library expects " +
+                         std::to_string(sizeof(fbhip_hparams)) + " (caller built against another include/fbhip.h?)";
+        return FBHIP_E_INVALID;
+    }
+    return FBHIP_OK;
+}
+
 int need_bound(fbhip_ctx* c, bool replay) {
     if (!c) { g_err = "fbhip: null context"; return FBHIP_E_INVALID; }
     if (!c->bound) { c->err = g_err = "fbhip: buffers not bound (fbhip_bind_buffers)"; return FBHIP_E_STATE; }
@@ -1533,7 +1548,7 @@ int fbhip_get_step_counts(fbhip_ctx* c, int32_t* host_fb_steps, int32_t* host_ac
 int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inject, int32_t phase_mask,
                  int32_t use_graph, void* stream) {
     RC(need_bound(c, (phase_mask & FBHIP_PHASE_SAMPLE) != 0));
-    if (!hp) { c->err = g_err = "fbhip: null hparams"; return FBHIP_E_INVALID; }
+    RC(check_hparams(c, hp));
     hipStream_t s = (hipStream_t)stream;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     for (auto& g : c->graphs) {
@@ -1579,7 +1594,8 @@ int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
 
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
     RC(need_bound(c, true));
-    if (!hp || n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
+    RC(check_hparams(c, hp));
+    if (n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     for (auto& g : c->graphs) {
         if (g.n_steps == n_steps && g.set == c->cur && g.mask == FBHIP_PHASE_ALL && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 12
+#define FBHIP_ABI_VERSION 13
 
 enum {
     FBHIP_OK = 0,
@@ -72,7 +72,12 @@ enum {
     FBHIP_PHASE_ALL = 511
 };
 
+/* Both parameter structs start with their own size: the caller sets ``struct_size = sizeof(fbhip_dims)`` (resp.
+ * ``sizeof(fbhip_hparams)``) as compiled against ITS copy of this header; every entry point that takes the struct
+ * compares it with the library's own sizeof and returns FBHIP_E_INVALID on a mismatch, so a binding written against an
+ * older header (a field short) is refused instead of being read past its end. */
 typedef struct fbhip_dims {
+    uint32_t struct_size;          /* = sizeof(fbhip_dims)                               */
     int32_t batch;                 /* B   cfg.batch_size                                 */
     int32_t obs_dim;               /* o                                                 */
     int32_t action_dim;            /* a                                                 */
@@ -107,6 +112,7 @@ typedef struct fbhip_dims {
 } fbhip_dims;
 
 typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82 */
+    uint32_t struct_size;          /* = sizeof(fbhip_hparams) */
     float lr;                      /* 1e-4   */
     float lr_coef;                 /* 1      */
     float fb_target_tau;           /* 0.01   */

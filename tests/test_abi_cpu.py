@@ -132,6 +132,43 @@ def test_unbound_context_is_an_error_not_a_crash(lib):
     assert l.fbhip_destroy(ctx) == 0
 
 
+def test_struct_size_guard(lib):
+    """a struct built against another header (wrong struct_size) is refused by every entry point that takes it"""
+    l = lib.load()
+    d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1, 1)
+    assert d.struct_size == C.sizeof(lib.Dims) == 15 * 4
+    d.struct_size -= 4                                   # what an ABI-12 era binding (no ``discrete``) would have passed
+    assert l.fbhip_net_numel(C.byref(d), 0) < 0 and b"struct_size" in l.fbhip_last_error(None)
+    ctx = C.c_void_p()
+    assert l.fbhip_create(C.byref(d), C.byref(ctx)) == -1
+    d.struct_size += 4
+    assert l.fbhip_create(C.byref(d), C.byref(ctx)) == 0
+    hp = lib.HParams()
+    assert hp.struct_size == C.sizeof(lib.HParams)
+    hp.struct_size = 0
+    assert l.fbhip_update(ctx, C.byref(hp), None, lib.PHASE_ALL, 0, None) in (-1, -3)
+    assert l.fbhip_destroy(ctx) == 0
+
+
+def test_plain_c_program_links_and_runs_against_the_header(lib, tmp_path):
+    """a real non-Python consumer: gcc compiles tests/c_consumer/abi_consumer.c against include/fbhip.h, links libfbhip.so,
+    and the program checks version / layout / struct_size guard / error path on its own"""
+    import os, shutil, subprocess
+    lib.load()
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "abi_consumer"
+    so_dir = lib.LIB_PATH.parent
+    torch_lib = Path(__import__("torch").__file__).parent / "lib"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(ROOT / "tests" / "c_consumer" / "abi_consumer.c"),
+           "-o", str(exe), "-L", str(so_dir), "-l:libfbhip.so", f"-Wl,-rpath,{so_dir}", f"-Wl,-rpath,{torch_lib}",
+           f"-Wl,-rpath-link,{torch_lib}", "-Wl,--allow-shlib-undefined"]
+    subprocess.run(cmd, check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{torch_lib}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
 def test_no_gpu_means_loud_failure(lib):
     import torch
     if torch.cuda.is_available():
@@ -144,3 +181,25 @@ def test_product_never_imports_oracle():
     for f in list((ROOT / "controllable_agent_amd").rglob("*.py")) + list((ROOT / "controllable_agent_amd").rglob("*.hip")):
         txt = f.read_text()
         assert "oracle" not in txt.lower().replace("# oracle", ""), f"{f} mentions oracle/"
+
+
+def test_integration_doc_structs_match_the_header(lib):
+    """INTEGRATION.md section 4 shows the ctypes structs a maintainer would write: their field lists must be the header's
+    (round 1 shipped the doc one field short of ABI 12)."""
+    header = (ROOT / "include" / "fbhip.h").read_text()
+    doc = (ROOT / "INTEGRATION.md").read_text()
+
+    def header_fields(struct):
+        body = header[header.index(f"typedef struct {struct} {{"):header.index(f"}} {struct};")]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return re.findall(r"\b(?:u?int32_t|float)\s+([a-z_0-9]+)\s*;", body)
+
+    def doc_fields(cls):
+        body = doc[doc.index(f"class {cls}(C.Structure)"):]
+        body = body[:body.index("\nclass ") if "\nclass " in body[1:200 + len(body)] and body.index("\nclass ") < body.index("assert lib") else body.index("assert lib")]
+        return re.findall(r'"([a-z_0-9]+)"', body)
+
+    for struct, cls, ct in (("fbhip_dims", "Dims", lib.Dims), ("fbhip_hparams", "HParams", lib.HParams)):
+        h = header_fields(struct)
+        assert h == [n for n, _ in ct._fields_], f"_lib.{cls} out of sync with include/fbhip.h"
+        assert doc_fields(cls) == h, f"INTEGRATION.md {cls} out of sync with include/fbhip.h"
