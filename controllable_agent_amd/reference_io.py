@@ -109,22 +109,55 @@ def _placeholder(module: str, name: str) -> type:
 
 
 def _is_foreign(module: str) -> bool:
-    root = module.split(".", 1)[0]
-    if root not in _FOREIGN_ROOTS:
-        return False
-    if root == "controllable_agent":           # the upstream repo's own top-level package name, not this package
+    """Classes under these roots ALWAYS become placeholders: nothing named by the pickle stream is ever imported (a same-named
+    module on sys.path -- a user's ``utils.py`` -- must neither run code nor change what the loader returns)."""
+    return module.split(".", 1)[0] in _FOREIGN_ROOTS
+
+
+# Everything else a reference checkpoint legitimately references (pretrain.py:437-449 pickles nn.Modules, optimisers, numpy
+# arrays, paths): an allow-list, not pickle's default "import anything".  Files are still trusted input -- torch's tensor
+# rebuild functions are not hardened against hostile streams -- but a global outside this list is refused, loudly.
+_SAFE_BUILTINS = frozenset({"set", "frozenset", "slice", "range", "complex", "bytearray", "bytes", "tuple", "list", "dict",
+                            "int", "float", "str", "bool", "object"})
+_SAFE_EXACT = frozenset({
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "deque"), ("_codecs", "encode"),
+    ("copyreg", "_reconstructor"), ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"), ("pathlib", "Path"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    ("torch", "device"), ("torch", "dtype"), ("torch", "Size"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("torch.serialization", "_get_layout"),
+})
+
+
+def _is_allowed(module: str, name: str) -> bool:
+    if (module, name) in _SAFE_EXACT:
         return True
-    try:                                         # a real, importable module of that name wins (e.g. a user's ``utils``)
-        __import__(module)
-        return False
-    except Exception:
-        return True
+    if module in ("builtins", "__builtin__"):                        # (torch's legacy-name shim passes "__builtin__" through)
+        return name in _SAFE_BUILTINS
+    if module == "numpy" or module.startswith("numpy.dtypes"):
+        return name.startswith(("float", "int", "uint", "bool", "Float", "Int", "UInt", "Bool")) and "." not in name
+    if module == "torch":
+        return name.endswith("Storage") or name.endswith("Tensor")
+    if module == "torch._utils":
+        return name.startswith("_rebuild")
+    if module.startswith("torch.nn.modules.") or module.startswith("torch.optim."):
+        return name[:1].isupper() and "." not in name            # classes (Linear, Sequential, Adam ...), never functions
+    if module == "torch.storage":
+        return name in ("TypedStorage", "UntypedStorage", "_load_from_bytes")
+    return False
 
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module: str, name: str) -> tp.Any:
         if _is_foreign(module):
             return _placeholder(module, name)
+        if module == "__builtin__":
+            module = "builtins"
+        if not _is_allowed(module, name):
+            raise pickle.UnpicklingError(f"reference_io: refusing global {module}.{name} (not on the allow-list of what a "
+                                         f"reference checkpoint contains; see controllable_agent_amd/reference_io.py)")
         return super().find_class(module, name)
 
 
@@ -160,14 +193,44 @@ def payload_parts(payload: tp.Any) -> tp.Dict[str, tp.Any]:
     raise TypeError(f"not a reference checkpoint / replay payload: {type(payload)}")
 
 
+def _plain(v: tp.Any, depth: int = 0) -> tp.Any:
+    """omegaconf containers -> plain Python.  Reference checkpoints come from ``hydra.utils.instantiate(cfg.agent)``
+    (pretrain.py:112-120, ``_convert_`` defaults to "none"), so list-valued config fields -- ``obs_shape``, ``action_shape``,
+    ``log_std_bounds`` -- are pickled as ``omegaconf.ListConfig``.  Without omegaconf installed they arrive here as inert
+    placeholders holding the state of ``BaseContainer.__getstate__``: ``_content`` = list (dict for DictConfig) of value nodes,
+    each node's state holding ``_val``.  With omegaconf installed the real containers support list() / dict()."""
+    if depth > 8:
+        return v
+    if isinstance(v, ReferenceObject):
+        d = v.__dict__
+        if v._ref_name in ("ListConfig", "DictConfig") or ("_content" in d and "_metadata" in d):
+            content = d.get("_content")
+            if isinstance(content, dict):
+                return {(_plain(k, depth + 1)): _plain(x, depth + 1) for k, x in content.items()}
+            if isinstance(content, (list, tuple)):
+                return tuple(_plain(x, depth + 1) for x in content)
+            return content                                           # None / "???" (a missing container)
+        if "_val" in d:                                              # AnyNode / IntegerNode / FloatNode / StringNode ...
+            return _plain(d["_val"], depth + 1)
+        return v
+    mod = type(v).__module__ or ""
+    if mod.startswith("omegaconf"):                                  # the real thing (omegaconf importable)
+        if hasattr(v, "keys"):
+            return {k: _plain(v[k], depth + 1) for k in v.keys()}
+        if hasattr(v, "__len__"):
+            return tuple(_plain(x, depth + 1) for x in v)
+        return getattr(v, "_val", v)
+    if isinstance(v, list):
+        return tuple(_plain(x, depth + 1) for x in v)
+    return v
+
+
 def reference_agent_config(agent: tp.Any) -> tp.Dict[str, tp.Any]:
-    """The ``FBDDPGAgentConfig`` fields of a pickled reference agent as a plain dict (``fb_ddpg.py:37-82``)."""
+    """The ``FBDDPGAgentConfig`` fields of a pickled reference agent as a plain dict (``fb_ddpg.py:37-82``): lists and
+    omegaconf containers (see :func:`_plain`) become tuples / dicts."""
     cfg = getattr(agent, "cfg", None)
     if cfg is None:
         raise TypeError("object has no .cfg")
     fields = dict(cfg.__dict__) if isinstance(cfg, ReferenceObject) else dict(vars(cfg))
     fields.pop("_ctor_args", None)
-    for k, v in list(fields.items()):
-        if isinstance(v, list):                  # obs_shape / action_shape may round-trip as lists
-            fields[k] = tuple(v)
-    return fields
+    return {k: _plain(v) for k, v in fields.items()}

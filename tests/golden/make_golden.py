@@ -472,6 +472,72 @@ def checkpoint_fixture(R):
     print("[ref_checkpoint] ok")
 
 
+def hydra_checkpoint_fixture(R):
+    """The checkpoint a HYDRA-launched reference run writes.  ``make_agent`` (pretrain.py:112-120) calls
+    ``hydra.utils.instantiate(cfg.agent)`` (``_convert_`` = "none"), so the list-valued kwargs reach ``FBDDPGAgentConfig`` as
+    ``omegaconf.ListConfig`` objects and are pickled as such inside ``agent.cfg`` (``obs_shape``, ``action_shape``,
+    ``log_std_bounds``).  omegaconf is not in this image, so the containers here are stand-ins registered under omegaconf's
+    class paths (``omegaconf.listconfig.ListConfig``, ``omegaconf.nodes.AnyNode``, ``omegaconf.base.ContainerMetadata`` /
+    ``Metadata``) whose pickled STATE has the shape omegaconf 2.1-2.3 produces (``BaseContainer.__getstate__``: the
+    instance dict without ``_flags_cache`` -> ``_metadata``, ``_parent``, ``_content`` = list of value nodes;
+    ``Node.__getstate__``: ``_metadata``, ``_parent``, ``_val``) -- restated from omegaconf's source, not executed from it.
+    Everything else in the file (agent, nets, Adam state) is the live reference, as in ``checkpoint_fixture``."""
+    def mod(name):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    base, nodes, listconfig = mod("omegaconf.base"), mod("omegaconf.nodes"), mod("omegaconf.listconfig")
+
+    def cls(m, name, **ns):
+        c = type(name, (), dict(ns, __module__=m.__name__, __qualname__=name))
+        setattr(m, name, c)
+        return c
+
+    Metadata = cls(base, "Metadata")
+    ContainerMetadata = cls(base, "ContainerMetadata")
+
+    def meta(kind, **kw):
+        m = kind()
+        m.__dict__.update(dict(ref_type=None, object_type=None, optional=True, key=None, flags=None, flags_root=False,
+                               resolver_cache={}), **kw)
+        return m
+
+    AnyNode = cls(nodes, "AnyNode")
+    ListConfig = cls(listconfig, "ListConfig",
+                     __len__=lambda self: len(self._content), __iter__=lambda self: (n._val for n in self._content),
+                     __getitem__=lambda self, i: self._content[i]._val,
+                     __getstate__=lambda self: {k: v for k, v in self.__dict__.items() if k != "_flags_cache"})
+
+    def lc(values, key):
+        out = ListConfig()
+        out.__dict__.update(_metadata=meta(ContainerMetadata, key=key, element_type=None), _parent=None, _flags_cache=None,
+                            _content=[])
+        for i, v in enumerate(values):
+            n = AnyNode()
+            n.__dict__.update(_metadata=meta(Metadata, key=i), _parent=out, _val=v)
+            out._content.append(n)
+        return out
+
+    cfg = tiny_cfg()
+    rng = np.random.default_rng(33)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg.obs_dim, cfg.action_dim, None, None)
+    agent = make_ref_agent(R, cfg)
+    load_nets(agent, nets)
+    rb = fill_ref_buffer(R, storage, lengths, cfg.discount)
+    with inject(R, fo.make_draws(rng, cfg, 6, lengths), False):
+        agent.update(rb, 0)
+    agent.cfg.obs_shape = lc([cfg.obs_dim], "obs_shape")
+    agent.cfg.action_shape = lc([cfg.action_dim], "action_shape")
+    agent.cfg.log_std_bounds = lc([-5, 2], "log_std_bounds")
+    with (HERE / "ref_checkpoint_hydra_tiny.pt").open("wb") as f:
+        torch.save({"agent": agent, "global_step": 1, "global_episode": 1}, f, pickle_protocol=4)
+    arrays = {f"state/{k}": v for k, v in ref_state(agent).items()}
+    np.savez_compressed(HERE / "ref_checkpoint_hydra_expect.npz", **arrays)
+    print("[ref_checkpoint_hydra] ok")
+
+
 def tiny_cfg(**kw):
     base = dict(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
                 backward_hidden_dim=18, batch_size=16, lr=1e-3)
@@ -508,6 +574,7 @@ def main():
     init_fixture(R)
     inference_fixture(R)
     checkpoint_fixture(R)
+    hydra_checkpoint_fixture(R)
 
 
 if __name__ == "__main__":

@@ -288,6 +288,19 @@ def test_agent_from_reference_checkpoint_file():
     assert np.isfinite(m["fb_loss"]) and agent.step_counts() == (3, 3)
 
 
+def test_agent_from_hydra_written_reference_checkpoint():
+    """``agent.cfg`` of a hydra-launched reference run holds omegaconf ListConfig objects (pretrain.py:112-120); the agent
+    must still come up from such a file without omegaconf (fixture: make_golden.py::hydra_checkpoint_fixture)."""
+    from controllable_agent_amd.agent import FBHipAgent
+    exp = np.load(H.GOLDEN / "ref_checkpoint_hydra_expect.npz")
+    agent = FBHipAgent.from_reference_checkpoint(H.GOLDEN / "ref_checkpoint_hydra_tiny.pt", device="cuda")
+    assert agent.obs_dim == 5 and agent.action_dim == 3 and tuple(agent.cfg.log_std_bounds) == (-5, 2)
+    got = H.get_agent_state(agent)
+    for k in exp.files:
+        np.testing.assert_array_equal(got[k[len("state/"):]], exp[k], err_msg=k)
+    assert agent.step_counts() == (1, 1)
+
+
 def test_batch1_fast_path_matches_the_batched_entry_points():
     """fbhip_act / fbhip_z_correl (GEMV chain in one graph) against the general row-batched inference path and against
     the distribution the reference samples from (TruncatedNormal.sample(clip=None), utils.py:176-185)."""
