@@ -77,6 +77,8 @@ PROTOTYPES = {
     "fbhip_set_policy_squash": (C.c_int, [_P, _F, _F, _F]),
     "fbhip_set_step_counts": (C.c_int, [_P, _I, _I, _P]),
     "fbhip_get_step_counts": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), _P]),
+    "fbhip_get_rng_counts": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P]),
+    "fbhip_set_rng_counts": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
     "fbhip_update_many": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_select_workspace_set": (C.c_int, [_P, _I]),

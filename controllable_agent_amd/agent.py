@@ -407,6 +407,7 @@ class FBHipAgent:
 
     def load_nets(self, nets: tp.Mapping[str, tp.Mapping[str, tp.Any]], copy_targets: bool = True) -> None:
         """Load {net: state_dict} (reference key names); targets start as copies (fb_ddpg.py:140-141)."""
+        self._replicas_verified = False
         for n in (() if self._discrete else ("actor",)) + ("forward_net", "backward_net"):
             if n in nets:
                 getattr(self, n).load_state_dict(nets[n])
@@ -438,8 +439,10 @@ class FBHipAgent:
         fb, ac = self.step_counts()
         flat = {k: getattr(self, k).detach().cpu() for k in ("_fb_params", "_fb_m", "_fb_v", "_fb_targets",
                                                               "_actor_params", "_actor_m", "_actor_v")}
+        # (the device RNG counters travel too: a resumed run continues its Philox streams instead of replaying the batches,
+        # z draws and exploration noise of the first steps of training)
         return dict(cfg=dataclasses.asdict(self.cfg), flat=flat, fb_steps=fb, actor_steps=ac, seed=self._seed,
-                    solved_meta=self.solved_meta, training=self.training, goal_dim=self.goal_dim)
+                    rng_counts=self.rng_counts(), solved_meta=self.solved_meta, training=self.training, goal_dim=self.goal_dim)
 
     def __setstate__(self, st: tp.Dict[str, tp.Any]) -> None:
         cfg = self._config_cls(**st["cfg"])
@@ -455,6 +458,8 @@ class FBHipAgent:
         for k, v in st["flat"].items():
             getattr(self, k).copy_(v)
         self.set_step_counts(st["fb_steps"], st["actor_steps"])
+        if "rng_counts" in st:                   # (pickles of round 1 do not have it: those restart their streams)
+            self.set_rng_counts(*st["rng_counts"])
 
     # ------------------------------------------------------------------ small surface methods
     def train(self, training: bool = True) -> None:                      # fb_ddpg.py:161-164
@@ -470,7 +475,25 @@ class FBHipAgent:
     def set_step_counts(self, fb_steps: int, actor_steps: int) -> None:
         check(_lib.load().fbhip_set_step_counts(self._ctx, int(fb_steps), int(actor_steps), stream_ptr()), self._ctx)
 
+    def rng_counts(self) -> tp.Tuple[int, int]:
+        """(update() calls drawn, fast-path act() calls drawn): the counters of the device Philox streams"""
+        u, a = C.c_uint32(), C.c_uint32()
+        check(_lib.load().fbhip_get_rng_counts(self._ctx, C.byref(u), C.byref(a), stream_ptr()), self._ctx)
+        return int(u.value), int(a.value)
+
+    def set_rng_counts(self, update_count: int, act_count: int) -> None:
+        check(_lib.load().fbhip_set_rng_counts(self._ctx, int(update_count), int(act_count), stream_ptr()), self._ctx)
+
+    def _join_fast_path_stream(self) -> None:
+        """The batch-1 entry points launch on the agent's own stream.  Whatever last wrote the weights -- an update enqueued
+        on the caller's (non-default) stream, ``load_state_dict`` / ``init_from`` copies -- was issued on torch's current
+        stream: order the fast path behind it (an event, no host synchronisation)."""
+        cur = torch.cuda.current_stream(self._device)
+        if cur != self._stream:
+            self._stream.wait_stream(cur)
+
     def init_from(self, other: tp.Any) -> None:                          # fb_ddpg.py:166-175
+        self._replicas_verified = False
         names = [] if self._discrete else ["actor"]          # (discrete_fb.py:170-178 copies "encoder" only, + the FB nets)
         if self.cfg.init_fb:
             names += ["forward_net", "backward_net", "backward_target_net", "forward_target_net"]
@@ -576,6 +599,7 @@ class FBHipAgent:
         obs, z = np.ascontiguousarray(obs), np.ascontiguousarray(z)
         out = np.empty(self.action_dim, np.float32)
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
+        self._join_fast_path_stream()
         with torch.cuda.stream(self._stream):
             check(_lib.load().fbhip_act(self._ctx, obs.ctypes.data, z.ctypes.data, None if nz is None else nz.ctypes.data,
                                         float(stddev), int(bool(eval_mode)), out.ctypes.data,
@@ -627,6 +651,7 @@ class FBHipAgent:
         if g.shape[0] != self.goal_dim or z.shape[0] != self.cfg.z_dim:
             raise ValueError(f"compute_z_correl: expected goal[{self.goal_dim}] and z[{self.cfg.z_dim}]")
         out = np.empty(1, np.float32)
+        self._join_fast_path_stream()
         check(_lib.load().fbhip_z_correl(self._ctx, g.ctypes.data, z.ctypes.data, out.ctypes.data,
                                          self._stream.cuda_stream), self._ctx)
         return float(out[0])
@@ -687,6 +712,7 @@ class FBHipAgent:
         lib = _lib.load()
         s = stream_ptr()
 
+        self._verify_replicas()
         global_batch = bool(self.cfg.dp_global_batch)
         hp_fb = hp
         if global_batch:                # the FB loss is normalised by the GLOBAL pair counts: its gradients are summed
@@ -705,6 +731,58 @@ class FBHipAgent:
 
         dp_update(run_phases, self._fb_grads, self._actor_grads, self._exchange_embeddings if global_batch else None,
                   early=self._early_grad_range())
+
+    # ---- data-parallel replica consistency (distributed.py relies on bit-identical replicas: no parameter broadcast per step)
+    def _replica_buffers(self) -> tp.List[torch.Tensor]:
+        bufs = [self._fb_params, self._fb_targets, self._fb_m, self._fb_v]
+        if not self._discrete:
+            bufs += [self._actor_params, self._actor_m, self._actor_v]
+        return bufs
+
+    def sync_from_rank0(self) -> None:
+        """Make every rank's replica rank 0's: parameters, targets, both Adam moment sets and the Adam step counts are
+        broadcast.  Call it after constructing the agents under different seeds (the common ``seed + rank`` convention),
+        after ``init_from`` / ``load_nets`` / unpickling on some ranks only -- anything that may leave replicas different.
+        (The RNG seed stays per rank: ranks must draw different batches.)"""
+        import torch.distributed as dist
+        if self._world() < 2:
+            return
+        on_dev = dist.get_backend() == "nccl"
+        for t in self._replica_buffers():
+            if on_dev:
+                dist.broadcast(t, src=0)
+            else:                                    # gloo (tests: several ranks sharing one GPU)
+                h = t.detach().cpu()
+                dist.broadcast(h, src=0)
+                t.copy_(h)
+        counts = torch.tensor(self.step_counts(), dtype=torch.int64, device=self._device if on_dev else "cpu")
+        dist.broadcast(counts, src=0)
+        self.set_step_counts(int(counts[0]), int(counts[1]))
+        self._replicas_verified = False
+
+    def _verify_replicas(self) -> None:
+        """First data-parallel update (and again after anything that rewrites the weights): all ranks must hold the same
+        replica, else averaged gradients would be applied to different weights and the replicas would silently stay
+        different.  One small all-reduce of checksums; raises on every rank."""
+        if getattr(self, "_replicas_verified", False) or self._world() < 2:
+            return
+        import torch.distributed as dist
+        sums = [t.double().sum() for t in self._replica_buffers()] + [t.double().abs().sum() for t in self._replica_buffers()]
+        vec = torch.stack(sums + [torch.tensor(float(x), dtype=torch.float64, device=self._device) for x in self.step_counts()])
+        both = torch.cat([vec, -vec])
+        if dist.get_backend() != "nccl":
+            both = both.cpu()
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        n = vec.numel()
+        hi, lo = both[:n], -both[n:]
+        if not torch.equal(hi, lo):
+            bad = [i for i in range(n) if float(hi[i]) != float(lo[i])]
+            raise RuntimeError(
+                f"FBHipAgent: data-parallel replicas differ across ranks (checksum slots {bad}; rank {self._rank()}).  The "
+                "schedule never broadcasts parameters: construct every rank's agent under the SAME torch seed (e.g. "
+                "torch.manual_seed(seed) before FBHipAgent(...), as bench.py does) or call agent.sync_from_rank0() after "
+                "construction / init_from / load_nets.")
+        self._replicas_verified = True
 
     def _early_grad_range(self) -> tp.Tuple[int, int]:
         """(offset, count) of the FB gradient bucket that FB_BWD_A completes (both ForwardMap heads): reduced under FB_BWD_B."""
@@ -817,6 +895,7 @@ class FBHipAgent:
             from .distributed import dp_update_many
             want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
             self._bind_replay(replay_loader)
+            self._verify_replicas()
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
             lib = _lib.load()
 
@@ -998,6 +1077,7 @@ class DiscreteFBHipAgent(FBHipAgent):
         if o.shape[0] != self.obs_dim or z.shape[0] != self.cfg.z_dim:
             raise ValueError(f"act: expected obs[{self.obs_dim}] and z[{self.cfg.z_dim}], got {o.shape} / {z.shape}")
         out = C.c_int32()
+        self._join_fast_path_stream()
         with torch.cuda.stream(self._stream):
             check(_lib.load().fbhip_discrete_act_host(self._ctx, o.ctypes.data, z.ctypes.data, C.byref(out),
                                                       self._stream.cuda_stream), self._ctx)

@@ -1545,6 +1545,29 @@ int fbhip_get_step_counts(fbhip_ctx* c, int32_t* host_fb_steps, int32_t* host_ac
     return FBHIP_OK;
 }
 
+int fbhip_get_rng_counts(fbhip_ctx* c, uint32_t* host_update_count, uint32_t* host_act_count, void* stream) {
+    RC(need_bound(c, false));
+    hipStream_t s = (hipStream_t)stream;
+    StepState h{};
+    HIPCK(c, hipMemcpyAsync(&h, c->W().st, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    if (host_update_count) *host_update_count = h.update_count;
+    if (host_act_count) *host_act_count = h.act_count;
+    return FBHIP_OK;
+}
+
+int fbhip_set_rng_counts(fbhip_ctx* c, uint32_t update_count, uint32_t act_count, void* stream) {
+    RC(need_bound(c, false));
+    hipStream_t s = (hipStream_t)stream;
+    StepState h{};
+    HIPCK(c, hipMemcpyAsync(&h, c->W().st, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    h.update_count = update_count; h.act_count = act_count;
+    HIPCK(c, hipMemcpyAsync(c->W().st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIPCK(c, hipStreamSynchronize(s));
+    return FBHIP_OK;
+}
+
 int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inject, int32_t phase_mask,
                  int32_t use_graph, void* stream) {
     RC(need_bound(c, (phase_mask & FBHIP_PHASE_SAMPLE) != 0));

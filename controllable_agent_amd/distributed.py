@@ -10,7 +10,11 @@ the two flat gradient buckets are sum-all-reduced:
     phase ACTOR_STEP
 
 ``1 / world`` is folded into the Adam pass (``grad_scale``), so the optimiser steps are bit-identical on every
-rank and no parameter broadcast is ever needed.  This equals ONE device fed the same ``world`` micro-batches with
+rank and no parameter broadcast is ever needed -- PROVIDED the replicas start identical: build every rank's agent under
+the same torch seed (bench.py: ``torch.manual_seed(1)`` before the constructor) or call ``agent.sync_from_rank0()``
+(broadcast of parameters, targets, Adam moments and step counts).  ``FBHipAgent`` verifies it with a checksum all-reduce
+on its first data-parallel update and after every ``init_from`` / ``load_nets`` (``_verify_replicas``) and raises on a
+mismatch instead of training diverged replicas.  This equals ONE device fed the same ``world`` micro-batches with
 gradient averaging -- not the single-device loss on the concatenated batch (the contrastive off-diagonal mean
 runs over world * B(B-1) pairs instead of (world*B)(world*B - 1)).
 

@@ -205,6 +205,12 @@ int fbhip_set_seed(fbhip_ctx* ctx, uint64_t seed, uint32_t rank);
 int fbhip_set_policy_squash(fbhip_ctx* ctx, float temp, float log_std_min, float log_std_max);
 int fbhip_set_step_counts(fbhip_ctx* ctx, int32_t fb_steps, int32_t actor_steps, void* stream); /* Adam t */
 int fbhip_get_step_counts(fbhip_ctx* ctx, int32_t* host_fb_steps, int32_t* host_actor_steps, void* stream);
+/* The device-side Philox counters: number of update() calls drawn so far (sampler / z / noise streams) and number of act()
+ * calls of the batch-1 fast path.  A checkpoint that restores them (with the same seed) continues the random streams where
+ * they stopped instead of replaying the batches and exploration noise from the start of training.  Blocking, like
+ * fbhip_get/set_step_counts. */
+int fbhip_get_rng_counts(fbhip_ctx* ctx, uint32_t* host_update_count, uint32_t* host_act_count, void* stream);
+int fbhip_set_rng_counts(fbhip_ctx* ctx, uint32_t update_count, uint32_t act_count, void* stream);
 
 /* ---- the hot path --------------------------------------------------------------------------------- */
 /* Enqueue the selected phases of one FBDDPGAgent.update() (fb_ddpg.py:427-520).  use_graph != 0 replays a

@@ -235,3 +235,54 @@ def test_pipelined_dp_steps_equal_single_dp_updates():
             assert m1[k] == m2[k], (r, k)
     for k in got[0][1][0]:
         np.testing.assert_array_equal(got[0][1][0][k], got[1][1][0][k], err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------ replica consistency
+def _worker_replicas(rank, port, out_q):
+    """ranks construct under DIFFERENT seeds (the common seed + rank convention): the first data-parallel update must refuse;
+    after sync_from_rank0 the same update runs and the replicas end bit-identical"""
+    import torch.distributed as dist
+    from controllable_agent_amd.agent import FBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    cfg, nets, storage, lengths = T._setup()
+    torch.manual_seed(100 + rank)
+    agent = FBHipAgent(**H.agent_kwargs(cfg))                              # reference-style init: differs per rank
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    refused = False
+    try:
+        agent.update(rb, 0)
+    except RuntimeError as e:
+        refused = "replicas differ" in str(e)
+    before = H.get_agent_state(agent)
+    agent.sync_from_rank0()
+    after = H.get_agent_state(agent)
+    agent.update(rb, 0)
+    agent.update_many(rb, 1, 3)
+    torch.cuda.synchronize()
+    out_q.put((rank, refused, before["actor/policy.0.weight"], after["actor/policy.0.weight"], H.get_agent_state(agent),
+               agent.step_counts()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicas_built_under_different_seeds_are_refused_then_synced():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_worker_replicas, args=(r, port, q)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(T.WORLD)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(g[1] for g in got), "the first data-parallel update must refuse replicas that differ"
+    assert not np.array_equal(got[0][2], got[1][2])                      # they really started different
+    np.testing.assert_array_equal(got[0][3], got[1][3])                  # rank 0's weights everywhere after the sync
+    np.testing.assert_array_equal(got[0][3], got[0][2])
+    for k in got[0][4]:                                                   # ... and they stay identical through training
+        np.testing.assert_array_equal(got[0][4][k], got[1][4][k], err_msg=k)
+    assert got[0][5] == got[1][5] == (4, 4)

@@ -288,6 +288,43 @@ def test_agent_from_reference_checkpoint_file():
     assert np.isfinite(m["fb_loss"]) and agent.step_counts() == (3, 3)
 
 
+def test_pickled_agent_resumes_its_random_streams():
+    """the device Philox counters travel with the pickle -- a resumed agent draws what the original would have
+    drawn next (same seed, continued counters), not the batches / z / noise of the start of training."""
+    import pickle
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16, backward_hidden_dim=18,
+                          batch_size=16)
+    rng = np.random.default_rng(77)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 9, 14, cfg.obs_dim, cfg.action_dim)
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+    a = H.make_hip_agent(cfg, nets)
+    for s in range(3):
+        a.update(rb, s)
+    obs, z = rng.standard_normal(5).astype(np.float32), rng.standard_normal(8).astype(np.float32)
+    a.act(obs, {"z": z}, 0, eval_mode=False)
+    assert a.rng_counts() == (3, 1)
+    b = pickle.loads(pickle.dumps(a))
+    assert b.rng_counts() == (3, 1) and b.step_counts() == (3, 3)
+    first = None
+    for ag in (a, b):
+        ag.update(rb, 3)
+        torch.cuda.synchronize()
+        got = (ag.workspace_view("ep_idx").cpu().numpy().copy(), ag.workspace_view("z").cpu().numpy().copy(),
+               ag.act(obs, {"z": z}, 0, eval_mode=False))
+        if first is None:
+            first = got
+        else:
+            for x, y in zip(first, got):
+                np.testing.assert_array_equal(x, y)
+    c = H.make_hip_agent(cfg, nets)                       # a fresh agent with the same seed starts the streams over
+    c._seed = a._seed
+    c.update(rb, 0)
+    torch.cuda.synchronize()
+    assert not np.array_equal(c.workspace_view("ep_idx").cpu().numpy(), first[0])
+
+
 def test_agent_from_hydra_written_reference_checkpoint():
     """``agent.cfg`` of a hydra-launched reference run holds omegaconf ListConfig objects (pretrain.py:112-120); the agent
     must still come up from such a file without omegaconf (fixture: make_golden.py::hydra_checkpoint_fixture)."""
