@@ -203,3 +203,66 @@ def test_reader_refuses_globals_outside_the_allow_list_and_never_imports(tmp_pat
     sys.modules.pop("utils", None)
     cls = rio._Unpickler(__import__("io").BytesIO(b"")).find_class("utils", "Until")
     assert issubclass(cls, rio.ReferenceObject) and "utils" not in sys.modules
+
+
+# ------------------------------------------------------------------------------------------------ staging / load / relabel
+def test_episode_stage_supports_what_callers_do_with_current_episode():
+    """pretrain.py:485 calls ``_current_episode.clear()``; url_benchmark/test_dmc.py:25 asserts ``"physics" in
+    rb._current_episode``; episodes longer than the stage's first capacity grow it without losing rows"""
+    rb = DeviceReplayBuffer(max_episodes=3, discount=1.0, future=1.0, device="cpu")
+    ts = lambda st, v: TimeStep(step_type=st, reward=v, discount=1.0, observation=np.full(4, v, np.float32),
+                                action=np.zeros(2, np.float32), physics=np.full(3, -v, np.float32))
+    rb.add(ts(0, 0.0), {"z": np.arange(5, dtype=np.float32)})
+    assert "physics" in rb._current_episode and "z" in rb._current_episode and "goal" not in rb._current_episode
+    assert len(rb._current_episode) == 1 and len(rb) == 0
+    rb._current_episode.clear()                                    # load_checkpoint drops the pending episode
+    assert "physics" not in rb._current_episode and len(rb._current_episode) == 0
+    L = 150                                                        # > the stage's initial 64-row capacity
+    for s in range(L + 1):
+        rb.add(ts(0 if s == 0 else (2 if s == L else 1), float(s)), {"z": np.full(5, s, np.float32)})
+    assert len(rb) == 1 and rb._episodes_length[0] == L and len(rb._current_episode) == 0
+    np.testing.assert_array_equal(rb._storage["observation"][0, :, 0].numpy(), np.arange(L + 1, dtype=np.float32))
+    np.testing.assert_array_equal(rb._storage["z"][0, :, 4].numpy(), np.arange(L + 1, dtype=np.float32))
+    np.testing.assert_array_equal(rb._storage["physics"][0, 7].numpy(), np.full(3, -7, np.float32))
+    assert rb._storage["reward"].shape == (3, L + 1, 1)
+    # a second, shorter episode reuses the stage: rows beyond its length stay zero in the storage
+    for s in range(11):
+        rb.add(ts(0 if s == 0 else (2 if s == 10 else 1), 100.0 + s), {"z": np.zeros(5, np.float32)})
+    assert rb._episodes_length[1] == 10 and not rb._is_fixed_episode_length
+    assert float(rb._storage["observation"][1, 10, 0]) == 110.0 and float(rb._storage["observation"][1, 11:].abs().sum()) == 0.0
+
+
+class _RewardFromPhysics:
+    def from_physics(self, p):
+        return float(p[0] * 2 + 1)
+
+
+def test_load_npz_directory_and_relabel(tmp_path):
+    """ExORL layout (in_memory_replay_buffer.py:33-37, 192-216): one ``*.npz`` per episode, keys observation / action /
+    reward / discount / physics, each [T+1, dim]; ``load`` fills the ring in sorted order and stops when it is full;
+    ``relabel`` / ``sample(custom_reward=...)`` recompute rewards from the stored physics."""
+    rng = np.random.default_rng(3)
+    T1, eps = 9, []
+    for e in range(4):
+        ep = dict(observation=rng.standard_normal((T1, 4)).astype(np.float32), action=rng.standard_normal((T1, 2)).astype(np.float32),
+                  reward=rng.standard_normal((T1, 1)).astype(np.float32), discount=np.ones((T1, 1), np.float32),
+                  physics=rng.standard_normal((T1, 3)).astype(np.float32))
+        np.savez(tmp_path / f"episode_{e:03d}.npz", **ep)
+        eps.append(ep)
+    rb = DeviceReplayBuffer(max_episodes=3, discount=0.9, future=1.0, device="cpu")
+    with pytest.raises(ValueError, match="relabel=True needs"):
+        rb.load(None, tmp_path)
+    rb.load(None, tmp_path, relabel=False)
+    assert rb._full and len(rb) == 3 and rb._idx == 0 and rb._is_fixed_episode_length       # the 4th file did not fit
+    for e in range(3):
+        for k in eps[e]:
+            np.testing.assert_array_equal(rb._storage[k][e].numpy(), eps[e][k], err_msg=f"{k}[{e}]")
+    np.testing.assert_array_equal(rb._episodes_length, [T1 - 1] * 3)
+    np.random.seed(5)
+    b = rb.sample(32, custom_reward=_RewardFromPhysics(), with_physics=True)
+    np.testing.assert_allclose(b.reward.numpy()[:, 0], b._physics.numpy()[:, 0] * 2 + 1, rtol=0, atol=0)
+    assert b.discount.numpy().max() == pytest.approx(0.9)
+    rb.relabel(_RewardFromPhysics())
+    want = np.stack([eps[e]["physics"][:, :1] * 2 + 1 for e in range(3)]).astype(np.float32)
+    np.testing.assert_array_equal(rb._storage["reward"].numpy(), want)
+    assert rb._max_episodes == 3 and rb._full
