@@ -65,11 +65,10 @@ def make_replay(n_episodes, T, o, a, device, seed, goal_dim=None):
     return rb
 
 
-def cpu_baseline(seed=1, budget_s=15.0, max_steps=120):
-    """The oracle (our CPU restatement of the reference's update, pinned to it by tests/golden) timed on this
-    box's host cores -- the reference's Python cannot travel to the GPU box.  Bounded sample of the same workload."""
+def _cpu_port_rate(batch_size, threads, budget_s, max_steps, seed=1):
+    """updates/s of the oracle (CPU restatement of fb_ddpg.py:427-520) at walker dims with ``threads`` torch threads"""
     from oracle import fb_oracle as fo
-    cfg = fo.OracleConfig(**WALKER)
+    cfg = fo.OracleConfig(**dict(WALKER, batch_size=batch_size))
     rng = np.random.default_rng(seed)
     nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
     n_eps, T = 50, 1000
@@ -79,30 +78,45 @@ def cpu_baseline(seed=1, budget_s=15.0, max_steps=120):
     def one():
         d = fo.make_draws(rng, cfg, n_eps, lengths)
         agent.update(fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount), d)
+    torch.set_num_threads(threads)
+    one()                                              # warm-up (allocator, thread pool)
+    t0, n = time.time(), 0
+    while n < max_steps and (n == 0 or time.time() - t0 < budget_s):
+        one()
+        n += 1
+    dt = time.time() - t0
+    return n / dt, n, dt
+
+
+def cpu_baseline(seed=1, budget_s=12.0, max_steps=120):
+    """The oracle (our CPU restatement of the reference's update, pinned to it by tests/golden) timed on this box's host
+    cores.  Against the imported reference on the same 8 cores of the build container the port needs 1.11x (batch 1024) to
+    1.18x (batch 256) the time per update (tools/port_vs_reference_timing.py -> profiles/r02_port_vs_reference_timing.json;
+    BASELINE.md section 4 hoped for +-10 %): read ``value`` as a LOWER bound of the reference's CPU rate, ~10-18 % low -- the reference's Python cannot travel to the GPU box.  Bounded sample of the same
+    workload.  Headline: batch 1024 at the fastest of a few thread counts; ``also``: BASELINE.md section 4's other figures
+    (configs[0] = batch 256, and the 1-thread rates), each on a 2-4 s sample."""
     # torch-CPU oversubscribes badly when given every hardware thread of a big host (75 s/update at 256 threads):
     # probe a few thread counts on the cores this process may actually use and keep the fastest
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best = None
     for nt in sorted({min(avail, n) for n in (8, 16, 32, 64)}):
-        torch.set_num_threads(nt)
-        one()
-        t0 = time.time()
-        one()
-        dt1 = time.time() - t0
-        if best is None or dt1 < best[1]:
-            best = (nt, dt1)
-        if dt1 > 3.0:
+        rate, _, _ = _cpu_port_rate(1024, nt, 0.0, 1, seed)
+        if best is None or rate > best[1]:
+            best = (nt, rate)
+        if rate < 1.0 / 3.0:
             break
-    torch.set_num_threads(best[0])
-    t0, n = time.time(), 0
-    while n < max_steps and time.time() - t0 < budget_s:
-        one()
-        n += 1
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "update-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    rate, n, dt = _cpu_port_rate(1024, best[0], budget_s, max_steps, seed)
+    also = []
+    for bs, nt, bud in ((256, best[0], 4.0), (1024, 1, 3.0), (256, 1, 3.0)):
+        r, k, d = _cpu_port_rate(bs, nt, bud, 60, seed)
+        also.append({"batch": bs, "threads": nt, "value": r, "unit": "update-steps/s", "sample": f"{k} updates, {d:.1f} s"})
+    return {"value": rate, "unit": "update-steps/s", "cores": best[0], "kind": "port",
             "sample": f"{n} updates of the same workload (walker dims, batch 1024, z_dim 50, metrics on) with "
                       f"oracle/fb_oracle.py (torch-CPU fp32 restatement of fb_ddpg.py:427-520, autograd + "
-                      f"boolean-mask loss like the reference), {dt:.1f} s"}
+                      f"boolean-mask loss like the reference), {dt:.1f} s; host has {avail} usable hardware threads",
+            "port_vs_reference": "the port takes 1.11x (batch 1024) / 1.18x (batch 256) the reference's time per update on the "
+                                 "same 8 cores (profiles/r02_port_vs_reference_timing.json, build container)",
+            "also": also}
 
 
 def measured_traffic():
@@ -147,6 +161,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--episodes", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps updates between barrier + synchronize pairs) is run this many times; "
+                         "value / ms_per_step are the MEDIAN repeat, every repeat is listed under 'repeats'")
+    ap.add_argument("--no-single-update-probe", action="store_true",
+                    help="skip the extra measurement of plain agent.update() calls (config.single_update_steps_per_s)")
     ap.add_argument("--steps-per-launch", type=int, default=32,
                     help="consecutive updates handed to one hipGraph launch (FBHipAgent.update_many, as run_offline does "
                          "between two log lines); 1 = one launch per update.  With N > 1 the same call pipelines the steps "
@@ -154,6 +173,10 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with the gloo backend (RCCL refuses two ranks per device): exercises the "
                          "multi-rank code path of this script on a 1-GPU box; the number it prints is NOT a scaling result")
+    ap.add_argument("--nccl-world1", action="store_true",
+                    help="with ONE rank under torch.distributed.run: still create the nccl (RCCL) process group, so that together "
+                         "with FBHIP_FORCE_PHASE_SPLIT=1 the data-parallel schedule issues its real RCCL all-reduces (on one "
+                         "rank): a kept execution of the RCCL code path on a 1-GPU box")
     ap.add_argument("--global-batch", action="store_true",
                     help="data-parallel mode B (FBHipAgent(dp_global_batch=True)): the exact loss of the concatenated "
                          "world x batch rows (one embedding all-gather per step) instead of per-rank blocks with gradient "
@@ -183,6 +206,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    elif args.nccl_world1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29535")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
 
     if args.pretend_world > 1:
         os.environ["FBHIP_PRETEND_WORLD"] = str(args.pretend_world)
@@ -216,21 +247,64 @@ def main():
                 agent.update_many(rb, first_step + done, k)
             done += k
 
-    run(0, args.warmup)
-    # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
-    # untimed launch of each size (these are additional warm-up steps)
-    sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
-    for sz in sorted(sizes):
-        run(args.warmup, sz)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.warmup, args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    # everything is enqueued on ONE explicit stream so that the HIP events below bracket the same launches the wall clock does
+    # (torch.cuda.Event only sees the stream it is recorded on; on the legacy default stream the agent would hop to its own)
+    bench_stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(bench_stream):
+        run(0, args.warmup)
+        # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
+        # untimed launch of each size (these are additional warm-up steps)
+        sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
+        for sz in sorted(sizes):
+            run(args.warmup, sz)
+        walls, events = [], []
+        for rep in range(max(1, args.repeats)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t0 = time.perf_counter()
+            e0.record(bench_stream)
+            run(args.warmup + rep * args.steps, args.steps)
+            e1.record(bench_stream)
+            barrier()
+            wall = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([wall], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                wall = float(t.item())
+            walls.append(wall)
+            events.append(e0.elapsed_time(e1) * 1e-3)
+        order = sorted(range(len(walls)), key=lambda i: walls[i])
+        mid = order[len(order) // 2]
+        dt = walls[mid]                                   # the median repeat IS one contiguous region of exactly --steps updates
+        single = None
+        if world == 1 and args.workload == "walker" and not args.no_single_update_probe and not args.global_batch:
+            # what a reference workspace literally does: agent.update(replay_loader, step) once per loop iteration
+            # (train_offline.py:118) -- one graph launch per update, no cross-step pipelining
+            n1 = max(300, min(args.steps, 1000))
+            for i in range(20):
+                agent.update(rb, i)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(n1):
+                agent.update(rb, i)
+            barrier()
+            single = n1 / (time.perf_counter() - t1)
+
+    replicas = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # data-parallel replicas must END identical (the schedule never broadcasts parameters): every rank's float64
+        # checksums of its parameter / target buffers, gathered and compared on rank 0
+        mine = torch.stack([t.double().sum() for t in agent._replica_buffers()] +
+                           [t.double().pow(2).sum() for t in agent._replica_buffers()]).cpu()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        if dist.get_backend() == "nccl":
+            g_dev = [torch.zeros_like(mine, device=dev) for _ in range(world)]
+            dist.all_gather(g_dev, mine.to(dev))
+            gathered = [g.cpu() for g in g_dev]
+        else:
+            dist.all_gather(gathered, mine)
+        replicas = {"identical": all(torch.equal(gathered[0], g) for g in gathered[1:]),
+                    "checksum_rank0": [float(x) for x in gathered[0][:3]], "ranks": world, "adam_steps": list(agent.step_counts())}
 
     if rank == 0:
         steps_per_s = args.steps / dt                     # per-rank update rate (== global step rate)
@@ -252,7 +326,17 @@ def main():
                                     "synthetic replay resident in HBM; metrics off"),
                        "steps_per_graph_launch": spl, **({"dp_loss": "global batch (mode B)" + (f", pretend world {args.pretend_world}" if args.pretend_world > 1 else "")} if args.global_batch else {}),
                        "global_batch": W["batch_size"] * world, "parallelism": f"dp{world}",
-                       "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s},
+                       "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s,
+                       **({"single_update_steps_per_s": single} if single is not None else {})},
+            "repeats": {"n": len(walls), "steps_each": args.steps, "reported": "median by wall time",
+                        "wall_s": walls, "hip_event_s": events,
+                        "steps_per_s": {"median": world * args.steps / dt, "min": world * args.steps / max(walls),
+                                        "max": world * args.steps / min(walls)},
+                        "hip_event_steps_per_s_median_repeat": world * args.steps / events[mid]},
+            "timed_region_s": dt,
+            **({"replicas": replicas} if replicas is not None else {}),
+            **({"flags": [f"timed region of {dt * 1e3:.1f} ms < 0.5 s: --steps {args.steps} is too short for a stable rate "
+                          f"(host launch jitter); the {len(walls)} repeats bound it, prefer --steps >= 1000"]} if dt < 0.5 else {}),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(),
                          "what": f"whole update step: {gflop:.2f} algorithmic GFLOP/update (SURVEY.md section 8d) x "
@@ -265,7 +349,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.nccl_world1:
         dist.barrier()
         dist.destroy_process_group()
 

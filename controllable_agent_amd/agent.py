@@ -1014,6 +1014,38 @@ class FBHipAgent:
         self._run_update(hp, inj, use_graph)
         return self._metrics()
 
+    def update_many_injected(self, replay_loader: DeviceReplayBuffer, step: int,
+                             draws_per_step: tp.Sequence[tp.Mapping[str, tp.Any]]) -> tp.Dict[str, float]:
+        """Parity mode of ``update_many``: ``len(draws_per_step)`` consecutive updates as ONE pipelined multi-step graph
+        (``fbhip_update_many_injected``), every random draw of every step supplied like ``update_injected`` does for one.
+        Returns the metrics of the last step.  Single rank, constant stddev only."""
+        n = len(draws_per_step)
+        if not 1 <= n <= 64:
+            raise ValueError("update_many_injected: 1..64 steps per call")
+        if self._world() > 1 or len({schedule(self.cfg.stddev_schedule, step + i) for i in range(n)}) != 1:
+            raise ValueError("update_many_injected: single rank and a constant stddev over the steps only")
+        dev = self._device
+        self._bind_replay(replay_loader)
+        ints = ["ep_idx", "step_idx", "perm"] + (["future_idx"] if self.cfg.future_ratio > 0 else [])
+        flts = ["z_gauss", "mix_uniform", "eps_next", "eps_actor"] + (["rand_weight", "rand_weight_u"] if self.cfg.rand_weight else []) + \
+               ([] if self.cfg.norm_z else ["z_uniform"]) + (["future_uniform"] if self.cfg.future_ratio > 0 else [])
+        keep: tp.List[torch.Tensor] = []
+        injs = (Inject * n)()
+        for i, draws in enumerate(draws_per_step):
+            for name in ints:
+                keep.append(torch.as_tensor(np.asarray(draws[name]), dtype=torch.int32, device=dev).contiguous())
+                setattr(injs[i], name, ptr(keep[-1]))
+            for name in flts:
+                keep.append(torch.as_tensor(np.asarray(draws[name], dtype=np.float32), device=dev).contiguous())
+                setattr(injs[i], name, ptr(keep[-1]))
+        c = self.cfg
+        want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+        hp = self._hparams(step, want, 1.0, float(replay_loader._discount), float(replay_loader._future))
+        self._on_update_stream(lambda: check(_lib.load().fbhip_update_many_injected(self._ctx, C.byref(hp), n, injs, stream_ptr()),
+                                             self._ctx))
+        torch.cuda.current_stream(dev).synchronize()                  # ``keep`` must outlive the launches
+        return self._metrics()
+
     def workspace_view(self, name: str) -> torch.Tensor:
         """A named intermediate of the last update as a tensor view into the workspace (tests / debugging)."""
         p, rows, cols, ld = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()

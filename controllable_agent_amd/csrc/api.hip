@@ -1615,13 +1615,15 @@ int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
     return FBHIP_OK;
 }
 
-int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
+// injs: NULL (device-drawn batches) or n_steps inject structs, one per step (parity runs through the pipelined graph)
+static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injs, void* stream) {
     RC(need_bound(c, true));
     RC(check_hparams(c, hp));
     if (n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     for (auto& g : c->graphs) {
-        if (g.n_steps == n_steps && g.set == c->cur && g.mask == FBHIP_PHASE_ALL && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {
+        if (g.n_steps == n_steps && g.set == c->cur && g.mask == FBHIP_PHASE_ALL && g.has_inj == (injs != nullptr) &&
+            (!injs || memcmp(&g.inj, injs, sizeof(*injs)) == 0) && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {
             HIPCK(c, hipGraphLaunch(g.exec, s));
             return FBHIP_OK;
         }
@@ -1651,13 +1653,13 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     int rc = FBHIP_OK;
     hipError_t he = hipSuccess;
     if (!pipe) {
-        for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ALL, s);
+        for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, injs ? &injs[i] : nullptr, FBHIP_PHASE_ALL, s);
     } else {
         const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
         const int MID = FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD | FBHIP_PHASE_FB_STEP;   // (both FB_BWD bits)
         const int TAIL = FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP;
         const int cur0 = c->cur;
-        rc = enqueue_update(c, *hp, nullptr, HEAD, s);
+        rc = enqueue_update(c, *hp, injs ? &injs[0] : nullptr, HEAD, s);
         for (int i = 0; i < n_steps && rc == FBHIP_OK && he == hipSuccess; ++i) {
             rc = enqueue_update(c, *hp, nullptr, MID, s);
             if (rc != FBHIP_OK) break;
@@ -1666,7 +1668,7 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
                 if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
                 if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
                 c->cur ^= 1;
-                rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
+                rc = enqueue_update(c, *hp, injs ? &injs[i + 1] : nullptr, HEAD, c->side);
                 c->cur ^= 1;
                 if (rc != FBHIP_OK) break;
             }
@@ -1684,7 +1686,8 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     if (he != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCK(c, he); }
     HIPCK(c, e);
     GraphEntry ge{};
-    ge.mask = FBHIP_PHASE_ALL; ge.hp = *hp; ge.has_inj = false; ge.n_steps = n_steps; ge.set = c->cur;
+    ge.mask = FBHIP_PHASE_ALL; ge.hp = *hp; ge.has_inj = injs != nullptr; ge.n_steps = n_steps; ge.set = c->cur;
+    if (injs) ge.inj = injs[0];              // (cache key: a caller that reuses its per-step buffers replays the same graph)
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCK(c, e);
@@ -1692,6 +1695,15 @@ int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, vo
     c->graphs.push_back(ge);
     HIPCK(c, hipGraphLaunch(ge.exec, s));
     return FBHIP_OK;
+}
+
+int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
+    return update_many_impl(c, hp, n_steps, nullptr, stream);
+}
+
+int fbhip_update_many_injected(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injects, void* stream) {
+    if (!injects) { if (c) c->err = g_err = "fbhip_update_many_injected: null injects"; return FBHIP_E_INVALID; }
+    return update_many_impl(c, hp, n_steps, injects, stream);
 }
 
 int fbhip_read_metrics(fbhip_ctx* c, float* host_out, void* stream) {

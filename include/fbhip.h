@@ -227,6 +227,12 @@ int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* in
  * the gradient all-reduce inside the graph); ``hp`` is constant over the n_steps (1 <= n_steps <= 64).
  * After the call fbhip_workspace_view refers to set 0, which holds the last or the second-to-last step's intermediates. */
 int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
+/* The same n-step pipelined graph with every random draw supplied: ``injects`` is an array of n_steps structs, one per step
+ * (all fields a single update needs, like fbhip_update's parity mode).  For parity runs of the bench configuration -- the
+ * reference's recorded draws through the pipelined multi-step graph; the graph is cached on (hp, n_steps, injects[0]), so a
+ * caller that refills the same per-step device buffers replays it. */
+int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injects,
+                               void* stream);
 /* The workspace holds two complete per-step sets (fbhip_update_many alternates them).  A host that pipelines steps itself
  * (data parallel: the next step's SAMPLE | FB_FWD_ONLINE under this step's actor all-reduce) selects the set the following
  * fbhip_update calls work on; phases of one step must all run on the same set.  Default 0. */

@@ -327,6 +327,19 @@ def long_curve_fixtures(R):
                   checksum_steps=(1, 10, 50))
 
 
+def bench_config_curve_fixture(R):
+    """configs[1] exactly as bench.py runs it -- walker dims, batch 1024 -- for 50 free-running reference steps (metric dict
+    per step, parameter checksums at steps 10 / 32 / 50): the GPU test feeds the same draws through the 32-step PIPELINED
+    graph (fbhip_update_many_injected), i.e. the code path the headline number times.  And configs[2] at its own batch size:
+    quadruped + goal space, batch 2048, z_dim 100, 3 steps."""
+    trace_fixture(R, "walker_b1024_50", fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50, batch_size=1024),
+                  seed=221, n_eps=20, T=100, n_steps=50, full_state=False, checksum_steps=(10, 32, 50))
+    trace_fixture(R, "quadruped_goal_b2048",
+                  fo.OracleConfig(obs_dim=78, action_dim=12, goal_dim=2, z_dim=100, batch_size=2048, use_goal=True),
+                  seed=222, n_eps=12, T=60, n_steps=3, goal_space="simplified_quadruped", full_state=False,
+                  checksum_steps=(1, 3))
+
+
 def sampler_fixture(R):
     """ReplayBuffer.sample KAT: variable lengths + goal + stored meta z; real numpy RNG, fixed seed."""
     rng = np.random.default_rng(7)
@@ -570,6 +583,7 @@ def main():
                   seed=203, n_eps=12, T=60, n_steps=3, goal_space="simplified_quadruped", full_state=False,
                   checksum_steps=(1, 3))
     long_curve_fixtures(R)
+    bench_config_curve_fixture(R)
     sampler_fixture(R)
     init_fixture(R)
     inference_fixture(R)

@@ -286,3 +286,27 @@ def test_replicas_built_under_different_seeds_are_refused_then_synced():
     for k in got[0][4]:                                                   # ... and they stay identical through training
         np.testing.assert_array_equal(got[0][4][k], got[1][4][k], err_msg=k)
     assert got[0][5] == got[1][5] == (4, 4)
+
+
+# ------------------------------------------------------------------------------------------ configs[3] rehearsal at walker dims
+def test_bench_two_rank_rehearsal_at_walker_dims_keeps_replicas_identical():
+    """configs[3]'s code path at ITS per-GPU size (walker dims, batch 1024 per rank) with two ranks: ``bench.py --gpus 2
+    --rehearse-on-one-gpu`` under torch.distributed.run -- the pipelined data-parallel schedule (dp_update_many: early FB
+    bucket, next head on a side stream under the actor all-reduce), 64 timed steps + warm-up.  Both ranks must finish and
+    report bit-identical parameter / target / Adam checksums.  (All ranks share this box's one GPU over gloo: it is a
+    correctness rehearsal of the RCCL run, not a scaling measurement.)"""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    port = T._free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "64",
+           "--warmup", "8", "--repeats", "1", "--episodes", "400", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root),
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 2048
+    assert res["replicas"]["identical"] is True and res["replicas"]["ranks"] == 2
+    assert res["replicas"]["adam_steps"][0] >= 64 + 8 and res["value"] > 0 and "REHEARSAL" in res["data"]

@@ -53,7 +53,9 @@ def test_tiny_traces_full_state(name):
 
 
 @pytest.mark.parametrize("name,tol", [("walker_b256", 2e-4), ("walker_b1024", 1e-4), ("quadruped_goal_b512", 1e-4),
-                                      ("walker_b256_50", 2e-4), ("quadruped_goal_b256_50", 2e-4)])     # 50 steps, checksums at 1/10/50
+                                      ("walker_b256_50", 2e-4), ("quadruped_goal_b256_50", 2e-4),      # 50 steps, checksums at 1/10/50
+                                      ("walker_b1024_50", 2e-4),                                      # configs[1] as benchmarked, 50 steps
+                                      ("quadruped_goal_b2048", 1e-4)])                                # configs[2] at its batch size
 def test_full_dim_metric_curves(name, tol):
     """Full network dims: loss curves + parameter checksums.  Free-running, so the tolerance is the
     reference's own 1-vs-8-thread envelope, not bit equality."""

@@ -99,7 +99,8 @@ def test_teacher_forced_against_reference_trace(name, goal_space):
 
 
 @pytest.mark.parametrize("name,tol", [("walker_b256", 3e-4), ("walker_b1024", 3e-4), ("walker_b256_50", 3e-4),
-                                      ("quadruped_goal_b256_50", 3e-4)])
+                                      ("quadruped_goal_b256_50", 3e-4), ("quadruped_goal_b512", 3e-4),
+                                      ("quadruped_goal_b2048", 3e-4)])          # the last: configs[2] at ITS size (B 2048, d 100, g 2)
 def test_free_running_full_dims_against_reference_curves(name, tol):
     """Full network dims, free-running from the seed-defined init: FB-loss / actor-loss / Q curves and parameter
     checksums vs the reference (the ``_50`` fixtures: 50 steps, checksums at steps 1 / 10 / 50; measured drift of the HIP
@@ -125,6 +126,101 @@ def test_free_running_full_dims_against_reference_curves(name, tol):
             ref = meta["checksums"][str(s + 1)]
             for k, (ssum, l2) in H.checksums(H.get_agent_state(agent)).items():
                 assert l2 == pytest.approx(ref[k][1], rel=1e-5 * (1 + s / 4)), (s, k)
+
+
+@pytest.mark.parametrize("chunks", [(32, 18), (10, 22, 18)])
+def test_bench_configuration_through_the_pipelined_graph_against_the_reference_curve(chunks):
+    """configs[1] AS BENCHMARKED: walker dims, batch 1024, the multi-step PIPELINED graph (fbhip_update_many: step t+1's
+    sampling + online passes captured beside step t's actor phase, 32 steps per launch in bench.py) -- fed the draws of the
+    reference's 50-step free-running run (tests/golden/walker_b1024_50.json, made by the real reference).  Losses at the end
+    of every launch and parameter checksums at steps 10 / 32 / 50 must sit inside the same step-proportional envelope as the
+    single-update free-running test (the reference's own 1-vs-8-thread drift)."""
+    meta = H.load_meta("walker_b1024_50")
+    cfg, nets, storage, lengths, rng = H.regenerate_inputs(meta)
+    assert cfg.batch_size == 1024 and meta["n_steps"] == 50
+    agent = H.make_hip_agent(cfg, nets, meta["goal_space"])
+    rb = _buffer(storage, lengths, cfg.discount)
+    draws = [H.draws_dict(fo.make_draws(rng, cfg, meta["n_eps"], lengths)) for _ in range(meta["n_steps"])]
+    tol, done = 3e-4, 0
+    for n in chunks:
+        m = agent.update_many_injected(rb, done, draws[done:done + n])
+        done += n
+        s = done - 1
+        scale = max(1.0, abs(meta["metrics"][s]["fb_offdiag"]))
+        for k in H.LOSS_KEYS:
+            assert m[k] == pytest.approx(meta["metrics"][s][k], rel=tol * (1 + s), abs=tol * (1 + s) * scale), (s, k)
+        assert m["B_norm"] == pytest.approx(np.sqrt(cfg.z_dim), rel=1e-5)
+        assert agent.step_counts() == (done, done)
+        if str(done) in meta["checksums"]:
+            ref = meta["checksums"][str(done)]
+            for k, (ssum, l2) in H.checksums(H.get_agent_state(agent)).items():
+                assert l2 == pytest.approx(ref[k][1], rel=1e-5 * (1 + s / 4)), (s, k)
+    assert done == 50
+
+
+def test_online_loop_at_quadruped_dims_with_the_2000_episode_ring():
+    """configs[4] at ITS size: run_online (the reference's per-environment-step call sequence, pretrain.py:559-659) with
+    quadruped dims (obs 78, action 12, hidden 1024, batch 1024, z 50), update_every_steps 2 and a 2000-episode x 1000-step
+    ring buffer.  The ring starts 1998 episodes full, so the four episodes collected here wrap it (slots 1998, 1999, 0, 1):
+    ring bookkeeping, the overwritten rows, the update count and a finite agent state are asserted.  (MuJoCo is not in the
+    image: the environment is synthetic; its stepping cost is not what this test is about.)"""
+    from controllable_agent_amd.agent import FBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer, TimeStep
+    from controllable_agent_amd.train_online import run_online
+    o, a, T, ring = 78, 12, 1000, 2000
+    torch.manual_seed(3)
+    agent = FBHipAgent(obs_type="states", obs_shape=(o,), action_shape=(a,), device="cuda", num_expl_steps=200,
+                       use_tb=True, use_wandb=False, use_hiplog=False, goal_space=None, z_dim=50, batch_size=1024,
+                       update_every_steps=2)
+    rb = DeviceReplayBuffer(max_episodes=ring, discount=0.99, future=0.99, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rb._storage = {"observation": torch.randn((ring, T + 1, o), device="cuda", generator=g),
+                   "action": torch.rand((ring, T + 1, a), device="cuda", generator=g) * 2 - 1,
+                   "reward": torch.zeros((ring, T + 1, 1), device="cuda"), "discount": torch.ones((ring, T + 1, 1), device="cuda"),
+                   "physics": torch.zeros((ring, T + 1, 2), device="cuda"), "z": torch.zeros((ring, T + 1, 50), device="cuda")}
+    rb._episodes_length[:1998] = T
+    rb._idx = 1998
+    rb._touch()
+    old_slot0 = rb._storage["observation"][0].clone()
+    rng = np.random.default_rng(9)
+
+    class Env:
+        t, episode = 0, 0
+
+        def _ts(self, kind, action):
+            obs = rng.standard_normal(o).astype(np.float32)
+            obs[0] = 1000.0 + self.episode                 # marks which collected episode wrote a storage row
+            return TimeStep(step_type=kind, reward=0.1, discount=1.0, observation=obs, action=np.asarray(action, np.float32),
+                            physics=np.zeros(2, np.float32))
+
+        def reset(self):
+            self.t = 0
+            return self._ts(0, np.zeros(a))
+
+        def step(self, action):
+            assert action.shape == (a,) and np.all(np.abs(action) <= 1.0)
+            self.t += 1
+            ts = self._ts(2 if self.t == T else 1, action)
+            if self.t == T:
+                self.episode += 1
+            return ts
+
+    logged = []
+    st = run_online(agent, rb, Env(), num_train_frames=4 * T + 50, num_seed_frames=1000,
+                    log_fn=lambda step, m: logged.append((step, m)) if "fb_loss" in m else None)
+    torch.cuda.synchronize()
+    assert (st.env_steps, st.episodes) == (4 * T + 50, 4)
+    assert st.updates == (4 * T + 50 - 1000) // 2 and agent.step_counts() == (st.updates, st.updates)
+    assert rb._full and rb._idx == 2 and len(rb) == ring                           # 1998 + 4 episodes: wrapped
+    np.testing.assert_array_equal(rb._episodes_length, np.full(ring, T))
+    marks = {slot: float(rb._storage["observation"][slot, 5, 0]) for slot in (1998, 1999, 0, 1)}
+    assert marks == {1998: 1000.0, 1999: 1001.0, 0: 1002.0, 1: 1003.0}           # the ring was overwritten in place, in order
+    assert not torch.equal(rb._storage["observation"][0], old_slot0)
+    assert float(rb._storage["observation"][2, 5, 0]) < 100.0                     # untouched slot keeps the prefill
+    assert rb._storage["z"][0].abs().sum() > 0                                    # the meta z of the collected steps is stored
+    assert len(logged) == st.updates and all(np.isfinite(m["fb_loss"]) and np.isfinite(m["actor_loss"]) for _, m in logged)
+    assert all(np.isfinite(v).all() for v in H.get_agent_state(agent).values())
+    assert logged[-1][1]["B_norm"] == pytest.approx(np.sqrt(50), rel=1e-5)
 
 
 def test_graph_replay_equals_eager_launches():
