@@ -77,13 +77,16 @@ def import_reference():
     w.action_scale = mod("dm_control.suite.wrappers.action_scale")
     w.pixels = mod("dm_control.suite.wrappers.pixels")
     mod("url_benchmark.custom_dmc_tasks")
-    mod("url_benchmark.goals", get_goal_space_dim={"simplified_walker": 3, "simplified_quadruped": 2}.__getitem__)
+    # (sf.py:401 reads the goal dimension as len(next(iter(goals.goals.funcs[goal_space].values()))()))
+    _gdims = {"simplified_walker": 3, "simplified_quadruped": 2}
+    mod("url_benchmark.goals", get_goal_space_dim=_gdims.__getitem__,
+        goals=types.SimpleNamespace(funcs={k: {"stub": (lambda n=n: np.zeros(n, np.float32))} for k, n in _gdims.items()}))
     import url_benchmark  # noqa: F401
     mod("url_benchmark.agent").__path__ = [str(REF / "url_benchmark/agent")]
-    from url_benchmark.agent import fb_ddpg, discrete_fb
+    from url_benchmark.agent import fb_ddpg, discrete_fb, sf
     from url_benchmark.in_memory_replay_buffer import ReplayBuffer
     from url_benchmark import dmc, utils
-    return types.SimpleNamespace(fb_ddpg=fb_ddpg, discrete_fb=discrete_fb, ReplayBuffer=ReplayBuffer, dmc=dmc, utils=utils,
+    return types.SimpleNamespace(fb_ddpg=fb_ddpg, discrete_fb=discrete_fb, sf=sf, ReplayBuffer=ReplayBuffer, dmc=dmc, utils=utils,
                                  StepType=StepType)
 
 
@@ -314,6 +317,73 @@ def discrete_fixture(R):
     trace_fixture(R, "tiny_discrete_boltz_trace", tiny_cfg(action_dim=3, preprocess=False, boltzmann=True, temp=0.7, q_loss=True,
                                                            norm_z=False, batch_size=32, z_dim=6, backward_hidden_dim=20),
                   seed=121, n_eps=6, T=12, n_steps=4, discrete=True)
+
+
+def sf_state(agent):
+    out = {}
+    for n in ("actor", "successor_net", "successor_target_net", "feature_learner"):
+        for k, v in getattr(agent, n).state_dict().items():
+            out[f"{n}/{k}"] = v.detach().numpy().copy()
+    for opt, n in ((agent.actor_opt, "actor"), (agent.sf_opt, "successor_net"), (agent.phi_opt, "feature_learner")):
+        for (k, p) in getattr(agent, n).named_parameters():
+            st = opt.state.get(p, None)
+            if st:
+                out[f"adam_m/{n}/{k}"] = st["exp_avg"].numpy().copy()
+                out[f"adam_v/{n}/{k}"] = st["exp_avg_sq"].numpy().copy()
+    return out
+
+
+def sf_fixture(R):
+    """SFAgent.update (sf.py:594-768; SURVEY section 8 row n4, second sibling): the TD regression on successor features with the
+    two feature learners the round targets.  (1) the defaults: feature_learner="icm", q_loss=True (scalar Q regression);
+    (2) feature_learner="lap" (Laplacian + orthonormality loss), q_loss=False (regression in feature space), goal space, variable
+    episode lengths, lr_coef=5 like the reference default."""
+    from oracle import sf_oracle as so
+    for name, learner, q_loss, kw, extra in (
+            ("tiny_sf_icm_trace", "icm", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0), dict(seed=131, n_eps=6, T=12, n_steps=4)),
+            ("tiny_sf_lap_trace", "lap", False, dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0),
+             dict(seed=132, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True))):
+        cfg = tiny_cfg(**kw)
+        seed, n_eps, T, n_steps = extra["seed"], extra["n_eps"], extra["T"], extra["n_steps"]
+        goal_space, variable_len = extra.get("goal_space"), extra.get("variable_len", False)
+        rng = np.random.default_rng(seed)
+        shapes = so.net_shapes(cfg, learner)
+        nets = {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}
+        lengths = None
+        if variable_len:
+            lengths = rng.integers(max(2, T // 2), T + 1, size=n_eps).astype(np.int32)
+            lengths[0] = T
+        storage, lengths = fo.synthetic_storage(rng, n_eps, T, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if cfg.use_goal else None, lengths)
+        agent = R.sf.SFAgent(
+            obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cpu", num_expl_steps=0,
+            use_tb=True, use_wandb=False, use_hiplog=False, update_encoder=True, goal_space=goal_space, lr=cfg.lr,
+            lr_coef=cfg.lr_coef, sf_target_tau=cfg.fb_target_tau, hidden_dim=cfg.hidden_dim,
+            backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim, z_dim=cfg.z_dim,
+            stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size, q_loss=q_loss,
+            feature_learner=learner, mix_ratio=0.0, update_every_steps=1)
+        for n in nets:
+            getattr(agent, n).load_state_dict(nets[n])
+        agent.successor_target_net.load_state_dict(agent.successor_net.state_dict())
+        rb = fill_ref_buffer(R, storage, lengths, cfg.discount, future=cfg.future, max_len=(T + 1) if variable_len else None)
+        arrays = {f"init/{n}/{k}": v.numpy() for n, p in nets.items() for k, v in p.items()}
+        arrays.update({f"storage/{k}": v for k, v in storage.items()})
+        arrays["lengths"] = lengths
+        meta = {"name": name, "seed": seed, "n_eps": n_eps, "T": T, "n_steps": n_steps, "goal_space": goal_space,
+                "variable_len": variable_len, "feature_learner": learner, "sf_q_loss": q_loss,
+                "cfg": {k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, "metrics": []}
+        for s_ in range(n_steps):
+            d = fo.make_draws(rng, cfg, n_eps, lengths)
+            with inject(R, d, variable_len, 0.0):
+                m = agent.update(rb, s_)
+            meta["metrics"].append({k: float(v) for k, v in m.items()})
+            for f in d.__dataclass_fields__:
+                if getattr(d, f) is not None:
+                    arrays[f"draws/{s_}/{f}"] = getattr(d, f)
+            for k, v in sf_state(agent).items():
+                arrays[f"state/{s_}/{k}"] = v
+        (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1))
+        np.savez_compressed(HERE / f"{name}.npz", **arrays)
+        print(f"[{name}] sf_loss={[round(m['sf_loss'], 4) for m in meta['metrics']]} phi_loss={[round(m['phi_loss'], 4) for m in meta['metrics']]}")
 
 
 def long_curve_fixtures(R):
@@ -573,6 +643,7 @@ def main():
     single_trunk_fixture(R)
     boltzmann_fixture(R)
     discrete_fixture(R)
+    sf_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -118,3 +118,31 @@ def test_inference_kat():
     np.testing.assert_allclose(zi, z["z_inferred"], rtol=1e-5, atol=1e-6)
     Bout = fo.backward_map(ag.backward_net, torch.from_numpy(z["goal_obs"]), cfg.z_dim).numpy()
     np.testing.assert_allclose(Bout, z["backward_out"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ SFAgent (row n4, second sibling)
+def sf_trace_inputs(name):
+    """(meta, npz, cfg, nets, storage, lengths) of a tiny_sf_* trace (tests/golden/make_golden.py::sf_fixture)"""
+    meta = H.load_meta(name)
+    z = np.load(H.GOLDEN / f"{name}.npz")
+    cfg = H.cfg_from_meta(meta)
+    nets = {n: {k.split("/", 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"init/{n}/")}
+            for n in ("actor", "successor_net", "feature_learner")}
+    storage = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("storage/")}
+    return meta, z, cfg, nets, storage, z["lengths"]
+
+
+@pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace"])
+def test_sf_oracle_full_state_against_the_reference(name):
+    """oracle/sf_oracle.py against traces of the real url_benchmark.agent.sf.SFAgent: metrics and every parameter / target /
+    Adam tensor after every step (icm + scalar Q regression; lap + feature-space regression + goal space + variable lengths)."""
+    from oracle import sf_oracle as so
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs(name)
+    agent = so.SFOracleAgent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"])
+    for s in range(meta["n_steps"]):
+        d = fo.Draws(**{f: z[f"draws/{s}/{f}"] for f in fo.Draws.__dataclass_fields__ if f"draws/{s}/{f}" in z.files})
+        m = agent.update(fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount, d.future_idx), d)
+        for k, v in meta["metrics"][s].items():
+            assert m[k] == pytest.approx(v, rel=2e-5, abs=1e-6), (s, k)
+        for k, v in agent.state_tensors().items():
+            np.testing.assert_allclose(v, z[f"state/{s}/{k}"], rtol=1e-4, atol=2e-6, err_msg=f"step {s} {k}")
