@@ -7,11 +7,12 @@ Compute goes through libfbhip.so (hand-written HIP kernels, include/fbhip.h); th
 """
 from ._lib import LIB_PATH  # noqa: F401
 
-__all__ = ["FBHipAgent", "FBDDPGAgentConfig", "DiscreteFBHipAgent", "DiscreteFBAgentConfig", "DeviceReplayBuffer", "EpisodeBatch", "kernels"]
+__all__ = ["FBHipAgent", "FBDDPGAgentConfig", "DiscreteFBHipAgent", "DiscreteFBAgentConfig", "SFHipAgent", "SFAgentConfig",
+           "DeviceReplayBuffer", "EpisodeBatch", "kernels"]
 
 
 def __getattr__(name):
-    if name in ("FBHipAgent", "FBDDPGAgentConfig", "DiscreteFBHipAgent", "DiscreteFBAgentConfig"):
+    if name in ("FBHipAgent", "FBDDPGAgentConfig", "DiscreteFBHipAgent", "DiscreteFBAgentConfig", "SFHipAgent", "SFAgentConfig"):
         from . import agent
         return getattr(agent, name)
     if name in ("DeviceReplayBuffer", "EpisodeBatch"):

@@ -22,7 +22,8 @@ NUM_METRICS = 32
 # metric name -> index in the device metrics array (fb_ddpg.py:356-377, 413-418)
 METRIC_INDEX = {n: i for i, n in enumerate(
     ["target_M", "M1", "F1", "B", "B_norm", "z_norm", "fb_loss", "fb_diag", "fb_offdiag", "q_loss", "orth_loss",
-     "orth_loss_diag", "orth_loss_offdiag", "orth_linf", "orth_l2", "actor_loss", "q", "actor_logprob", "q1_success"])}
+     "orth_loss_diag", "orth_loss_offdiag", "orth_linf", "orth_l2", "actor_loss", "q", "actor_logprob", "q1_success",
+     "sf_loss", "target_F", "phi", "phi_norm", "phi_loss"])}
 EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK_RELU, EPI_TANH_BWD = range(5)
 
 
@@ -30,7 +31,7 @@ class Dims(C.Structure):
     """include/fbhip.h::fbhip_dims; ``struct_size`` (first field) is filled in here, positional arguments start at ``batch``"""
     _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
                                           "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z", "boltzmann",
-                                          "discrete")]
+                                          "discrete", "sf")]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(Dims), *args, **kw)

@@ -131,11 +131,20 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
                        "F2.0.weight", "F2.0.bias", "F2.2.weight", "F2.2.bias"});
     } else if (net == FBHIP_NET_BACKWARD) {       // BackwardMap, fb_modules.py:220
         const int HbP = pad64(Hb);
-        b.mat("B.0.weight", Hb, g, pad32(g), HbP); b.vec("B.0.bias", Hb, HbP); b.vec("B.1.weight", Hb, HbP);
-        b.vec("B.1.bias", Hb, HbP);
-        b.mat("B.3.weight", Hb, Hb, HbP, HbP); b.vec("B.3.bias", Hb, HbP);
-        b.mat("B.5.weight", z, Hb, HbP); b.vec("B.5.bias", z);
-        order = {"B.0.weight", "B.0.bias", "B.1.weight", "B.1.bias", "B.3.weight", "B.3.bias", "B.5.weight", "B.5.bias"};
+        // SFAgent (dims.sf): the same architecture is feature_learner.feature_net (sf.py:84-88; the projection is its last module)
+        const std::string q = d.sf ? "feature_net." : "B.";
+        b.mat(q + "0.weight", Hb, g, pad32(g), HbP); b.vec(q + "0.bias", Hb, HbP); b.vec(q + "1.weight", Hb, HbP);
+        b.vec(q + "1.bias", Hb, HbP);
+        b.mat(q + "3.weight", Hb, Hb, HbP, HbP); b.vec(q + "3.bias", Hb, HbP);
+        b.mat(q + "5.weight", z, Hb, HbP); b.vec(q + "5.bias", z);
+        order = {q + "0.weight", q + "0.bias", q + "1.weight", q + "1.bias", q + "3.weight", q + "3.bias", q + "5.weight", q + "5.bias"};
+        if (d.sf == 1) {      // ICM: inverse_dynamic_net = mlp(2 z, Hb, 'irelu', Hb, 'irelu', a, 'tanh')  (sf.py:198)
+            const std::string i = "inverse_dynamic_net.";
+            b.mat(i + "0.weight", Hb, 2 * z, pad32(2 * z), HbP); b.vec(i + "0.bias", Hb, HbP);
+            b.mat(i + "2.weight", Hb, Hb, HbP, HbP); b.vec(i + "2.bias", Hb, HbP);
+            b.mat(i + "4.weight", a, Hb, HbP); b.vec(i + "4.bias", a);
+            append(order, {i + "0.weight", i + "0.bias", i + "2.weight", i + "2.bias", i + "4.weight", i + "4.bias"});
+        }
     } else if (d.discrete) {                      // DiscreteFBAgent has no actor: empty layout
     } else if (d.boltzmann) {                     // DiagGaussianActor.policy = mlp(o + z, H, "ntanh", H, "relu", 2a)
         b.trunk("policy", o + z, H, H);
@@ -176,6 +185,8 @@ int check_dims(const fbhip_dims* d) {
     if (d->batch > 8192) { g_err = "fbhip: batch > 8192 per GPU unsupported (permutation sort)"; return FBHIP_E_INVALID; }
     if (d->discrete && d->preprocess) { g_err = "fbhip: discrete needs preprocess == 0 (the reference's discrete ForwardMap.forward only runs without the preprocess nets, discrete_fb.py:91-94)"; return FBHIP_E_INVALID; }
     if (d->discrete && (int64_t)d->z_dim * d->action_dim > 8192) { g_err = "fbhip: discrete: z_dim * actions > 8192 unsupported"; return FBHIP_E_INVALID; }
+    if (d->sf < 0 || d->sf > 2) { g_err = "fbhip: dims.sf must be 0, 1 (icm) or 2 (lap)"; return FBHIP_E_INVALID; }
+    if (d->sf && (d->discrete || d->boltzmann || !d->norm_z)) { g_err = "fbhip: dims.sf needs discrete = 0, boltzmann = 0, norm_z = 1"; return FBHIP_E_INVALID; }
     if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
     return FBHIP_OK;
 }
@@ -208,6 +219,12 @@ struct Ws {
     float* rw = nullptr;                // rand_weight: [B, B] mixing weights, [B] row scales, and the mixed rows
     float* rw_u = nullptr;
     Buf ymixw;
+    // SFAgent (dims.sf): the feature pass runs on 2 batch rows -- [goal ; next_goal] -- so that one backward sums both uses
+    Buf goal2;                          // [2B, g]: bin = rows [0, B), next_goal = rows [B, 2B)
+    BSet bsS;                           // feature_net activations, 2B rows
+    Buf dBm2, dy2, s_dr2, s_dt1;        // its gradient panels, 2B rows
+    Buf icat, ih1, ih2, ipre, d_ipre, d_ih1, d_ih2;          // icm: inverse-dynamics activations / gradients
+    Buf zeroF, lapS1, lapS2;                                 // lap: the zero F panel and two throw-away dF panels of the pairwise pass
     float* act_in = nullptr;            // batch-1 fast path: [obs | z | 0.. | noise] / [goal | 0.. | z] as staged by the host
     float* act_vec = nullptr;           // its activation vectors
     float* act_out = nullptr;           // action (a floats) or the z correlation (1 float)
@@ -274,7 +291,14 @@ Ws carve(const fbhip_dims& d, void* base) {
         w.Xnoa = c.buf(B, o + a, pad32(o + a)); w.Xopi = c.buf(B, o + a, pad32(o + a));
     }
     w.Xo = c.buf(B, o, pad32(o));
-    w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.fgoal = c.buf(B, g, pad32(g));
+    if (d.sf) {
+        w.goal2 = c.buf(2 * B, g, pad32(g));
+        w.bin = w.goal2; w.bin.rows = B;
+        w.next_goal = w.bin; w.next_goal.p = base ? w.goal2.p + (size_t)B * w.goal2.ld : nullptr;
+        w.fgoal = c.buf(1, g, pad32(g));
+    } else {
+        w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.fgoal = c.buf(B, g, pad32(g));
+    }
     w.z = c.buf(B, z); w.zrand = c.buf(B, z);
     w.disc = c.f(B);
     for (BSet* s : {&w.bsA, &w.bsO, &w.bsM, &w.bsF}) {
@@ -305,10 +329,23 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
     w.ln_partials = c.f((size_t)2 * ((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);   // two trunks
-    w.ln_partials_b = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
+    w.ln_partials_b = c.f((size_t)(((d.sf ? 2 : 1) * B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
     w.splitk = c.f((size_t)6 << 20);
     w.rw = c.f((size_t)B * B); w.rw_u = c.f(B); w.ymixw = c.buf(B, z);
+    if (d.sf) {
+        const int Lb = pad64(Hb), Lz = pad4(z), La = pad4(a);
+        w.bsS.pre1 = c.buf(2 * B, Hb, Lb); w.bsS.t1 = c.buf(2 * B, Hb, Lb); w.bsS.r2 = c.buf(2 * B, Hb, Lb);
+        w.bsS.y = c.buf(2 * B, z); w.bsS.Bm = c.buf(2 * B, z);
+        w.bsS.stats = c.f(4 * (size_t)B); w.bsS.norms = c.f(2 * (size_t)B);
+        w.dBm2 = c.buf(2 * B, z); w.dy2 = c.buf(2 * B, z); w.s_dr2 = c.buf(2 * B, Hb, Lb); w.s_dt1 = c.buf(2 * B, Hb, Lb);
+        if (d.sf == 2) { w.zeroF = c.buf(B, z); w.lapS1 = c.buf(B, z); w.lapS2 = c.buf(B, z); }
+        if (d.sf == 1) {
+            w.icat = c.buf(B, 2 * z, pad32(2 * z)); w.ih1 = c.buf(B, Hb, Lb); w.ih2 = c.buf(B, Hb, Lb);
+            w.ipre = c.buf(B, a, La); w.d_ipre = c.buf(B, a, La); w.d_ih1 = c.buf(B, Hb, Lb); w.d_ih2 = c.buf(B, Hb, Lb);
+        }
+        (void)Lz;
+    }
     w.act_in = c.f(act_in_floats(d));
     w.act_vec = c.f((size_t)5 * 2048 + 256);
     w.act_out = c.f(64);
@@ -320,6 +357,7 @@ Ws carve(const fbhip_dims& d, void* base) {
 struct TrunkP { float *W1, *b1, *g1, *be1, *W2, *b2; int k1, ld1; };
 struct FwdP { TrunkP oa, oz; float *Wt = nullptr, *bt = nullptr; float *W3s, *b3s, *W4[2], *b4[2]; };   // Wt: add_trunk
 struct BwdP { float *W1, *b1, *g1, *be1, *W2, *b2, *W3, *b3; };
+struct IcmP { float *W1 = nullptr, *b1, *W2, *b2, *W3, *b3; };     // SFAgent's inverse_dynamic_net (in the backward segment)
 struct ActP { TrunkP o, oz; float *Wt = nullptr, *bt = nullptr; float *W3, *b3, *W4, *b4; };
 
 TrunkP trunk_p(float* base, const NetLayout& L, const std::string& p) {
@@ -349,11 +387,21 @@ FwdP fwd_p(float* base, const NetLayout& L) {
 }
 BwdP bwd_p(float* base, const NetLayout& L) {
     BwdP b;
-    b.W1 = base + L.by_name.at("B.0.weight").off; b.b1 = base + L.by_name.at("B.0.bias").off;
-    b.g1 = base + L.by_name.at("B.1.weight").off; b.be1 = base + L.by_name.at("B.1.bias").off;
-    b.W2 = base + L.by_name.at("B.3.weight").off; b.b2 = base + L.by_name.at("B.3.bias").off;
-    b.W3 = base + L.by_name.at("B.5.weight").off; b.b3 = base + L.by_name.at("B.5.bias").off;
+    const std::string q = L.by_name.count("B.0.weight") ? "B." : "feature_net.";
+    b.W1 = base + L.by_name.at(q + "0.weight").off; b.b1 = base + L.by_name.at(q + "0.bias").off;
+    b.g1 = base + L.by_name.at(q + "1.weight").off; b.be1 = base + L.by_name.at(q + "1.bias").off;
+    b.W2 = base + L.by_name.at(q + "3.weight").off; b.b2 = base + L.by_name.at(q + "3.bias").off;
+    b.W3 = base + L.by_name.at(q + "5.weight").off; b.b3 = base + L.by_name.at(q + "5.bias").off;
     return b;
+}
+IcmP icm_p(float* base, const NetLayout& L) {
+    IcmP i;
+    if (!L.by_name.count("inverse_dynamic_net.0.weight")) return i;
+    const std::string q = "inverse_dynamic_net.";
+    i.W1 = base + L.by_name.at(q + "0.weight").off; i.b1 = base + L.by_name.at(q + "0.bias").off;
+    i.W2 = base + L.by_name.at(q + "2.weight").off; i.b2 = base + L.by_name.at(q + "2.bias").off;
+    i.W3 = base + L.by_name.at(q + "4.weight").off; i.b3 = base + L.by_name.at(q + "4.bias").off;
+    return i;
 }
 ActP act_p(float* base, const NetLayout& L) {
     ActP a;
@@ -398,6 +446,7 @@ struct fbhip_ctx {
     uint32_t rank = 0;
     FwdP F_p, F_g, F_t;
     BwdP K_p, K_g, K_t;
+    IcmP I_p, I_g;                           // dims.sf == 1
     ActP A_p, A_g;
     std::vector<GraphEntry> graphs;
     std::vector<InferGraph> infer_graphs;    // batch-1 fast path (fbhip_act / fbhip_z_correl)
@@ -825,8 +874,10 @@ int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet&
 }
 
 // backward of BackwardMap from dB (gradient wrt the projected embedding)
+// gradient panels of one BackwardMap backward (default: the workspace's B-row set; SFAgent's 2B-row feature pass brings its own)
+struct BGrad { const float* dBm; float* dy; float* dr2; float* dt1; };
 void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S, int rows,
-                            Chain& out, bool dy_done = false) {
+                            Chain& out, bool dy_done = false, const BGrad* bufs = nullptr) {
     const fbhip_dims& d = c->d;
     const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
     // weight gradient of the first layer: X must be a zero-padded panel to use the padded width
@@ -834,28 +885,29 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
     const int Ng = padded_x ? pad32(g) : g;
     Ws* w = &c->W();
     BSet* Sp = &S;
-    const float* dy = d.norm_z ? w->dy.p : w->dBm.p;    // no projection: the gradient wrt y is dB itself
+    const BGrad B_ = bufs ? *bufs : BGrad{w->dBm.p, w->dy.p, w->b_dr2.p, w->b_dt1.p};
+    const float* dy = d.norm_z ? B_.dy : B_.dBm;        // no projection: the gradient wrt y is dB itself
     out.push_back([=](Ops& o) {                 // dy = d/dy of sqrt(d) normalize(y)   (F.normalize backward)
         if (!c->d.norm_z || dy_done) return;     // (the stage stays, empty: the chain's thin last round must meet forward_net's)
         o.post.push_back([=](hipStream_t s) -> int {
-            HIPCK(c, launch_l2norm_bwd(w->dBm.p, Lz, Sp->y.p, Lz, Sp->norms, w->dy.p, Lz, rows, z, s));
+            HIPCK(c, launch_l2norm_bwd(B_.dBm, Lz, Sp->y.p, Lz, Sp->norms, B_.dy, Lz, rows, z, s));
             return (int)FBHIP_OK;
         });
     });
     out.push_back([=](Ops& o) {                 // (the output layer's thin weight gradient waits for the last round, see forward_map_bwd_chain)
-        o.gemms.push_back(P(dy, Lz, 1, W.W3, Lb, 0, w->b_dr2.p, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb));
+        o.gemms.push_back(P(dy, Lz, 1, W.W3, Lb, 0, B_.dr2, Lb, rows, Lb, z, nullptr, EPI_MASK_RELU, Sp->r2.p, Lb));
     });
     out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(w->b_dr2.p, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Lb, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2));
-        o.gemms.push_back(P(w->b_dr2.p, Lb, 1, W.W2, Lb, 0, w->b_dt1.p, Lb, rows, Lb, Lb));
+        o.gemms.push_back(P(B_.dr2, Lb, 0, Sp->t1.p, Lb, 0, G.W2, Lb, Lb, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b2));
+        o.gemms.push_back(P(B_.dr2, Lb, 1, W.W2, Lb, 0, B_.dt1, Lb, rows, Lb, Lb));
     });
     out.push_back([=](Ops& o) {
-        o.lnb.push_back(LnBwdProblem{w->b_dt1.p, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, w->b_dt1.p, Lb, G.g1,
+        o.lnb.push_back(LnBwdProblem{B_.dt1, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, B_.dt1, Lb, G.g1,
                                      G.be1, w->ln_partials_b, rows, Hb, 0, 0, 0, 0, 0, pad4(Hb)});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
-        o.gemms.push_back(P(w->b_dt1.p, Lb, 0, X, ldx, 0, G.W1, pad32(g), Lb, Ng, rows, nullptr, EPI_NONE, nullptr, 0, G.b1));
+        o.gemms.push_back(P(B_.dt1, Lb, 0, X, ldx, 0, G.W1, pad32(g), Lb, Ng, rows, nullptr, EPI_NONE, nullptr, 0, G.b1));
     });
 }
 
@@ -1303,8 +1355,161 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 #undef POST_BEGIN
 #undef POST_END
 
+// ---- one SFAgent.update(): sf.py:700-768 (dims.sf) ---------------------------------------------------------------------
+// Everything up to and including the two critic-side optimiser steps (sf_opt, phi_opt: the two lr groups of the FB flat
+// buffer); the actor phase (sf.py:666-694) and the target EMA are FBDDPGAgent's and come from build_update.
+#define POST_BEGIN prog_post(prog, [=, &w](hipStream_t s) -> int {
+#define POST_END return (int)FBHIP_OK; });
+int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, Program& prog) {
+    const fbhip_dims& d = c->d;
+    Ws& w = c->W();
+    const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
+              Hb = d.backward_hidden_dim, Lb = pad64(Hb), Lz = pad4(z), La = pad4(a);
+    const Geom gm = geom_of(d);
+    const int aoff = gm.single ? o + z : o;
+    if (hp.mix_ratio != 0.f || hp.future_ratio != 0.f || hp.rand_weight) {
+        c->err = g_err = "fbhip: dims.sf supports the reference's default z sampling only (mix_ratio = 0, sf.py:728-743 not built)";
+        return FBHIP_E_INVALID;
+    }
+    // ---- sample: the FB sampler with the identity permutation: goal2 = [goal ; next_goal] (sf.py:705-721), z = sample_z (:723)
+    const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->z_gauss && inj->eps_next && inj->eps_actor;
+    POST_BEGIN
+    if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, -1.f, 1, s));
+    if (inj != nullptr) {
+#define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
+        INJ(ep_idx, B * 4); INJ(step_idx, B * 4); INJ(z_gauss, (size_t)B * z * 4); INJ(eps_next, (size_t)B * a * 4);
+        INJ(eps_actor, (size_t)B * a * 4);
+#undef INJ
+    }
+    GatherArgs ga{};
+    ga.rv = c->rv; ga.ep_idx = w.so.ep_idx; ga.step_idx = w.so.step_idx; ga.perm = nullptr;
+    ga.Xoa = w.Xoa.p; ga.ld_oa = w.Xoa.ld; ga.Xoz = w.Xoz.p; ga.ld_oz = w.Xoz.ld; ga.Xnoz = w.Xnoz.p; ga.ld_noz = w.Xnoz.ld;
+    ga.Xnoa = w.Xnoa.p; ga.ld_noa = w.Xnoa.ld; ga.Xopi = w.Xopi.p; ga.ld_opi = w.Xopi.ld;
+    ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
+    ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld; ga.future_idx = nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
+    ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount; ga.aoff = aoff; ga.act_idx = nullptr;
+    HIPCK(c, launch_gather(ga, s));
+    ZPanels zx{};
+    if (gm.single) zx = ZPanels{{w.Xoa.p, w.Xnoa.p, w.Xopi.p}, {w.Xoa.ld, w.Xnoa.ld, w.Xopi.ld}};
+    HIPCK(c, launch_mix_z(w.so.z_gauss, z, nullptr, Lz, w.so.mix_uniform, 0.f, w.z.p, Lz, w.Xoz.p, w.Xoz.ld, w.Xnoz.p, w.Xnoz.ld,
+                          o, B, z, w.st, nullptr, nullptr, 0.f, nullptr, 2, zx, s));
+    POST_END
+
+    // ---- forward passes: target chain (actor(next_obs) -> next_action -> successor_target), online successor_net, the
+    // feature pass on [goal ; next_goal], and update_actor's own actor pass (it reads only the actor weights)
+    static const bool head_env = [] { const char* e = getenv("FBHIP_FUSED_POLICY_HEAD"); return !(e && e[0] == '0'); }();
+    const bool fused_policy = head_env && policy_head_ok(H, a);
+    if (fused_policy) {
+        const float stddev = hp.stddev, clip = hp.stddev_clip;
+        c->run_policy_heads = [=](const PolicyHeadJobs& jobs, hipStream_t q) -> int {
+            HIPCK(c, launch_policy_head(jobs, c->A_p.W4, H, c->A_p.b4, La, a, stddev, clip, La, B, H, a, a, c->sq, q));
+            return (int)FBHIP_OK;
+        };
+    }
+    auto policy_stage = [=](const float* noise, float* mu, float* action_dst, int ld_dst, ASet* S) {
+        return [=](Ops& o2) {
+            if (fused_policy) { o2.ph.push_back(PolicyHeadJob{S->p.p, H, S->premu.p, noise, mu, action_dst, ld_dst}); return; }
+            o2.post.push_back([=](hipStream_t q) -> int {
+                HIPCK(c, launch_policy_sample(S->premu.p, La, noise, a, hp.stddev, hp.stddev_clip, mu, La, action_dst, ld_dst, B, a, c->sq, q));
+                return (int)FBHIP_OK;
+            });
+        };
+    };
+    {
+        std::vector<Chain> ch(4);
+        actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.asT, B, ch[0], !fused_policy);
+        ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
+        forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
+        forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
+        backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, ch[2]);
+        actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[3], !fused_policy);
+        ch[3].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld, &w.as));
+        prog_parallel(prog, ch);
+    }
+    const float* phi = w.bsS.Bm.p;                                    // phi(goal)       rows [0, B)
+    const float* nphi = w.bsS.Bm.p + (size_t)B * Lz;                  // phi(next_goal)  rows [B, 2B)
+    float* dphi = w.dBm2.p;
+    float* dnphi = w.dBm2.p + (size_t)B * Lz;
+    // ---- critic loss (sf.py:607-626) -> dF1, dF2
+    POST_BEGIN
+    HIPCK(c, launch_sf_loss(w.fsO.F1.p, w.fsO.F2.p, w.fsT.F1.p, w.fsT.F2.p, nphi, w.z.p, Lz, w.disc, hp.q_loss, w.dF1.p, w.dF2.p,
+                            w.metrics, w.pw_scratch, B, z, s));
+    POST_END
+    // ---- feature loss and its gradient wrt [phi ; next_phi]  (sf.py:628 -> ICM :203-213 / Laplacian :100-116), then both backward
+    // passes side by side: successor_net from (dF1, dF2), feature_learner from d[phi ; next_phi]
+    Chain feat;
+    if (d.sf == 1) {
+        const IcmP &I = c->I_p, &G = c->I_g;
+        const int Kc = pad32(2 * z);
+        feat.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_concat2(w.icat.p, Kc, phi, Lz, z, nphi, Lz, z, B, q));
+                return (int)FBHIP_OK;
+            });
+        });
+        feat.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.icat.p, Kc, 1, I.W1, Kc, 1, w.ih1.p, Lb, B, Lb, Kc, I.b1, EPI_BIAS_RELU)); });
+        feat.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(w.ih1.p, Lb, 1, I.W2, Lb, 1, w.ih2.p, Lb, B, Lb, Lb, I.b2, EPI_BIAS_RELU)); });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.ih2.p, Lb, 1, I.W3, Lb, 1, w.ipre.p, La, B, a, Lb, I.b3, EPI_BIAS));
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_icm_loss(w.ipre.p, La, w.Xoa.p + aoff, w.Xoa.ld, w.d_ipre.p, La, B, a, w.metrics, q));
+                return (int)FBHIP_OK;
+            });
+        });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.d_ipre.p, La, 0, w.ih2.p, Lb, 0, G.W3, Lb, a, Lb, B, nullptr, EPI_NONE, nullptr, 0, G.b3));
+            o2.gemms.push_back(P(w.d_ipre.p, La, 1, I.W3, Lb, 0, w.d_ih2.p, Lb, B, Lb, a, nullptr, EPI_MASK_RELU, w.ih2.p, Lb));
+        });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.d_ih2.p, Lb, 0, w.ih1.p, Lb, 0, G.W2, Lb, Lb, Lb, B, nullptr, EPI_NONE, nullptr, 0, G.b2));
+            o2.gemms.push_back(P(w.d_ih2.p, Lb, 1, I.W2, Lb, 0, w.d_ih1.p, Lb, B, Lb, Lb, nullptr, EPI_MASK_RELU, w.ih1.p, Lb));
+        });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.d_ih1.p, Lb, 0, w.icat.p, Kc, 0, G.W1, Kc, Lb, Kc, B, nullptr, EPI_NONE, nullptr, 0, G.b1));
+            o2.gemms.push_back(P(w.d_ih1.p, Lb, 1, I.W1, Kc, 0, dphi, Lz, B, z, Lb));            // d cat[:, :z]
+            o2.gemms.push_back(P(w.d_ih1.p, Lb, 1, I.W1 + z, Kc, 0, dnphi, Lz, B, z, Lb));       // d cat[:, z:2z]
+        });
+    } else {
+        feat.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                // orthonormality part: the pairwise kernel with zero F panels leaves 2 Hm . phi in d phi and orth_loss in the
+                // metrics; lap_kernel adds the mean((phi - next_phi)^2) part and writes d next_phi
+                HIPCK(c, launch_pairwise_fb(w.zeroF.p, w.zeroF.p, phi, w.zeroF.p, w.zeroF.p, phi, w.disc, B, z, Lz, 1.0f, w.lapS1.p,
+                                            w.lapS2.p, dphi, w.metrics, w.pw_scratch, q));
+                HIPCK(c, launch_lap(phi, nphi, Lz, dphi, dnphi, w.metrics, w.pw_scratch, B, z, q));
+                return (int)FBHIP_OK;
+            });
+        });
+    }
+    BGrad bg{w.dBm2.p, w.dy2.p, w.s_dr2.p, w.s_dt1.p};
+    backward_map_bwd_chain(c, c->K_p, c->K_g, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, feat, false, &bg);
+    Chain succ;
+    forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, succ);
+    {
+        std::vector<Chain> ch{succ, feat};
+        prog_parallel(prog, ch);
+    }
+    // ---- sf_opt.step() + phi_opt.step() (sf.py:643-653): one pass over forward ++ backward, lr | lr_coef * lr; the EMA of
+    // successor_target_net (sf.py:751-752) rides along like FBDDPGAgent's (nothing reads a target before the next update)
+    POST_BEGIN
+    HIPCK(c, launch_step_advance(w.st, 0, s));
+    const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
+    HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf, hp.grad_scale,
+                             hp.fb_target_tau, w.st, 0, 0, s));
+    POST_END
+    return FBHIP_OK;
+}
+#undef POST_BEGIN
+#undef POST_END
+
 int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s) {
     Program prog;
+    if (c->d.sf) {
+        if (mask != FBHIP_PHASE_ALL) { c->err = g_err = "fbhip: dims.sf runs complete updates only (phase_mask = FBHIP_PHASE_ALL)"; return FBHIP_E_INVALID; }
+        RC(build_update_sf(c, hp, inj, prog));
+        RC(build_update(c, hp, nullptr, FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP, prog));      // sf.py:666-694
+        return run_program(c, prog, s);
+    }
     RC(build_update(c, hp, inj, mask, prog));
     return run_program(c, prog, s);
 }
@@ -1434,6 +1639,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     const int64_t nf = c->L[FBHIP_NET_FORWARD].numel;
     c->F_p = fwd_p(fb_params, c->L[0]); c->F_g = fwd_p(fb_grads, c->L[0]); c->F_t = fwd_p(fb_targets, c->L[0]);
     c->K_p = bwd_p(fb_params + nf, c->L[1]); c->K_g = bwd_p(fb_grads + nf, c->L[1]); c->K_t = bwd_p(fb_targets + nf, c->L[1]);
+    c->I_p = icm_p(fb_params + nf, c->L[1]); c->I_g = icm_p(fb_grads + nf, c->L[1]);
     if (has_actor) { c->A_p = act_p(actor_params, c->L[2]); c->A_g = act_p(actor_grads, c->L[2]); }
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();
@@ -1639,7 +1845,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     // updates/s.  (Zipping the two programs round by round into the SAME launches instead was slower, 933/s: one tile
     // configuration per launch makes the thin GEMMs of one program stragglers of the other's fat ones.)
     static const bool pipelined = [] { const char* e = getenv("FBHIP_UPDATE_PIPELINE"); return !(e && e[0] == '0'); }();
-    const bool pipe = pipelined && n_steps > 1 && !c->d.discrete;   // (no actor phase to overlap with)
+    const bool pipe = pipelined && n_steps > 1 && !c->d.discrete && !c->d.sf;   // (discrete: no actor phase to overlap with)
     if (pipe) {
         if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         while ((int)c->events.size() < 2 * 64) {
@@ -1728,7 +1934,8 @@ int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* r
         {"y", w.bsO.y}, {"tF1", w.fsT.F1}, {"tF2", w.fsT.F2}, {"tB", d.norm_z ? w.bsA.Bm : w.bsA.y}, {"dF1", w.dF1}, {"dF2", w.dF2},
         {"dBm", w.dBm}, {"dy", d.norm_z ? w.dy : w.dBm}, {"mu", w.as.mu}, {"d_premu", w.a_dpremu},
         {"dp", w.dp}, {"dh", w.dh}, {"dt1a", w.dt1a}, {"a_dp", w.a_dp}, {"actor_p", w.as.p}, {"actor_h", w.as.h},
-        {"actor_premu", w.as.premu}, {"online_p", w.fsO.p}, {"online_h", w.fsO.h}};
+        {"actor_premu", w.as.premu}, {"online_p", w.fsO.p}, {"online_h", w.fsO.h},
+        {"phi2", w.bsS.Bm}, {"dphi2", w.dBm2}, {"dy2", w.dy2}};          // SFAgent: [phi(goal) ; phi(next_goal)] and its gradients, 2B rows
     Buf b;
     const std::string n(name);
     if (m.count(n)) b = m[n];

@@ -180,6 +180,19 @@ hipError_t launch_discrete_gather(const float* Fall1, const float* Fall2, int ld
                                   float* out2, int ldo, int rows, int d, int A, hipStream_t s);
 hipError_t launch_discrete_scatter(const float* dF1, const float* dF2, int ldf, const float* act_idx, float* dFall1,
                                    float* dFall2, int ldfa, int rows, int d, int A, hipStream_t s);
+// ---- SFAgent (sf.hip) ------------------------------------------------------------------------------------------------
+// TD regression on successor features (sf.py:594-626): writes dF1, dF2 [rows, d] (ld) and SF_LOSS, SF_TARGET_F, F1, SF_PHI,
+// SF_PHI_NORM, Z_NORM into metrics; scratch >= 6 * ceil(rows / 4) floats
+hipError_t launch_sf_loss(const float* F1, const float* F2, const float* nF1, const float* nF2, const float* phi_next,
+                          const float* z, int ld, const float* discount, int q_loss, float* dF1, float* dF2, float* metrics,
+                          float* scratch, int rows, int d, hipStream_t s);
+// inverse-dynamics loss of the ICM feature learner (sf.py:207-210): pred = tanh(pre), PHI_LOSS = mean((action - pred)^2), d pre
+hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int lda, float* dpre, int ldd, int rows, int a,
+                           float* metrics, hipStream_t s);
+// Laplacian feature learner (sf.py:104-114) on top of pairwise_kernel's orthonormality pass: dphi += d mse, dnext_phi = d mse,
+// PHI_LOSS = mse + metrics[ORTH_LOSS]; scratch >= ceil(rows / 4) floats
+hipError_t launch_lap(const float* phi, const float* next_phi, int ld, float* dphi, float* dnext_phi, float* metrics,
+                      float* scratch, int rows, int d, hipStream_t s);
 hipError_t launch_inverse(const float* A, int lda, int d, float scale, float* out, int ldo, hipStream_t s);
 hipError_t inverse_prepare();
 hipError_t launch_qloss(const float* F1, const float* F2, const float* tF1, const float* tF2, const float* BinvC,
@@ -238,7 +251,7 @@ hipError_t launch_draw(const ReplayView& rv, const SampleOut& so, int B, int d, 
                        hipStream_t s);
 struct GatherArgs {
     ReplayView rv;
-    const int32_t* ep_idx; const int32_t* step_idx; const int32_t* perm;
+    const int32_t* ep_idx; const int32_t* step_idx; const int32_t* perm;      // perm == nullptr: identity
     float* Xoa; int ld_oa;      // [obs | action]
     float* Xoz; int ld_oz;      // [obs | z]          (z filled later)
     float* Xnoz; int ld_noz;    // [next_obs | z]

@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
     if (lane == 0) g.disc[i] = g.gamma * g.rv.discount[t];            // discount * storage['discount'] (:171)
     copy_row(g.next_goal + (size_t)i * g.ld_ng, g.use_goal ? g.rv.goal + t * g.g : nobs, g.g, lane);
     // backward_input[perm] (fb_ddpg.py:460-468): row i of the permuted panel is transition perm[i]
-    const int pi = g.perm[i];
+    const int pi = g.perm != nullptr ? g.perm[i] : i;
     const size_t tp = (size_t)g.ep_idx[pi] * g.rv.t1 + g.step_idx[pi] - 1;
     const float* bsrc = g.use_goal ? g.rv.goal + tp * g.g : g.rv.observation + tp * g.o;
     copy_row(g.bin + (size_t)i * g.ld_bin, bsrc, g.g, lane);

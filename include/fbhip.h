@@ -109,6 +109,16 @@ typedef struct fbhip_dims {
                                     * of the target ForwardMap on next_obs, or with ``boltzmann`` the softmax(next_Q / temp) mix
                                     * (temp: fbhip_set_policy_squash; :289-303); online embedding = the column of the stored action
                                     * (:309-311); q_loss uses that next_Q (:329).  Greedy actions: fbhip_discrete_act */
+    int32_t sf;                    /* 0: FBDDPGAgent.  1 / 2: the sibling SFAgent (url_benchmark/agent/sf.py:383-768) with
+                                    * feature_learner "icm" (1, sf.py:194-213) / "lap" (2, sf.py:100-116).  NET_FORWARD is
+                                    * ``successor_net`` (the same ForwardMap; its target = successor_target_net), NET_BACKWARD is
+                                    * ``feature_learner``: ``feature_net.{0,1,3,5}`` (the BackwardMap architecture, projection
+                                    * included) followed for icm by ``inverse_dynamic_net.{0,2,4}`` = mlp(2 z_dim, Hb, relu, Hb, relu,
+                                    * action_dim, tanh); both optimisers of the reference map onto the two lr groups of the FB
+                                    * flat buffer (sf_opt: lr; phi_opt: lr_coef * lr).  The critic loss is the TD regression of
+                                    * sf.py:594-626 (hparams.q_loss: scalar Q regression (the reference default) or feature space);
+                                    * z is sample_z only (the reference's default mix_ratio = 0; hparams.mix_ratio must be 0);
+                                    * needs norm_z = 1, boltzmann = 0, discrete = 0.  The actor phase is FBDDPGAgent's. */
 } fbhip_dims;
 
 typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82 */
@@ -163,6 +173,8 @@ enum {
     FBHIP_M_ORTH_LOSS_DIAG, FBHIP_M_ORTH_LOSS_OFFDIAG, FBHIP_M_ORTH_LINF, FBHIP_M_ORTH_L2,
     FBHIP_M_ACTOR_LOSS, FBHIP_M_Q, FBHIP_M_ACTOR_LOGPROB,
     FBHIP_M_Q1_SUCCESS,            /* (Q1 > Q2).mean() of update_actor, reported when cfg.additional_metric (fb_ddpg.py:403-404, 417) */
+    /* dims.sf (SFAgent, sf.py:627-636): sf_loss, target_F, phi, phi_norm, phi_loss; F1 and z_norm use the slots above */
+    FBHIP_M_SF_LOSS, FBHIP_M_SF_TARGET_F, FBHIP_M_SF_PHI, FBHIP_M_SF_PHI_NORM, FBHIP_M_PHI_LOSS,
     FBHIP_M_COUNT
 };
 

@@ -386,6 +386,23 @@ def sf_fixture(R):
         print(f"[{name}] sf_loss={[round(m['sf_loss'], 4) for m in meta['metrics']]} phi_loss={[round(m['phi_loss'], 4) for m in meta['metrics']]}")
 
 
+def sf_init_fixture(R):
+    """SFAgent's constructor under torch.manual_seed(1) (sf.py:419-463: actor, successor_net, successor_target_net, then the
+    feature learner, whose ``self.apply(weight_init)`` runs once in FeatureLearner.__init__ and, for icm, AGAIN over every Linear
+    in ICM.__init__) for both feature learners; plus a checkpoint-style pickle is not needed here (reference_io covers the format)."""
+    for learner in ("icm", "lap"):
+        cfg = tiny_cfg(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0)
+        torch.manual_seed(1)
+        agent = R.sf.SFAgent(obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cpu",
+                             num_expl_steps=0, use_tb=True, use_wandb=False, use_hiplog=False, update_encoder=True, goal_space=None,
+                             hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
+                             z_dim=cfg.z_dim, batch_size=cfg.batch_size, feature_learner=learner)
+        arrays = {k: v for k, v in sf_state(agent).items()}
+        arrays["torch_version"] = np.array(torch.__version__)
+        np.savez_compressed(HERE / f"init_seed1_tiny_sf_{learner}.npz", **arrays)
+    print("[sf init] ok")
+
+
 def long_curve_fixtures(R):
     """50 free-running steps at full network dims, metric dict per step + parameter checksums at
     steps {1, 10, 50}: walker B=256; quadruped with goal_space B=256."""
@@ -644,6 +661,7 @@ def main():
     boltzmann_fixture(R)
     discrete_fixture(R)
     sf_fixture(R)
+    sf_init_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -136,8 +136,8 @@ def test_struct_size_guard(lib):
     """a struct built against another header (wrong struct_size) is refused by every entry point that takes it"""
     l = lib.load()
     d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1, 1)
-    assert d.struct_size == C.sizeof(lib.Dims) == 15 * 4
-    d.struct_size -= 4                                   # what an ABI-12 era binding (no ``discrete``) would have passed
+    assert d.struct_size == C.sizeof(lib.Dims) == 16 * 4
+    d.struct_size -= 4                                   # what a binding written against an older header (a field short) passes
     assert l.fbhip_net_numel(C.byref(d), 0) < 0 and b"struct_size" in l.fbhip_last_error(None)
     ctx = C.c_void_p()
     assert l.fbhip_create(C.byref(d), C.byref(ctx)) == -1
@@ -203,3 +203,26 @@ def test_integration_doc_structs_match_the_header(lib):
         h = header_fields(struct)
         assert h == [n for n, _ in ct._fields_], f"_lib.{cls} out of sync with include/fbhip.h"
         assert doc_fields(cls) == h, f"INTEGRATION.md {cls} out of sync with include/fbhip.h"
+
+
+def test_sf_layout_follows_the_reference_modules(lib):
+    """dims.sf (sf.py:84-88, 194-200): NET_BACKWARD is feature_learner -- feature_net.{0,1,3,5} and, for icm, the
+    inverse_dynamic_net mlp(2 z, Hb, relu, Hb, relu, a, tanh) at Sequential indices 0, 2, 4 -- in state_dict() order"""
+    l = lib.load()
+    def names(sf):
+        d = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 0, 0, sf)
+        out = []
+        for i in range(l.fbhip_layout_count(C.byref(d), lib.NET_BACKWARD)):
+            t = lib.TensorDesc()
+            assert l.fbhip_layout_entry(C.byref(d), lib.NET_BACKWARD, i, C.byref(t)) == 0
+            out.append((t.name.decode(), t.rows, t.cols))
+        return out
+    feat = [("feature_net.0.weight", 20, 5), ("feature_net.0.bias", 1, 20), ("feature_net.1.weight", 1, 20), ("feature_net.1.bias", 1, 20),
+            ("feature_net.3.weight", 20, 20), ("feature_net.3.bias", 1, 20), ("feature_net.5.weight", 10, 20), ("feature_net.5.bias", 1, 10)]
+    assert names(2) == feat
+    assert names(1) == feat + [("inverse_dynamic_net.0.weight", 20, 20), ("inverse_dynamic_net.0.bias", 1, 20),
+                               ("inverse_dynamic_net.2.weight", 20, 20), ("inverse_dynamic_net.2.bias", 1, 20),
+                               ("inverse_dynamic_net.4.weight", 3, 20), ("inverse_dynamic_net.4.bias", 1, 3)]
+    assert names(0)[0][0] == "B.0.weight"
+    bad = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 1, 0, 1)          # boltzmann + sf
+    assert l.fbhip_net_numel(C.byref(bad), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)
