@@ -1452,7 +1452,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         feat.push_back([=, &w](Ops& o2) {
             o2.gemms.push_back(P(w.ih2.p, Lb, 1, I.W3, Lb, 1, w.ipre.p, La, B, a, Lb, I.b3, EPI_BIAS));
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_icm_loss(w.ipre.p, La, w.Xoa.p + aoff, w.Xoa.ld, w.d_ipre.p, La, B, a, w.metrics, q));
+                HIPCK(c, launch_icm_loss(w.ipre.p, La, w.Xoa.p + aoff, w.Xoa.ld, w.d_ipre.p, La, B, a, w.metrics, w.pw_scratch, q));
                 return (int)FBHIP_OK;
             });
         });

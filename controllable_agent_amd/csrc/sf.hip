@@ -106,25 +106,34 @@ __global__ void __launch_bounds__(64) sf_loss_finalize_kernel(const float* __res
     }
 }
 
-// one workgroup, fixed order: the [rows, a] error of the inverse-dynamics head is a few thousand elements
+// one thread per element of the [rows, a] inverse-dynamics output; per-workgroup partial sums folded in a fixed order
 __global__ void __launch_bounds__(256) icm_loss_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ action,
                                                        int lda, float* __restrict__ dpre, int ldd, int rows, int a,
-                                                       float* __restrict__ metrics) {
-    __shared__ double red[4];
+                                                       float* __restrict__ part) {
+    __shared__ float red[4];
     const float sc = 2.f / ((float)rows * (float)a);
-    double s = 0.0;
-    for (int e = threadIdx.x; e < rows * a; e += 256) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    float sq = 0.f;
+    if (e < rows * a) {
         const int r = e / a, j = e - r * a;
         const float pred = tanhf(pre[(size_t)r * ldp + j]);
         const float err = action[(size_t)r * lda + j] - pred;
         dpre[(size_t)r * ldd + j] = -sc * err * (1.f - pred * pred);
-        s += (double)err * (double)err;
+        sq = err * err;
     }
+    sq = wsum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(64) icm_loss_finalize_kernel(const float* __restrict__ part, int nblk, int rows, int a,
+                                                               float* __restrict__ metrics) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[b];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) metrics[FBHIP_M_PHI_LOSS] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / ((double)rows * (double)a));
+    if (threadIdx.x == 0) metrics[FBHIP_M_PHI_LOSS] = (float)(s / ((double)rows * (double)a));
 }
 
 // d phi += 2 (phi - next_phi) / (rows d);  d next_phi = -2 (phi - next_phi) / (rows d);  partial sums of the squared difference
@@ -175,8 +184,12 @@ hipError_t launch_sf_loss(const float* F1, const float* F2, const float* nF1, co
 }
 
 hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int lda, float* dpre, int ldd, int rows, int a,
-                           float* metrics, hipStream_t s) {
-    hipLaunchKernelGGL(icm_loss_kernel, dim3(1), dim3(256), 0, s, pre, ldp, action, lda, dpre, ldd, rows, a, metrics);
+                           float* metrics, float* scratch, hipStream_t s) {
+    const int nblk = (rows * a + 255) / 256;
+    hipLaunchKernelGGL(icm_loss_kernel, dim3(nblk), dim3(256), 0, s, pre, ldp, action, lda, dpre, ldd, rows, a, scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(icm_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, a, metrics);
     return hipGetLastError();
 }
 

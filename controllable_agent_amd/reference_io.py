@@ -60,24 +60,30 @@ class ReferenceObject:
     def _is_module(self) -> bool:
         return "_parameters" in self.__dict__ and "_modules" in self.__dict__
 
-    def state_dict(self, prefix: str = "") -> "collections.OrderedDict[str, torch.Tensor]":
+    def state_dict(self, *args: tp.Any, destination: tp.Any = None, prefix: str = "", keep_vars: bool = False
+                   ) -> "collections.OrderedDict[str, torch.Tensor]":
+        """nn.Module.state_dict's signature: a placeholder can sit INSIDE a real torch container (sf.py's ``_L2`` projection is the
+        last module of an ``nn.Sequential``), whose own state_dict() then calls this with ``destination`` / ``prefix``."""
+        if args:                                                     # legacy positional (destination, prefix, keep_vars)
+            destination = args[0]
+            prefix = args[1] if len(args) > 1 else prefix
         if not self._is_module():
             raise AttributeError(f"{self!r} was not an nn.Module")
-        out: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
+        out: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict() if destination is None else destination
         for name, p in self.__dict__["_parameters"].items():
             if p is not None:
-                out[prefix + name] = p.detach()
+                out[prefix + name] = p if keep_vars else p.detach()
         skip = self.__dict__.get("_non_persistent_buffers_set", set())
         for name, b in self.__dict__.get("_buffers", {}).items():
             if b is not None and name not in skip:
-                out[prefix + name] = b.detach()
+                out[prefix + name] = b if keep_vars else b.detach()
         for name, m in self.__dict__["_modules"].items():
             if m is None:
                 continue
             if isinstance(m, ReferenceObject):
-                out.update(m.state_dict(prefix + name + "."))
+                m.state_dict(destination=out, prefix=prefix + name + ".", keep_vars=keep_vars)
             else:
-                out.update(m.state_dict(prefix=prefix + name + "."))
+                m.state_dict(destination=out, prefix=prefix + name + ".", keep_vars=keep_vars)
         return out
 
     def parameters(self) -> tp.Iterator[torch.Tensor]:

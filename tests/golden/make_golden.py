@@ -401,6 +401,35 @@ def sf_init_fixture(R):
         arrays["torch_version"] = np.array(torch.__version__)
         np.savez_compressed(HERE / f"init_seed1_tiny_sf_{learner}.npz", **arrays)
     print("[sf init] ok")
+    # a checkpoint written by the reference holding a live SFAgent (icm) after two updates (pretrain.py:437-449)
+    cfg = tiny_cfg(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0)
+    from oracle import sf_oracle as so
+    rng = np.random.default_rng(34)
+    shapes = so.net_shapes(cfg, "icm")
+    nets = {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg.obs_dim, cfg.action_dim, None, None)
+    agent = R.sf.SFAgent(obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cpu", num_expl_steps=0,
+                         use_tb=True, use_wandb=False, use_hiplog=False, update_encoder=True, goal_space=None, lr=cfg.lr,
+                         lr_coef=cfg.lr_coef, hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim,
+                         feature_dim=cfg.feature_dim, z_dim=cfg.z_dim, batch_size=cfg.batch_size, feature_learner="icm",
+                         update_every_steps=1)
+    for n in nets:
+        getattr(agent, n).load_state_dict(nets[n])
+    agent.successor_target_net.load_state_dict(agent.successor_net.state_dict())
+    rb = fill_ref_buffer(R, storage, lengths, cfg.discount)
+    for s_ in range(2):
+        with inject(R, fo.make_draws(rng, cfg, 6, lengths), False, 0.0):
+            agent.update(rb, s_)
+    with (HERE / "ref_checkpoint_tiny_sf.pt").open("wb") as f:
+        torch.save({"agent": agent, "global_step": 2, "global_episode": 1, "replay_loader": rb}, f, pickle_protocol=4)
+    obs = rng.standard_normal((5, cfg.obs_dim)).astype(np.float32)
+    zs = fo.sample_z_from_gauss(torch.from_numpy(rng.standard_normal((5, cfg.z_dim)).astype(np.float32)), cfg.z_dim).numpy()
+    with torch.no_grad():
+        acts = np.stack([agent.act(obs[i], {"z": zs[i]}, 0, eval_mode=True) for i in range(5)])
+    arrays = {f"state/{k}": v for k, v in sf_state(agent).items()}
+    arrays.update(obs=obs, z=zs, act_eval=acts)
+    np.savez_compressed(HERE / "ref_checkpoint_sf_expect.npz", **arrays)
+    print("[sf checkpoint] ok")
 
 
 def long_curve_fixtures(R):

@@ -266,3 +266,21 @@ def test_load_npz_directory_and_relabel(tmp_path):
     want = np.stack([eps[e]["physics"][:, :1] * 2 + 1 for e in range(3)]).astype(np.float32)
     np.testing.assert_array_equal(rb._storage["reward"].numpy(), want)
     assert rb._max_episodes == 3 and rb._full
+
+
+def test_reference_sf_checkpoint_reads_without_the_reference():
+    """the second sibling's checkpoint (a pickled ``sf.SFAgent``) through the same reader"""
+    from controllable_agent_amd import reference_io as rio
+    payload = rio.load_reference_payload(H.GOLDEN / "ref_checkpoint_tiny_sf.pt")
+    exp = np.load(H.GOLDEN / "ref_checkpoint_sf_expect.npz")
+    agent = payload["agent"]
+    assert isinstance(agent, rio.ReferenceObject) and agent._ref_name == "SFAgent"
+    fields = rio.reference_agent_config(agent)
+    assert fields["name"] == "sf" and fields["feature_learner"] == "icm" and fields["q_loss"] is True and fields["obs_shape"] == (5,)
+    for net in ("actor", "successor_net", "successor_target_net", "feature_learner"):
+        sd = getattr(agent, net).state_dict()
+        assert list(sd) == [k.split("/", 2)[2] for k in exp.files if k.startswith(f"state/{net}/")]
+        for k, v in sd.items():
+            np.testing.assert_array_equal(v.numpy(), exp[f"state/{net}/{k}"], err_msg=f"{net}/{k}")
+    assert "inverse_dynamic_net.4.bias" in agent.feature_learner.state_dict()
+    assert len(agent.phi_opt.state_dict()["state"]) == 14 and len(agent.sf_opt.state_dict()["state"]) == 20

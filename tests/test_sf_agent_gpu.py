@@ -199,3 +199,23 @@ def test_sf_unsupported_options_fail_loudly():
     for bad in (dict(feature_learner="contrastive"), dict(mix_ratio=0.3), dict(boltzmann=True), dict(num_sf_updates=2)):
         with pytest.raises(NotImplementedError):
             SFHipAgent(**{**base, **bad})
+
+
+def test_sf_agent_from_reference_checkpoint_file():
+    """a checkpoint written by the REAL reference holding a live SFAgent (pretrain.py:437-449) -> SFHipAgent.from_reference_checkpoint
+    without the reference installed: nets, target, Adam moments, step counts, and the same greedy actions"""
+    from controllable_agent_amd.agent import SFHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    exp = np.load(H.GOLDEN / "ref_checkpoint_sf_expect.npz")
+    agent = SFHipAgent.from_reference_checkpoint(H.GOLDEN / "ref_checkpoint_tiny_sf.pt", device="cuda")
+    assert agent.cfg.feature_learner == "icm" and agent.cfg.z_dim == 10 and agent.cfg.lr_coef == 5.0
+    got = get_sf_state(agent)
+    for k in exp.files:
+        if k.startswith("state/"):
+            np.testing.assert_array_equal(got[k[len("state/"):]], exp[k], err_msg=k)
+    assert agent.step_counts() == (2, 2)
+    acts = np.stack([agent.act(exp["obs"][i], {"z": exp["z"][i]}, 0, eval_mode=True) for i in range(5)])
+    np.testing.assert_allclose(acts, exp["act_eval"], rtol=2e-5, atol=2e-6)
+    rb = DeviceReplayBuffer.from_reference_file(H.GOLDEN / "ref_checkpoint_tiny_sf.pt", device="cuda")
+    m = agent.update(rb, 2)
+    assert np.isfinite(m["sf_loss"]) and np.isfinite(m["phi_loss"]) and agent.step_counts() == (3, 3)
