@@ -177,6 +177,10 @@ def main():
                     help="with ONE rank under torch.distributed.run: still create the nccl (RCCL) process group, so that together "
                          "with FBHIP_FORCE_PHASE_SPLIT=1 the data-parallel schedule issues its real RCCL all-reduces (on one "
                          "rank): a kept execution of the RCCL code path on a 1-GPU box")
+    ap.add_argument("--peer-allreduce", action="store_true",
+                    help="N > 1: the gradient all-reduces as kernels INSIDE each rank's update graph (peers' buckets mapped with hipIpc, "
+                         "csrc/peer.hip; FBHIP_DP_ALLREDUCE=peer) instead of RCCL calls between three phase graphs: one graph launch "
+                         "per rank per --steps-per-launch updates.  Single node only")
     ap.add_argument("--global-batch", action="store_true",
                     help="data-parallel mode B (FBHipAgent(dp_global_batch=True)): the exact loss of the concatenated "
                          "world x batch rows (one embedding all-gather per step) instead of per-rank blocks with gradient "
@@ -215,6 +219,8 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
+    if args.peer_allreduce:
+        os.environ["FBHIP_DP_ALLREDUCE"] = "peer"
     if args.pretend_world > 1:
         os.environ["FBHIP_PRETEND_WORLD"] = str(args.pretend_world)
     from controllable_agent_amd.agent import FBHipAgent
@@ -257,13 +263,14 @@ def main():
         sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
         for sz in sorted(sizes):
             run(args.warmup, sz)
-        walls, events = [], []
+        walls, events, host_enqueue = [], [], []
         for rep in range(max(1, args.repeats)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             barrier()
             t0 = time.perf_counter()
             e0.record(bench_stream)
             run(args.warmup + rep * args.steps, args.steps)
+            host_enqueue.append(time.perf_counter() - t0)         # the host's share: every launch of the region is enqueued by now
             e1.record(bench_stream)
             barrier()
             wall = time.perf_counter() - t0
@@ -326,6 +333,9 @@ def main():
                                     "synthetic replay resident in HBM; metrics off"),
                        "steps_per_graph_launch": spl, **({"dp_loss": "global batch (mode B)" + (f", pretend world {args.pretend_world}" if args.pretend_world > 1 else "")} if args.global_batch else {}),
                        "global_batch": W["batch_size"] * world, "parallelism": f"dp{world}",
+                       **({"allreduce": "peer-access kernels inside the update graph (csrc/peer.hip)" if args.peer_allreduce else
+                           ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "RCCL via torch.distributed between phase graphs")} if world > 1 else {}),
+                       "host_enqueue_ms_per_step": 1e3 * host_enqueue[mid] / args.steps,
                        "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s,
                        **({"single_update_steps_per_s": single} if single is not None else {})},
             "repeats": {"n": len(walls), "steps_each": args.steps, "reported": "median by wall time",

@@ -83,6 +83,10 @@ PROTOTYPES = {
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
     "fbhip_update_many": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_update_many_injected": (C.c_int, [_P, _P, _I, _P, _P]),
+    "fbhip_dp_bind_peers": (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
+    "fbhip_peer_allreduce": (C.c_int, [_P, _I, _P]),
+    "fbhip_update_many_dp": (C.c_int, [_P, _P, _I, _P]),
+    "fbhip_dp_status": (C.c_int, [_P, C.POINTER(_I), _P]),
     "fbhip_select_workspace_set": (C.c_int, [_P, _I]),
     "fbhip_fb_early_grad_range": (C.c_int, [C.POINTER(Dims), C.POINTER(_L), C.POINTER(_L)]),
     "fbhip_embeddings_floats": (_Z, [C.POINTER(Dims)]),

@@ -866,6 +866,14 @@ class FBHipAgent:
         c = self.cfg
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
         if isinstance(replay_loader, DeviceReplayBuffer):
+            from . import peer
+            if self._world() > 1 and peer.enabled() and not c.dp_global_batch and self._use_graph and self._stddev_is_constant():
+                self._bind_replay(replay_loader)
+                self._verify_replicas()
+                peer.bind(self)
+                hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
+                self._on_update_stream(lambda: check(_lib.load().fbhip_update_many_dp(self._ctx, C.byref(hp), 1, stream_ptr()), self._ctx))
+                return self._metrics()
             self._bind_replay(replay_loader)
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
             # a captured graph bakes stddev in: with a time-varying stddev_schedule (utils.py:235-255) every step would be a
@@ -894,6 +902,21 @@ class FBHipAgent:
             for i in range(n_steps):
                 out = self.update(replay_loader, step + i)
             return out
+        from . import peer
+        if split and self._world() > 1 and peer.enabled():
+            # data parallel without host-issued collectives: the peers' gradient buckets are mapped into this process and the
+            # all-reduces are kernels INSIDE the n-step graph (csrc/peer.hip): one graph launch per rank per call
+            want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+            self._bind_replay(replay_loader)
+            self._verify_replicas()
+            peer.bind(self)
+            hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
+            done = 0
+            while done < n_steps:
+                n = min(64, n_steps - done)
+                self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many_dp(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
+                done += n
+            return self._metrics()
         if split:
             # data parallel: the steps are pipelined around the gradient all-reduces (distributed.dp_update_many)
             from .distributed import dp_update_many

@@ -455,6 +455,7 @@ struct fbhip_ctx {
     const float* gb_panels = nullptr;        // global-batch data parallel (fbhip_bind_global_batch): [6][gb_rows][Lz]
     const float* gb_discount = nullptr;      //   F1, F2, B, tF1, tF2, tB of ALL ranks' rows, and their discounts [gb_rows]
     int gb_rows = 0, gb_off = 0;             //   this rank owns rows [gb_off, gb_off + batch)
+    PeerComm peers{};                        // fbhip_dp_bind_peers (world >= 2: bound)
     Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
     std::function<int(const PolicyHeadJobs&, hipStream_t)> run_policy_heads;   // set by the update that declares Ops::ph
     ColReduceJobs cr_pending{};              // LayerNorm column reduces waiting for the next split-K reduce launch (flush_round)
@@ -1821,14 +1822,16 @@ int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
     return FBHIP_OK;
 }
 
+constexpr int DP_GRAPH_BIT = 1 << 20;         // graph-cache key: the data-parallel variant of an n-step graph
 // injs: NULL (device-drawn batches) or n_steps inject structs, one per step (parity runs through the pipelined graph)
-static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injs, void* stream) {
+static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injs, void* stream,
+                            bool dp = false) {
     RC(need_bound(c, true));
     RC(check_hparams(c, hp));
     if (n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     for (auto& g : c->graphs) {
-        if (g.n_steps == n_steps && g.set == c->cur && g.mask == FBHIP_PHASE_ALL && g.has_inj == (injs != nullptr) &&
+        if (g.n_steps == n_steps && g.set == c->cur && g.mask == (FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0)) && g.has_inj == (injs != nullptr) &&
             (!injs || memcmp(&g.inj, injs, sizeof(*injs)) == 0) && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {
             HIPCK(c, hipGraphLaunch(g.exec, s));
             return FBHIP_OK;
@@ -1858,7 +1861,51 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = FBHIP_OK;
     hipError_t he = hipSuccess;
-    if (!pipe) {
+    const bool has_actor = !c->d.discrete;
+    const int64_t n_fb = c->L[FBHIP_NET_FORWARD].numel + c->L[FBHIP_NET_BACKWARD].numel, n_ac = c->L[FBHIP_NET_ACTOR].numel;
+    auto allreduce = [&](int which) -> int {                     // the peers' gradients, summed in place (peer.hip)
+        HIPCK(c, launch_peer_allreduce(c->peers, which, which == 0 ? n_fb : n_ac, s));
+        return (int)FBHIP_OK;
+    };
+    if (dp && !pipe) {
+        for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) {
+            rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_GRAD | FBHIP_PHASE_ACTOR_FWD, s);
+            if (rc == FBHIP_OK) rc = allreduce(0);
+            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_FB_STEP | FBHIP_PHASE_ACTOR_GRAD, s);
+            if (rc == FBHIP_OK && has_actor) rc = allreduce(1);
+            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_STEP, s);
+        }
+    } else if (dp) {
+        // the single-rank pipeline below with the optimiser steps cut off their phases and the two all-reduces in the cuts:
+        //   [target chain | FB backward | actor fwd] -> AR(fb) -> FB step -> fork [next head] || [actor grad -> AR(actor) -> actor step] -> join
+        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
+        const int cur0 = c->cur;
+        rc = enqueue_update(c, *hp, nullptr, HEAD, s);
+        for (int i = 0; i < n_steps && rc == FBHIP_OK && he == hipSuccess; ++i) {
+            rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD, s);
+            if (rc == FBHIP_OK) rc = allreduce(0);
+            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_FB_STEP, s);
+            if (rc != FBHIP_OK) break;
+            const bool more = i + 1 < n_steps;
+            if (more) {
+                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
+                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
+                c->cur ^= 1;
+                rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
+                c->cur ^= 1;
+                if (rc != FBHIP_OK) break;
+            }
+            rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_GRAD, s);
+            if (rc == FBHIP_OK) rc = allreduce(1);
+            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_STEP, s);
+            if (more) {
+                if ((he = hipEventRecord(c->events[2 * i + 1], c->side)) != hipSuccess) break;
+                if ((he = hipStreamWaitEvent(s, c->events[2 * i + 1], 0)) != hipSuccess) break;
+                c->cur ^= 1;
+            }
+        }
+        c->cur = cur0;
+    } else if (!pipe) {
         for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, injs ? &injs[i] : nullptr, FBHIP_PHASE_ALL, s);
     } else {
         const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
@@ -1892,7 +1939,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     if (he != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCK(c, he); }
     HIPCK(c, e);
     GraphEntry ge{};
-    ge.mask = FBHIP_PHASE_ALL; ge.hp = *hp; ge.has_inj = injs != nullptr; ge.n_steps = n_steps; ge.set = c->cur;
+    ge.mask = FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0); ge.hp = *hp; ge.has_inj = injs != nullptr; ge.n_steps = n_steps; ge.set = c->cur;
     if (injs) ge.inj = injs[0];              // (cache key: a caller that reuses its per-step buffers replays the same graph)
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -1905,6 +1952,59 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
 
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
     return update_many_impl(c, hp, n_steps, nullptr, stream);
+}
+
+int fbhip_dp_bind_peers(fbhip_ctx* c, int32_t world, int32_t rank, float* const* fb_grad_ptrs, float* const* actor_grad_ptrs,
+                        int32_t* const* flag_ptrs, int32_t* local_state) {
+    RC(need_bound(c, false));
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);            // the pointers are baked into captured launches
+    c->graphs.clear();
+    if (world <= 1) { c->peers = PeerComm{}; return FBHIP_OK; }
+    const bool has_actor = c->d.discrete == 0;
+    if (world > PEER_MAX_WORLD || rank < 0 || rank >= world || !fb_grad_ptrs || !flag_ptrs || !local_state || (has_actor && !actor_grad_ptrs)) {
+        c->err = g_err = "fbhip_dp_bind_peers: bad argument (world <= 8, 0 <= rank < world, non-null pointer tables)"; return FBHIP_E_INVALID;
+    }
+    if (c->d.sf) { c->err = g_err = "fbhip_dp_bind_peers: dims.sf runs on a single rank"; return FBHIP_E_INVALID; }
+    PeerComm pc{};
+    pc.world = world; pc.rank = rank; pc.state = (PeerState*)local_state;
+    for (int q = 0; q < world; ++q) {
+        pc.bucket[0][q] = fb_grad_ptrs[q]; pc.bucket[1][q] = has_actor ? actor_grad_ptrs[q] : nullptr; pc.flags[q] = flag_ptrs[q];
+        if (!pc.bucket[0][q] || !pc.flags[q] || (has_actor && !pc.bucket[1][q]) || ((uintptr_t)pc.bucket[0][q] & 15) || ((uintptr_t)pc.bucket[1][q] & 15)) {
+            c->err = g_err = "fbhip_dp_bind_peers: null / unaligned peer pointer"; return FBHIP_E_INVALID;
+        }
+    }
+    if (pc.bucket[0][rank] != c->fb_g || (has_actor && pc.bucket[1][rank] != c->a_g)) {
+        c->err = g_err = "fbhip_dp_bind_peers: entry [rank] must be this context's own gradient buffers"; return FBHIP_E_INVALID;
+    }
+    c->peers = pc;
+    return FBHIP_OK;
+}
+
+int fbhip_peer_allreduce(fbhip_ctx* c, int32_t which, void* stream) {
+    RC(need_bound(c, false));
+    if (c->peers.world < 2) { c->err = g_err = "fbhip_peer_allreduce: no peers bound (fbhip_dp_bind_peers)"; return FBHIP_E_STATE; }
+    if (which < 0 || which > 1 || (which == 1 && c->d.discrete)) return FBHIP_E_INVALID;
+    const int64_t n = which == 0 ? c->L[FBHIP_NET_FORWARD].numel + c->L[FBHIP_NET_BACKWARD].numel : c->L[FBHIP_NET_ACTOR].numel;
+    HIPCK(c, launch_peer_allreduce(c->peers, which, n, (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_update_many_dp(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
+    RC(need_bound(c, true));
+    if (c->peers.world < 2) { c->err = g_err = "fbhip_update_many_dp: no peers bound (fbhip_dp_bind_peers)"; return FBHIP_E_STATE; }
+    return update_many_impl(c, hp, n_steps, nullptr, stream, /*dp=*/true);
+}
+
+int fbhip_dp_status(fbhip_ctx* c, int32_t* host_status, void* stream) {
+    RC(need_bound(c, false));
+    if (!host_status) return FBHIP_E_INVALID;
+    *host_status = 0;
+    if (c->peers.world < 2) return FBHIP_OK;
+    PeerState h{};
+    HIPCK(c, hipMemcpyAsync(&h, c->peers.state, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCK(c, hipStreamSynchronize((hipStream_t)stream));
+    *host_status = h.status;
+    return FBHIP_OK;
 }
 
 int fbhip_update_many_injected(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injects, void* stream) {

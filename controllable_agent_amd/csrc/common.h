@@ -222,6 +222,18 @@ hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* 
                            float lr, float lr2, int64_t split, float grad_scale, float tau,
                            const StepState* st, int which, int t_explicit, hipStream_t s);
 
+// ---- peer-access all-reduce (peer.hip): the data-parallel gradient exchange as graph-capturable kernels -------------------
+constexpr int PEER_MAX_WORLD = 8;
+constexpr int PEER_TIMEOUT = 1;
+struct PeerState { int epoch[3]; int status; };             // device-resident, this rank's (zero-initialised by the host)
+struct PeerComm {
+    int world, rank;
+    float* bucket[2][PEER_MAX_WORLD];                       // [fb | actor][rank]: every rank's gradient bucket, mapped into this process
+    int* flags[PEER_MAX_WORLD];                             // [rank]: int32[3][PEER_MAX_WORLD] barrier slots of every rank
+    PeerState* state;
+};
+hipError_t launch_peer_allreduce(const PeerComm& pc, int which, int64_t numel, hipStream_t s);
+
 // ---- batch-1 inference (infer.hip) -----------------------------------------------------------------------------
 // y[n] = (relu)( W[n, :K] . f(x) + bias[n] ), f = identity or tanh(LayerNorm(x[:n_ln])) (entries >= n_ln read as 0)
 struct GemvProblem { const float* x; const float* W; const float* bias; float* y; const float* ln_g; const float* ln_b;

@@ -245,6 +245,24 @@ int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, 
  * caller that refills the same per-step device buffers replays it. */
 int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injects,
                                void* stream);
+/* ---- data parallel on ONE node without host-issued collectives (SURVEY section 8e fallback; RCCL through torch.distributed
+ * stays the default transport).  The host maps every peer's gradient buckets and barrier-flag arrays into this process (hipIpc,
+ * e.g. torch.multiprocessing.reductions.reduce_tensor handles exchanged through the process group) and binds the pointers:
+ *   fb_grad_ptrs[q] / actor_grad_ptrs[q]: rank q's FB / actor gradient bucket (index ``rank`` = this rank's own buffers, as bound
+ *   by fbhip_bind_buffers; actor pointers ignored for dims.discrete); flag_ptrs[q]: rank q's int32[3 * 8] flag array;
+ *   local_state: this rank's int32[4] (epochs + status).  Flags and state must be ZERO-initialised device memory that lives as
+ * long as the context uses them.  world <= 8; world == 1 unbinds.
+ * fbhip_peer_allreduce enqueues a sum-all-reduce of one bucket (which: 0 FB, 1 actor) as three kernels -- reduce-scatter,
+ * all-gather, release, each behind a flag barrier across the ranks -- on ``stream``; capturable; deterministic; every rank must
+ * enqueue the same sequence.  fbhip_update_many_dp is fbhip_update_many for a bound rank: n_steps complete data-parallel updates
+ * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph, the
+ * next step's SAMPLE | FB_FWD_ONLINE on the second branch beside the actor phase and its all-reduce.  fbhip_dp_status blocks and
+ * returns the status word (0 ok, 1 = a peer did not arrive within the spin limit: results of that step are garbage, nothing hangs). */
+int fbhip_dp_bind_peers(fbhip_ctx* ctx, int32_t world, int32_t rank, float* const* fb_grad_ptrs, float* const* actor_grad_ptrs,
+                        int32_t* const* flag_ptrs, int32_t* local_state);
+int fbhip_peer_allreduce(fbhip_ctx* ctx, int32_t which, void* stream);
+int fbhip_update_many_dp(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
+int fbhip_dp_status(fbhip_ctx* ctx, int32_t* host_status, void* stream);
 /* The workspace holds two complete per-step sets (fbhip_update_many alternates them).  A host that pipelines steps itself
  * (data parallel: the next step's SAMPLE | FB_FWD_ONLINE under this step's actor all-reduce) selects the set the following
  * fbhip_update calls work on; phases of one step must all run on the same set.  Default 0. */

@@ -310,3 +310,72 @@ def test_bench_two_rank_rehearsal_at_walker_dims_keeps_replicas_identical():
     assert res["n_gpus"] == 2 and res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 2048
     assert res["replicas"]["identical"] is True and res["replicas"]["ranks"] == 2
     assert res["replicas"]["adam_steps"][0] >= 64 + 8 and res["value"] > 0 and "REHEARSAL" in res["data"]
+
+
+# ------------------------------------------------------------------------------------------ peer-access all-reduce (in-graph)
+def _worker_peer(rank, port, out_q, mode):
+    """``mode`` "peer": FBHIP_DP_ALLREDUCE=peer -- the ranks map each other's gradient buckets (hipIpc) and every data-parallel
+    step is ONE graph launch per rank with the all-reduce kernels inside (csrc/peer.hip);  "host": the default schedule with
+    torch.distributed (gloo here) between the phase graphs.  Same seeds, same shards, device-drawn batches."""
+    import torch.distributed as dist
+    from controllable_agent_amd import peer
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_DP_ALLREDUCE="peer" if mode == "peer" else "rccl",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    cfg, nets, storage, lengths = T._setup()
+    torch.manual_seed(4321)                   # the agent's device RNG key is torch.initial_seed(): same batches in both modes
+    agent = H.make_hip_agent(cfg, nets, metrics=False)
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    agent.update(rb, 0)                       # one single step (n = 1 graph) ...
+    agent.update_many(rb, 1, 5)               # ... then five pipelined ones in one launch, twice (graph replay)
+    agent.update_many(rb, 6, 5)
+    torch.cuda.synchronize()
+    st = peer.status(agent) if mode == "peer" else 0
+    # the raw primitive on a known pattern: bucket value = rank + 1 everywhere -> sum = W (W + 1) / 2 on every rank
+    summed = None
+    if mode == "peer":
+        agent._fb_grads.fill_(float(rank + 1))
+        torch.cuda.synchronize()
+        dist.barrier()
+        from controllable_agent_amd import _lib
+        _lib.check(_lib.load().fbhip_peer_allreduce(agent._ctx, 0, _lib.stream_ptr()), agent._ctx)
+        torch.cuda.synchronize()
+        summed = (float(agent._fb_grads.min()), float(agent._fb_grads.max()), peer.status(agent))
+    out_q.put((rank, H.get_agent_state(agent), agent.step_counts(), st, summed))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_peer(mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_worker_peer, args=(r, port, q, mode)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(T.WORLD)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_peer_allreduce_inside_the_graph_equals_the_host_schedule():
+    """two REAL ranks on one GPU: the in-graph peer all-reduce (one graph launch per rank per call) leaves the replicas
+    bit-identical to each other, never times out, sums a known pattern exactly, and lands where the host-issued schedule lands
+    (the two schedules group a few launches differently: fp32 summation order at most)"""
+    peer_res, host_res = _run_peer("peer"), _run_peer("host")
+    for res in (peer_res, host_res):
+        assert res[0][2] == res[1][2] == (11, 11)
+        for k in res[0][1]:
+            np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)                 # replicas identical
+    assert all(r[3] == 0 for r in peer_res), "a peer barrier timed out"
+    want = float(sum(range(1, T.WORLD + 1)))
+    assert all(r[4] == (want, want, 0) for r in peer_res), [r[4] for r in peer_res]
+    for k, v in host_res[0][1].items():
+        if k.startswith("adam_"):
+            assert H.rel_err(peer_res[0][1][k], v) < 2e-3, k
+        else:
+            np.testing.assert_allclose(peer_res[0][1][k], v, rtol=0, atol=2e-5, err_msg=k)
