@@ -280,6 +280,15 @@ def main():
                 wall = float(t.item())
             walls.append(wall)
             events.append(e0.elapsed_time(e1) * 1e-3)
+        # the host's own cost of a data-parallel step: one update_many call into an EMPTY queue returns as soon as its launches
+        # (and, on the RCCL / gloo path, its collectives) are issued
+        host_idle = None
+        if world > 1 and spl > 1:
+            barrier()
+            th = time.perf_counter()
+            run(0, spl)
+            host_idle = (time.perf_counter() - th) / spl
+            barrier()
         order = sorted(range(len(walls)), key=lambda i: walls[i])
         mid = order[len(order) // 2]
         dt = walls[mid]                                   # the median repeat IS one contiguous region of exactly --steps updates
@@ -336,6 +345,7 @@ def main():
                        **({"allreduce": "peer-access kernels inside the update graph (csrc/peer.hip)" if args.peer_allreduce else
                            ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "RCCL via torch.distributed between phase graphs")} if world > 1 else {}),
                        "host_enqueue_ms_per_step": 1e3 * host_enqueue[mid] / args.steps,
+                       **({"host_issue_ms_per_step_idle_queue": 1e3 * host_idle} if host_idle is not None else {}),
                        "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s,
                        **({"single_update_steps_per_s": single} if single is not None else {})},
             "repeats": {"n": len(walls), "steps_each": args.steps, "reported": "median by wall time",

@@ -41,8 +41,8 @@ struct GemmGroup {
 };
 
 // tile configurations: <waves along M, waves along N, waves along K>, each wave owns one 32x32 MFMA tile
-enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4x1x1 = 4, CFG_DMA128 = 5, CFG_DMA64 = 6,
-               CFG_COUNT };   // the last two: LDS-DMA kernels (128x64 / 64x64 tiles), need gemm_problem_dma_ok()
+enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4x1x1 = 4, CFG_DMA128 = 5,
+               CFG_COUNT };   // the last: the LDS-DMA kernel (128x64 tiles), needs gemm_problem_dma_ok()
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
 // LayerNorm-backward column reduces (d gamma, d beta = sums of per-block partials) that ride in a split-K reduce launch instead

@@ -136,13 +136,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx
 // registers -> LDS staging of the next K chunks, prefetch distance 2).  One s_barrier per K chunk couples them.  With
 // symmetric waves the co-resident workgroups fall into lockstep and the matrix pipe idles through every
 // store/barrier/refill phase (PMC: 44-52 % MFMA busy); here the pipe-owning waves have nothing else to do.
-// PF3 (FBHIP_GEMM_PF3=1, off by default): the producers keep TWO chunks in flight behind the one being landed (prefetch
-// distance 3, three register sets) instead of one.  The hypothesis was Little's law -- one 16 KB chunk per workgroup in flight
-// = 32 KB per CU against the L2 round trip, and the knock-out runs measured only ~22 B/clk/CU from cache-resident operands.
-// Measured: the ISA is as intended (counted vmcnt(7..11) in the steady loop, 110 VGPRs, still 2 workgroups per CU) and it is
-// SLOWER -- 1024x2048x1024 alone 45-46 us vs 43.8, the step 1000 vs 1094 updates/s (two same-box pairs): more bytes in flight
-// per CU do not raise the global->LDS rate, so the staging path is not latency-bound.  Kept as a switch for that record.
-template <int WM, int WN, int WK, int BK, bool PF3 = false>
+// (A deeper producer prefetch -- two chunks in flight behind the landing one -- was built and measured in round 1: ISA as intended,
+// 9 % slower on the step: the staging path is not latency-bound.  Removed in round 2; DESIGN.md section 9 keeps the record.)
+template <int WM, int WN, int WK, int BK>
 __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     constexpr int BM = 32 * WM, BN = 32 * WN, BKT = BK * WK;
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
@@ -255,50 +251,7 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
         constexpr std::true_type T{};
         constexpr std::false_type F{};
         float4 ra0[QA], rb0[QB], ra1[QA], rb1[QB];
-        if constexpr (PF3) {
-            if (nfast > 0) {
-                float4 ra2[QA], rb2[QB];
-                const int nf = nfast;
-                load_fast(0, ra0, rb0);
-                if (nf > 1) load_fast(1, ra1, rb1);
-                if (nf > 2) load_fast(2, ra2, rb2);
-                store_chunk(0, ra0, rb0);
-                __syncthreads();                                      // barrier #0: chunk 0 visible
-                int it = 0;
-                // step ``it``: request chunk it+3 into the set chunk ``it`` just left, land chunk it+1, meet the consumers
-                for (; it + 5 < nf; it += 3) {
-                    load_fast(it + 3, ra0, rb0); store_chunk((it + 1) & 1, ra1, rb1); __syncthreads();
-                    load_fast(it + 4, ra1, rb1); store_chunk((it + 2) & 1, ra2, rb2); __syncthreads();
-                    load_fast(it + 5, ra2, rb2); store_chunk((it + 3) & 1, ra0, rb0); __syncthreads();
-                }
-                // the last <= 6 steps (incl. a ragged K tail chunk, index nf): same rotation, conditions at run time
-#define FBHIP_RSTEP(r, LA, LB, SA, SB)                                                                      \
-                if (it + r < nt) {                                                                          \
-                    if (it + r + 3 < nf) load_fast(it + r + 3, LA, LB);                                     \
-                    if (it + r + 1 < nf) store_chunk((it + r + 1) & 1, SA, SB);                             \
-                    else if (it + r + 1 < nt) { load_slow(nf, SA, SB); store_chunk((it + r + 1) & 1, SA, SB); } \
-                    __syncthreads();                                                                        \
-                }
-                FBHIP_RSTEP(0, ra0, rb0, ra1, rb1)
-                FBHIP_RSTEP(1, ra1, rb1, ra2, rb2)
-                FBHIP_RSTEP(2, ra2, rb2, ra0, rb0)
-                FBHIP_RSTEP(3, ra0, rb0, ra1, rb1)
-                FBHIP_RSTEP(4, ra1, rb1, ra2, rb2)
-                FBHIP_RSTEP(5, ra2, rb2, ra0, rb0)
-#undef FBHIP_RSTEP
-            } else {
-                load_slow(0, ra0, rb0);
-                store_chunk(0, ra0, rb0);
-                __syncthreads();
-                for (int it = 0; it < nt; ++it) {
-                    if (it + 1 < nt) {
-                        load_slow(it + 1, ra0, rb0);
-                        store_chunk((it + 1) & 1, ra0, rb0);
-                    }
-                    __syncthreads();
-                }
-            }
-        } else if (nfast > 0) {
+        if (nfast > 0) {
             const int nf = nfast;
             load_fast(0, ra0, rb0);
             if (nf > 1) load_fast(1, ra1, rb1);
@@ -457,14 +410,13 @@ __device__ __forceinline__ void wait_chunks(int chunks) {
 
 template <int TM> struct DmaGeom {
     static constexpr int BM = 64 * TM, BN = 64, BKT = 32;
-    static constexpr int S = TM == 1 ? 4 : 3;                  // ring depth (chunks)
+    static constexpr int S = 3;                                // ring depth (chunks)
     static constexpr int NPW = 4;                              // producer waves (a DMA costs its wave 60-180 issue cycles)
     static constexpr int STAGE = (BM + BN) * BKT;              // floats per chunk buffer: A tile then B tile
     static constexpr int BOFF = BM * BKT;
     static constexpr int PIECES = (BM + BN) / 8;               // 1 KiB DMA pieces per chunk
     static constexpr int P = PIECES / NPW;                     // per producer wave
     static constexpr size_t LDS_BYTES = (size_t)S * STAGE * sizeof(float);
-    static constexpr bool PREFETCH = TM == 1;                  // fragments of chunk i+1 read during the MFMAs of chunk i
 };
 
 // fragment offsets (floats) inside an operand tile of R rows
@@ -515,26 +467,12 @@ __device__ __forceinline__ void dma_consume(const float* __restrict__ smem, int 
                 }
     };
     __syncthreads();                                            // barrier "init": chunk 0 has landed
-    if constexpr (G::PREFETCH) {
-        float a1[TM][4][4], b1[4][4];
-        read(0, a0, b0);
-        for (int it = 0; it < nt; it += 2) {
-            __syncthreads();                                    // barrier it: chunk it+1 has landed, chunk it is in set 0
-            if (it + 1 < nt) read(it + 1, a1, b1);
-            mfma(a0, b0);
-            if (it + 1 >= nt) break;
-            __syncthreads();                                    // barrier it+1
-            if (it + 2 < nt) read(it + 2, a0, b0);
-            mfma(a1, b1);
-        }
-    } else {
-        // two independent accumulator chains per wave and a second workgroup on the CU cover the fragment-read latency;
-        // one register set keeps the kernel at two workgroups per CU
-        for (int it = 0; it < nt; ++it) {
-            read(it, a0, b0);
-            mfma(a0, b0);
-            __syncthreads();                                    // barrier it: reads of chunk it retired
-        }
+    // two independent accumulator chains per wave and a second workgroup on the CU cover the fragment-read latency;
+    // one register set keeps the kernel at two workgroups per CU
+    for (int it = 0; it < nt; ++it) {
+        read(it, a0, b0);
+        mfma(a0, b0);
+        __syncthreads();                                        // barrier it: reads of chunk it retired
     }
 }
 
@@ -705,8 +643,8 @@ hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t
     return hipGetLastError();
 }
 
-static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4, 4, 2};     // CFG_DMA128: 128 x 64, CFG_DMA64: 64 x 64 (LDS-DMA kernels)
-static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1, 2, 2};
+static const int kCfgWM[CFG_COUNT] = {2, 2, 1, 1, 4, 4};        // CFG_DMA128: 128 x 64 (LDS-DMA kernel)
+static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1, 2};
 
 // <WM, WN, WK, BK> per configuration.  (BK = 64 for the 64x64 configuration -- half the barriers per K -- was measured at the
 // end of round 1: 151 VGPRs = one workgroup per CU unless forced to 128 with amdgpu_waves_per_eu(4) (16 dwords of scratch);
@@ -739,17 +677,11 @@ hipError_t gemm_init() {
                                            hipFuncAttributeMaxDynamicSharedMemorySize,                               \
                                            (int)gemm_lds_bytes<wm, wn, wk, bk>());                                   \
         if (e != hipSuccess) return e;                                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<wm, wn, wk, bk, true>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<wm, wn, wk, bk>());  \
-        if (e != hipSuccess) return e;                                                                               \
     }
     FBHIP_CFGS(X)
 #undef X
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DmaGeom<1>::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dma_kernel<2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)DmaGeom<2>::LDS_BYTES);
         if (e != hipSuccess) return e;
     }
@@ -757,15 +689,8 @@ hipError_t gemm_init() {
     return hipSuccess;
 }
 
-// FBHIP_GEMM_DMA=1 also routes the 64x64 configuration through the LDS-DMA kernel.  Measured on the FB-DDPG step
-// (MI355X, 1-2 tiles per CU per launch): register staging 882 updates/s, DMA 64x64 870, DMA 128x64 from 512 tiles 854 --
-// the DMA kernels only win once a launch has >= 4 128x64 tiles per CU (4096^3: 132 vs 122 TFLOP/s), so the default
-// keeps the step on the register-staged kernel and uses CFG_DMA128 for large generic GEMMs only.
-static bool gemm_dma64_enabled() {
-    static const bool on = [] { const char* e = getenv("FBHIP_GEMM_DMA"); return e && e[0] == '1'; }();
-    return on;
-}
-
+// (The 64x64 LDS-DMA variant tied the register-staged kernel on large GEMMs and lost on the step's launches -- 870 vs 882
+// updates/s in round 1 -- and was removed in round 2; the 128x64 one stays for large generic GEMMs, fbhip_gemm.)
 // the LDS-DMA kernels need whole 32-deep chunks and 16-byte aligned operands
 bool gemm_problem_dma_ok(const GemmProblem& p) {
     const bool a_vec = (((uintptr_t)p.A & 15) == 0 && (p.lda & 3) == 0), b_vec = (((uintptr_t)p.B & 15) == 0 && (p.ldb & 3) == 0);
@@ -803,18 +728,10 @@ hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
         hipLaunchKernelGGL(gemm_dma_kernel<2>, grid, dim3(256 + 64 * DmaGeom<2>::NPW), DmaGeom<2>::LDS_BYTES, stream, g);
         return hipGetLastError();
     }
-    if (cfg == CFG_DMA64 && !gemm_group_dma_ok(g)) return hipErrorInvalidValue;
-    if (cfg == CFG_DMA64 || (cfg == CFG_2x2x1 && gemm_dma64_enabled() && gemm_group_dma_ok(g))) {
-        hipLaunchKernelGGL(gemm_dma_kernel<1>, grid, dim3(256 + 64 * DmaGeom<1>::NPW), DmaGeom<1>::LDS_BYTES, stream, g);
-        return hipGetLastError();
-    }
-    // FBHIP_GEMM_PF3=1: prefetch distance 3 in the producer waves (see gemm_kernel)
-    static const bool pf3 = [] { const char* e = getenv("FBHIP_GEMM_PF3"); return e && e[0] == '1'; }();
     switch (cfg) {
 #define X(id, wm, wn, wk, bk)                                                                                       \
     case id:                                                                                                         \
-        if (pf3) hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk, true>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
-        else hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
+        hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
         break;
         FBHIP_CFGS(X)
 #undef X

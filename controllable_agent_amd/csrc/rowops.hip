@@ -950,7 +950,7 @@ bool actor_head_bwd_ok(int H, int a);
 // quadruped (a = 12, B = 2048, 96 KB: one workgroup per CU) +0.2 %.  An earlier version with runtime-width predicated loops
 // and select-guarded loads took 27 us instead of 12 and LOST at quadruped dims -- hence the exact-width instantiations.
 bool actor_head_bwd_ok(int H, int a) {
-    static const long cap = [] { const char* e = getenv("FBHIP_AHB_LDS_KB"); return (e ? atol(e) : 128L) * 1024; }();
+    constexpr long cap = 128L * 1024;
     return a <= AHB_MAXA && (long)(2 * a * H * sizeof(float)) <= cap;
 }
 

@@ -9,6 +9,7 @@
 // (fb_modules.py:114,190-191) never happens.  Random numbers: Philox4x32-10, counter = (index, stream,
 // update_count), key = (seed, rank) -- reproducible and independent of launch geometry.
 #include "common.h"
+#include <cassert>
 #include "philox.h"
 
 namespace fbhip {
@@ -119,6 +120,11 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= g.B) return;
     const int e = g.ep_idx[i], s = g.step_idx[i];
+#ifdef FBHIP_DEBUG       // make debug: every gathered row must lie inside its episode of the bound storage
+    assert(e >= 0 && e < g.rv.n_episodes && s >= 1 && s < g.rv.t1 && s <= g.rv.episode_len[e]);
+    assert(g.future_idx == nullptr || (g.future_idx[i] >= 1 && g.future_idx[i] <= g.rv.episode_len[e]));
+    assert(g.perm == nullptr || (g.perm[i] >= 0 && g.perm[i] < g.B));
+#endif
     const size_t t = (size_t)e * g.rv.t1 + s;                         // row of the "next" step
     const float* obs = g.rv.observation + (t - 1) * g.o;              // observation[ep, step-1]
     const float* nobs = obs + g.o;                                    // observation[ep, step] (adjacent row)

@@ -28,6 +28,30 @@ int main(void) {
     printf("actor[0] %s %d x %d ld %d off %lld\n", t.name, t.rows, t.cols, t.ld, (long long)t.offset);
     if (strcmp(t.name, "obs_net.0.weight") != 0 || t.rows != 1024 || t.cols != 24) { printf("FAIL entry\n"); return 1; }
     if (fbhip_workspace_bytes(&d) == 0) { printf("FAIL workspace\n"); return 1; }
+    /* every layout of every configuration flag: names, bounds, no overlap (also what the ASan build of the library runs) */
+    for (int variant = 0; variant < 7; ++variant) {
+        fbhip_dims v = walker();
+        v.batch = 64; v.hidden_dim = 64; v.feature_dim = 32; v.backward_hidden_dim = 22; v.z_dim = 10;
+        if (variant == 1) v.add_trunk = 1;
+        if (variant == 2) v.preprocess = 0;
+        if (variant == 3) v.boltzmann = 1;
+        if (variant == 4) { v.preprocess = 0; v.discrete = 1; }
+        if (variant == 5) v.sf = 1;
+        if (variant == 6) { v.sf = 2; v.use_goal = 1; v.goal_dim = 3; }
+        for (int net = 0; net < 3; ++net) {
+            long long numel = fbhip_net_numel(&v, net), last_end = 0;
+            int n = fbhip_layout_count(&v, net);
+            if (numel < 0 || n < 0) { printf("FAIL variant %d net %d: %s\n", variant, net, fbhip_last_error(NULL)); return 1; }
+            for (int i = 0; i < n; ++i) {
+                if (fbhip_layout_entry(&v, net, i, &t) != FBHIP_OK || t.ld < t.cols || t.offset < 0 ||
+                    t.offset + (long long)t.rows * t.ld > numel) { printf("FAIL entry %d of variant %d net %d\n", i, variant, net); return 1; }
+                if (t.offset + (long long)t.rows * t.ld > last_end) last_end = t.offset + (long long)t.rows * t.ld;
+            }
+            if (fbhip_layout_entry(&v, net, n, &t) == FBHIP_OK) { printf("FAIL out-of-range entry accepted\n"); return 1; }
+        }
+        fbhip_ctx* vc = NULL;
+        if (fbhip_workspace_bytes(&v) == 0 || fbhip_create(&v, &vc) != FBHIP_OK || fbhip_destroy(vc) != FBHIP_OK) { printf("FAIL create variant %d: %s\n", variant, fbhip_last_error(NULL)); return 1; }
+    }
 
     /* a caller compiled against an older header (one field short) is refused, not read past its end */
     fbhip_dims shorter = d;

@@ -226,3 +226,27 @@ def test_sf_layout_follows_the_reference_modules(lib):
     assert names(0)[0][0] == "B.0.weight"
     bad = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 1, 0, 1)          # boltzmann + sf
     assert l.fbhip_net_numel(C.byref(bad), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)
+
+
+def test_host_side_under_address_sanitizer(lib, tmp_path):
+    """SURVEY section 5: an ASan build of the library's HOST side (``make asan``: layout, schedule and C-ABI translation units;
+    device code as usual) driven by the plain-C consumer -- layout queries over every configuration flag, context create /
+    destroy, the struct_size guard and the unbound error path must be clean under AddressSanitizer."""
+    import glob, os, shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    rts = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rts:
+        pytest.skip("no clang ASan runtime in this image")
+    csrc = lib.LIB_PATH.parent / "csrc"
+    subprocess.run(["make", "-C", str(csrc), "asan"], check=True, stdout=subprocess.DEVNULL)
+    so_dir = lib.LIB_PATH.parent
+    torch_lib = Path(__import__("torch").__file__).parent / "lib"
+    exe = tmp_path / "abi_consumer_asan"
+    subprocess.run(["gcc", "-std=c99", "-g", "-I", str(ROOT / "include"), str(ROOT / "tests" / "c_consumer" / "abi_consumer.c"), "-o", str(exe),
+                    "-L", str(so_dir), "-l:libfbhip_asan.so", f"-Wl,-rpath,{so_dir}", f"-Wl,-rpath,{torch_lib}",
+                    f"-Wl,-rpath-link,{torch_lib}", "-Wl,--allow-shlib-undefined"], check=True)
+    env = dict(os.environ, LD_PRELOAD=rts[0], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
+               LD_LIBRARY_PATH=f"{torch_lib}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK") and "AddressSanitizer" not in out.stderr, out.stdout + out.stderr

@@ -55,18 +55,18 @@ def test_gemm_layouts(K, M, N, K_, akc, bkc):
     assert rel_err(C.cpu(), ref) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])      # (cfg 5, 6 need K % 32 == 0: test_gemm_lds_dma_kernels)
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])      # (cfg 5 needs K % 32 == 0: test_gemm_lds_dma_kernels)
 def test_gemm_every_tile_config(K, cfg):
     A, B = _r(200, 300, seed=3), _r(150, 300, seed=4)
     C = K.gemm(A.cuda(), B.cuda(), cfg=cfg)
     assert rel_err(C.cpu(), A.double() @ B.double().T) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [5, 6])
+@pytest.mark.parametrize("cfg", [5])
 @pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, False), (False, True)])
 @pytest.mark.parametrize("M,N,Kd", [(256, 192, 128), (200, 100, 96), (50, 1024, 1024), (1024, 52, 576), (130, 70, 32)])
 def test_gemm_lds_dma_kernels(K, cfg, akc, bkc, M, N, Kd):
-    """cfg 5 / 6 = the LDS-DMA kernels (128x64 / 64x64 tiles; K % 32 == 0, aligned operands); ragged M and N tiles read
+    """cfg 5 = the LDS-DMA kernel (128x64 tiles; K % 32 == 0, aligned operands); ragged M and N tiles read
     clamped rows.  NaN padding columns must never reach the result."""
     A = _r(M, Kd, seed=21) if akc else _r(Kd, M, seed=21)
     B = _r(N, Kd, seed=22) if bkc else _r(Kd, N, seed=22)
