@@ -326,7 +326,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     const bool pipe = pipelined && n_steps > 1 && !c->d.discrete && !c->d.sf;   // (discrete: no actor phase to overlap with)
     if (pipe) {
         if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        while ((int)c->events.size() < 2 * 64) {
+        while ((int)c->events.size() < 3 * 64) {
             hipEvent_t ev;
             HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             c->events.push_back(ev);
@@ -365,12 +365,17 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
             if (more) {
                 if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
                 if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
+                rc = enqueue_actor_v(c, c->side);
+                if (rc != FBHIP_OK) break;
+                if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) break;
                 c->cur ^= 1;
                 rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
                 c->cur ^= 1;
                 if (rc != FBHIP_OK) break;
+                c->v_ready = c->events[128 + i];
             }
             rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_GRAD, s);
+            c->v_ready = nullptr;
             if (rc == FBHIP_OK) rc = allreduce(1);
             if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_STEP, s);
             if (more) {
@@ -392,15 +397,20 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
             rc = enqueue_update(c, *hp, nullptr, MID, s);
             if (rc != FBHIP_OK) break;
             const bool more = i + 1 < n_steps;
-            if (more) {                          // fork: the next step's head on the twin workspace set
+            if (more) {                          // fork: V of this step's actor phase, then the next step's head on the twin workspace set
                 if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
                 if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
+                rc = enqueue_actor_v(c, c->side);
+                if (rc != FBHIP_OK) break;
+                if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) break;
                 c->cur ^= 1;
                 rc = enqueue_update(c, *hp, injs ? &injs[i + 1] : nullptr, HEAD, c->side);
                 c->cur ^= 1;
                 if (rc != FBHIP_OK) break;
+                c->v_ready = c->events[128 + i];
             }
             rc = enqueue_update(c, *hp, nullptr, TAIL, s);
+            c->v_ready = nullptr;
             if (more) {                          // join, then continue on the set the head filled
                 if ((he = hipEventRecord(c->events[2 * i + 1], c->side)) != hipSuccess) break;
                 if ((he = hipStreamWaitEvent(s, c->events[2 * i + 1], 0)) != hipSuccess) break;

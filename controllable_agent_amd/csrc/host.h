@@ -120,6 +120,7 @@ struct fbhip_ctx {
     size_t ws_bytes = 0;
     hipStream_t side = nullptr;              // second capture branch of fbhip_update_many
     std::vector<hipEvent_t> events;
+    hipEvent_t v_ready = nullptr;            // set while the actor phase of a pipelined graph is being built: V comes from the side branch
     fbhip::ReplayView rv{};
     uint64_t seed = 0;
     uint32_t rank = 0;
@@ -200,6 +201,7 @@ int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float
 
 // selected phases of one update() onto a stream (FBDDPGAgent / DiscreteFBAgent: build_update; SFAgent: build_update_sf)
 int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s);
+int enqueue_actor_v(fbhip_ctx* c, hipStream_t s);
 int check_hparams(fbhip_ctx* c, const fbhip_hparams* hp);
 int need_bound(fbhip_ctx* c, bool replay);
 

@@ -773,7 +773,11 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         // (no dependence on this pass, so it joins the chain's first round) Q_i = p_i . V_i + b4_i . z and the heads'
         // data gradient is -(w_i / B) V_i * relu'(p_i) -- one row kernel instead of GEMM + reduce + loss + GEMM
         forward_map_fwd_chain(c, c->F_p, w.Xopi.p, w.Xopi.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch, /*with_heads=*/false);
-        {
+        // In the pipelined multi-step graph V is produced on the OTHER capture branch (enqueue_actor_v, ahead of the next step's
+        // head): it depends on the FB optimiser step only, and as part of this chain's first round its two K = z_dim problems
+        // cost ~20 us of the actor phase's critical path.  c->v_ready then carries the event this chain waits for before actor_q.
+        hipEvent_t v_ready = c->v_ready;
+        if (v_ready == nullptr) {
             Stage first = ch.front();
             ch.front() = [=, &w](Ops& o2) {
                 first(o2);
@@ -785,6 +789,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         // gradient of forward_net here)
         ch.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
+                if (v_ready != nullptr) HIPCK(c, hipStreamWaitEvent(q, v_ready, 0));
                 HIPCK(c, launch_actor_q(w.fsO.p.p, 2 * H, w.dp.p, 2 * H, w.z.p, Lz, c->F_p.b4[0], c->F_p.b4[1], w.as.mu.p, La,
                                         w.Xopi.p + aoff, w.Xopi.ld, hp.stddev, hp.want_metrics ? w.metrics : nullptr,
                                         w.pw_scratch, B, H, z, a, c->sq, w.as.premu.p, Lh, w.so.eps_actor, a, q,
@@ -1004,6 +1009,16 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
 }
 #undef POST_BEGIN
 #undef POST_END
+
+// V_i = z . W4_i of the CURRENT workspace set (update_actor's Q and head gradient read it, see build_update) as a launch of its
+// own: the pipelined multi-step graph issues it on the second capture branch right after the FB optimiser step
+int enqueue_actor_v(fbhip_ctx* c, hipStream_t s) {
+    const fbhip_dims& d = c->d;
+    Ws& w = c->W();
+    const int B = d.batch, z = d.z_dim, H = d.hidden_dim, Lz = pad4(z);
+    return run_gemms(c, {P(w.z.p, Lz, 1, c->F_p.W4[0], H, 0, w.dp.p, 2 * H, B, H, z),
+                         P(w.z.p, Lz, 1, c->F_p.W4[1], H, 0, w.dp.p + H, 2 * H, B, H, z)}, s);
+}
 
 int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s) {
     Program prog;
