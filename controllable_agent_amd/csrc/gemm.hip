@@ -131,6 +131,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx
     }
 }
 
+// -DFBHIP_TRACE (tools/gemm_trace.hip only): cycle stamps of one consumer and one producer wave per workgroup, kept in LDS
+// behind the stages and dumped at the end -- where a chunk's time goes (MFMA span, barrier waits, load landing)
+#ifdef FBHIP_TRACE
+constexpr int TRACE_IT = 40, TRACE_SLOTS = 4, TRACE_WGS = 2048;
+__device__ unsigned long long g_trace[TRACE_WGS * 2 * TRACE_IT * TRACE_SLOTS];
+__device__ unsigned g_trace_hw[TRACE_WGS];
+#define FBHIP_TR(role, it, slot)                                                                                      \
+    do {                                                                                                              \
+        if (lane == 0 && (it) < TRACE_IT)                                                                             \
+            reinterpret_cast<unsigned long long*>(smem + 2 * STAGE)[((role) * TRACE_IT + (it)) * TRACE_SLOTS + (slot)] = \
+                __builtin_readcyclecounter();                                                                         \
+    } while (0)
+#else
+#define FBHIP_TR(role, it, slot) do {} while (0)
+#endif
+
 // Wave-specialised workgroup of 8 waves: waves 0-3 are CONSUMERS (one 32x32 accumulator each, arranged WM x WN x WK;
 // they only read MFMA fragments from LDS and issue the dependent MFMA chain), waves 4-7 are PRODUCERS (global ->
 // registers -> LDS staging of the next K chunks, prefetch distance 2).  One s_barrier per K chunk couples them.  With
@@ -244,9 +260,13 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
         // straight-line code and hipcc emits a COUNTED s_waitcnt vmcnt(n) that keeps the newest chunk in flight.
         auto p_step = [&](int it, auto do_load, auto do_store, float4 (&la_)[QA], float4 (&lb_)[QB],
                           const float4 (&sa_)[QA], const float4 (&sb_)[QB]) __attribute__((always_inline)) {
+            if (wid == 4) FBHIP_TR(1, it, 0);
             if constexpr (decltype(do_load)::value) load_fast(it + 2, la_, lb_);
+            if (wid == 4) FBHIP_TR(1, it, 1);
             if constexpr (decltype(do_store)::value) store_chunk((it + 1) & 1, sa_, sb_);
+            if (wid == 4) FBHIP_TR(1, it, 2);
             __syncthreads();
+            if (wid == 4) FBHIP_TR(1, it, 3);
         };
         constexpr std::true_type T{};
         constexpr std::false_type F{};
@@ -297,6 +317,9 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
             }
         }
         if constexpr (WK > 1) __syncthreads();                          // stay for the consumers' reduction barrier
+#ifdef FBHIP_TRACE
+        __syncthreads();
+#endif
         return;
     }
 
@@ -314,6 +337,7 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
 
     __syncthreads();                                                    // barrier #0
     for (int it = 0; it < nt; ++it) {
+        if (wid == 0) FBHIP_TR(0, it, 0);
         const float* st = smem + (it & 1) * STAGE;
         float av[NF], bv[NF];
 #pragma unroll
@@ -335,8 +359,23 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // DS reads for pair j + 2
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);              // last two MFMA pairs
+        if (wid == 0) FBHIP_TR(0, it, 1);
         __syncthreads();
+        if (wid == 0) FBHIP_TR(0, it, 2);
     }
+#ifdef FBHIP_TRACE
+    __syncthreads();
+    if (orig < TRACE_WGS) {
+        const unsigned long long* tl = reinterpret_cast<const unsigned long long*>(smem + 2 * STAGE);
+        for (int i = threadIdx.x; i < 2 * TRACE_IT * TRACE_SLOTS; i += 256) g_trace[(size_t)orig * 2 * TRACE_IT * TRACE_SLOTS + i] = tl[i];
+        if (threadIdx.x == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_trace_hw[orig] = (hw & 0xffffff) | (xcc << 24);
+        }
+    }
+#endif
 
     if constexpr (WK > 1) {
         // reduce the WK partial tiles (and the partial column sums) through LDS; wave group wk == 0 finishes
@@ -653,7 +692,13 @@ static const int kCfgWN[CFG_COUNT] = {2, 1, 2, 1, 1, 2};
 #define FBHIP_CFGS(X) X(CFG_2x2x1, 2, 2, 1, 32) X(CFG_2x1x2, 2, 1, 2, 32) X(CFG_1x2x2, 1, 2, 2, 32) X(CFG_1x1x4, 1, 1, 4, 16) X(CFG_4x1x1, 4, 1, 1, 32)
 
 template <int WM, int WN, int WK, int BK>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BK * WK) * (32 * WM + 1 + 32 * WN + 1) * sizeof(float); }
+constexpr size_t gemm_lds_bytes() {
+    size_t b = (size_t)2 * (BK * WK) * (32 * WM + 1 + 32 * WN + 1) * sizeof(float);
+#ifdef FBHIP_TRACE
+    b += 2 * TRACE_IT * TRACE_SLOTS * sizeof(unsigned long long);
+#endif
+    return b;
+}
 
 int gemm_cfg_bkt(int cfg) {
     switch (cfg) {

@@ -13,7 +13,7 @@ B = torch.randn((N, Kd) if bkc else (Kd, N), device="cuda")
 C = torch.empty(M, N, device="cuda")
 us = timeit(lambda: K.gemm(A, B, a_kcontig=akc, b_kcontig=bkc, out=C))
 print(f"{(M, N, Kd)} {lay} auto {us:8.1f} us {2 * M * N * Kd / us / 1e6:7.1f} TF/s")
-for cfg in range(5):
+for cfg in range(6):
     try:
         us = timeit(lambda: K.gemm(A, B, a_kcontig=akc, b_kcontig=bkc, out=C, cfg=cfg))
         print(f"{(M, N, Kd)} {lay} cfg{cfg} {us:8.1f} us {2 * M * N * Kd / us / 1e6:7.1f} TF/s")
