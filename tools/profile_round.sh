@@ -7,8 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py --steps 2000 --warmup 200 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o t -- python $ROOT/bench.py --steps 300 --warmup 50 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.log 2>&1
+python $ROOT/bench.py --steps 1920 --warmup 192 --repeats 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o t -- python $ROOT/bench.py --steps 320 --warmup 64 --repeats 1 --no-cpu-baseline --no-single-update-probe > $OUT/${TAG}_bench_under_rocprof.log 2>&1
 DB=$(ls $OUT/${TAG}_trace/*.db 2>/dev/null | head -1)
 if [ -n "$DB" ]; then
   python $ROOT/tools/prof_summary.py $DB $OUT/${TAG}_kernel_stats.txt > /dev/null
@@ -17,7 +17,7 @@ if [ -n "$DB" ]; then
 fi
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$N -o p -- python $ROOT/bench.py --steps 40 --warmup 16 --no-cpu-baseline > $OUT/${TAG}_pmc_$N.log 2>&1
+  timeout 420 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$N -o p -- python $ROOT/bench.py --steps 64 --warmup 32 --repeats 1 --no-cpu-baseline --no-single-update-probe > $OUT/${TAG}_pmc_$N.log 2>&1
   python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_$N $OUT/${TAG}_pmc_$N.txt > /dev/null
   rm -rf $OUT/${TAG}_pmc_$N
 done
