@@ -33,3 +33,6 @@ done
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 \
     --rehearse-on-one-gpu --steps 320 --warmup 32 --repeats 3 --episodes 1000 --no-cpu-baseline > $OUT/${TAG}_two_rank_rehearsal.log 2>&1
 ls -la $OUT/${TAG}_*
+# the same two ranks with the gradient all-reduces as peer-access kernels inside each rank's graph (csrc/peer.hip)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 2 \
+    --rehearse-on-one-gpu --peer-allreduce --steps 320 --warmup 32 --repeats 3 --episodes 1000 --no-cpu-baseline > $OUT/${TAG}_two_rank_peer_allreduce.log 2>&1
