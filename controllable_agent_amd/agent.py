@@ -711,6 +711,43 @@ class FBHipAgent:
             fn()
         cur.wait_stream(self._stream)
 
+    def _dp_schedule_graph(self, n_steps: int, hp: HParams, launch: tp.Callable[[int], None]) -> bool:
+        """The host-issued data-parallel schedule of ``n_steps`` updates -- four or five phase launches and two or three RCCL
+        all-reduces per step (distributed.dp_update_many) -- captured ONCE, collectives included, into one graph and replayed:
+        the host then issues one launch per call instead of ~7 per step, like the single-GPU ``fbhip_update_many``.  Same
+        kernels, operands and order as the eager schedule.  Needs a capturable transport: backend nccl (RCCL), or no process
+        group at all (FBHIP_FORCE_PHASE_SPLIT rehearsal); with gloo the collectives run on the host and the eager schedule
+        stays.  ``FBHIP_DP_GRAPH=0`` turns it off; a capture that fails once is not retried.  Returns False when the caller
+        must run the eager schedule."""
+        import torch.distributed as dist
+        if os.environ.get("FBHIP_DP_GRAPH", "1") == "0" or getattr(self, "_dp_graph_failed", False):
+            return False
+        live = dist.is_available() and dist.is_initialized()
+        if live and dist.get_backend() != "nccl":
+            return False
+        cache = self.__dict__.setdefault("_dp_graphs", {})
+        key = (n_steps, bytes(hp), os.environ.get("FBHIP_DP_SIDE_STREAM", "1"))
+        g = cache.get(key)
+        if g is None:
+            # (the communicator exists by now: _verify_replicas() has issued an eager collective on this device)
+            cur = torch.cuda.current_stream(self._device)
+            cap = self._stream if cur.cuda_stream == 0 else cur
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, stream=cap):
+                    launch(0)                            # eager phase launches: they become nodes of THIS graph
+            except Exception as e:                       # noqa: BLE001 -- any refusal (transport, driver) falls back for good
+                self._dp_graph_failed = True
+                import warnings
+                warnings.warn(f"data-parallel schedule graph capture failed ({type(e).__name__}: {e}); using host-issued launches")
+                check(_lib.load().fbhip_select_workspace_set(self._ctx, 0), self._ctx)
+                return False
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            cache[key] = g
+        self._on_update_stream(g.replay)
+        return True
+
     def _launch_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         from .distributed import dp_update
         lib = _lib.load()
@@ -926,12 +963,12 @@ class FBHipAgent:
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
             lib = _lib.load()
 
-            def launch() -> None:
+            def launch(phase_graphs: int = 1) -> None:
                 actor_bits = (_lib.PHASE_ACTOR_GRAD | _lib.PHASE_ACTOR_STEP | _lib.PHASE_ACTOR_FWD) if self._discrete else 0
 
                 def phases(mask: int) -> None:           # (on torch's CURRENT stream: dp_update_many switches to its side stream)
                     if mask & ~actor_bits:
-                        check(lib.fbhip_update(self._ctx, C.byref(hp), None, mask & ~actor_bits, 1, stream_ptr()), self._ctx)
+                        check(lib.fbhip_update(self._ctx, C.byref(hp), None, mask & ~actor_bits, phase_graphs, stream_ptr()), self._ctx)
                 side = None
                 if not self._discrete and os.environ.get("FBHIP_DP_SIDE_STREAM", "1") != "0":
                     if getattr(self, "_side_stream", None) is None:
@@ -940,6 +977,8 @@ class FBHipAgent:
                 dp_update_many(phases,
                                lambda which: check(lib.fbhip_select_workspace_set(self._ctx, which), self._ctx),
                                self._fb_grads, self._actor_grads, n_steps, early=self._early_grad_range(), side=side)
+            if self._dp_schedule_graph(n_steps, hp, launch):
+                return self._metrics()
             self._on_update_stream(launch)
             return self._metrics()
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)

@@ -379,3 +379,66 @@ def test_peer_allreduce_inside_the_graph_equals_the_host_schedule():
             assert H.rel_err(peer_res[0][1][k], v) < 2e-3, k
         else:
             np.testing.assert_allclose(peer_res[0][1][k], v, rtol=0, atol=2e-5, err_msg=k)
+
+
+# ------------------------------------------------------------------------------ the schedule captured into one graph (round 2)
+def _run_schedule(monkeypatch, graph: bool):
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    cfg, nets, storage, lengths = T._setup()
+    agent = H.make_hip_agent(cfg, nets)
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+    monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+    monkeypatch.setenv("FBHIP_DP_GRAPH", "1" if graph else "0")
+    for call in range(3):                                   # the second and third call replay the cached graph
+        agent.update_many(rb, 6 * call, 6)
+    torch.cuda.synchronize()
+    assert bool(getattr(agent, "_dp_graphs", {})) == graph and not getattr(agent, "_dp_graph_failed", False)
+    return H.get_agent_state(agent), agent.step_counts()
+
+
+def test_dp_schedule_captured_as_one_graph_equals_the_host_issued_schedule(monkeypatch):
+    """FBHipAgent._dp_schedule_graph: the multi-step data-parallel schedule (phase launches on two streams + the places of its
+    all-reduces) captured once into a torch CUDAGraph and replayed, against the same schedule issued launch by launch: same
+    kernels, operands and order, so bit-identical state, device RNG streams included."""
+    s1, c1 = _run_schedule(monkeypatch, graph=False)
+    s2, c2 = _run_schedule(monkeypatch, graph=True)
+    assert c1 == c2 == (18, 18)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+
+
+def _worker_nccl_world1(graph, port, out_q):
+    import torch.distributed as dist
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_GRAPH="1" if graph else "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    cfg, nets, storage, lengths = T._setup()
+    torch.manual_seed(4321)            # the agent's device RNG key comes from torch's seed, which differs between fresh processes
+    agent = H.make_hip_agent(cfg, nets)
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+    for call in range(3):
+        agent.update_many(rb, 6 * call, 6)
+    torch.cuda.synchronize()
+    out_q.put((graph, H.get_agent_state(agent), agent.step_counts(), bool(getattr(agent, "_dp_graphs", {})),
+               bool(getattr(agent, "_dp_graph_failed", False))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_schedule_graph_captures_rccl_collectives_with_one_rank():
+    """The same comparison with a live RCCL process group (backend nccl, world 1 -- all this box can hold): the all-reduce
+    calls of the schedule are captured into the graph with the kernels around them and replayed; state equals the host-issued
+    schedule bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    got = {}
+    for graph in (False, True):                               # one after the other: one RCCL rank per device at a time
+        q = ctx.Queue()
+        p = ctx.Process(target=_worker_nccl_world1, args=(graph, T._free_port(), q))
+        p.start()
+        g, state, counts, captured, failed = q.get(timeout=300)
+        p.join(timeout=120)
+        assert p.exitcode == 0 and counts == (18, 18) and captured == graph and not failed
+        got[g] = state
+    for k in got[False]:
+        np.testing.assert_array_equal(got[False][k], got[True][k], err_msg=k)
