@@ -1251,13 +1251,19 @@ class SFHipAgent(FBHipAgent):
     loss is the TD regression on successor features (``sf_loss_kernel``) and ``feature_learner`` -- ``feature_net`` = the
     BackwardMap architecture, trained by its own loss at ``lr_coef * lr`` -- is one of
 
-        "icm"  inverse dynamics  mean((action - tanh-mlp(cat[phi(goal), phi(next_goal)]))^2)      sf.py:194-213
-        "lap"  Laplacian         mean((phi - next_phi)^2) + orthonormality loss of phi phi^T        sf.py:100-116
+        "icm"          inverse dynamics  mean((action - tanh-mlp(cat[phi(goal), phi(next_goal)]))^2)      sf.py:194-213
+        "lap"          Laplacian         mean((phi - next_phi)^2) + orthonormality loss of phi phi^T        sf.py:100-116
+        "random"       feature_net keeps its initial weights: no loss, no phi_opt                         sf.py:84-92, 447
+        "autoencoder"  mean((decoder(phi(goal)) - goal)^2)                                                sf.py:249-262
+        "transition"   mean((forward_dynamic_net(cat[phi(goal), action]) - next_goal)^2)                  sf.py:215-227
 
-    The reference's other ten feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    The reference's other eight feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
-    _LEARNERS = {"icm": 1, "lap": 2}
+    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5}
+    # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
+    _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
+              5: ("forward_dynamic_net", lambda z, a, g: (z + a, g))}
 
     def __init__(self, **kwargs: tp.Any) -> None:
         cfg = SFAgentConfig(**kwargs)
@@ -1306,10 +1312,10 @@ class SFHipAgent(FBHipAgent):
         g, d, Hb, a = self.goal_dim, c.z_dim, c.backward_hidden_dim, self.action_dim
         feat = [("feature_net.0", torch.nn.Linear(g, Hb)), ("feature_net.3", torch.nn.Linear(Hb, Hb)), ("feature_net.5", torch.nn.Linear(Hb, d))]
         ortho(feat)                                                                # FeatureLearner.__init__: self.apply(weight_init), sf.py:88
-        if self._sf_mode == 1:                                                     # ICM.__init__ (sf.py:195-200) applies it AGAIN to everything
-            inv = [("inverse_dynamic_net.0", torch.nn.Linear(2 * d, Hb)), ("inverse_dynamic_net.2", torch.nn.Linear(Hb, Hb)),
-                   ("inverse_dynamic_net.4", torch.nn.Linear(Hb, a))]
-            feat = feat + inv
+        if self._sf_mode in self._HEADS:        # e.g. ICM.__init__ (sf.py:195-200): builds its head, then applies weight_init AGAIN to everything
+            name, io = self._HEADS[self._sf_mode]
+            fin, fout = io(d, a, g)
+            feat = feat + [(f"{name}.0", torch.nn.Linear(fin, Hb)), (f"{name}.2", torch.nn.Linear(Hb, Hb)), (f"{name}.4", torch.nn.Linear(Hb, fout))]
             ortho(feat)
         sd = {}
         for p_, lin in feat:
@@ -1333,7 +1339,8 @@ class SFHipAgent(FBHipAgent):
             delattr(self, stale)
         c = self.cfg
         self.sf_opt = AdamView(self, "fb", ["successor_net"], [c.lr])                          # sf.py:459
-        self.phi_opt = AdamView(self, "fb", ["feature_learner"], [c.lr_coef * c.lr])           # sf.py:461-463
+        # sf.py:461-463 ("random" trains nothing: no optimiser, its block of the fused pass sees zero gradients)
+        self.phi_opt = AdamView(self, "fb", ["feature_learner"], [c.lr_coef * c.lr]) if self._sf_mode != 3 else None
         if nets is not None:
             self.load_nets(nets)
 
@@ -1434,8 +1441,8 @@ class SFHipAgent(FBHipAgent):
         buf = (C.c_float * _lib.NUM_METRICS)()
         check(_lib.load().fbhip_read_metrics(self._ctx, buf, stream_ptr()), self._ctx)
         g = lambda k: float(buf[_lib.METRIC_INDEX[k]])
-        for k in ("target_F", "F1", "phi", "phi_norm", "z_norm", "sf_loss", "phi_loss"):
-            out[k] = g(k)
+        for k in ("target_F", "F1", "phi", "phi_norm", "z_norm", "sf_loss") + (("phi_loss",) if self._sf_mode != 3 else ()):
+            out[k] = g(k)                        # (sf.py:634-635: "random" has no phi_loss)
         out["sf_opt_lr"] = self.sf_opt.param_groups[0]["lr"]
         if c.use_tb or c.use_wandb:
             out["actor_loss"], out["actor_logprob"] = g("actor_loss"), g("actor_logprob")

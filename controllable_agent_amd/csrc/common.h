@@ -189,7 +189,7 @@ hipError_t launch_sf_loss(const float* F1, const float* F2, const float* nF1, co
 // inverse-dynamics loss of the ICM feature learner (sf.py:207-210): pred = tanh(pre), PHI_LOSS = mean((action - pred)^2), d pre;
 // scratch >= ceil(rows * a / 256) floats
 hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int lda, float* dpre, int ldd, int rows, int a,
-                           float* metrics, float* scratch, hipStream_t s);
+                           int squash, float* metrics, float* scratch, hipStream_t s);
 // Laplacian feature learner (sf.py:104-114) on top of pairwise_kernel's orthonormality pass: dphi += d mse, dnext_phi = d mse,
 // PHI_LOSS = mse + metrics[ORTH_LOSS]; scratch >= ceil(rows / 4) floats
 hipError_t launch_lap(const float* phi, const float* next_phi, int ld, float* dphi, float* dnext_phi, float* metrics,

@@ -94,7 +94,13 @@ Ws carve(const fbhip_dims& d, void* base);
 struct TrunkP { float *W1, *b1, *g1, *be1, *W2, *b2; int k1, ld1; };
 struct FwdP { TrunkP oa, oz; float *Wt = nullptr, *bt = nullptr; float *W3s, *b3s, *W4[2], *b4[2]; };   // Wt: add_trunk
 struct BwdP { float *W1, *b1, *g1, *be1, *W2, *b2, *W3, *b3; };
-struct IcmP { float *W1 = nullptr, *b1, *W2, *b2, *W3, *b3; };     // SFAgent's inverse_dynamic_net (in the backward segment)
+struct IcmP { float *W1 = nullptr, *b1, *W2, *b2, *W3, *b3; };     // the feature learner's head mlp (in the backward segment)
+// dims.sf -> the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) that the feature learner trains feature_net through (sf.py):
+//   1 icm          inverse_dynamic_net   in = 2 z  (cat[phi, next_phi])   out = a (tanh), target = action        :194-213
+//   4 autoencoder  decoder               in = z    (phi)                  out = g,        target = goal          :249-262
+//   5 transition   forward_dynamic_net   in = z + a (cat[phi, action])    out = g,        target = next_goal     :215-227
+// (2 lap and 3 random have none)
+bool sf_head_dims(const fbhip_dims& d, int* in, int* out, const char** prefix);
 struct ActP { TrunkP o, oz; float *Wt = nullptr, *bt = nullptr; float *W3, *b3, *W4, *b4; };
 FwdP fwd_p(float* base, const NetLayout& L);
 BwdP bwd_p(float* base, const NetLayout& L);

@@ -107,11 +107,13 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
         b.mat(q + "3.weight", Hb, Hb, HbP, HbP); b.vec(q + "3.bias", Hb, HbP);
         b.mat(q + "5.weight", z, Hb, HbP); b.vec(q + "5.bias", z);
         order = {q + "0.weight", q + "0.bias", q + "1.weight", q + "1.bias", q + "3.weight", q + "3.bias", q + "5.weight", q + "5.bias"};
-        if (d.sf == 1) {      // ICM: inverse_dynamic_net = mlp(2 z, Hb, 'irelu', Hb, 'irelu', a, 'tanh')  (sf.py:198)
-            const std::string i = "inverse_dynamic_net.";
-            b.mat(i + "0.weight", Hb, 2 * z, pad32(2 * z), HbP); b.vec(i + "0.bias", Hb, HbP);
+        int hin = 0, hout = 0;
+        const char* pfx = nullptr;
+        if (sf_head_dims(d, &hin, &hout, &pfx)) {      // e.g. ICM: inverse_dynamic_net = mlp(2 z, Hb, 'irelu', Hb, 'irelu', a, 'tanh')  (sf.py:198)
+            const std::string i = pfx;
+            b.mat(i + "0.weight", Hb, hin, pad32(hin), HbP); b.vec(i + "0.bias", Hb, HbP);
             b.mat(i + "2.weight", Hb, Hb, HbP, HbP); b.vec(i + "2.bias", Hb, HbP);
-            b.mat(i + "4.weight", a, Hb, HbP); b.vec(i + "4.bias", a);
+            b.mat(i + "4.weight", hout, Hb, HbP); b.vec(i + "4.bias", hout);
             append(order, {i + "0.weight", i + "0.bias", i + "2.weight", i + "2.bias", i + "4.weight", i + "4.bias"});
         }
     } else if (d.discrete) {                      // DiscreteFBAgent has no actor: empty layout
@@ -154,7 +156,7 @@ int check_dims(const fbhip_dims* d) {
     if (d->batch > 8192) { g_err = "fbhip: batch > 8192 per GPU unsupported (permutation sort)"; return FBHIP_E_INVALID; }
     if (d->discrete && d->preprocess) { g_err = "fbhip: discrete needs preprocess == 0 (the reference's discrete ForwardMap.forward only runs without the preprocess nets, discrete_fb.py:91-94)"; return FBHIP_E_INVALID; }
     if (d->discrete && (int64_t)d->z_dim * d->action_dim > 8192) { g_err = "fbhip: discrete: z_dim * actions > 8192 unsupported"; return FBHIP_E_INVALID; }
-    if (d->sf < 0 || d->sf > 2) { g_err = "fbhip: dims.sf must be 0, 1 (icm) or 2 (lap)"; return FBHIP_E_INVALID; }
+    if (d->sf < 0 || d->sf > 5) { g_err = "fbhip: dims.sf must be 0, 1 (icm), 2 (lap), 3 (random), 4 (autoencoder) or 5 (transition)"; return FBHIP_E_INVALID; }
     if (d->sf && (d->discrete || d->boltzmann || !d->norm_z)) { g_err = "fbhip: dims.sf needs discrete = 0, boltzmann = 0, norm_z = 1"; return FBHIP_E_INVALID; }
     if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
     return FBHIP_OK;
@@ -272,11 +274,13 @@ Ws carve(const fbhip_dims& d, void* base) {
         w.bsS.stats = c.f(4 * (size_t)B); w.bsS.norms = c.f(2 * (size_t)B);
         w.dBm2 = c.buf(2 * B, z); w.dy2 = c.buf(2 * B, z); w.s_dr2 = c.buf(2 * B, Hb, Lb); w.s_dt1 = c.buf(2 * B, Hb, Lb);
         if (d.sf == 2) { w.zeroF = c.buf(B, z); w.lapS1 = c.buf(B, z); w.lapS2 = c.buf(B, z); }
-        if (d.sf == 1) {
-            w.icat = c.buf(B, 2 * z, pad32(2 * z)); w.ih1 = c.buf(B, Hb, Lb); w.ih2 = c.buf(B, Hb, Lb);
-            w.ipre = c.buf(B, a, La); w.d_ipre = c.buf(B, a, La); w.d_ih1 = c.buf(B, Hb, Lb); w.d_ih2 = c.buf(B, Hb, Lb);
+        int hin = 0, hout = 0;
+        const char* pfx = nullptr;
+        if (sf_head_dims(d, &hin, &hout, &pfx)) {
+            w.icat = c.buf(B, hin, pad32(hin)); w.ih1 = c.buf(B, Hb, Lb); w.ih2 = c.buf(B, Hb, Lb);
+            w.ipre = c.buf(B, hout, pad4(hout)); w.d_ipre = c.buf(B, hout, pad4(hout)); w.d_ih1 = c.buf(B, Hb, Lb); w.d_ih2 = c.buf(B, Hb, Lb);
         }
-        (void)Lz;
+        (void)Lz; (void)La;
     }
     w.act_in = c.f(act_in_floats(d));
     w.act_vec = c.f((size_t)5 * 2048 + 256);
@@ -321,10 +325,20 @@ BwdP bwd_p(float* base, const NetLayout& L) {
     b.W3 = base + L.by_name.at(q + "5.weight").off; b.b3 = base + L.by_name.at(q + "5.bias").off;
     return b;
 }
+bool sf_head_dims(const fbhip_dims& d, int* in, int* out, const char** prefix) {
+    switch (d.sf) {
+        case 1: *in = 2 * d.z_dim; *out = d.action_dim; *prefix = "inverse_dynamic_net."; return true;
+        case 4: *in = d.z_dim; *out = d.goal_dim; *prefix = "decoder."; return true;
+        case 5: *in = d.z_dim + d.action_dim; *out = d.goal_dim; *prefix = "forward_dynamic_net."; return true;
+        default: return false;
+    }
+}
 IcmP icm_p(float* base, const NetLayout& L) {
     IcmP i;
-    if (!L.by_name.count("inverse_dynamic_net.0.weight")) return i;
-    const std::string q = "inverse_dynamic_net.";
+    std::string q;
+    for (const char* cand : {"inverse_dynamic_net.", "decoder.", "forward_dynamic_net."})
+        if (L.by_name.count(std::string(cand) + "0.weight")) q = cand;
+    if (q.empty()) return i;
     i.W1 = base + L.by_name.at(q + "0.weight").off; i.b1 = base + L.by_name.at(q + "0.bias").off;
     i.W2 = base + L.by_name.at(q + "2.weight").off; i.b2 = base + L.by_name.at(q + "2.bias").off;
     i.W3 = base + L.by_name.at(q + "4.weight").off; i.b3 = base + L.by_name.at(q + "4.bias").off;

@@ -946,12 +946,22 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     // ---- feature loss and its gradient wrt [phi ; next_phi]  (sf.py:628 -> ICM :203-213 / Laplacian :100-116), then both backward
     // passes side by side: successor_net from (dF1, dF2), feature_learner from d[phi ; next_phi]
     Chain feat;
-    if (d.sf == 1) {
+    int hin = 0, hout = 0;
+    const char* hpfx = nullptr;
+    if (sf_head_dims(d, &hin, &hout, &hpfx)) {
+        // the feature learner's head mlp on [phi | ...] regressed on a target (icm: tanh head vs the action, sf.py:203-213;
+        // autoencoder: vs the goal itself, :249-262; transition: [phi | action] vs the next goal, :215-227)
         const IcmP &I = c->I_p, &G = c->I_g;
-        const int Kc = pad32(2 * z);
+        const int Kc = pad32(hin), a = hout, La = pad4(hout), sfm = d.sf, act = d.action_dim;
+        const float* second = sfm == 1 ? nphi : sfm == 5 ? w.Xoa.p + aoff : nullptr;
+        const int ld2 = sfm == 1 ? Lz : w.Xoa.ld, n2 = sfm == 1 ? z : sfm == 5 ? act : 0;
+        const float* target = sfm == 1 ? w.Xoa.p + aoff : sfm == 4 ? w.goal2.p : w.goal2.p + (size_t)B * w.goal2.ld;
+        const int ldt = sfm == 1 ? w.Xoa.ld : w.goal2.ld;
         feat.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_concat2(w.icat.p, Kc, phi, Lz, z, nphi, Lz, z, B, q));
+                HIPCK(c, launch_concat2(w.icat.p, Kc, phi, Lz, z, second, ld2, n2, B, q));
+                // only icm's head sees next_phi: the feature pass runs on [goal ; next_goal], so its half of the gradient panel is zero
+                if (sfm != 1) HIPCK(c, hipMemsetAsync(dnphi, 0, (size_t)B * Lz * sizeof(float), q));
                 return (int)FBHIP_OK;
             });
         });
@@ -960,7 +970,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         feat.push_back([=, &w](Ops& o2) {
             o2.gemms.push_back(P(w.ih2.p, Lb, 1, I.W3, Lb, 1, w.ipre.p, La, B, a, Lb, I.b3, EPI_BIAS));
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                HIPCK(c, launch_icm_loss(w.ipre.p, La, w.Xoa.p + aoff, w.Xoa.ld, w.d_ipre.p, La, B, a, w.metrics, w.pw_scratch, q));
+                HIPCK(c, launch_icm_loss(w.ipre.p, La, target, ldt, w.d_ipre.p, La, B, a, sfm == 1 ? 1 : 0, w.metrics, w.pw_scratch, q));
                 return (int)FBHIP_OK;
             });
         });
@@ -975,9 +985,9 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         feat.push_back([=, &w](Ops& o2) {
             o2.gemms.push_back(P(w.d_ih1.p, Lb, 0, w.icat.p, Kc, 0, G.W1, Kc, Lb, Kc, B, nullptr, EPI_NONE, nullptr, 0, G.b1));
             o2.gemms.push_back(P(w.d_ih1.p, Lb, 1, I.W1, Kc, 0, dphi, Lz, B, z, Lb));            // d cat[:, :z]
-            o2.gemms.push_back(P(w.d_ih1.p, Lb, 1, I.W1 + z, Kc, 0, dnphi, Lz, B, z, Lb));       // d cat[:, z:2z]
+            if (sfm == 1) o2.gemms.push_back(P(w.d_ih1.p, Lb, 1, I.W1 + z, Kc, 0, dnphi, Lz, B, z, Lb));       // d cat[:, z:2z]
         });
-    } else {
+    } else if (d.sf == 2) {
         feat.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
                 // orthonormality part: the pairwise kernel with zero F panels leaves 2 Hm . phi in d phi and orth_loss in the
@@ -989,12 +999,15 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
             });
         });
     }
+    // (random, sf.py:430: feature_net keeps its initial weights -- no loss, no phi_opt; its gradient block stays zero and the
+    // Adam pass below leaves it where it is)
     BGrad bg{w.dBm2.p, w.dy2.p, w.s_dr2.p, w.s_dt1.p};
-    backward_map_bwd_chain(c, c->K_p, c->K_g, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, feat, false, &bg);
+    if (d.sf != 3) backward_map_bwd_chain(c, c->K_p, c->K_g, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, feat, false, &bg);
     Chain succ;
     forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, succ);
     {
-        std::vector<Chain> ch{succ, feat};
+        std::vector<Chain> ch{succ};
+        if (d.sf != 3) ch.push_back(feat);
         prog_parallel(prog, ch);
     }
     // ---- sf_opt.step() + phi_opt.step() (sf.py:643-653): one pass over forward ++ backward, lr | lr_coef * lr; the EMA of

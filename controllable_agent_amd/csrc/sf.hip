@@ -109,16 +109,17 @@ __global__ void __launch_bounds__(64) sf_loss_finalize_kernel(const float* __res
 // one thread per element of the [rows, a] inverse-dynamics output; per-workgroup partial sums folded in a fixed order
 __global__ void __launch_bounds__(256) icm_loss_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ action,
                                                        int lda, float* __restrict__ dpre, int ldd, int rows, int a,
-                                                       float* __restrict__ part) {
+                                                       int squash, float* __restrict__ part) {
     __shared__ float red[4];
     const float sc = 2.f / ((float)rows * (float)a);
     const int e = blockIdx.x * 256 + threadIdx.x;
     float sq = 0.f;
     if (e < rows * a) {
         const int r = e / a, j = e - r * a;
-        const float pred = tanhf(pre[(size_t)r * ldp + j]);
+        const float x = pre[(size_t)r * ldp + j];
+        const float pred = squash ? tanhf(x) : x;                       // (autoencoder / transition heads are linear)
         const float err = action[(size_t)r * lda + j] - pred;
-        dpre[(size_t)r * ldd + j] = -sc * err * (1.f - pred * pred);
+        dpre[(size_t)r * ldd + j] = -sc * err * (squash ? 1.f - pred * pred : 1.f);
         sq = err * err;
     }
     sq = wsum(sq);
@@ -184,9 +185,9 @@ hipError_t launch_sf_loss(const float* F1, const float* F2, const float* nF1, co
 }
 
 hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int lda, float* dpre, int ldd, int rows, int a,
-                           float* metrics, float* scratch, hipStream_t s) {
+                           int squash, float* metrics, float* scratch, hipStream_t s) {
     const int nblk = (rows * a + 255) / 256;
-    hipLaunchKernelGGL(icm_loss_kernel, dim3(nblk), dim3(256), 0, s, pre, ldp, action, lda, dpre, ldd, rows, a, scratch);
+    hipLaunchKernelGGL(icm_loss_kernel, dim3(nblk), dim3(256), 0, s, pre, ldp, action, lda, dpre, ldd, rows, a, squash, scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(icm_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, a, metrics);

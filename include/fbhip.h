@@ -109,12 +109,14 @@ typedef struct fbhip_dims {
                                     * of the target ForwardMap on next_obs, or with ``boltzmann`` the softmax(next_Q / temp) mix
                                     * (temp: fbhip_set_policy_squash; :289-303); online embedding = the column of the stored action
                                     * (:309-311); q_loss uses that next_Q (:329).  Greedy actions: fbhip_discrete_act */
-    int32_t sf;                    /* 0: FBDDPGAgent.  1 / 2: the sibling SFAgent (url_benchmark/agent/sf.py:383-768) with
-                                    * feature_learner "icm" (1, sf.py:194-213) / "lap" (2, sf.py:100-116).  NET_FORWARD is
+    int32_t sf;                    /* 0: FBDDPGAgent.  1..5: the sibling SFAgent (url_benchmark/agent/sf.py:383-768) with
+                                    * feature_learner "icm" (1, sf.py:194-213) / "lap" (2, :100-116) / "random" (3, :84-92: feature_net
+                                    * frozen, no feature loss) / "autoencoder" (4, :249-262) / "transition" (5, :215-227).  NET_FORWARD is
                                     * ``successor_net`` (the same ForwardMap; its target = successor_target_net), NET_BACKWARD is
                                     * ``feature_learner``: ``feature_net.{0,1,3,5}`` (the BackwardMap architecture, projection
-                                    * included) followed for icm by ``inverse_dynamic_net.{0,2,4}`` = mlp(2 z_dim, Hb, relu, Hb, relu,
-                                    * action_dim, tanh); both optimisers of the reference map onto the two lr groups of the FB
+                                    * included) followed by the learner's head mlp(in, Hb, relu, Hb, relu, out) at Sequential indices
+                                    * {0,2,4}: icm ``inverse_dynamic_net`` (2 z_dim -> action_dim, tanh), autoencoder ``decoder``
+                                    * (z_dim -> goal_dim), transition ``forward_dynamic_net`` (z_dim + action_dim -> goal_dim); both optimisers of the reference map onto the two lr groups of the FB
                                     * flat buffer (sf_opt: lr; phi_opt: lr_coef * lr).  The critic loss is the TD regression of
                                     * sf.py:594-626 (hparams.q_loss: scalar Q regression (the reference default) or feature space);
                                     * z is sample_z only (the reference's default mix_ratio = 0; hparams.mix_ratio must be 0);

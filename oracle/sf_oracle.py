@@ -39,13 +39,19 @@ def feature_learner_shapes(cfg: fo.OracleConfig, learner: str):
     out = [("feature_net.0.weight", (Hb, g)), ("feature_net.0.bias", (Hb,)), ("feature_net.1.weight", (Hb,)),
            ("feature_net.1.bias", (Hb,)), ("feature_net.3.weight", (Hb, Hb)), ("feature_net.3.bias", (Hb,)),
            ("feature_net.5.weight", (d, Hb)), ("feature_net.5.bias", (d,))]
-    if learner == "icm":          # mlp(2 z_dim, Hb, 'irelu', Hb, 'irelu', action_dim, 'tanh')
-        out += [("inverse_dynamic_net.0.weight", (Hb, 2 * d)), ("inverse_dynamic_net.0.bias", (Hb,)),
-                ("inverse_dynamic_net.2.weight", (Hb, Hb)), ("inverse_dynamic_net.2.bias", (Hb,)),
-                ("inverse_dynamic_net.4.weight", (a, Hb)), ("inverse_dynamic_net.4.bias", (a,))]
-    elif learner != "lap":
+    if learner in HEADS:          # e.g. icm: mlp(2 z_dim, Hb, 'irelu', Hb, 'irelu', action_dim, 'tanh')
+        name, fin, fout = HEADS[learner](cfg)
+        out += [(f"{name}.0.weight", (Hb, fin)), (f"{name}.0.bias", (Hb,)), (f"{name}.2.weight", (Hb, Hb)), (f"{name}.2.bias", (Hb,)),
+                (f"{name}.4.weight", (fout, Hb)), (f"{name}.4.bias", (fout,))]
+    elif learner not in ("lap", "random"):
         raise NotImplementedError(learner)
     return out
+
+
+# the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) a feature learner trains feature_net through: (module name, in, out)
+HEADS = {"icm": lambda c: ("inverse_dynamic_net", 2 * c.z_dim, c.action_dim),              # sf.py:198 (+ 'tanh')
+         "autoencoder": lambda c: ("decoder", c.z_dim, c.goal_dim),                        # sf.py:253
+         "transition": lambda c: ("forward_dynamic_net", c.z_dim + c.action_dim, c.goal_dim)}   # sf.py:219
 
 
 def net_shapes(cfg: fo.OracleConfig, learner: str):
@@ -69,11 +75,25 @@ def inverse_dynamics(p: Params, phi: torch.Tensor, next_phi: torch.Tensor) -> to
     return torch.tanh(F.linear(h, p["inverse_dynamic_net.4.weight"], p["inverse_dynamic_net.4.bias"]))
 
 
-def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int) -> tp.Dict[str, torch.Tensor]:
+def head_mlp(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
+    h = torch.relu(F.linear(x, p[f"{name}.0.weight"], p[f"{name}.0.bias"]))
+    h = torch.relu(F.linear(h, p[f"{name}.2.weight"], p[f"{name}.2.bias"]))
+    return F.linear(h, p[f"{name}.4.weight"], p[f"{name}.4.bias"])
+
+
+def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int) -> tp.Dict[str, tp.Any]:
     phi, next_phi = feature_net(p, goal, z_dim), feature_net(p, next_goal, z_dim)
     if learner == "icm":                                           # sf.py:203-213
         pred = inverse_dynamics(p, phi, next_phi)
         return {"phi_loss": (action - pred).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred}
+    if learner == "random":                                        # FeatureLearner.forward returns None, sf.py:91-92
+        return {"phi_loss": None, "phi": phi, "next_phi": next_phi}
+    if learner == "autoencoder":                                   # sf.py:256-262
+        pred = head_mlp(p, "decoder", phi)
+        return {"phi_loss": (pred - goal).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred}
+    if learner == "transition":                                    # sf.py:222-227
+        pred = head_mlp(p, "forward_dynamic_net", torch.cat([phi, action], dim=-1))
+        return {"phi_loss": (pred - next_goal).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred}
     loss = (phi - next_phi).pow(2).mean()                          # lap, sf.py:101-116
     Cov = torch.matmul(phi, phi.T)
     off = ~torch.eye(*Cov.size()).bool()
@@ -81,8 +101,14 @@ def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int)
     return {"phi_loss": loss + orth, "phi": phi, "next_phi": next_phi, "orth_loss": orth}
 
 
+def _grad_or_zero(x: torch.Tensor, retained: bool) -> torch.Tensor:
+    g = x.grad if retained else None
+    return g.detach().clone() if g is not None else torch.zeros_like(x).detach()
+
+
 class SFOracleAgent:
-    """State of one SFAgent (sf.py:383-474) and its ``update`` (:700-768) for ``feature_learner`` in {"icm", "lap"}."""
+    """State of one SFAgent (sf.py:383-474) and its ``update`` (:700-768) for ``feature_learner`` in {"icm", "lap", "random",
+    "autoencoder", "transition"}."""
 
     NETS = ("actor", "successor_net", "feature_learner")
 
@@ -131,20 +157,24 @@ class SFOracleAgent:
         pp = self._req(self.feature_learner)
         L = phi_loss_terms(pp, self.learner, goal, action, next_goal, cfg.z_dim)
         if keep:
-            for x in (F1, F2, L["phi"], L["next_phi"]):
+            for x in (F1, F2) + ((L["phi"], L["next_phi"]) if L["phi_loss"] is not None else ()):
                 x.retain_grad()
         metrics.update({                                            # sf.py:627-636
             "target_F": target_F.mean().item(), "F1": F1.mean().item(), "phi": target_phi.mean().item(),
             "phi_norm": torch.norm(target_phi, dim=-1).mean().item(), "z_norm": torch.norm(z, dim=-1).mean().item(),
-            "sf_loss": sf_loss.item(), "phi_loss": L["phi_loss"].item(), "sf_opt_lr": cfg.lr})
+            "sf_loss": sf_loss.item(), "sf_opt_lr": cfg.lr})
+        if L["phi_loss"] is not None:                               # sf.py:634-635
+            metrics["phi_loss"] = L["phi_loss"].item()
         sf_loss.backward()
         gS = {k: v.grad for k, v in sp.items()}
         self.sf_steps += 1
         fo.adam_step(self.successor_net, gS, self.adam["successor_net"]["m"], self.adam["successor_net"]["v"], self.sf_steps, cfg.lr)
-        L["phi_loss"].backward()
-        gP = {k: v.grad for k, v in pp.items()}
-        fo.adam_step(self.feature_learner, gP, self.adam["feature_learner"]["m"], self.adam["feature_learner"]["v"], self.sf_steps,
-                     cfg.lr_coef * cfg.lr)
+        gP: tp.Dict[str, tp.Any] = {}
+        if L["phi_loss"] is not None:                               # sf.py:447-449, 657-660: "random" has no phi_opt
+            L["phi_loss"].backward()
+            gP = {k: v.grad for k, v in pp.items()}
+            fo.adam_step(self.feature_learner, gP, self.adam["feature_learner"]["m"], self.adam["feature_learner"]["v"], self.sf_steps,
+                         cfg.lr_coef * cfg.lr)
 
         # ---------------- update_actor (sf.py:666-694) ------------- #
         ap = self._req(self.actor)
@@ -168,7 +198,10 @@ class SFOracleAgent:
             d = lambda x: x.detach().clone()
             self.last = dict(z=d(z), next_action=d(next_action), nF1=d(nF1), nF2=d(nF2), target_phi=d(target_phi),
                              target_F=d(target_F), F1=d(F1), F2=d(F2), dF1=d(F1.grad), dF2=d(F2.grad), phi=d(L["phi"]),
-                             next_phi=d(L["next_phi"]), dphi=d(L["phi"].grad), dnext_phi=d(L["next_phi"].grad),
+                             next_phi=d(L["next_phi"]),
+                             # (only icm / lap read next_phi; "random" has no feature loss at all)
+                             dphi=_grad_or_zero(L["phi"], L["phi_loss"] is not None),
+                             dnext_phi=_grad_or_zero(L["next_phi"], L["phi_loss"] is not None),
                              grads_successor={k: d(v) for k, v in gS.items()}, grads_feature={k: d(v) for k, v in gP.items()},
                              grads_actor={k: d(v) for k, v in gA.items()}, mu=d(mu), pi_action=d(act),
                              d_premu=d(mu.grad) * (1 - d(mu) ** 2))

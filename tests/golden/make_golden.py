@@ -325,6 +325,8 @@ def sf_state(agent):
         for k, v in getattr(agent, n).state_dict().items():
             out[f"{n}/{k}"] = v.detach().numpy().copy()
     for opt, n in ((agent.actor_opt, "actor"), (agent.sf_opt, "successor_net"), (agent.phi_opt, "feature_learner")):
+        if opt is None:                                   # feature_learner="random": no phi_opt (sf.py:447-449)
+            continue
         for (k, p) in getattr(agent, n).named_parameters():
             st = opt.state.get(p, None)
             if st:
@@ -338,11 +340,29 @@ def sf_fixture(R):
     two feature learners the round targets.  (1) the defaults: feature_learner="icm", q_loss=True (scalar Q regression);
     (2) feature_learner="lap" (Laplacian + orthonormality loss), q_loss=False (regression in feature space), goal space, variable
     episode lengths, lr_coef=5 like the reference default."""
+    _sf_traces(R, (
+        ("tiny_sf_icm_trace", "icm", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0), dict(seed=131, n_eps=6, T=12, n_steps=4)),
+        ("tiny_sf_lap_trace", "lap", False, dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0),
+         dict(seed=132, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True))))
+
+
+def sf_more_fixture(R):
+    """Three more feature learners of sf.py on the same update: "random" (:84-92, 447: feature_net frozen, no phi_opt, no phi_loss
+    metric), "autoencoder" (:249-262, decoder(phi(goal)) vs goal; here with a goal space, so the decoder emits goal_dim columns) and
+    "transition" (:215-227, forward_dynamic_net(cat[phi(goal), action]) vs next_goal); plus their constructors under seed 1."""
+    _sf_traces(R, (
+        ("tiny_sf_random_trace", "random", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0), dict(seed=133, n_eps=6, T=12, n_steps=4)),
+        ("tiny_sf_autoencoder_trace", "autoencoder", False,
+         dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0),
+         dict(seed=134, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)),
+        ("tiny_sf_transition_trace", "transition", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=2.0, mix_ratio=0.0),
+         dict(seed=135, n_eps=6, T=12, n_steps=4))))
+    _sf_inits(R, ("random", "autoencoder", "transition"))
+
+
+def _sf_traces(R, table):
     from oracle import sf_oracle as so
-    for name, learner, q_loss, kw, extra in (
-            ("tiny_sf_icm_trace", "icm", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0), dict(seed=131, n_eps=6, T=12, n_steps=4)),
-            ("tiny_sf_lap_trace", "lap", False, dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0),
-             dict(seed=132, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True))):
+    for name, learner, q_loss, kw, extra in table:
         cfg = tiny_cfg(**kw)
         seed, n_eps, T, n_steps = extra["seed"], extra["n_eps"], extra["T"], extra["n_steps"]
         goal_space, variable_len = extra.get("goal_space"), extra.get("variable_len", False)
@@ -383,23 +403,14 @@ def sf_fixture(R):
                 arrays[f"state/{s_}/{k}"] = v
         (HERE / f"{name}.json").write_text(json.dumps(meta, indent=1))
         np.savez_compressed(HERE / f"{name}.npz", **arrays)
-        print(f"[{name}] sf_loss={[round(m['sf_loss'], 4) for m in meta['metrics']]} phi_loss={[round(m['phi_loss'], 4) for m in meta['metrics']]}")
+        print(f"[{name}] sf_loss={[round(m['sf_loss'], 4) for m in meta['metrics']]} phi_loss={[round(m.get('phi_loss', float('nan')), 4) for m in meta['metrics']]}")
 
 
 def sf_init_fixture(R):
     """SFAgent's constructor under torch.manual_seed(1) (sf.py:419-463: actor, successor_net, successor_target_net, then the
     feature learner, whose ``self.apply(weight_init)`` runs once in FeatureLearner.__init__ and, for icm, AGAIN over every Linear
     in ICM.__init__) for both feature learners; plus a checkpoint-style pickle is not needed here (reference_io covers the format)."""
-    for learner in ("icm", "lap"):
-        cfg = tiny_cfg(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0)
-        torch.manual_seed(1)
-        agent = R.sf.SFAgent(obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cpu",
-                             num_expl_steps=0, use_tb=True, use_wandb=False, use_hiplog=False, update_encoder=True, goal_space=None,
-                             hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
-                             z_dim=cfg.z_dim, batch_size=cfg.batch_size, feature_learner=learner)
-        arrays = {k: v for k, v in sf_state(agent).items()}
-        arrays["torch_version"] = np.array(torch.__version__)
-        np.savez_compressed(HERE / f"init_seed1_tiny_sf_{learner}.npz", **arrays)
+    _sf_inits(R, ("icm", "lap"))
     print("[sf init] ok")
     # a checkpoint written by the reference holding a live SFAgent (icm) after two updates (pretrain.py:437-449)
     cfg = tiny_cfg(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0)
@@ -430,6 +441,19 @@ def sf_init_fixture(R):
     arrays.update(obs=obs, z=zs, act_eval=acts)
     np.savez_compressed(HERE / "ref_checkpoint_sf_expect.npz", **arrays)
     print("[sf checkpoint] ok")
+
+
+def _sf_inits(R, learners):
+    for learner in learners:
+        cfg = tiny_cfg(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0)
+        torch.manual_seed(1)
+        agent = R.sf.SFAgent(obs_type="states", obs_shape=(cfg.obs_dim,), action_shape=(cfg.action_dim,), device="cpu",
+                             num_expl_steps=0, use_tb=True, use_wandb=False, use_hiplog=False, update_encoder=True, goal_space=None,
+                             hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim,
+                             z_dim=cfg.z_dim, batch_size=cfg.batch_size, feature_learner=learner)
+        arrays = {k: v for k, v in sf_state(agent).items()}
+        arrays["torch_version"] = np.array(torch.__version__)
+        np.savez_compressed(HERE / f"init_seed1_tiny_sf_{learner}.npz", **arrays)
 
 
 def long_curve_fixtures(R):
@@ -691,6 +715,7 @@ def main():
     discrete_fixture(R)
     sf_fixture(R)
     sf_init_fixture(R)
+    sf_more_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -223,7 +223,14 @@ def test_sf_layout_follows_the_reference_modules(lib):
     assert names(1) == feat + [("inverse_dynamic_net.0.weight", 20, 20), ("inverse_dynamic_net.0.bias", 1, 20),
                                ("inverse_dynamic_net.2.weight", 20, 20), ("inverse_dynamic_net.2.bias", 1, 20),
                                ("inverse_dynamic_net.4.weight", 3, 20), ("inverse_dynamic_net.4.bias", 1, 3)]
+    head = lambda n, fin, fout: [(f"{n}.0.weight", 20, fin), (f"{n}.0.bias", 1, 20), (f"{n}.2.weight", 20, 20), (f"{n}.2.bias", 1, 20),
+                                 (f"{n}.4.weight", fout, 20), (f"{n}.4.bias", 1, fout)]
+    assert names(3) == feat                                                    # random: feature_net only (sf.py:84-92)
+    assert names(4) == feat + head("decoder", 10, 5)                           # autoencoder: mlp(z, Hb, Hb, goal_dim), sf.py:253
+    assert names(5) == feat + head("forward_dynamic_net", 13, 5)               # transition: mlp(z + a, Hb, Hb, goal_dim), sf.py:219
     assert names(0)[0][0] == "B.0.weight"
+    too = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 0, 0, 6)
+    assert l.fbhip_net_numel(C.byref(too), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)
     bad = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 1, 0, 1)          # boltzmann + sf
     assert l.fbhip_net_numel(C.byref(bad), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)
 
