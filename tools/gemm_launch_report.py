@@ -12,7 +12,7 @@ lines = [l.strip() for l in open(log, errors="ignore") if l.startswith("GEMMLOG"
 rows = sqlite3.connect(db).execute("select name, start, end from kernels order by start").fetchall()
 starts = [i for i, r in enumerate(rows) if "draw_kernel" in r[0]]
 a, b = starts[-2], starts[-1]
-gemms = [r for r in rows[a:b] if "gemm_kernel" in r[0] or "gemm_dma_kernel" in r[0]]
+gemms = [r for r in rows[a:b] if "gemm_kernel" in r[0] or "gemm_dma_kernel" in r[0] or "gemm_thin_kernel" in r[0]]
 n = len(gemms)
 lines = lines[:n]          # the update graph is the first thing captured (bench.py --steps-per-launch 1); later lines: probes
 print(f"{n} GEMM launches per update, {len(lines)} log lines; total GEMM time {sum(r[2]-r[1] for r in gemms)/1e3:.1f} us of step span {(rows[b-1][2]-rows[a][1])/1e3:.1f} us")
