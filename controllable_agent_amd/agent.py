@@ -695,6 +695,7 @@ class FBHipAgent:
                                             v["t1"], int(v["fixed_length"])), self._ctx)
         self._replay_view = v           # keeps the tensors alive while bound
         self._replay_token = token
+        self.__dict__.pop("_dp_graphs", None)       # (captured data-parallel schedules hold the old storage pointers, like the library's own graphs)
 
     def _run_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         self._on_update_stream(lambda: self._launch_update(hp, inject, use_graph))

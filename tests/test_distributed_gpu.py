@@ -391,6 +391,9 @@ def _run_schedule(monkeypatch, graph: bool):
     monkeypatch.setenv("FBHIP_DP_GRAPH", "1" if graph else "0")
     for call in range(3):                                   # the second and third call replay the cached graph
         agent.update_many(rb, 6 * call, 6)
+    # another buffer object (other device pointers): the captured schedule holds the old ones and must be re-captured
+    rb2 = DeviceReplayBuffer.from_arrays({k: v[::-1].copy() for k, v in storage.items()}, lengths[::-1].copy(), cfg.discount, device="cuda")
+    agent.update_many(rb2, 18, 6)
     torch.cuda.synchronize()
     assert bool(getattr(agent, "_dp_graphs", {})) == graph and not getattr(agent, "_dp_graph_failed", False)
     return H.get_agent_state(agent), agent.step_counts()
@@ -402,7 +405,7 @@ def test_dp_schedule_captured_as_one_graph_equals_the_host_issued_schedule(monke
     kernels, operands and order, so bit-identical state, device RNG streams included."""
     s1, c1 = _run_schedule(monkeypatch, graph=False)
     s2, c2 = _run_schedule(monkeypatch, graph=True)
-    assert c1 == c2 == (18, 18)
+    assert c1 == c2 == (24, 24)
     for k in s1:
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
 
