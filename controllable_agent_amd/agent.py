@@ -1257,25 +1257,48 @@ class SFHipAgent(FBHipAgent):
         "random"       feature_net keeps its initial weights: no loss, no phi_opt                         sf.py:84-92, 447
         "autoencoder"  mean((decoder(phi(goal)) - goal)^2)                                                sf.py:249-262
         "transition"   mean((forward_dynamic_net(cat[phi(goal), action]) - next_goal)^2)                  sf.py:215-227
+        "FB"           feature_net = the backward_net of a trained FB agent (``fb_features=``), frozen       sf.py:368-380
 
-    The reference's other eight feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    The reference's other seven feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
-    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5}
+    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3}     # -> fbhip_dims.sf
     # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
     _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
               5: ("forward_dynamic_net", lambda z, a, g: (z + a, g))}
 
-    def __init__(self, **kwargs: tp.Any) -> None:
+    def __init__(self, fb_features: tp.Any = None, **kwargs: tp.Any) -> None:
         cfg = SFAgentConfig(**kwargs)
         bad = [k for k, v in dict(feature_learner=cfg.feature_learner not in self._LEARNERS, boltzmann=cfg.boltzmann,
                                   mix_ratio=cfg.mix_ratio != 0, num_sf_updates=cfg.num_sf_updates != 1).items() if v]
         if bad:
             raise NotImplementedError(f"SFHipAgent: not implemented in the HIP path: {bad} (feature_learner in {sorted(self._LEARNERS)})")
+        if cfg.feature_learner == "FB" and fb_features is None:
+            # FBFeatures (sf.py:368-380) reads a trained FB agent from a path hard-coded in the reference's source
+            raise ValueError('feature_learner="FB" needs fb_features=<checkpoint the reference wrote | an FB agent>: its backward_net '
+                             "becomes the (frozen) feature_net")
         self._sf_mode = self._LEARNERS[cfg.feature_learner]
         self.inv_cov: tp.Optional[torch.Tensor] = None
         super().__init__(**kwargs)
         self.inv_cov = torch.eye(self.cfg.z_dim, dtype=torch.float32, device=self._device)      # sf.py:469
+        if cfg.feature_learner == "FB":
+            self.load_fb_features(fb_features)
+
+    def load_fb_features(self, source: tp.Any) -> None:
+        """``feature_net`` <- ``backward_net`` of a trained FB agent (sf.py:368-380, FBFeatures): ``source`` is a checkpoint file
+        the reference (or ``torch.save`` of a reference agent) wrote, or an agent object (reference placeholder, FBHipAgent).
+        The features stay frozen (sf.py:447: no phi_opt for "FB")."""
+        ref = source
+        if isinstance(source, (str, os.PathLike)):
+            from . import reference_io
+            parts = reference_io.payload_parts(reference_io.load_reference_payload(source))
+            if "agent" not in parts:
+                raise KeyError(f"{source}: no 'agent' in the payload (keys: {sorted(parts)})")
+            ref = parts["agent"]
+        sd = {k: torch.as_tensor(np.asarray(v.detach().cpu() if isinstance(v, torch.Tensor) else v)) for k, v in ref.backward_net.state_dict().items()}
+        if not all(k.startswith("B.") for k in sd):
+            raise KeyError(f"backward_net has unexpected entries {sorted(sd)[:3]}...: not a BackwardMap (fb_modules.py:211-230)")
+        self.feature_learner.load_state_dict({"feature_net." + k[2:]: v for k, v in sd.items()})
 
     def __getstate__(self) -> tp.Dict[str, tp.Any]:
         st = super().__getstate__()

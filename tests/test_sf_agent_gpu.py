@@ -234,3 +234,36 @@ def test_sf_agent_from_reference_checkpoint_file():
     rb = DeviceReplayBuffer.from_reference_file(H.GOLDEN / "ref_checkpoint_tiny_sf.pt", device="cuda")
     m = agent.update(rb, 2)
     assert np.isfinite(m["sf_loss"]) and np.isfinite(m["phi_loss"]) and agent.step_counts() == (3, 3)
+
+
+def test_sf_fb_features_take_the_backward_net_of_a_trained_fb_agent():
+    """feature_learner="FB" (sf.py:368-380, FBFeatures): feature_net is the backward_net of a trained FB agent -- here read from a
+    checkpoint file the reference wrote -- and stays frozen (sf.py:447: no phi_opt); the SF update runs on top of it."""
+    from controllable_agent_amd.agent import FBHipAgent, SFHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    path = H.GOLDEN / "ref_checkpoint_tiny.pt"
+    fb = FBHipAgent.from_reference_checkpoint(path, device="cuda")
+    c = fb.cfg
+    cfg = fo.OracleConfig(obs_dim=fb.obs_dim, action_dim=fb.action_dim, goal_dim=fb.goal_dim, z_dim=c.z_dim, hidden_dim=c.hidden_dim,
+                          feature_dim=c.feature_dim, backward_hidden_dim=c.backward_hidden_dim, batch_size=16, lr=1e-3, lr_coef=5.0,
+                          mix_ratio=0.0)
+    with pytest.raises(ValueError, match="fb_features"):
+        SFHipAgent(**sf_kwargs(cfg, "FB", True))
+    agent = SFHipAgent(fb_features=path, **sf_kwargs(cfg, "FB", True))
+    assert agent.phi_opt is None
+    x = torch.randn(7, fb.goal_dim, generator=torch.Generator().manual_seed(5)).cuda()
+    torch.testing.assert_close(agent.feature_learner.feature_net(x), fb.backward_net(x), rtol=0, atol=0)
+    before = {k: v.clone() for k, v in agent.feature_learner.state_dict().items()}
+    for k, v in fb.backward_net.state_dict().items():
+        torch.testing.assert_close(before["feature_net." + k[2:]], v, rtol=0, atol=0)
+    rng = np.random.default_rng(9)
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg.obs_dim, cfg.action_dim)
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+    for s in range(3):
+        m = agent.update(rb, s)
+    assert np.isfinite(m["sf_loss"]) and "phi_loss" not in m and agent.step_counts() == (3, 3)
+    for k, v in agent.feature_learner.state_dict().items():
+        torch.testing.assert_close(v, before[k], rtol=0, atol=0)
+    # an agent object works as the source too
+    again = SFHipAgent(fb_features=fb, **sf_kwargs(cfg, "FB", True))
+    torch.testing.assert_close(again.feature_learner.feature_net(x), fb.backward_net(x), rtol=0, atol=0)
