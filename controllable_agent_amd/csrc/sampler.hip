@@ -122,7 +122,8 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
     const int e = g.ep_idx[i], s = g.step_idx[i];
 #ifdef FBHIP_DEBUG       // make debug: every gathered row must lie inside its episode of the bound storage
     assert(e >= 0 && e < g.rv.n_episodes && s >= 1 && s < g.rv.t1 && s <= g.rv.episode_len[e]);
-    assert(g.future_idx == nullptr || (g.future_idx[i] >= 1 && g.future_idx[i] <= g.rv.episode_len[e]));
+    // (the hindsight row is storage[ep, future_idx - 1]; the external-batch path keeps it as a third row behind a 2-row episode)
+    assert(g.future_idx == nullptr || (g.future_idx[i] >= 1 && g.future_idx[i] <= g.rv.t1));
     assert(g.perm == nullptr || (g.perm[i] >= 0 && g.perm[i] < g.B));
 #endif
     const size_t t = (size_t)e * g.rv.t1 + s;                         // row of the "next" step
