@@ -1258,11 +1258,13 @@ class SFHipAgent(FBHipAgent):
         "autoencoder"  mean((decoder(phi(goal)) - goal)^2)                                                sf.py:249-262
         "transition"   mean((forward_dynamic_net(cat[phi(goal), action]) - next_goal)^2)                  sf.py:215-227
         "FB"           feature_net = the backward_net of a trained FB agent (``fb_features=``), frozen       sf.py:368-380
+        "svd_p"        P = mu_net(cat[goal, action]) . phi(next_goal)^T:  -2 mean diag P + mean offdiag P^2
+                       + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
-    The reference's other seven feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    The reference's other six feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
-    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3}     # -> fbhip_dims.sf
+    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6}     # -> fbhip_dims.sf
     # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
     _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
               5: ("forward_dynamic_net", lambda z, a, g: (z + a, g))}
@@ -1341,10 +1343,15 @@ class SFHipAgent(FBHipAgent):
             fin, fout = io(d, a, g)
             feat = feat + [(f"{name}.0", torch.nn.Linear(fin, Hb)), (f"{name}.2", torch.nn.Linear(Hb, Hb)), (f"{name}.4", torch.nn.Linear(Hb, fout))]
             ortho(feat)
+        if self._sf_mode == 6:                  # SVDP.__init__ (sf.py:338-342): mu_net = mlp(g + a, Hb, "ntanh", Hb, "relu", z), then weight_init again
+            feat = feat + [("mu_net.0", torch.nn.Linear(g + a, Hb)), ("mu_net.3", torch.nn.Linear(Hb, Hb)), ("mu_net.5", torch.nn.Linear(Hb, d))]
+            ortho(feat)
         sd = {}
         for p_, lin in feat:
             sd[f"{p_}.weight"], sd[f"{p_}.bias"] = lin.weight.data, torch.zeros_like(lin.bias.data)
         sd["feature_net.1.weight"], sd["feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
+        if self._sf_mode == 6:
+            sd["mu_net.1.weight"], sd["mu_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
         nets["feature_learner"] = sd
         return nets
 

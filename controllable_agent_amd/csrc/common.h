@@ -141,13 +141,14 @@ hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm,
                               float ortho_coef, float* dF1, float* dF2, float* dB, float* metrics,
                               float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0,
                               const float* y = nullptr /* + norms, dy: also the backward of B = sqrt(d) y/|y| (rows [.,ld]) */,
-                              const float* norms = nullptr, float* dy = nullptr);
+                              const float* norms = nullptr, float* dy = nullptr,
+                              float out_scale = 1.f /* every gradient (and dy) times this: losses that are a multiple of the FB form */);
 // rows [row_off, row_off + rows) of the same loss on B-row panels (global-batch data parallel); outputs are [rows, ld]
 hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, const float* tF1,
                                     const float* tF2, const float* tB, const float* discount, int B, int d, int ld,
                                     float ortho_coef, int row_off, int rows, float* dF1, float* dF2, float* dB,
                                     float* metrics, float* scratch, hipStream_t s, StepState* adv = nullptr, int adv_which = 0, const float* y = nullptr,
-                                    const float* norms = nullptr, float* dy = nullptr);
+                                    const float* norms = nullptr, float* dy = nullptr, float out_scale = 1.f);
 // dy = (sqrt(d)/||y||) (dB - yhat (yhat . dB))      (F.normalize backward)
 hipError_t launch_l2norm_bwd(const float* dB, int lddb, const float* y, int ldy, const float* norms,
                              float* dy, int lddy, int rows, int d, hipStream_t s);
@@ -188,6 +189,7 @@ hipError_t launch_sf_loss(const float* F1, const float* F2, const float* nF1, co
                           float* scratch, int rows, int d, hipStream_t s);
 // inverse-dynamics loss of the ICM feature learner (sf.py:207-210): pred = tanh(pre), PHI_LOSS = mean((action - pred)^2), d pre;
 // scratch >= ceil(rows * a / 256) floats
+hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hipStream_t s);      // metrics[dst] = scale * metrics[src]
 hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int lda, float* dpre, int ldd, int rows, int a,
                            int squash, float* metrics, float* scratch, hipStream_t s);
 // Laplacian feature learner (sf.py:104-114) on top of pairwise_kernel's orthonormality pass: dphi += d mse, dnext_phi = d mse,

@@ -78,6 +78,10 @@ struct Ws {
     Buf goal2;                          // [2B, g]: bin = rows [0, B), next_goal = rows [B, 2B)
     BSet bsS;                           // feature_net activations, 2B rows
     Buf dBm2, dy2, s_dr2, s_dt1;        // its gradient panels, 2B rows
+    Buf Xga;                            // svd_p: [goal | action] input of mu_net, B rows
+                                        // (mu_net's activations live in bsM, the z-mix set SFAgent does not use: mu = bsM.y)
+    Buf dmu, m_dr2, m_dt1;              // its gradient panels
+    float* ln_partials_m = nullptr;     // its LayerNorm-backward partial sums (it shares rounds with feature_net's backward)
     Buf icat, ih1, ih2, ipre, d_ipre, d_ih1, d_ih2;          // icm: inverse-dynamics activations / gradients
     Buf zeroF, lapS1, lapS2;                                 // lap: the zero F panel and two throw-away dF panels of the pairwise pass
     float* act_in = nullptr;            // batch-1 fast path: [obs | z | 0.. | noise] / [goal | 0.. | z] as staged by the host
@@ -105,6 +109,7 @@ struct ActP { TrunkP o, oz; float *Wt = nullptr, *bt = nullptr; float *W3, *b3, 
 FwdP fwd_p(float* base, const NetLayout& L);
 BwdP bwd_p(float* base, const NetLayout& L);
 IcmP icm_p(float* base, const NetLayout& L);
+BwdP mu_p(float* base, const NetLayout& L);               // svd_p's mu_net (same module structure as BackwardMap.B, no projection)
 ActP act_p(float* base, const NetLayout& L);
 
 struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; int set; };
@@ -132,6 +137,7 @@ struct fbhip_ctx {
     uint32_t rank = 0;
     fbhip::host::FwdP F_p, F_g, F_t;
     fbhip::host::BwdP K_p, K_g, K_t;
+    fbhip::host::BwdP M_p, M_g;                           // dims.sf == 6 (svd_p): mu_net
     fbhip::host::IcmP I_p, I_g;                           // dims.sf == 1
     fbhip::host::ActP A_p, A_g;
     std::vector<fbhip::host::GraphEntry> graphs;
@@ -199,7 +205,7 @@ void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda
                            int disc_ldz = 0);
 int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S, int rows, hipStream_t s);
 void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, Chain& out,
-                            bool with_projection = true);
+                            bool with_projection = true, int in_dim = -1);     // in_dim: input width if not goal_dim (mu_net)
 int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, hipStream_t s);
 void actor_fwd_chain(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float* Xz, int ldz, ASet& S, int rows,
                      Chain& out, bool with_head = true);

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
                                                               float* __restrict__ dF2, float* __restrict__ dB,
                                                               float* __restrict__ metrics, StepState* adv, int adv_which,
                                                               const float* __restrict__ y, const float* __restrict__ norms,
-                                                              float* __restrict__ dy) {
+                                                              float* __restrict__ dy, float out_scale) {
     if (adv != nullptr && blockIdx.x == 0 && threadIdx.x == 255) step_advance_device(adv, adv_which);
     // one wavefront per row (d <= 128: two elements per lane); with ``y`` the backward of B = sqrt(d) y / |y|
     // (dy = (sqrt(d)/|y|)(dB - yhat (yhat . dB)), exactly l2norm_bwd_kernel) follows in the same registers
@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
                         b += base[(size_t)Bp * DP];
                         c += base[(size_t)2 * Bp * DP] + base[(size_t)3 * Bp * DP];
                     }
+                    a *= out_scale; b *= out_scale; c *= out_scale;
                     dF1[(size_t)r * ld + n] = a;
                     dF2[(size_t)r * ld + n] = b;
                     dB[(size_t)r * ld + n] = c;
@@ -447,9 +448,9 @@ hipError_t pairwise_prepare(int B, int d) {
 hipError_t launch_pairwise_fb(const float* F1, const float* F2, const float* Bm, const float* tF1, const float* tF2,
                               const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
                               float* dF1, float* dF2, float* dB, float* metrics, float* scratch, hipStream_t s,
-                              StepState* adv, int adv_which, const float* y, const float* norms, float* dy) {
+                              StepState* adv, int adv_which, const float* y, const float* norms, float* dy, float out_scale) {
     return launch_pairwise_fb_block(F1, F2, Bm, tF1, tF2, tB, discount, B, d, ld, ortho_coef, 0, B, dF1, dF2, dB, metrics,
-                                    scratch, s, adv, adv_which, y, norms, dy);
+                                    scratch, s, adv, adv_which, y, norms, dy, out_scale);
 }
 
 // Rows [row_off, row_off + rows) of the loss on B-row panels: dF_i and dB of THOSE rows (each complete: the workgroups walk
@@ -458,7 +459,7 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
                                     const float* tB, const float* discount, int B, int d, int ld, float ortho_coef,
                                     int row_off, int rows, float* dF1, float* dF2, float* dB, float* metrics,
                                     float* scratch, hipStream_t s, StepState* adv, int adv_which, const float* y,
-                                    const float* norms, float* dy) {
+                                    const float* norms, float* dy, float out_scale) {
     const PwPlan pl = make_plan(B, d, rows);
     if (pl.ks < 0 || B < 2 || rows < 1 || row_off < 0 || row_off + rows > B) return hipErrorInvalidValue;
     if (rows != B && ((row_off & 31) || (rows & 31))) return hipErrorInvalidValue;      // whole 32-row blocks
@@ -493,7 +494,7 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     if (d > 128 || (y != nullptr && (norms == nullptr || dy == nullptr))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a.partial, a.scal,
                        pl.nchunks, pl.nchunks * pl.nI, rows, pl.Bp, d, pl.dp, ld, B, ortho_coef, dF1, dF2, dB, metrics, adv,
-                       adv_which, y, norms, dy);
+                       adv_which, y, norms, dy, out_scale);
     return hipGetLastError();
 }
 

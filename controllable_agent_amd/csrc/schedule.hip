@@ -7,7 +7,7 @@
 namespace fbhip {
 namespace host {
 
-struct BGrad { const float* dBm; float* dy; float* dr2; float* dt1; };
+struct BGrad { const float* dBm; float* dy; float* dr2; float* dt1; float* ln_partials = nullptr; };
 
 
 
@@ -354,10 +354,10 @@ void forward_map_bwd_chain(fbhip_ctx* c, const FwdP& W, const FwdP& G, const flo
 
 // BackwardMap.forward (fb_modules.py:223-230)
 void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, Chain& out,
-                            bool with_projection) {
+                            bool with_projection, int in_dim) {
     const fbhip_dims& d = c->d;
     // GEMMs run on the padded width Lb = pad64(Hb) (zero weight rows / columns), LayerNorm on the logical Hb
-    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
+    const int g = in_dim > 0 ? in_dim : d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
     // workspace panels have >= pad32(g) finite columns per row (the weight's pad columns are zero, so whatever sits
     // there contributes nothing); arbitrary caller tensors are read on their logical width
     const bool in_ws = (const char*)X >= c->ws_lo && (const char*)X < c->ws_lo + c->ws_bytes;
@@ -387,19 +387,22 @@ int backward_map_fwd(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet&
 
 // backward of BackwardMap from dB (gradient wrt the projected embedding)
 // gradient panels of one BackwardMap backward (default: the workspace's B-row set; SFAgent's 2B-row feature pass brings its own)
+// (in_dim > 0: a net of the same structure on another input width and WITHOUT the projection -- svd_p's mu_net: the incoming
+// gradient is wrt y itself and X is a zero-padded workspace panel)
 void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const float* X, int ldx, BSet& S, int rows,
-                            Chain& out, bool dy_done = false, const BGrad* bufs = nullptr) {
+                            Chain& out, bool dy_done = false, const BGrad* bufs = nullptr, int in_dim = -1) {
     const fbhip_dims& d = c->d;
-    const int g = d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
+    const int g = in_dim > 0 ? in_dim : d.goal_dim, Hb = d.backward_hidden_dim, Lb = pad64(Hb), z = d.z_dim, Lz = pad4(z);
     // weight gradient of the first layer: X must be a zero-padded panel to use the padded width
-    const bool padded_x = (X == c->W().next_goal.p) || (X == c->W().bin.p);     // zero-padded panels only
+    const bool padded_x = (X == c->W().next_goal.p) || (X == c->W().bin.p) || in_dim > 0;     // zero-padded panels only
     const int Ng = padded_x ? pad32(g) : g;
     Ws* w = &c->W();
     BSet* Sp = &S;
     const BGrad B_ = bufs ? *bufs : BGrad{w->dBm.p, w->dy.p, w->b_dr2.p, w->b_dt1.p};
-    const float* dy = d.norm_z ? B_.dy : B_.dBm;        // no projection: the gradient wrt y is dB itself
+    const bool projected = d.norm_z && in_dim <= 0;
+    const float* dy = projected ? B_.dy : B_.dBm;       // no projection: the gradient wrt y is dB itself
     out.push_back([=](Ops& o) {                 // dy = d/dy of sqrt(d) normalize(y)   (F.normalize backward)
-        if (!c->d.norm_z || dy_done) return;     // (the stage stays, empty: the chain's thin last round must meet forward_net's)
+        if (!projected || dy_done) return;       // (the stage stays, empty: the chain's thin last round must meet forward_net's)
         o.post.push_back([=](hipStream_t s) -> int {
             HIPCK(c, launch_l2norm_bwd(B_.dBm, Lz, Sp->y.p, Lz, Sp->norms, B_.dy, Lz, rows, z, s));
             return (int)FBHIP_OK;
@@ -414,7 +417,7 @@ void backward_map_bwd_chain(fbhip_ctx* c, const BwdP& W, const BwdP& G, const fl
     });
     out.push_back([=](Ops& o) {
         o.lnb.push_back(LnBwdProblem{B_.dt1, Lb, Sp->t1.p, Lb, Sp->pre1.p, Lb, Sp->stats, W.g1, B_.dt1, Lb, G.g1,
-                                     G.be1, w->ln_partials_b, rows, Hb, 0, 0, 0, 0, 0, pad4(Hb)});
+                                     G.be1, B_.ln_partials ? B_.ln_partials : w->ln_partials_b, rows, Hb, 0, 0, 0, 0, 0, pad4(Hb)});
     });
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(dy, Lz, 0, Sp->r2.p, Lb, 0, G.W3, Lb, z, Lb, rows, nullptr, EPI_NONE, nullptr, 0, G.b3));
@@ -932,6 +935,17 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, ch[2]);
         actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[3], !fused_policy);
         ch[3].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld, &w.as));
+        if (d.sf == 6) {      // svd_p: mu = mu_net(cat[goal, action]) (sf.py:347), the BackwardMap module chain on another input, unprojected
+            ch.emplace_back();
+            const int g = d.goal_dim, act = d.action_dim;
+            ch[4].push_back([=, &w](Ops& o2) {       // (a stage of its own: the panel is built behind the first round, mu_net starts in the second)
+                o2.post.push_back([=, &w](hipStream_t q) -> int {
+                    HIPCK(c, launch_concat2(w.Xga.p, w.Xga.ld, w.goal2.p, w.goal2.ld, g, w.Xoa.p + aoff, w.Xoa.ld, act, B, q));
+                    return (int)FBHIP_OK;
+                });
+            });
+            backward_map_fwd_chain(c, c->M_p, w.Xga.p, w.Xga.ld, w.bsM, B, ch[4], false, g + act);
+        }
         prog_parallel(prog, ch);
     }
     const float* phi = w.bsS.Bm.p;                                    // phi(goal)       rows [0, B)
@@ -987,6 +1001,19 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
             o2.gemms.push_back(P(w.d_ih1.p, Lb, 1, I.W1, Kc, 0, dphi, Lz, B, z, Lb));            // d cat[:, :z]
             if (sfm == 1) o2.gemms.push_back(P(w.d_ih1.p, Lb, 1, I.W1 + z, Kc, 0, dnphi, Lz, B, z, Lb));       // d cat[:, z:2z]
         });
+    } else if (d.sf == 6) {
+        // svd_p (sf.py:344-362): P = mu . phi'^T,  loss = -2 mean diag P + mean offdiag P^2 + orthonormality(phi')  with phi' = phi(next_goal)
+        //   = 2 x [ the FB loss of (F1 = mu, F2 = 0, B = phi', no target) with ortho_coef = 1/2 ]: the pairwise kernel as it is, every
+        // gradient doubled; dF1 is d mu, dB is d phi' (rows [B, 2B) of the feature pass; the goal rows get no gradient)
+        feat.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, hipMemsetAsync(dphi, 0, (size_t)B * Lz * sizeof(float), q));
+                HIPCK(c, launch_pairwise_fb(w.bsM.y.p, w.zeroF.p, nphi, w.zeroF.p, w.zeroF.p, nphi, w.disc, B, z, Lz, 0.5f, w.dmu.p,
+                                            w.lapS2.p, dnphi, w.metrics, w.pw_scratch, q, nullptr, 0, nullptr, nullptr, nullptr, 2.0f));
+                HIPCK(c, launch_scale_metric(w.metrics, FBHIP_M_FB_LOSS, FBHIP_M_PHI_LOSS, 2.0f, q));
+                return (int)FBHIP_OK;
+            });
+        });
     } else if (d.sf == 2) {
         feat.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
@@ -1008,6 +1035,13 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     {
         std::vector<Chain> ch{succ};
         if (d.sf != 3) ch.push_back(feat);
+        if (d.sf == 6) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
+            Chain mu;
+            mu.push_back([](Ops&) {});
+            BGrad mg{w.dmu.p, w.dmu.p, w.m_dr2.p, w.m_dt1.p, w.ln_partials_m};
+            backward_map_bwd_chain(c, c->M_p, c->M_g, w.Xga.p, w.Xga.ld, w.bsM, B, mu, true, &mg, d.goal_dim + d.action_dim);
+            ch.push_back(mu);
+        }
         prog_parallel(prog, ch);
     }
     // ---- sf_opt.step() + phi_opt.step() (sf.py:643-653): one pass over forward ++ backward, lr | lr_coef * lr; the EMA of

@@ -194,6 +194,13 @@ hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int l
     return hipGetLastError();
 }
 
+__global__ void scale_metric_kernel(float* __restrict__ metrics, int src, int dst, float scale) { metrics[dst] = scale * metrics[src]; }
+
+hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_metric_kernel, dim3(1), dim3(1), 0, s, metrics, src, dst, scale);
+    return hipGetLastError();
+}
+
 hipError_t launch_lap(const float* phi, const float* next_phi, int ld, float* dphi, float* dnext_phi, float* metrics,
                       float* scratch, int rows, int d, hipStream_t s) {
     const int nblk = (rows + 3) / 4;

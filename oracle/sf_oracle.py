@@ -43,6 +43,9 @@ def feature_learner_shapes(cfg: fo.OracleConfig, learner: str):
         name, fin, fout = HEADS[learner](cfg)
         out += [(f"{name}.0.weight", (Hb, fin)), (f"{name}.0.bias", (Hb,)), (f"{name}.2.weight", (Hb, Hb)), (f"{name}.2.bias", (Hb,)),
                 (f"{name}.4.weight", (fout, Hb)), (f"{name}.4.bias", (fout,))]
+    elif learner == "svd_p":      # mu_net = mlp(goal_dim + action_dim, Hb, "ntanh", Hb, "relu", z_dim)   (sf.py:340)
+        out += [("mu_net.0.weight", (Hb, g + a)), ("mu_net.0.bias", (Hb,)), ("mu_net.1.weight", (Hb,)), ("mu_net.1.bias", (Hb,)),
+                ("mu_net.3.weight", (Hb, Hb)), ("mu_net.3.bias", (Hb,)), ("mu_net.5.weight", (d, Hb)), ("mu_net.5.bias", (d,))]
     elif learner not in ("lap", "random"):
         raise NotImplementedError(learner)
     return out
@@ -91,6 +94,18 @@ def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int)
     if learner == "autoencoder":                                   # sf.py:256-262
         pred = head_mlp(p, "decoder", phi)
         return {"phi_loss": (pred - goal).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred}
+    if learner == "svd_p":                                         # sf.py:344-362 (the features are those of NEXT_goal)
+        x = torch.cat([goal, action], dim=1)
+        h = F.linear(x, p["mu_net.0.weight"], p["mu_net.0.bias"])
+        h = torch.tanh(F.layer_norm(h, (h.shape[-1],), p["mu_net.1.weight"], p["mu_net.1.bias"], fo.LN_EPS))
+        h = torch.relu(F.linear(h, p["mu_net.3.weight"], p["mu_net.3.bias"]))
+        mu = F.linear(h, p["mu_net.5.weight"], p["mu_net.5.bias"])
+        P = torch.einsum("sd, td -> st", mu, next_phi)
+        off = ~torch.eye(*P.size()).bool()
+        loss = -2 * P.diag().mean() + P[off].pow(2).mean()
+        Cov = torch.matmul(next_phi, next_phi.T)
+        orth = Cov[off].pow(2).mean() - 2 * Cov.diag().mean()
+        return {"phi_loss": loss + orth, "phi": phi, "next_phi": next_phi, "mu": mu, "orth_loss": orth}
     if learner == "transition":                                    # sf.py:222-227
         pred = head_mlp(p, "forward_dynamic_net", torch.cat([phi, action], dim=-1))
         return {"phi_loss": (pred - next_goal).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred}
@@ -108,7 +123,7 @@ def _grad_or_zero(x: torch.Tensor, retained: bool) -> torch.Tensor:
 
 class SFOracleAgent:
     """State of one SFAgent (sf.py:383-474) and its ``update`` (:700-768) for ``feature_learner`` in {"icm", "lap", "random",
-    "autoencoder", "transition"}."""
+    "autoencoder", "transition", "svd_p"}."""
 
     NETS = ("actor", "successor_net", "feature_learner")
 

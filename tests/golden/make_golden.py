@@ -360,6 +360,18 @@ def sf_more_fixture(R):
     _sf_inits(R, ("random", "autoencoder", "transition"))
 
 
+def sf_svdp_fixture(R):
+    """feature_learner="svd_p" (SVDP, sf.py:337-362; the paper's LRA-P): a second net mu_net on cat[goal, action], the low-rank
+    loss on P = mu . phi(next_goal)^T plus the orthonormality loss of phi(next_goal).  Once with the defaults, once with a goal
+    space + variable episode lengths + the feature-space critic loss; and the constructor under seed 1."""
+    _sf_traces(R, (
+        ("tiny_sf_svdp_trace", "svd_p", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0), dict(seed=136, n_eps=6, T=12, n_steps=4)),
+        ("tiny_sf_svdp_goal_trace", "svd_p", False,
+         dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0),
+         dict(seed=137, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True))))
+    _sf_inits(R, ("svd_p",))
+
+
 def _sf_traces(R, table):
     from oracle import sf_oracle as so
     for name, learner, q_loss, kw, extra in table:
@@ -716,6 +728,7 @@ def main():
     sf_fixture(R)
     sf_init_fixture(R)
     sf_more_fixture(R)
+    sf_svdp_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -60,7 +60,8 @@ def set_sf_state(agent, state: dict, steps: int) -> None:
     agent.set_step_counts(steps, steps)
 
 
-@pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace"])
+@pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
+                                  "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace"])
 def test_sf_teacher_forced_against_reference_trace(name):
     """Each step starts from the REFERENCE SFAgent's recorded state, runs one HIP update with the recorded draws and must land
     on the reference's next state and metrics; intermediates and gradients are compared with the oracle's autograd."""
@@ -87,14 +88,12 @@ def test_sf_teacher_forced_against_reference_trace(name):
         for view, ref in (("dF1", L["dF1"]), ("dF2", L["dF2"]), ("d_premu", L["d_premu"])):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < GRAD_REL_L2, (s, view)
         dphi2 = agent.workspace_view("dphi2").cpu()
-        if learner == "random":                              # no feature loss: nothing flows into feature_net (sf.py:447-449)
-            assert float(dphi2.abs().max()) == 0.0
-        else:
-            assert H.rel_err(dphi2[:B], L["dphi"]) < GRAD_REL_L2, s
-            if float(L["dnext_phi"].abs().max()) == 0.0:     # autoencoder / transition never read next_phi
-                assert float(dphi2[B:].abs().max()) == 0.0, s
+        # "random" has no feature loss (sf.py:447-449); autoencoder / transition never read next_phi, svd_p never reads phi
+        for got, ref in ((dphi2[:B], L["dphi"]), (dphi2[B:], L["dnext_phi"])):
+            if float(ref.abs().max()) == 0.0:
+                assert float(got.abs().max()) == 0.0, s
             else:
-                assert H.rel_err(dphi2[B:], L["dnext_phi"]) < GRAD_REL_L2, s
+                assert H.rel_err(got, ref) < GRAD_REL_L2, s
         for net, key in (("successor_net", "grads_successor"), ("feature_learner", "grads_feature"), ("actor", "grads_actor")):
             for k, g in agent._grad_views[net].state_dict().items():
                 ref = L[key].get(k, torch.zeros(1)) if learner == "random" else L[key][k]
@@ -118,7 +117,8 @@ def test_sf_teacher_forced_against_reference_trace(name):
 
 @pytest.mark.parametrize("learner,q_loss,goal", [("icm", True, False), ("lap", False, True), ("icm", False, True), ("lap", True, False),
                                                  ("random", True, False), ("autoencoder", False, True), ("autoencoder", True, False),
-                                                 ("transition", True, False), ("transition", False, True)])
+                                                 ("transition", True, False), ("transition", False, True), ("svd_p", True, False),
+                                                 ("svd_p", False, True)])
 def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal):
     """hidden 1024 / feature 512 / Hb 512 (the reference defaults), z 100, batch 256, walker-sized inputs: three free-running
     updates against the oracle (metrics + parameter checksums)."""
@@ -149,7 +149,7 @@ def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal)
             assert float(np.linalg.norm(got[k])) == pytest.approx(float(np.linalg.norm(v)), rel=2e-5 if v.ndim == 2 else 2e-4), k
 
 
-@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition"])
+@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p"])
 def test_sf_constructor_init_matches_reference_seed(learner):
     """same torch.manual_seed => SFAgent's orthogonal init tensor for tensor (sf.py:419-463; ICM re-applies weight_init)"""
     z = np.load(H.GOLDEN / f"init_seed1_tiny_sf_{learner}.npz")
