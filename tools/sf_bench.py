@@ -86,7 +86,7 @@ def main():
            "config": {"workload": f"sf offline (SFAgent defaults, feature_learner={args.learner}, q_loss on): obs 24, action 6, z_dim 100, "
                                   "hidden 1024, feature 512, backward hidden 512, batch 1024; 5000 x 1000 synthetic replay in HBM; "
                                   "metrics off in the timed loop", "steps_per_graph_launch": spl,
-                      "metrics_after": {k: m[k] for k in ("sf_loss", "phi_loss", "actor_loss", "phi_norm", "z_norm")}},
+                      "metrics_after": {k: m[k] for k in ("sf_loss", "phi_loss", "actor_loss", "phi_norm", "z_norm") if k in m}},
            "roofline": {"bound": "mfma", "achieved": gf * rate / 1e3, "peak": bench.PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": gf * rate / 1e3 / bench.PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                         "what": f"whole update step: {gf:.2f} algorithmic GFLOP/update x measured updates/s vs the exact-fp32 MFMA peak"}}
