@@ -324,7 +324,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     // updates/s.  (Zipping the two programs round by round into the SAME launches instead was slower, 933/s: one tile
     // configuration per launch makes the thin GEMMs of one program stragglers of the other's fat ones.)
     static const bool pipelined = [] { const char* e = getenv("FBHIP_UPDATE_PIPELINE"); return !(e && e[0] == '0'); }();
-    const bool pipe = pipelined && n_steps > 1 && !c->d.discrete && !c->d.sf;   // (discrete: no actor phase to overlap with)
+    const bool pipe = pipelined && n_steps > 1 && !c->d.discrete;               // (discrete: no actor phase to overlap with)
     if (pipe) {
         if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         while ((int)c->events.size() < 3 * 64) {

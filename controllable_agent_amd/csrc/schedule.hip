@@ -872,7 +872,10 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 // buffer); the actor phase (sf.py:666-694) and the target EMA are FBDDPGAgent's and come from build_update.
 #define POST_BEGIN prog_post(prog, [=, &w](hipStream_t s) -> int {
 #define POST_END return (int)FBHIP_OK; });
-int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, Program& prog) {
+// head: sampling + the passes that depend on the previous step only through its optimiser steps (online successor_net,
+// feature_net [, mu_net]) -- what the pipelined multi-step graph runs on its second branch beside the previous actor phase;
+// mid: target chain, the actor's own pass, losses, backward passes, sf_opt / phi_opt steps.  Both: one complete update_sf.
+int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, Program& prog, bool head, bool mid) {
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
@@ -885,6 +888,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     }
     // ---- sample: the FB sampler with the identity permutation: goal2 = [goal ; next_goal] (sf.py:705-721), z = sample_z (:723)
     const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->z_gauss && inj->eps_next && inj->eps_actor;
+    if (head) {
     POST_BEGIN
     if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, -1.f, 1, s));
     if (inj != nullptr) {
@@ -906,6 +910,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     HIPCK(c, launch_mix_z(w.so.z_gauss, z, nullptr, Lz, w.so.mix_uniform, 0.f, w.z.p, Lz, w.Xoz.p, w.Xoz.ld, w.Xnoz.p, w.Xnoz.ld,
                           o, B, z, w.st, nullptr, nullptr, 0.f, nullptr, 2, zx, s));
     POST_END
+    }
 
     // ---- forward passes: target chain (actor(next_obs) -> next_action -> successor_target), online successor_net, the
     // feature pass on [goal ; next_goal], and update_actor's own actor pass (it reads only the actor weights)
@@ -927,16 +932,21 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         };
     };
     {
-        std::vector<Chain> ch(4);
-        actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.asT, B, ch[0], !fused_policy);
-        ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
-        forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
-        forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
-        backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, ch[2]);
-        actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[3], !fused_policy);
-        ch[3].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld, &w.as));
-        if (d.sf == 6) {      // svd_p: mu = mu_net(cat[goal, action]) (sf.py:347), the BackwardMap module chain on another input, unprojected
-            ch.emplace_back();
+        std::vector<Chain> ch(5);                // (empty chains contribute nothing; the order keeps the one-call launches as they were)
+        if (mid) {
+            actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.asT, B, ch[0], !fused_policy);
+            ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
+            forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
+        }
+        if (head) {
+            forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
+            backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, ch[2]);
+        }
+        if (mid) {
+            actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[3], !fused_policy);
+            ch[3].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld, &w.as));
+        }
+        if (d.sf == 6 && head) {      // svd_p: mu = mu_net(cat[goal, action]) (sf.py:347), the BackwardMap module chain on another input, unprojected
             const int g = d.goal_dim, act = d.action_dim;
             ch[4].push_back([=, &w](Ops& o2) {       // (a stage of its own: the panel is built behind the first round, mu_net starts in the second)
                 o2.post.push_back([=, &w](hipStream_t q) -> int {
@@ -948,6 +958,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         }
         prog_parallel(prog, ch);
     }
+    if (!mid) return FBHIP_OK;
     const float* phi = w.bsS.Bm.p;                                    // phi(goal)       rows [0, B)
     const float* nphi = w.bsS.Bm.p + (size_t)B * Lz;                  // phi(next_goal)  rows [B, 2B)
     float* dphi = w.dBm2.p;
@@ -1070,9 +1081,16 @@ int enqueue_actor_v(fbhip_ctx* c, hipStream_t s) {
 int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s) {
     Program prog;
     if (c->d.sf) {
-        if (mask != FBHIP_PHASE_ALL) { c->err = g_err = "fbhip: dims.sf runs complete updates only (phase_mask = FBHIP_PHASE_ALL)"; return FBHIP_E_INVALID; }
-        RC(build_update_sf(c, hp, inj, prog));
-        RC(build_update(c, hp, nullptr, FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP, prog));      // sf.py:666-694
+        // a complete update, or one of the three groups the pipelined multi-step graph cuts it into
+        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE, TAIL = FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP;
+        const int MID = FBHIP_PHASE_ALL & ~HEAD & ~TAIL;
+        const bool head = (mask & HEAD) == HEAD, mid = (mask & MID) == MID, tail = (mask & TAIL) == TAIL;
+        if (mask != ((head ? HEAD : 0) | (mid ? MID : 0) | (tail ? TAIL : 0)) || (head && tail && !mid)) {
+            c->err = g_err = "fbhip: dims.sf runs a complete update or its head / middle / actor-phase group (phase_mask)";
+            return FBHIP_E_INVALID;
+        }
+        if (head || mid) RC(build_update_sf(c, hp, inj, prog, head, mid));
+        if (tail) RC(build_update(c, hp, nullptr, TAIL, prog));                                         // sf.py:666-694
         return run_program(c, prog, s);
     }
     RC(build_update(c, hp, inj, mask, prog));

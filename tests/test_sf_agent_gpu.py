@@ -267,3 +267,22 @@ def test_sf_fb_features_take_the_backward_net_of_a_trained_fb_agent():
     # an agent object works as the source too
     again = SFHipAgent(fb_features=fb, **sf_kwargs(cfg, "FB", True))
     torch.testing.assert_close(again.feature_learner.feature_net(x), fb.backward_net(x), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_sf_lap_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace", "tiny_sf_svdp_goal_trace",
+                                  "tiny_sf_random_trace"])
+def test_sf_pipelined_update_many_equals_single_updates(name):
+    """fbhip_update_many cuts an SF update into head (sampling, online successor_net, feature_net [, mu_net]), middle and actor phase
+    and runs the next step's head beside the actor phase: same kernels and operands, so the state after n pipelined steps equals n
+    single updates bit for bit at these dimensions, for every feature learner's schedule."""
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs(name)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    a1 = make_sf_agent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"], meta["goal_space"], metrics=False)
+    a2 = pickle.loads(pickle.dumps(a1))
+    a1.update_many(rb, 0, 5)
+    for s in range(5):
+        a2.update(rb, s)
+    s1, s2 = get_sf_state(a1), get_sf_state(a2)
+    assert a1.step_counts() == a2.step_counts() == (5, 5)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
