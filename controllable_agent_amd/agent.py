@@ -1458,10 +1458,11 @@ class SFHipAgent(FBHipAgent):
     # ---- the hot path
     def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float, future: float = 1.0) -> HParams:
         c = self.cfg
-        if self._world() > 1:
-            raise NotImplementedError("SFHipAgent: single rank only (the data-parallel schedules cover the FB agents)")
+        if self._world() > 1 and (getattr(c, "dp_global_batch", False) or os.environ.get("FBHIP_DP_ALLREDUCE", "rccl").lower() == "peer"):
+            raise NotImplementedError("SFHipAgent: data parallel = gradient averaging with host-issued all-reduces only")
+        # (grad_scale = 1 / world: the data-parallel schedule sums the ranks' gradient buckets, the optimiser passes average them)
         return HParams(lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.sf_target_tau, stddev=schedule(c.stddev_schedule, step),
-                       stddev_clip=c.stddev_clip, ortho_coef=1.0, mix_ratio=0.0, q_loss_coef=0.0, discount=discount, grad_scale=1.0,
+                       stddev_clip=c.stddev_clip, ortho_coef=1.0, mix_ratio=0.0, q_loss_coef=0.0, discount=discount, grad_scale=float(grad_scale),
                        q_loss=int(bool(c.q_loss)), want_metrics=int(want_metrics), future_ratio=0.0, future=float(future), rand_weight=0)
 
     def _metrics(self) -> tp.Dict[str, float]:                           # sf.py:627-639, 688-692
@@ -1479,9 +1480,14 @@ class SFHipAgent(FBHipAgent):
             out["actor_loss"], out["actor_logprob"] = g("actor_loss"), g("actor_logprob")
         return out
 
+    def _early_grad_range(self) -> tp.Optional[tp.Tuple[int, int]]:
+        return None                              # (one all-reduce per bucket: the SF backward is not cut for an early share)
+
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         c = self.cfg
+        # (data parallel: single updates, each through the phase-split schedule with its two gradient all-reduces)
         if (n_steps < 2 or not isinstance(replay_loader, DeviceReplayBuffer) or c.update_every_steps != 1 or not self._use_graph or
+                self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or
                 len({schedule(c.stddev_schedule, step + i) for i in range(n_steps)}) != 1):
             out: tp.Dict[str, float] = {}
             for i in range(n_steps):

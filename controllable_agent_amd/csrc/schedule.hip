@@ -874,8 +874,9 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
 #define POST_END return (int)FBHIP_OK; });
 // head: sampling + the passes that depend on the previous step only through its optimiser steps (online successor_net,
 // feature_net [, mu_net]) -- what the pipelined multi-step graph runs on its second branch beside the previous actor phase;
-// mid: target chain, the actor's own pass, losses, backward passes, sf_opt / phi_opt steps.  Both: one complete update_sf.
-int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, Program& prog, bool head, bool mid) {
+// mid: target chain, the actor's own pass, losses, backward passes; step: sf_opt / phi_opt steps + the target EMA (a data-parallel
+// host all-reduces the gradient bucket in between).  All three: one complete update_sf.
+int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, Program& prog, bool head, bool mid, bool step) {
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, g = d.goal_dim, z = d.z_dim, H = d.hidden_dim,
@@ -958,7 +959,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         }
         prog_parallel(prog, ch);
     }
-    if (!mid) return FBHIP_OK;
+    if (mid) {
     const float* phi = w.bsS.Bm.p;                                    // phi(goal)       rows [0, B)
     const float* nphi = w.bsS.Bm.p + (size_t)B * Lz;                  // phi(next_goal)  rows [B, 2B)
     float* dphi = w.dBm2.p;
@@ -1055,6 +1056,8 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         }
         prog_parallel(prog, ch);
     }
+    }
+    if (!step) return FBHIP_OK;
     // ---- sf_opt.step() + phi_opt.step() (sf.py:643-653): one pass over forward ++ backward, lr | lr_coef * lr; the EMA of
     // successor_target_net (sf.py:751-752) rides along like FBDDPGAgent's (nothing reads a target before the next update)
     POST_BEGIN
@@ -1082,15 +1085,19 @@ int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* in
     Program prog;
     if (c->d.sf) {
         // a complete update, or one of the three groups the pipelined multi-step graph cuts it into
-        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE, TAIL = FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP;
-        const int MID = FBHIP_PHASE_ALL & ~HEAD & ~TAIL;
-        const bool head = (mask & HEAD) == HEAD, mid = (mask & MID) == MID, tail = (mask & TAIL) == TAIL;
-        if (mask != ((head ? HEAD : 0) | (mid ? MID : 0) | (tail ? TAIL : 0)) || (head && tail && !mid)) {
-            c->err = g_err = "fbhip: dims.sf runs a complete update or its head / middle / actor-phase group (phase_mask)";
+        // a complete update, the three groups the pipelined multi-step graph cuts it into, or the data-parallel cuts: the
+        // gradient passes and the two optimiser steps are separable (head | gradients | sf/phi step | actor gradient | actor step,
+        // in this order; each group whole)
+        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
+        const int GRAD = FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD;
+        const bool head = (mask & HEAD) == HEAD, grad = (mask & GRAD) == GRAD, step = (mask & FBHIP_PHASE_FB_STEP) != 0;
+        const int tail = mask & (FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP);
+        if ((mask & HEAD) != (head ? HEAD : 0) || (mask & GRAD) != (grad ? GRAD : 0) || mask == 0 || (mask & ~FBHIP_PHASE_ALL)) {
+            c->err = g_err = "fbhip: dims.sf runs whole phase groups only: SAMPLE|FB_FWD_ONLINE, FB_FWD_TARGET|FB_BWD|ACTOR_FWD, FB_STEP, ACTOR_GRAD, ACTOR_STEP";
             return FBHIP_E_INVALID;
         }
-        if (head || mid) RC(build_update_sf(c, hp, inj, prog, head, mid));
-        if (tail) RC(build_update(c, hp, nullptr, TAIL, prog));                                         // sf.py:666-694
+        if (head || grad || step) RC(build_update_sf(c, hp, inj, prog, head, grad, step));
+        if (tail) RC(build_update(c, hp, nullptr, tail, prog));                                         // sf.py:666-694
         return run_program(c, prog, s);
     }
     RC(build_update(c, hp, inj, mask, prog));

@@ -445,3 +445,62 @@ def test_dp_schedule_graph_captures_rccl_collectives_with_one_rank():
         got[g] = state
     for k in got[False]:
         np.testing.assert_array_equal(got[False][k], got[True][k], err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------ the SF sibling, data parallel
+def _sf_inputs():
+    from tests.test_oracle_golden import sf_trace_inputs
+    from tests.test_sf_agent_gpu import make_sf_agent, _buffer
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_svdp_trace")
+    agent = make_sf_agent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"], meta["goal_space"])
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)              # NOT sharded: every rank sees the same batches
+    draws = [H.draws_dict(fo.Draws(**{f: z[f"draws/{s}/{f}"] for f in fo.Draws.__dataclass_fields__ if f"draws/{s}/{f}" in z.files}))
+             for s in range(3)]
+    return agent, rb, draws
+
+
+def _worker_sf(rank, port, out_q):
+    import torch.distributed as dist
+    from tests.test_sf_agent_gpu import get_sf_state
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    torch.manual_seed(4321)
+    agent, rb, draws = _sf_inputs()
+    for s, d in enumerate(draws):
+        agent.update_injected(rb, s, d)
+    torch.cuda.synchronize()
+    after3 = get_sf_state(agent)
+    agent.update_many(rb, 3, 2)                                           # (falls back to data-parallel single updates; device-drawn)
+    torch.cuda.synchronize()
+    out_q.put((rank, after3, get_sf_state(agent), agent.step_counts()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sf_agent_two_ranks_average_gradients():
+    """SFHipAgent under the data-parallel schedule (gradients | all-reduce | sf_opt + phi_opt step, actor gradient | all-reduce |
+    actor step): two ranks fed IDENTICAL batches average two equal gradients -- (g + g) / 2 is exact in fp32 -- so both must land
+    on the state of ONE process running the same three updates (to the fp32 summation order of the regrouped launches), and the
+    replicas stay bit-identical, also through the device-drawn update_many that follows (same seed, unsharded buffer)."""
+    import torch.multiprocessing as mp
+    from tests.test_sf_agent_gpu import get_sf_state
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = T._free_port()
+    procs = [ctx.Process(target=_worker_sf, args=(r, port, q)) for r in range(T.WORLD)]
+    for p in procs:
+        p.start()
+    got = {r: (a3, fin, cnt) for r, a3, fin, cnt in (q.get(timeout=300) for _ in range(T.WORLD))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][2] == got[1][2] == (5, 5)
+    for which in (0, 1):
+        for k in got[0][which]:
+            np.testing.assert_array_equal(got[0][which][k], got[1][which][k], err_msg=k)
+    agent, rb, draws = _sf_inputs()
+    for s, d in enumerate(draws):
+        agent.update_injected(rb, s, d)
+    ref = get_sf_state(agent)
+    for k, v in ref.items():
+        np.testing.assert_allclose(got[0][0][k], v, rtol=0, atol=3e-6, err_msg=k)

@@ -286,3 +286,25 @@ def test_sf_pipelined_update_many_equals_single_updates(name):
     assert a1.step_counts() == a2.step_counts() == (5, 5)
     for k in s1:
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_svdp_goal_trace"])
+def test_sf_phase_split_schedule_equals_single_call(name, monkeypatch):
+    """The data-parallel cut of an SF update (gradients | sf_opt + phi_opt step + actor gradient | actor step, distributed.dp_update)
+    on one rank against the single-graph update on the same draws: launches group differently, so fp32 tolerance."""
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs(name)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    a1, a2 = (make_sf_agent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"], meta["goal_space"]) for _ in range(2))
+    for s in range(3):
+        d = H.draws_dict(fo.Draws(**{f: z[f"draws/{s}/{f}"] for f in fo.Draws.__dataclass_fields__ if f"draws/{s}/{f}" in z.files}))
+        monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+        m1 = a1.update_injected(rb, s, d)
+        monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+        m2 = a2.update_injected(rb, s, d)
+        for k in m1:
+            assert m2[k] == pytest.approx(m1[k], rel=2e-5, abs=1e-6), (s, k)
+    monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+    s1, s2 = get_sf_state(a1), get_sf_state(a2)
+    assert a1.step_counts() == a2.step_counts() == (3, 3)
+    for k in s1:
+        np.testing.assert_allclose(s2[k], s1[k], rtol=0, atol=3e-6, err_msg=k)
