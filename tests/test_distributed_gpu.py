@@ -313,7 +313,7 @@ def test_bench_two_rank_rehearsal_at_walker_dims_keeps_replicas_identical():
 
 
 # ------------------------------------------------------------------------------------------ peer-access all-reduce (in-graph)
-def _worker_peer(rank, port, out_q, mode):
+def _worker_peer(rank, port, out_q, mode, world=T.WORLD):
     """``mode`` "peer": FBHIP_DP_ALLREDUCE=peer -- the ranks map each other's gradient buckets (hipIpc) and every data-parallel
     step is ONE graph launch per rank with the all-reduce kernels inside (csrc/peer.hip);  "host": the default schedule with
     torch.distributed (gloo here) between the phase graphs.  Same seeds, same shards, device-drawn batches."""
@@ -322,11 +322,11 @@ def _worker_peer(rank, port, out_q, mode):
     from controllable_agent_amd.replay import DeviceReplayBuffer
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_DP_ALLREDUCE="peer" if mode == "peer" else "rccl",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg, nets, storage, lengths = T._setup()
     torch.manual_seed(4321)                   # the agent's device RNG key is torch.initial_seed(): same batches in both modes
     agent = H.make_hip_agent(cfg, nets, metrics=False)
-    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, T.WORLD)
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda").shard(rank, world)
     agent.update(rb, 0)                       # one single step (n = 1 graph) ...
     agent.update_many(rb, 1, 5)               # ... then five pipelined ones in one launch, twice (graph replay)
     agent.update_many(rb, 6, 5)
@@ -347,19 +347,31 @@ def _worker_peer(rank, port, out_q, mode):
     dist.destroy_process_group()
 
 
-def _run_peer(mode):
+def _run_peer(mode, world=T.WORLD):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = T._free_port()
-    procs = [ctx.Process(target=_worker_peer, args=(r, port, q, mode)) for r in range(T.WORLD)]
+    procs = [ctx.Process(target=_worker_peer, args=(r, port, q, mode, world)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=300) for _ in range(T.WORLD)), key=lambda t: t[0])
+    got = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     return got
+
+
+def test_peer_allreduce_with_four_ranks():
+    """the same kernels with world 4 (four processes sharing the GPU): chunking of the bucket over four owners, four flag slots
+    per barrier -- replicas bit-identical, no barrier timeout, a known pattern summed exactly"""
+    res = _run_peer("peer", world=4)
+    assert all(r[2] == (11, 11) for r in res)
+    for r in res[1:]:
+        for k in res[0][1]:
+            np.testing.assert_array_equal(res[0][1][k], r[1][k], err_msg=k)
+    assert all(r[3] == 0 for r in res), "a peer barrier timed out"
+    assert all(r[4] == (10.0, 10.0, 0) for r in res), [r[4] for r in res]
 
 
 def test_peer_allreduce_inside_the_graph_equals_the_host_schedule():
