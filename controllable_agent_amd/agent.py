@@ -735,7 +735,9 @@ class FBHipAgent:
             cap = self._stream if cur.cuda_stream == 0 else cur
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g, stream=cap):
+                # (thread_local: c10d's watchdog thread polls its events with cudaEventQuery while we capture; in the default
+                # global mode that call from another thread would invalidate the capture)
+                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
                     launch(0)                            # eager phase launches: they become nodes of THIS graph
             except Exception as e:                       # noqa: BLE001 -- any refusal (transport, driver) falls back for good
                 self._dp_graph_failed = True
