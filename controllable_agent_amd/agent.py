@@ -1260,16 +1260,18 @@ class SFHipAgent(FBHipAgent):
         "autoencoder"  mean((decoder(phi(goal)) - goal)^2)                                                sf.py:249-262
         "transition"   mean((forward_dynamic_net(cat[phi(goal), action]) - next_goal)^2)                  sf.py:215-227
         "FB"           feature_net = the backward_net of a trained FB agent (``fb_features=``), frozen       sf.py:368-380
+        "latent"       mean((forward_dynamic_net(cat[phi(goal), action]) - target_feature_net(next_goal))^2), the
+                       target net following feature_net at rate 0.01                                          sf.py:230-246
         "svd_p"        P = mu_net(cat[goal, action]) . phi(next_goal)^T:  -2 mean diag P + mean offdiag P^2
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
-    The reference's other six feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    The reference's other five feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
-    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6}     # -> fbhip_dims.sf
+    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7}     # -> fbhip_dims.sf
     # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
     _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
-              5: ("forward_dynamic_net", lambda z, a, g: (z + a, g))}
+              5: ("forward_dynamic_net", lambda z, a, g: (z + a, g)), 7: ("forward_dynamic_net", lambda z, a, g: (z + a, z))}
 
     def __init__(self, fb_features: tp.Any = None, **kwargs: tp.Any) -> None:
         cfg = SFAgentConfig(**kwargs)
@@ -1344,9 +1346,16 @@ class SFHipAgent(FBHipAgent):
             name, io = self._HEADS[self._sf_mode]
             fin, fout = io(d, a, g)
             feat = feat + [(f"{name}.0", torch.nn.Linear(fin, Hb)), (f"{name}.2", torch.nn.Linear(Hb, Hb)), (f"{name}.4", torch.nn.Linear(Hb, fout))]
-            ortho(feat)
+            if self._sf_mode != 7:               # (latent builds one more net before its second weight_init, below)
+                ortho(feat)
         if self._sf_mode == 6:                  # SVDP.__init__ (sf.py:338-342): mu_net = mlp(g + a, Hb, "ntanh", Hb, "relu", z), then weight_init again
             feat = feat + [("mu_net.0", torch.nn.Linear(g + a, Hb)), ("mu_net.3", torch.nn.Linear(Hb, Hb)), ("mu_net.5", torch.nn.Linear(Hb, d))]
+            ortho(feat)
+        if self._sf_mode == 7:                  # TransitionLatentModel.__init__ (sf.py:231-236): forward_dynamic_net (above), then target_feature_net --
+            # its OWN random weights, never a copy of feature_net -- and weight_init over all three
+            tgt = [("target_feature_net.0", torch.nn.Linear(g, Hb)), ("target_feature_net.3", torch.nn.Linear(Hb, Hb)),
+                   ("target_feature_net.5", torch.nn.Linear(Hb, d))]
+            feat = feat + tgt
             ortho(feat)
         sd = {}
         for p_, lin in feat:
@@ -1354,6 +1363,8 @@ class SFHipAgent(FBHipAgent):
         sd["feature_net.1.weight"], sd["feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
         if self._sf_mode == 6:
             sd["mu_net.1.weight"], sd["mu_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
+        if self._sf_mode == 7:
+            sd["target_feature_net.1.weight"], sd["target_feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
         nets["feature_learner"] = sd
         return nets
 
@@ -1365,6 +1376,14 @@ class SFHipAgent(FBHipAgent):
         fwd._name, tgt._name = "successor_net", "successor_target_net"
         self.feature_learner = FeatureLearnerView("feature_learner", bwd._flat, self._layout_of(1),
                                                   forward=lambda x: self._backward_map(x, target=False))
+        if self._sf_mode == 7:
+            # latent (sf.py:234): ``feature_learner.target_feature_net`` is the feature block of the TARGET buffer -- a parameter-less
+            # module to the optimiser (it never has gradients), part of ``feature_learner.state_dict()`` for checkpoints
+            tb = self.backward_target_net
+            for k, v in tb._views.items():
+                if k.startswith("feature_net."):
+                    self.feature_learner._views["target_" + k] = v
+            self.feature_learner._pads += tb._pads
         self._adam_views["successor_net"] = self._adam_views["forward_net"]
         self._adam_views["feature_learner"] = self._adam_views["backward_net"]
         self._grad_views["successor_net"], self._grad_views["feature_learner"] = self._grad_views["forward_net"], self._grad_views["backward_net"]
@@ -1387,11 +1406,13 @@ class SFHipAgent(FBHipAgent):
 
     def load_nets(self, nets: tp.Mapping[str, tp.Mapping[str, tp.Any]], copy_targets: bool = True) -> None:
         self._replicas_verified = False
-        for n in ("actor", "successor_net", "feature_learner"):
+        for n in ("actor", "successor_net"):
             if n in nets:
                 getattr(self, n).load_state_dict(nets[n])
         if copy_targets:
             self._fb_targets.copy_(self._fb_params)                      # successor_target_net := successor_net (sf.py:451)
+        if "feature_learner" in nets:                                    # (after the copy: latent's target_feature_net lives in the target buffer)
+            self.feature_learner.load_state_dict(nets["feature_learner"])
         if "successor_target_net" in nets:
             self.successor_target_net.load_state_dict(nets["successor_target_net"])
 

@@ -222,7 +222,9 @@ __device__ inline void step_advance_device(StepState* st, int which) {
 hipError_t launch_step_advance(StepState* st, int which /*0 fb, 1 actor, 2 rng*/, hipStream_t s);
 hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel,
                            float lr, float lr2, int64_t split, float grad_scale, float tau,
-                           const StepState* st, int which, int t_explicit, hipStream_t s);
+                           const StepState* st, int which, int t_explicit, hipStream_t s,
+                           float tau2 = -1.f /* the target rate of the elements behind ``split`` (< 0: tau) */,
+                           int ema_before2 = 0 /* there, the target follows the parameter as it was BEFORE this step */);
 
 // ---- peer-access all-reduce (peer.hip): the data-parallel gradient exchange as graph-capturable kernels -------------------
 constexpr int PEER_MAX_WORLD = 8;

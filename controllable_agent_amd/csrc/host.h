@@ -103,6 +103,8 @@ struct IcmP { float *W1 = nullptr, *b1, *W2, *b2, *W3, *b3; };     // the featur
 //   1 icm          inverse_dynamic_net   in = 2 z  (cat[phi, next_phi])   out = a (tanh), target = action        :194-213
 //   4 autoencoder  decoder               in = z    (phi)                  out = g,        target = goal          :249-262
 //   5 transition   forward_dynamic_net   in = z + a (cat[phi, action])    out = g,        target = next_goal     :215-227
+//   7 latent       forward_dynamic_net   in = z + a (cat[phi, action])    out = z,        target = target_feature_net(next_goal) :230-246
+//                  (target_feature_net = the backward segment of the TARGET buffer: own init, moved at 0.01 before phi_opt.step())
 // (2 lap and 3 random have none)
 bool sf_head_dims(const fbhip_dims& d, int* in, int* out, const char** prefix);
 struct ActP { TrunkP o, oz; float *Wt = nullptr, *bt = nullptr; float *W3, *b3, *W4, *b4; };

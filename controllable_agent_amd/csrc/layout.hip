@@ -164,7 +164,7 @@ int check_dims(const fbhip_dims* d) {
     if (d->batch > 8192) { g_err = "fbhip: batch > 8192 per GPU unsupported (permutation sort)"; return FBHIP_E_INVALID; }
     if (d->discrete && d->preprocess) { g_err = "fbhip: discrete needs preprocess == 0 (the reference's discrete ForwardMap.forward only runs without the preprocess nets, discrete_fb.py:91-94)"; return FBHIP_E_INVALID; }
     if (d->discrete && (int64_t)d->z_dim * d->action_dim > 8192) { g_err = "fbhip: discrete: z_dim * actions > 8192 unsupported"; return FBHIP_E_INVALID; }
-    if (d->sf < 0 || d->sf > 6) { g_err = "fbhip: dims.sf must be 0, 1 (icm), 2 (lap), 3 (random), 4 (autoencoder), 5 (transition) or 6 (svd_p)"; return FBHIP_E_INVALID; }
+    if (d->sf < 0 || d->sf > 7) { g_err = "fbhip: dims.sf must be 0, 1 (icm), 2 (lap), 3 (random), 4 (autoencoder), 5 (transition), 6 (svd_p) or 7 (latent)"; return FBHIP_E_INVALID; }
     if (d->sf && (d->discrete || d->boltzmann || !d->norm_z)) { g_err = "fbhip: dims.sf needs discrete = 0, boltzmann = 0, norm_z = 1"; return FBHIP_E_INVALID; }
     if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
     return FBHIP_OK;
@@ -343,6 +343,7 @@ bool sf_head_dims(const fbhip_dims& d, int* in, int* out, const char** prefix) {
         case 1: *in = 2 * d.z_dim; *out = d.action_dim; *prefix = "inverse_dynamic_net."; return true;
         case 4: *in = d.z_dim; *out = d.goal_dim; *prefix = "decoder."; return true;
         case 5: *in = d.z_dim + d.action_dim; *out = d.goal_dim; *prefix = "forward_dynamic_net."; return true;
+        case 7: *in = d.z_dim + d.action_dim; *out = d.z_dim; *prefix = "forward_dynamic_net."; return true;
         default: return false;
     }
 }

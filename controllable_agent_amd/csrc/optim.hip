@@ -25,7 +25,8 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
                                                        float4* __restrict__ m, float4* __restrict__ v,
                                                        float4* __restrict__ tgt, int64_t nquad, float lr, float lr2,
                                                        int64_t split_quad, float grad_scale, float tau,
-                                                       const StepState* __restrict__ st, int which, int t_explicit) {
+                                                       const StepState* __restrict__ st, int which, int t_explicit,
+                                                       float tau2, int ema_before2) {
     double bc1, bc2s;
     if (st != nullptr) {
         bc1 = which == 0 ? st->fb_bc1 : st->actor_bc1;
@@ -40,8 +41,10 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
     const float omt = (float)(1.0 - (double)tau);
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquad; i += stride) {
-        const float ss = i < split_quad ? ss1 : ss2;
+        const bool second = i >= split_quad;
+        const float ss = second ? ss2 : ss1;
         float4 gg = g[i], mm = m[i], vv = v[i], pp = p[i];
+        const float4 p0 = pp;
 #define ADAM1(c)                                                         \
         {                                                                \
             const float gr = gg.c * grad_scale;                          \
@@ -55,8 +58,12 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
         m[i] = mm; v[i] = vv; p[i] = pp;
         if (tgt != nullptr) {
             float4 tt = tgt[i];
-            tt.x = tau * pp.x + omt * tt.x; tt.y = tau * pp.y + omt * tt.y;
-            tt.z = tau * pp.z + omt * tt.z; tt.w = tau * pp.w + omt * tt.w;
+            // (sf.py:237 TransitionLatentModel: the learner's own target net is moved inside its forward(), i.e. towards the
+            // parameters BEFORE phi_opt.step(), at its own fixed rate)
+            const float4 src = (second && ema_before2) ? p0 : pp;
+            const float ta = second ? tau2 : tau, om = second ? (float)(1.0 - (double)tau2) : omt;
+            tt.x = ta * src.x + om * tt.x; tt.y = ta * src.y + om * tt.y;
+            tt.z = ta * src.z + om * tt.z; tt.w = ta * src.w + om * tt.w;
             tgt[i] = tt;
         }
     }
@@ -64,14 +71,15 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
 
 hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel, float lr,
                            float lr2, int64_t split, float grad_scale, float tau, const StepState* st, int which,
-                           int t_explicit, hipStream_t s) {
+                           int t_explicit, hipStream_t s, float tau2, int ema_before2) {
     if (numel <= 0) return hipSuccess;
     if ((numel & 3) || (split & 3)) return hipErrorInvalidValue;
     const int64_t nquad = numel / 4;
     int blocks = (int)((nquad + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m,
-                       (float4*)v, (float4*)target, nquad, lr, lr2, split / 4, grad_scale, tau, st, which, t_explicit);
+                       (float4*)v, (float4*)target, nquad, lr, lr2, split / 4, grad_scale, tau, st, which, t_explicit,
+                       tau2 < 0.f ? tau : tau2, ema_before2);
     return hipGetLastError();
 }
 

@@ -947,6 +947,8 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
             actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[3], !fused_policy);
             ch[3].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld, &w.as));
         }
+        if (d.sf == 7 && head)       // latent: next_phi of its loss = target_feature_net(next_goal) (sf.py:241-242), the TARGET copy of the feature block
+            backward_map_fwd_chain(c, c->K_t, w.next_goal.p, w.next_goal.ld, w.bsA, B, ch[4]);
         if (d.sf == 6 && head) {      // svd_p: mu = mu_net(cat[goal, action]) (sf.py:347), the BackwardMap module chain on another input, unprojected
             const int g = d.goal_dim, act = d.action_dim;
             ch[4].push_back([=, &w](Ops& o2) {       // (a stage of its own: the panel is built behind the first round, mu_net starts in the second)
@@ -979,10 +981,11 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         // autoencoder: vs the goal itself, :249-262; transition: [phi | action] vs the next goal, :215-227)
         const IcmP &I = c->I_p, &G = c->I_g;
         const int Kc = pad32(hin), a = hout, La = pad4(hout), sfm = d.sf, act = d.action_dim;
-        const float* second = sfm == 1 ? nphi : sfm == 5 ? w.Xoa.p + aoff : nullptr;
-        const int ld2 = sfm == 1 ? Lz : w.Xoa.ld, n2 = sfm == 1 ? z : sfm == 5 ? act : 0;
-        const float* target = sfm == 1 ? w.Xoa.p + aoff : sfm == 4 ? w.goal2.p : w.goal2.p + (size_t)B * w.goal2.ld;
-        const int ldt = sfm == 1 ? w.Xoa.ld : w.goal2.ld;
+        const bool with_action = sfm == 5 || sfm == 7;
+        const float* second = sfm == 1 ? nphi : with_action ? w.Xoa.p + aoff : nullptr;
+        const int ld2 = sfm == 1 ? Lz : w.Xoa.ld, n2 = sfm == 1 ? z : with_action ? act : 0;
+        const float* target = sfm == 1 ? w.Xoa.p + aoff : sfm == 4 ? w.goal2.p : sfm == 7 ? w.bsA.Bm.p : w.goal2.p + (size_t)B * w.goal2.ld;
+        const int ldt = sfm == 1 ? w.Xoa.ld : sfm == 7 ? Lz : w.goal2.ld;
         feat.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
                 HIPCK(c, launch_concat2(w.icat.p, Kc, phi, Lz, z, second, ld2, n2, B, q));
@@ -1063,8 +1066,10 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     POST_BEGIN
     HIPCK(c, launch_step_advance(w.st, 0, s));
     const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
+    // (latent, sf.py:245: utils.soft_update_params(feature_net, target_feature_net, 0.01) runs inside the learner's forward(), i.e.
+    // towards the feature parameters as they were BEFORE phi_opt.step(); the other learners never read that part of the target buffer)
     HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf, hp.grad_scale,
-                             hp.fb_target_tau, w.st, 0, 0, s));
+                             hp.fb_target_tau, w.st, 0, 0, s, d.sf == 7 ? 0.01f : -1.f, d.sf == 7 ? 1 : 0));
     POST_END
     return FBHIP_OK;
 }

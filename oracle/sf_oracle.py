@@ -43,16 +43,19 @@ def feature_learner_shapes(cfg: fo.OracleConfig, learner: str):
         name, fin, fout = HEADS[learner](cfg)
         out += [(f"{name}.0.weight", (Hb, fin)), (f"{name}.0.bias", (Hb,)), (f"{name}.2.weight", (Hb, Hb)), (f"{name}.2.bias", (Hb,)),
                 (f"{name}.4.weight", (fout, Hb)), (f"{name}.4.bias", (fout,))]
+    if learner == "latent":       # + target_feature_net: feature_net's architecture, own weights, no gradients (sf.py:234)
+        out += [("target_" + n, shp) for n, shp in out[:8]]
     elif learner == "svd_p":      # mu_net = mlp(goal_dim + action_dim, Hb, "ntanh", Hb, "relu", z_dim)   (sf.py:340)
         out += [("mu_net.0.weight", (Hb, g + a)), ("mu_net.0.bias", (Hb,)), ("mu_net.1.weight", (Hb,)), ("mu_net.1.bias", (Hb,)),
                 ("mu_net.3.weight", (Hb, Hb)), ("mu_net.3.bias", (Hb,)), ("mu_net.5.weight", (d, Hb)), ("mu_net.5.bias", (d,))]
-    elif learner not in ("lap", "random"):
+    elif learner not in ("lap", "random") and learner not in HEADS:
         raise NotImplementedError(learner)
     return out
 
 
 # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) a feature learner trains feature_net through: (module name, in, out)
 HEADS = {"icm": lambda c: ("inverse_dynamic_net", 2 * c.z_dim, c.action_dim),              # sf.py:198 (+ 'tanh')
+         "latent": lambda c: ("forward_dynamic_net", c.z_dim + c.action_dim, c.z_dim),     # sf.py:233
          "autoencoder": lambda c: ("decoder", c.z_dim, c.goal_dim),                        # sf.py:253
          "transition": lambda c: ("forward_dynamic_net", c.z_dim + c.action_dim, c.goal_dim)}   # sf.py:219
 
@@ -106,6 +109,11 @@ def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int)
         Cov = torch.matmul(next_phi, next_phi.T)
         orth = Cov[off].pow(2).mean() - 2 * Cov.diag().mean()
         return {"phi_loss": loss + orth, "phi": phi, "next_phi": next_phi, "mu": mu, "orth_loss": orth}
+    if learner == "latent":                                        # sf.py:238-246 (the caller moves the target net afterwards)
+        with torch.no_grad():
+            tgt = feature_net({k[len("target_"):]: v for k, v in p.items() if k.startswith("target_feature_net.")}, next_goal, z_dim)
+        pred = head_mlp(p, "forward_dynamic_net", torch.cat([phi, action], dim=-1))
+        return {"phi_loss": (pred - tgt).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred, "target_phi": tgt}
     if learner == "transition":                                    # sf.py:222-227
         pred = head_mlp(p, "forward_dynamic_net", torch.cat([phi, action], dim=-1))
         return {"phi_loss": (pred - next_goal).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred}
@@ -123,7 +131,7 @@ def _grad_or_zero(x: torch.Tensor, retained: bool) -> torch.Tensor:
 
 class SFOracleAgent:
     """State of one SFAgent (sf.py:383-474) and its ``update`` (:700-768) for ``feature_learner`` in {"icm", "lap", "random",
-    "autoencoder", "transition", "svd_p"}."""
+    "autoencoder", "transition", "svd_p", "latent"}."""
 
     NETS = ("actor", "successor_net", "feature_learner")
 
@@ -186,10 +194,15 @@ class SFOracleAgent:
         fo.adam_step(self.successor_net, gS, self.adam["successor_net"]["m"], self.adam["successor_net"]["v"], self.sf_steps, cfg.lr)
         gP: tp.Dict[str, tp.Any] = {}
         if L["phi_loss"] is not None:                               # sf.py:447-449, 657-660: "random" has no phi_opt
+            if self.learner == "latent":                            # sf.py:245: inside the learner's forward(), i.e. BEFORE phi_opt.step()
+                with torch.no_grad():
+                    for k in [k for k in self.feature_learner if k.startswith("feature_net.")]:
+                        self.feature_learner["target_" + k].mul_(0.99).add_(self.feature_learner[k], alpha=0.01)
             L["phi_loss"].backward()
-            gP = {k: v.grad for k, v in pp.items()}
-            fo.adam_step(self.feature_learner, gP, self.adam["feature_learner"]["m"], self.adam["feature_learner"]["v"], self.sf_steps,
-                         cfg.lr_coef * cfg.lr)
+            gP = {k: v.grad for k, v in pp.items() if v.grad is not None}    # (target_feature_net never has gradients: Adam skips it)
+            sub = lambda dct: {k: dct[k] for k in gP}
+            fo.adam_step(sub(self.feature_learner), gP, sub(self.adam["feature_learner"]["m"]), sub(self.adam["feature_learner"]["v"]),
+                         self.sf_steps, cfg.lr_coef * cfg.lr)
 
         # ---------------- update_actor (sf.py:666-694) ------------- #
         ap = self._req(self.actor)

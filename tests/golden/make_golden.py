@@ -372,6 +372,16 @@ def sf_svdp_fixture(R):
     _sf_inits(R, ("svd_p",))
 
 
+def sf_latent_fixture(R):
+    """feature_learner="latent" (TransitionLatentModel, sf.py:230-246): forward_dynamic_net(cat[phi(goal), action]) regressed on
+    target_feature_net(next_goal); the target net has its OWN initial weights and follows feature_net at rate 0.01 inside the
+    learner's forward(), i.e. before phi_opt.step().  sf_target_tau is set to 0.03 so that a mix-up of the two rates shows."""
+    _sf_traces(R, (
+        ("tiny_sf_latent_trace", "latent", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0, fb_target_tau=0.03),
+         dict(seed=138, n_eps=6, T=12, n_steps=4)),))
+    _sf_inits(R, ("latent",))
+
+
 def _sf_traces(R, table):
     from oracle import sf_oracle as so
     for name, learner, q_loss, kw, extra in table:
@@ -729,6 +739,7 @@ def main():
     sf_init_fixture(R)
     sf_more_fixture(R)
     sf_svdp_fixture(R)
+    sf_latent_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -133,7 +133,7 @@ def sf_trace_inputs(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
-                                  "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace"])
+                                  "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace"])
 def test_sf_oracle_full_state_against_the_reference(name):
     """oracle/sf_oracle.py against traces of the real url_benchmark.agent.sf.SFAgent: metrics and every parameter / target /
     Adam tensor after every step (icm + scalar Q regression; lap + feature-space regression + goal space + variable lengths)."""
@@ -146,8 +146,9 @@ def test_sf_oracle_full_state_against_the_reference(name):
         for k, v in meta["metrics"][s].items():
             assert m[k] == pytest.approx(v, rel=2e-5, abs=1e-6), (s, k)
         for k, v in agent.state_tensors().items():
-            if f"state/{s}/{k}" not in z.files:               # "random": the reference has no phi_opt, hence no Adam state to record
-                assert meta["feature_learner"] == "random" and k.startswith(("adam_m/feature_learner", "adam_v/feature_learner"))
+            if f"state/{s}/{k}" not in z.files:               # no Adam state in the reference: "random" has no phi_opt; latent's target net has no gradients
+                assert k.startswith(("adam_m/feature_learner", "adam_v/feature_learner"))
+                assert meta["feature_learner"] == "random" or "target_feature_net" in k, k
                 assert float(np.abs(v).max()) == 0.0, k
                 continue
             np.testing.assert_allclose(v, z[f"state/{s}/{k}"], rtol=1e-4, atol=2e-6, err_msg=f"step {s} {k}")
