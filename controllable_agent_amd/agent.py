@@ -1262,13 +1262,17 @@ class SFHipAgent(FBHipAgent):
         "FB"           feature_net = the backward_net of a trained FB agent (``fb_features=``), frozen       sf.py:368-380
         "latent"       mean((forward_dynamic_net(cat[phi(goal), action]) - target_feature_net(next_goal))^2), the
                        target net following feature_net at rate 0.01                                          sf.py:230-246
+        "svd_sr"       SR = phi(goal) . mu_net(next_goal)^T against 0.99 x the same product of two target nets:
+                       -2 mean diag SR + mean offdiag (SR - 0.99 target_SR)^2 + orthonormality loss of phi (LRA-SR)   sf.py:264-299
+        "svd_srv2"     the same with the roles swapped: SR = mu_net(goal) . phi(next_goal)^T, 0.98, orthonormality of phi(next_goal)   sf.py:303-335
         "svd_p"        P = mu_net(cat[goal, action]) . phi(next_goal)^T:  -2 mean diag P + mean offdiag P^2
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
-    The reference's other five feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    The reference's other three feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
-    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7}     # -> fbhip_dims.sf
+    _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7, "svd_sr": 8,
+                 "svd_srv2": 9}                  # -> fbhip_dims.sf
     # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
     _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
               5: ("forward_dynamic_net", lambda z, a, g: (z + a, g)), 7: ("forward_dynamic_net", lambda z, a, g: (z + a, z))}
@@ -1351,6 +1355,10 @@ class SFHipAgent(FBHipAgent):
         if self._sf_mode == 6:                  # SVDP.__init__ (sf.py:338-342): mu_net = mlp(g + a, Hb, "ntanh", Hb, "relu", z), then weight_init again
             feat = feat + [("mu_net.0", torch.nn.Linear(g + a, Hb)), ("mu_net.3", torch.nn.Linear(Hb, Hb)), ("mu_net.5", torch.nn.Linear(Hb, d))]
             ortho(feat)
+        if self._sf_mode in (8, 9):             # SVDSR.__init__ / SVDSRv2.__init__ (sf.py:265-270, 304-309): mu_net on the goal alone, then BOTH target nets (own weights), one weight_init
+            feat = feat + [(f"{n}.{i}", torch.nn.Linear(*io)) for n in ("mu_net", "target_feature_net", "target_mu_net")
+                           for i, io in ((0, (g, Hb)), (3, (Hb, Hb)), (5, (Hb, d)))]
+            ortho(feat)
         if self._sf_mode == 7:                  # TransitionLatentModel.__init__ (sf.py:231-236): forward_dynamic_net (above), then target_feature_net --
             # its OWN random weights, never a copy of feature_net -- and weight_init over all three
             tgt = [("target_feature_net.0", torch.nn.Linear(g, Hb)), ("target_feature_net.3", torch.nn.Linear(Hb, Hb)),
@@ -1365,6 +1373,9 @@ class SFHipAgent(FBHipAgent):
             sd["mu_net.1.weight"], sd["mu_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
         if self._sf_mode == 7:
             sd["target_feature_net.1.weight"], sd["target_feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
+        if self._sf_mode in (8, 9):
+            for n in ("mu_net", "target_feature_net", "target_mu_net"):
+                sd[f"{n}.1.weight"], sd[f"{n}.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
         nets["feature_learner"] = sd
         return nets
 
@@ -1376,12 +1387,12 @@ class SFHipAgent(FBHipAgent):
         fwd._name, tgt._name = "successor_net", "successor_target_net"
         self.feature_learner = FeatureLearnerView("feature_learner", bwd._flat, self._layout_of(1),
                                                   forward=lambda x: self._backward_map(x, target=False))
-        if self._sf_mode == 7:
-            # latent (sf.py:234): ``feature_learner.target_feature_net`` is the feature block of the TARGET buffer -- a parameter-less
-            # module to the optimiser (it never has gradients), part of ``feature_learner.state_dict()`` for checkpoints
+        if self._sf_mode in (7, 8, 9):
+            # latent (sf.py:234) / svd_sr, svd_srv2 (:266-267, :306-307): ``feature_learner.target_feature_net`` [and ``target_mu_net``] are blocks of the
+            # TARGET buffer -- modules without gradients to the optimiser, part of ``feature_learner.state_dict()`` for checkpoints
             tb = self.backward_target_net
             for k, v in tb._views.items():
-                if k.startswith("feature_net."):
+                if k.startswith(("feature_net.", "mu_net.")):
                     self.feature_learner._views["target_" + k] = v
             self.feature_learner._pads += tb._pads
         self._adam_views["successor_net"] = self._adam_views["forward_net"]

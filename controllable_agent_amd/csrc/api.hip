@@ -116,7 +116,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     c->F_p = fwd_p(fb_params, c->L[0]); c->F_g = fwd_p(fb_grads, c->L[0]); c->F_t = fwd_p(fb_targets, c->L[0]);
     c->K_p = bwd_p(fb_params + nf, c->L[1]); c->K_g = bwd_p(fb_grads + nf, c->L[1]); c->K_t = bwd_p(fb_targets + nf, c->L[1]);
     c->I_p = icm_p(fb_params + nf, c->L[1]); c->I_g = icm_p(fb_grads + nf, c->L[1]);
-    c->M_p = mu_p(fb_params + nf, c->L[1]); c->M_g = mu_p(fb_grads + nf, c->L[1]);
+    c->M_p = mu_p(fb_params + nf, c->L[1]); c->M_g = mu_p(fb_grads + nf, c->L[1]); c->M_t = mu_p(fb_targets + nf, c->L[1]);
     if (has_actor) { c->A_p = act_p(actor_params, c->L[2]); c->A_g = act_p(actor_grads, c->L[2]); }
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
     c->graphs.clear();

@@ -189,7 +189,8 @@ hipError_t launch_sf_loss(const float* F1, const float* F2, const float* nF1, co
                           float* scratch, int rows, int d, hipStream_t s);
 // inverse-dynamics loss of the ICM feature learner (sf.py:207-210): pred = tanh(pre), PHI_LOSS = mean((action - pred)^2), d pre;
 // scratch >= ceil(rows * a / 256) floats
-hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hipStream_t s);      // metrics[dst] = scale * metrics[src]
+hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hipStream_t s, int accumulate = 0);   // metrics[dst] (+)= scale * metrics[src]
+hipError_t launch_fill_add(float* dst, const float* add, float fill, int64_t n, hipStream_t s);   // add ? dst[i] += add[i] : dst[i] = fill
 hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int lda, float* dpre, int ldd, int rows, int a,
                            int squash, float* metrics, float* scratch, hipStream_t s);
 // Laplacian feature learner (sf.py:104-114) on top of pairwise_kernel's orthonormality pass: dphi += d mse, dnext_phi = d mse,

@@ -82,6 +82,8 @@ struct Ws {
                                         // (mu_net's activations live in bsM, the z-mix set SFAgent does not use: mu = bsM.y)
     Buf dmu, m_dr2, m_dt1;              // its gradient panels
     float* ln_partials_m = nullptr;     // its LayerNorm-backward partial sums (it shares rounds with feature_net's backward)
+    float* c99 = nullptr;               // svd_sr: the constant 0.99 "discount" of its target term, one per row
+    Buf dphi_o;                         // svd_sr: the orthonormality share of d phi (a second pairwise launch), added to the first
     Buf icat, ih1, ih2, ipre, d_ipre, d_ih1, d_ih2;          // icm: inverse-dynamics activations / gradients
     Buf zeroF, lapS1, lapS2;                                 // lap: the zero F panel and two throw-away dF panels of the pairwise pass
     float* act_in = nullptr;            // batch-1 fast path: [obs | z | 0.. | noise] / [goal | 0.. | z] as staged by the host
@@ -139,7 +141,7 @@ struct fbhip_ctx {
     uint32_t rank = 0;
     fbhip::host::FwdP F_p, F_g, F_t;
     fbhip::host::BwdP K_p, K_g, K_t;
-    fbhip::host::BwdP M_p, M_g;                           // dims.sf == 6 (svd_p): mu_net
+    fbhip::host::BwdP M_p, M_g, M_t;                      // dims.sf == 6 / 8 (svd_p / svd_sr): mu_net (M_t: svd_sr's target_mu_net)
     fbhip::host::IcmP I_p, I_g;                           // dims.sf == 1
     fbhip::host::ActP A_p, A_g;
     std::vector<fbhip::host::GraphEntry> graphs;

@@ -933,7 +933,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         };
     };
     {
-        std::vector<Chain> ch(5);                // (empty chains contribute nothing; the order keeps the one-call launches as they were)
+        std::vector<Chain> ch(7);                // (empty chains contribute nothing; the order keeps the one-call launches as they were)
         if (mid) {
             actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.asT, B, ch[0], !fused_policy);
             ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
@@ -949,6 +949,19 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         }
         if (d.sf == 7 && head)       // latent: next_phi of its loss = target_feature_net(next_goal) (sf.py:241-242), the TARGET copy of the feature block
             backward_map_fwd_chain(c, c->K_t, w.next_goal.p, w.next_goal.ld, w.bsA, B, ch[4]);
+        if (d.sf == 8 && head) {
+            // svd_sr (sf.py:264-275): mu = mu_net(next_goal) and the two target nets on next_goal -- the TARGET copies of the feature
+            // block and of mu_net (own initial weights, followed at 0.01 like latent's)
+            backward_map_fwd_chain(c, c->M_p, w.next_goal.p, w.next_goal.ld, w.bsM, B, ch[4], false, d.goal_dim);
+            backward_map_fwd_chain(c, c->K_t, w.next_goal.p, w.next_goal.ld, w.bsA, B, ch[5]);
+            backward_map_fwd_chain(c, c->M_t, w.next_goal.p, w.next_goal.ld, w.bsO, B, ch[6], false, d.goal_dim);
+        }
+        if (d.sf == 9 && head) {
+            // svd_srv2 (sf.py:303-318): mu = mu_net(goal); the two target nets on next_goal as for svd_sr
+            backward_map_fwd_chain(c, c->M_p, w.bin.p, w.bin.ld, w.bsM, B, ch[4], false, d.goal_dim);
+            backward_map_fwd_chain(c, c->K_t, w.next_goal.p, w.next_goal.ld, w.bsA, B, ch[5]);
+            backward_map_fwd_chain(c, c->M_t, w.next_goal.p, w.next_goal.ld, w.bsO, B, ch[6], false, d.goal_dim);
+        }
         if (d.sf == 6 && head) {      // svd_p: mu = mu_net(cat[goal, action]) (sf.py:347), the BackwardMap module chain on another input, unprojected
             const int g = d.goal_dim, act = d.action_dim;
             ch[4].push_back([=, &w](Ops& o2) {       // (a stage of its own: the panel is built behind the first round, mu_net starts in the second)
@@ -1029,6 +1042,42 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
                 return (int)FBHIP_OK;
             });
         });
+    } else if (d.sf == 8) {
+        // svd_sr (sf.py:271-292): SR = phi . mu^T, target_SR = target_phi . target_mu^T (both on next_goal),
+        //   loss = -2 mean diag SR + mean offdiag (SR - 0.99 target_SR)^2 + orthonormality(phi)
+        // The first two terms are the FB loss of two IDENTICAL heads F1 = F2 = phi against B = mu with targets tF1 = tF2 = target_phi,
+        // tB = target_mu and a constant discount 0.99 (min of two equal target products; 1/2 + 1/2 of the squares; diag + diag); the
+        // third is the pairwise kernel's covariance role on phi alone, as for lap.  d phi = dF1 + dF2 + the orthonormality share.
+        feat.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_fill_add(w.c99, nullptr, 0.99f, B, q));
+                HIPCK(c, hipMemsetAsync(dnphi, 0, (size_t)B * Lz * sizeof(float), q));
+                HIPCK(c, launch_pairwise_fb(phi, phi, w.bsM.y.p, w.bsA.Bm.p, w.bsA.Bm.p, w.bsO.y.p, w.c99, B, z, Lz, 0.0f, dphi, w.lapS2.p, w.dmu.p,
+                                            w.metrics, w.pw_scratch, q));
+                HIPCK(c, launch_scale_metric(w.metrics, FBHIP_M_FB_LOSS, FBHIP_M_PHI_LOSS, 1.0f, q));
+                HIPCK(c, launch_fill_add(dphi, w.lapS2.p, 0.f, (int64_t)B * Lz, q));
+                HIPCK(c, launch_pairwise_fb(w.zeroF.p, w.zeroF.p, phi, w.zeroF.p, w.zeroF.p, phi, w.disc, B, z, Lz, 1.0f, w.lapS1.p, w.lapS2.p,
+                                            w.dphi_o.p, w.metrics, w.pw_scratch, q));
+                HIPCK(c, launch_scale_metric(w.metrics, FBHIP_M_FB_LOSS, FBHIP_M_PHI_LOSS, 1.0f, q, 1));
+                HIPCK(c, launch_fill_add(dphi, w.dphi_o.p, 0.f, (int64_t)B * Lz, q));
+                return (int)FBHIP_OK;
+            });
+        });
+    } else if (d.sf == 9) {
+        // svd_srv2 (sf.py:311-329): SR = mu(goal) . phi(next_goal)^T against 0.98 x target_mu . target_phi^T (both on next_goal), plus
+        // the orthonormality of phi(next_goal): the FB loss itself -- two identical heads F = mu, B = phi', its own orthonormality
+        // term on B with ortho_coef = 1 -- in ONE launch;  d mu = dF1 + dF2, d phi' = dB, the goal rows of the feature pass get none
+        feat.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_fill_add(w.c99, nullptr, 0.98f, B, q));
+                HIPCK(c, hipMemsetAsync(dphi, 0, (size_t)B * Lz * sizeof(float), q));
+                HIPCK(c, launch_pairwise_fb(w.bsM.y.p, w.bsM.y.p, nphi, w.bsO.y.p, w.bsO.y.p, w.bsA.Bm.p, w.c99, B, z, Lz, 1.0f, w.dmu.p, w.lapS2.p,
+                                            dnphi, w.metrics, w.pw_scratch, q));
+                HIPCK(c, launch_scale_metric(w.metrics, FBHIP_M_FB_LOSS, FBHIP_M_PHI_LOSS, 1.0f, q));
+                HIPCK(c, launch_fill_add(w.dmu.p, w.lapS2.p, 0.f, (int64_t)B * Lz, q));
+                return (int)FBHIP_OK;
+            });
+        });
     } else if (d.sf == 2) {
         feat.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
@@ -1050,11 +1099,13 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     {
         std::vector<Chain> ch{succ};
         if (d.sf != 3) ch.push_back(feat);
-        if (d.sf == 6) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
+        if (d.sf == 6 || d.sf == 8 || d.sf == 9) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
             Chain mu;
             mu.push_back([](Ops&) {});
             BGrad mg{w.dmu.p, w.dmu.p, w.m_dr2.p, w.m_dt1.p, w.ln_partials_m};
-            backward_map_bwd_chain(c, c->M_p, c->M_g, w.Xga.p, w.Xga.ld, w.bsM, B, mu, true, &mg, d.goal_dim + d.action_dim);
+            if (d.sf == 6) backward_map_bwd_chain(c, c->M_p, c->M_g, w.Xga.p, w.Xga.ld, w.bsM, B, mu, true, &mg, d.goal_dim + d.action_dim);
+            else if (d.sf == 8) backward_map_bwd_chain(c, c->M_p, c->M_g, w.next_goal.p, w.next_goal.ld, w.bsM, B, mu, true, &mg, d.goal_dim);
+            else backward_map_bwd_chain(c, c->M_p, c->M_g, w.bin.p, w.bin.ld, w.bsM, B, mu, true, &mg, d.goal_dim);
             ch.push_back(mu);
         }
         prog_parallel(prog, ch);
@@ -1069,7 +1120,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     // (latent, sf.py:245: utils.soft_update_params(feature_net, target_feature_net, 0.01) runs inside the learner's forward(), i.e.
     // towards the feature parameters as they were BEFORE phi_opt.step(); the other learners never read that part of the target buffer)
     HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf, hp.grad_scale,
-                             hp.fb_target_tau, w.st, 0, 0, s, d.sf == 7 ? 0.01f : -1.f, d.sf == 7 ? 1 : 0));
+                             hp.fb_target_tau, w.st, 0, 0, s, d.sf >= 7 ? 0.01f : -1.f, d.sf >= 7 ? 1 : 0));
     POST_END
     return FBHIP_OK;
 }

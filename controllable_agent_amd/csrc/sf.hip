@@ -194,10 +194,23 @@ hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int l
     return hipGetLastError();
 }
 
-__global__ void scale_metric_kernel(float* __restrict__ metrics, int src, int dst, float scale) { metrics[dst] = scale * metrics[src]; }
+__global__ void scale_metric_kernel(float* __restrict__ metrics, int src, int dst, float scale, int accumulate) {
+    metrics[dst] = (accumulate ? metrics[dst] : 0.f) + scale * metrics[src];
+}
 
-hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hipStream_t s) {
-    hipLaunchKernelGGL(scale_metric_kernel, dim3(1), dim3(1), 0, s, metrics, src, dst, scale);
+hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hipStream_t s, int accumulate) {
+    hipLaunchKernelGGL(scale_metric_kernel, dim3(1), dim3(1), 0, s, metrics, src, dst, scale, accumulate);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) fill_add_kernel(float* __restrict__ dst, const float* __restrict__ add, float fill, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = add != nullptr ? dst[i] + add[i] : fill;
+}
+
+hipError_t launch_fill_add(float* dst, const float* add, float fill, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, add, fill, n);
     return hipGetLastError();
 }
 

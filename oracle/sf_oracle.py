@@ -45,6 +45,10 @@ def feature_learner_shapes(cfg: fo.OracleConfig, learner: str):
                 (f"{name}.4.weight", (fout, Hb)), (f"{name}.4.bias", (fout,))]
     if learner == "latent":       # + target_feature_net: feature_net's architecture, own weights, no gradients (sf.py:234)
         out += [("target_" + n, shp) for n, shp in out[:8]]
+    elif learner in ("svd_sr", "svd_srv2"):     # mu_net on the goal alone, then target copies of both nets (sf.py:265-269)
+        mu = [("mu_net.0.weight", (Hb, g)), ("mu_net.0.bias", (Hb,)), ("mu_net.1.weight", (Hb,)), ("mu_net.1.bias", (Hb,)),
+              ("mu_net.3.weight", (Hb, Hb)), ("mu_net.3.bias", (Hb,)), ("mu_net.5.weight", (d, Hb)), ("mu_net.5.bias", (d,))]
+        out += mu + [("target_" + n, shp) for n, shp in out[:8] + mu]
     elif learner == "svd_p":      # mu_net = mlp(goal_dim + action_dim, Hb, "ntanh", Hb, "relu", z_dim)   (sf.py:340)
         out += [("mu_net.0.weight", (Hb, g + a)), ("mu_net.0.bias", (Hb,)), ("mu_net.1.weight", (Hb,)), ("mu_net.1.bias", (Hb,)),
                 ("mu_net.3.weight", (Hb, Hb)), ("mu_net.3.bias", (Hb,)), ("mu_net.5.weight", (d, Hb)), ("mu_net.5.bias", (d,))]
@@ -109,6 +113,23 @@ def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int)
         Cov = torch.matmul(next_phi, next_phi.T)
         orth = Cov[off].pow(2).mean() - 2 * Cov.diag().mean()
         return {"phi_loss": loss + orth, "phi": phi, "next_phi": next_phi, "mu": mu, "orth_loss": orth}
+    if learner in ("svd_sr", "svd_srv2"):                          # sf.py:271-292 / :311-332 (the caller moves both target nets afterwards)
+        mlp3 = lambda q, x: F.linear(torch.relu(F.linear(torch.tanh(F.layer_norm(F.linear(x, p[q + "0.weight"], p[q + "0.bias"]),
+                                                                                  (p[q + "0.bias"].shape[0],), p[q + "1.weight"], p[q + "1.bias"], fo.LN_EPS)),
+                                                         p[q + "3.weight"], p[q + "3.bias"])), p[q + "5.weight"], p[q + "5.bias"])
+        v2 = learner == "svd_srv2"                                 # v2: mu on the goal, the features of next_goal, 0.98
+        mu = mlp3("mu_net.", goal if v2 else next_goal)
+        feat = next_phi if v2 else phi
+        SR = torch.einsum("sd, td -> st", mu, feat) if v2 else torch.einsum("sd, td -> st", feat, mu)
+        with torch.no_grad():
+            tphi = feature_net({k[len("target_"):]: v for k, v in p.items() if k.startswith("target_feature_net.")}, next_goal, z_dim)
+            tmu = mlp3("target_mu_net.", next_goal)
+            tSR = torch.einsum("sd, td -> st", tmu, tphi) if v2 else torch.einsum("sd, td -> st", tphi, tmu)
+        off = ~torch.eye(*SR.size()).bool()
+        loss = -2 * SR.diag().mean() + (SR - (0.98 if v2 else 0.99) * tSR)[off].pow(2).mean()
+        Cov = torch.matmul(feat, feat.T)
+        orth = Cov[off].pow(2).mean() - 2 * Cov.diag().mean()
+        return {"phi_loss": loss + orth, "phi": phi, "next_phi": next_phi, "mu": mu, "orth_loss": orth}
     if learner == "latent":                                        # sf.py:238-246 (the caller moves the target net afterwards)
         with torch.no_grad():
             tgt = feature_net({k[len("target_"):]: v for k, v in p.items() if k.startswith("target_feature_net.")}, next_goal, z_dim)
@@ -131,7 +152,7 @@ def _grad_or_zero(x: torch.Tensor, retained: bool) -> torch.Tensor:
 
 class SFOracleAgent:
     """State of one SFAgent (sf.py:383-474) and its ``update`` (:700-768) for ``feature_learner`` in {"icm", "lap", "random",
-    "autoencoder", "transition", "svd_p", "latent"}."""
+    "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2"}."""
 
     NETS = ("actor", "successor_net", "feature_learner")
 
@@ -194,9 +215,9 @@ class SFOracleAgent:
         fo.adam_step(self.successor_net, gS, self.adam["successor_net"]["m"], self.adam["successor_net"]["v"], self.sf_steps, cfg.lr)
         gP: tp.Dict[str, tp.Any] = {}
         if L["phi_loss"] is not None:                               # sf.py:447-449, 657-660: "random" has no phi_opt
-            if self.learner == "latent":                            # sf.py:245: inside the learner's forward(), i.e. BEFORE phi_opt.step()
+            if self.learner in ("latent", "svd_sr", "svd_srv2"):                # sf.py:245 / :294-295: inside the learner's forward(), i.e. BEFORE phi_opt.step()
                 with torch.no_grad():
-                    for k in [k for k in self.feature_learner if k.startswith("feature_net.")]:
+                    for k in [k for k in self.feature_learner if k.startswith(("feature_net.", "mu_net.") if self.learner != "latent" else "feature_net.")]:
                         self.feature_learner["target_" + k].mul_(0.99).add_(self.feature_learner[k], alpha=0.01)
             L["phi_loss"].backward()
             gP = {k: v.grad for k, v in pp.items() if v.grad is not None}    # (target_feature_net never has gradients: Adam skips it)

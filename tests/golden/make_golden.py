@@ -382,6 +382,27 @@ def sf_latent_fixture(R):
     _sf_inits(R, ("latent",))
 
 
+def sf_svdsr_fixture(R):
+    """feature_learner="svd_sr" (SVDSR, sf.py:264-299; the paper's LRA-SR): SR = phi(goal) . mu_net(next_goal)^T against 0.99 x the
+    product of two target nets (own weights, moved at 0.01 inside forward()), plus the orthonormality loss of phi(goal); with a goal
+    space + variable lengths in the second trace."""
+    _sf_traces(R, (
+        ("tiny_sf_svdsr_trace", "svd_sr", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0, fb_target_tau=0.03),
+         dict(seed=139, n_eps=6, T=12, n_steps=4)),
+        ("tiny_sf_svdsr_goal_trace", "svd_sr", False,
+         dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0),
+         dict(seed=140, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True))))
+    _sf_inits(R, ("svd_sr",))
+
+
+def sf_svdsrv2_fixture(R):
+    """feature_learner="svd_srv2" (SVDSRv2, sf.py:303-335): svd_sr with mu on the goal and the features of next_goal (0.98)."""
+    _sf_traces(R, (
+        ("tiny_sf_svdsrv2_trace", "svd_srv2", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0, fb_target_tau=0.03),
+         dict(seed=141, n_eps=6, T=12, n_steps=4)),))
+    _sf_inits(R, ("svd_srv2",))
+
+
 def _sf_traces(R, table):
     from oracle import sf_oracle as so
     for name, learner, q_loss, kw, extra in table:
@@ -740,6 +761,8 @@ def main():
     sf_more_fixture(R)
     sf_svdp_fixture(R)
     sf_latent_fixture(R)
+    sf_svdsr_fixture(R)
+    sf_svdsrv2_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

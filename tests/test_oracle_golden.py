@@ -133,7 +133,8 @@ def sf_trace_inputs(name):
 
 
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
-                                  "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace"])
+                                  "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
+                                  "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace"])
 def test_sf_oracle_full_state_against_the_reference(name):
     """oracle/sf_oracle.py against traces of the real url_benchmark.agent.sf.SFAgent: metrics and every parameter / target /
     Adam tensor after every step (icm + scalar Q regression; lap + feature-space regression + goal space + variable lengths)."""
@@ -148,7 +149,7 @@ def test_sf_oracle_full_state_against_the_reference(name):
         for k, v in agent.state_tensors().items():
             if f"state/{s}/{k}" not in z.files:               # no Adam state in the reference: "random" has no phi_opt; latent's target net has no gradients
                 assert k.startswith(("adam_m/feature_learner", "adam_v/feature_learner"))
-                assert meta["feature_learner"] == "random" or "target_feature_net" in k, k
+                assert meta["feature_learner"] == "random" or "/target_" in k, k
                 assert float(np.abs(v).max()) == 0.0, k
                 continue
             np.testing.assert_allclose(v, z[f"state/{s}/{k}"], rtol=1e-4, atol=2e-6, err_msg=f"step {s} {k}")

@@ -61,7 +61,8 @@ def set_sf_state(agent, state: dict, steps: int) -> None:
 
 
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
-                                  "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace"])
+                                  "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
+                                  "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace"])
 def test_sf_teacher_forced_against_reference_trace(name):
     """Each step starts from the REFERENCE SFAgent's recorded state, runs one HIP update with the recorded draws and must land
     on the reference's next state and metrics; intermediates and gradients are compared with the oracle's autograd."""
@@ -118,7 +119,8 @@ def test_sf_teacher_forced_against_reference_trace(name):
 @pytest.mark.parametrize("learner,q_loss,goal", [("icm", True, False), ("lap", False, True), ("icm", False, True), ("lap", True, False),
                                                  ("random", True, False), ("autoencoder", False, True), ("autoencoder", True, False),
                                                  ("transition", True, False), ("transition", False, True), ("svd_p", True, False),
-                                                 ("svd_p", False, True), ("latent", True, False)])
+                                                 ("svd_p", False, True), ("latent", True, False), ("svd_sr", True, False),
+                                                 ("svd_sr", False, True), ("svd_srv2", True, False)])
 def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal):
     """hidden 1024 / feature 512 / Hb 512 (the reference defaults), z 100, batch 256, walker-sized inputs: three free-running
     updates against the oracle (metrics + parameter checksums)."""
@@ -149,7 +151,7 @@ def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal)
             assert float(np.linalg.norm(got[k])) == pytest.approx(float(np.linalg.norm(v)), rel=2e-5 if v.ndim == 2 else 2e-4), k
 
 
-@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent"])
+@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2"])
 def test_sf_constructor_init_matches_reference_seed(learner):
     """same torch.manual_seed => SFAgent's orthogonal init tensor for tensor (sf.py:419-463; ICM re-applies weight_init)"""
     z = np.load(H.GOLDEN / f"init_seed1_tiny_sf_{learner}.npz")
@@ -270,7 +272,7 @@ def test_sf_fb_features_take_the_backward_net_of_a_trained_fb_agent():
 
 
 @pytest.mark.parametrize("name", ["tiny_sf_lap_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace", "tiny_sf_svdp_goal_trace",
-                                  "tiny_sf_random_trace", "tiny_sf_latent_trace"])
+                                  "tiny_sf_random_trace", "tiny_sf_latent_trace", "tiny_sf_svdsr_goal_trace"])
 def test_sf_pipelined_update_many_equals_single_updates(name):
     """fbhip_update_many cuts an SF update into head (sampling, online successor_net, feature_net [, mu_net]), middle and actor phase
     and runs the next step's head beside the actor phase: same kernels and operands, so the state after n pipelined steps equals n
