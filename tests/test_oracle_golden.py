@@ -145,7 +145,8 @@ def test_sf_oracle_full_state_against_the_reference(name):
         d = fo.Draws(**{f: z[f"draws/{s}/{f}"] for f in fo.Draws.__dataclass_fields__ if f"draws/{s}/{f}" in z.files})
         m = agent.update(fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount, d.future_idx), d)
         for k, v in meta["metrics"][s].items():
-            assert m[k] == pytest.approx(v, rel=2e-5, abs=1e-6), (s, k)
+            # (phi_loss of the low-rank learners is a difference of O(1..10) terms: its last digits follow the thread count's summation order)
+            assert m[k] == pytest.approx(v, rel=2e-5, abs=1e-5 if k == "phi_loss" else 1e-6), (s, k)
         for k, v in agent.state_tensors().items():
             if f"state/{s}/{k}" not in z.files:               # no Adam state in the reference: "random" has no phi_opt; latent's target net has no gradients
                 assert k.startswith(("adam_m/feature_learner", "adam_v/feature_learner"))
