@@ -79,7 +79,8 @@ def test_sf_teacher_forced_against_reference_trace(name):
         oracle.update(fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount, draws.future_idx), draws, keep=True)
         m = agent.update_injected(rb, s, H.draws_dict(draws))
         for k, v in meta["metrics"][s].items():
-            assert m[k] == pytest.approx(v, rel=LOSS_RTOL if k not in ("target_F", "F1", "phi") else 2e-4, abs=2e-6), (s, k)
+            # (phi_loss of the low-rank learners is a difference of O(1..10) terms: absolute tolerance of that scale)
+            assert m[k] == pytest.approx(v, rel=LOSS_RTOL if k not in ("target_F", "F1", "phi") else 2e-4, abs=2e-5 if k == "phi_loss" else 2e-6), (s, k)
         L = oracle.last
         phi2 = agent.workspace_view("phi2").cpu()
         assert H.rel_err(phi2[:B], L["phi"]) < 2e-5 and H.rel_err(phi2[B:], L["next_phi"]) < 2e-5, s
