@@ -1076,6 +1076,9 @@ class FBHipAgent:
             keep["future_idx"] = torch.as_tensor(np.asarray(draws["future_idx"]), dtype=torch.int32, device=dev).contiguous()
             keep["future_uniform"] = torch.as_tensor(np.asarray(draws["future_uniform"], dtype=np.float32), device=dev).contiguous()
             inj.future_idx, inj.future_uniform = ptr(keep["future_idx"]), ptr(keep["future_uniform"])
+        elif self._sf_mode == 10:                                      # SFAgent's contrastive learner reads batch.future_goal (sf.py:125)
+            keep["future_idx"] = torch.as_tensor(np.asarray(draws["future_idx"]), dtype=torch.int32, device=dev).contiguous()
+            inj.future_idx = ptr(keep["future_idx"])
         self._inject_keep = keep
         c = self.cfg
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
@@ -1262,17 +1265,19 @@ class SFHipAgent(FBHipAgent):
         "FB"           feature_net = the backward_net of a trained FB agent (``fb_features=``), frozen       sf.py:368-380
         "latent"       mean((forward_dynamic_net(cat[phi(goal), action]) - target_feature_net(next_goal))^2), the
                        target net following feature_net at rate 0.01                                          sf.py:230-246
+        "contrastive"  logits = cos(phi(goal), mu_net(future_goal)):  mean(-diag + logsumexp over the off-diagonal of each row);
+                       the buffer must sample hindsight goals (future < 1)                                    sf.py:118-143
         "svd_sr"       SR = phi(goal) . mu_net(next_goal)^T against 0.99 x the same product of two target nets:
                        -2 mean diag SR + mean offdiag (SR - 0.99 target_SR)^2 + orthonormality loss of phi (LRA-SR)   sf.py:264-299
         "svd_srv2"     the same with the roles swapped: SR = mu_net(goal) . phi(next_goal)^T, 0.98, orthonormality of phi(next_goal)   sf.py:303-335
         "svd_p"        P = mu_net(cat[goal, action]) . phi(next_goal)^T:  -2 mean diag P + mean offdiag P^2
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
-    The reference's other three feature learners, ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    The reference's other two feature learners (contrastivev2, identity), ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
     _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7, "svd_sr": 8,
-                 "svd_srv2": 9}                  # -> fbhip_dims.sf
+                 "svd_srv2": 9, "contrastive": 10}   # -> fbhip_dims.sf
     # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
     _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
               5: ("forward_dynamic_net", lambda z, a, g: (z + a, g)), 7: ("forward_dynamic_net", lambda z, a, g: (z + a, z))}
@@ -1355,6 +1360,9 @@ class SFHipAgent(FBHipAgent):
         if self._sf_mode == 6:                  # SVDP.__init__ (sf.py:338-342): mu_net = mlp(g + a, Hb, "ntanh", Hb, "relu", z), then weight_init again
             feat = feat + [("mu_net.0", torch.nn.Linear(g + a, Hb)), ("mu_net.3", torch.nn.Linear(Hb, Hb)), ("mu_net.5", torch.nn.Linear(Hb, d))]
             ortho(feat)
+        if self._sf_mode == 10:                 # ContrastiveFeature.__init__ (sf.py:119-123): mu_net = feature_net's architecture (with "L2"), weight_init again
+            feat = feat + [("mu_net.0", torch.nn.Linear(g, Hb)), ("mu_net.3", torch.nn.Linear(Hb, Hb)), ("mu_net.5", torch.nn.Linear(Hb, d))]
+            ortho(feat)
         if self._sf_mode in (8, 9):             # SVDSR.__init__ / SVDSRv2.__init__ (sf.py:265-270, 304-309): mu_net on the goal alone, then BOTH target nets (own weights), one weight_init
             feat = feat + [(f"{n}.{i}", torch.nn.Linear(*io)) for n in ("mu_net", "target_feature_net", "target_mu_net")
                            for i, io in ((0, (g, Hb)), (3, (Hb, Hb)), (5, (Hb, d)))]
@@ -1369,7 +1377,7 @@ class SFHipAgent(FBHipAgent):
         for p_, lin in feat:
             sd[f"{p_}.weight"], sd[f"{p_}.bias"] = lin.weight.data, torch.zeros_like(lin.bias.data)
         sd["feature_net.1.weight"], sd["feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
-        if self._sf_mode == 6:
+        if self._sf_mode in (6, 10):
             sd["mu_net.1.weight"], sd["mu_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
         if self._sf_mode == 7:
             sd["target_feature_net.1.weight"], sd["target_feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)

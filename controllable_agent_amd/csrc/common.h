@@ -190,6 +190,9 @@ hipError_t launch_sf_loss(const float* F1, const float* F2, const float* nF1, co
 // inverse-dynamics loss of the ICM feature learner (sf.py:207-210): pred = tanh(pre), PHI_LOSS = mean((action - pred)^2), d pre;
 // scratch >= ceil(rows * a / 256) floats
 hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hipStream_t s, int accumulate = 0);   // metrics[dst] (+)= scale * metrics[src]
+// contrastive (sf.py:134-142): L[s, t] = phi_s . mu_t (raw), rows = cols = B.  In place: L <- d loss / d L; loss = mean_s(-l_ss + logsumexp_{t != s} l_st),
+// l = L / d (both embeddings have norm sqrt(d): the cosine) -> metrics[FBHIP_M_PHI_LOSS]
+hipError_t launch_contrastive_rows(float* L, int ld, int B, int d, float* metrics, float* scratch, hipStream_t s);
 hipError_t launch_fill_add(float* dst, const float* add, float fill, int64_t n, hipStream_t s);   // add ? dst[i] += add[i] : dst[i] = fill
 hipError_t launch_icm_loss(const float* pre, int ldp, const float* action, int lda, float* dpre, int ldd, int rows, int a,
                            int squash, float* metrics, float* scratch, hipStream_t s);

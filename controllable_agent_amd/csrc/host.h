@@ -83,6 +83,7 @@ struct Ws {
     Buf dmu, m_dr2, m_dt1;              // its gradient panels
     float* ln_partials_m = nullptr;     // its LayerNorm-backward partial sums (it shares rounds with feature_net's backward)
     float* c99 = nullptr;               // svd_sr: the constant 0.99 "discount" of its target term, one per row
+    Buf dmu_y;                          // contrastive: d(mu_net's pre-projection output)
     Buf dphi_o;                         // svd_sr: the orthonormality share of d phi (a second pairwise launch), added to the first
     Buf icat, ih1, ih2, ipre, d_ipre, d_ih1, d_ih2;          // icm: inverse-dynamics activations / gradients
     Buf zeroF, lapS1, lapS2;                                 // lap: the zero F panel and two throw-away dF panels of the pairwise pass

@@ -888,14 +888,18 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         return FBHIP_E_INVALID;
     }
     // ---- sample: the FB sampler with the identity permutation: goal2 = [goal ; next_goal] (sf.py:705-721), z = sample_z (:723)
-    const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->z_gauss && inj->eps_next && inj->eps_actor;
+    // contrastive reads batch.future_goal (sf.py:125, 713-719): the hindsight draw of in_memory_replay_buffer.py:157-161 without FB's z override
+    const bool hind = d.sf == 10;
+    if (hind && !(hp.future < 1.f)) { c->err = g_err = "fbhip: the contrastive feature learner needs a replay buffer with future < 1"; return FBHIP_E_INVALID; }
+    const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->z_gauss && inj->eps_next && inj->eps_actor && (!hind || inj->future_idx);
     if (head) {
     POST_BEGIN
-    if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, -1.f, 1, s));
+    if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, hind ? hp.future : -1.f, 1, s));
     if (inj != nullptr) {
 #define INJ(field, bytes) if (inj->field) HIPCK(c, hipMemcpyAsync(w.so.field, inj->field, (size_t)(bytes), hipMemcpyDeviceToDevice, s))
         INJ(ep_idx, B * 4); INJ(step_idx, B * 4); INJ(z_gauss, (size_t)B * z * 4); INJ(eps_next, (size_t)B * a * 4);
         INJ(eps_actor, (size_t)B * a * 4);
+        if (hind) INJ(future_idx, B * 4);
 #undef INJ
     }
     GatherArgs ga{};
@@ -903,7 +907,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     ga.Xoa = w.Xoa.p; ga.ld_oa = w.Xoa.ld; ga.Xoz = w.Xoz.p; ga.ld_oz = w.Xoz.ld; ga.Xnoz = w.Xnoz.p; ga.ld_noz = w.Xnoz.ld;
     ga.Xnoa = w.Xnoa.p; ga.ld_noa = w.Xnoa.ld; ga.Xopi = w.Xopi.p; ga.ld_opi = w.Xopi.ld;
     ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
-    ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld; ga.future_idx = nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
+    ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld; ga.future_idx = hind ? w.so.future_idx : nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
     ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount; ga.aoff = aoff; ga.act_idx = nullptr;
     HIPCK(c, launch_gather(ga, s));
     ZPanels zx{};
@@ -956,6 +960,8 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
             backward_map_fwd_chain(c, c->K_t, w.next_goal.p, w.next_goal.ld, w.bsA, B, ch[5]);
             backward_map_fwd_chain(c, c->M_t, w.next_goal.p, w.next_goal.ld, w.bsO, B, ch[6], false, d.goal_dim);
         }
+        if (d.sf == 10 && head)      // contrastive (sf.py:136): future_mu = mu_net(future_goal), the BackwardMap chain WITH its projection
+            backward_map_fwd_chain(c, c->M_p, w.fgoal.p, w.fgoal.ld, w.bsM, B, ch[4]);
         if (d.sf == 9 && head) {
             // svd_srv2 (sf.py:303-318): mu = mu_net(goal); the two target nets on next_goal as for svd_sr
             backward_map_fwd_chain(c, c->M_p, w.bin.p, w.bin.ld, w.bsM, B, ch[4], false, d.goal_dim);
@@ -1063,6 +1069,24 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
                 return (int)FBHIP_OK;
             });
         });
+    } else if (d.sf == 10) {
+        // contrastive (sf.py:134-142): logits = normalize(phi) . normalize(future_mu)^T = phi . mu^T / d (both already have norm sqrt(d)),
+        // loss = mean_s(-logits_ss + logsumexp_{t != s} logits_st).  Three small GEMMs around one row kernel on the [B, B] scratch
+        // matrix (the rand_weight panel, unused here): L = phi . mu^T;  L <- dloss/dL;  d phi = L . mu,  d mu = L^T . phi.  The
+        // projections' own backward passes (feature_net's and mu_net's L2 stages) remove the radial parts, as F.normalize does twice.
+        const float* mu = w.bsM.Bm.p;
+        feat.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(phi, Lz, 1, mu, Lz, 1, w.rw, B, B, B, z)); });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_contrastive_rows(w.rw, B, B, z, w.metrics, w.pw_scratch, q));
+                HIPCK(c, hipMemsetAsync(dnphi, 0, (size_t)B * Lz * sizeof(float), q));
+                return (int)FBHIP_OK;
+            });
+        });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.rw, B, 1, mu, Lz, 0, dphi, Lz, B, z, B));
+            o2.gemms.push_back(P(w.rw, B, 0, phi, Lz, 0, w.dmu.p, Lz, B, z, B));
+        });
     } else if (d.sf == 9) {
         // svd_srv2 (sf.py:311-329): SR = mu(goal) . phi(next_goal)^T against 0.98 x target_mu . target_phi^T (both on next_goal), plus
         // the orthonormality of phi(next_goal): the FB loss itself -- two identical heads F = mu, B = phi', its own orthonormality
@@ -1099,12 +1123,18 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     {
         std::vector<Chain> ch{succ};
         if (d.sf != 3) ch.push_back(feat);
-        if (d.sf == 6 || d.sf == 8 || d.sf == 9) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
+        if (d.sf == 6 || d.sf == 8 || d.sf == 9 || d.sf == 10) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
             Chain mu;
             mu.push_back([](Ops&) {});
             BGrad mg{w.dmu.p, w.dmu.p, w.m_dr2.p, w.m_dt1.p, w.ln_partials_m};
             if (d.sf == 6) backward_map_bwd_chain(c, c->M_p, c->M_g, w.Xga.p, w.Xga.ld, w.bsM, B, mu, true, &mg, d.goal_dim + d.action_dim);
             else if (d.sf == 8) backward_map_bwd_chain(c, c->M_p, c->M_g, w.next_goal.p, w.next_goal.ld, w.bsM, B, mu, true, &mg, d.goal_dim);
+            else if (d.sf == 10) {        // projected: d mu -> d y first; two more empty stages: its loss has three
+                mu.push_back([](Ops&) {});
+                mu.push_back([](Ops&) {});
+                BGrad cg{w.dmu.p, w.dmu_y.p, w.m_dr2.p, w.m_dt1.p, w.ln_partials_m};
+                backward_map_bwd_chain(c, c->M_p, c->M_g, w.fgoal.p, w.fgoal.ld, w.bsM, B, mu, false, &cg);
+            }
             else backward_map_bwd_chain(c, c->M_p, c->M_g, w.bin.p, w.bin.ld, w.bsM, B, mu, true, &mg, d.goal_dim);
             ch.push_back(mu);
         }

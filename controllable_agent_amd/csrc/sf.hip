@@ -203,6 +203,50 @@ hipError_t launch_scale_metric(float* metrics, int src, int dst, float scale, hi
     return hipGetLastError();
 }
 
+// one wavefront per row s of the [B, B] logit matrix
+__global__ void __launch_bounds__(256) contrastive_rows_kernel(float* __restrict__ L, int ld, int B, float inv_d, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float loss = 0.f;
+    if (s < B) {
+        float* row = L + (size_t)s * ld;
+        float mx = -3.0e38f;
+        for (int t = lane; t < B; t += 64)
+            if (t != s) mx = fmaxf(mx, row[t] * inv_d);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float se = 0.f;
+        for (int t = lane; t < B; t += 64)
+            if (t != s) se += expf(row[t] * inv_d - mx);
+        se = wsum(se);
+        const float lse = mx + logf(se);
+        const float lss = row[s] * inv_d;
+        const float gs = inv_d / (float)B;                                   // d mean / d l  times  d l / d L
+        for (int t = lane; t < B; t += 64) row[t] = t == s ? -gs : gs * expf(row[t] * inv_d - lse);
+        loss = lse - lss;
+    }
+    if (lane == 0) red[threadIdx.x >> 6] = loss;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(64) contrastive_finalize_kernel(const float* __restrict__ part, int nblk, int B, float* __restrict__ metrics) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) metrics[FBHIP_M_PHI_LOSS] = (float)(s / (double)B);
+}
+
+hipError_t launch_contrastive_rows(float* L, int ld, int B, int d, float* metrics, float* scratch, hipStream_t s) {
+    const int nblk = (B + 3) / 4;
+    hipLaunchKernelGGL(contrastive_rows_kernel, dim3(nblk), dim3(256), 0, s, L, ld, B, 1.0f / (float)d, scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(contrastive_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, B, metrics);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) fill_add_kernel(float* __restrict__ dst, const float* __restrict__ add, float fill, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = add != nullptr ? dst[i] + add[i] : fill;

@@ -403,6 +403,19 @@ def sf_svdsrv2_fixture(R):
     _sf_inits(R, ("svd_srv2",))
 
 
+def sf_contrastive_fixture(R):
+    """feature_learner="contrastive" (ContrastiveFeature, sf.py:118-143; the paper's CL): the cosine of phi(goal) and mu_net(future_goal)
+    over the batch, InfoNCE without the diagonal in the denominator; the buffer samples hindsight goals (future = 0.8).  Second trace
+    with a goal space and variable episode lengths."""
+    _sf_traces(R, (
+        ("tiny_sf_contrastive_trace", "contrastive", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0, future=0.8),
+         dict(seed=142, n_eps=6, T=12, n_steps=4)),
+        ("tiny_sf_contrastive_goal_trace", "contrastive", False,
+         dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0, future=0.7),
+         dict(seed=143, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True))))
+    _sf_inits(R, ("contrastive",))
+
+
 def _sf_traces(R, table):
     from oracle import sf_oracle as so
     for name, learner, q_loss, kw, extra in table:
@@ -763,6 +776,7 @@ def main():
     sf_latent_fixture(R)
     sf_svdsr_fixture(R)
     sf_svdsrv2_fixture(R)
+    sf_contrastive_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

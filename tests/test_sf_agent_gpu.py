@@ -62,7 +62,8 @@ def set_sf_state(agent, state: dict, steps: int) -> None:
 
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
                                   "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
-                                  "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace"])
+                                  "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace",
+                                  "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace"])
 def test_sf_teacher_forced_against_reference_trace(name):
     """Each step starts from the REFERENCE SFAgent's recorded state, runs one HIP update with the recorded draws and must land
     on the reference's next state and metrics; intermediates and gradients are compared with the oracle's autograd."""
@@ -91,10 +92,12 @@ def test_sf_teacher_forced_against_reference_trace(name):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < GRAD_REL_L2, (s, view)
         dphi2 = agent.workspace_view("dphi2").cpu()
         # "random" has no feature loss (sf.py:447-449); autoencoder / transition never read next_phi, svd_p never reads phi
-        for got, ref in ((dphi2[:B], L["dphi"]), (dphi2[B:], L["dnext_phi"])):
+        for got, ref, at in ((dphi2[:B], L["dphi"], L["phi"]), (dphi2[B:], L["dnext_phi"], L["next_phi"])):
             if float(ref.abs().max()) == 0.0:
                 assert float(got.abs().max()) == 0.0, s
             else:
+                if learner == "contrastive":     # F.normalize(phi) drops the radial part of the gradient; here feature_net's own L2 stage does
+                    got = got - at * (got * at).sum(1, keepdim=True) / (at * at).sum(1, keepdim=True)
                 assert H.rel_err(got, ref) < GRAD_REL_L2, s
         for net, key in (("successor_net", "grads_successor"), ("feature_learner", "grads_feature"), ("actor", "grads_actor")):
             for k, g in agent._grad_views[net].state_dict().items():
@@ -121,23 +124,24 @@ def test_sf_teacher_forced_against_reference_trace(name):
                                                  ("random", True, False), ("autoencoder", False, True), ("autoencoder", True, False),
                                                  ("transition", True, False), ("transition", False, True), ("svd_p", True, False),
                                                  ("svd_p", False, True), ("latent", True, False), ("svd_sr", True, False),
-                                                 ("svd_sr", False, True), ("svd_srv2", True, False)])
+                                                 ("svd_sr", False, True), ("svd_srv2", True, False), ("contrastive", True, False),
+                                                 ("contrastive", False, True)])
 def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal):
     """hidden 1024 / feature 512 / Hb 512 (the reference defaults), z 100, batch 256, walker-sized inputs: three free-running
     updates against the oracle (metrics + parameter checksums)."""
     cfg = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=3 if goal else 24, z_dim=100, backward_hidden_dim=512, batch_size=256,
-                          lr_coef=5.0, mix_ratio=0.0, use_goal=goal)
+                          lr_coef=5.0, mix_ratio=0.0, use_goal=goal, future=0.8 if learner == "contrastive" else 1.0)
     rng = np.random.default_rng(41)
     shapes = so.net_shapes(cfg, learner)
     nets = {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}
     storage, lengths = fo.synthetic_storage(rng, 10, 40, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if goal else None)
     agent = make_sf_agent(cfg, nets, learner, q_loss, "simplified_walker" if goal else None)
-    rb = _buffer(storage, lengths, cfg.discount)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
     torch.set_num_threads(8)
     oracle = so.SFOracleAgent(cfg, nets, learner, q_loss)
     for s in range(3):
         d = fo.make_draws(rng, cfg, 10, lengths)
-        mo = oracle.update(fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount), d)
+        mo = oracle.update(fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount, d.future_idx), d)
         m = agent.update_injected(rb, s, H.draws_dict(d))
         for k in ("sf_loss", "phi_loss", "actor_loss", "target_F", "phi_norm", "z_norm"):
             if k == "phi_loss" and learner == "random":
@@ -152,7 +156,7 @@ def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal)
             assert float(np.linalg.norm(got[k])) == pytest.approx(float(np.linalg.norm(v)), rel=2e-5 if v.ndim == 2 else 2e-4), k
 
 
-@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2"])
+@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive"])
 def test_sf_constructor_init_matches_reference_seed(learner):
     """same torch.manual_seed => SFAgent's orthogonal init tensor for tensor (sf.py:419-463; ICM re-applies weight_init)"""
     z = np.load(H.GOLDEN / f"init_seed1_tiny_sf_{learner}.npz")
@@ -214,7 +218,8 @@ def test_sf_pickle_init_from_update_many_and_inference():
 def test_sf_unsupported_options_fail_loudly():
     from controllable_agent_amd.agent import SFHipAgent
     base = dict(obs_type="states", obs_shape=(5,), action_shape=(3,), num_expl_steps=0)
-    for bad in (dict(feature_learner="contrastive"), dict(mix_ratio=0.3), dict(boltzmann=True), dict(num_sf_updates=2)):
+    for bad in (dict(feature_learner="contrastivev2"), dict(feature_learner="identity"), dict(mix_ratio=0.3), dict(boltzmann=True),
+                dict(num_sf_updates=2)):
         with pytest.raises(NotImplementedError):
             SFHipAgent(**{**base, **bad})
 
@@ -273,7 +278,7 @@ def test_sf_fb_features_take_the_backward_net_of_a_trained_fb_agent():
 
 
 @pytest.mark.parametrize("name", ["tiny_sf_lap_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace", "tiny_sf_svdp_goal_trace",
-                                  "tiny_sf_random_trace", "tiny_sf_latent_trace", "tiny_sf_svdsr_goal_trace"])
+                                  "tiny_sf_random_trace", "tiny_sf_latent_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_contrastive_goal_trace"])
 def test_sf_pipelined_update_many_equals_single_updates(name):
     """fbhip_update_many cuts an SF update into head (sampling, online successor_net, feature_net [, mu_net]), middle and actor phase
     and runs the next step's head beside the actor phase: same kernels and operands, so the state after n pipelined steps equals n
@@ -289,6 +294,18 @@ def test_sf_pipelined_update_many_equals_single_updates(name):
     assert a1.step_counts() == a2.step_counts() == (5, 5)
     for k in s1:
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+
+
+def test_sf_contrastive_needs_hindsight_goals():
+    """the contrastive learner reads batch.future_goal (sf.py:125): a buffer with future = 1 has none -- loud error, no update"""
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_contrastive_trace")
+    agent = make_sf_agent(cfg, nets, "contrastive", True)
+    with pytest.raises(RuntimeError, match="future < 1"):
+        agent.update(_buffer(storage, lengths, cfg.discount, 1.0), 0)
+    assert agent.step_counts() == (0, 0)
+    agent.update(_buffer(storage, lengths, cfg.discount, 0.8), 0)        # device-drawn hindsight indices
+    fut, step = (agent.workspace_view(n).cpu().numpy()[0] for n in ("future_idx", "step_idx"))
+    assert np.all(fut >= step) and np.all(fut <= 12) and agent.step_counts() == (1, 1)
 
 
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_svdp_goal_trace"])
