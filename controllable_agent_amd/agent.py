@@ -1076,7 +1076,7 @@ class FBHipAgent:
             keep["future_idx"] = torch.as_tensor(np.asarray(draws["future_idx"]), dtype=torch.int32, device=dev).contiguous()
             keep["future_uniform"] = torch.as_tensor(np.asarray(draws["future_uniform"], dtype=np.float32), device=dev).contiguous()
             inj.future_idx, inj.future_uniform = ptr(keep["future_idx"]), ptr(keep["future_uniform"])
-        elif self._sf_mode == 10:                                      # SFAgent's contrastive learner reads batch.future_goal (sf.py:125)
+        elif self._sf_mode in (10, 11):                                # SFAgent's contrastive learners read batch.future_goal (sf.py:125, 167)
             keep["future_idx"] = torch.as_tensor(np.asarray(draws["future_idx"]), dtype=torch.int32, device=dev).contiguous()
             inj.future_idx = ptr(keep["future_idx"])
         self._inject_keep = keep
@@ -1267,17 +1267,18 @@ class SFHipAgent(FBHipAgent):
                        target net following feature_net at rate 0.01                                          sf.py:230-246
         "contrastive"  logits = cos(phi(goal), mu_net(future_goal)):  mean(-diag + logsumexp over the off-diagonal of each row);
                        the buffer must sample hindsight goals (future < 1)                                    sf.py:118-143
+        "contrastivev2" the same with the roles swapped: cos(mu_net(goal), phi(future_goal))                    sf.py:159-186
         "svd_sr"       SR = phi(goal) . mu_net(next_goal)^T against 0.99 x the same product of two target nets:
                        -2 mean diag SR + mean offdiag (SR - 0.99 target_SR)^2 + orthonormality loss of phi (LRA-SR)   sf.py:264-299
         "svd_srv2"     the same with the roles swapped: SR = mu_net(goal) . phi(next_goal)^T, 0.98, orthonormality of phi(next_goal)   sf.py:303-335
         "svd_p"        P = mu_net(cat[goal, action]) . phi(next_goal)^T:  -2 mean diag P + mean offdiag P^2
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
-    The reference's other two feature learners (contrastivev2, identity), ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    The reference's last feature learner (identity: feature_net = nn.Identity, z_dim = goal_dim), ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
     _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7, "svd_sr": 8,
-                 "svd_srv2": 9, "contrastive": 10}   # -> fbhip_dims.sf
+                 "svd_srv2": 9, "contrastive": 10, "contrastivev2": 11}   # -> fbhip_dims.sf
     # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
     _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
               5: ("forward_dynamic_net", lambda z, a, g: (z + a, g)), 7: ("forward_dynamic_net", lambda z, a, g: (z + a, z))}
@@ -1360,7 +1361,7 @@ class SFHipAgent(FBHipAgent):
         if self._sf_mode == 6:                  # SVDP.__init__ (sf.py:338-342): mu_net = mlp(g + a, Hb, "ntanh", Hb, "relu", z), then weight_init again
             feat = feat + [("mu_net.0", torch.nn.Linear(g + a, Hb)), ("mu_net.3", torch.nn.Linear(Hb, Hb)), ("mu_net.5", torch.nn.Linear(Hb, d))]
             ortho(feat)
-        if self._sf_mode == 10:                 # ContrastiveFeature.__init__ (sf.py:119-123): mu_net = feature_net's architecture (with "L2"), weight_init again
+        if self._sf_mode in (10, 11):           # ContrastiveFeature(v2).__init__ (sf.py:119-123, 160-164): mu_net = feature_net's architecture (with "L2"), weight_init again
             feat = feat + [("mu_net.0", torch.nn.Linear(g, Hb)), ("mu_net.3", torch.nn.Linear(Hb, Hb)), ("mu_net.5", torch.nn.Linear(Hb, d))]
             ortho(feat)
         if self._sf_mode in (8, 9):             # SVDSR.__init__ / SVDSRv2.__init__ (sf.py:265-270, 304-309): mu_net on the goal alone, then BOTH target nets (own weights), one weight_init
@@ -1377,7 +1378,7 @@ class SFHipAgent(FBHipAgent):
         for p_, lin in feat:
             sd[f"{p_}.weight"], sd[f"{p_}.bias"] = lin.weight.data, torch.zeros_like(lin.bias.data)
         sd["feature_net.1.weight"], sd["feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
-        if self._sf_mode in (6, 10):
+        if self._sf_mode in (6, 10, 11):
             sd["mu_net.1.weight"], sd["mu_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
         if self._sf_mode == 7:
             sd["target_feature_net.1.weight"], sd["target_feature_net.1.bias"] = torch.ones(Hb), torch.zeros(Hb)

@@ -116,7 +116,7 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
             b.mat(i + "4.weight", hout, Hb, HbP); b.vec(i + "4.bias", hout);
             append(order, {i + "0.weight", i + "0.bias", i + "2.weight", i + "2.bias", i + "4.weight", i + "4.bias"});
         }
-        if (d.sf == 6 || d.sf == 8 || d.sf == 9 || d.sf == 10) {      // (contrastive, sf.py:121: the same modules + the projection) SVDP: mu_net = mlp(g + a, Hb, "ntanh", Hb, "relu", z)  (sf.py:340; BackwardMap.B's modules, no projection);
+        if (d.sf == 6 || d.sf >= 8) {      // (contrastive / contrastivev2, sf.py:121, 162: the same modules + the projection) SVDP: mu_net = mlp(g + a, Hb, "ntanh", Hb, "relu", z)  (sf.py:340; BackwardMap.B's modules, no projection);
             const std::string m = "mu_net.";   // SVDSR: the same on the goal alone (sf.py:268)
             const int mi = d.sf == 6 ? g + a : g;
             b.mat(m + "0.weight", Hb, mi, pad32(mi), HbP); b.vec(m + "0.bias", Hb, HbP); b.vec(m + "1.weight", Hb, HbP);
@@ -165,7 +165,7 @@ int check_dims(const fbhip_dims* d) {
     if (d->batch > 8192) { g_err = "fbhip: batch > 8192 per GPU unsupported (permutation sort)"; return FBHIP_E_INVALID; }
     if (d->discrete && d->preprocess) { g_err = "fbhip: discrete needs preprocess == 0 (the reference's discrete ForwardMap.forward only runs without the preprocess nets, discrete_fb.py:91-94)"; return FBHIP_E_INVALID; }
     if (d->discrete && (int64_t)d->z_dim * d->action_dim > 8192) { g_err = "fbhip: discrete: z_dim * actions > 8192 unsupported"; return FBHIP_E_INVALID; }
-    if (d->sf < 0 || d->sf > 10) { g_err = "fbhip: dims.sf must be 0 or 1..10 (icm, lap, random, autoencoder, transition, svd_p, latent, svd_sr, svd_srv2, contrastive)"; return FBHIP_E_INVALID; }
+    if (d->sf < 0 || d->sf > 11) { g_err = "fbhip: dims.sf must be 0 or 1..11 (icm, lap, random, autoencoder, transition, svd_p, latent, svd_sr, svd_srv2, contrastive, contrastivev2)"; return FBHIP_E_INVALID; }
     if (d->sf && (d->discrete || d->boltzmann || !d->norm_z)) { g_err = "fbhip: dims.sf needs discrete = 0, boltzmann = 0, norm_z = 1"; return FBHIP_E_INVALID; }
     if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
     return FBHIP_OK;
@@ -235,10 +235,12 @@ Ws carve(const fbhip_dims& d, void* base) {
     }
     w.Xo = c.buf(B, o, pad32(o));
     if (d.sf) {
-        w.goal2 = c.buf(2 * B, g, pad32(g));
+        // [goal ; next_goal] -- contrastivev2 also runs feature_net on the hindsight goals: a third block of rows
+        w.goal2 = c.buf((d.sf == 11 ? 3 : 2) * B, g, pad32(g));
         w.bin = w.goal2; w.bin.rows = B;
         w.next_goal = w.bin; w.next_goal.p = base ? w.goal2.p + (size_t)B * w.goal2.ld : nullptr;
-        w.fgoal = c.buf(d.sf == 10 ? B : 1, g, pad32(g));      // (contrastive reads the hindsight goal of every row)
+        if (d.sf == 11) { w.fgoal = w.bin; w.fgoal.p = base ? w.goal2.p + (size_t)2 * B * w.goal2.ld : nullptr; }
+        else w.fgoal = c.buf(d.sf == 10 ? B : 1, g, pad32(g));      // (contrastive reads the hindsight goal of every row)
     } else {
         w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.fgoal = c.buf(B, g, pad32(g));
     }
@@ -272,20 +274,21 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.cov = c.buf(z, z); w.inv_cov = c.buf(z, z); w.BinvC = c.buf(B, z);
     const int nmax = H > Hb ? H : Hb;
     w.ln_partials = c.f((size_t)2 * ((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);   // two trunks
-    w.ln_partials_b = c.f((size_t)(((d.sf ? 2 : 1) * B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
+    w.ln_partials_b = c.f((size_t)(((d.sf == 11 ? 3 : d.sf ? 2 : 1) * B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * nmax);
     w.pw_scratch = c.f(pairwise_scratch_floats(B, z));
     w.splitk = c.f((size_t)6 << 20);
     w.rw = c.f((size_t)B * B); w.rw_u = c.f(B); w.ymixw = c.buf(B, z);
     if (d.sf) {
         const int Lb = pad64(Hb), Lz = pad4(z), La = pad4(a);
-        w.bsS.pre1 = c.buf(2 * B, Hb, Lb); w.bsS.t1 = c.buf(2 * B, Hb, Lb); w.bsS.r2 = c.buf(2 * B, Hb, Lb);
-        w.bsS.y = c.buf(2 * B, z); w.bsS.Bm = c.buf(2 * B, z);
-        w.bsS.stats = c.f(4 * (size_t)B); w.bsS.norms = c.f(2 * (size_t)B);
-        w.dBm2 = c.buf(2 * B, z); w.dy2 = c.buf(2 * B, z); w.s_dr2 = c.buf(2 * B, Hb, Lb); w.s_dt1 = c.buf(2 * B, Hb, Lb);
+        const int RB = (d.sf == 11 ? 3 : 2) * B;              // rows of the feature pass
+        w.bsS.pre1 = c.buf(RB, Hb, Lb); w.bsS.t1 = c.buf(RB, Hb, Lb); w.bsS.r2 = c.buf(RB, Hb, Lb);
+        w.bsS.y = c.buf(RB, z); w.bsS.Bm = c.buf(RB, z);
+        w.bsS.stats = c.f(2 * (size_t)RB); w.bsS.norms = c.f((size_t)RB);
+        w.dBm2 = c.buf(RB, z); w.dy2 = c.buf(RB, z); w.s_dr2 = c.buf(RB, Hb, Lb); w.s_dt1 = c.buf(RB, Hb, Lb);
         if (d.sf == 2 || d.sf == 6 || d.sf == 8 || d.sf == 9) { w.zeroF = c.buf(B, z); w.lapS1 = c.buf(B, z); w.lapS2 = c.buf(B, z); }
         if (d.sf == 8 || d.sf == 9) { w.c99 = c.f(B); w.dphi_o = c.buf(B, z); }
-        if (d.sf == 10) w.dmu_y = c.buf(B, z);
-        if (d.sf == 6 || d.sf == 8 || d.sf == 9 || d.sf == 10) {
+        if (d.sf == 10 || d.sf == 11) w.dmu_y = c.buf(B, z);
+        if (d.sf == 6 || d.sf >= 8) {
             w.Xga = c.buf(B, g + a, pad32(g + a));
             w.dmu = c.buf(B, z); w.m_dr2 = c.buf(B, Hb, Lb); w.m_dt1 = c.buf(B, Hb, Lb);
             w.ln_partials_m = c.f((size_t)((B + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK) * 2 * (size_t)(H > Hb ? H : Hb));

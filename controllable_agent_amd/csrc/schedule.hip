@@ -889,7 +889,8 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     }
     // ---- sample: the FB sampler with the identity permutation: goal2 = [goal ; next_goal] (sf.py:705-721), z = sample_z (:723)
     // contrastive reads batch.future_goal (sf.py:125, 713-719): the hindsight draw of in_memory_replay_buffer.py:157-161 without FB's z override
-    const bool hind = d.sf == 10;
+    const bool hind = d.sf == 10 || d.sf == 11;
+    const int RB = (d.sf == 11 ? 3 : 2) * B;              // rows of the feature pass: [goal ; next_goal (; future_goal)]
     if (hind && !(hp.future < 1.f)) { c->err = g_err = "fbhip: the contrastive feature learner needs a replay buffer with future < 1"; return FBHIP_E_INVALID; }
     const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->z_gauss && inj->eps_next && inj->eps_actor && (!hind || inj->future_idx);
     if (head) {
@@ -945,7 +946,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         }
         if (head) {
             forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
-            backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, ch[2]);
+            backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, RB, ch[2]);
         }
         if (mid) {
             actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[3], !fused_policy);
@@ -962,6 +963,8 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         }
         if (d.sf == 10 && head)      // contrastive (sf.py:136): future_mu = mu_net(future_goal), the BackwardMap chain WITH its projection
             backward_map_fwd_chain(c, c->M_p, w.fgoal.p, w.fgoal.ld, w.bsM, B, ch[4]);
+        if (d.sf == 11 && head)      // contrastivev2 (sf.py:175-176): mu = mu_net(goal); future_phi is the third block of the feature pass
+            backward_map_fwd_chain(c, c->M_p, w.bin.p, w.bin.ld, w.bsM, B, ch[4]);
         if (d.sf == 9 && head) {
             // svd_srv2 (sf.py:303-318): mu = mu_net(goal); the two target nets on next_goal as for svd_sr
             backward_map_fwd_chain(c, c->M_p, w.bin.p, w.bin.ld, w.bsM, B, ch[4], false, d.goal_dim);
@@ -1069,6 +1072,23 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
                 return (int)FBHIP_OK;
             });
         });
+    } else if (d.sf == 11) {
+        // contrastivev2 (sf.py:173-186): the same loss with the roles swapped -- logits[s, t] = cos(mu_net(goal)_s, feature_net(future_goal)_t)
+        const float* mu = w.bsM.Bm.p;
+        const float* fphi = w.bsS.Bm.p + (size_t)2 * B * Lz;
+        float* dfphi = w.dBm2.p + (size_t)2 * B * Lz;
+        feat.push_back([=, &w](Ops& o2) { o2.gemms.push_back(P(mu, Lz, 1, fphi, Lz, 1, w.rw, B, B, B, z)); });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.post.push_back([=, &w](hipStream_t q) -> int {
+                HIPCK(c, launch_contrastive_rows(w.rw, B, B, z, w.metrics, w.pw_scratch, q));
+                HIPCK(c, hipMemsetAsync(dphi, 0, (size_t)2 * B * Lz * sizeof(float), q));      // goal and next_goal rows: no gradient
+                return (int)FBHIP_OK;
+            });
+        });
+        feat.push_back([=, &w](Ops& o2) {
+            o2.gemms.push_back(P(w.rw, B, 1, fphi, Lz, 0, w.dmu.p, Lz, B, z, B));
+            o2.gemms.push_back(P(w.rw, B, 0, mu, Lz, 0, dfphi, Lz, B, z, B));
+        });
     } else if (d.sf == 10) {
         // contrastive (sf.py:134-142): logits = normalize(phi) . normalize(future_mu)^T = phi . mu^T / d (both already have norm sqrt(d)),
         // loss = mean_s(-logits_ss + logsumexp_{t != s} logits_st).  Three small GEMMs around one row kernel on the [B, B] scratch
@@ -1117,23 +1137,24 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     // (random, sf.py:430: feature_net keeps its initial weights -- no loss, no phi_opt; its gradient block stays zero and the
     // Adam pass below leaves it where it is)
     BGrad bg{w.dBm2.p, w.dy2.p, w.s_dr2.p, w.s_dt1.p};
-    if (d.sf != 3) backward_map_bwd_chain(c, c->K_p, c->K_g, w.goal2.p, w.goal2.ld, w.bsS, 2 * B, feat, false, &bg);
+    if (d.sf != 3) backward_map_bwd_chain(c, c->K_p, c->K_g, w.goal2.p, w.goal2.ld, w.bsS, RB, feat, false, &bg);
     Chain succ;
     forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, succ);
     {
         std::vector<Chain> ch{succ};
         if (d.sf != 3) ch.push_back(feat);
-        if (d.sf == 6 || d.sf == 8 || d.sf == 9 || d.sf == 10) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
+        if (d.sf == 6 || d.sf >= 8) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
             Chain mu;
             mu.push_back([](Ops&) {});
             BGrad mg{w.dmu.p, w.dmu.p, w.m_dr2.p, w.m_dt1.p, w.ln_partials_m};
             if (d.sf == 6) backward_map_bwd_chain(c, c->M_p, c->M_g, w.Xga.p, w.Xga.ld, w.bsM, B, mu, true, &mg, d.goal_dim + d.action_dim);
             else if (d.sf == 8) backward_map_bwd_chain(c, c->M_p, c->M_g, w.next_goal.p, w.next_goal.ld, w.bsM, B, mu, true, &mg, d.goal_dim);
-            else if (d.sf == 10) {        // projected: d mu -> d y first; two more empty stages: its loss has three
+            else if (d.sf == 10 || d.sf == 11) {        // projected: d mu -> d y first; two more empty stages: its loss has three
                 mu.push_back([](Ops&) {});
                 mu.push_back([](Ops&) {});
                 BGrad cg{w.dmu.p, w.dmu_y.p, w.m_dr2.p, w.m_dt1.p, w.ln_partials_m};
-                backward_map_bwd_chain(c, c->M_p, c->M_g, w.fgoal.p, w.fgoal.ld, w.bsM, B, mu, false, &cg);
+                const Buf& xin = d.sf == 10 ? w.fgoal : w.bin;
+                backward_map_bwd_chain(c, c->M_p, c->M_g, xin.p, xin.ld, w.bsM, B, mu, false, &cg);
             }
             else backward_map_bwd_chain(c, c->M_p, c->M_g, w.bin.p, w.bin.ld, w.bsM, B, mu, true, &mg, d.goal_dim);
             ch.push_back(mu);
@@ -1150,7 +1171,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     // (latent, sf.py:245: utils.soft_update_params(feature_net, target_feature_net, 0.01) runs inside the learner's forward(), i.e.
     // towards the feature parameters as they were BEFORE phi_opt.step(); the other learners never read that part of the target buffer)
     HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf, hp.grad_scale,
-                             hp.fb_target_tau, w.st, 0, 0, s, d.sf >= 7 ? 0.01f : -1.f, d.sf >= 7 ? 1 : 0));
+                             hp.fb_target_tau, w.st, 0, 0, s, (d.sf >= 7 && d.sf <= 9) ? 0.01f : -1.f, (d.sf >= 7 && d.sf <= 9) ? 1 : 0));
     POST_END
     return FBHIP_OK;
 }

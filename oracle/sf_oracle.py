@@ -45,7 +45,7 @@ def feature_learner_shapes(cfg: fo.OracleConfig, learner: str):
                 (f"{name}.4.weight", (fout, Hb)), (f"{name}.4.bias", (fout,))]
     if learner == "latent":       # + target_feature_net: feature_net's architecture, own weights, no gradients (sf.py:234)
         out += [("target_" + n, shp) for n, shp in out[:8]]
-    elif learner == "contrastive":     # mu_net = feature_net's architecture on the hindsight goal (sf.py:121)
+    elif learner in ("contrastive", "contrastivev2"):     # mu_net = feature_net's architecture (sf.py:121, 162)
         out += [("mu_net" + n[len("feature_net"):], shp) for n, shp in out[:8]]
     elif learner in ("svd_sr", "svd_srv2"):     # mu_net on the goal alone, then target copies of both nets (sf.py:265-269)
         mu = [("mu_net.0.weight", (Hb, g)), ("mu_net.0.bias", (Hb,)), ("mu_net.1.weight", (Hb,)), ("mu_net.1.bias", (Hb,)),
@@ -95,10 +95,16 @@ def head_mlp(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
 
 def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int, future_goal=None) -> tp.Dict[str, tp.Any]:
     phi, next_phi = feature_net(p, goal, z_dim), feature_net(p, next_goal, z_dim)
-    if learner == "contrastive":                                   # sf.py:125-143
+    if learner in ("contrastive", "contrastivev2"):                # sf.py:125-143 / :166-186
         assert future_goal is not None
-        mu = feature_net({"feature_net" + k[len("mu_net"):]: v for k, v in p.items() if k.startswith("mu_net.")}, future_goal, z_dim)
-        logits = torch.einsum('sd, td-> st', F.normalize(phi, dim=1), F.normalize(mu, dim=1))
+        mup = {"feature_net" + k[len("mu_net"):]: v for k, v in p.items() if k.startswith("mu_net.")}
+        if learner == "contrastive":
+            mu = feature_net(mup, future_goal, z_dim)
+            logits = torch.einsum('sd, td-> st', F.normalize(phi, dim=1), F.normalize(mu, dim=1))
+        else:                                                      # v2: mu on the goal, the features of the hindsight goal
+            mu = feature_net(mup, goal, z_dim)
+            future_phi = feature_net(p, future_goal, z_dim)
+            logits = torch.einsum('sd, td-> st', F.normalize(mu, dim=1), F.normalize(future_phi, dim=1))
         off = ~torch.eye(*logits.size()).bool()
         lod = logits[off].reshape(logits.shape[0], logits.shape[0] - 1)
         return {"phi_loss": (-logits.diag() + torch.logsumexp(lod, dim=1)).mean(), "phi": phi, "next_phi": next_phi, "mu": mu}
@@ -161,7 +167,7 @@ def _grad_or_zero(x: torch.Tensor, retained: bool) -> torch.Tensor:
 
 class SFOracleAgent:
     """State of one SFAgent (sf.py:383-474) and its ``update`` (:700-768) for ``feature_learner`` in {"icm", "lap", "random",
-    "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive"}."""
+    "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive", "contrastivev2"}."""
 
     NETS = ("actor", "successor_net", "feature_learner")
 
@@ -209,7 +215,7 @@ class SFOracleAgent:
             sf_loss = F.mse_loss(Q1, target_Q) + F.mse_loss(Q2, target_Q)
         pp = self._req(self.feature_learner)
         future_goal = None
-        if self.learner == "contrastive":                           # sf.py:713, 719
+        if self.learner in ("contrastive", "contrastivev2"):        # sf.py:713, 719
             future_goal = t(batch["future_goal"] if cfg.use_goal else batch["future_obs"])
         L = phi_loss_terms(pp, self.learner, goal, action, next_goal, cfg.z_dim, future_goal)
         if keep:

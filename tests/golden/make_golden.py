@@ -416,6 +416,15 @@ def sf_contrastive_fixture(R):
     _sf_inits(R, ("contrastive",))
 
 
+def sf_contrastivev2_fixture(R):
+    """feature_learner="contrastivev2" (sf.py:159-186): contrastive with mu_net on the goal and feature_net on the hindsight goal."""
+    _sf_traces(R, (
+        ("tiny_sf_contrastivev2_trace", "contrastivev2", True,
+         dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.0, future=0.75),
+         dict(seed=144, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)),))
+    _sf_inits(R, ("contrastivev2",))
+
+
 def _sf_traces(R, table):
     from oracle import sf_oracle as so
     for name, learner, q_loss, kw, extra in table:
@@ -777,6 +786,7 @@ def main():
     sf_svdsr_fixture(R)
     sf_svdsrv2_fixture(R)
     sf_contrastive_fixture(R)
+    sf_contrastivev2_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -236,7 +236,8 @@ def test_sf_layout_follows_the_reference_modules(lib):
                                ("mu_net.3.weight", 20, 20), ("mu_net.3.bias", 1, 20), ("mu_net.5.weight", 10, 20), ("mu_net.5.bias", 1, 10)]   # svd_sr, sf.py:265
     assert names(9) == names(8)                                                # svd_srv2: the same modules (sf.py:304-308)
     assert names(10) == names(8)                                               # contrastive: mu_net on the (hindsight) goal (sf.py:121)
-    too = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 0, 0, 11)
+    assert names(11) == names(8)                                               # contrastivev2 (sf.py:162)
+    too = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 0, 0, 12)
     assert l.fbhip_net_numel(C.byref(too), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)
     bad = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 1, 0, 1)          # boltzmann + sf
     assert l.fbhip_net_numel(C.byref(bad), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)

@@ -63,7 +63,7 @@ def set_sf_state(agent, state: dict, steps: int) -> None:
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
                                   "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
                                   "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace",
-                                  "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace"])
+                                  "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace", "tiny_sf_contrastivev2_trace"])
 def test_sf_teacher_forced_against_reference_trace(name):
     """Each step starts from the REFERENCE SFAgent's recorded state, runs one HIP update with the recorded draws and must land
     on the reference's next state and metrics; intermediates and gradients are compared with the oracle's autograd."""
@@ -84,7 +84,7 @@ def test_sf_teacher_forced_against_reference_trace(name):
             assert m[k] == pytest.approx(v, rel=LOSS_RTOL if k not in ("target_F", "F1", "phi") else 2e-4, abs=2e-5 if k == "phi_loss" else 2e-6), (s, k)
         L = oracle.last
         phi2 = agent.workspace_view("phi2").cpu()
-        assert H.rel_err(phi2[:B], L["phi"]) < 2e-5 and H.rel_err(phi2[B:], L["next_phi"]) < 2e-5, s
+        assert H.rel_err(phi2[:B], L["phi"]) < 2e-5 and H.rel_err(phi2[B:2 * B], L["next_phi"]) < 2e-5, s   # (contrastivev2: a third block, phi(future_goal))
         for view, ref in (("z", L["z"]), ("next_action", L["next_action"]), ("F1", L["F1"]), ("F2", L["F2"]), ("tF1", L["nF1"]),
                           ("tF2", L["nF2"]), ("mu", L["mu"]), ("pi_action", L["pi_action"])):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < 2e-5, (s, view)
@@ -92,11 +92,11 @@ def test_sf_teacher_forced_against_reference_trace(name):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < GRAD_REL_L2, (s, view)
         dphi2 = agent.workspace_view("dphi2").cpu()
         # "random" has no feature loss (sf.py:447-449); autoencoder / transition never read next_phi, svd_p never reads phi
-        for got, ref, at in ((dphi2[:B], L["dphi"], L["phi"]), (dphi2[B:], L["dnext_phi"], L["next_phi"])):
+        for got, ref, at in ((dphi2[:B], L["dphi"], L["phi"]), (dphi2[B:2 * B], L["dnext_phi"], L["next_phi"])):
             if float(ref.abs().max()) == 0.0:
                 assert float(got.abs().max()) == 0.0, s
             else:
-                if learner == "contrastive":     # F.normalize(phi) drops the radial part of the gradient; here feature_net's own L2 stage does
+                if learner.startswith("contrastive"):     # F.normalize(phi) drops the radial part of the gradient; here feature_net's own L2 stage does
                     got = got - at * (got * at).sum(1, keepdim=True) / (at * at).sum(1, keepdim=True)
                 assert H.rel_err(got, ref) < GRAD_REL_L2, s
         for net, key in (("successor_net", "grads_successor"), ("feature_learner", "grads_feature"), ("actor", "grads_actor")):
@@ -125,12 +125,12 @@ def test_sf_teacher_forced_against_reference_trace(name):
                                                  ("transition", True, False), ("transition", False, True), ("svd_p", True, False),
                                                  ("svd_p", False, True), ("latent", True, False), ("svd_sr", True, False),
                                                  ("svd_sr", False, True), ("svd_srv2", True, False), ("contrastive", True, False),
-                                                 ("contrastive", False, True)])
+                                                 ("contrastive", False, True), ("contrastivev2", True, True)])
 def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal):
     """hidden 1024 / feature 512 / Hb 512 (the reference defaults), z 100, batch 256, walker-sized inputs: three free-running
     updates against the oracle (metrics + parameter checksums)."""
     cfg = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=3 if goal else 24, z_dim=100, backward_hidden_dim=512, batch_size=256,
-                          lr_coef=5.0, mix_ratio=0.0, use_goal=goal, future=0.8 if learner == "contrastive" else 1.0)
+                          lr_coef=5.0, mix_ratio=0.0, use_goal=goal, future=0.8 if learner.startswith("contrastive") else 1.0)
     rng = np.random.default_rng(41)
     shapes = so.net_shapes(cfg, learner)
     nets = {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}
@@ -156,7 +156,7 @@ def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal)
             assert float(np.linalg.norm(got[k])) == pytest.approx(float(np.linalg.norm(v)), rel=2e-5 if v.ndim == 2 else 2e-4), k
 
 
-@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive"])
+@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive", "contrastivev2"])
 def test_sf_constructor_init_matches_reference_seed(learner):
     """same torch.manual_seed => SFAgent's orthogonal init tensor for tensor (sf.py:419-463; ICM re-applies weight_init)"""
     z = np.load(H.GOLDEN / f"init_seed1_tiny_sf_{learner}.npz")
@@ -218,7 +218,7 @@ def test_sf_pickle_init_from_update_many_and_inference():
 def test_sf_unsupported_options_fail_loudly():
     from controllable_agent_amd.agent import SFHipAgent
     base = dict(obs_type="states", obs_shape=(5,), action_shape=(3,), num_expl_steps=0)
-    for bad in (dict(feature_learner="contrastivev2"), dict(feature_learner="identity"), dict(mix_ratio=0.3), dict(boltzmann=True),
+    for bad in (dict(feature_learner="identity"), dict(feature_learner="no_such_learner"), dict(mix_ratio=0.3), dict(boltzmann=True),
                 dict(num_sf_updates=2)):
         with pytest.raises(NotImplementedError):
             SFHipAgent(**{**base, **bad})

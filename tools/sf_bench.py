@@ -7,7 +7,7 @@ target EMA) replayed as one hipGraph, 32 steps per launch.  Dims: the walker inp
 publishes no benchmark configuration for this agent.  Prints one JSON line with the roofline / cpu_baseline objects of bench.py
 (cpu_baseline = oracle/sf_oracle.py on the host cores).
 
-    python tools/sf_bench.py [--steps 2000] [--warmup 100] [--learner icm|lap|random|autoencoder|transition|svd_p|latent|svd_sr|svd_srv2|contrastive] [--no-cpu-baseline]
+    python tools/sf_bench.py [--steps 2000] [--warmup 100] [--learner icm|lap|random|autoencoder|transition|svd_p|latent|svd_sr|svd_srv2|contrastive|contrastivev2] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -35,10 +35,10 @@ def gflop_per_update(o, a, g, d, H, Fd, Hb, B, learner):
     extra = 3 * (head[0] * Hb + Hb * Hb + Hb * head[1]) if head else (3 * B * d if learner == "lap" else 0)
     # feature_net passes: forward on [goal ; next_goal] always; trained through both (icm, lap), through goal only (autoencoder,
     # transition) or not at all (random)
-    nphi = {"icm": 6, "lap": 6, "autoencoder": 4, "transition": 4, "random": 2, "svd_p": 4, "latent": 5, "svd_sr": 5, "svd_srv2": 5, "contrastive": 4}[learner]   # latent / svd_sr: + target nets on next_goal
+    nphi = {"icm": 6, "lap": 6, "autoencoder": 4, "transition": 4, "random": 2, "svd_p": 4, "latent": 5, "svd_sr": 5, "svd_srv2": 5, "contrastive": 4, "contrastivev2": 5}[learner]   # latent / svd_sr: + target nets on next_goal
     if learner in ("svd_sr", "svd_srv2"):    # mu_net trained (3x) + target_mu_net (1x) + the low-rank and orthonormality products
         extra = 4 * (g * Hb + Hb * Hb + Hb * d) + 9 * B * d
-    if learner == "contrastive":    # mu_net on the hindsight goal trained (3x) + the logits and the two gradient contractions
+    if learner in ("contrastive", "contrastivev2"):    # mu_net on the hindsight goal trained (3x) + the logits and the two gradient contractions
         extra = 3 * (g * Hb + Hb * Hb + Hb * d) + 3 * B * d
     if learner == "svd_p":        # mu_net on [goal | action] trained (3x) + the low-rank and orthonormality products (P, Cov and their contractions)
         extra = 3 * ((g + a) * Hb + Hb * Hb + Hb * d) + 6 * B * d
@@ -49,7 +49,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--learner", choices=("icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive"), default="icm")
+    ap.add_argument("--learner", choices=("icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive", "contrastivev2"), default="icm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     W = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=100, hidden_dim=1024, feature_dim=512, backward_hidden_dim=512, batch_size=1024)
