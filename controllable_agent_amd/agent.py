@@ -1268,17 +1268,19 @@ class SFHipAgent(FBHipAgent):
         "contrastive"  logits = cos(phi(goal), mu_net(future_goal)):  mean(-diag + logsumexp over the off-diagonal of each row);
                        the buffer must sample hindsight goals (future < 1)                                    sf.py:118-143
         "contrastivev2" the same with the roles swapped: cos(mu_net(goal), phi(future_goal))                    sf.py:159-186
+        "identity"     feature_net = nn.Identity(): phi(goal) = goal (z_dim must equal the goal dimension), nothing trained   sf.py:94-98
         "svd_sr"       SR = phi(goal) . mu_net(next_goal)^T against 0.99 x the same product of two target nets:
                        -2 mean diag SR + mean offdiag (SR - 0.99 target_SR)^2 + orthonormality loss of phi (LRA-SR)   sf.py:264-299
         "svd_srv2"     the same with the roles swapped: SR = mu_net(goal) . phi(next_goal)^T, 0.98, orthonormality of phi(next_goal)   sf.py:303-335
         "svd_p"        P = mu_net(cat[goal, action]) . phi(next_goal)^T:  -2 mean diag P + mean offdiag P^2
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
-    The reference's last feature learner (identity: feature_net = nn.Identity, z_dim = goal_dim), ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    Those are all thirteen feature learners of the reference; ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
     ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
     _config_cls = SFAgentConfig
     _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7, "svd_sr": 8,
-                 "svd_srv2": 9, "contrastive": 10, "contrastivev2": 11}   # -> fbhip_dims.sf
+                 "svd_srv2": 9, "contrastive": 10, "contrastivev2": 11,
+                 "identity": 12}                 # -> fbhip_dims.sf
     # the head mlp(in, Hb, 'irelu', Hb, 'irelu', out) next to feature_net: (module name, in, out) from (z, a, g)
     _HEADS = {1: ("inverse_dynamic_net", lambda z, a, g: (2 * z, a)), 4: ("decoder", lambda z, a, g: (z, g)),
               5: ("forward_dynamic_net", lambda z, a, g: (z + a, g)), 7: ("forward_dynamic_net", lambda z, a, g: (z + a, z))}
@@ -1385,7 +1387,7 @@ class SFHipAgent(FBHipAgent):
         if self._sf_mode in (8, 9):
             for n in ("mu_net", "target_feature_net", "target_mu_net"):
                 sd[f"{n}.1.weight"], sd[f"{n}.1.bias"] = torch.ones(Hb), torch.zeros(Hb)
-        nets["feature_learner"] = sd
+        nets["feature_learner"] = sd if self._sf_mode != 12 else {}     # (identity: the net above only consumed the RNG, sf.py:94-98)
         return nets
 
     def _allocate(self, nets: tp.Optional[tp.Dict[str, tp.Dict[str, torch.Tensor]]]) -> None:
@@ -1412,7 +1414,13 @@ class SFHipAgent(FBHipAgent):
         c = self.cfg
         self.sf_opt = AdamView(self, "fb", ["successor_net"], [c.lr])                          # sf.py:459
         # sf.py:461-463 ("random" trains nothing: no optimiser, its block of the fused pass sees zero gradients)
-        self.phi_opt = AdamView(self, "fb", ["feature_learner"], [c.lr_coef * c.lr]) if self._sf_mode != 3 else None
+        self.phi_opt = AdamView(self, "fb", ["feature_learner"], [c.lr_coef * c.lr]) if self._sf_mode not in (3, 12) else None
+        if self._sf_mode == 12:
+            # identity (sf.py:94-98): FeatureLearner.__init__ builds (and initialises) a feature_net, then replaces it with nn.Identity():
+            # no parameters, phi(goal) = goal.  The context keeps the unused block; this view shows none of it
+            self.feature_learner._views.clear()
+            self.feature_learner.feature_net = lambda x: torch.as_tensor(np.asarray(x, np.float32) if not isinstance(x, torch.Tensor) else x,
+                                                                         dtype=torch.float32, device=self._device)
         if nets is not None:
             self.load_nets(nets)
 
@@ -1457,6 +1465,11 @@ class SFHipAgent(FBHipAgent):
     def update_meta(self, meta: MetaDict, global_step: int, time_step: tp.Any, finetune: bool = False,
                     replay_loader: tp.Any = None) -> MetaDict:            # sf.py:587-592
         return self.init_meta() if global_step % self.cfg.update_z_every_step == 0 else meta
+
+    def _backward_map(self, goal: tp.Any, target: bool = False) -> torch.Tensor:
+        if self._sf_mode == 12:                  # identity features
+            return self.feature_learner.feature_net(goal).reshape(-1, self.cfg.z_dim)
+        return super()._backward_map(goal, target)
 
     def _compute_cov(self, goal: tp.Any) -> torch.Tensor:                # sf.py:509-515 (phi on the device; the d x d pinv in torch)
         phi = self._backward_map(goal)
@@ -1516,7 +1529,7 @@ class SFHipAgent(FBHipAgent):
         buf = (C.c_float * _lib.NUM_METRICS)()
         check(_lib.load().fbhip_read_metrics(self._ctx, buf, stream_ptr()), self._ctx)
         g = lambda k: float(buf[_lib.METRIC_INDEX[k]])
-        for k in ("target_F", "F1", "phi", "phi_norm", "z_norm", "sf_loss") + (("phi_loss",) if self._sf_mode != 3 else ()):
+        for k in ("target_F", "F1", "phi", "phi_norm", "z_norm", "sf_loss") + (("phi_loss",) if self._sf_mode not in (3, 12) else ()):
             out[k] = g(k)                        # (sf.py:634-635: "random" has no phi_loss)
         out["sf_opt_lr"] = self.sf_opt.param_groups[0]["lr"]
         if c.use_tb or c.use_wandb:

@@ -165,7 +165,8 @@ int check_dims(const fbhip_dims* d) {
     if (d->batch > 8192) { g_err = "fbhip: batch > 8192 per GPU unsupported (permutation sort)"; return FBHIP_E_INVALID; }
     if (d->discrete && d->preprocess) { g_err = "fbhip: discrete needs preprocess == 0 (the reference's discrete ForwardMap.forward only runs without the preprocess nets, discrete_fb.py:91-94)"; return FBHIP_E_INVALID; }
     if (d->discrete && (int64_t)d->z_dim * d->action_dim > 8192) { g_err = "fbhip: discrete: z_dim * actions > 8192 unsupported"; return FBHIP_E_INVALID; }
-    if (d->sf < 0 || d->sf > 11) { g_err = "fbhip: dims.sf must be 0 or 1..11 (icm, lap, random, autoencoder, transition, svd_p, latent, svd_sr, svd_srv2, contrastive, contrastivev2)"; return FBHIP_E_INVALID; }
+    if (d->sf < 0 || d->sf > 12) { g_err = "fbhip: dims.sf must be 0 or 1..12 (icm, lap, random, autoencoder, transition, svd_p, latent, svd_sr, svd_srv2, contrastive, contrastivev2, identity)"; return FBHIP_E_INVALID; }
+    if (d->sf == 12 && d->z_dim != d->goal_dim) { g_err = "fbhip: dims.sf = 12 (identity features) needs z_dim == goal_dim"; return FBHIP_E_INVALID; }
     if (d->sf && (d->discrete || d->boltzmann || !d->norm_z)) { g_err = "fbhip: dims.sf needs discrete = 0, boltzmann = 0, norm_z = 1"; return FBHIP_E_INVALID; }
     if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
     return FBHIP_OK;

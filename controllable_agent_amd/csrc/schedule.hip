@@ -946,7 +946,14 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         }
         if (head) {
             forward_map_fwd_chain(c, c->F_p, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1]);
-            backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, RB, ch[2]);
+            if (d.sf != 12) backward_map_fwd_chain(c, c->K_p, w.goal2.p, w.goal2.ld, w.bsS, RB, ch[2]);
+            else            // identity (sf.py:94-98): feature_net = nn.Identity(): phi(goal) is the goal itself (z_dim == goal_dim), a copy into the phi panel
+                ch[2].push_back([=, &w](Ops& o2) {
+                    o2.post.push_back([=, &w](hipStream_t q) -> int {
+                        HIPCK(c, launch_concat2(w.bsS.Bm.p, Lz, w.goal2.p, w.goal2.ld, z, nullptr, 0, 0, RB, q));
+                        return (int)FBHIP_OK;
+                    });
+                });
         }
         if (mid) {
             actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[3], !fused_policy);
@@ -1137,12 +1144,13 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     // (random, sf.py:430: feature_net keeps its initial weights -- no loss, no phi_opt; its gradient block stays zero and the
     // Adam pass below leaves it where it is)
     BGrad bg{w.dBm2.p, w.dy2.p, w.s_dr2.p, w.s_dt1.p};
-    if (d.sf != 3) backward_map_bwd_chain(c, c->K_p, c->K_g, w.goal2.p, w.goal2.ld, w.bsS, RB, feat, false, &bg);
+    const bool frozen = d.sf == 3 || d.sf == 12;          // random / FB, identity: nothing to train behind phi
+    if (!frozen) backward_map_bwd_chain(c, c->K_p, c->K_g, w.goal2.p, w.goal2.ld, w.bsS, RB, feat, false, &bg);
     Chain succ;
     forward_map_bwd_chain(c, c->F_p, c->F_g, w.Xoa.p, w.Xoa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, succ);
     {
         std::vector<Chain> ch{succ};
-        if (d.sf != 3) ch.push_back(feat);
+        if (!frozen) ch.push_back(feat);
         if (d.sf == 6 || d.sf >= 8) {      // mu_net's backward from d mu; its first stage is empty (no projection), which keeps it one round behind the loss
             Chain mu;
             mu.push_back([](Ops&) {});

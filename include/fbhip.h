@@ -109,7 +109,7 @@ typedef struct fbhip_dims {
                                     * of the target ForwardMap on next_obs, or with ``boltzmann`` the softmax(next_Q / temp) mix
                                     * (temp: fbhip_set_policy_squash; :289-303); online embedding = the column of the stored action
                                     * (:309-311); q_loss uses that next_Q (:329).  Greedy actions: fbhip_discrete_act */
-    int32_t sf;                    /* 0: FBDDPGAgent.  1..11: the sibling SFAgent (url_benchmark/agent/sf.py:383-768) with
+    int32_t sf;                    /* 0: FBDDPGAgent.  1..12: the sibling SFAgent (url_benchmark/agent/sf.py:383-768) with
                                     * feature_learner "icm" (1, sf.py:194-213) / "lap" (2, :100-116) / "random" (3, :84-92: feature_net
                                     * frozen, no feature loss) / "autoencoder" (4, :249-262) / "transition" (5, :215-227) / "svd_p"
                                     * (6, :337-362: a second LayerNorm mlp ``mu_net.{0,1,3,5}`` on cat[goal, action] behind feature_net)
@@ -119,7 +119,8 @@ typedef struct fbhip_dims {
                                     * ``mu_net.{0,1,3,5}`` on the goal alone; ``target_feature_net`` and ``target_mu_net`` = the TARGET
                                     * buffer's copies of both blocks, moved like latent's / "contrastive" (10, :118-143): ``mu_net`` =
                                     * feature_net's modules (projection included) on the hindsight goal; hparams.future must be < 1 /
-                                    * "contrastivev2" (11, :159-186): mu_net on the goal, feature_net also on the hindsight goal.  NET_FORWARD is
+                                    * "contrastivev2" (11, :159-186): mu_net on the goal, feature_net also on the hindsight goal /
+                                    * "identity" (12, :94-98): phi(goal) = goal, z_dim == goal_dim, the feature block unused.  NET_FORWARD is
                                     * ``successor_net`` (the same ForwardMap; its target = successor_target_net), NET_BACKWARD is
                                     * ``feature_learner``: ``feature_net.{0,1,3,5}`` (the BackwardMap architecture, projection
                                     * included) followed by the learner's head mlp(in, Hb, relu, Hb, relu, out) at Sequential indices

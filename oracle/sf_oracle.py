@@ -36,6 +36,8 @@ Params = fo.Params
 def feature_learner_shapes(cfg: fo.OracleConfig, learner: str):
     """``feature_learner.state_dict()`` names and shapes (sf.py:84-88 feature_net; :198 inverse_dynamic_net for icm)."""
     g, d, Hb, a = cfg.goal_dim, cfg.z_dim, cfg.backward_hidden_dim, cfg.action_dim
+    if learner == "identity":     # feature_net = nn.Identity() (sf.py:94-98): no parameters
+        return []
     out = [("feature_net.0.weight", (Hb, g)), ("feature_net.0.bias", (Hb,)), ("feature_net.1.weight", (Hb,)),
            ("feature_net.1.bias", (Hb,)), ("feature_net.3.weight", (Hb, Hb)), ("feature_net.3.bias", (Hb,)),
            ("feature_net.5.weight", (d, Hb)), ("feature_net.5.bias", (d,))]
@@ -72,7 +74,9 @@ def net_shapes(cfg: fo.OracleConfig, learner: str):
 
 
 def feature_net(p: Params, goal: torch.Tensor, z_dim: int) -> torch.Tensor:
-    """feature_learner.feature_net (sf.py:87): Linear, LayerNorm, Tanh, Linear, ReLU, Linear, _L2"""
+    """feature_learner.feature_net (sf.py:87): Linear, LayerNorm, Tanh, Linear, ReLU, Linear, _L2  (no parameters: nn.Identity, sf.py:97)"""
+    if not p:
+        return goal
     h = F.linear(goal, p["feature_net.0.weight"], p["feature_net.0.bias"])
     h = torch.tanh(F.layer_norm(h, (h.shape[-1],), p["feature_net.1.weight"], p["feature_net.1.bias"], fo.LN_EPS))
     h = torch.relu(F.linear(h, p["feature_net.3.weight"], p["feature_net.3.bias"]))
@@ -111,7 +115,7 @@ def phi_loss_terms(p: Params, learner: str, goal, action, next_goal, z_dim: int,
     if learner == "icm":                                           # sf.py:203-213
         pred = inverse_dynamics(p, phi, next_phi)
         return {"phi_loss": (action - pred).pow(2).mean(), "phi": phi, "next_phi": next_phi, "pred": pred}
-    if learner == "random":                                        # FeatureLearner.forward returns None, sf.py:91-92
+    if learner in ("random", "identity"):                          # FeatureLearner.forward returns None, sf.py:91-92
         return {"phi_loss": None, "phi": phi, "next_phi": next_phi}
     if learner == "autoencoder":                                   # sf.py:256-262
         pred = head_mlp(p, "decoder", phi)
@@ -167,7 +171,7 @@ def _grad_or_zero(x: torch.Tensor, retained: bool) -> torch.Tensor:
 
 class SFOracleAgent:
     """State of one SFAgent (sf.py:383-474) and its ``update`` (:700-768) for ``feature_learner`` in {"icm", "lap", "random",
-    "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive", "contrastivev2"}."""
+    "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive", "contrastivev2", "identity"}."""
 
     NETS = ("actor", "successor_net", "feature_learner")
 

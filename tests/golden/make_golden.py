@@ -425,6 +425,13 @@ def sf_contrastivev2_fixture(R):
     _sf_inits(R, ("contrastivev2",))
 
 
+def sf_identity_fixture(R):
+    """feature_learner="identity" (sf.py:94-98): feature_net = nn.Identity(), z_dim = the goal dimension, nothing trained (no phi_opt)."""
+    _sf_traces(R, (
+        ("tiny_sf_identity_trace", "identity", True, dict(z_dim=5, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.0),
+         dict(seed=145, n_eps=6, T=12, n_steps=4)),))
+
+
 def _sf_traces(R, table):
     from oracle import sf_oracle as so
     for name, learner, q_loss, kw, extra in table:
@@ -787,6 +794,7 @@ def main():
     sf_svdsrv2_fixture(R)
     sf_contrastive_fixture(R)
     sf_contrastivev2_fixture(R)
+    sf_identity_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

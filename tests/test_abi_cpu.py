@@ -237,7 +237,10 @@ def test_sf_layout_follows_the_reference_modules(lib):
     assert names(9) == names(8)                                                # svd_srv2: the same modules (sf.py:304-308)
     assert names(10) == names(8)                                               # contrastive: mu_net on the (hindsight) goal (sf.py:121)
     assert names(11) == names(8)                                               # contrastivev2 (sf.py:162)
-    too = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 0, 0, 12)
+    ident = lib.Dims(16, 5, 3, 5, 5, 32, 16, 20, 0, 0, 1, 1, 0, 0, 12)         # identity: needs z_dim == goal_dim (sf.py:94-98)
+    assert l.fbhip_net_numel(C.byref(ident), 0) > 0
+    assert l.fbhip_net_numel(C.byref(lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 0, 0, 12)), 0) < 0 and b"z_dim == goal_dim" in l.fbhip_last_error(None)
+    too = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 0, 0, 13)
     assert l.fbhip_net_numel(C.byref(too), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)
     bad = lib.Dims(16, 5, 3, 5, 10, 32, 16, 20, 0, 0, 1, 1, 1, 0, 1)          # boltzmann + sf
     assert l.fbhip_net_numel(C.byref(bad), 0) < 0 and b"dims.sf" in l.fbhip_last_error(None)

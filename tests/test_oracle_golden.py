@@ -135,7 +135,8 @@ def sf_trace_inputs(name):
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
                                   "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
                                   "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace",
-                                  "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace", "tiny_sf_contrastivev2_trace"])
+                                  "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace", "tiny_sf_contrastivev2_trace",
+                                  "tiny_sf_identity_trace"])
 def test_sf_oracle_full_state_against_the_reference(name):
     """oracle/sf_oracle.py against traces of the real url_benchmark.agent.sf.SFAgent: metrics and every parameter / target /
     Adam tensor after every step (icm + scalar Q regression; lap + feature-space regression + goal space + variable lengths)."""

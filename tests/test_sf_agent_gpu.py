@@ -63,7 +63,8 @@ def set_sf_state(agent, state: dict, steps: int) -> None:
 @pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_lap_trace", "tiny_sf_random_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace",
                                   "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
                                   "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace",
-                                  "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace", "tiny_sf_contrastivev2_trace"])
+                                  "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace", "tiny_sf_contrastivev2_trace",
+                                  "tiny_sf_identity_trace"])
 def test_sf_teacher_forced_against_reference_trace(name):
     """Each step starts from the REFERENCE SFAgent's recorded state, runs one HIP update with the recorded draws and must land
     on the reference's next state and metrics; intermediates and gradients are compared with the oracle's autograd."""
@@ -101,14 +102,14 @@ def test_sf_teacher_forced_against_reference_trace(name):
                 assert H.rel_err(got, ref) < GRAD_REL_L2, s
         for net, key in (("successor_net", "grads_successor"), ("feature_learner", "grads_feature"), ("actor", "grads_actor")):
             for k, g in agent._grad_views[net].state_dict().items():
-                ref = L[key].get(k, torch.zeros(1)) if learner == "random" else L[key][k]
+                ref = L[key].get(k, torch.zeros(1)) if learner in ("random", "identity") else L[key][k]
                 if float(ref.abs().max()) == 0.0:
                     assert float(g.abs().max()) == 0.0, (s, net, k)
                 else:
                     assert H.rel_err(g.cpu(), ref) < GRAD_REL_L2, (s, net, k)
         for k, v in get_sf_state(agent).items():
             if f"state/{s}/{k}" not in z.files:               # "random": no phi_opt in the reference; ours must not have moved
-                assert learner == "random" and k.startswith("adam_") and "feature_learner" in k and float(np.abs(v).max()) == 0.0, k
+                assert learner in ("random", "identity") and k.startswith("adam_") and "feature_learner" in k and float(np.abs(v).max()) == 0.0, k
                 continue
             ref = z[f"state/{s}/{k}"]
             if k.startswith("adam_"):
@@ -218,7 +219,7 @@ def test_sf_pickle_init_from_update_many_and_inference():
 def test_sf_unsupported_options_fail_loudly():
     from controllable_agent_amd.agent import SFHipAgent
     base = dict(obs_type="states", obs_shape=(5,), action_shape=(3,), num_expl_steps=0)
-    for bad in (dict(feature_learner="identity"), dict(feature_learner="no_such_learner"), dict(mix_ratio=0.3), dict(boltzmann=True),
+    for bad in (dict(feature_learner="no_such_learner"), dict(mix_ratio=0.3), dict(boltzmann=True),
                 dict(num_sf_updates=2)):
         with pytest.raises(NotImplementedError):
             SFHipAgent(**{**base, **bad})
@@ -328,3 +329,20 @@ def test_sf_phase_split_schedule_equals_single_call(name, monkeypatch):
     assert a1.step_counts() == a2.step_counts() == (3, 3)
     for k in s1:
         np.testing.assert_allclose(s2[k], s1[k], rtol=0, atol=3e-6, err_msg=k)
+
+
+def test_sf_identity_features_surface():
+    """feature_learner="identity" (sf.py:94-98): no feature parameters are exposed, phi(goal) is the goal on the inference surface too,
+    and z_dim != goal_dim is refused by the library"""
+    from controllable_agent_amd.agent import SFHipAgent
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_identity_trace")
+    agent = make_sf_agent(cfg, nets, "identity", True)
+    assert agent.phi_opt is None and len(agent.feature_learner.state_dict()) == 0 and list(agent.feature_learner.parameters()) == []
+    goal = np.random.default_rng(2).standard_normal((9, cfg.goal_dim)).astype(np.float32)
+    np.testing.assert_array_equal(agent.feature_learner.feature_net(goal).cpu().numpy(), goal)
+    agent.inv_cov = agent._compute_cov(goal)
+    want = np.sqrt(cfg.z_dim) * torch.nn.functional.normalize(torch.from_numpy(goal[:1]) @ agent.inv_cov.cpu(), dim=1)[0].numpy()
+    np.testing.assert_allclose(agent.get_goal_meta(goal[0])["z"], want, rtol=1e-5, atol=1e-6)
+    bad = fo.OracleConfig(**{**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, "z_dim": cfg.goal_dim + 1})
+    with pytest.raises(ValueError, match="z_dim == goal_dim"):
+        SFHipAgent(**sf_kwargs(bad, "identity", True))
