@@ -1276,7 +1276,8 @@ class SFHipAgent(FBHipAgent):
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
     Those are all thirteen feature learners of the reference; ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
-    ``num_sf_updates != 1`` and pixels raise NotImplementedError at construction."""
+    pixels raise NotImplementedError at construction.  ``num_sf_updates = k`` (sf.py:706): every ``update`` call runs k complete
+    updates, each on a fresh batch."""
     _config_cls = SFAgentConfig
     _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7, "svd_sr": 8,
                  "svd_srv2": 9, "contrastive": 10, "contrastivev2": 11,
@@ -1288,7 +1289,7 @@ class SFHipAgent(FBHipAgent):
     def __init__(self, fb_features: tp.Any = None, **kwargs: tp.Any) -> None:
         cfg = SFAgentConfig(**kwargs)
         bad = [k for k, v in dict(feature_learner=cfg.feature_learner not in self._LEARNERS, boltzmann=cfg.boltzmann,
-                                  mix_ratio=cfg.mix_ratio != 0, num_sf_updates=cfg.num_sf_updates != 1).items() if v]
+                                  mix_ratio=cfg.mix_ratio != 0, num_sf_updates=cfg.num_sf_updates < 1).items() if v]
         if bad:
             raise NotImplementedError(f"SFHipAgent: not implemented in the HIP path: {bad} (feature_learner in {sorted(self._LEARNERS)})")
         if cfg.feature_learner == "FB" and fb_features is None:
@@ -1539,10 +1540,19 @@ class SFHipAgent(FBHipAgent):
     def _early_grad_range(self) -> tp.Optional[tp.Tuple[int, int]]:
         return None                              # (one all-reduce per bucket: the SF backward is not cut for an early share)
 
+    def update(self, replay_loader: tp.Any, step: int) -> tp.Dict[str, float]:                   # sf.py:700-754
+        out: tp.Dict[str, float] = {}
+        for _ in range(int(self.cfg.num_sf_updates)):             # :706: sample, update_sf, update_actor, target EMA -- num_sf_updates times
+            out = super().update(replay_loader, step)
+            if step % self.cfg.update_every_steps != 0:
+                break
+        return out
+
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         c = self.cfg
+        total = n_steps * int(c.num_sf_updates)                  # (every update() call is num_sf_updates complete updates)
         # (data parallel: single updates, each through the phase-split schedule with its two gradient all-reduces)
-        if (n_steps < 2 or not isinstance(replay_loader, DeviceReplayBuffer) or c.update_every_steps != 1 or not self._use_graph or
+        if (total < 2 or not isinstance(replay_loader, DeviceReplayBuffer) or c.update_every_steps != 1 or not self._use_graph or
                 self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or
                 len({schedule(c.stddev_schedule, step + i) for i in range(n_steps)}) != 1):
             out: tp.Dict[str, float] = {}
@@ -1553,8 +1563,8 @@ class SFHipAgent(FBHipAgent):
         self._bind_replay(replay_loader)
         hp = self._hparams(step, want, 1.0, float(replay_loader._discount), float(replay_loader._future))
         done = 0
-        while done < n_steps:
-            n = min(64, n_steps - done)
+        while done < total:
+            n = min(64, total - done)
             self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
             done += n
         return self._metrics()

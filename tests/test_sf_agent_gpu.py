@@ -220,7 +220,7 @@ def test_sf_unsupported_options_fail_loudly():
     from controllable_agent_amd.agent import SFHipAgent
     base = dict(obs_type="states", obs_shape=(5,), action_shape=(3,), num_expl_steps=0)
     for bad in (dict(feature_learner="no_such_learner"), dict(mix_ratio=0.3), dict(boltzmann=True),
-                dict(num_sf_updates=2)):
+                dict(num_sf_updates=0)):
         with pytest.raises(NotImplementedError):
             SFHipAgent(**{**base, **bad})
 
@@ -346,3 +346,24 @@ def test_sf_identity_features_surface():
     bad = fo.OracleConfig(**{**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__}, "z_dim": cfg.goal_dim + 1})
     with pytest.raises(ValueError, match="z_dim == goal_dim"):
         SFHipAgent(**sf_kwargs(bad, "identity", True))
+
+
+def test_sf_num_sf_updates_runs_that_many_updates_per_call():
+    """num_sf_updates = k (sf.py:706): one update() call = k complete updates on fresh batches; update_many(n) = n k of them, and the
+    two agree bit for bit (same device RNG stream)"""
+    from controllable_agent_amd.agent import SFHipAgent
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_icm_trace")
+    rb = _buffer(storage, lengths, cfg.discount)
+    mk = lambda: SFHipAgent(**sf_kwargs(cfg, "icm", True, metrics=False, num_sf_updates=3))
+    torch.manual_seed(7)
+    a1 = mk()
+    a1.load_nets({n: dict(p) for n, p in nets.items()})
+    a2 = pickle.loads(pickle.dumps(a1))
+    a1.update(rb, 0)
+    assert a1.step_counts() == (3, 3)
+    a1.update(rb, 1)
+    a2.update_many(rb, 0, 2)
+    assert a1.step_counts() == a2.step_counts() == (6, 6)
+    s1, s2 = get_sf_state(a1), get_sf_state(a2)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
