@@ -1275,7 +1275,8 @@ class SFHipAgent(FBHipAgent):
         "svd_p"        P = mu_net(cat[goal, action]) . phi(next_goal)^T:  -2 mean diag P + mean offdiag P^2
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
-    Those are all thirteen feature learners of the reference; ``boltzmann``, ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743),
+    Those are all thirteen feature learners of the reference.  ``boltzmann`` raises: the reference's own constructor does (sf.py:415 passes
+    ``cfg.obs_type`` to DiagGaussianActor as an extra positional argument: TypeError), so there is nothing to pin; ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743) and
     pixels raise NotImplementedError at construction.  ``num_sf_updates = k`` (sf.py:706): every ``update`` call runs k complete
     updates, each on a fresh batch."""
     _config_cls = SFAgentConfig
