@@ -1276,8 +1276,10 @@ class SFHipAgent(FBHipAgent):
                        + orthonormality loss of phi(next_goal) (the paper's LRA-P)                         sf.py:337-362
 
     Those are all thirteen feature learners of the reference.  ``boltzmann`` raises: the reference's own constructor does (sf.py:415 passes
-    ``cfg.obs_type`` to DiagGaussianActor as an extra positional argument: TypeError), so there is nothing to pin; ``mix_ratio > 0`` (the pinv-whitened z mix, sf.py:728-743) and
-    pixels raise NotImplementedError at construction.  ``num_sf_updates = k`` (sf.py:706): every ``update`` call runs k complete
+    ``cfg.obs_type`` to DiagGaussianActor as an extra positional argument: TypeError), so there is nothing to pin; pixels raise
+    NotImplementedError at construction.  ``mix_ratio > 0`` (sf.py:725-739): the rows drawn by the mix uniform take
+    ``z = sqrt(d) normalize(phi(next_goal[perm]) @ inverse(phi^T phi / B))`` -- the reference's ``pinv`` equals this inverse while the
+    feature covariance has full rank, which needs ``batch_size >= z_dim`` (checked here); a rank-deficient covariance is not supported.  ``num_sf_updates = k`` (sf.py:706): every ``update`` call runs k complete
     updates, each on a fresh batch."""
     _config_cls = SFAgentConfig
     _LEARNERS = {"icm": 1, "lap": 2, "random": 3, "autoencoder": 4, "transition": 5, "FB": 3, "svd_p": 6, "latent": 7, "svd_sr": 8,
@@ -1290,7 +1292,8 @@ class SFHipAgent(FBHipAgent):
     def __init__(self, fb_features: tp.Any = None, **kwargs: tp.Any) -> None:
         cfg = SFAgentConfig(**kwargs)
         bad = [k for k, v in dict(feature_learner=cfg.feature_learner not in self._LEARNERS, boltzmann=cfg.boltzmann,
-                                  mix_ratio=cfg.mix_ratio != 0, num_sf_updates=cfg.num_sf_updates < 1).items() if v]
+                                  mix_ratio=cfg.mix_ratio > 0 and cfg.batch_size < cfg.z_dim,
+                                  num_sf_updates=cfg.num_sf_updates < 1).items() if v]
         if bad:
             raise NotImplementedError(f"SFHipAgent: not implemented in the HIP path: {bad} (feature_learner in {sorted(self._LEARNERS)})")
         if cfg.feature_learner == "FB" and fb_features is None:
@@ -1520,7 +1523,7 @@ class SFHipAgent(FBHipAgent):
             raise NotImplementedError("SFHipAgent: data parallel = gradient averaging with host-issued all-reduces only")
         # (grad_scale = 1 / world: the data-parallel schedule sums the ranks' gradient buckets, the optimiser passes average them)
         return HParams(lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.sf_target_tau, stddev=schedule(c.stddev_schedule, step),
-                       stddev_clip=c.stddev_clip, ortho_coef=1.0, mix_ratio=0.0, q_loss_coef=0.0, discount=discount, grad_scale=float(grad_scale),
+                       stddev_clip=c.stddev_clip, ortho_coef=1.0, mix_ratio=max(float(c.mix_ratio), 0.0), q_loss_coef=0.0, discount=discount, grad_scale=float(grad_scale),
                        q_loss=int(bool(c.q_loss)), want_metrics=int(want_metrics), future_ratio=0.0, future=float(future), rand_weight=0)
 
     def _metrics(self) -> tp.Dict[str, float]:                           # sf.py:627-639, 688-692

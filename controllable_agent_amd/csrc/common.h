@@ -281,6 +281,8 @@ struct GatherArgs {
     float* Xo; int ld_o;        // [obs] alone (zero padded: operand of the actor's obs_net weight gradient)
     float* next_goal; int ld_ng;    // goal[ep, step] if use_goal else next_obs
     float* bin; int ld_bin;     // backward_input[perm]
+    float* pgoal; int ld_pg;    // nullable (SFAgent's z-mix, sf.py:726-727): next_goal[pperm]
+    const int32_t* pperm;
     const int32_t* future_idx;  // nullable: hindsight replay off
     float* fgoal; int ld_fg;    // (goal if use_goal else observation)[ep, future_idx - 1]
     float* disc;

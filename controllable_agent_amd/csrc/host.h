@@ -76,6 +76,7 @@ struct Ws {
     Buf ymixw;
     // SFAgent (dims.sf): the feature pass runs on 2 batch rows -- [goal ; next_goal] -- so that one backward sums both uses
     Buf goal2;                          // [2B, g]: bin = rows [0, B), next_goal = rows [B, 2B)
+    Buf pgoal;                          // [B, g]: next_goal[perm], input of the z-mix (mix_ratio > 0)
     BSet bsS;                           // feature_net activations, 2B rows
     Buf dBm2, dy2, s_dr2, s_dt1;        // its gradient panels, 2B rows
     Buf Xga;                            // svd_p: [goal | action] input of mu_net, B rows

@@ -242,6 +242,7 @@ Ws carve(const fbhip_dims& d, void* base) {
         w.next_goal = w.bin; w.next_goal.p = base ? w.goal2.p + (size_t)B * w.goal2.ld : nullptr;
         if (d.sf == 11) { w.fgoal = w.bin; w.fgoal.p = base ? w.goal2.p + (size_t)2 * B * w.goal2.ld : nullptr; }
         else w.fgoal = c.buf(d.sf == 10 ? B : 1, g, pad32(g));      // (contrastive reads the hindsight goal of every row)
+        w.pgoal = c.buf(B, g, pad32(g));                            // next_goal[perm]: the z-mix of sf.py:726-727
     } else {
         w.next_goal = c.buf(B, g, pad32(g)); w.bin = c.buf(B, g, pad32(g)); w.fgoal = c.buf(B, g, pad32(g));
     }

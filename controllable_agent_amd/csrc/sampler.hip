@@ -148,6 +148,14 @@ __global__ void __launch_bounds__(256) gather_kernel(const GatherArgs g) {
     const size_t tp = (size_t)g.ep_idx[pi] * g.rv.t1 + g.step_idx[pi] - 1;
     const float* bsrc = g.use_goal ? g.rv.goal + tp * g.g : g.rv.observation + tp * g.o;
     copy_row(g.bin + (size_t)i * g.ld_bin, bsrc, g.g, lane);
+    if (g.pgoal != nullptr) {        // desired_goal = next_goal[perm] (sf.py:726-727)
+        const int qi = g.pperm[i];
+#ifdef FBHIP_DEBUG
+        assert(qi >= 0 && qi < g.B);
+#endif
+        const size_t tq = (size_t)g.ep_idx[qi] * g.rv.t1 + g.step_idx[qi];
+        copy_row(g.pgoal + (size_t)i * g.ld_pg, g.use_goal ? g.rv.goal + tq * g.g : g.rv.observation + tq * g.o, g.g, lane);
+    }
     if (g.future_idx != nullptr) {   // future_goal / future_obs = storage[ep, future_idx - 1] (in_memory_replay_buffer.py:176-183)
         const size_t tf = (size_t)e * g.rv.t1 + g.future_idx[i] - 1;
         copy_row(g.fgoal + (size_t)i * g.ld_fg, g.use_goal ? g.rv.goal + tf * g.g : g.rv.observation + tf * g.o, g.g, lane);

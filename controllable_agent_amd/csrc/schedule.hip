@@ -883,16 +883,21 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
               Hb = d.backward_hidden_dim, Lb = pad64(Hb), Lz = pad4(z), La = pad4(a);
     const Geom gm = geom_of(d);
     const int aoff = gm.single ? o + z : o;
-    if (hp.mix_ratio != 0.f || hp.future_ratio != 0.f || hp.rand_weight) {
-        c->err = g_err = "fbhip: dims.sf supports the reference's default z sampling only (mix_ratio = 0, sf.py:728-743 not built)";
+    if (hp.future_ratio != 0.f || hp.rand_weight) {
+        c->err = g_err = "fbhip: SFAgent has no future_ratio / rand_weight (sf.py:57-96)";
         return FBHIP_E_INVALID;
     }
+    // mix_ratio > 0 (sf.py:725-739): z[mix] = sqrt(d) normalize(phi(next_goal[perm]) @ pinv(phi^T phi / B)).  The covariance is
+    // inverted by inverse_kernel (Gauss-Jordan in fp64): equal to pinv while phi^T phi has full rank, i.e. B >= z_dim and no
+    // feature column that is constant zero or a combination of others -- the only regime in which the whitening means anything.
+    const bool mixz = hp.mix_ratio > 0.f;
     // ---- sample: the FB sampler with the identity permutation: goal2 = [goal ; next_goal] (sf.py:705-721), z = sample_z (:723)
     // contrastive reads batch.future_goal (sf.py:125, 713-719): the hindsight draw of in_memory_replay_buffer.py:157-161 without FB's z override
     const bool hind = d.sf == 10 || d.sf == 11;
     const int RB = (d.sf == 11 ? 3 : 2) * B;              // rows of the feature pass: [goal ; next_goal (; future_goal)]
     if (hind && !(hp.future < 1.f)) { c->err = g_err = "fbhip: the contrastive feature learner needs a replay buffer with future < 1"; return FBHIP_E_INVALID; }
-    const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->z_gauss && inj->eps_next && inj->eps_actor && (!hind || inj->future_idx);
+    const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->z_gauss && inj->eps_next && inj->eps_actor && (!hind || inj->future_idx) &&
+                              (!mixz || (inj->perm && inj->mix_uniform));
     if (head) {
     POST_BEGIN
     if (!all_injected) HIPCK(c, launch_draw(c->rv, w.so, B, z, a, c->seed, c->rank, w.st, hind ? hp.future : -1.f, 1, s));
@@ -901,6 +906,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
         INJ(ep_idx, B * 4); INJ(step_idx, B * 4); INJ(z_gauss, (size_t)B * z * 4); INJ(eps_next, (size_t)B * a * 4);
         INJ(eps_actor, (size_t)B * a * 4);
         if (hind) INJ(future_idx, B * 4);
+        if (mixz) { INJ(perm, B * 4); INJ(mix_uniform, B * 4); }
 #undef INJ
     }
     GatherArgs ga{};
@@ -910,11 +916,28 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     ga.next_goal = w.next_goal.p; ga.ld_ng = w.next_goal.ld; ga.bin = w.bin.p; ga.ld_bin = w.bin.ld; ga.disc = w.disc;
     ga.Xo = w.Xo.p; ga.ld_o = w.Xo.ld; ga.future_idx = hind ? w.so.future_idx : nullptr; ga.fgoal = w.fgoal.p; ga.ld_fg = w.fgoal.ld;
     ga.B = B; ga.o = o; ga.a = a; ga.g = g; ga.use_goal = d.use_goal; ga.gamma = hp.discount; ga.aoff = aoff; ga.act_idx = nullptr;
+    if (mixz) { ga.pgoal = w.pgoal.p; ga.ld_pg = w.pgoal.ld; ga.pperm = w.so.perm; }
     HIPCK(c, launch_gather(ga, s));
+    POST_END
+    const float* phi_p = w.pgoal.p;            // identity: phi = the raw goal (sf.py:74-81; g == z)
+    int ld_phi = w.pgoal.ld;
+    if (mixz && d.sf != 12) {                  // feature_net on the permuted next goals, with the weights as they are now (no_grad)
+        std::vector<Chain> ch(1);
+        backward_map_fwd_chain(c, c->K_p, w.pgoal.p, w.pgoal.ld, w.bsF, B, ch[0]);
+        prog_parallel(prog, ch);
+        phi_p = w.bsF.Bm.p; ld_phi = Lz;
+    }
+    POST_BEGIN
+    if (mixz) {
+        RC(run_gemms(c, {P(phi_p, ld_phi, 0, phi_p, ld_phi, 0, w.cov.p, w.cov.ld, z, z, B)}, s));                 // phi^T phi
+        HIPCK(c, launch_inverse(w.cov.p, w.cov.ld, z, 1.0f / (float)B, w.inv_cov.p, w.inv_cov.ld, s));
+        RC(run_gemms(c, {P(phi_p, ld_phi, 1, w.inv_cov.p, w.inv_cov.ld, 0, w.ymixw.p, Lz, B, z, z)}, s));         // phi @ inv_cov
+    }
     ZPanels zx{};
     if (gm.single) zx = ZPanels{{w.Xoa.p, w.Xnoa.p, w.Xopi.p}, {w.Xoa.ld, w.Xnoa.ld, w.Xopi.ld}};
-    HIPCK(c, launch_mix_z(w.so.z_gauss, z, nullptr, Lz, w.so.mix_uniform, 0.f, w.z.p, Lz, w.Xoz.p, w.Xoz.ld, w.Xnoz.p, w.Xnoz.ld,
-                          o, B, z, w.st, nullptr, nullptr, 0.f, nullptr, 2, zx, s));
+    // (one projection for the mixed rows: sf.py:738)
+    HIPCK(c, launch_mix_z(w.so.z_gauss, z, mixz ? w.ymixw.p : nullptr, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
+                          w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, nullptr, nullptr, 0.f, nullptr, 1, zx, s));
     POST_END
     }
 

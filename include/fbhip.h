@@ -128,7 +128,8 @@ typedef struct fbhip_dims {
                                     * (z_dim -> goal_dim), transition ``forward_dynamic_net`` (z_dim + action_dim -> goal_dim); both optimisers of the reference map onto the two lr groups of the FB
                                     * flat buffer (sf_opt: lr; phi_opt: lr_coef * lr).  The critic loss is the TD regression of
                                     * sf.py:594-626 (hparams.q_loss: scalar Q regression (the reference default) or feature space);
-                                    * z is sample_z only (the reference's default mix_ratio = 0; hparams.mix_ratio must be 0);
+                                    * z is sample_z; with hparams.mix_ratio > 0 the rows drawn by the mix uniform take
+                                    * sqrt(d) normalize(phi(next_goal[perm]) @ inverse(phi^T phi / batch)) (sf.py:725-739; batch >= z_dim);
                                     * needs norm_z = 1, boltzmann = 0, discrete = 0.  The actor phase is FBDDPGAgent's. */
 } fbhip_dims;
 

@@ -11,7 +11,7 @@ The second sibling of fb_oracle.py: the successor-
     its own optimiser at ``lr_coef * lr`` (sf.py:461-463, 649-653):
         icm  (sf.py:194-213):  mean((action - tanh-mlp(cat[phi(goal), phi(next_goal)]))^2)      inverse dynamics
         lap  (sf.py:100-116):  mean((phi(goal) - phi(next_goal))^2) + mean_{s!=t} Cov^2 - 2 mean_s Cov_ss,  Cov = phi phi^T
-  * z is ``sqrt(d) normalize(randn)`` with no mixing at the default ``mix_ratio = 0`` (sf.py:724-743)
+  * z is ``sqrt(d) normalize(randn)``; with ``mix_ratio > 0`` the rows drawn by the mix uniform take the whitened feature of a permuted next goal (sf.py:724-739)
 
 Same import rule as fb_oracle.py: tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` only.
 
@@ -176,8 +176,6 @@ class SFOracleAgent:
     NETS = ("actor", "successor_net", "feature_learner")
 
     def __init__(self, cfg: fo.OracleConfig, nets: tp.Dict[str, Params], learner: str = "icm", sf_q_loss: bool = True) -> None:
-        if cfg.mix_ratio != 0:
-            raise NotImplementedError("sf_oracle restates the default mix_ratio = 0 branch (sf.py:728-743 is skipped)")
         self.cfg, self.learner, self.sf_q_loss = cfg, learner, sf_q_loss
         for n in self.NETS:
             setattr(self, n, {k: v.clone() for k, v in nets[n].items()})
@@ -198,6 +196,15 @@ class SFOracleAgent:
         if cfg.use_goal:                                           # sf.py:716-721
             goal, next_goal = t(batch["goal"]), t(batch["next_goal"])
         z = fo.sample_z_from_gauss(t(draws.z_gauss), cfg.z_dim)    # sf.py:570-573, 723
+        if cfg.mix_ratio > 0:                                      # sf.py:725-739: whitened features of permuted next goals as tasks
+            with torch.no_grad():
+                phi_p = feature_net(self.feature_learner, next_goal[torch.as_tensor(draws.perm, dtype=torch.long)], cfg.z_dim)
+                cov = torch.matmul(phi_p.T, phi_p) / phi_p.shape[0]
+                inv_cov = torch.linalg.pinv(cov)
+                mix_idxs = np.where(draws.mix_uniform < cfg.mix_ratio)[0]
+                new_z = math.sqrt(cfg.z_dim) * F.normalize(torch.matmul(phi_p[mix_idxs], inv_cov), dim=1)
+                z = z.clone()
+                z[mix_idxs] = new_z
         metrics: tp.Dict[str, float] = {}
 
         # ---------------- update_sf (sf.py:594-664) ---------------- #

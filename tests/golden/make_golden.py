@@ -360,6 +360,19 @@ def sf_more_fixture(R):
     _sf_inits(R, ("random", "autoencoder", "transition"))
 
 
+def sf_mix_fixture(R):
+    """SFAgent with mix_ratio > 0 (sf.py:725-739): rows with uniform < mix_ratio take z = sqrt(d) normalize(phi(next_goal[perm]) @
+    pinv(phi^T phi / B)) instead of the gaussian draw.  Three learners: icm (feature-space critic loss), lap with a goal space and
+    variable episode lengths, and identity (phi = the raw goal: the covariance of the observations themselves)."""
+    _sf_traces(R, (
+        ("tiny_sf_mix_icm_trace", "icm", True, dict(z_dim=10, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.5), dict(seed=151, n_eps=6, T=12, n_steps=4)),
+        ("tiny_sf_mix_lap_trace", "lap", False,
+         dict(goal_dim=3, use_goal=True, z_dim=8, backward_hidden_dim=22, batch_size=24, lr_coef=5.0, mix_ratio=0.4),
+         dict(seed=152, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)),
+        ("tiny_sf_mix_identity_trace", "identity", True, dict(z_dim=5, backward_hidden_dim=20, lr_coef=5.0, mix_ratio=0.6),
+         dict(seed=153, n_eps=6, T=12, n_steps=4))))
+
+
 def sf_svdp_fixture(R):
     """feature_learner="svd_p" (SVDP, sf.py:337-362; the paper's LRA-P): a second net mu_net on cat[goal, action], the low-rank
     loss on P = mu . phi(next_goal)^T plus the orthonormality loss of phi(next_goal).  Once with the defaults, once with a goal
@@ -452,7 +465,7 @@ def _sf_traces(R, table):
             lr_coef=cfg.lr_coef, sf_target_tau=cfg.fb_target_tau, hidden_dim=cfg.hidden_dim,
             backward_hidden_dim=cfg.backward_hidden_dim, feature_dim=cfg.feature_dim, z_dim=cfg.z_dim,
             stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size, q_loss=q_loss,
-            feature_learner=learner, mix_ratio=0.0, update_every_steps=1)
+            feature_learner=learner, mix_ratio=cfg.mix_ratio, update_every_steps=1)
         for n in nets:
             getattr(agent, n).load_state_dict(nets[n])
         agent.successor_target_net.load_state_dict(agent.successor_net.state_dict())
@@ -795,6 +808,7 @@ def main():
     sf_contrastive_fixture(R)
     sf_contrastivev2_fixture(R)
     sf_identity_fixture(R)
+    sf_mix_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

@@ -136,7 +136,7 @@ def sf_trace_inputs(name):
                                   "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
                                   "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace",
                                   "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace", "tiny_sf_contrastivev2_trace",
-                                  "tiny_sf_identity_trace"])
+                                  "tiny_sf_identity_trace", "tiny_sf_mix_icm_trace", "tiny_sf_mix_lap_trace", "tiny_sf_mix_identity_trace"])
 def test_sf_oracle_full_state_against_the_reference(name):
     """oracle/sf_oracle.py against traces of the real url_benchmark.agent.sf.SFAgent: metrics and every parameter / target /
     Adam tensor after every step (icm + scalar Q regression; lap + feature-space regression + goal space + variable lengths)."""

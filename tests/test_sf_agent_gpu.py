@@ -23,7 +23,7 @@ def sf_kwargs(cfg: fo.OracleConfig, learner: str, q_loss: bool, goal_space=None,
               use_tb=metrics, use_wandb=False, use_hiplog=False, goal_space=goal_space, lr=cfg.lr, lr_coef=cfg.lr_coef,
               sf_target_tau=cfg.fb_target_tau, hidden_dim=cfg.hidden_dim, backward_hidden_dim=cfg.backward_hidden_dim,
               feature_dim=cfg.feature_dim, z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip,
-              batch_size=cfg.batch_size, q_loss=q_loss, feature_learner=learner, mix_ratio=0.0, update_every_steps=1,
+              batch_size=cfg.batch_size, q_loss=q_loss, feature_learner=learner, mix_ratio=cfg.mix_ratio, update_every_steps=1,
               add_trunk=cfg.add_trunk, preprocess=cfg.preprocess)
     kw.update(extra)
     return kw
@@ -64,7 +64,7 @@ def set_sf_state(agent, state: dict, steps: int) -> None:
                                   "tiny_sf_svdp_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_latent_trace",
                                   "tiny_sf_svdsr_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_svdsrv2_trace",
                                   "tiny_sf_contrastive_trace", "tiny_sf_contrastive_goal_trace", "tiny_sf_contrastivev2_trace",
-                                  "tiny_sf_identity_trace"])
+                                  "tiny_sf_identity_trace", "tiny_sf_mix_icm_trace", "tiny_sf_mix_lap_trace", "tiny_sf_mix_identity_trace"])
 def test_sf_teacher_forced_against_reference_trace(name):
     """Each step starts from the REFERENCE SFAgent's recorded state, runs one HIP update with the recorded draws and must land
     on the reference's next state and metrics; intermediates and gradients are compared with the oracle's autograd."""
@@ -130,8 +130,19 @@ def test_sf_teacher_forced_against_reference_trace(name):
 def test_sf_free_running_at_full_width_against_the_oracle(learner, q_loss, goal):
     """hidden 1024 / feature 512 / Hb 512 (the reference defaults), z 100, batch 256, walker-sized inputs: three free-running
     updates against the oracle (metrics + parameter checksums)."""
-    cfg = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=3 if goal else 24, z_dim=100, backward_hidden_dim=512, batch_size=256,
-                          lr_coef=5.0, mix_ratio=0.0, use_goal=goal, future=0.8 if learner.startswith("contrastive") else 1.0)
+    _free_running_full_width(learner, q_loss, goal, 0.0)
+
+
+@pytest.mark.parametrize("learner,q_loss,goal,z_dim", [("icm", True, False, 50), ("lap", False, True, 50), ("svd_sr", True, False, 50)])
+def test_sf_mix_free_running_at_full_width_against_the_oracle(learner, q_loss, goal, z_dim):
+    """mix_ratio = 0.5 at the full widths (sf.py:725-739): half of the tasks are whitened features of permuted next goals.  The d x d
+    covariance of 256 unit-norm features is inverted (fp64 Gauss-Jordan here, SVD pinv in the oracle)."""
+    _free_running_full_width(learner, q_loss, goal, 0.5, z_dim)
+
+
+def _free_running_full_width(learner, q_loss, goal, mix_ratio, z_dim=100):
+    cfg = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=3 if goal else 24, z_dim=z_dim, backward_hidden_dim=512, batch_size=256,
+                          lr_coef=5.0, mix_ratio=mix_ratio, use_goal=goal, future=0.8 if learner.startswith("contrastive") else 1.0)
     rng = np.random.default_rng(41)
     shapes = so.net_shapes(cfg, learner)
     nets = {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}
@@ -219,7 +230,7 @@ def test_sf_pickle_init_from_update_many_and_inference():
 def test_sf_unsupported_options_fail_loudly():
     from controllable_agent_amd.agent import SFHipAgent
     base = dict(obs_type="states", obs_shape=(5,), action_shape=(3,), num_expl_steps=0)
-    for bad in (dict(feature_learner="no_such_learner"), dict(mix_ratio=0.3), dict(boltzmann=True),
+    for bad in (dict(feature_learner="no_such_learner"), dict(mix_ratio=0.3, batch_size=8, z_dim=10), dict(boltzmann=True),
                 dict(num_sf_updates=0)):
         with pytest.raises(NotImplementedError):
             SFHipAgent(**{**base, **bad})
@@ -279,7 +290,8 @@ def test_sf_fb_features_take_the_backward_net_of_a_trained_fb_agent():
 
 
 @pytest.mark.parametrize("name", ["tiny_sf_lap_trace", "tiny_sf_autoencoder_trace", "tiny_sf_transition_trace", "tiny_sf_svdp_goal_trace",
-                                  "tiny_sf_random_trace", "tiny_sf_latent_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_contrastive_goal_trace"])
+                                  "tiny_sf_random_trace", "tiny_sf_latent_trace", "tiny_sf_svdsr_goal_trace", "tiny_sf_contrastive_goal_trace",
+                                  "tiny_sf_mix_icm_trace", "tiny_sf_mix_lap_trace", "tiny_sf_mix_identity_trace"])
 def test_sf_pipelined_update_many_equals_single_updates(name):
     """fbhip_update_many cuts an SF update into head (sampling, online successor_net, feature_net [, mu_net]), middle and actor phase
     and runs the next step's head beside the actor phase: same kernels and operands, so the state after n pipelined steps equals n
@@ -309,7 +321,7 @@ def test_sf_contrastive_needs_hindsight_goals():
     assert np.all(fut >= step) and np.all(fut <= 12) and agent.step_counts() == (1, 1)
 
 
-@pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_svdp_goal_trace"])
+@pytest.mark.parametrize("name", ["tiny_sf_icm_trace", "tiny_sf_svdp_goal_trace", "tiny_sf_mix_icm_trace"])
 def test_sf_phase_split_schedule_equals_single_call(name, monkeypatch):
     """The data-parallel cut of an SF update (gradients | sf_opt + phi_opt step + actor gradient | actor step, distributed.dp_update)
     on one rank against the single-graph update on the same draws: launches group differently, so fp32 tolerance."""
@@ -329,6 +341,30 @@ def test_sf_phase_split_schedule_equals_single_call(name, monkeypatch):
     assert a1.step_counts() == a2.step_counts() == (3, 3)
     for k in s1:
         np.testing.assert_allclose(s2[k], s1[k], rtol=0, atol=3e-6, err_msg=k)
+
+
+def test_sf_mix_draws_on_device():
+    """mix_ratio > 0 with nothing injected: the permutation and the mix uniforms come from the device sampler, the rows below the
+    ratio carry sqrt(d) normalize(phi(next_goal[perm]) @ inv_cov) recomputed here from the agent's own feature_net, the others the
+    gaussian draw."""
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_mix_lap_trace")
+    agent = make_sf_agent(cfg, nets, "lap", False, meta["goal_space"])
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    w0 = {k: v.detach().cpu().clone() for k, v in agent.feature_learner.state_dict().items()}    # weights BEFORE the update
+    agent.update(rb, 0)
+    v = lambda n: agent.workspace_view(n).cpu()
+    perm, u, ep, st = v("perm")[0].long(), v("mix_uniform")[0], v("ep_idx")[0].long(), v("step_idx")[0].long()
+    assert sorted(perm.tolist()) == list(range(cfg.batch_size)) and perm.tolist() != list(range(cfg.batch_size))
+    mixed = u < cfg.mix_ratio
+    assert 0 < int(mixed.sum()) < cfg.batch_size
+    goal = torch.from_numpy(storage["goal"])
+    next_goal = goal[ep, st]
+    ref = so.feature_net({k: v_ for k, v_ in w0.items()}, next_goal[perm], cfg.z_dim)
+    inv = torch.linalg.pinv(ref.T @ ref / ref.shape[0])
+    want = np.sqrt(cfg.z_dim) * torch.nn.functional.normalize(ref @ inv, dim=1)
+    gauss = fo.sample_z_from_gauss(v("z_gauss"), cfg.z_dim)
+    zz = v("z")
+    assert H.rel_err(zz[mixed], want[mixed]) < 2e-5 and H.rel_err(zz[~mixed], gauss[~mixed]) < 1e-6
 
 
 def test_sf_identity_features_surface():

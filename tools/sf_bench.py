@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--learner", choices=("icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive", "contrastivev2"), default="icm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mix-ratio", type=float, default=0.0, help="SFAgent.mix_ratio (sf.py:725-739); the reference default is 0")
     args = ap.parse_args()
     W = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=100, hidden_dim=1024, feature_dim=512, backward_hidden_dim=512, batch_size=1024)
     dev = "cuda:0"
@@ -58,7 +59,7 @@ def main():
     from controllable_agent_amd.agent import SFHipAgent
     torch.manual_seed(1)
     agent = SFHipAgent(obs_type="states", obs_shape=(W["obs_dim"],), action_shape=(W["action_dim"],), device=dev, num_expl_steps=0,
-                       update_every_steps=1, feature_learner=args.learner, use_tb=False, use_wandb=False, use_hiplog=False)
+                       update_every_steps=1, feature_learner=args.learner, mix_ratio=args.mix_ratio, use_tb=False, use_wandb=False, use_hiplog=False)
     rb = bench.make_replay(5000, 1000, W["obs_dim"], W["action_dim"], dev, seed=100)
     spl = 32
 
@@ -87,7 +88,7 @@ def main():
     out = {"metric": "SF update-steps/sec (batch=1024, z_dim=100)", "value": rate, "unit": "update-steps/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / rate, "higher_is_better": True, "vs_baseline": None,
            "dtype": "f32", "data": "synthetic", "repeats": rates,
-           "config": {"workload": f"sf offline (SFAgent defaults, feature_learner={args.learner}, q_loss on): obs 24, action 6, z_dim 100, "
+           "config": {"workload": f"sf offline (SFAgent defaults, feature_learner={args.learner}, q_loss on{f', mix_ratio {args.mix_ratio}' if args.mix_ratio else ''}): obs 24, action 6, z_dim 100, "
                                   "hidden 1024, feature 512, backward hidden 512, batch 1024; 5000 x 1000 synthetic replay in HBM; "
                                   "metrics off in the timed loop", "steps_per_graph_launch": spl,
                       "metrics_after": {k: m[k] for k in ("sf_loss", "phi_loss", "actor_loss", "phi_norm", "z_norm") if k in m}},
@@ -97,7 +98,7 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import fb_oracle as fo
         from oracle import sf_oracle as so
-        cfg = fo.OracleConfig(**W, lr_coef=5.0, mix_ratio=0.0)
+        cfg = fo.OracleConfig(**W, lr_coef=5.0, mix_ratio=args.mix_ratio)
         rng = np.random.default_rng(1)
         shapes = so.net_shapes(cfg, args.learner)
         nets = {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}
