@@ -145,74 +145,108 @@ hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z
 //   cov = B^T B / batch;  inv_cov = inverse(cov)                       -> inverse_kernel (d x d, one workgroup)
 //   implicit_reward = rowsum((B inv_cov) * z);  next_Q = min(tF1.z, tF2.z);  target_Q = ir + discount * next_Q
 //   q_loss = mse(F1.z, target_Q) + mse(F2.z, target_Q);  dF_i += coef * 2 (F_i.z - target_Q) / batch * z
-// In-place Gauss-Jordan with partial pivoting, fp64 in LDS (the matrix is tiny; fp64 keeps the result at the
-// conditioning of the fp32 input rather than adding a second fp32 round-off on top of torch.inverse's).
-__global__ void __launch_bounds__(256) inverse_kernel(const float* __restrict__ A, int lda, int d, float scale,
-                                                      float* __restrict__ out, int ldo) {
-    extern __shared__ double sm[];
-    double* M = sm;                  // [d][d]
-    double* rowk = M + d * d;        // [d]
-    double* colk = rowk + d;         // [d]
-    int* piv = (int*)(colk + d);     // [d]
-    __shared__ int s_p;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < d * d; e += 256) M[e] = (double)A[(size_t)(e / d) * lda + (e % d)] * (double)scale;
-    __syncthreads();
+// Gauss-Jordan with partial pivoting in fp64 (the matrix is tiny; fp64 keeps the result at the conditioning of the fp32 input
+// rather than adding a second fp32 round-off on top of torch.inverse's), by ONE workgroup of 1024 threads that keeps the matrix
+// in REGISTERS: thread (ri, cj) = (t % 32, t / 32) owns the 4 x 4 elements of rows ri + 32 a, columns cj + 32 b (d <= 128).
+// Per pivot step k only two vectors cross threads, through LDS: column k (written by its 32 owners, one half-wave, which also
+// pick the pivot among the rows not used so far with five xor-shuffles and compute 1 / pivot once) and the scaled pivot row
+// (written by its 32 owners after the first barrier); then every thread reads 4 + 4 values and updates its 16 elements.
+// Rows are never exchanged: the pivot order sigma is remembered and the result is scattered as
+//   inverse[a][b] = M_final[sigma(a)][sigma^-1(b)]      (Gauss-Jordan without pivoting applied to the row-permuted matrix).
+// d = 100, measured inside the SF step where it runs beside the previous step's actor phase (profiles/r02g_sf_lap_mix_*): 0.24 ms,
+// i.e. 2.4 us per pivot step (two barriers of 16 waves + the shuffle reduction on a CU it shares with GEMM workgroups).  The
+// first version (256 threads over an LDS-resident matrix, an fp64 division per element, four barriers per step) took 0.85 ms --
+// more than a whole FB update -- and a 1024-thread LDS-resident one 0.34 ms.
+constexpr int INV_T = 1024;
+__device__ __forceinline__ double rcp_f64(double x) {          // v_rcp_f64 seed + two Newton steps: ~1 ulp, no div expansion
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+__global__ void __launch_bounds__(INV_T) inverse_kernel(const float* __restrict__ A, int lda, int d, float scale,
+                                                        float* __restrict__ out, int ldo) {
+    __shared__ double colk[2][128], rowk[128], s_rkk[2];
+    __shared__ int s_p[2], piv[128], pinv[128];
+    const int tid = threadIdx.x, ri = tid & 31, cj = tid >> 5, wave = tid >> 6;
+    double m[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ri + 32 * a, j = cj + 32 * b;
+            m[a][b] = (i < d && j < d) ? (double)A[(size_t)i * lda + j] * (double)scale : 0.0;
+        }
+    unsigned used = 0;                          // bit a: row ri + 32 a has been a pivot row
     for (int k = 0; k < d; ++k) {
-        if (tid < 64) {              // pivot search by wave 0: argmax_i>=k |M[i][k]| (lowest index on ties)
-            double best = -1.0;
-            int bi = k;
-            for (int i = k + tid; i < d; i += 64) {
-                const double v = fabs(M[i * d + k]);
-                if (v > best) { best = v; bi = i; }
+        const int par = k & 1, kb = k >> 5, kc = k & 31;
+        if (wave == (kc >> 1)) {                // the wave that holds column k (the other half-wave runs along, writes nothing)
+            const bool owner = cj == kc;
+            double v[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = kb == 0 ? m[a][0] : kb == 1 ? m[a][1] : kb == 2 ? m[a][2] : m[a][3];
+            double bv = 0.0, babs = -1.0;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = ri + 32 * a;
+                if (owner) colk[par][i] = v[a];
+                const double av = (i < d && !((used >> a) & 1u)) ? fabs(v[a]) : -1.0;
+                if (av > babs) { babs = av; bv = v[a]; bi = i; }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(best, o);
+            for (int o = 16; o > 0; o >>= 1) {   // within the half-wave; lowest row on ties
+                const double ov = __shfl_xor(bv, o), oa = __shfl_xor(babs, o);
                 const int oi = __shfl_xor(bi, o);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                if (oa > babs || (oa == babs && oi < bi)) { babs = oa; bv = ov; bi = oi; }
             }
-            if (tid == 0) { s_p = bi; piv[k] = bi; }
+            if ((unsigned)bi >= (unsigned)d) bi = k;           // (only with NaNs in the input: garbage out, but in bounds)
+            if (owner && ri == 0) { s_p[par] = bi; s_rkk[par] = rcp_f64(bv); piv[k] = bi; pinv[bi] = k; }
         }
         __syncthreads();
-        const int p = s_p;
-        if (p != k)
-            for (int j = tid; j < d; j += 256) { const double t = M[k * d + j]; M[k * d + j] = M[p * d + j]; M[p * d + j] = t; }
-        __syncthreads();
-        const double pv = M[k * d + k];
-        for (int j = tid; j < d; j += 256) {
-            rowk[j] = (j == k) ? 1.0 / pv : M[k * d + j] / pv;
-            colk[j] = (j == k) ? 0.0 : M[j * d + k];
+        const int p = s_p[par];
+        const double rkk = s_rkk[par];
+        if (ri == (p & 31)) {                   // the owners of the pivot row: scaled row -> LDS
+            const int pa = p >> 5;
+            used |= 1u << pa;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = cj + 32 * b;
+                const double x = pa == 0 ? m[0][b] : pa == 1 ? m[1][b] : pa == 2 ? m[2][b] : m[3][b];
+                rowk[j] = (j == k) ? rkk : x * rkk;
+            }
         }
         __syncthreads();
-        for (int e = tid; e < d * d; e += 256) {
-            const int i = e / d, j = e % d;
-            if (i == k) M[e] = rowk[j];
-            else if (j == k) M[e] = -colk[i] * rowk[k];
-            else M[e] -= colk[i] * rowk[j];
-        }
-        __syncthreads();
+        double rj[4], ca[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) rj[b] = rowk[cj + 32 * b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) ca[a] = colk[par][ri + 32 * a];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool isp = (ri + 32 * a) == p, isk = (cj + 32 * b) == k;
+                m[a][b] = isp ? rj[b] : (isk ? -ca[a] * rkk : fma(-ca[a], rj[b], m[a][b]));
+            }
     }
-    for (int k = d - 1; k >= 0; --k) {               // undo the row exchanges as column exchanges
-        const int p = piv[k];
-        if (p != k)
-            for (int i = tid; i < d; i += 256) { const double t = M[i * d + k]; M[i * d + k] = M[i * d + p]; M[i * d + p] = t; }
-        __syncthreads();
-    }
-    for (int e = tid; e < d * d; e += 256) out[(size_t)(e / d) * ldo + (e % d)] = (float)M[e];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ri + 32 * a, j = cj + 32 * b;
+            if (i < d && j < d) out[(size_t)pinv[i] * ldo + piv[j]] = (float)m[a][b];
+        }
 }
 
 hipError_t launch_inverse(const float* A, int lda, int d, float scale, float* out, int ldo, hipStream_t s) {
     if (d < 1 || d > 128) return hipErrorInvalidValue;
-    const size_t bytes = ((size_t)d * d + 2 * d) * sizeof(double) + (size_t)d * sizeof(int);
-    hipLaunchKernelGGL(inverse_kernel, dim3(1), dim3(256), bytes, s, A, lda, d, scale, out, ldo);
+    hipLaunchKernelGGL(inverse_kernel, dim3(1), dim3(INV_T), 0, s, A, lda, d, scale, out, ldo);
     return hipGetLastError();
 }
 
-hipError_t inverse_prepare() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&inverse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(((size_t)128 * 128 + 256) * sizeof(double) + 128 * sizeof(int)));
-}
+hipError_t inverse_prepare() { return hipSuccess; }      // (static LDS only)
 
 // one wavefront per row; partial sums of the two squared errors go to ``part`` (2 floats per workgroup)
 __global__ void __launch_bounds__(256) qloss_kernel(const float* __restrict__ F1, const float* __restrict__ F2,
