@@ -112,6 +112,7 @@ PROTOTYPES = {
     "fbhip_pairwise_fb": (C.c_int, [_P] * 7 + [_I, _I, _I, _F] + [_P] * 5 + [_P]),
     "fbhip_pairwise_fb_block": (C.c_int, [_P] * 7 + [_I, _I, _I, _F, _I, _I] + [_P] * 5 + [_P]),
     "fbhip_adam_ema": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _I, _F, _F, _P]),
+    "fbhip_inverse": (C.c_int, [_P, _I, _I, _F, _P, _I, _P]),
 }
 
 _lib = None

@@ -908,6 +908,13 @@ int fbhip_adam_ema(float* params, const float* grads, float* m, float* v, float*
     return FBHIP_OK;
 }
 
+int fbhip_inverse(const float* A, int32_t lda, int32_t d, float scale, float* out, int32_t ldo, void* stream) {
+    fbhip_ctx* none = nullptr;
+    if (A == nullptr || out == nullptr || d < 1 || d > 128 || lda < d || ldo < d) { g_err = "fbhip_inverse: 1 <= d <= 128, lda / ldo >= d"; return FBHIP_E_INVALID; }
+    HIPCK(none, launch_inverse(A, lda, d, scale, out, ldo, (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
 int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float* z, int32_t ldz, const float* mu,
                      int32_t ldmu, const float* action, int32_t lda, float stddev, float* dF1, float* dF2, float* metrics,
                      float* scratch, int32_t rows, int32_t d, int32_t a, void* stream) {

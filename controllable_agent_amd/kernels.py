@@ -133,6 +133,15 @@ def adam_ema(params, grads, m, v, target, lr: float, t: int, grad_scale: float =
                                      int(t), float(grad_scale), float(tau), stream_ptr()))
 
 
+def inverse(A: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """inverse(scale * A) of a [d, d] fp32 matrix (row stride >= d), 1 <= d <= 128."""
+    _lib.require_device()
+    d = A.shape[0]
+    out = torch.empty((d, d), device=A.device)
+    check(_lib.load().fbhip_inverse(ptr(A), A.stride(0), d, float(scale), ptr(out), d, stream_ptr()))
+    return out
+
+
 def actor_loss(F1, F2, z, mu, action, stddev: float):
     _lib.require_device()
     rows, d = F1.shape

@@ -389,6 +389,9 @@ int fbhip_pairwise_fb_block(const float* F1, const float* F2, const float* Bm, c
  * t = 1-based step count; target nullable (utils.py:66-69 fused when given). */
 int fbhip_adam_ema(float* params, const float* grads, float* m, float* v, float* target, int64_t numel,
                    float lr, int32_t t, float grad_scale, float tau, void* stream);
+/* out[d,d] = inverse(scale * A[d,d]), 1 <= d <= 128: Gauss-Jordan with partial pivoting in fp64 on one workgroup -- torch.inverse of
+ * the q_loss covariance (fb_ddpg.py:334-335) and the pinv of SFAgent's z-mix covariance (sf.py:731-732, full rank). */
+int fbhip_inverse(const float* A, int32_t lda, int32_t d, float scale, float* out, int32_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

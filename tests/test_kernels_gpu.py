@@ -247,6 +247,27 @@ def test_adam_ema_matches_torch_optim(K):
     assert rel_err(m.cpu(), st["exp_avg"]) < 1e-6 and rel_err(v.cpu(), st["exp_avg_sq"]) < 1e-6
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 31, 32, 33, 50, 64, 100, 127, 128])
+def test_inverse_general_and_covariance_matrices(K, d):
+    """inverse_kernel against torch.linalg.inv in fp64: (a) a general matrix whose largest column entries sit off the diagonal, so
+    that nearly every pivot step picks another row (the kernel never moves rows: it scatters the result through the pivot order);
+    (b) a covariance phi^T phi / n as the q_loss / z-mix paths produce, through a padded row stride and the scale argument."""
+    g = torch.Generator().manual_seed(100 + d)
+    A = torch.randn(d, d, generator=g) + 3.0 * torch.eye(d)[torch.randperm(d, generator=g)]
+    want = torch.linalg.inv(A.double())
+    got = K.inverse(A.cuda()).cpu().double()
+    cond = float(torch.linalg.cond(A.double()))
+    assert float((got - want).abs().max() / want.abs().max()) < 4e-7 * max(cond, 1.0), cond
+    assert float((got @ A.double() - torch.eye(d, dtype=torch.float64)).abs().max()) < 2e-6 * max(cond, 1.0)
+    n = 4 * d + 8
+    phi = torch.randn(n, d, generator=g)
+    C = torch.zeros(d, d + 5)
+    C[:, :d] = phi.T @ phi
+    want = torch.linalg.inv((C[:, :d].double() / n))
+    got = K.inverse(C.cuda()[:, :d], scale=1.0 / n).cpu().double()
+    assert float((got - want).abs().max() / want.abs().max()) < 4e-7 * float(torch.linalg.cond(C[:, :d].double()))
+
+
 def test_adam_grad_scale(K):
     n = 64
     p, g = _r(n, seed=1).cuda(), _r(n, seed=2).cuda()
