@@ -31,7 +31,7 @@ class Dims(C.Structure):
     """include/fbhip.h::fbhip_dims; ``struct_size`` (first field) is filled in here, positional arguments start at ``batch``"""
     _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("batch", "obs_dim", "action_dim", "goal_dim", "z_dim", "hidden_dim",
                                           "feature_dim", "backward_hidden_dim", "use_goal", "add_trunk", "preprocess", "norm_z", "boltzmann",
-                                          "discrete", "sf")]
+                                          "discrete", "sf", "backward_identity")]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(Dims), *args, **kw)
@@ -134,7 +134,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 13:
+    if lib.fbhip_abi_version() != 14:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

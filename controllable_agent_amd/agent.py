@@ -265,7 +265,9 @@ class FBHipAgent:
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         # (``nstep`` is accepted and ignored like in the reference: neither FBDDPGAgent nor the in-memory ReplayBuffer reads
         # it -- only the file-based loader of url_benchmark/replay_buffer.py:182-259 did)
-        unsupported = {"obs_type": cfg.obs_type == "pixels", "debug": cfg.debug}
+        # cfg.debug (fb_ddpg.py:128-130): IdentityMap backward nets.  DiscreteFBAgent has the switch too (discrete_fb.py:134) -- not
+        # built here; SFAgent declares the field and never reads it (sf.py:70, 436): ignored there as in the reference
+        unsupported = {"obs_type": cfg.obs_type == "pixels", "debug": bool(cfg.debug) and self._discrete}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"FBHipAgent: non-default options not implemented in the HIP path yet: {bad}")
@@ -278,6 +280,12 @@ class FBHipAgent:
         if cfg.goal_space is not None:
             goal_dim = get_goal_space_dim(cfg.goal_space)
         self.goal_dim = goal_dim
+        self._identity_b = bool(cfg.debug) and not self._discrete and not self._sf_mode
+        if self._identity_b:
+            if goal_dim != cfg.z_dim:               # (the reference fails in update_fb: F [B, z_dim] x B(goal)^T [goal_dim, B])
+                raise ValueError(f"debug=True makes the backward map the identity: z_dim ({cfg.z_dim}) must equal the goal dimension ({goal_dim})")
+            if cfg.future_ratio > 0 or cfg.rand_weight:
+                raise NotImplementedError("FBHipAgent: debug=True is built for future_ratio = 0 and rand_weight = False")
         if cfg.feature_dim < self.obs_dim:
             logger.warning(f"feature_dim {cfg.feature_dim} should not be smaller that obs_dim {self.obs_dim}")
         if cfg.z_dim < goal_dim:
@@ -300,7 +308,8 @@ class FBHipAgent:
         cfg = self.cfg
         return Dims(cfg.batch_size, self.obs_dim, self.action_dim, self.goal_dim, cfg.z_dim, cfg.hidden_dim, cfg.feature_dim,
                     cfg.backward_hidden_dim, int(cfg.goal_space is not None), int(bool(cfg.add_trunk)), int(bool(cfg.preprocess)),
-                    int(bool(getattr(cfg, "norm_z", True))), int(bool(cfg.boltzmann)), int(self._discrete), int(self._sf_mode))
+                    int(bool(getattr(cfg, "norm_z", True))), int(bool(cfg.boltzmann)), int(self._discrete), int(self._sf_mode),
+                    int(getattr(self, "_identity_b", False)))
 
     @staticmethod
     def _resolve_device(device: tp.Any) -> torch.device:
@@ -339,9 +348,12 @@ class FBHipAgent:
 
         if self._discrete:        # discrete_fb.py:131-147: forward_net, backward_net, backward_target_net, forward_target_net
             nets = {"forward_net": build("forward_net"), "backward_net": build("backward_net")}
+        elif self._identity_b:    # cfg.debug: two IdentityMap()s, no parameters, no RNG draws (fb_ddpg.py:128-130)
+            nets = {"actor": build("actor"), "forward_net": build("forward_net"), "backward_net": {}}
         else:
             nets = {"actor": build("actor"), "forward_net": build("forward_net"), "backward_net": build("backward_net")}
-        build("backward_net")     # backward_target_net: constructed (RNG consumed), then overwritten by a copy
+        if not self._identity_b:
+            build("backward_net") # backward_target_net: constructed (RNG consumed), then overwritten by a copy
         build("forward_net")      # forward_target_net
         return nets
 
@@ -401,6 +413,11 @@ class FBHipAgent:
                              "v": NetView("v", self._fb_v[seg["backward_net"]], lay["backward_net"]).state_dict()},
             "actor": {"m": NetView("m", self._actor_m, lay["actor"]).state_dict(),
                       "v": NetView("v", self._actor_v, lay["actor"]).state_dict()}}
+        if getattr(self, "_identity_b", False):
+            # cfg.debug: IdentityMap holds no parameters.  The context keeps the block (unused, zero gradients); these views show none of it
+            for v in (self.backward_net, self.backward_target_net, self._grad_views["backward_net"]):
+                v._views.clear()
+            self._adam_views["backward_net"] = {"m": collections.OrderedDict(), "v": collections.OrderedDict()}
         c = self.cfg
         self.encoder_opt = None
         if self._discrete:                       # discrete_fb.py:103-165 has neither
@@ -456,6 +473,7 @@ class FBHipAgent:
         self.action_dim, self.obs_dim, self.goal_dim = int(cfg.action_shape[0]), int(cfg.obs_shape[0]), st["goal_dim"]
         self.solved_meta, self.actor_success, self.training = st["solved_meta"], [], st["training"]
         self._device = self._resolve_device(cfg.device)
+        self._identity_b = bool(cfg.debug) and not self._discrete and not self._sf_mode
         self._dims = self._make_dims()
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)

@@ -648,6 +648,11 @@ int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
     const BwdP& K = c->K_p;
     float* pre1 = w.act_vec; float* r2 = pre1 + 2048; float* y = r2 + 2048;
     HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, (act_z_off(d) + z) * sizeof(float), hipMemcpyHostToDevice, s));
+    if (d.backward_identity) {                   // IdentityMap: B(goal) = goal, no projection
+        HIPCK(c, launch_zcorrel(w.act_in, w.act_in + act_z_off(d), z, 0, w.act_out, s));
+        HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(float), hipMemcpyDeviceToHost, s));
+        return FBHIP_OK;
+    }
     // BackwardMap.forward (fb_modules.py:223-230) on the padded layout: pad rows of W1 / W2 are zero
     GemvGroup g1{}; g1.n = 1;
     g1.p[0] = GV(w.act_in, K.W1, pad32(g), K.b1, pre1, Lb, pad32(g), false);

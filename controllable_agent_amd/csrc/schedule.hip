@@ -363,6 +363,16 @@ void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx
     const bool in_ws = (const char*)X >= c->ws_lo && (const char*)X < c->ws_lo + c->ws_bytes;
     const int Kg = (in_ws && ldx >= pad32(g)) ? pad32(g) : g;
     BSet* Sp = &S;
+    if (d.backward_identity) {                   // cfg.debug: IdentityMap.forward (fb_modules.py:207-208) -- the map's output, projected or
+        out.push_back([=](Ops& o) {               // not, is its input (z_dim == goal_dim): both output panels of the set get the copy
+            o.post.push_back([=](hipStream_t q) -> int {
+                HIPCK(c, launch_concat2(Sp->y.p, Lz, X, ldx, z, nullptr, 0, 0, rows, q));
+                HIPCK(c, launch_concat2(Sp->Bm.p, Lz, X, ldx, z, nullptr, 0, 0, rows, q));
+                return (int)FBHIP_OK;
+            });
+        });
+        return;
+    }
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(X, ldx, 1, W.W1, pad32(g), 1, Sp->pre1.p, Lb, rows, Lb, Kg, W.b1, EPI_BIAS));
     });
@@ -546,6 +556,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         // every NULL field of ``inj`` is drawn on device; injected fields (parity mode / externally sampled
         // batches) overwrite the draw
         const bool hindsight = hp.future_ratio > 0.f;
+        if (d.backward_identity && (hindsight || hp.rand_weight)) { c->err = g_err = "fbhip: backward_identity (cfg.debug) is built for future_ratio = 0 and rand_weight = 0"; return FBHIP_E_INVALID; }
         if (hindsight && !(hp.future < 1.f)) { c->err = g_err = "fbhip: future_ratio > 0 needs a replay buffer with future < 1"; return FBHIP_E_INVALID; }
         const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
                                   inj->z_gauss && inj->eps_next && inj->eps_actor &&
@@ -612,7 +623,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         if (gm.single) zx = ZPanels{{w.Xoa.p, w.Xnoa.p, w.Xopi.p}, {w.Xoa.ld, w.Xnoa.ld, w.Xopi.ld}};
         HIPCK(c, launch_mix_z(w.so.z_gauss, z, ymix, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, hindsight ? w.bsF.y.p : nullptr, w.so.future_uniform,
-                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, randw ? 1 : 2,
+                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, (randw || d.backward_identity) ? 1 : 2,
                               zx, s));
         POST_END
     }
@@ -632,7 +643,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                            !(mask & FBHIP_PHASE_FB_STEP);
     // d/dy of B = sqrt(d) y/|y| is a row operation on the loss kernel's own output dB: pairwise_reduce_kernel does it when the
     // call continues with the backward (the BackwardMap chain then skips its l2norm_bwd launch)
-    const bool fused_dy = d.norm_z && (mask & FBHIP_PHASE_FB_BWD_A) && pad4(z) == w.bsO.y.ld && z <= 128;
+    const bool fused_dy = d.norm_z && !d.backward_identity && (mask & FBHIP_PHASE_FB_BWD_A) && pad4(z) == w.bsO.y.ld && z <= 128;
     const bool early_actor = !actor_with_target && (mask & FBHIP_PHASE_FB_BWD) && (mask & FBHIP_PHASE_ACTOR_FWD);
     // policy head + sample: one row kernel when the head's width has an instantiation and its weight fits 48 KB of LDS,
     // else head GEMM (in the chain) + sample
@@ -744,7 +755,8 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             std::vector<Chain> ch(3);
             const Buf& Xa = d.discrete ? w.Xoz : w.Xoa;
             forward_map_bwd_chain(c, c->F_p, c->F_g, Xa.p, Xa.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[0]);
-            backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1], fused_dy);
+            if (!d.backward_identity)             // (IdentityMap: dB ends at the input, nothing behind it)
+                backward_map_bwd_chain(c, c->K_p, c->K_g, next_goal, ld_ng, w.bsO, B, ch[1], fused_dy);
             if (early_actor) {
                 actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch[2], !fused_policy);
                 ch[2].push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));

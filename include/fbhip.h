@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 13
+#define FBHIP_ABI_VERSION 14
 
 enum {
     FBHIP_OK = 0,
@@ -131,6 +131,10 @@ typedef struct fbhip_dims {
                                     * z is sample_z; with hparams.mix_ratio > 0 the rows drawn by the mix uniform take
                                     * sqrt(d) normalize(phi(next_goal[perm]) @ inverse(phi^T phi / batch)) (sf.py:725-739; batch >= z_dim);
                                     * needs norm_z = 1, boltzmann = 0, discrete = 0.  The actor phase is FBDDPGAgent's. */
+    int32_t backward_identity;     /* cfg.debug (fb_ddpg.py:128-130; default 0).  1: backward_net and backward_target_net are IdentityMap
+                                    * (fb_modules.py:202-208): B(goal) = goal, unprojected whatever norm_z says, nothing to train;
+                                    * needs z_dim == goal_dim, sf = 0, discrete = 0, hparams.future_ratio = 0 and rand_weight = 0.  The
+                                    * NET_BACKWARD block keeps its place in the flat buffers (unused, its gradients stay zero). */
 } fbhip_dims;
 
 typedef struct fbhip_hparams {     /* FBDDPGAgentConfig fields, fb_ddpg.py:47-82 */

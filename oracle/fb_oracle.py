@@ -74,6 +74,8 @@ class OracleConfig:
     temp: float = 1.0             # fb_ddpg.py:71
     log_std_min: float = -5.0     # fb_ddpg.py:70  log_std_bounds
     log_std_max: float = 2.0
+    debug: bool = False           # backward_net = backward_target_net = IdentityMap(): B(goal) = goal, no parameters, no projection
+                                  # (fb_ddpg.py:128-130, fb_modules.py:202-208; needs goal_dim == z_dim)
 
 
 @dataclasses.dataclass
@@ -185,6 +187,8 @@ def actor_shapes(cfg: OracleConfig):
 def backward_map_shapes(cfg: OracleConfig):
     """BackwardMap parameter list (fb_modules.py:220): mlp(g, Hb, "ntanh", Hb, "relu", d)."""
     g, d, Hb = cfg.goal_dim, cfg.z_dim, cfg.backward_hidden_dim
+    if cfg.debug:                 # IdentityMap holds nn.Identity(): an empty state_dict
+        return []
     return [("B.0.weight", (Hb, g)), ("B.0.bias", (Hb,)),
             ("B.1.weight", (Hb,)), ("B.1.bias", (Hb,)),
             ("B.3.weight", (Hb, Hb)), ("B.3.bias", (Hb,)),
@@ -254,7 +258,9 @@ def backward_map_raw(p: Params, goal) -> torch.Tensor:
 
 
 def backward_map(p: Params, goal, z_dim: int, norm_z: bool = True) -> torch.Tensor:
-    """BackwardMap.forward (fb_modules.py:223-230)."""
+    """BackwardMap.forward (fb_modules.py:223-230); no parameters: IdentityMap.forward (fb_modules.py:207-208)."""
+    if not p:
+        return goal
     y = backward_map_raw(p, goal)
     return math.sqrt(z_dim) * F.normalize(y, dim=1) if norm_z else y
 
@@ -505,10 +511,13 @@ class OracleAgent:
             tB = backward_map(self.backward_target_net, next_goal, cfg.z_dim, cfg.norm_z)
         fp, bp = self._req(self.forward_net), self._req(self.backward_net)
         F1, F2 = forward_map(fp, obs, z, action)
-        y = backward_map_raw(bp, next_goal)
-        Bm = math.sqrt(cfg.z_dim) * F.normalize(y, dim=1) if cfg.norm_z else y * 1.0
+        if cfg.debug:                                              # IdentityMap: B = next_goal, a leaf like any input
+            y = Bm = next_goal.clone().requires_grad_(keep)
+        else:
+            y = backward_map_raw(bp, next_goal)
+            Bm = math.sqrt(cfg.z_dim) * F.normalize(y, dim=1) if cfg.norm_z else y * 1.0
         if keep:
-            for x in (F1, F2, Bm, y):
+            for x in (F1, F2) + (() if cfg.debug else (Bm, y)):
                 x.retain_grad()
         L = fb_loss_terms(F1, F2, Bm, tF1, tF2, tB, discount, cfg.ortho_coef)
         fb_loss = L["fb_loss"]

@@ -101,7 +101,7 @@ def make_ref_agent(R, cfg: fo.OracleConfig, goal_space=None, discrete=False, **e
         z_dim=cfg.z_dim, stddev_schedule=str(cfg.stddev), stddev_clip=cfg.stddev_clip, batch_size=cfg.batch_size,
         ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
         future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, rand_weight=cfg.rand_weight, add_trunk=cfg.add_trunk, preprocess=cfg.preprocess,
-        boltzmann=cfg.boltzmann, temp=cfg.temp, log_std_bounds=(cfg.log_std_min, cfg.log_std_max),
+        boltzmann=cfg.boltzmann, temp=cfg.temp, log_std_bounds=(cfg.log_std_min, cfg.log_std_max), debug=cfg.debug,
         update_every_steps=1, **extra)
 
 
@@ -277,6 +277,15 @@ def future_fixtures(R):
 def nonorm_fixture(R):
     """norm_z=False: BackwardMap unprojected, z = sqrt(d) U g/|g| (fb_ddpg.py:227-231, :483; fb_modules.py:228-229)"""
     trace_fixture(R, "tiny_nonorm_trace", tiny_cfg(norm_z=False, future=0.8, future_ratio=0.3), seed=105, n_eps=6, T=12, n_steps=4)
+
+
+def debug_fixture(R):
+    """cfg.debug (fb_ddpg.py:128-130): backward_net = backward_target_net = IdentityMap() -- B(goal) = goal, no parameters, no
+    projection; z_dim must equal the goal dimension.  Once with the defaults (z-mix of raw observations, projected once), once with a
+    goal space, variable episode lengths, norm_z off and the q_loss branch (covariance of the raw goals)."""
+    trace_fixture(R, "tiny_debug_trace", tiny_cfg(z_dim=5, debug=True), seed=161, n_eps=6, T=12, n_steps=4)
+    trace_fixture(R, "tiny_debug_goal_trace", tiny_cfg(goal_dim=3, use_goal=True, z_dim=3, debug=True, norm_z=False, q_loss=True, batch_size=24),
+                  seed=162, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)
 
 
 def randweight_fixture(R):
@@ -809,6 +818,7 @@ def main():
     sf_contrastivev2_fixture(R)
     sf_identity_fixture(R)
     sf_mix_fixture(R)
+    debug_fixture(R)
     walker = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50)
     trace_fixture(R, "walker_b256", fo.OracleConfig(batch_size=256, **walker), seed=201, n_eps=20, T=100,
                   n_steps=10, full_state=False, checksum_steps=(1, 5, 10))

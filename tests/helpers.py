@@ -62,7 +62,7 @@ def agent_kwargs(cfg: fo.OracleConfig, goal_space=None, metrics=True, **extra):
               ortho_coef=cfg.ortho_coef, mix_ratio=cfg.mix_ratio, q_loss=cfg.q_loss, q_loss_coef=cfg.q_loss_coef,
               future_ratio=cfg.future_ratio, norm_z=cfg.norm_z, rand_weight=cfg.rand_weight,
               add_trunk=cfg.add_trunk, preprocess=cfg.preprocess, boltzmann=cfg.boltzmann, temp=cfg.temp,
-              log_std_bounds=(cfg.log_std_min, cfg.log_std_max), update_every_steps=1)
+              log_std_bounds=(cfg.log_std_min, cfg.log_std_max), debug=cfg.debug, update_every_steps=1)
     kw.update(extra)
     return kw
 

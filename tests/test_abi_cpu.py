@@ -136,7 +136,7 @@ def test_struct_size_guard(lib):
     """a struct built against another header (wrong struct_size) is refused by every entry point that takes it"""
     l = lib.load()
     d = lib.Dims(16, 5, 3, 5, 8, 32, 16, 18, 0, 0, 1, 1)
-    assert d.struct_size == C.sizeof(lib.Dims) == 16 * 4
+    assert d.struct_size == C.sizeof(lib.Dims) == 17 * 4
     d.struct_size -= 4                                   # what a binding written against an older header (a field short) passes
     assert l.fbhip_net_numel(C.byref(d), 0) < 0 and b"struct_size" in l.fbhip_last_error(None)
     ctx = C.c_void_p()

@@ -91,9 +91,15 @@ def test_episode_batch_surface():
 def test_agent_rejects_unsupported_flags_loudly():
     from controllable_agent_amd.agent import FBHipAgent
     base = dict(obs_type="states", obs_shape=(4,), action_shape=(2,), num_expl_steps=0)
-    for flag in (dict(debug=True), dict(obs_type="pixels")):
+    from controllable_agent_amd.agent import DiscreteFBHipAgent
+    # (debug=True, the IdentityMap backward nets of fb_ddpg.py:128-130, is built for the default sampler of FBDDPGAgent only)
+    for flag in (dict(obs_type="pixels"), dict(debug=True, z_dim=4, future_ratio=0.5), dict(debug=True, z_dim=4, rand_weight=True)):
         with pytest.raises(NotImplementedError):
             FBHipAgent(**{**base, **flag})
+    with pytest.raises(NotImplementedError):
+        DiscreteFBHipAgent(**{**base, "debug": True, "z_dim": 4})
+    with pytest.raises(ValueError, match="must equal the goal dimension"):
+        FBHipAgent(**{**base, "debug": True, "z_dim": 8})
     with pytest.raises(ValueError):
         FBHipAgent(obs_type="states", obs_shape=(4,), action_shape=(2,))            # num_expl_steps missing
     if not torch.cuda.is_available():

@@ -43,7 +43,8 @@ def _param_close(got, ref, lr, name, max_step=0.5, one_in=1000):
                                              ("tiny_single_trunk_trace", None),
                                              ("tiny_single_trunk_goal_trace", "simplified_walker"),
                                              ("tiny_boltzmann_trace", None),
-                                             ("tiny_boltzmann_goal_trace", "simplified_walker")])
+                                             ("tiny_boltzmann_goal_trace", "simplified_walker"),
+                                             ("tiny_debug_trace", None), ("tiny_debug_goal_trace", "simplified_walker")])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
@@ -75,7 +76,8 @@ def test_teacher_forced_against_reference_trace(name, goal_space):
                           ("tF2", oracle.last["tF2"]), ("Bm", oracle.last["Bm"]), ("tB", oracle.last["tB"]),
                           ("pi_action", oracle.last["pi_action"]), ("mu", oracle.last["mu"])):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < 2e-5, (s, view)
-        for view, ref in (("dy", oracle.last["dy"]), ("d_premu", oracle.last["d_premu"])):
+        # (cfg.debug: the IdentityMap has nothing behind dB -- the pairwise kernel's dB is the end of that branch)
+        for view, ref in (("dBm" if cfg.debug else "dy", oracle.last["dy"]), ("d_premu", oracle.last["d_premu"])):
             assert H.rel_err(agent.workspace_view(view).cpu(), ref) < GRAD_REL_L2, (s, view)
         for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward"), ("actor", "grads_actor")):
             for k, g in agent._grad_views[net].state_dict().items():
@@ -340,6 +342,46 @@ def test_constructor_init_matches_reference_seed():
     for k, v in H.get_agent_state(agent).items():
         if not k.startswith("adam_"):
             np.testing.assert_allclose(v, z[k], rtol=0, atol=2e-6, err_msg=k)   # LAPACK QR thread-count jitter
+
+
+def test_debug_identity_backward_map_surface_and_pipelined_graph():
+    """cfg.debug (fb_ddpg.py:128-130): backward_net / backward_target_net are IdentityMap -- no parameters in state_dict(), the
+    optimiser's second group is empty, B(goal) = goal on every inference entry point; the pipelined multi-step graph equals single
+    updates bit for bit; a pickle round trip keeps all of it."""
+    import pickle
+    meta = H.load_meta("tiny_debug_trace")
+    cfg = H.cfg_from_meta(meta)
+    z = np.load(H.GOLDEN / "tiny_debug_trace.npz")
+    storage = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("storage/")}
+    nets = {n: {k.split("/", 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"init/{n}/")}
+            for n in ("actor", "forward_net", "backward_net")}
+    a1 = H.make_hip_agent(cfg, nets, None, metrics=False)
+    assert len(a1.backward_net.state_dict()) == 0 and len(a1.backward_target_net.state_dict()) == 0
+    assert len(list(a1.backward_net.parameters())) == 0
+    x = torch.randn(7, cfg.z_dim)
+    torch.testing.assert_close(a1.backward_net(x.cuda()).cpu(), x, rtol=0, atol=0)
+    torch.testing.assert_close(a1.backward_target_net(x.cuda()).cpu(), x, rtol=0, atol=0)
+    goal, zz = x[0].numpy(), x[1].numpy()
+    want = float((torch.nn.functional.normalize(x[0:1], 1) * torch.nn.functional.normalize(x[1:2], 1)).sum())   # fb_ddpg.py:283-289 (p = 1)
+    assert a1.compute_z_correl(_TimeStep(goal), {"z": zz}) == pytest.approx(want, rel=1e-5, abs=1e-7)
+    rb = _buffer(storage, z["lengths"], cfg.discount, cfg.future)
+    a2 = pickle.loads(pickle.dumps(a1))
+    assert len(a2.backward_net.state_dict()) == 0
+    a1.update_many(rb, 0, 5)
+    for s in range(5):
+        a2.update(rb, s)
+    s1, s2 = H.get_agent_state(a1), H.get_agent_state(a2)
+    assert a1.step_counts() == a2.step_counts() == (5, 5) and not any(k.startswith(("backward", "adam_m/backward")) for k in s1)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+    fb = a1.fb_opt.state_dict()
+    assert len(fb["param_groups"]) == 2 and len(fb["param_groups"][1]["params"]) == 0        # torch.optim.Adam with an empty second group
+
+
+class _TimeStep:
+    def __init__(self, obs):
+        self.observation = obs
+        self.goal = obs
 
 
 def test_pickle_and_init_from_round_trip():
