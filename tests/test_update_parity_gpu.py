@@ -879,6 +879,20 @@ def test_random_configurations_one_update_against_the_oracle(seed):
     preprocess, boltzmann, rand_weight, hindsight replay, mix_ratio incl. 0 and 1, lr_coef, ortho_coef, temp): one injected
     update, losses and every gradient tensor against the oracle.  Combinations no hand-written case covers."""
     cfg, goal_space = _random_case(seed)
+    _one_random_update(cfg, goal_space, seed)
+
+
+@pytest.mark.parametrize("seed", list(range(400, 424)))
+def test_random_debug_configurations_one_update_against_the_oracle(seed):
+    """The same sweep with cfg.debug (IdentityMap backward nets, fb_ddpg.py:128-130): z_dim follows the goal dimension, hindsight
+    replay and rand_weight off (not built for it); q_loss then inverts the covariance of the raw goals."""
+    cfg, goal_space = _random_case(seed)
+    cfg = dataclasses.replace(cfg, debug=True, z_dim=cfg.goal_dim, rand_weight=False, future_ratio=0.0, future=1.0,
+                              batch_size=max(cfg.batch_size, 3 * cfg.goal_dim))
+    _one_random_update(cfg, goal_space, seed)
+
+
+def _one_random_update(cfg, goal_space, seed):
     rng = np.random.default_rng(1000 + seed)
     nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
     storage, lengths = fo.synthetic_storage(rng, 6, 9, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if cfg.use_goal else None)
