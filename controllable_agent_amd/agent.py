@@ -265,9 +265,9 @@ class FBHipAgent:
                 raise ValueError(f"FBHipAgent: missing required config field {f!r}")
         # (``nstep`` is accepted and ignored like in the reference: neither FBDDPGAgent nor the in-memory ReplayBuffer reads
         # it -- only the file-based loader of url_benchmark/replay_buffer.py:182-259 did)
-        # cfg.debug (fb_ddpg.py:128-130): IdentityMap backward nets.  DiscreteFBAgent has the switch too (discrete_fb.py:134) -- not
-        # built here; SFAgent declares the field and never reads it (sf.py:70, 436): ignored there as in the reference
-        unsupported = {"obs_type": cfg.obs_type == "pixels", "debug": bool(cfg.debug) and self._discrete}
+        # cfg.debug (fb_ddpg.py:128-130, discrete_fb.py:134-136): IdentityMap backward nets.  SFAgent declares the field and never
+        # reads it (sf.py:70, 436): ignored there as in the reference
+        unsupported = {"obs_type": cfg.obs_type == "pixels"}
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"FBHipAgent: non-default options not implemented in the HIP path yet: {bad}")
@@ -280,7 +280,7 @@ class FBHipAgent:
         if cfg.goal_space is not None:
             goal_dim = get_goal_space_dim(cfg.goal_space)
         self.goal_dim = goal_dim
-        self._identity_b = bool(cfg.debug) and not self._discrete and not self._sf_mode
+        self._identity_b = bool(cfg.debug) and not self._sf_mode
         if self._identity_b:
             if goal_dim != cfg.z_dim:               # (the reference fails in update_fb: F [B, z_dim] x B(goal)^T [goal_dim, B])
                 raise ValueError(f"debug=True makes the backward map the identity: z_dim ({cfg.z_dim}) must equal the goal dimension ({goal_dim})")
@@ -347,7 +347,7 @@ class FBHipAgent:
             return sd
 
         if self._discrete:        # discrete_fb.py:131-147: forward_net, backward_net, backward_target_net, forward_target_net
-            nets = {"forward_net": build("forward_net"), "backward_net": build("backward_net")}
+            nets = {"forward_net": build("forward_net"), "backward_net": {} if self._identity_b else build("backward_net")}
         elif self._identity_b:    # cfg.debug: two IdentityMap()s, no parameters, no RNG draws (fb_ddpg.py:128-130)
             nets = {"actor": build("actor"), "forward_net": build("forward_net"), "backward_net": {}}
         else:
@@ -473,7 +473,7 @@ class FBHipAgent:
         self.action_dim, self.obs_dim, self.goal_dim = int(cfg.action_shape[0]), int(cfg.obs_shape[0]), st["goal_dim"]
         self.solved_meta, self.actor_success, self.training = st["solved_meta"], [], st["training"]
         self._device = self._resolve_device(cfg.device)
-        self._identity_b = bool(cfg.debug) and not self._discrete and not self._sf_mode
+        self._identity_b = bool(cfg.debug) and not self._sf_mode
         self._dims = self._make_dims()
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)

@@ -168,7 +168,7 @@ int check_dims(const fbhip_dims* d) {
     if (d->sf < 0 || d->sf > 12) { g_err = "fbhip: dims.sf must be 0 or 1..12 (icm, lap, random, autoencoder, transition, svd_p, latent, svd_sr, svd_srv2, contrastive, contrastivev2, identity)"; return FBHIP_E_INVALID; }
     if (d->sf == 12 && d->z_dim != d->goal_dim) { g_err = "fbhip: dims.sf = 12 (identity features) needs z_dim == goal_dim"; return FBHIP_E_INVALID; }
     if (d->sf && (d->discrete || d->boltzmann || !d->norm_z)) { g_err = "fbhip: dims.sf needs discrete = 0, boltzmann = 0, norm_z = 1"; return FBHIP_E_INVALID; }
-    if (d->backward_identity && (d->sf || d->discrete || d->z_dim != d->goal_dim)) { g_err = "fbhip: backward_identity (cfg.debug) needs sf = 0, discrete = 0 and z_dim == goal_dim"; return FBHIP_E_INVALID; }
+    if (d->backward_identity && (d->sf || d->z_dim != d->goal_dim)) { g_err = "fbhip: backward_identity (cfg.debug) needs sf = 0 and z_dim == goal_dim"; return FBHIP_E_INVALID; }
     if (!d->use_goal && d->goal_dim != d->obs_dim) { g_err = "fbhip: goal_dim must equal obs_dim when use_goal == 0"; return FBHIP_E_INVALID; }
     return FBHIP_OK;
 }

@@ -123,10 +123,13 @@ class DiscreteOracleAgent:
         idxs = action.repeat(1, d)[:, :, None]                     # :309
         F1a, F2a = forward_map(fp, obs, z, A)
         F1, F2 = F1a.gather(-1, idxs).squeeze(-1), F2a.gather(-1, idxs).squeeze(-1)
-        y = fo.backward_map_raw(bp, next_goal)
-        Bm = math.sqrt(d) * F.normalize(y, dim=1) if cfg.norm_z else y * 1.0
+        if cfg.debug:                                              # IdentityMap (discrete_fb.py:134-136): B = next_goal
+            y = Bm = next_goal.clone().requires_grad_(keep)
+        else:
+            y = fo.backward_map_raw(bp, next_goal)
+            Bm = math.sqrt(d) * F.normalize(y, dim=1) if cfg.norm_z else y * 1.0
         if keep:
-            for x in (F1, F2, Bm, y):
+            for x in (F1, F2) + (() if cfg.debug else (Bm, y)):
                 x.retain_grad()
         L = fo.fb_loss_terms(F1, F2, Bm, tF1, tF2, tB, discount, 0.0)      # fb_loss = offdiag + diag first (:317) ...
         fb_loss = L["fb_offdiag"] + L["fb_diag"]

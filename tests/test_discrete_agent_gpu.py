@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 DKEYS = ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss", "orth_loss_offdiag")
 
 
-@pytest.mark.parametrize("name,goal_space", [("tiny_discrete_trace", "simplified_walker"), ("tiny_discrete_boltz_trace", None)])
+@pytest.mark.parametrize("name,goal_space", [("tiny_discrete_trace", "simplified_walker"), ("tiny_discrete_boltz_trace", None),
+                                             ("tiny_discrete_debug_trace", None)])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state (DiscreteFBAgent), runs one HIP update with the recorded draws and
     must land on the reference's next state; embeddings and gradients are compared with the oracle's autograd."""

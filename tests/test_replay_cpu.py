@@ -96,8 +96,8 @@ def test_agent_rejects_unsupported_flags_loudly():
     for flag in (dict(obs_type="pixels"), dict(debug=True, z_dim=4, future_ratio=0.5), dict(debug=True, z_dim=4, rand_weight=True)):
         with pytest.raises(NotImplementedError):
             FBHipAgent(**{**base, **flag})
-    with pytest.raises(NotImplementedError):
-        DiscreteFBHipAgent(**{**base, "debug": True, "z_dim": 4})
+    with pytest.raises(ValueError, match="must equal the goal dimension"):
+        DiscreteFBHipAgent(**{**base, "debug": True, "z_dim": 8, "preprocess": False})
     with pytest.raises(ValueError, match="must equal the goal dimension"):
         FBHipAgent(**{**base, "debug": True, "z_dim": 8})
     with pytest.raises(ValueError):
