@@ -284,8 +284,6 @@ class FBHipAgent:
         if self._identity_b:
             if goal_dim != cfg.z_dim:               # (the reference fails in update_fb: F [B, z_dim] x B(goal)^T [goal_dim, B])
                 raise ValueError(f"debug=True makes the backward map the identity: z_dim ({cfg.z_dim}) must equal the goal dimension ({goal_dim})")
-            if cfg.future_ratio > 0 or cfg.rand_weight:
-                raise NotImplementedError("FBHipAgent: debug=True is built for future_ratio = 0 and rand_weight = False")
         if cfg.feature_dim < self.obs_dim:
             logger.warning(f"feature_dim {cfg.feature_dim} should not be smaller that obs_dim {self.obs_dim}")
         if cfg.z_dim < goal_dim:

@@ -193,7 +193,11 @@ __global__ void __launch_bounds__(256) mix_z_kernel(const float* __restrict__ ga
         s += v[k] * v[k];
     }
     const float sc = sqrtf((float)d);
-    if (zunif == nullptr) {
+    // mix_proj < 0 (IdentityMap backward nets, cfg.debug): hindsight rows are the RAW goal -- no BackwardMap projection exists
+    const bool fut_raw = mix_proj < 0;
+    if (mix_proj < 0) mix_proj = -mix_proj;
+    if (fut && fut_raw) {
+    } else if (zunif == nullptr) {
         // norm_z: gaussian and hindsight rows are projected once, mixed rows twice (BackwardMap's own + fb_ddpg.py:483-484);
         // with rand_weight the mixed row is a weighted sum of already projected rows and gets the :483 projection only
 #pragma unroll

@@ -556,7 +556,6 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         // every NULL field of ``inj`` is drawn on device; injected fields (parity mode / externally sampled
         // batches) overwrite the draw
         const bool hindsight = hp.future_ratio > 0.f;
-        if (d.backward_identity && (hindsight || hp.rand_weight)) { c->err = g_err = "fbhip: backward_identity (cfg.debug) is built for future_ratio = 0 and rand_weight = 0"; return FBHIP_E_INVALID; }
         if (hindsight && !(hp.future < 1.f)) { c->err = g_err = "fbhip: future_ratio > 0 needs a replay buffer with future < 1"; return FBHIP_E_INVALID; }
         const bool all_injected = inj && inj->ep_idx && inj->step_idx && inj->perm && inj->mix_uniform &&
                                   inj->z_gauss && inj->eps_next && inj->eps_actor &&
@@ -623,7 +622,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         if (gm.single) zx = ZPanels{{w.Xoa.p, w.Xnoa.p, w.Xopi.p}, {w.Xoa.ld, w.Xnoa.ld, w.Xopi.ld}};
         HIPCK(c, launch_mix_z(w.so.z_gauss, z, ymix, Lz, w.so.mix_uniform, hp.mix_ratio, w.z.p, Lz, w.Xoz.p, w.Xoz.ld,
                               w.Xnoz.p, w.Xnoz.ld, o, B, z, w.st, hindsight ? w.bsF.y.p : nullptr, w.so.future_uniform,
-                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, (randw || d.backward_identity) ? 1 : 2,
+                              hp.future_ratio, d.norm_z ? nullptr : w.so.z_uniform, d.backward_identity ? -1 : (randw ? 1 : 2),
                               zx, s));
         POST_END
     }

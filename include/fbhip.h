@@ -133,7 +133,7 @@ typedef struct fbhip_dims {
                                     * needs norm_z = 1, boltzmann = 0, discrete = 0.  The actor phase is FBDDPGAgent's. */
     int32_t backward_identity;     /* cfg.debug (fb_ddpg.py:128-130; default 0).  1: backward_net and backward_target_net are IdentityMap
                                     * (fb_modules.py:202-208): B(goal) = goal, unprojected whatever norm_z says, nothing to train;
-                                    * needs z_dim == goal_dim, sf = 0, hparams.future_ratio = 0 and rand_weight = 0 (DiscreteFBAgent has the same switch, discrete_fb.py:134-136).  The
+                                    * needs z_dim == goal_dim and sf = 0 (DiscreteFBAgent has the same switch, discrete_fb.py:134-136).  The
                                     * NET_BACKWARD block keeps its place in the flat buffers (unused, its gradients stay zero). */
 } fbhip_dims;
 

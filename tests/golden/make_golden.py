@@ -286,6 +286,10 @@ def debug_fixture(R):
     trace_fixture(R, "tiny_debug_trace", tiny_cfg(z_dim=5, debug=True), seed=161, n_eps=6, T=12, n_steps=4)
     trace_fixture(R, "tiny_debug_goal_trace", tiny_cfg(goal_dim=3, use_goal=True, z_dim=3, debug=True, norm_z=False, q_loss=True, batch_size=24),
                   seed=162, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)
+    # hindsight rows are then the raw future goal (fb_ddpg.py:491), rand_weight mixes raw goals (:475-482)
+    trace_fixture(R, "tiny_debug_future_randw_trace", tiny_cfg(goal_dim=3, use_goal=True, z_dim=3, debug=True, future=0.7, future_ratio=0.5,
+                                                               rand_weight=True, mix_ratio=0.6, batch_size=24),
+                  seed=164, n_eps=7, T=11, n_steps=4, goal_space="simplified_walker", variable_len=True)
     # DiscreteFBAgent has the same switch (discrete_fb.py:134-136)
     trace_fixture(R, "tiny_discrete_debug_trace", tiny_cfg(action_dim=4, preprocess=False, z_dim=5, debug=True, q_loss=True, batch_size=24),
                   seed=163, n_eps=6, T=12, n_steps=4, discrete=True)

@@ -37,7 +37,7 @@ def _replay(name, full_state):
 @pytest.mark.parametrize("name", ["tiny_trace", "tiny_goal_trace", "tiny_future_trace", "tiny_future_goal_trace", "tiny_nonorm_trace",
                                   "tiny_randw_trace", "tiny_randw_nonorm_trace", "tiny_trunk_trace",
                                   "tiny_single_trunk_trace", "tiny_single_trunk_goal_trace",
-                                  "tiny_boltzmann_trace", "tiny_boltzmann_goal_trace", "tiny_debug_trace", "tiny_debug_goal_trace",
+                                  "tiny_boltzmann_trace", "tiny_boltzmann_goal_trace", "tiny_debug_trace", "tiny_debug_goal_trace", "tiny_debug_future_randw_trace",
                                   "tiny_discrete_trace", "tiny_discrete_boltz_trace", "tiny_discrete_debug_trace"])
 def test_tiny_traces_full_state(name):
     """Every parameter / target / Adam tensor after every step, tiny dims (incl. goal_space, q_loss,

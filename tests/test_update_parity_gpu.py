@@ -44,7 +44,8 @@ def _param_close(got, ref, lr, name, max_step=0.5, one_in=1000):
                                              ("tiny_single_trunk_goal_trace", "simplified_walker"),
                                              ("tiny_boltzmann_trace", None),
                                              ("tiny_boltzmann_goal_trace", "simplified_walker"),
-                                             ("tiny_debug_trace", None), ("tiny_debug_goal_trace", "simplified_walker")])
+                                             ("tiny_debug_trace", None), ("tiny_debug_goal_trace", "simplified_walker"),
+                                             ("tiny_debug_future_randw_trace", "simplified_walker")])
 def test_teacher_forced_against_reference_trace(name, goal_space):
     """Each step starts from the REFERENCE's recorded state, runs one HIP update with the recorded draws and must
     land on the reference's next state; gradients are compared with the oracle's autograd on the same step."""
@@ -884,11 +885,10 @@ def test_random_configurations_one_update_against_the_oracle(seed):
 
 @pytest.mark.parametrize("seed", list(range(400, 424)))
 def test_random_debug_configurations_one_update_against_the_oracle(seed):
-    """The same sweep with cfg.debug (IdentityMap backward nets, fb_ddpg.py:128-130): z_dim follows the goal dimension, hindsight
-    replay and rand_weight off (not built for it); q_loss then inverts the covariance of the raw goals."""
+    """The same sweep with cfg.debug (IdentityMap backward nets, fb_ddpg.py:128-130): z_dim follows the goal dimension; q_loss then
+    inverts the covariance of the raw goals, hindsight rows are raw future goals, rand_weight mixes raw goals."""
     cfg, goal_space = _random_case(seed)
-    cfg = dataclasses.replace(cfg, debug=True, z_dim=cfg.goal_dim, rand_weight=False, future_ratio=0.0, future=1.0,
-                              batch_size=max(cfg.batch_size, 3 * cfg.goal_dim))
+    cfg = dataclasses.replace(cfg, debug=True, z_dim=cfg.goal_dim, batch_size=max(cfg.batch_size, 3 * cfg.goal_dim))
     _one_random_update(cfg, goal_space, seed)
 
 
