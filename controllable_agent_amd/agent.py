@@ -746,9 +746,15 @@ class FBHipAgent:
         key = (n_steps, bytes(hp), os.environ.get("FBHIP_DP_SIDE_STREAM", "1"))
         g = cache.get(key)
         if g is None:
-            # (the communicator exists by now: _verify_replicas() has issued an eager collective on this device)
+            # (the communicator exists by now: _verify_replicas() has issued an eager collective on this device; the collectives
+            # of the schedule, at their sizes, are run once eagerly first -- connection set-up cannot happen inside a capture)
             cur = torch.cuda.current_stream(self._device)
             cap = self._stream if cur.cuda_stream == 0 else cur
+            if live and not getattr(self, "_dp_collectives_warm", False):
+                from .distributed import warm_up_collectives
+                with torch.cuda.stream(cap):
+                    warm_up_collectives(self._fb_grads, self._actor_grads, self._early_grad_range())
+                self._dp_collectives_warm = True
             g = torch.cuda.CUDAGraph()
             try:
                 # (thread_local: c10d's watchdog thread polls its events with cudaEventQuery while we capture; in the default
