@@ -5,8 +5,6 @@ C ABI (include/fbhip.h) and launches on torch's current stream.  No arithmetic h
 """
 from __future__ import annotations
 
-import ctypes as C
-import math
 import typing as tp
 
 import torch
