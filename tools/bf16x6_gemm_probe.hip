@@ -32,15 +32,16 @@ __global__ void split3(const float* __restrict__ x, __bf16* __restrict__ p, size
     }
 }
 
-constexpr int BK = 16, RS = 24;          // 16 k per chunk; LDS row stride in bf16 (48 bytes)
-
-template <int WT>
+// BK k per chunk (16 or 32), LDS row stride BK + 8 bf16 (48 / 80 bytes: ds_read_b128 conflict-free); DB: two LDS stages and one
+// barrier per chunk, else one stage, the next chunk waits in registers, two barriers per chunk
+template <int WT, int BK, bool DB>
 __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp,
                                                     float* __restrict__ C, int M, int N, int K) {
     constexpr int ROWS = 64 * WT;                         // tile rows of either operand
+    constexpr int RS = BK + 8, UPR = BK / 8;              // row stride (bf16), 16-byte units per row
     constexpr int PLANE = ROWS * RS;                      // bf16 per staged plane
     constexpr int STAGE = 6 * PLANE;                      // A hi/mid/lo, B hi/mid/lo
-    constexpr int U = 6 * ROWS * 2 / 256;                 // 16-byte units per thread per chunk
+    constexpr int U = 6 * ROWS * UPR / 256;               // 16-byte units per thread per chunk
     extern __shared__ __attribute__((aligned(16))) __bf16 smem[];      // 2 * STAGE
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int q = tid + 256 * i;
-        const int po = q / (ROWS * 2), r = (q % (ROWS * 2)) >> 1, half = q & 1;
+        const int po = q / (ROWS * UPR), r = (q % (ROWS * UPR)) / UPR, half = q % UPR;
         const int pl = po % 3;
         src[i] = po < 3 ? Ap + pl * planeA + (size_t)(row0 + r) * K + half * 8 : Bp + pl * planeB + (size_t)(col0 + r) * K + half * 8;
         dst[i] = po * PLANE + r * RS + half * 8;
@@ -75,17 +76,19 @@ __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap
     for (int i = 0; i < U; ++i) *reinterpret_cast<uint4*>(smem + dst[i]) = regs[i];
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const __bf16* st = smem + (c & 1) * STAGE;
+        const __bf16* st = smem + (DB ? (c & 1) * STAGE : 0);
         const int cn = c + 1 < nchunks ? c + 1 : c;              // (branch-free: the last iteration re-loads its own chunk)
 #pragma unroll
         for (int i = 0; i < U; ++i) regs[i] = *reinterpret_cast<const uint4*>(src[i] + (size_t)cn * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 a[3][WT], b[3][WT];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int i = 0; i < WT; ++i) {
-                a[p][i] = *reinterpret_cast<const bf16x8*>(st + p * PLANE + (wm * 32 * WT + i * 32 + l31) * RS + kh * 8);
-                b[p][i] = *reinterpret_cast<const bf16x8*>(st + (3 + p) * PLANE + (wn * 32 * WT + i * 32 + l31) * RS + kh * 8);
+                a[p][i] = *reinterpret_cast<const bf16x8*>(st + p * PLANE + (wm * 32 * WT + i * 32 + l31) * RS + ks * 16 + kh * 8);
+                b[p][i] = *reinterpret_cast<const bf16x8*>(st + (3 + p) * PLANE + (wn * 32 * WT + i * 32 + l31) * RS + ks * 16 + kh * 8);
             }
         // small terms first: mid.mid, hi.lo, lo.hi, hi.mid, mid.hi, hi.hi
 #define TERM(pa, pb)                                                                                              \
@@ -94,7 +97,9 @@ __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[pb][j], acc[i][j], 0, 0, 0);
         TERM(1, 1) TERM(0, 2) TERM(2, 0) TERM(0, 1) TERM(1, 0) TERM(0, 0)
 #undef TERM
-        __bf16* nx = smem + ((c + 1) & 1) * STAGE;
+        }
+        __bf16* nx = smem + (DB ? ((c + 1) & 1) * STAGE : 0);
+        if (!DB) __syncthreads();                                // every wave is done reading the only stage
 #pragma unroll
         for (int i = 0; i < U; ++i) *reinterpret_cast<uint4*>(nx + dst[i]) = regs[i];
         __syncthreads();
@@ -111,16 +116,16 @@ __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap
             }
 }
 
-template <int WT>
+template <int WT, int BK, bool DB>
 static double run(const __bf16* Ap, const __bf16* Bp, float* C, int M, int N, int K, int iters) {
     constexpr int ROWS = 64 * WT;
-    const size_t lds = (size_t)2 * 6 * ROWS * RS * sizeof(__bf16);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x6<WT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = (size_t)(DB ? 2 : 1) * 6 * ROWS * (BK + 8) * sizeof(__bf16);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x6<WT, BK, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (M / ROWS) * (N / ROWS);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_bf16x6<WT>, dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_bf16x6<WT, BK, DB>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm_bf16x6<WT>, dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_bf16x6<WT, BK, DB>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms * 1e3 / iters;
@@ -147,21 +152,25 @@ int main() {
         hipLaunchKernelGGL(split3, dim3(1024), dim3(256), 0, 0, dB, pB, hB.size());
         CK(hipDeviceSynchronize());
         const double flop = 2.0 * M * N * K;
-        for (int wt = 1; wt <= 2; ++wt) {
+        struct V { int wt, bk, db; } vs[] = {{1, 16, 1}, {2, 16, 1}, {1, 32, 1}, {1, 32, 0}, {1, 64, 1}, {1, 64, 0}, {2, 32, 1}, {2, 64, 0}};
+        for (auto& v : vs) {
             CK(hipMemset(dC, 0, (size_t)M * N * 4));
             const int iters = K >= 4096 ? 5 : 20;
-            const double us = wt == 1 ? run<1>(pA, pB, dC, M, N, K, iters) : run<2>(pA, pB, dC, M, N, K, iters);
+            double us = 0;
+#define V_(W, Bk, D) if (v.wt == W && v.bk == Bk && v.db == D) us = run<W, Bk, (D != 0)>(pA, pB, dC, M, N, K, iters);
+            V_(1, 16, 1) V_(2, 16, 1) V_(1, 32, 1) V_(1, 32, 0) V_(1, 64, 1) V_(1, 64, 0) V_(2, 32, 1) V_(2, 64, 0)
+#undef V_
             std::vector<float> hC((size_t)M * N);
             CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
             double num = 0, den = 0, num32 = 0;
-            for (int t = 0; t < 400; ++t) {                       // 400 sampled entries against fp64 (and a plain fp32 dot product)
+            for (int t = 0; t < 200; ++t) {                       // sampled entries against fp64 (and a plain fp32 dot product)
                 const int r = rand() % M, c = rand() % N;
                 double ref = 0; float f32 = 0.f;
                 for (int k = 0; k < K; ++k) { ref += (double)hA[(size_t)r * K + k] * hB[(size_t)c * K + k]; f32 += hA[(size_t)r * K + k] * hB[(size_t)c * K + k]; }
                 num += (hC[(size_t)r * N + c] - ref) * (hC[(size_t)r * N + c] - ref); den += ref * ref; num32 += (f32 - ref) * (f32 - ref);
             }
-            printf("%5d x %5d x %5d  wave tile %3d^2 (%4d workgroups): %8.1f us  %6.1f TFLOP/s fp32-equivalent   rel L2 err %.2e (serial fp32 dot: %.2e)   [split pass of A: %.1f us]\n",
-                   M, N, K, 32 * wt, (M / (64 * wt)) * (N / (64 * wt)), us, flop / us / 1e6, sqrt(num / den), sqrt(num32 / den), ms_split * 1e3 / 10);
+            printf("%5d x %5d x %5d  wave tile %3d^2, K chunk %2d, %d LDS stage(s) (%4d workgroups): %8.1f us  %6.1f TFLOP/s fp32-equivalent   rel L2 err %.2e (serial fp32 dot: %.2e)   [split pass of A: %.1f us]\n",
+                   M, N, K, 32 * v.wt, v.bk, v.db ? 2 : 1, (M / (64 * v.wt)) * (N / (64 * v.wt)), us, flop / us / 1e6, sqrt(num / den), sqrt(num32 / den), ms_split * 1e3 / 10);
         }
         hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB);
     }
