@@ -116,6 +116,84 @@ __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap
             }
 }
 
+// The same product from fp32 operands, split INSIDE the kernel while staging (64x64 tiles, K chunks of 32, two LDS stages):
+// x_hi = x & 0xffff0000, r = x - x_hi, x_mid = r & 0xffff0000, x_lo = r - x_mid (exact: 8 + 8 + 8 mantissa bits), packed in pairs.
+__device__ __forceinline__ void split_store(const float4 v, __bf16* dst_hi, int plane_stride) {
+    unsigned hi[4], mid[4], lo[4];
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned xb = __float_as_uint(x[i]);
+        hi[i] = xb & 0xffff0000u;
+        const float r1 = x[i] - __uint_as_float(hi[i]);
+        mid[i] = __float_as_uint(r1) & 0xffff0000u;
+        lo[i] = __float_as_uint(r1 - __uint_as_float(mid[i]));
+    }
+    uint2 ph, pm, pl;
+    ph.x = (hi[0] >> 16) | hi[1]; ph.y = (hi[2] >> 16) | hi[3];
+    pm.x = (mid[0] >> 16) | mid[1]; pm.y = (mid[2] >> 16) | mid[3];
+    pl.x = (lo[0] >> 16) | (lo[1] & 0xffff0000u); pl.y = (lo[2] >> 16) | (lo[3] & 0xffff0000u);
+    *reinterpret_cast<uint2*>(dst_hi) = ph;
+    *reinterpret_cast<uint2*>(dst_hi + plane_stride) = pm;
+    *reinterpret_cast<uint2*>(dst_hi + 2 * plane_stride) = pl;
+}
+
+__global__ void __launch_bounds__(256) gemm_bf16x6_insplit(const float* __restrict__ A, const float* __restrict__ B,
+                                                           float* __restrict__ C, int M, int N, int K) {
+    constexpr int ROWS = 64, BK = 32, RS = BK + 8, PLANE = ROWS * RS, STAGE = 6 * PLANE;
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int tiles_n = N / ROWS;
+    const int row0 = (blockIdx.x / tiles_n) * ROWS, col0 = (blockIdx.x % tiles_n) * ROWS;
+    // 4 float4 per thread per chunk: A rows tid/8 and 32 + tid/8, B the same; quad tid % 8
+    const int r = tid >> 3, q = tid & 7;
+    const float* srcA0 = A + (size_t)(row0 + r) * K + 4 * q;
+    const float* srcA1 = A + (size_t)(row0 + 32 + r) * K + 4 * q;
+    const float* srcB0 = B + (size_t)(col0 + r) * K + 4 * q;
+    const float* srcB1 = B + (size_t)(col0 + 32 + r) * K + 4 * q;
+    const int dA0 = r * RS + 4 * q, dA1 = (32 + r) * RS + 4 * q, dB0 = 3 * PLANE + dA0, dB1 = 3 * PLANE + dA1;
+    floatx16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float4 ra0 = *reinterpret_cast<const float4*>(srcA0), ra1 = *reinterpret_cast<const float4*>(srcA1);
+    float4 rb0 = *reinterpret_cast<const float4*>(srcB0), rb1 = *reinterpret_cast<const float4*>(srcB1);
+    split_store(ra0, smem + dA0, PLANE); split_store(ra1, smem + dA1, PLANE);
+    split_store(rb0, smem + dB0, PLANE); split_store(rb1, smem + dB1, PLANE);
+    __syncthreads();
+    const int nchunks = K / BK;
+    for (int c = 0; c < nchunks; ++c) {
+        const __bf16* st = smem + (c & 1) * STAGE;
+        const int cn = c + 1 < nchunks ? c + 1 : c;
+        ra0 = *reinterpret_cast<const float4*>(srcA0 + (size_t)cn * BK); ra1 = *reinterpret_cast<const float4*>(srcA1 + (size_t)cn * BK);
+        rb0 = *reinterpret_cast<const float4*>(srcB0 + (size_t)cn * BK); rb1 = *reinterpret_cast<const float4*>(srcB1 + (size_t)cn * BK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[3], b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[p] = *reinterpret_cast<const bf16x8*>(st + p * PLANE + (wm * 32 + l31) * RS + ks * 16 + kh * 8);
+                b[p] = *reinterpret_cast<const bf16x8*>(st + (3 + p) * PLANE + (wn * 32 + l31) * RS + ks * 16 + kh * 8);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+        }
+        __bf16* nx = smem + ((c + 1) & 1) * STAGE;
+        split_store(ra0, nx + dA0, PLANE); split_store(ra1, nx + dA1, PLANE);
+        split_store(rb0, nx + dB0, PLANE); split_store(rb1, nx + dB1, PLANE);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rr = row0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        C[(size_t)rr * N + col0 + wn * 32 + l31] = acc[e];
+    }
+}
+
 template <int WT, int BK, bool DB>
 static double run(const __bf16* Ap, const __bf16* Bp, float* C, int M, int N, int K, int iters) {
     constexpr int ROWS = 64 * WT;
@@ -171,6 +249,29 @@ int main() {
             }
             printf("%5d x %5d x %5d  wave tile %3d^2, K chunk %2d, %d LDS stage(s) (%4d workgroups): %8.1f us  %6.1f TFLOP/s fp32-equivalent   rel L2 err %.2e (serial fp32 dot: %.2e)   [split pass of A: %.1f us]\n",
                    M, N, K, 32 * v.wt, v.bk, v.db ? 2 : 1, (M / (64 * v.wt)) * (N / (64 * v.wt)), us, flop / us / 1e6, sqrt(num / den), sqrt(num32 / den), ms_split * 1e3 / 10);
+        }
+        {
+            constexpr size_t lds = (size_t)2 * 6 * 64 * 40 * sizeof(__bf16);
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x6_insplit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CK(hipMemset(dC, 0, (size_t)M * N * 4));
+            const int grid = (M / 64) * (N / 64), iters = K >= 4096 ? 5 : 20;
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_bf16x6_insplit, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K);
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm_bf16x6_insplit, dim3(grid), dim3(256), lds, 0, dA, dB, dC, M, N, K);
+            CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / iters;
+            std::vector<float> hC((size_t)M * N);
+            CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+            double num = 0, den = 0;
+            for (int t = 0; t < 200; ++t) {
+                const int r = rand() % M, c = rand() % N;
+                double ref = 0;
+                for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)r * K + k] * hB[(size_t)c * K + k];
+                num += (hC[(size_t)r * N + c] - ref) * (hC[(size_t)r * N + c] - ref); den += ref * ref;
+            }
+            printf("%5d x %5d x %5d  SPLIT IN THE KERNEL from fp32 operands, wave tile 32^2, K chunk 32, 2 LDS stages (%4d workgroups): %8.1f us  %6.1f TFLOP/s fp32-equivalent   rel L2 err %.2e\n",
+                   M, N, K, grid, us, flop / us / 1e6, sqrt(num / den));
         }
         hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB);
     }
