@@ -36,7 +36,7 @@ __global__ void split3(const float* __restrict__ x, __bf16* __restrict__ p, size
 // barrier per chunk, else one stage, the next chunk waits in registers, two barriers per chunk
 template <int WT, int BK, bool DB>
 __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap, const __bf16* __restrict__ Bp,
-                                                    float* __restrict__ C, int M, int N, int K) {
+                                                    float* __restrict__ C, int M, int N, int K, int kper) {
     constexpr int ROWS = 64 * WT;                         // tile rows of either operand
     constexpr int RS = BK + 8, UPR = BK / 8;              // row stride (bf16), 16-byte units per row
     constexpr int PLANE = ROWS * RS;                      // bf16 per staged plane
@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap
         const int q = tid + 256 * i;
         const int po = q / (ROWS * UPR), r = (q % (ROWS * UPR)) / UPR, half = q % UPR;
         const int pl = po % 3;
-        src[i] = po < 3 ? Ap + pl * planeA + (size_t)(row0 + r) * K + half * 8 : Bp + pl * planeB + (size_t)(col0 + r) * K + half * 8;
+        src[i] = (po < 3 ? Ap + pl * planeA + (size_t)(row0 + r) * K + half * 8 : Bp + pl * planeB + (size_t)(col0 + r) * K + half * 8) +
+                 (size_t)blockIdx.y * kper;              // grid-level K slices: slice y contracts k in [y kper, (y + 1) kper)
         dst[i] = po * PLANE + r * RS + half * 8;
     }
     floatx16 acc[WT][WT];
@@ -69,7 +70,8 @@ __global__ void __launch_bounds__(256) gemm_bf16x6(const __bf16* __restrict__ Ap
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     uint4 regs[U];
-    const int nchunks = K / BK;
+    const int nchunks = kper / BK;
+    C += (size_t)blockIdx.y * M * N;                      // raw partial tiles, folded by reduce_slices
 #pragma unroll
     for (int i = 0; i < U; ++i) regs[i] = *reinterpret_cast<const uint4*>(src[i]);
 #pragma unroll
@@ -194,16 +196,28 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_insplit(const float* __restri
     }
 }
 
+__global__ void reduce_slices(const float4* __restrict__ part, float4* __restrict__ out, size_t n4, int S) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 a = part[i];
+        for (int s = 1; s < S; ++s) { const float4 b = part[(size_t)s * n4 + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        out[i] = a;
+    }
+}
+
 template <int WT, int BK, bool DB>
-static double run(const __bf16* Ap, const __bf16* Bp, float* C, int M, int N, int K, int iters) {
+static double run(const __bf16* Ap, const __bf16* Bp, float* C, int M, int N, int K, int iters, int S = 1, float* Cpart = nullptr) {
     constexpr int ROWS = 64 * WT;
     const size_t lds = (size_t)(DB ? 2 : 1) * 6 * ROWS * (BK + 8) * sizeof(__bf16);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x6<WT, BK, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = (M / ROWS) * (N / ROWS);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((gemm_bf16x6<WT, BK, DB>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    auto go = [&]() {
+        hipLaunchKernelGGL((gemm_bf16x6<WT, BK, DB>), dim3(grid, S), dim3(256), lds, 0, Ap, Bp, S > 1 ? Cpart : C, M, N, K, K / S);
+        if (S > 1) hipLaunchKernelGGL(reduce_slices, dim3(512), dim3(256), 0, 0, (const float4*)Cpart, (float4*)C, (size_t)M * N / 4, S);
+    };
+    for (int i = 0; i < 3; ++i) go();
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm_bf16x6<WT, BK, DB>), dim3(grid), dim3(256), lds, 0, Ap, Bp, C, M, N, K);
+    for (int i = 0; i < iters; ++i) go();
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms * 1e3 / iters;
@@ -230,12 +244,15 @@ int main() {
         hipLaunchKernelGGL(split3, dim3(1024), dim3(256), 0, 0, dB, pB, hB.size());
         CK(hipDeviceSynchronize());
         const double flop = 2.0 * M * N * K;
-        struct V { int wt, bk, db; } vs[] = {{1, 16, 1}, {2, 16, 1}, {1, 32, 1}, {1, 32, 0}, {1, 64, 1}, {1, 64, 0}, {2, 32, 1}, {2, 64, 0}};
+        float* dPart; CK(hipMalloc(&dPart, (size_t)8 * M * N * 4));
+        struct V { int wt, bk, db, S; } vs[] = {{1, 16, 1, 1}, {2, 16, 1, 1}, {1, 32, 1, 1}, {1, 32, 0, 1}, {1, 64, 1, 1}, {1, 64, 0, 1}, {2, 32, 1, 1}, {2, 64, 0, 1},
+                                              {2, 32, 1, 2}, {2, 32, 1, 4}, {2, 32, 1, 8}, {1, 32, 1, 2}};
         for (auto& v : vs) {
             CK(hipMemset(dC, 0, (size_t)M * N * 4));
             const int iters = K >= 4096 ? 5 : 20;
             double us = 0;
-#define V_(W, Bk, D) if (v.wt == W && v.bk == Bk && v.db == D) us = run<W, Bk, (D != 0)>(pA, pB, dC, M, N, K, iters);
+            if (v.S > 1 && (M * (size_t)N > 2048u * 2048u)) continue;       // K slices: the step's sizes only
+#define V_(W, Bk, D) if (v.wt == W && v.bk == Bk && v.db == D) us = run<W, Bk, (D != 0)>(pA, pB, dC, M, N, K, iters, v.S, dPart);
             V_(1, 16, 1) V_(2, 16, 1) V_(1, 32, 1) V_(1, 32, 0) V_(1, 64, 1) V_(1, 64, 0) V_(2, 32, 1) V_(2, 64, 0)
 #undef V_
             std::vector<float> hC((size_t)M * N);
@@ -247,8 +264,8 @@ int main() {
                 for (int k = 0; k < K; ++k) { ref += (double)hA[(size_t)r * K + k] * hB[(size_t)c * K + k]; f32 += hA[(size_t)r * K + k] * hB[(size_t)c * K + k]; }
                 num += (hC[(size_t)r * N + c] - ref) * (hC[(size_t)r * N + c] - ref); den += ref * ref; num32 += (f32 - ref) * (f32 - ref);
             }
-            printf("%5d x %5d x %5d  wave tile %3d^2, K chunk %2d, %d LDS stage(s) (%4d workgroups): %8.1f us  %6.1f TFLOP/s fp32-equivalent   rel L2 err %.2e (serial fp32 dot: %.2e)   [split pass of A: %.1f us]\n",
-                   M, N, K, 32 * v.wt, v.bk, v.db ? 2 : 1, (M / (64 * v.wt)) * (N / (64 * v.wt)), us, flop / us / 1e6, sqrt(num / den), sqrt(num32 / den), ms_split * 1e3 / 10);
+            printf("%5d x %5d x %5d  wave tile %3d^2, K chunk %2d, %d LDS stage(s), %d K slice(s) (%4d workgroups): %8.1f us  %6.1f TFLOP/s fp32-equivalent   rel L2 err %.2e (serial fp32 dot: %.2e)   [split pass of A: %.1f us]\n",
+                   M, N, K, 32 * v.wt, v.bk, v.db ? 2 : 1, v.S, v.S * (M / (64 * v.wt)) * (N / (64 * v.wt)), us, flop / us / 1e6, sqrt(num / den), sqrt(num32 / den), ms_split * 1e3 / 10);
         }
         {
             constexpr size_t lds = (size_t)2 * 6 * 64 * 40 * sizeof(__bf16);
@@ -273,7 +290,7 @@ int main() {
             printf("%5d x %5d x %5d  SPLIT IN THE KERNEL from fp32 operands, wave tile 32^2, K chunk 32, 2 LDS stages (%4d workgroups): %8.1f us  %6.1f TFLOP/s fp32-equivalent   rel L2 err %.2e\n",
                    M, N, K, grid, us, flop / us / 1e6, sqrt(num / den));
         }
-        hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB);
+        hipFree(dPart); hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB);
     }
     return 0;
 }
