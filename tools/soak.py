@@ -9,6 +9,7 @@ import bench
 from controllable_agent_amd.agent import FBHipAgent
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+torch.manual_seed(0)            # (the agent's Philox key and initial weights come from torch's seed: fixed, so checksums compare across runs)
 W = bench.WALKER
 agent = FBHipAgent(obs_type="states", obs_shape=(W["obs_dim"],), action_shape=(W["action_dim"],), device="cuda",
                    num_expl_steps=0, update_every_steps=1, batch_size=W["batch_size"], z_dim=W["z_dim"], use_tb=False,
