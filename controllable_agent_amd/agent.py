@@ -1120,9 +1120,11 @@ class FBHipAgent:
             raise ValueError("update_many_injected: single rank and a constant stddev over the steps only")
         dev = self._device
         self._bind_replay(replay_loader)
-        ints = ["ep_idx", "step_idx", "perm"] + (["future_idx"] if self.cfg.future_ratio > 0 else [])
-        flts = ["z_gauss", "mix_uniform", "eps_next", "eps_actor"] + (["rand_weight", "rand_weight_u"] if self.cfg.rand_weight else []) + \
-               ([] if self.cfg.norm_z else ["z_uniform"]) + (["future_uniform"] if self.cfg.future_ratio > 0 else [])
+        # (SFAgentConfig has no future_ratio / rand_weight / norm_z; its contrastive learners read the hindsight goal, sf.py:125, 167)
+        hindsight = getattr(self.cfg, "future_ratio", 0.0) > 0
+        ints = ["ep_idx", "step_idx", "perm"] + (["future_idx"] if hindsight or self._sf_mode in (10, 11) else [])
+        flts = ["z_gauss", "mix_uniform", "eps_next", "eps_actor"] + (["rand_weight", "rand_weight_u"] if getattr(self.cfg, "rand_weight", False) else []) + \
+               ([] if getattr(self.cfg, "norm_z", True) else ["z_uniform"]) + (["future_uniform"] if hindsight else [])
         keep: tp.List[torch.Tensor] = []
         injs = (Inject * n)()
         for i, draws in enumerate(draws_per_step):

@@ -309,6 +309,26 @@ def test_sf_pipelined_update_many_equals_single_updates(name):
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["tiny_sf_mix_lap_trace", "tiny_sf_contrastive_goal_trace"])
+def test_sf_update_many_injected_equals_injected_single_updates(name):
+    """the parity entry point of the pipelined graph (fbhip_update_many_injected) with an SF agent: the recorded draws of four steps in
+    one call against four update_injected calls -- bit for bit at these dimensions (mix_ratio > 0; the contrastive hindsight goal)."""
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs(name)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    a1 = make_sf_agent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"], meta["goal_space"])
+    a2 = pickle.loads(pickle.dumps(a1))
+    draws = [H.draws_dict(fo.Draws(**{f: z[f"draws/{s}/{f}"] for f in fo.Draws.__dataclass_fields__ if f"draws/{s}/{f}" in z.files}))
+             for s in range(meta["n_steps"])]
+    m1 = a1.update_many_injected(rb, 0, draws)
+    for s, d in enumerate(draws):
+        m2 = a2.update_injected(rb, s, d)
+    for k in m2:
+        assert m1[k] == pytest.approx(m2[k], rel=1e-6, abs=1e-7), k
+    s1, s2 = get_sf_state(a1), get_sf_state(a2)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+
+
 def test_sf_contrastive_needs_hindsight_goals():
     """the contrastive learner reads batch.future_goal (sf.py:125): a buffer with future = 1 has none -- loud error, no update"""
     meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_contrastive_trace")
