@@ -1028,13 +1028,14 @@ class FBHipAgent:
         f = lambda x: torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32,
                                       device=dev).reshape(Bn, -1)
         obs, nobs, act, disc = f(batch.obs), f(batch.next_obs), f(batch.action), f(batch.discount)
-        hindsight = getattr(c, "future_ratio", 0.0) > 0
+        # (hindsight rows: FB's future_ratio > 0, fb_ddpg.py:487-491; SFAgent's contrastive learners read batch.future_goal, sf.py:125, 167)
+        hindsight = getattr(c, "future_ratio", 0.0) > 0 or self._sf_mode in (10, 11)
         # a one-transition-per-episode storage [B, 2 (+1), dim]: row 0 = (obs, goal), row 1 = (next_obs, action, ...),
         # row 2 = (future_obs, future_goal) when hindsight replay is on
         rows = lambda *xs: torch.stack(list(xs), 1).contiguous()
         if hindsight:
             if batch.future_obs is None or (c.goal_space is not None and batch.future_goal is None):
-                raise ValueError("future_ratio > 0 needs batch.future_obs / future_goal (sample from a buffer with future < 1)")
+                raise ValueError("future_ratio > 0 (and SFAgent's contrastive learners) need batch.future_obs / future_goal (sample from a buffer with future < 1)")
             storage = {"observation": rows(obs, nobs, f(batch.future_obs)), "action": rows(torch.zeros_like(act), act, torch.zeros_like(act)),
                        "discount": rows(torch.ones_like(disc), disc, torch.ones_like(disc))}
             if c.goal_space is not None:
