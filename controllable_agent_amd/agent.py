@@ -1532,7 +1532,8 @@ class SFHipAgent(FBHipAgent):
         meta["z"] = z.squeeze().numpy()
         return meta
 
-    def compute_z_correl(self, time_step: tp.Any, meta: MetaDict) -> float:
+    @property
+    def compute_z_correl(self) -> tp.Any:            # SFAgent has none (sf.py): hasattr() must say so (run_online asks)
         raise AttributeError("SFAgent has no compute_z_correl (sf.py)")
 
     def act(self, obs: tp.Any, meta: MetaDict, step: int, eval_mode: bool) -> np.ndarray:      # sf.py:594-609... the Actor path of FBDDPGAgent

@@ -348,6 +348,45 @@ def test_sf_external_batch_path_matches_device_path(name):
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
 
 
+@pytest.mark.parametrize("learner,kw", [("lap", dict(mix_ratio=0.5)), ("contrastivev2", dict(future=0.8)), ("identity", dict(z_dim=5, mix_ratio=0.3))])
+def test_sf_online_and_offline_loops(learner, kw):
+    """run_online (pretrain.py:559-659 counterpart: the ring fills through add(), act on the batch-1 fast path, no compute_z_correl
+    -- SFAgent has none and hasattr() must say so) and run_offline with an SF agent, end to end on tiny dims."""
+    from controllable_agent_amd.replay import DeviceReplayBuffer, TimeStep
+    from controllable_agent_amd.train_offline import run_offline
+    from controllable_agent_amd.train_online import run_online
+    cfg = fo.OracleConfig(**{**dict(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16, backward_hidden_dim=18,
+                                    batch_size=16, lr=1e-3, lr_coef=5.0, mix_ratio=0.0), **kw})
+    rng = np.random.default_rng(3)
+    shapes = so.net_shapes(cfg, learner)
+    agent = make_sf_agent(cfg, {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}, learner, True)
+    assert not hasattr(agent, "compute_z_correl")
+    agent.cfg.update_every_steps = 2
+
+    class Env:
+        T, t = 6, 0
+
+        def _ts(self, kind, action):
+            return TimeStep(step_type=kind, reward=0.5, discount=1.0, observation=rng.standard_normal(5).astype(np.float32),
+                            action=np.asarray(action, np.float32), physics=np.zeros(2, np.float32))
+
+        def reset(self):
+            self.t = 0
+            return self._ts(0, np.zeros(3))
+
+        def step(self, action):
+            assert action.shape == (3,) and np.all(np.abs(action) <= 1.0)
+            self.t += 1
+            return self._ts(2 if self.t == self.T else 1, action)
+
+    rb = DeviceReplayBuffer(max_episodes=4, discount=0.98, future=cfg.future, device="cuda")
+    st = run_online(agent, rb, Env(), num_train_frames=40, num_seed_frames=18)
+    assert (st.env_steps, st.episodes, st.updates) == (40, 6, 11) and agent.step_counts() == (11, 11)
+    run_offline(agent, rb, num_grad_steps=37, log_every_steps=10, steps_per_launch=8)
+    assert agent.step_counts() == (48, 48)
+    assert all(np.isfinite(v).all() for v in get_sf_state(agent).values())
+
+
 def test_sf_contrastive_needs_hindsight_goals():
     """the contrastive learner reads batch.future_goal (sf.py:125): a buffer with future = 1 has none -- loud error, no update"""
     meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_contrastive_trace")
