@@ -460,24 +460,36 @@ def test_dp_schedule_graph_captures_rccl_collectives_with_one_rank():
 
 
 # ------------------------------------------------------------------------------------------ the SF sibling, data parallel
-def _sf_inputs():
+def _sf_inputs(name="tiny_sf_svdp_trace"):
+    """(agent, replay, three steps of recorded draws, state reader) of a reference trace: an SFAgent one, or (tiny_debug_*) an
+    FBDDPGAgent one with the IdentityMap backward nets"""
     from tests.test_oracle_golden import sf_trace_inputs
-    from tests.test_sf_agent_gpu import make_sf_agent, _buffer
-    meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_svdp_trace")
-    agent = make_sf_agent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"], meta["goal_space"])
+    from tests.test_sf_agent_gpu import make_sf_agent, _buffer, get_sf_state
+    if name.startswith("tiny_sf_"):
+        meta, z, cfg, nets, storage, lengths = sf_trace_inputs(name)
+        agent = make_sf_agent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"], meta["goal_space"])
+        reader = get_sf_state
+    else:
+        meta = H.load_meta(name)
+        cfg = H.cfg_from_meta(meta)
+        z = np.load(H.GOLDEN / f"{name}.npz")
+        storage, lengths = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("storage/")}, z["lengths"]
+        nets = {n: {k.split("/", 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"init/{n}/")}
+                for n in ("actor", "forward_net", "backward_net")}
+        agent = H.make_hip_agent(cfg, nets, meta["goal_space"])
+        reader = H.get_agent_state
     rb = _buffer(storage, lengths, cfg.discount, cfg.future)              # NOT sharded: every rank sees the same batches
     draws = [H.draws_dict(fo.Draws(**{f: z[f"draws/{s}/{f}"] for f in fo.Draws.__dataclass_fields__ if f"draws/{s}/{f}" in z.files}))
              for s in range(3)]
-    return agent, rb, draws
+    return agent, rb, draws, reader
 
 
-def _worker_sf(rank, port, out_q):
+def _worker_sf(rank, port, out_q, name):
     import torch.distributed as dist
-    from tests.test_sf_agent_gpu import get_sf_state
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
     torch.manual_seed(4321)
-    agent, rb, draws = _sf_inputs()
+    agent, rb, draws, get_sf_state = _sf_inputs(name)
     for s, d in enumerate(draws):
         agent.update_injected(rb, s, d)
     torch.cuda.synchronize()
@@ -489,17 +501,18 @@ def _worker_sf(rank, port, out_q):
     dist.destroy_process_group()
 
 
-def test_sf_agent_two_ranks_average_gradients():
-    """SFHipAgent under the data-parallel schedule (gradients | all-reduce | sf_opt + phi_opt step, actor gradient | all-reduce |
+@pytest.mark.parametrize("name", ["tiny_sf_svdp_trace", "tiny_sf_mix_lap_trace", "tiny_debug_trace", "tiny_debug_future_randw_trace"])
+def test_sf_agent_two_ranks_average_gradients(name):
+    """(also: SFAgent's z-mix, and FBDDPGAgent with the IdentityMap backward nets of cfg.debug, whose block of the bucket stays zero)
+    SFHipAgent under the data-parallel schedule (gradients | all-reduce | sf_opt + phi_opt step, actor gradient | all-reduce |
     actor step): two ranks fed IDENTICAL batches average two equal gradients -- (g + g) / 2 is exact in fp32 -- so both must land
     on the state of ONE process running the same three updates (to the fp32 summation order of the regrouped launches), and the
     replicas stay bit-identical, also through the device-drawn update_many that follows (same seed, unsharded buffer)."""
     import torch.multiprocessing as mp
-    from tests.test_sf_agent_gpu import get_sf_state
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = T._free_port()
-    procs = [ctx.Process(target=_worker_sf, args=(r, port, q)) for r in range(T.WORLD)]
+    procs = [ctx.Process(target=_worker_sf, args=(r, port, q, name)) for r in range(T.WORLD)]
     for p in procs:
         p.start()
     got = {r: (a3, fin, cnt) for r, a3, fin, cnt in (q.get(timeout=300) for _ in range(T.WORLD))}
@@ -510,7 +523,7 @@ def test_sf_agent_two_ranks_average_gradients():
     for which in (0, 1):
         for k in got[0][which]:
             np.testing.assert_array_equal(got[0][which][k], got[1][which][k], err_msg=k)
-    agent, rb, draws = _sf_inputs()
+    agent, rb, draws, get_sf_state = _sf_inputs(name)
     for s, d in enumerate(draws):
         agent.update_injected(rb, s, d)
     ref = get_sf_state(agent)
