@@ -1,0 +1,129 @@
+"""Every public method of the three agents (FBHipAgent, DiscreteFBHipAgent, SFHipAgent) under every configuration switch / feature
+learner, once: no parity claims here (the trace and oracle suites make those) -- this is the "does any surface call raise" net that
+caught SFHipAgent.update_many_injected / update_from_batch / compute_z_correl in round 2.  Tiny dims, a few seconds in total."""
+import io
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import discrete_fb_oracle as do
+from oracle import fb_oracle as fo
+from oracle import sf_oracle as so
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+BATCH_KEYS = ("obs", "action", "reward", "next_obs", "discount", "goal", "next_goal", "future_obs", "future_goal")
+
+
+class _TS:
+    def __init__(self, obs, goal):
+        self.observation, self.goal = obs, goal
+
+
+def _surface(a, cfg, rb, rng):
+    g = cfg.goal_dim
+    a.train(False)
+    a.train(True)
+    m = a.init_meta()
+    o = rng.standard_normal(cfg.obs_dim).astype(np.float32)
+    a.act(o, m, 0, eval_mode=True)
+    a.act(o, m, 10 ** 6, eval_mode=False)
+    ts = _TS(o, rng.standard_normal(g).astype(np.float32))
+    a.update_meta(m, 0, ts)
+    a.update_meta(m, 1, ts)
+    assert a.get_goal_meta(rng.standard_normal(g).astype(np.float32))["z"].shape == (cfg.z_dim,)
+    if hasattr(a, "infer_meta"):
+        a.infer_meta(rb)
+    assert a.infer_meta_from_obs_and_rewards(torch.randn(40, g), torch.randn(40, 1))["z"].shape == (cfg.z_dim,)
+    if hasattr(a, "compute_z_correl"):
+        assert np.isfinite(a.compute_z_correl(ts, m))
+    assert tuple(a.sample_z(7).shape) == (7, cfg.z_dim)
+    for opt in (x for x in ("fb_opt", "actor_opt", "sf_opt", "phi_opt") if getattr(a, x, None) is not None):
+        getattr(a, opt).load_state_dict(getattr(a, opt).state_dict())
+    pickle.loads(pickle.dumps(a)).init_from(a)
+    f = io.BytesIO()
+    torch.save({"agent": a}, f)
+    f.seek(0)
+    torch.load(f, weights_only=False)
+    a.update(rb, 0)
+    a.update_many(rb, 1, 3)
+    a.cfg.use_tb = True
+    mm = a.update(rb, 4)
+    assert mm and all(np.isfinite(v) for v in mm.values()), mm
+    a.cfg.use_tb = False
+    assert a.step_counts()[0] == 5
+
+
+def _batch(storage, d, cfg):
+    from controllable_agent_amd.replay import EpisodeBatch
+    b = fo.gather_batch(storage, d.ep_idx, d.step_idx, cfg.discount, d.future_idx)
+    return EpisodeBatch(**{k: b[k] for k in BATCH_KEYS if k in b})
+
+
+FB_CASES = {"default": {}, "goal+q_loss": dict(goal=True, q_loss=True, batch_size=24), "boltzmann": dict(boltzmann=True),
+            "norm_z off+rand_weight": dict(norm_z=False, rand_weight=True), "hindsight": dict(future=0.7, future_ratio=0.4),
+            "add_trunk": dict(add_trunk=True), "preprocess off": dict(preprocess=False), "debug": dict(z_dim=5, debug=True),
+            "debug+goal+hindsight": dict(goal=True, z_dim=3, debug=True, future=0.7, future_ratio=0.4, batch_size=24)}
+
+
+@pytest.mark.parametrize("label", list(FB_CASES))
+def test_fb_agent_surface(label):
+    from tests.test_update_parity_gpu import _buffer
+    kw = dict(FB_CASES[label])
+    goal = kw.pop("goal", False)
+    rng = np.random.default_rng(11)
+    cfg = fo.OracleConfig(**{**dict(obs_dim=5, action_dim=3, goal_dim=3 if goal else 5, use_goal=goal, z_dim=8, hidden_dim=32, feature_dim=16,
+                                    backward_hidden_dim=18, batch_size=16, lr=1e-3), **kw})
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, cfg.obs_dim, cfg.action_dim, cfg.goal_dim if goal else None)
+    a = H.make_hip_agent(cfg, nets, "simplified_walker" if goal else None)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    _surface(a, cfg, rb, rng)
+    a.update_many_injected(rb, 5, [H.draws_dict(fo.make_draws(rng, cfg, 6, lengths)) for _ in range(3)])
+    d = fo.make_draws(rng, cfg, 6, lengths)
+    a.update_from_batch(_batch(storage, d, cfg), 8, draws=H.draws_dict(d))
+    assert a.step_counts() == (9, 9)
+
+
+DISCRETE_CASES = {"default": {}, "boltzmann+q_loss": dict(boltzmann=True, temp=0.7, q_loss=True, batch_size=32, z_dim=6, backward_hidden_dim=20),
+                  "debug": dict(z_dim=5, debug=True), "goal+hindsight": dict(goal_dim=3, use_goal=True, future=0.8, future_ratio=0.3)}
+
+
+@pytest.mark.parametrize("label", list(DISCRETE_CASES))
+def test_discrete_agent_surface(label):
+    from tests.test_update_parity_gpu import _buffer
+    rng = np.random.default_rng(12)
+    cfg = fo.OracleConfig(**{**dict(obs_dim=5, action_dim=4, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16, backward_hidden_dim=18,
+                                    batch_size=16, lr=1e-3, preprocess=False), **DISCRETE_CASES[label]})
+    nets = {n: fo.synthetic_params(rng, do.NET_SHAPES[n](cfg)) for n in do.NET_SHAPES}
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, 5, 4, cfg.goal_dim if cfg.use_goal else None)
+    do.synthetic_actions(rng, storage, 4)
+    a = H.make_hip_agent(cfg, nets, "simplified_walker" if cfg.use_goal else None, discrete=True)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    _surface(a, cfg, rb, rng)
+    d = fo.make_draws(rng, cfg, 6, lengths)
+    a.update_from_batch(_batch(storage, d, cfg), 5, draws=H.draws_dict(d))
+
+
+@pytest.mark.parametrize("goal", [False, True])
+@pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2",
+                                     "contrastive", "contrastivev2", "identity"])
+def test_sf_agent_surface(learner, goal):
+    from tests.test_sf_agent_gpu import _buffer, make_sf_agent
+    rng = np.random.default_rng(13)
+    z_dim = (3 if goal else 5) if learner == "identity" else 8
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=3 if goal else 5, use_goal=goal, z_dim=z_dim, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=16, lr=1e-3, lr_coef=5.0, mix_ratio=0.4,
+                          future=0.8 if learner.startswith("contrastive") else 1.0)
+    shapes = so.net_shapes(cfg, learner)
+    a = make_sf_agent(cfg, {n: fo.synthetic_params(rng, shapes[n]) for n in shapes}, learner, True, "simplified_walker" if goal else None)
+    storage, lengths = fo.synthetic_storage(rng, 6, 12, 5, 3, 3 if goal else None)
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    _surface(a, cfg, rb, rng)
+    a.precompute_cov(rb)
+    d = fo.make_draws(rng, cfg, 6, lengths)
+    a.update_from_batch(_batch(storage, d, cfg), 5, draws=H.draws_dict(d))
+    a.update_many_injected(rb, 6, [H.draws_dict(fo.make_draws(rng, cfg, 6, lengths)) for _ in range(2)])
+    assert a.step_counts() == (8, 8)
