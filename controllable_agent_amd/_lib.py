@@ -75,7 +75,6 @@ PROTOTYPES = {
     "fbhip_bind_buffers": (C.c_int, [_P] + [_P] * 9 + [_P, _Z]),
     "fbhip_replay_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I]),
     "fbhip_set_seed": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
-    "fbhip_set_precapture_hook": (C.c_int, [_P, C.c_void_p]),
     "fbhip_set_policy_squash": (C.c_int, [_P, _F, _F, _F]),
     "fbhip_set_step_counts": (C.c_int, [_P, _I, _I, _P]),
     "fbhip_get_step_counts": (C.c_int, [_P, C.POINTER(_I), C.POINTER(_I), _P]),

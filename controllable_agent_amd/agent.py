@@ -256,14 +256,11 @@ def _quiesce_collectives(device: tp.Any) -> None:
     """Before a stream capture in a process that holds an RCCL process group: let c10d's watchdog thread retire every finished
     collective first.  The watchdog polls the end event of each enqueued Work (every ~100 ms) until it has seen it complete; if
     such a poll lands while a capture is active in this process the HIP runtime answers hipErrorCapturedEvent, the watchdog
-    throws and the process aborts (seen on ROCm 7.0 / torch 2.10 in ~5 % of agent constructions under a live group, with the
-    schedule graph and with the host-issued schedule alike).  Captures happen a handful of times per run: the wait is free."""
+    throws and the process aborts (seen on ROCm 7.0 / torch 2.10 in ~7 % of agent constructions under a live group).  Called before
+    the torch-level capture of the data-parallel schedule; captures happen a handful of times per run: the wait is free."""
     import time
     torch.cuda.synchronize(device)
     time.sleep(float(os.environ.get("FBHIP_QUIESCE_S", "0.35")))
-
-
-_PRECAPTURE_T = C.CFUNCTYPE(None)
 
 
 class FBHipAgent:
@@ -312,15 +309,6 @@ class FBHipAgent:
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._allocate(self._reference_init())
         self.train()
-
-    def _on_precapture(self) -> None:
-        import torch.distributed as dist
-        try:
-            if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and \
-                    not torch.cuda.is_current_stream_capturing():
-                _quiesce_collectives(self._device)
-        except Exception:                        # noqa: BLE001 -- never throw across the C ABI
-            pass
 
     # ------------------------------------------------------------------ construction
     _sf_mode = 0                    # SFHipAgent: 1 icm / 2 lap (fbhip_dims.sf)
@@ -400,10 +388,6 @@ class FBHipAgent:
                                      ptr(self._actor_m), ptr(self._actor_v), ptr(self._workspace),
                                      self._workspace.numel()), ctx)
         check(lib.fbhip_set_seed(ctx, self._seed, self._rank()), ctx)
-        # every stream capture of the library (graph-cache misses of the update / fast-path entry points) first lets c10d's RCCL
-        # watchdog retire its finished collectives: see _quiesce_collectives.  (The callback object must outlive the context.)
-        self._precapture_cb = _PRECAPTURE_T(self._on_precapture)
-        check(lib.fbhip_set_precapture_hook(ctx, C.cast(self._precapture_cb, C.c_void_p)), ctx)
         if self.cfg.boltzmann:                         # fb_ddpg.py:70-71, 118-120
             lo, hi = self.cfg.log_std_bounds
             check(lib.fbhip_set_policy_squash(ctx, float(self.cfg.temp), float(lo), float(hi)), ctx)

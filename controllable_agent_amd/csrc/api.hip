@@ -195,12 +195,6 @@ int fbhip_bind_global_batch(fbhip_ctx* c, const float* panels, const float* disc
     return FBHIP_OK;
 }
 
-int fbhip_set_precapture_hook(fbhip_ctx* c, void (*hook)(void)) {
-    if (!c) return FBHIP_E_INVALID;
-    c->precapture = hook;
-    return FBHIP_OK;
-}
-
 int fbhip_set_seed(fbhip_ctx* c, uint64_t seed, uint32_t rank) {
     if (!c) return FBHIP_E_INVALID;
     c->seed = seed; c->rank = rank;
@@ -271,7 +265,6 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
         }
     }
     hipGraph_t graph = nullptr;
-    if (c->precapture) c->precapture();
     HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue_update(c, *hp, inject, phase_mask, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
@@ -341,7 +334,6 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
         }
     }
     hipGraph_t graph = nullptr;
-    if (c->precapture) c->precapture();
     HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = FBHIP_OK;
     hipError_t he = hipSuccess;
@@ -683,8 +675,7 @@ int run_infer_graph(fbhip_ctx* c, int kind, float stddev, int eval_mode, bool ha
         if (g.kind == kind && g.eval_mode == eval_mode && g.has_noise == (int)has_noise && g.stddev == stddev) exec = g.exec;
     if (!exec) {
         hipGraph_t graph = nullptr;
-        if (c->precapture) c->precapture();
-    HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         const int rc = kind == INFER_ACT ? enqueue_act(c, stddev, eval_mode, has_noise, s)
                        : kind == INFER_DISCRETE_ACT ? enqueue_discrete_act(c, s) : enqueue_zcorrel(c, s);
         hipError_t e = hipStreamEndCapture(s, &graph);

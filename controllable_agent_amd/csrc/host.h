@@ -148,7 +148,6 @@ struct fbhip_ctx {
     fbhip::host::ActP A_p, A_g;
     std::vector<fbhip::host::GraphEntry> graphs;
     std::vector<fbhip::host::InferGraph> infer_graphs;    // batch-1 fast path (fbhip_act / fbhip_z_correl)
-    void (*precapture)(void) = nullptr;                   // fbhip_set_precapture_hook
     float* h_in = nullptr;                   // pinned host staging, same layout as w.act_in
     float* h_out = nullptr;                  // pinned: action / correlation
     const float* gb_panels = nullptr;        // global-batch data parallel (fbhip_bind_global_batch): [6][gb_rows][Lz]

@@ -228,11 +228,6 @@ int fbhip_replay_bind(fbhip_ctx* ctx, const float* observation, const float* act
                       const float* goal, const int32_t* episode_len, const int64_t* cum_len,
                       int32_t n_episodes, int32_t t1, int32_t fixed_length);
 int fbhip_set_seed(fbhip_ctx* ctx, uint64_t seed, uint32_t rank);
-/* ``hook`` (nullable) is called on the calling thread right before every hipStreamBeginCapture the library issues (a graph-cache
- * miss of fbhip_update / fbhip_update_many* / the batch-1 fast paths) -- never while a capture is active.  A host that shares the
- * process with other users of HIP events quiesces them here: torch.distributed's RCCL watchdog thread polls the end events of
- * finished collectives, and a poll that lands inside a capture aborts the process (hipErrorCapturedEvent). */
-int fbhip_set_precapture_hook(fbhip_ctx* ctx, void (*hook)(void));
 /* boltzmann contexts only: cfg.temp and cfg.log_std_bounds (fb_ddpg.py:70-71; defaults 1, (-5, 2) are in effect until
  * this is called).  Drops every captured graph (the values are baked into the launches). */
 int fbhip_set_policy_squash(fbhip_ctx* ctx, float temp, float log_std_min, float log_std_max);

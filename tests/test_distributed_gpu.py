@@ -556,8 +556,8 @@ def test_api_surface_of_every_agent_under_a_live_rccl_group():
 def test_captures_beside_the_rccl_watchdog_do_not_abort_the_process():
     """c10d's RCCL watchdog thread polls the end event of every finished collective; a poll that lands while a stream capture is active in
     the process makes the HIP runtime answer hipErrorCapturedEvent, the watchdog throws and the process aborts (SIGABRT) -- seen in ~7 %
-    of agent constructions under a live group before FBHipAgent quiesced the watchdog ahead of its captures (fbhip_set_precapture_hook,
-    _quiesce_collectives): six agents built, warmed and replayed in one process with a world-1 RCCL group must now exit cleanly."""
+    of agent constructions under a live group before FBHipAgent quiesced the watchdog ahead of its capture of the schedule
+    (_quiesce_collectives): six agents built, warmed and replayed in one process with a world-1 RCCL group must now exit cleanly."""
     import subprocess
     import sys
     code = ("import os, sys, time, torch, torch.distributed as dist\n"
