@@ -78,6 +78,10 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
 
 int fbhip_destroy(fbhip_ctx* ctx) {
     if (!ctx) return FBHIP_OK;
+    // The context's launches are asynchronous: its graphs, events and side stream (and, on the caller's side, the buffers it was
+    // bound to) may still be in use by work in flight.  Destroying a graph exec / stream under a running launch corrupted the runtime
+    // (an intermittent segfault in a LATER capture, NaNs in a later agent that was handed the freed memory): drain the device first.
+    (void)hipDeviceSynchronize();
     for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& g : ctx->infer_graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto e : ctx->events) (void)hipEventDestroy(e);

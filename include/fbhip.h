@@ -209,7 +209,7 @@ size_t fbhip_workspace_bytes(const fbhip_dims* dims);
 
 /* ---- context ------------------------------------------------------------------------------------- */
 int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out);
-int fbhip_destroy(fbhip_ctx* ctx);
+int fbhip_destroy(fbhip_ctx* ctx);       /* waits for the device first (work of this context may still be in flight) */
 /* FB flat buffers hold forward_net ++ backward_net (fb_opt's two param groups, fb_ddpg.py:149-151);
  * fb_targets holds forward_target_net ++ backward_target_net in the same layout.
  * ZERO-INITIALISE before binding: (1) every flat buffer -- the physical layout pads matrices (fbhip_tensor_desc.ld >
