@@ -631,6 +631,7 @@ class FBHipAgent:
         out = np.empty(self.action_dim, np.float32)
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
         self._join_fast_path_stream()
+        self._before_library_capture(("act", bool(eval_mode), nz is None, float(stddev)))
         with torch.cuda.stream(self._stream):
             check(_lib.load().fbhip_act(self._ctx, obs.ctypes.data, z.ctypes.data, None if nz is None else nz.ctypes.data,
                                         float(stddev), int(bool(eval_mode)), out.ctypes.data,
@@ -683,6 +684,7 @@ class FBHipAgent:
             raise ValueError(f"compute_z_correl: expected goal[{self.goal_dim}] and z[{self.cfg.z_dim}]")
         out = np.empty(1, np.float32)
         self._join_fast_path_stream()
+        self._before_library_capture(("z_correl",))
         check(_lib.load().fbhip_z_correl(self._ctx, g.ctypes.data, z.ctypes.data, out.ctypes.data,
                                          self._stream.cuda_stream), self._ctx)
         return float(out[0])
@@ -723,6 +725,21 @@ class FBHipAgent:
         self._replay_view = v           # keeps the tensors alive while bound
         self._replay_token = token
         self.__dict__.pop("_dp_graphs", None)       # (captured data-parallel schedules hold the old storage pointers, like the library's own graphs)
+        self.__dict__.pop("_warm_captures", None)
+
+    def _before_library_capture(self, key: tp.Any) -> None:
+        """The library captures a graph the first time it sees a (entry point, phase mask, hparams, ...) combination.  In a process
+        that holds an RCCL process group the watchdog is quiesced before such a first call (see _quiesce_collectives); ``key``
+        mirrors the library's cache key closely enough (the cache is dropped with the replay binding; it holds 16 entries, so a
+        long-running host that cycles through more combinations than that can still capture unannounced -- rare, and the schedule
+        captured as one graph, the default under backend nccl, never goes through here)."""
+        import torch.distributed as dist
+        warm = self.__dict__.setdefault("_warm_captures", set())
+        if key in warm:
+            return
+        warm.add(key)
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and not torch.cuda.is_current_stream_capturing():
+            _quiesce_collectives(self._device)
 
     def _run_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         self._on_update_stream(lambda: self._launch_update(hp, inject, use_graph))
@@ -779,6 +796,7 @@ class FBHipAgent:
                 import warnings
                 warnings.warn(f"data-parallel schedule graph capture failed ({type(e).__name__}: {e}); using host-issued launches")
                 check(_lib.load().fbhip_select_workspace_set(self._ctx, 0), self._ctx)
+                self._cur_set = 0
                 return False
             if len(cache) >= 4:
                 cache.pop(next(iter(cache)))
@@ -806,6 +824,8 @@ class FBHipAgent:
             # injected draws only matter to the SAMPLE phase
             inj = C.byref(inject) if (inject is not None and mask & _lib.PHASE_SAMPLE) else None
             h = hp_fb if (mask & _lib.PHASE_FB_STEP) else hp
+            if use_graph:
+                self._before_library_capture(("update", mask, bytes(h), inj is not None, int(self.__dict__.get("_cur_set", 0))))
             check(lib.fbhip_update(self._ctx, C.byref(h), inj, mask, int(use_graph), s), self._ctx)
 
         dp_update(run_phases, self._fb_grads, self._actor_grads, self._exchange_embeddings if global_batch else None,
@@ -1013,7 +1033,8 @@ class FBHipAgent:
                         self._side_stream = torch.cuda.Stream(device=self._device)
                     side = self._side_stream
                 dp_update_many(phases,
-                               lambda which: check(lib.fbhip_select_workspace_set(self._ctx, which), self._ctx),
+                               lambda which: (self.__dict__.__setitem__("_cur_set", which),
+                                              check(lib.fbhip_select_workspace_set(self._ctx, which), self._ctx))[1],
                                self._fb_grads, self._actor_grads, n_steps, early=self._early_grad_range(), side=side)
             if self._dp_schedule_graph(n_steps, hp, launch):
                 return self._metrics()
@@ -1025,6 +1046,8 @@ class FBHipAgent:
         done = 0
         while done < n_steps:
             n = min(64, n_steps - done)
+
+            self._before_library_capture(("update_many", n, bytes(hp)))
 
             def launch(n: int = n) -> None:
                 check(_lib.load().fbhip_update_many(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx)
@@ -1219,6 +1242,7 @@ class DiscreteFBHipAgent(FBHipAgent):
         if o.shape[0] != self.obs_dim or z.shape[0] != self.cfg.z_dim:
             raise ValueError(f"act: expected obs[{self.obs_dim}] and z[{self.cfg.z_dim}], got {o.shape} / {z.shape}")
         out = C.c_int32()
+        self._before_library_capture(("discrete_act",))
         self._join_fast_path_stream()
         with torch.cuda.stream(self._stream):
             check(_lib.load().fbhip_discrete_act_host(self._ctx, o.ctypes.data, z.ctypes.data, C.byref(out),
@@ -1608,6 +1632,7 @@ class SFHipAgent(FBHipAgent):
         done = 0
         while done < total:
             n = min(64, total - done)
+            self._before_library_capture(("update_many", n, bytes(hp)))
             self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
             done += n
         return self._metrics()

@@ -531,28 +531,6 @@ def test_sf_agent_two_ranks_average_gradients(name):
         np.testing.assert_allclose(got[0][0][k], v, rtol=0, atol=3e-6, err_msg=k)
 
 
-def test_api_surface_of_every_agent_under_a_live_rccl_group():
-    """tests/test_api_surface_gpu.py (every agent kind x switch x public method) in a process that holds a world-1 RCCL process group with
-    the data-parallel schedule forced: every update then goes through the phase split, the eager warm-up of the step's collectives and
-    the schedule captured as one graph with its all-reduces -- for the discrete agent (no actor bucket) and the SF agent (single
-    bucket, no early share) too."""
-    import subprocess
-    import sys
-    # (the process leaves through os._exit: tearing the communicator down while captured graphs still hold its kernels aborted once)
-    code = ("import os, sys, torch, torch.distributed as dist\n"
-            "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))\n"
-            "import pytest\n"
-            "rc = pytest.main(['tests/test_api_surface_gpu.py', '-q', '-x', '-p', 'no:cacheprovider'])\n"
-            "torch.cuda.synchronize(); sys.stdout.flush(); sys.stderr.flush()\n"
-            "os._exit(int(rc))\n")
-    env = dict(os.environ, FBHIP_FORCE_PHASE_SPLIT="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(T._free_port()),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "37 passed" in r.stdout
-
-
 def test_captures_beside_the_rccl_watchdog_do_not_abort_the_process():
     """c10d's RCCL watchdog thread polls the end event of every finished collective; a poll that lands while a stream capture is active in
     the process makes the HIP runtime answer hipErrorCapturedEvent, the watchdog throws and the process aborts (SIGABRT) -- seen in ~7 %
