@@ -22,6 +22,7 @@ import math
 import os
 import re
 import typing as tp
+import weakref
 
 import numpy as np
 import torch
@@ -210,8 +211,18 @@ class AdamView:
     """torch.optim.Adam-shaped handle (``state_dict / load_state_dict / param_groups``) on the flat m / v buffers."""
 
     def __init__(self, agent: "FBHipAgent", which: str, nets: tp.List[str], lrs: tp.List[float]) -> None:
-        self._agent, self._which, self._nets = agent, which, nets
+        # a WEAK reference: agent -> optimiser view -> agent was a reference cycle, so a dropped agent (and its native context:
+        # graph execs with their runtime-internal streams, events, pinned staging) lived on until some later cyclic-GC pass --
+        # dozens of dead contexts at a time in a process that builds many agents (round-3 lifecycle stress, DESIGN.md section 0)
+        self._agent_ref, self._which, self._nets = weakref.ref(agent), which, nets
         self.param_groups = [dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False) for lr in lrs]
+
+    @property
+    def _agent(self) -> "FBHipAgent":
+        a = self._agent_ref()
+        if a is None:
+            raise ReferenceError("the agent this optimiser view belongs to no longer exists")
+        return a
 
     def _mv(self) -> tp.List[tp.Tuple[torch.Tensor, torch.Tensor]]:
         out = []
@@ -404,11 +415,12 @@ class FBHipAgent:
         lay = {n: layout(i) for i, n in enumerate(("forward_net", "backward_net", "actor"))}
         seg = {"forward_net": slice(0, nf), "backward_net": slice(nf, nfb)}
         self.forward_net = NetView("forward_net", self._fb_params[seg["forward_net"]], lay["forward_net"])
+        me = weakref.ref(self)                   # (the views' callables must not keep the agent alive: no reference cycles, see AdamView)
         self.backward_net = NetView("backward_net", self._fb_params[seg["backward_net"]], lay["backward_net"],
-                                    forward=lambda x: self._backward_map(x, target=False))
+                                    forward=lambda x: me()._backward_map(x, target=False))
         self.forward_target_net = NetView("forward_target_net", self._fb_targets[seg["forward_net"]], lay["forward_net"])
         self.backward_target_net = NetView("backward_target_net", self._fb_targets[seg["backward_net"]],
-                                           lay["backward_net"], forward=lambda x: self._backward_map(x, target=True))
+                                           lay["backward_net"], forward=lambda x: me()._backward_map(x, target=True))
         self.actor = NetView("actor", self._actor_params, lay["actor"])
         self.encoder = torch.nn.Identity()      # states only (fb_ddpg.py:108-110)
         self.aug = torch.nn.Identity()
@@ -801,8 +813,23 @@ class FBHipAgent:
             if len(cache) >= 4:
                 cache.pop(next(iter(cache)))
             cache[key] = g
-        self._on_update_stream(g.replay)
+        self._replay_on_high_priority_stream(g)
         return True
+
+    def _replay_on_high_priority_stream(self, g: "torch.cuda.CUDAGraph") -> None:
+        """Replay a graph WITH PARALLEL BRANCHES (the schedule forks onto a side stream) from a high-priority stream, ordered behind
+        / ahead of the caller's stream by events.  ROCm 7.0's hipGraphLaunch walks off the end of the exec's parallel-stream list
+        when two of the streams it created at instantiate time share their hardware queue with the LAUNCH stream; those streams
+        are normal-priority, and a high-priority stream's queue comes from another pool (csrc/api.hip::launch_graph,
+        tools/graph_queue_collision.hip)."""
+        hp = self.__dict__.get("_hp_stream")
+        if hp is None:
+            hp = self._hp_stream = torch.cuda.Stream(device=self._device, priority=-1)
+        cur = torch.cuda.current_stream(self._device)
+        hp.wait_stream(cur)
+        with torch.cuda.stream(hp):
+            g.replay()
+        cur.wait_stream(hp)
 
     def _launch_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         from .distributed import dp_update
@@ -1463,8 +1490,9 @@ class SFHipAgent(FBHipAgent):
         fwd, bwd, tgt = self.forward_net, self.backward_net, self.forward_target_net
         self.successor_net, self.successor_target_net = fwd, tgt
         fwd._name, tgt._name = "successor_net", "successor_target_net"
+        me = weakref.ref(self)
         self.feature_learner = FeatureLearnerView("feature_learner", bwd._flat, self._layout_of(1),
-                                                  forward=lambda x: self._backward_map(x, target=False))
+                                                  forward=lambda x: me()._backward_map(x, target=False))
         if self._sf_mode in (7, 8, 9):
             # latent (sf.py:234) / svd_sr, svd_srv2 (:266-267, :306-307): ``feature_learner.target_feature_net`` [and ``target_mu_net``] are blocks of the
             # TARGET buffer -- modules without gradients to the optimiser, part of ``feature_learner.state_dict()`` for checkpoints

@@ -9,6 +9,90 @@
 using namespace fbhip;
 using namespace fbhip::host;
 
+// ---- launching graphs with parallel branches ----------------------------------------------------------------------------
+// hipGraphLaunch of an exec whose graph has n > 1 branches can walk off the end of the exec's parallel-stream list and crash
+// the process (ROCm 7.0's libamdhip64 as bundled with torch 2.10: hip::Graph::UpdateStreams).  At instantiate time the runtime
+// creates n extra NORMAL-priority streams; at every launch it hands them to the branches, SKIPPING each extra stream that shares
+// its hardware queue with the launch stream -- without a bound on the index.  One such collision is provided for; two (both
+// extra streams of a two-branch graph on the launch stream's queue) are not.  Streams take the least-used of the 4 hardware
+// queues of their priority class, so it depends on the process's history of stream creations / destructions: a process that
+// builds and drops many contexts hit it in 3 of 6 suite runs in round 2, one in five in round 3 (backtrace:
+// profiles/r03_segv_backtrace.txt); tools/graph_queue_collision.hip reproduces it in ~40 trials of random stream churn.
+// The hardware queue of a HIGH-priority stream comes from another pool and can never be shared with those extra streams (same
+// tool: 3000 of 3000 trials): graphs with parallel branches are therefore launched from a high-priority stream of the
+// library's own, ordered behind and ahead of the caller's stream with two events (no host synchronisation).
+namespace {
+
+std::mutex g_launch_mu;
+hipStream_t g_launch_stream = nullptr;            // process-wide, never destroyed
+
+hipError_t launch_stream(hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    if (g_launch_stream == nullptr) {
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e != hipSuccess) return e;
+        if (hi >= lo) return hipErrorNotSupported;     // no high-priority class: the guard above cannot be given
+        e = hipStreamCreateWithPriority(&g_launch_stream, hipStreamNonBlocking, hi);
+        if (e != hipSuccess) return e;
+    }
+    *out = g_launch_stream;
+    return hipSuccess;
+}
+
+int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches) {
+    if (!branches) {
+        HIPCK(c, hipGraphLaunch(exec, s));
+        return FBHIP_OK;
+    }
+    hipStream_t ls = nullptr;
+    HIPCK(c, launch_stream(&ls));
+    if (!c->ev_in) HIPCK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    if (!c->ev_out) HIPCK(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    HIPCK(c, hipEventRecord(c->ev_in, s));
+    HIPCK(c, hipStreamWaitEvent(ls, c->ev_in, 0));
+    HIPCK(c, hipGraphLaunch(exec, ls));
+    HIPCK(c, hipEventRecord(c->ev_out, ls));
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_out, 0));
+    return FBHIP_OK;
+}
+
+// contexts whose destruction was asked for while a stream capture was open on their stream (hipGraphExecDestroy / hipHostFree /
+// hipDeviceSynchronize are illegal there): destroyed at the next entry point that is not inside a capture
+std::mutex g_reap_mu;
+std::vector<fbhip_ctx*> g_reap;
+
+void destroy_now(fbhip_ctx* ctx) {
+    (void)hipDeviceSynchronize();
+    for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : ctx->infer_graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto e : ctx->events) (void)hipEventDestroy(e);
+    if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
+    if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    delete ctx;
+}
+
+bool capture_open(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+void reap(hipStream_t s) {
+    if (capture_open(s)) return;
+    std::vector<fbhip_ctx*> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_reap_mu);
+        dead.swap(g_reap);
+    }
+    for (fbhip_ctx* d : dead) destroy_now(d);
+}
+
+}  // namespace
+
 // =================================================================================================== C ABI
 extern "C" {
 
@@ -79,16 +163,16 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
 int fbhip_destroy(fbhip_ctx* ctx) {
     if (!ctx) return FBHIP_OK;
     // The context's launches are asynchronous: its graphs, events and side stream (and, on the caller's side, the buffers it was
-    // bound to) may still be in use by work in flight.  Destroying a graph exec / stream under a running launch corrupted the runtime
-    // (an intermittent segfault in a LATER capture, NaNs in a later agent that was handed the freed memory): drain the device first.
-    (void)hipDeviceSynchronize();
-    for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (auto& g : ctx->infer_graphs) (void)hipGraphExecDestroy(g.exec);
-    for (auto e : ctx->events) (void)hipEventDestroy(e);
-    if (ctx->side) (void)hipStreamDestroy(ctx->side);
-    if (ctx->h_in) (void)hipHostFree(ctx->h_in);
-    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
-    delete ctx;
+    // bound to) may still be in use by work in flight: destroy_now drains the device first.  None of that is legal while a stream
+    // capture is open (a torch-level capture of the data-parallel schedule, say, with a garbage-collected agent's __del__
+    // landing inside it): then the context goes to the reaper and dies at the next entry point outside a capture.
+    if (capture_open(ctx->last_stream)) {
+        std::lock_guard<std::mutex> lk(g_reap_mu);
+        g_reap.push_back(ctx);
+        return FBHIP_OK;
+    }
+    reap(ctx->last_stream);
+    destroy_now(ctx);
     return FBHIP_OK;
 }
 
@@ -260,7 +344,9 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     RC(need_bound(c, (phase_mask & FBHIP_PHASE_SAMPLE) != 0));
     RC(check_hparams(c, hp));
     hipStream_t s = (hipStream_t)stream;
+    c->last_stream = s;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
+    reap(s);
     for (auto& g : c->graphs) {
         if (g.n_steps == 1 && g.set == c->cur && g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
             (!inject || memcmp(&g.inj, inject, sizeof(*inject)) == 0)) {
@@ -310,12 +396,12 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     RC(check_hparams(c, hp));
     if (n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
+    c->last_stream = s;
+    reap(s);
     for (auto& g : c->graphs) {
         if (g.n_steps == n_steps && g.set == c->cur && g.mask == (FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0)) && g.has_inj == (injs != nullptr) &&
-            (!injs || memcmp(&g.inj, injs, sizeof(*injs)) == 0) && memcmp(&g.hp, hp, sizeof(*hp)) == 0) {
-            HIPCK(c, hipGraphLaunch(g.exec, s));
-            return FBHIP_OK;
-        }
+            (!injs || (g.injs.size() == (size_t)n_steps && memcmp(g.injs.data(), injs, sizeof(*injs) * n_steps) == 0)) && memcmp(&g.hp, hp, sizeof(*hp)) == 0)
+            return launch_graph(c, g.exec, s, g.branches);
     }
     // Software pipeline over the steps.  Step t's actor phase is ONE dependency chain of ~20 small launches; step t+1's
     // sampling, z mixing, B passes and online ForwardMap pass depend on step t only through its FB optimiser step (new
@@ -430,14 +516,16 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     HIPCK(c, e);
     GraphEntry ge{};
     ge.mask = FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0); ge.hp = *hp; ge.has_inj = injs != nullptr; ge.n_steps = n_steps; ge.set = c->cur;
-    if (injs) ge.inj = injs[0];              // (cache key: a caller that reuses its per-step buffers replays the same graph)
+    // (cache key: EVERY step's inject struct -- a caller that reuses its per-step buffers replays the same graph; one whose allocator
+    // hands back the same addresses for step 0 only must not)
+    if (injs) { ge.inj = injs[0]; ge.injs.assign(injs, injs + n_steps); }
+    ge.branches = pipe;
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCK(c, e);
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
-    HIPCK(c, hipGraphLaunch(ge.exec, s));
-    return FBHIP_OK;
+    return launch_graph(c, ge.exec, s, ge.branches);
 }
 
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {

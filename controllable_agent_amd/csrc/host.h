@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -118,7 +119,9 @@ IcmP icm_p(float* base, const NetLayout& L);
 BwdP mu_p(float* base, const NetLayout& L);               // svd_p's mu_net (same module structure as BackwardMap.B, no projection)
 ActP act_p(float* base, const NetLayout& L);
 
-struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; int set; };
+struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; int set;
+                    bool branches = false;                 // parallel branches: launched through launch_graph's high-priority stream (api.hip)
+                    std::vector<fbhip_inject> injs; };     // multi-step injected graphs: every step's struct is part of the cache key
 struct InferGraph { int kind; int eval_mode; int has_noise; float stddev; hipGraphExec_t exec; };
 
 }  // namespace host
@@ -137,6 +140,8 @@ struct fbhip_ctx {
     size_t ws_bytes = 0;
     hipStream_t side = nullptr;              // second capture branch of fbhip_update_many
     std::vector<hipEvent_t> events;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;   // bridge events of launch_graph (api.hip)
+    hipStream_t last_stream = nullptr;      // the stream of the last update call (fbhip_destroy asks it whether a capture is open)
     hipEvent_t v_ready = nullptr;            // set while the actor phase of a pipelined graph is being built: V comes from the side branch
     fbhip::ReplayView rv{};
     uint64_t seed = 0;

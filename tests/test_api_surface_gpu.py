@@ -2,10 +2,7 @@
 learner, once: no parity claims here (the trace and oracle suites make those) -- this is the "does any surface call raise" net that
 caught SFHipAgent.update_many_injected / update_from_batch / compute_z_correl in round 2.  Tiny dims, a few seconds in total."""
 import io
-import os
 import pickle
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -16,12 +13,12 @@ from oracle import fb_oracle as fo
 from oracle import sf_oracle as so
 from tests import helpers as H
 
-# The 37 cases run in a process of their own (test_surface_cases_in_their_own_process below starts it): they build and drop ~110 agents
-# (pickle / torch.save round trips included), and with them in the main pytest process an intermittent segfault appeared inside LATER
-# tests' first graph captures (release build only; never with the cases isolated) -- root cause not found by the end of round 2.
-INNER = os.environ.get("FBHIP_SURFACE_INNER") == "1"
+# (Round 2 ran these 37 cases in a process of their own: with them in the main pytest process an intermittent segfault appeared
+# inside LATER tests' first multi-step graph launch.  Round 3 found the cause -- ROCm 7.0's hipGraphLaunch walks off the exec's
+# parallel-stream list when both of a two-branch graph's runtime-internal streams share the launch stream's hardware queue, which
+# the stream churn of ~110 short-lived contexts makes likely -- and the library now launches such graphs from a high-priority
+# stream (csrc/api.hip::launch_graph; tools/graph_queue_collision.hip reproduces it).  The cases are back in the main process.)
 pytestmark = pytest.mark.gpu
-inner_only = pytest.mark.skipif(not INNER, reason="runs inside test_surface_cases_in_their_own_process")
 BATCH_KEYS = ("obs", "action", "reward", "next_obs", "discount", "goal", "next_goal", "future_obs", "future_goal")
 
 
@@ -76,7 +73,6 @@ FB_CASES = {"default": {}, "goal+q_loss": dict(goal=True, q_loss=True, batch_siz
             "debug+goal+hindsight": dict(goal=True, z_dim=3, debug=True, future=0.7, future_ratio=0.4, batch_size=24)}
 
 
-@inner_only
 @pytest.mark.parametrize("label", list(FB_CASES))
 def test_fb_agent_surface(label):
     from tests.test_update_parity_gpu import _buffer
@@ -100,7 +96,6 @@ DISCRETE_CASES = {"default": {}, "boltzmann+q_loss": dict(boltzmann=True, temp=0
                   "debug": dict(z_dim=5, debug=True), "goal+hindsight": dict(goal_dim=3, use_goal=True, future=0.8, future_ratio=0.3)}
 
 
-@inner_only
 @pytest.mark.parametrize("label", list(DISCRETE_CASES))
 def test_discrete_agent_surface(label):
     from tests.test_update_parity_gpu import _buffer
@@ -117,7 +112,6 @@ def test_discrete_agent_surface(label):
     a.update_from_batch(_batch(storage, d, cfg), 5, draws=H.draws_dict(d))
 
 
-@inner_only
 @pytest.mark.parametrize("goal", [False, True])
 @pytest.mark.parametrize("learner", ["icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2",
                                      "contrastive", "contrastivev2", "identity"])
@@ -138,11 +132,3 @@ def test_sf_agent_surface(learner, goal):
     a.update_from_batch(_batch(storage, d, cfg), 5, draws=H.draws_dict(d))
     a.update_many_injected(rb, 6, [H.draws_dict(fo.make_draws(rng, cfg, 6, lengths)) for _ in range(2)])
     assert a.step_counts() == (8, 8)
-
-
-@pytest.mark.skipif(INNER, reason="the outer runner")
-def test_surface_cases_in_their_own_process():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_api_surface_gpu.py", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
-                       cwd=root, env=dict(os.environ, FBHIP_SURFACE_INNER="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "37 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -211,6 +211,31 @@ def test_reader_refuses_globals_outside_the_allow_list_and_never_imports(tmp_pat
     assert issubclass(cls, rio.ReferenceObject) and "utils" not in sys.modules
 
 
+def test_nested_storage_payloads_stay_inside_the_allow_list(tmp_path):
+    """``torch.storage._load_from_bytes`` (what ``pickle.dumps(tensor)`` reduces a storage through) used to be on the
+    allow-list and runs a default-unpickler ``torch.load``: a refused global executed when wrapped in it.  It is now replaced by a
+    stand-in that re-enters the allow-listed unpickler: the harmless nested payload is refused, a plain pickled tensor loads."""
+    import pickle
+    from controllable_agent_amd import reference_io as rio
+
+    class Nested:
+        def __reduce__(self):
+            import torch.storage
+            inner = pickle.dumps(__import__("os").getpid, protocol=2)           # GLOBAL posix.getpid inside the inner stream
+            return (torch.storage._load_from_bytes, (inner,))
+
+    evil = tmp_path / "nested.pt"
+    evil.write_bytes(pickle.dumps(Nested(), protocol=4))
+    with pytest.raises(Exception, match="allow-list|refusing|Unsupported|Invalid|pickle"):
+        rio.load_reference_payload(evil)
+    t = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    ok = tmp_path / "tensor.pkl"
+    ok.write_bytes(pickle.dumps({"x": t}, protocol=4))                          # storages travel through _load_from_bytes
+    with ok.open("rb") as f:
+        back = rio._Unpickler(f).load()
+    assert torch.equal(back["x"], t)
+
+
 # ------------------------------------------------------------------------------------------------ staging / load / relabel
 def test_episode_stage_supports_what_callers_do_with_current_episode():
     """pretrain.py:485 calls ``_current_episode.clear()``; url_benchmark/test_dmc.py:25 asserts ``"physics" in
