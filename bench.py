@@ -195,10 +195,24 @@ def main():
     W = WALKER if args.workload == "walker" else QUADRUPED
     goal_space = None if args.workload == "walker" else "simplified_quadruped"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain ``python bench.py --gpus N``: become the launcher -- one rank per GPU under torch.distributed.run on this node,
+        # rendezvous on 127.0.0.1 and a free port; rank 0 of the children prints the one JSON line (the torchrun form documented
+        # at the top keeps working: it arrives here with WORLD_SIZE set)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execve(sys.executable, cmd, env)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched under torch.distributed.run with another --nproc-per-node?)")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include "p3.h"
 
 namespace fbhip {
 
@@ -92,13 +93,15 @@ constexpr int LN_BWD_ROWS_PER_BLOCK = 8;
 // np (optional, 0 = unknown): a multiple of 4 with n <= np <= every leading dimension and np readable elements in
 // gamma / beta -- lets the kernels use branch-free clamped float4 loads (all of a row's loads in flight at once)
 struct LnFwdProblem { const float* x; int ldx; const float* gamma; const float* beta; float* y; int ldy; float* stats;
-                      int rows, n, vx, vy, vp, np; };
+                      int rows, n, vx, vy, vp, np;
+                      char* y3; };      // nullable: also emit the P3 image of y (p3.h; n % 4 == 0, ldy % 32 == 0)
 constexpr int LN_MAX_GROUP = 6;
 struct LnFwdGroup { LnFwdProblem p[LN_MAX_GROUP]; int n; };
 hipError_t launch_ln_tanh_fwd_group(LnFwdGroup g, hipStream_t s);
 struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* stats;
                       const float* gamma; float* dx; int lddx; float* dgamma; float* dbeta; float* partials;
-                      int rows, n, vdy, vy, vx, vdx, vp, np; };
+                      int rows, n, vdy, vy, vx, vdx, vp, np;
+                      char* dx3; };     // nullable: also emit the P3 image of dx
 struct LnBwdGroup { LnBwdProblem p[LN_MAX_GROUP]; int n; };
 // defer != nullptr: the column reduce of (d gamma, d beta) is NOT launched; its jobs are appended to *defer for
 // launch_splitk_reduce (bit-identical result: same partials, same fold order)
@@ -247,7 +250,8 @@ hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* 
                            float lr, float lr2, int64_t split, float grad_scale, float tau,
                            const StepState* st, int which, int t_explicit, hipStream_t s,
                            float tau2 = -1.f /* the target rate of the elements behind ``split`` (< 0: tau) */,
-                           int ema_before2 = 0 /* there, the target follows the parameter as it was BEFORE this step */);
+                           int ema_before2 = 0 /* there, the target follows the parameter as it was BEFORE this step */,
+                           char* p3 = nullptr, char* t3 = nullptr /* nullable: P3 images of p / target, kept current by the pass */);
 
 // ---- peer-access all-reduce (peer.hip): the data-parallel gradient exchange as graph-capturable kernels -------------------
 constexpr int PEER_MAX_WORLD = 8;

@@ -16,7 +16,10 @@ struct LayoutBuilder {
     NetLayout L;
     int64_t cur = 0;
     // logical [rows x cols]; physical leading dimension ld (>= cols) and phys_rows (>= rows) allocated
-    void mat(const std::string& n, int rows, int cols, int ld = 0, int phys_rows = 0) {
+    // (weight matrices start on 128-byte boundaries: a matrix whose leading dimension is a multiple of 32 then consists of whole
+    // P3 blocks, p3.h; ``follow``: directly behind the previous matrix -- F2.0.weight behind F1.0.weight, one stacked GEMM operand)
+    void mat(const std::string& n, int rows, int cols, int ld = 0, int phys_rows = 0, bool follow = false) {
+        if (!follow) cur = (cur + 31) & ~(int64_t)31;
         Slot s{n, cur, rows, cols, ld > 0 ? ld : pad4(cols)};
         cur += (int64_t)(phys_rows > 0 ? phys_rows : rows) * s.ld;
         L.by_name[n] = s;
@@ -35,7 +38,7 @@ struct LayoutBuilder {
     }
     NetLayout finish(const std::vector<std::string>& order) {
         for (const auto& n : order) L.slots.push_back(L.by_name.at(n));
-        L.numel = cur;
+        L.numel = (cur + 31) & ~(int64_t)31;      // whole 128-byte blocks: the next net of a shared flat buffer stays aligned
         return L;
     }
 };
@@ -86,7 +89,7 @@ NetLayout build_layout(const fbhip_dims& d, int net) {
             if (d.add_trunk) { b.mat("trunk.0.weight", H, 2 * Fd); b.vec("trunk.0.bias", H); }
         }
         // F1/F2 first layers are stored back to back so both heads run as ONE [2H x feat] GEMM
-        b.mat("F1.0.weight", H, gm.feat); b.mat("F2.0.weight", H, gm.feat);
+        b.mat("F1.0.weight", H, gm.feat); b.mat("F2.0.weight", H, gm.feat, 0, 0, /*follow=*/true);
         b.vec("F1.0.bias", H); b.vec("F2.0.bias", H);
         b.mat("F1.2.weight", fhead_out(d), H); b.vec("F1.2.bias", fhead_out(d));
         b.mat("F2.2.weight", fhead_out(d), H); b.vec("F2.2.bias", fhead_out(d));
@@ -309,6 +312,17 @@ Ws carve(const fbhip_dims& d, void* base) {
     w.act_out = c.f(64);
     w.total_bytes = (c.cur + 255) & ~(size_t)255;
     return w;
+}
+
+// Buffers that only plane-emitting kernels ever write (gemm3's ReLU epilogues, the LayerNorm kernels): the forward activation
+// sets.  Their P3 images stay current across row kernels (schedule.hip::p3_opaque); every other buffer's image is re-made on demand.
+std::vector<Buf> p3_immune_bufs(const Ws& w) {
+    std::vector<Buf> v;
+    for (const FSet* s : {&w.fsT, &w.fsO}) { v.push_back(s->t1a); v.push_back(s->t1z); v.push_back(s->h); v.push_back(s->tr); v.push_back(s->p); }
+    for (const ASet* s : {&w.as, &w.asT}) { v.push_back(s->t1o); v.push_back(s->t1z); v.push_back(s->h); v.push_back(s->tr); v.push_back(s->p); }
+    for (const BSet* s : {&w.bsA, &w.bsO, &w.bsM, &w.bsF, &w.bsS}) { v.push_back(s->t1); v.push_back(s->r2); }
+    for (const Buf* b : {&w.ih1, &w.ih2}) v.push_back(*b);
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------ weights
