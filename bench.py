@@ -277,7 +277,7 @@ def main():
         sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
         for sz in sorted(sizes):
             run(args.warmup, sz)
-        walls, events, host_enqueue = [], [], []
+        walls, events, host_enqueue, per_rank_walls = [], [], [], []
         for rep in range(max(1, args.repeats)):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             barrier()
@@ -290,6 +290,9 @@ def main():
             wall = time.perf_counter() - t0
             if world > 1:
                 t = torch.tensor([wall], device=dev, dtype=torch.float64)
+                mine = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(mine, t)
+                per_rank_walls.append([float(x.item()) for x in mine])
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 wall = float(t.item())
             walls.append(wall)
@@ -369,6 +372,17 @@ def main():
                         "hip_event_steps_per_s_median_repeat": world * args.steps / events[mid]},
             "timed_region_s": dt,
             **({"replicas": replicas} if replicas is not None else {}),
+            **({"data_parallel": {
+                # which path actually carried the gradients (a capture that failed once falls back to host-issued launches for good)
+                "transport": ("peer" if args.peer_allreduce else ("gloo-host" if args.rehearse_on_one_gpu else
+                              ("rccl-host" if (getattr(agent, "_dp_graph_failed", False) or os.environ.get("FBHIP_DP_GRAPH", "1") == "0"
+                                               or spl == 1) else "rccl-graph"))),
+                "schedule_graph_capture_failed": bool(getattr(agent, "_dp_graph_failed", False)),
+                "nccl_env": {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                                     "HSA_ENABLE_IPC_MODE_LEGACY")},
+                "per_rank_steps_per_s_median_repeat": [args.steps / w for w in per_rank_walls[mid]] if per_rank_walls else None,
+                "scaling_efficiency_note": "efficiency = value / (N x the value of the same script at --gpus 1); the driver computes it from its own N = 1 run"}}
+               if world > 1 else {}),
             **({"flags": [f"timed region of {dt * 1e3:.1f} ms < 0.5 s: --steps {args.steps} is too short for a stable rate "
                           f"(host launch jitter); the {len(walls)} repeats bound it, prefer --steps >= 1000"]} if dt < 0.5 else {}),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

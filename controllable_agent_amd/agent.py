@@ -643,7 +643,7 @@ class FBHipAgent:
         out = np.empty(self.action_dim, np.float32)
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
         self._join_fast_path_stream()
-        self._before_library_capture(("act", bool(eval_mode), nz is None, float(stddev)))
+        self._before_library_capture(("act", bool(eval_mode), nz is None))      # (the graph reads stddev from its staged inputs: one capture for a whole schedule)
         with torch.cuda.stream(self._stream):
             check(_lib.load().fbhip_act(self._ctx, obs.ctypes.data, z.ctypes.data, None if nz is None else nz.ctypes.data,
                                         float(stddev), int(bool(eval_mode)), out.ctypes.data,
@@ -749,6 +749,8 @@ class FBHipAgent:
         warm = self.__dict__.setdefault("_warm_captures", set())
         if key in warm:
             return
+        if len(warm) >= 16:                 # the library's cache holds 16 graphs and evicts the oldest: forget with it (a recapture
+            warm.clear()                    # after an eviction must be announced again)
         warm.add(key)
         if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and not torch.cuda.is_current_stream_capturing():
             _quiesce_collectives(self._device)
@@ -955,7 +957,7 @@ class FBHipAgent:
             return out
         buf = (C.c_float * _lib.NUM_METRICS)()
         check(_lib.load().fbhip_read_metrics(self._ctx, buf, stream_ptr()), self._ctx)
-        if c.dp_global_batch and self._world() > 1:
+        if getattr(c, "dp_global_batch", False) and self._world() > 1:
             # every rank holds its SHARE of the pairwise terms (global normalisers) and local means of the row-wise
             # ones: sum the former, average the latter (orth_linf / orth_l2 come from the gathered B: equal everywhere)
             import torch.distributed as dist
@@ -989,12 +991,13 @@ class FBHipAgent:
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
         if isinstance(replay_loader, DeviceReplayBuffer):
             from . import peer
-            if self._world() > 1 and peer.enabled() and not c.dp_global_batch and self._use_graph and self._stddev_is_constant():
+            if self._world() > 1 and peer.enabled() and not getattr(c, "dp_global_batch", False) and self._use_graph and self._stddev_is_constant():
                 self._bind_replay(replay_loader)
                 self._verify_replicas()
                 peer.bind(self)
                 hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
                 self._on_update_stream(lambda: check(_lib.load().fbhip_update_many_dp(self._ctx, C.byref(hp), 1, stream_ptr()), self._ctx))
+                self._check_peer_status(every=64)
                 return self._metrics()
             self._bind_replay(replay_loader)
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
@@ -1005,6 +1008,23 @@ class FBHipAgent:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)
         return self._metrics()
+
+    def _check_peer_status(self, every: int = 1) -> None:
+        """The peer-access all-reduce kernels (csrc/peer.hip) give up on a cross-rank barrier after a bounded spin and set a status
+        word instead of hanging the GPU -- the optimiser step that follows then runs on unreduced gradients and the replicas
+        diverge.  Read that word (one 16-byte D2H + a stream synchronise) after every multi-step launch, every ``every``-th single
+        step, and raise: a lost peer must stop the run, not corrupt it."""
+        n = self.__dict__.get("_peer_calls", 0) + 1
+        self._peer_calls = n
+        if n % max(1, every):
+            return
+        st = C.c_int32(0)
+        with torch.cuda.stream(self._stream if torch.cuda.current_stream(self._device).cuda_stream == 0 else torch.cuda.current_stream(self._device)):
+            check(_lib.load().fbhip_dp_status(self._ctx, C.byref(st), stream_ptr()), self._ctx)
+        if st.value != 0:
+            self._replicas_verified = False
+            raise RuntimeError(f"fbhip: peer all-reduce reported status {st.value} (a rank did not reach a gradient barrier in time): "
+                               "the replicas can no longer be trusted; restart from a checkpoint")
 
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         """``n_steps`` consecutive ``update(replay_loader, step + i)`` calls as ONE graph launch (``fbhip_update_many``):
@@ -1018,7 +1038,7 @@ class FBHipAgent:
         c = self.cfg
         stds = {schedule(c.stddev_schedule, step + i) for i in range(n_steps)}
         split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
-        if (n_steps < 2 or c.dp_global_batch or not isinstance(replay_loader, DeviceReplayBuffer) or
+        if (n_steps < 2 or getattr(c, "dp_global_batch", False) or not isinstance(replay_loader, DeviceReplayBuffer) or
                 c.update_every_steps != 1 or len(stds) != 1 or not self._use_graph):
             out: tp.Dict[str, float] = {}
             for i in range(n_steps):
@@ -1038,6 +1058,7 @@ class FBHipAgent:
                 n = min(64, n_steps - done)
                 self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many_dp(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
                 done += n
+            self._check_peer_status(every=1)
             return self._metrics()
         if split:
             # data parallel: the steps are pipelined around the gradient all-reduces (distributed.dp_update_many)

@@ -143,9 +143,9 @@ static size_t p3_param_shadow_bytes(const fbhip_dims& d) {
 }
 size_t fbhip_workspace_bytes(const fbhip_dims* dims) {
     if (check_dims(dims) != FBHIP_OK) return 0;
-    // two complete sets (fbhip_update_many pipelines consecutive steps) + the P3 images of both sets (1.5 x) and of the parameters
+    // two complete sets (fbhip_update_many pipelines consecutive steps) + the P3 images of the parameter buffers
     const size_t one = carve(*dims, nullptr).total_bytes;
-    return 2 * one + 3 * one + p3_param_shadow_bytes(*dims);
+    return 2 * one + p3_param_shadow_bytes(*dims);
 }
 
 int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
@@ -191,7 +191,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     if (!fb_params || !fb_grads || !fb_adam_m || !fb_adam_v || !fb_targets || !workspace ||
         (has_actor && (!actor_params || !actor_grads || !actor_adam_m || !actor_adam_v))) { c->err = g_err = "fbhip: null buffer"; return FBHIP_E_INVALID; }
     const size_t one = carve(c->d, nullptr).total_bytes, need = 2 * one;
-    if (workspace_bytes < need + 3 * one + p3_param_shadow_bytes(c->d)) { c->err = g_err = "fbhip: workspace too small (fbhip_workspace_bytes)"; return FBHIP_E_INVALID; }
+    if (workspace_bytes < need + p3_param_shadow_bytes(c->d)) { c->err = g_err = "fbhip: workspace too small (fbhip_workspace_bytes)"; return FBHIP_E_INVALID; }
     if (((uintptr_t)workspace & 255) || ((uintptr_t)fb_params & 15) || ((uintptr_t)fb_grads & 15) ||
         ((uintptr_t)fb_targets & 15) || (has_actor && (((uintptr_t)actor_params & 15) || ((uintptr_t)actor_grads & 15)))) {
         c->err = g_err = "fbhip: buffers must be 16-byte aligned (workspace 256)";
@@ -208,23 +208,22 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     c->sets[1].act_in = c->sets[0].act_in; c->sets[1].act_vec = c->sets[0].act_vec; c->sets[1].act_out = c->sets[0].act_out;
     c->ws_lo = (const char*)workspace; c->ws_bytes = need;
     const int64_t nf = c->L[FBHIP_NET_FORWARD].numel;
-    {   // P3 images behind the two sets: [sets | image of the sets | image of fb params | of fb targets | of actor params]
-        static const int mode = [] { const char* e = getenv("FBHIP_P3"); return e ? atoi(e) : 1; }();
+    {   // P3 images of the parameters behind the two sets: [sets | image of fb params | of fb targets | of actor params]
+        // FBHIP_P3: 0 (default) the fp32-MFMA kernel everywhere | 1 gemm3_kernel where its launch estimate wins | 2 for every
+        // eligible problem (tests).  Off by default: measured inside the walker step (round 3) the bf16-plane
+        // kernel's faster tiles do not pay for what surrounds them at B = 1024 -- 1043-1075 vs 1112-1117 update-steps/s
+        static const int mode = [] { const char* e = getenv("FBHIP_P3"); return e ? atoi(e) : 0; }();
         c->p3_mode = mode;
-        c->p3r.clear(); c->p3_fresh.clear(); c->p3_immune.clear();
+        c->p3r.clear();
         char* sh = (char*)workspace + need;
-        auto region = [&](const void* lo, size_t bytes, bool weights) {
-            if (((uintptr_t)lo & 127) == 0 && bytes > 0) c->p3r.push_back(P3Region{(const char*)lo, bytes, sh, weights});
+        auto region = [&](const void* lo, size_t bytes) {
+            if (((uintptr_t)lo & 127) == 0 && bytes > 0) c->p3r.push_back(P3Region{(const char*)lo, bytes, sh, true});
             sh += (bytes / 2 * 3 + 255) & ~(size_t)255;
         };
         const size_t n_fb = (size_t)(nf + c->L[FBHIP_NET_BACKWARD].numel) * 4, n_ac = (size_t)c->L[FBHIP_NET_ACTOR].numel * 4;
-        region(workspace, need, false);
-        region(fb_params, n_fb, true);
-        region(fb_targets, n_fb, true);
-        if (has_actor) region(actor_params, n_ac, true);
-        for (int k = 0; k < 2; ++k)
-            for (const Buf& b : p3_immune_bufs(c->sets[k]))
-                if (b.p != nullptr) c->p3_immune.emplace_back(b.p, b.p + (size_t)b.rows * b.ld);
+        region(fb_params, n_fb);
+        region(fb_targets, n_fb);
+        if (has_actor) region(actor_params, n_ac);
     }
     c->F_p = fwd_p(fb_params, c->L[0]); c->F_g = fwd_p(fb_grads, c->L[0]); c->F_t = fwd_p(fb_targets, c->L[0]);
     c->K_p = bwd_p(fb_params + nf, c->L[1]); c->K_g = bwd_p(fb_grads + nf, c->L[1]); c->K_t = bwd_p(fb_targets + nf, c->L[1]);
@@ -371,7 +370,6 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     RC(check_hparams(c, hp));
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
-    c->p3_fresh.clear();
     const bool resplit = (phase_mask & FBHIP_PHASE_SAMPLE) && !(phase_mask & FBHIP_PHASE_KEEP_PLANES);
     phase_mask &= ~FBHIP_PHASE_KEEP_PLANES;
     if (!use_graph) {
@@ -696,7 +694,7 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
     Ws& w = c->W();
     const ActP& A = c->A_p;
     float* pre1o = w.act_vec; float* pre1z = pre1o + 2048; float* h = pre1z + 2048; float* pv = h + 2048;
-    const size_t nin = act_noise_off(d) + (has_noise ? a : 0);
+    const size_t nin = act_in_floats(d);       // obs, z, noise and -- in the last float -- the exploration stddev
     HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, nin * sizeof(float), hipMemcpyHostToDevice, s));
     // Actor.forward (fb_modules.py:107-121): first layers (the weight's zero pad columns absorb whatever follows
     // obs / [obs|z] in the staging vector); preprocess == 0 has ONE branch on [obs|z] ...
@@ -728,7 +726,7 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
     }
     // ... head + TruncatedNormal / SquashedNormal
     HIPCK(c, launch_act_head(feat, A.W4, H, A.b4, a, H, stddev, eval_mode, has_noise ? w.act_in + act_noise_off(d) : nullptr,
-                             c->seed, c->rank, w.st, w.act_out, c->sq, s));
+                             c->seed, c->rank, w.st, w.act_out, c->sq, s, w.act_in + (act_in_floats(d) - 1)));
     HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, (size_t)a * sizeof(float), hipMemcpyDeviceToHost, s));
     (void)o; (void)z;
     return FBHIP_OK;
@@ -797,7 +795,7 @@ int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
 int run_infer_graph(fbhip_ctx* c, int kind, float stddev, int eval_mode, bool has_noise, hipStream_t s) {
     hipGraphExec_t exec = nullptr;
     for (auto& g : c->infer_graphs)
-        if (g.kind == kind && g.eval_mode == eval_mode && g.has_noise == (int)has_noise && g.stddev == stddev) exec = g.exec;
+        if (g.kind == kind && g.eval_mode == eval_mode && g.has_noise == (int)has_noise) exec = g.exec;      // (stddev travels in the staged inputs)
     if (!exec) {
         hipGraph_t graph = nullptr;
         HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -832,6 +830,7 @@ int fbhip_act(fbhip_ctx* c, const float* host_obs, const float* host_z, const fl
     for (size_t i = (size_t)d.obs_dim + d.z_dim; i < act_noise_off(d); ++i) c->h_in[i] = 0.f;
     const bool has_noise = host_noise != nullptr && !eval_mode;
     if (has_noise) memcpy(c->h_in + act_noise_off(d), host_noise, (size_t)d.action_dim * sizeof(float));
+    c->h_in[act_in_floats(d) - 1] = stddev;
     RC(run_infer_graph(c, INFER_ACT, stddev, eval_mode ? 1 : 0, has_noise, (hipStream_t)stream));
     memcpy(host_action_out, c->h_out, (size_t)d.action_dim * sizeof(float));
     return FBHIP_OK;
@@ -989,17 +988,17 @@ int fbhip_p3_split(const float* x, int32_t ld, void* x3, int32_t rows, void* str
 int fbhip_gemm_p3(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig, float* C,
                   int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* aux, int32_t ldaux, int32_t epi,
                   float* colsum, void* a3, void* b3, void* c3, int32_t cfg, void* stream) {
-    if (!A || !B || !C || !a3 || !b3 || M < 1 || N < 1 || K < 32 || epi < 0 || epi > 4 || cfg < 0 || cfg >= G3_CFG_COUNT) { g_err = "fbhip_gemm_p3: bad argument"; return FBHIP_E_INVALID; }
+    if (!A || !B || !C || M < 1 || N < 1 || K < 32 || epi < 0 || epi > 4 || cfg < 0 || cfg >= G3_CFG_COUNT) { g_err = "fbhip_gemm_p3: bad argument"; return FBHIP_E_INVALID; }
     if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias) { g_err = "fbhip_gemm_p3: bias required"; return FBHIP_E_INVALID; }
     if ((epi == EPI_MASK_RELU || epi == EPI_TANH_BWD) && !aux) { g_err = "fbhip_gemm_p3: aux required"; return FBHIP_E_INVALID; }
     fbhip_ctx* none = nullptr;
     hipStream_t s = (hipStream_t)stream;
     GemmProblem p = P(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, aux, ldaux, colsum);
     p.A3 = (const char*)a3; p.B3 = (const char*)b3; p.C3 = (char*)c3;
-    if (!gemm3_problem_ok(p)) { g_err = "fbhip_gemm_p3: operands must be whole 32-float blocks (lda, ldb, K % 32 == 0; ldc % 32 == 0 with c3; 16-byte aligned images)"; return FBHIP_E_INVALID; }
+    if (!gemm3_problem_ok(p)) { g_err = "fbhip_gemm_p3: K % 32 == 0; an operand with an image needs ld % 32 == 0, one without 16-byte aligned rows (ld % 4 == 0); ldc % 32 == 0 with c3"; return FBHIP_E_INVALID; }
     HIPCK(none, gemm3_init());
-    HIPCK(none, launch_p3_split(A, lda, (char*)a3, a_kcontig ? M : K, lda, s));
-    HIPCK(none, launch_p3_split(B, ldb, (char*)b3, b_kcontig ? N : K, ldb, s));
+    if (a3) HIPCK(none, launch_p3_split(A, lda, (char*)a3, a_kcontig ? M : K, lda, s));
+    if (b3) HIPCK(none, launch_p3_split(B, ldb, (char*)b3, b_kcontig ? N : K, ldb, s));
     p.kslices = 1;
     gemm3_problem_finalize(p, cfg);
     GemmGroup g{};

@@ -93,15 +93,13 @@ constexpr int LN_BWD_ROWS_PER_BLOCK = 8;
 // np (optional, 0 = unknown): a multiple of 4 with n <= np <= every leading dimension and np readable elements in
 // gamma / beta -- lets the kernels use branch-free clamped float4 loads (all of a row's loads in flight at once)
 struct LnFwdProblem { const float* x; int ldx; const float* gamma; const float* beta; float* y; int ldy; float* stats;
-                      int rows, n, vx, vy, vp, np;
-                      char* y3; };      // nullable: also emit the P3 image of y (p3.h; n % 4 == 0, ldy % 32 == 0)
+                      int rows, n, vx, vy, vp, np; };
 constexpr int LN_MAX_GROUP = 6;
 struct LnFwdGroup { LnFwdProblem p[LN_MAX_GROUP]; int n; };
 hipError_t launch_ln_tanh_fwd_group(LnFwdGroup g, hipStream_t s);
 struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const float* x; int ldx; const float* stats;
                       const float* gamma; float* dx; int lddx; float* dgamma; float* dbeta; float* partials;
-                      int rows, n, vdy, vy, vx, vdx, vp, np;
-                      char* dx3; };     // nullable: also emit the P3 image of dx
+                      int rows, n, vdy, vy, vx, vdx, vp, np; };
 struct LnBwdGroup { LnBwdProblem p[LN_MAX_GROUP]; int n; };
 // defer != nullptr: the column reduce of (d gamma, d beta) is NOT launched; its jobs are appended to *defer for
 // launch_splitk_reduce (bit-identical result: same partials, same fold order)
@@ -274,7 +272,7 @@ struct GemvGroup { GemvProblem p[GEMV_MAX_GROUP]; int n; };
 hipError_t launch_gemv_group(GemvGroup g, hipStream_t s);
 hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
                            int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
-                           Squash sq, hipStream_t s);
+                           Squash sq, hipStream_t s, const float* stddev_dev = nullptr /* device-resident stddev (replayable graphs) */);
 hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s);
 
 // ---- sampler -----------------------------------------------------------------------------------------------

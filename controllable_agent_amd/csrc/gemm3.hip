@@ -89,11 +89,15 @@ hipError_t gemm3_init() {
     return hipSuccess;
 }
 
-// operands as whole 192-byte blocks: leading dimensions multiples of 32 floats, K a multiple of the 32-deep chunk
+// An operand is staged either from its P3 image (whole 192-byte blocks: leading dimension a multiple of 32 floats) or from fp32
+// (16-byte aligned rows); K is a multiple of the 32-deep chunk either way
 bool gemm3_problem_ok(const GemmProblem& p) {
-    return p.A3 != nullptr && p.B3 != nullptr && (p.lda & 31) == 0 && (p.ldb & 31) == 0 && p.K >= 32 && (p.K & 31) == 0 &&
-           ((uintptr_t)p.A3 & 15) == 0 && ((uintptr_t)p.B3 & 15) == 0 && (p.C3 == nullptr || ((p.ldc & 31) == 0 && ((uintptr_t)p.C3 & 15) == 0)) &&
-           (p.a_kcontig || (p.M & 31) == 0 || p.lda >= ((p.M + 31) & ~31)) && (p.b_kcontig || (p.N & 31) == 0 || p.ldb >= ((p.N + 31) & ~31));
+    auto operand_ok = [](const float* x, const char* x3, int ld, int kcontig, int nr) {
+        if (x3 != nullptr) return (ld & 31) == 0 && ((uintptr_t)x3 & 15) == 0 && (kcontig || (nr & 31) == 0 || ld >= ((nr + 31) & ~31));
+        return x != nullptr && ((uintptr_t)x & 15) == 0 && (ld & 3) == 0 && ld >= 4 && (kcontig || nr >= 4);
+    };
+    return operand_ok(p.A, p.A3, p.lda, p.a_kcontig, p.M) && operand_ok(p.B, p.B3, p.ldb, p.b_kcontig, p.N) && p.K >= 32 && (p.K & 31) == 0 &&
+           (p.C3 == nullptr || ((p.ldc & 31) == 0 && ((uintptr_t)p.C3 & 15) == 0));
 }
 
 void gemm3_problem_finalize(GemmProblem& p, int cfg) {

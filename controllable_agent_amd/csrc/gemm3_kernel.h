@@ -31,6 +31,8 @@
 #include "common.h"
 #include "p3.h"
 
+#include <type_traits>
+
 namespace fbhip {
 
 // -DG3_KNOCK (tools/gemm3_probe.hip only): a runtime mask that removes one pipeline stage at a time -- 1 no DMA issue, 2 no MFMA,
@@ -313,6 +315,131 @@ __device__ __forceinline__ void g3_store_tile(const GemmProblem& p, const floatx
             }
 }
 
+// ---- producers ------------------------------------------------------------------------------------------------------------
+// One operand tile of R rows per chunk = R blocks of 192 bytes in the chunk buffer at ``lds_op`` (layouts: file header).  Two
+// producer waves share an operand, half each (pw = 0 / 1).  Both variants keep the same cadence: one "init" barrier once chunk 0
+// is in LDS, then at barrier ``it`` chunk it + 1 is in LDS.
+
+// P3 image -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, ring of S chunks, counted vmcnt)
+template <int R, int S, int STAGE>
+__device__ __forceinline__ void g3_produce_dma(const char* __restrict__ base, int ld, bool kc, int r0, int nr, int kb, int nt, int pw,
+                                               int lane, char* __restrict__ lds_op G3_KARG) {
+    constexpr int P = R * P3_BLOCK_BYTES / 1024 / 2;           // pieces per wave and chunk
+    constexpr int NB = R / 32;
+    const char* src[P];
+    size_t adv[P];
+    const size_t rowblocks = (size_t)(ld / P3_BLOCK);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int slot = (pw * P + q) * 64 + lane, bs = slot / 12, gq = slot % 12;
+        if (kc) {
+            const int r = bs, pl = gq >> 2, q4 = (gq & 3) ^ ((r >> 2) & 3);
+            const int grow = min(r0 + r, nr - 1);
+            src[q] = base + ((size_t)grow * rowblocks + kb / P3_BLOCK) * P3_BLOCK_BYTES + 64 * pl + 16 * q4;
+            adv[q] = (size_t)P3_BLOCK_BYTES;
+        } else {
+            const int kk = 4 * (bs / (4 * NB)) + (bs & 3), nb = (bs >> 2) % NB;
+            const int cb = min(r0 / P3_BLOCK + nb, (nr - 1) / P3_BLOCK);
+            src[q] = base + ((size_t)(kb + kk) * rowblocks + cb) * P3_BLOCK_BYTES + 16 * gq;
+            adv[q] = (size_t)32 * rowblocks * P3_BLOCK_BYTES;
+        }
+    }
+    char* const dst = lds_op + (size_t)(pw * P) * 1024;
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        char* d = dst + (size_t)(c % S) * STAGE;
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (!G3_KNOCKED(1)) g3_glds16(src[q] + (size_t)c * adv[q], d + q * 1024);
+    };
+    for (int c = 0; c < S && c < nt; ++c) issue(c);
+    g3_wait_chunks<P, S - 1>(nt - 1);                          // barrier "init": chunk 0 landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int it = 0; it < nt; ++it) {
+        g3_wait_chunks<P, S - 2>(nt - 2 - it);                 // chunk it + 1 landed; later ones stay in flight
+        __builtin_amdgcn_s_barrier();                           // raw: a fence would drain the DMAs
+        asm volatile("" ::: "memory");
+        if (it + S < nt) issue(it + S);                         // the consumers retired their reads of chunk ``it`` before this barrier
+    }
+}
+
+// fp32 -> registers -> three bf16 planes -> LDS: the operand is an activation / gradient panel that exists in fp32 only.  Per chunk
+// and wave Q float4 loads of whole 128-byte lines, ~22 VALU per float4 for the split, 3 ds_write_b64 per float4; the loads of
+// chunk it + 2 are in flight while chunk it + 1 is split and written (straight-line code: hipcc emits counted vmcnt).
+template <int R, int S, int STAGE>
+__device__ __forceinline__ void g3_produce_f32(const float* __restrict__ base, int ld, bool kc, int r0, int nr, int kb, int nt, int pw,
+                                               int lane, char* __restrict__ lds_op) {
+    constexpr int NB = R / 32;
+    constexpr int Q = R / 16;                                   // float4 per lane and chunk (half a tile per wave)
+    constexpr int LPR = R / 4, RPI = 64 / LPR;                  // k-strided: lanes per k-row, k-rows per instruction
+    const float* src[Q];
+    int dsto[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        if (kc) {
+            const int r = pw * (R / 2) + 8 * i + (lane >> 3), kq = lane & 7;
+            src[i] = base + (size_t)min(r0 + r, nr - 1) * ld + kb + 4 * kq;
+            dsto[i] = P3_BLOCK_BYTES * r + 16 * ((kq >> 1) ^ ((r >> 2) & 3)) + 8 * (kq & 1);
+        } else {
+            const int k = pw * 16 + i * RPI + lane / LPR, n = 4 * (lane % LPR);
+            src[i] = base + (size_t)(kb + k) * ld + min(r0 + n, (nr - 1) & ~3);
+            dsto[i] = P3_BLOCK_BYTES * ((k >> 2) * 4 * NB + 4 * (n >> 5) + (k & 3)) + 2 * (n & 31);
+        }
+    }
+    const size_t adv = kc ? (size_t)32 : (size_t)32 * ld;
+    auto load = [&](int c, float4 (&x)[Q]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) x[i] = *reinterpret_cast<const float4*>(src[i] + (size_t)c * adv);
+    };
+    auto store = [&](int c, const float4 (&x)[Q]) __attribute__((always_inline)) {
+        char* d = lds_op + (size_t)(c % S) * STAGE;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const P3Triple a = p3_split(x[i].x), b = p3_split(x[i].y), cc = p3_split(x[i].z), e = p3_split(x[i].w);
+            *reinterpret_cast<uint2*>(d + dsto[i]) = make_uint2((unsigned)a.h | ((unsigned)b.h << 16), (unsigned)cc.h | ((unsigned)e.h << 16));
+            *reinterpret_cast<uint2*>(d + dsto[i] + 64) = make_uint2((unsigned)a.m | ((unsigned)b.m << 16), (unsigned)cc.m | ((unsigned)e.m << 16));
+            *reinterpret_cast<uint2*>(d + dsto[i] + 128) = make_uint2((unsigned)a.l | ((unsigned)b.l << 16), (unsigned)cc.l | ((unsigned)e.l << 16));
+        }
+    };
+    // step ``it``: request chunk it + 2 into ``la``, land chunk it + 1 (in flight in ``sa``) in its buffer, meet at barrier ``it``
+    auto p_step = [&](int it, auto do_load, auto do_store, float4 (&la)[Q], const float4 (&sa)[Q]) __attribute__((always_inline)) {
+        if constexpr (decltype(do_load)::value) load(it + 2, la);
+        if constexpr (decltype(do_store)::value) store(it + 1, sa);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+    float4 x0[Q], x1[Q];
+    load(0, x0);
+    if (nt > 1) load(1, x1);
+    else {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) x1[i] = x0[i];
+    }
+    store(0, x0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                               // barrier "init": chunk 0 visible
+    asm volatile("" ::: "memory");
+    int it = 0;
+    for (; it + 3 < nt; it += 2) {
+        p_step(it, T, T, x0, x1);
+        p_step(it + 1, T, T, x1, x0);
+    }
+    const int rem = nt - it;                                    // 1, 2 or 3 steps left
+    if (rem == 3) {
+        p_step(it, T, T, x0, x1);
+        p_step(it + 1, F, T, x1, x0);
+        p_step(it + 2, F, F, x0, x1);
+    } else if (rem == 2) {
+        p_step(it, F, T, x0, x1);
+        p_step(it + 1, F, F, x1, x0);
+    } else {
+        p_step(it, F, F, x0, x1);
+    }
+}
+
 template <int TM, int TN, int S>
 __global__ void __launch_bounds__(512) gemm3_kernel(const GemmGroup g) {
     using G = G3Geom<TM, TN, S>;
@@ -346,47 +473,15 @@ __global__ void __launch_bounds__(512) gemm3_kernel(const GemmGroup g) {
 
     if (wid >= 4) {
         // =========================================================================================== PRODUCERS
-        const int w = wid - 4;
-        const char* src[G::P];
-        size_t adv[G::P];
-#pragma unroll
-        for (int q = 0; q < G::P; ++q) {
-            const int pc = w * G::P + q;
-            const bool isA = pc < G::PA;
-            const int po = isA ? pc : pc - G::PA;
-            const char* base = isA ? p.A3 : p.B3;
-            const int ld = isA ? p.lda : p.ldb, kc = isA ? p.a_kcontig : p.b_kcontig;
-            const int r0 = isA ? row0 : col0, nr = isA ? M : N, NB = (isA ? BM : BN) / 32;
-            const int slot = po * 64 + lane, bs = slot / 12, gq = slot % 12;
-            const size_t rowblocks = (size_t)(ld / P3_BLOCK);
-            if (kc) {
-                const int r = bs, pl = gq >> 2, q4 = (gq & 3) ^ ((r >> 2) & 3);
-                const int grow = min(r0 + r, nr - 1);
-                src[q] = base + ((size_t)grow * rowblocks + kb / P3_BLOCK) * P3_BLOCK_BYTES + 64 * pl + 16 * q4;
-                adv[q] = (size_t)P3_BLOCK_BYTES;
-            } else {
-                const int kk = 4 * (bs / (4 * NB)) + (bs & 3), nb = (bs >> 2) % NB;
-                const int cb = min(r0 / P3_BLOCK + nb, (nr - 1) / P3_BLOCK);
-                src[q] = base + ((size_t)(kb + kk) * rowblocks + cb) * P3_BLOCK_BYTES + 16 * gq;
-                adv[q] = (size_t)BK * rowblocks * P3_BLOCK_BYTES;
-            }
-        }
-        char* const dst = smem3 + (size_t)(w * G::P) * 1024;
-        auto issue = [&](int c) __attribute__((always_inline)) {
-            char* d = dst + (size_t)(c % S) * G::STAGE;
-#pragma unroll
-            for (int q = 0; q < G::P; ++q)
-                if (!G3_KNOCKED(1)) g3_glds16(src[q] + (size_t)c * adv[q], d + q * 1024);
-        };
-        for (int c = 0; c < S && c < nt; ++c) issue(c);
-        g3_wait_chunks<G::P, S - 1>(nt - 1);                     // barrier "init": chunk 0 landed
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (int it = 0; it < nt; ++it) {
-            g3_wait_chunks<G::P, S - 2>(nt - 2 - it);            // chunk it + 1 landed; later ones stay in flight
-            __builtin_amdgcn_s_barrier();                         // raw: a fence would drain the DMAs
-            asm volatile("" ::: "memory");
-            if (it + S < nt) issue(it + S);                       // the consumers retired their reads of chunk ``it`` before this barrier
+        // waves 4, 5 stage operand A, waves 6, 7 operand B (half a tile each); per operand either the LDS-DMA path (a P3 image
+        // exists: parameters) or the register path (fp32 activations / gradient panels: load, split, ds_write)
+        const int w = wid - 4, pw = w & 1;
+        if (w < 2) {
+            if (p.A3 != nullptr) g3_produce_dma<BM, S, G::STAGE>(p.A3, p.lda, p.a_kcontig != 0, row0, M, kb, nt, pw, lane, smem3 G3_KPASS);
+            else g3_produce_f32<BM, S, G::STAGE>(p.A, p.lda, p.a_kcontig != 0, row0, M, kb, nt, pw, lane, smem3);
+        } else {
+            if (p.B3 != nullptr) g3_produce_dma<BN, S, G::STAGE>(p.B3, p.ldb, p.b_kcontig != 0, col0, N, kb, nt, pw, lane, smem3 + G::A_BYTES G3_KPASS);
+            else g3_produce_f32<BN, S, G::STAGE>(p.B, p.ldb, p.b_kcontig != 0, col0, N, kb, nt, pw, lane, smem3 + G::A_BYTES);
         }
         return;
     }

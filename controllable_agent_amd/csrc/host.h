@@ -119,14 +119,11 @@ IcmP icm_p(float* base, const NetLayout& L);
 BwdP mu_p(float* base, const NetLayout& L);               // svd_p's mu_net (same module structure as BackwardMap.B, no projection)
 ActP act_p(float* base, const NetLayout& L);
 
-// ---- P3 images (p3.h) of the GEMM operands --------------------------------------------------------------------------------
-// A shadowed region [lo, lo + bytes) of fp32 memory has its P3 image at shadow + 1.5 x offset: the workspace (activations,
-// gradient panels), the FB parameters, the FB targets and the actor parameters.  The shadows live behind the two workspace sets in
-// the caller's workspace allocation (fbhip_workspace_bytes covers them).
+// ---- P3 images (p3.h) of the parameter buffers ----------------------------------------------------------------------------------
+// A shadowed region [lo, lo + bytes) of fp32 parameters has its three-plane bf16 image at shadow + 1.5 x offset: FB parameters, FB
+// targets, actor parameters.  The shadows live behind the two workspace sets in the caller's workspace allocation
+// (fbhip_workspace_bytes covers them).
 struct P3Region { const char* lo; size_t bytes; char* shadow; bool weights; };
-// a view whose planes are current: written by a producer that emits them (gemm3's epilogue, the LayerNorm kernels, a split job)
-// and not overwritten since by a kernel that does not
-struct P3Rect { const float* p; int rows, cols, ld; };
 
 struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; int set;
                     bool branches = false;                 // parallel branches: launched through launch_graph's high-priority stream (api.hip)
@@ -171,12 +168,9 @@ struct fbhip_ctx {
     fbhip::Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
     std::function<int(const fbhip::PolicyHeadJobs&, hipStream_t)> run_policy_heads;   // set by the update that declares Ops::ph
     fbhip::ColReduceJobs cr_pending{};              // LayerNorm column reduces waiting for the next split-K reduce launch (flush_round)
-    // P3 GEMM state (schedule.hip::run_gemms): shadow map, which views have current planes, which buffers only plane-emitting
-    // kernels ever write (they survive the conservative reset after an opaque row kernel)
+    // P3 GEMM (schedule.hip::run_gemms): where the parameters' three-plane images live
     std::vector<fbhip::host::P3Region> p3r;
-    std::vector<fbhip::host::P3Rect> p3_fresh;
-    std::vector<std::pair<const float*, const float*>> p3_immune;
-    int p3_mode = 1;                                // FBHIP_P3: 0 off, 1 on for fat problems, 2 on for every eligible problem (tests)
+    int p3_mode = 0;                                // FBHIP_P3: 0 off (default), 1 on where the launch estimate wins, 2 on for every eligible problem (tests)
     std::string err;
 };
 
@@ -241,13 +235,9 @@ int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float
 int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s);
 int enqueue_actor_v(fbhip_ctx* c, hipStream_t s);
 int check_hparams(fbhip_ctx* c, const fbhip_hparams* hp);
-// P3 bookkeeping (schedule.hip)
-char* p3_of(fbhip_ctx* c, const float* p, bool* weights = nullptr);       // P3 address of a block-aligned fp32 address, or nullptr
-void p3_mark(fbhip_ctx* c, const float* p, int rows, int cols, int ld);    // planes of this view are current
-void p3_touch(fbhip_ctx* c, const float* p, int rows, int cols, int ld);   // the view was rewritten WITHOUT planes
-void p3_opaque(fbhip_ctx* c);                                              // a kernel with unknown outputs ran
+// P3 images of the parameters (schedule.hip)
+char* p3_of(fbhip_ctx* c, const float* p, bool* weights = nullptr);       // image address of a block-aligned parameter address, or nullptr
 int p3_split_params(fbhip_ctx* c, hipStream_t s);                          // fp32 -> P3 of every parameter / target buffer
-std::vector<Buf> p3_immune_bufs(const Ws& w);                              // layout.hip: buffers only GEMM epilogues / LayerNorm kernels write
 int need_bound(fbhip_ctx* c, bool replay);
 
 }  // namespace host

@@ -96,12 +96,16 @@ __global__ void __launch_bounds__(256) gemv_kernel(const GemvGroup g) {
 //   mu = tanh(W4 p + b4);  eval: action = mu;  else action = clamp(mu + stddev * eps, +-(1 - 1e-6))   (sample(clip=None))
 // eps: ``noise`` when given (parity tests), else Philox keyed by the agent's seed and a device-side act counter.
 __global__ void __launch_bounds__(256) act_head_kernel(const float* __restrict__ x, const float* __restrict__ W, int ldw,
-                                                       const float* __restrict__ bias, int a, int K, float stddev,
-                                                       int eval_mode, const float* __restrict__ noise, unsigned k0,
+                                                       const float* __restrict__ bias, int a, int K, float stddev_arg,
+                                                       const float* __restrict__ stddev_dev, int eval_mode,
+                                                       const float* __restrict__ noise, unsigned k0,
                                                        unsigned k1, StepState* __restrict__ st, float* __restrict__ out,
                                                        const Squash sq) {
     __shared__ float pre[64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // (the batch-1 graph reads the exploration stddev from its staged inputs: a schedule-driven stddev then replays ONE graph
+    // instead of capturing a new one per value)
+    const float stddev = stddev_dev != nullptr ? *stddev_dev : stddev_arg;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const int nout = sq.on ? 2 * a : a;            // DiagGaussianActor: [loc | raw log-std]
     for (int n = wid; n < nout; n += 4) {
@@ -189,10 +193,10 @@ hipError_t launch_gemv_group(GemvGroup g, hipStream_t s) {
 
 hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
                            int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
-                           Squash sq, hipStream_t s) {
+                           Squash sq, hipStream_t s, const float* stddev_dev) {
     if ((sq.on ? 2 * a : a) > 64 || (K & 3) || (ldw & 3)) return hipErrorInvalidValue;
     const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
-    hipLaunchKernelGGL(act_head_kernel, dim3(1), dim3(256), 0, s, x, W, ldw, bias, a, K, stddev, eval_mode, noise, k0, k1, st,
+    hipLaunchKernelGGL(act_head_kernel, dim3(1), dim3(256), 0, s, x, W, ldw, bias, a, K, stddev, stddev_dev, eval_mode, noise, k0, k1, st,
                        out, sq);
     return hipGetLastError();
 }

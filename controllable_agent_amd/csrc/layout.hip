@@ -314,17 +314,6 @@ Ws carve(const fbhip_dims& d, void* base) {
     return w;
 }
 
-// Buffers that only plane-emitting kernels ever write (gemm3's ReLU epilogues, the LayerNorm kernels): the forward activation
-// sets.  Their P3 images stay current across row kernels (schedule.hip::p3_opaque); every other buffer's image is re-made on demand.
-std::vector<Buf> p3_immune_bufs(const Ws& w) {
-    std::vector<Buf> v;
-    for (const FSet* s : {&w.fsT, &w.fsO}) { v.push_back(s->t1a); v.push_back(s->t1z); v.push_back(s->h); v.push_back(s->tr); v.push_back(s->p); }
-    for (const ASet* s : {&w.as, &w.asT}) { v.push_back(s->t1o); v.push_back(s->t1z); v.push_back(s->h); v.push_back(s->tr); v.push_back(s->p); }
-    for (const BSet* s : {&w.bsA, &w.bsO, &w.bsM, &w.bsF, &w.bsS}) { v.push_back(s->t1); v.push_back(s->r2); }
-    for (const Buf* b : {&w.ih1, &w.ih2}) v.push_back(*b);
-    return v;
-}
-
 // ------------------------------------------------------------------------------------------------ weights
 
 TrunkP trunk_p(float* base, const NetLayout& L, const std::string& p) {

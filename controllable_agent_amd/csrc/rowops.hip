@@ -54,15 +54,6 @@ __device__ __forceinline__ float4 ld4c(const float* __restrict__ row, int n0, in
     return *reinterpret_cast<const float4*>(row + (n0 < np ? n0 : np - 4));
 }
 
-// the P3 image (p3.h) of 4 consecutive elements starting at column n0 (a multiple of 4) of a row with leading dimension ld
-__device__ __forceinline__ void st4_p3(char* __restrict__ y3, size_t row, int n0, int ld, float4 o) {
-    const P3Triple a = p3_split(o.x), b = p3_split(o.y), c = p3_split(o.z), d = p3_split(o.w);
-    char* dst = y3 + p3_offset(row, (size_t)n0, (size_t)ld);
-    *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)a.h | ((unsigned)b.h << 16), (unsigned)c.h | ((unsigned)d.h << 16));
-    *reinterpret_cast<uint2*>(dst + 64) = make_uint2((unsigned)a.m | ((unsigned)b.m << 16), (unsigned)c.m | ((unsigned)d.m << 16));
-    *reinterpret_cast<uint2*>(dst + 128) = make_uint2((unsigned)a.l | ((unsigned)b.l << 16), (unsigned)c.l | ((unsigned)d.l << 16));
-}
-
 static inline bool aligned16(const void* p, int ld) { return (((uintptr_t)p & 15) == 0) && ((ld & 3) == 0); }
 
 // ------------------------------------------------------------------------------------------------------
@@ -119,7 +110,6 @@ __global__ void __launch_bounds__(256) ln_tanh_fwd_kernel(const LnFwdGroup g) {
             } else {
                 st4(yr, n0, n, vy, o);
             }
-            if (p.y3 != nullptr) st4_p3(p.y3, (size_t)row, n0, ldy, mask4(o, n0, n));
         }
     }
     if (lane == 0) {
@@ -236,7 +226,6 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const LnBwdGroup grp) 
                         o.z = rstd[rr] * (g[i].z - m1 - xh[i].z * m2);
                         o.w = rstd[rr] * (g[i].w - m1 - xh[i].w * m2);
                         *reinterpret_cast<float4*>(dxr + n0) = mask4(o, n0, n);     // pad columns [n, np) stay zero
-                        if (p.dx3 != nullptr) st4_p3(p.dx3, (size_t)rowi[rr], n0, p.lddx, mask4(o, n0, n));
                     }
                 }
             }
@@ -280,7 +269,6 @@ __global__ void __launch_bounds__(256) ln_tanh_bwd_kernel(const LnBwdGroup grp) 
                 o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
                 o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
                 st4(dxr, n0, n, p.vdx, o);
-                if (p.dx3 != nullptr && n0 < n) st4_p3(p.dx3, (size_t)row, n0, p.lddx, mask4(o, n0, n));
             }
         }
     }

@@ -21,13 +21,11 @@ GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc
     return p;
 }
 
-// ---- P3 operands (p3.h, gemm3.hip) ------------------------------------------------------------------------------------------
-// Which fp32 addresses have a P3 image, and which views' images are CURRENT.  The images of the parameters are always current
-// (every graph starts with p3_split_params, the optimiser pass keeps them so); a workspace view's image is current from the moment a
-// plane-emitting producer wrote it (gemm3's epilogue, the LayerNorm kernels, a split job) until a kernel that writes fp32 only
-// touches it.  Row kernels are opaque here: after one has run, only the buffers that no row kernel ever writes (the forward
-// activation sets: p3_immune_bufs) keep their mark.  An operand without a current image gets a split job right before the launch
-// that stages it, so a stale image can never be read -- the bookkeeping only decides how often the split is paid.
+// ---- P3 images of the parameters (p3.h, gemm3.hip) ------------------------------------------------------------------------------
+// gemm3_kernel stages the WEIGHT operand of a GEMM from its three-plane bf16 image by LDS-DMA; activations and gradient panels
+// stay fp32 (the kernel's staging waves split them on the way into LDS).  A parameter buffer's image lives at shadow + 1.5 x offset
+// (fbhip_bind_buffers); every update entry point rebuilds the images (the host may have written parameters through its views)
+// and the optimiser pass keeps them current from then on.
 char* p3_of(fbhip_ctx* c, const float* p, bool* weights) {
     if (c == nullptr || c->p3_mode == 0) return nullptr;
     for (const P3Region& r : c->p3r) {
@@ -42,66 +40,7 @@ char* p3_of(fbhip_ctx* c, const float* p, bool* weights) {
     return nullptr;
 }
 
-static bool p3_rect_covers(const P3Rect& r, const float* p, int rows, int cols, int ld, int* covered) {
-    if (r.ld != ld || p < r.p) return false;
-    const size_t off = (size_t)(p - r.p);
-    const int row_off = (int)(off / (size_t)ld), col_off = (int)(off % (size_t)ld);
-    if (row_off + rows > r.rows || col_off >= r.cols) return false;
-    *covered = r.cols - col_off;
-    return true;
-}
-
-static bool p3_is_fresh(fbhip_ctx* c, const float* p, int rows, int cols, int ld) {
-    while (cols > 0) {
-        int got = 0;
-        bool hit = false;
-        for (const P3Rect& r : c->p3_fresh)
-            if (p3_rect_covers(r, p, rows, cols, ld, &got)) { hit = true; break; }
-        if (!hit) return false;
-        p += got; cols -= got;
-    }
-    return true;
-}
-
-// do two views share an element?  (same leading dimension: compare row and column ranges; else: address ranges, conservatively)
-static bool p3_overlaps(const P3Rect& r, const float* p, int rows, int cols, int ld) {
-    const float* lo = p; const float* hi = p + (size_t)(rows - 1) * ld + cols;
-    const float* rlo = r.p; const float* rhi = r.p + (size_t)(r.rows - 1) * r.ld + r.cols;
-    if (!(lo < rhi && rlo < hi)) return false;
-    if (r.ld != ld) return true;
-    const ptrdiff_t d = p - r.p;                               // position of the view's (0, 0) in r's coordinates
-    ptrdiff_t rs = d / ld, cs = d % ld;
-    if (cs < 0) { cs += ld; rs -= 1; }
-    if (cs + cols > ld) return true;                           // wraps around a row end: not a column sub-view, be conservative
-    const bool rows_meet = rs < r.rows && rs + rows > 0;
-    const bool cols_meet = cs < r.cols && cs + cols > 0;
-    return rows_meet && cols_meet;
-}
-
-void p3_touch(fbhip_ctx* c, const float* p, int rows, int cols, int ld) {
-    if (c == nullptr || c->p3_fresh.empty()) return;
-    auto& v = c->p3_fresh;
-    v.erase(std::remove_if(v.begin(), v.end(), [&](const P3Rect& r) { return p3_overlaps(r, p, rows, cols, ld); }), v.end());
-}
-
-void p3_mark(fbhip_ctx* c, const float* p, int rows, int cols, int ld) {
-    if (c == nullptr) return;
-    p3_touch(c, p, rows, cols, ld);
-    c->p3_fresh.push_back(P3Rect{p, rows, cols, ld});
-}
-
-void p3_opaque(fbhip_ctx* c) {
-    if (c == nullptr) return;
-    auto& v = c->p3_fresh;
-    v.erase(std::remove_if(v.begin(), v.end(), [&](const P3Rect& r) {
-        for (auto& im : c->p3_immune)
-            if (r.p >= im.first && r.p < im.second) return false;
-        return true;
-    }), v.end());
-}
-
 int p3_split_params(fbhip_ctx* c, hipStream_t s) {
-    c->p3_fresh.clear();                         // an entry point starts here: what earlier calls (or the host) left in the workspace is unknown
     if (c->p3_mode == 0) return FBHIP_OK;
     P3SplitJobs jobs{};
     for (const P3Region& r : c->p3r) {
@@ -118,64 +57,49 @@ int p3_split_params(fbhip_ctx* c, hipStream_t s) {
 
 float* splitk_slab(fbhip_ctx* c) { return (c && c->W().splitk) ? c->W().splitk : nullptr; }
 
-// the problems of a round that run on gemm3_kernel: split jobs for operands without a current image, one tile configuration per
-// launch chosen by a cost model of the launch (waves of workgroups x time of a tile), up to MAX_GROUP problems per launch
-static int run_gemms_p3(fbhip_ctx* ctx, std::vector<GemmProblem>& v, hipStream_t s) {
-    // ---- operand images
-    P3SplitJobs jobs{};
-    auto flush_jobs = [&]() -> int {
-        if (jobs.n > 0) HIPCK(ctx, launch_p3_split_group(jobs, s));
-        jobs.n = 0;
-        return FBHIP_OK;
-    };
-    auto need = [&](const float* X, int rows, int cols, int ld) -> int {
-        bool weights = false;
-        char* x3 = p3_of(ctx, X, &weights);
-        if (weights) return FBHIP_OK;                          // kept current by p3_split_params + the optimiser pass
-        cols = (cols + 31) & ~31;                              // whole blocks (pad columns are zeros in fp32 too)
-        if (p3_is_fresh(ctx, X, rows, cols, ld)) return FBHIP_OK;
-        jobs.j[jobs.n++] = P3SplitJob{X, x3, rows, cols, ld, 0};
-        p3_mark(ctx, X, rows, cols, ld);
-        if (jobs.n == P3_SPLIT_MAX) RC(flush_jobs());
-        return FBHIP_OK;
-    };
-    for (auto& p : v) {
-        RC(p.a_kcontig ? need(p.A, p.M, p.K, p.lda) : need(p.A, p.K, p.M, p.lda));
-        RC(p.b_kcontig ? need(p.B, p.N, p.K, p.ldb) : need(p.B, p.K, p.N, p.ldb));
-    }
-    RC(flush_jobs());
-    // ---- tile configuration: estimated launch time = waves of workgroups over the 256 CUs x mean time of a tile
-    // (per 32-deep chunk / per epilogue, us, from tools/gemm3_probe.hip on MI355X; one workgroup per CU at a time)
-    static const double chunk_us[G3_CFG_COUNT] = {1.45, 0.85, 0.85, 0.55}, epi_us[G3_CFG_COUNT] = {6.0, 4.0, 4.0, 3.0};
-    int cfg = G3_64x64;
-    double best = 1e30;
-    for (int c = 0; c < G3_CFG_COUNT; ++c) {
-        const int bm = gemm3_cfg_bm(c), bn = gemm3_cfg_bn(c);
-        double tiles = 0, work = 0;
-        for (auto& p : v) {
-            const double t = (double)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-            tiles += t;
-            work += t * ((p.K / 32) * chunk_us[c] + epi_us[c]);
+// ---- the P3 GEMM inside a round -----------------------------------------------------------------------------------------------
+// Estimated time of a gemm3 launch of these problems with tile configuration ``cfg``: workgroups are dispatched in launch order
+// to whichever of the 256 CUs frees first (one 8-wave workgroup per CU: 108-144 KiB of LDS), a tile costs chunks x t_chunk + t_epi
+// (us; tools/gemm3_probe.hip on MI355X).  Problems are launched longest-K first.
+static double gemm3_estimate_us(const std::vector<GemmProblem>& v, int cfg) {
+    static const double chunk_us[G3_CFG_COUNT] = {1.40, 0.80, 0.80, 0.52}, epi_us[G3_CFG_COUNT] = {7.0, 4.5, 4.5, 3.5};
+    const int bm = gemm3_cfg_bm(cfg), bn = gemm3_cfg_bn(cfg);
+    std::vector<double> cu(256, 0.0);
+    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
+    double end = 0;
+    for (const GemmProblem& p : v) {
+        const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+        const double t = (p.K / 32) * chunk_us[cfg] + epi_us[cfg];
+        for (long i = 0; i < tiles; ++i) {
+            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
+            cu.back() += t;
+            end = std::max(end, cu.back());
+            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
         }
-        const double est = std::ceil(tiles / 256.0) * (work / tiles);
-        if (est < best) { best = est; cfg = c; }
     }
-    std::stable_sort(v.begin(), v.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.K > b.K; });
+    return end + 3.0;
+}
+
+// what the fp32-MFMA kernel needs for the same problems as one grouped launch (measured rates of the step's own launches)
+static double legacy_estimate_us(const std::vector<GemmProblem>& v) {
+    double fl = 0;
+    for (const GemmProblem& p : v) fl += 2.0 * p.M * p.N * p.K;
+    const double rate = fl >= 4e9 ? 104e12 : fl >= 2e9 ? 82e12 : fl >= 1e9 ? 60e12 : 40e12;
+    return fl / rate * 1e6 + 4.0;
+}
+
+static int run_gemms_p3(fbhip_ctx* ctx, std::vector<GemmProblem>& v, int cfg, hipStream_t s) {
     for (size_t i = 0; i < v.size();) {
         GemmGroup g{};
         int start = 0;
         while (i < v.size() && g.n < MAX_GROUP) {
             GemmProblem p = v[i++];
             p.kslices = 1;
+            p.C3 = nullptr;                      // activations stay fp32: the consumer's producer waves split them while staging
             gemm3_problem_finalize(p, cfg);
-            // the image of C is emitted where another GEMM stages it next: ReLU outputs (hidden activations) and ReLU-masked
-            // data gradients; plain-bias outputs feed row kernels (LayerNorm, heads), weight gradients feed the optimiser
-            p.C3 = (p.epi == EPI_BIAS_RELU || p.epi == EPI_MASK_RELU) && (p.ldc & 31) == 0 ? p3_of(ctx, p.C) : nullptr;
             p.tile_start = start;
             start += p.tiles_m * p.tiles_n;
             g.p[g.n++] = p;
-            if (p.C3 != nullptr) p3_mark(ctx, p.C, p.M, (p.N + 31) & ~31, p.ldc);
-            else p3_touch(ctx, p.C, p.M, p.N, p.ldc);
         }
         g.total_tiles = start;
         static const bool log_launches = [] { const char* e = getenv("FBHIP_GEMM_LOG"); return e && e[0] == '1'; }();
@@ -193,22 +117,38 @@ static int run_gemms_p3(fbhip_ctx* ctx, std::vector<GemmProblem>& v, hipStream_t
 
 int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     if (ctx != nullptr && ctx->p3_mode != 0 && !ctx->p3r.empty()) {
-        // problems whose operands are whole P3 blocks go to gemm3_kernel (six bf16 MFMA products per block, fp32 accuracy);
-        // thin / ragged / unaligned ones stay on the fp32 MFMA kernel below (mode 2, tests: every eligible problem moves)
+        // The fat problems of a round go to gemm3_kernel (six bf16 MFMA products per block, fp32 accuracy) when its estimated
+        // launch time beats the fp32-MFMA kernel's: parameters are staged from their P3 images (kept current by the optimiser
+        // pass), activations and gradient panels from fp32 with the split done by the staging waves.  Thin / ragged problems stay
+        // below.  (FBHIP_P3=2, tests: every eligible problem moves, whatever the estimate.)
         std::vector<GemmProblem> p3, rest;
         for (auto& p : v) {
             GemmProblem q = p;
-            q.A3 = p3_of(ctx, p.A); q.B3 = p3_of(ctx, p.B); q.C3 = nullptr;
+            bool wa = false, wb = false;
+            char* a3 = p3_of(ctx, p.A, &wa);
+            char* b3 = p3_of(ctx, p.B, &wb);
+            q.A3 = wa ? a3 : nullptr; q.B3 = wb ? b3 : nullptr; q.C3 = nullptr;
+            if (q.A3 != nullptr && (p.lda & 31)) q.A3 = nullptr;
+            if (q.B3 != nullptr && (p.ldb & 31)) q.B3 = nullptr;
             const bool fat = ctx->p3_mode == 2 || (p.M >= 128 && p.N >= 128 && p.K >= 128);
-            if (fat && q.A3 != nullptr && q.B3 != nullptr && gemm3_problem_ok(q)) p3.push_back(q);
+            if (fat && gemm3_problem_ok(q)) p3.push_back(q);
             else rest.push_back(p);
         }
-        if (!p3.empty()) RC(run_gemms_p3(ctx, p3, s));
-        if (rest.empty()) return FBHIP_OK;
-        v.swap(rest);
+        if (!p3.empty()) {
+            std::stable_sort(p3.begin(), p3.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.K > b.K; });
+            int cfg = G3_64x64;
+            double best = 1e30;
+            for (int c = 0; c < G3_CFG_COUNT; ++c) {
+                const double est = gemm3_estimate_us(p3, c);
+                if (est < best) { best = est; cfg = c; }
+            }
+            if (ctx->p3_mode == 2 || best < legacy_estimate_us(p3)) {
+                RC(run_gemms_p3(ctx, p3, cfg, s));
+                if (rest.empty()) return FBHIP_OK;
+                v.swap(rest);
+            }
+        }
     }
-    if (ctx != nullptr)
-        for (auto& p : v) p3_touch(ctx, p.C, p.M, p.N, p.ldc);      // fp32-only outputs: images of these views are stale from here on
     long tiles32 = 0;
     int kmax = 0, nmax = 0, mmax = 0;
     for (auto& p : v) {
@@ -331,34 +271,16 @@ int flush_colreduce(fbhip_ctx* c, hipStream_t s) {
 int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
     if (!o.gemms.empty()) RC(run_gemms(c, o.gemms, s));
     RC(flush_colreduce(c, s));
-    // the LayerNorm kernels emit the P3 image of what they write when the next consumer is a GEMM that stages planes
-    // (block-aligned outputs wide enough for gemm3: the hidden layers; tiny test nets keep fp32 only unless FBHIP_P3=2)
-    auto ln_planes = [&](float* y, int rows, int n, int ld) -> char* {
-        if (c->p3_mode == 0 || (ld & 31) || (n & 3) || !(c->p3_mode == 2 || (rows >= 128 && n >= 128))) { p3_touch(c, y, rows, n, ld); return nullptr; }
-        char* y3 = p3_of(c, y);
-        if (y3 != nullptr) p3_mark(c, y, rows, (n + 31) & ~31, ld); else p3_touch(c, y, rows, n, ld);
-        return y3;
-    };
     for (size_t i = 0; i < o.lnf.size(); i += LN_MAX_GROUP) {
         LnFwdGroup g{};
-        for (size_t j = i; j < o.lnf.size() && j < i + LN_MAX_GROUP; ++j) {
-            LnFwdProblem q = o.lnf[j];
-            q.y3 = ln_planes(q.y, q.rows, q.n, q.ldy);
-            g.p[g.n++] = q;
-        }
+        for (size_t j = i; j < o.lnf.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.lnf[j];
         HIPCK(c, launch_ln_tanh_fwd_group(g, s));
     }
     for (size_t i = 0; i < o.lnb.size(); i += LN_MAX_GROUP) {
         LnBwdGroup g{};
-        for (size_t j = i; j < o.lnb.size() && j < i + LN_MAX_GROUP; ++j) {
-            LnBwdProblem q = o.lnb[j];
-            q.dx3 = ln_planes(q.dx, q.rows, q.n, q.lddx);
-            g.p[g.n++] = q;
-        }
+        for (size_t j = i; j < o.lnb.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.lnb[j];
         HIPCK(c, launch_ln_tanh_bwd_group(g, s, &c->cr_pending));      // (d gamma, d beta) folds ride in the next reduce launch
     }
-    // row kernels write fp32 only, and what they write is not declared here: images outside the forward activation sets are stale
-    if (!o.l2n.empty() || !o.ph.empty() || !o.dh.empty() || !o.post.empty()) p3_opaque(c);
     for (size_t i = 0; i < o.l2n.size(); i += LN_MAX_GROUP) {
         L2Group g{};
         for (size_t j = i; j < o.l2n.size() && j < i + LN_MAX_GROUP; ++j) g.p[g.n++] = o.l2n[j];
@@ -378,10 +300,7 @@ int flush_round(fbhip_ctx* c, Ops& o, hipStream_t s) {
                                            d.boltzmann, c->sq.temp, s));
         }
     }
-    for (auto& f : o.post) {
-        RC(f(s));
-        p3_opaque(c);                            // (a lambda may run GEMMs of its own between its row kernels: reset after each)
-    }
+    for (auto& f : o.post) RC(f(s));
     return FBHIP_OK;
 }
 

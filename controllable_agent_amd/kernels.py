@@ -43,9 +43,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcontig:
 
 def gemm_p3(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcontig: bool = True,
             bias: tp.Optional[torch.Tensor] = None, aux: tp.Optional[torch.Tensor] = None, epi: int = _lib.EPI_NONE,
-            want_colsum: bool = False, want_image: bool = False, cfg: int = 0):
+            want_colsum: bool = False, want_image: bool = False, cfg: int = 0, a_image: bool = True, b_image: bool = True):
     """The same GEMM on three-plane bf16 images of the operands (csrc/p3.h, fbhip_gemm_p3): fp32-accurate products from six bf16
-    MFMAs per block.  A, B must have leading dimensions that are multiples of 32 (K too).  ``want_image`` also returns the image of
+    MFMAs per block.  ``a_image`` / ``b_image``: stage that operand from a prepared image (leading dimension a multiple of 32) or,
+    when False, straight from fp32 (rows 16-byte aligned); K a multiple of 32 either way.  ``want_image`` also returns the image of
     C as a uint8 tensor of 1.5 x the bytes of C's padded storage ([hi x 32 | mid x 32 | lo x 32] per 32-float block)."""
     _lib.require_device()
     M, K = (A.shape if a_kcontig else A.shape[::-1])
@@ -54,8 +55,8 @@ def gemm_p3(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcont
     ldc = (N + 31) // 32 * 32
     Cs = torch.zeros((M, ldc), device=A.device, dtype=torch.float32)
     Cm = Cs[:, :N]
-    a3 = torch.zeros(A.shape[0] * _ld(A) * 6, device=A.device, dtype=torch.uint8)
-    b3 = torch.zeros(B.shape[0] * _ld(B) * 6, device=A.device, dtype=torch.uint8)
+    a3 = torch.zeros(A.shape[0] * _ld(A) * 6, device=A.device, dtype=torch.uint8) if a_image else None
+    b3 = torch.zeros(B.shape[0] * _ld(B) * 6, device=A.device, dtype=torch.uint8) if b_image else None
     c3 = torch.zeros(M * ldc * 6, device=A.device, dtype=torch.uint8) if want_image else None
     colsum = torch.zeros(M, device=A.device) if want_colsum else None
     check(_lib.load().fbhip_gemm_p3(ptr(A), _ld(A), int(a_kcontig), ptr(B), _ld(B), int(b_kcontig), ptr(Cm), ldc, M, N, K,

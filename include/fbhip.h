@@ -361,12 +361,14 @@ int fbhip_gemm(const float* A, int32_t lda, int32_t a_kcontig, const float* B, i
  * M x N x K); no epilogue.  For tests and kernel benchmarking. */
 int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
                    float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t cfg, void* stream);
-/* The same contraction on three-plane bf16 images of the operands (csrc/p3.h, csrc/gemm3_kernel.h): six bf16 MFMA products per
- * block reproduce the fp32 product (error at or below an fp32 dot product's).  A, B: fp32 matrices with leading dimensions that
- * are multiples of 32 and 128-byte aligned bases; K a multiple of 32.  a3, b3: scratch for their images (1.5 x the fp32 bytes of
- * the [rows, ld] matrices, 16-byte aligned; filled here by the split kernel).  c3 (nullable, ldc % 32 == 0): also receives the
- * image of C.  cfg: 0 128x128, 1 128x64, 2 64x128, 3 64x64 workgroup tiles.  Epilogues as fbhip_gemm.  For tests / benchmarks:
- * inside an update the images come from the producing kernels, not from a split pass per GEMM. */
+/* The same contraction with six bf16 MFMA products per block in place of the fp32 MFMA (csrc/p3.h, csrc/gemm3_kernel.h): every
+ * operand is taken apart into three bf16 planes (hi + mid + lo = the fp32 value) and the products reproduce the fp32 product
+ * (error at or below an fp32 dot product's).  An operand is staged either from a prepared three-plane IMAGE by LDS-DMA -- how
+ * the update reads its parameters: pass scratch a3 / b3 for the image (1.5 x the fp32 bytes of the [rows, ld] matrix, 16-byte
+ * aligned, ld % 32 == 0; filled here by the split kernel) -- or straight from fp32 with the split done by the kernel's staging
+ * waves -- how it reads activations: pass a3 / b3 = NULL (16-byte aligned rows, ld % 4 == 0).  K a multiple of 32.  c3 (nullable,
+ * ldc % 32 == 0): also receives the image of C.  cfg: 0 128x128, 1 128x64, 2 64x128, 3 64x64 workgroup tiles.  Epilogues as
+ * fbhip_gemm. */
 int fbhip_gemm_p3(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
                   float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                   const float* bias, const float* aux, int32_t ldaux, int32_t epi, float* colsum,

@@ -353,7 +353,7 @@ def fb_loss_terms(F1, F2, Bm, tF1, tF2, tB, discount, ortho_coef: float) -> tp.D
     target_M = torch.min(torch.einsum('sd, td -> st', tF1, tB), torch.einsum('sd, td -> st', tF2, tB))
     M1 = torch.einsum('sd, td -> st', F1, Bm)
     M2 = torch.einsum('sd, td -> st', F2, Bm)
-    I = torch.eye(*M1.size())
+    I = torch.eye(*M1.size(), dtype=M1.dtype)
     off_diag = ~I.bool()
     fb_offdiag = 0.5 * sum((M - discount * target_M)[off_diag].pow(2).mean() for M in [M1, M2])
     fb_diag = -sum(M.diag().mean() for M in [M1, M2])
@@ -434,11 +434,14 @@ class OracleAgent:
 
     NETS = ("actor", "forward_net", "backward_net")
 
-    def __init__(self, cfg: OracleConfig, nets: tp.Dict[str, Params]) -> None:
+    def __init__(self, cfg: OracleConfig, nets: tp.Dict[str, Params], dtype: torch.dtype = torch.float32) -> None:
+        # dtype = torch.float64: the same arithmetic in double precision -- NOT the reference's numbers, but the yardstick
+        # for "how far from exact is an fp32 evaluation of this step" (tests bound the HIP path's error by the fp32 oracle's own)
         self.cfg = cfg
-        self.actor = {k: v.clone() for k, v in nets["actor"].items()}
-        self.forward_net = {k: v.clone() for k, v in nets["forward_net"].items()}
-        self.backward_net = {k: v.clone() for k, v in nets["backward_net"].items()}
+        self.dtype = dtype
+        self.actor = {k: v.clone().to(dtype) for k, v in nets["actor"].items()}
+        self.forward_net = {k: v.clone().to(dtype) for k, v in nets["forward_net"].items()}
+        self.backward_net = {k: v.clone().to(dtype) for k, v in nets["backward_net"].items()}
         # fb_ddpg.py:140-141: targets start as copies
         self.forward_target_net = {k: v.clone() for k, v in self.forward_net.items()}
         self.backward_target_net = {k: v.clone() for k, v in self.backward_net.items()}
@@ -462,8 +465,9 @@ class OracleAgent:
             mix_idxs = np.where(draws.mix_uniform < cfg.mix_ratio)[0]
             with torch.no_grad():
                 if cfg.rand_weight:                                # fb_ddpg.py:475-482
-                    weight = F.normalize(torch.from_numpy(draws.rand_weight[mix_idxs]), dim=1)
-                    weight = torch.from_numpy(draws.rand_weight_u[mix_idxs]).reshape(-1, 1) * weight
+                    dt = getattr(self, "dtype", torch.float32)
+                    weight = F.normalize(torch.from_numpy(draws.rand_weight[mix_idxs]).to(dt), dim=1)
+                    weight = torch.from_numpy(draws.rand_weight_u[mix_idxs]).to(dt).reshape(-1, 1) * weight
                     mz = torch.matmul(weight, backward_map(self.backward_net, bi, cfg.z_dim, cfg.norm_z))
                 else:
                     mz = backward_map(self.backward_net, bi[mix_idxs], cfg.z_dim, cfg.norm_z)
@@ -483,7 +487,7 @@ class OracleAgent:
     # -- one update ------------------------------------------------------- #
     def update(self, batch: tp.Dict[str, np.ndarray], draws: Draws, keep: bool = False) -> tp.Dict[str, float]:
         cfg = self.cfg
-        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32)
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).to(self.dtype)
         obs, action, next_obs = t(batch["obs"]), t(batch["action"]), t(batch["next_obs"])
         discount = t(batch["discount"]).reshape(-1, 1)
         next_goal = next_obs
@@ -540,7 +544,7 @@ class OracleAgent:
             "orth_loss": L["orth_loss"].item(), "orth_loss_diag": L["orth_loss_diag"].item(),
             "orth_loss_offdiag": L["orth_loss_offdiag"].item()})
         with torch.no_grad():
-            eye_diff = torch.matmul(Bm.T, Bm) / Bm.shape[0] - torch.eye(Bm.shape[1])
+            eye_diff = torch.matmul(Bm.T, Bm) / Bm.shape[0] - torch.eye(Bm.shape[1], dtype=Bm.dtype)
             metrics["orth_linf"] = torch.max(torch.abs(eye_diff)).item()
             metrics["orth_l2"] = eye_diff.norm().item() / math.sqrt(Bm.shape[1])
         metrics["fb_opt_lr"] = cfg.lr

@@ -91,12 +91,12 @@ static const int cfg_bm[] = {128, 128, 128, 64, 128, 64, 128};
 static const int cfg_bn[] = {128, 64, 64, 64, 128, 128, 64};
 
 // mode: 3 = NT (A [M,K], B [N,K]), 2 = NN (A [M,K], B [K,N]), 0 = TN (A [K,M], B [K,N])
-struct Case { int M, N, K, mode, epi; };
+struct Case { int M, N, K, mode, epi; int pa = 1, pb = 1; };      // pa / pb: stage the operand from its image (1) or from fp32 (0)
 
 static GemmProblem problem(const Case& c, const Mat& A, const Mat& B, Mat& C, const float* bias, const float* aux, int ldaux,
                            float* colsum, int cfg) {
     GemmProblem p{};
-    p.A = A.d; p.B = B.d; p.C = C.d; p.A3 = A.d3; p.B3 = B.d3; p.C3 = C.d3;
+    p.A = A.d; p.B = B.d; p.C = C.d; p.A3 = c.pa ? A.d3 : nullptr; p.B3 = c.pb ? B.d3 : nullptr; p.C3 = c.pa && c.pb ? C.d3 : nullptr;
     p.bias = bias; p.aux = aux; p.ldaux = ldaux; p.colsum = colsum;
     p.M = c.M; p.N = c.N; p.K = c.K; p.lda = A.ld; p.ldb = B.ld; p.ldc = C.ld;
     p.a_kcontig = (c.mode >> 1) & 1; p.b_kcontig = c.mode & 1; p.epi = c.epi;
@@ -145,8 +145,8 @@ static void time_case(const Case& c, int group, int cfg, int iters, int knock, s
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, tf = 2.0 * c.M * c.N * c.K * group / (us * 1e-6) * 1e-12;
-    printf("single %4dx%4dx%4d mode %d x%d  %-11s knock %d  %4d wgs  %8.1f us  %6.1f TFLOP/s fp32-equivalent\n", c.M, c.N, c.K, c.mode, group,
-           cfg_name[cfg], knock, start, us, tf);
+    printf("single %4dx%4dx%4d mode %d x%d  %-11s knock %d images %d%d  %4d wgs  %8.1f us  %6.1f TFLOP/s fp32-equivalent\n", c.M, c.N, c.K, c.mode, group,
+           cfg_name[cfg], knock, c.pa, c.pb, start, us, tf);
 #ifdef G3_KNOCK
     const int zero = 0;
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g3_knock_mask), &zero, sizeof(int)));
@@ -160,7 +160,8 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     if (argc > 1 && !strcmp(argv[1], "single")) {        // single M N K mode group cfg iters knock
-        const Case c{atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), EPI_BIAS_RELU};
+        Case c{atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), EPI_BIAS_RELU};
+        if (argc > 11) { c.pa = atoi(argv[10]); c.pb = atoi(argv[11]); }
         time_case(c, atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), argc > 9 ? atoi(argv[9]) : 0, rng, s, e0, e1);
         return 0;
     }
@@ -172,7 +173,10 @@ int main(int argc, char** argv) {
                            {320, 96, 192, 0, EPI_NONE},      {1024, 2048, 1024, 3, EPI_BIAS_RELU}, {1024, 1024, 2048, 2, EPI_MASK_RELU},
                            {2048, 1024, 1024, 0, EPI_NONE}};
     int bad = 0;
-    for (const Case& c : checks) {
+    for (const Case& c0 : checks) {
+      for (int om = 0; om < 3; ++om) {
+        Case c = c0;
+        c.pa = om == 0; c.pb = om != 2;                        // images for both | A from fp32 | both from fp32
         for (int cfg = 0; cfg < 7; ++cfg) {
             Mat A = (c.mode & 2) ? make(c.M, c.K, rng) : make(c.K, c.M, rng);
             Mat B = (c.mode & 1) ? make(c.N, c.K, rng) : make(c.K, c.N, rng);
@@ -203,7 +207,7 @@ int main(int argc, char** argv) {
                 const size_t o = p3_offset(m, n, C.ld) / 2;
                 auto bf = [&](unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return (double)f; };
                 const double rec = bf(h3[o]) + bf(h3[o + 32]) + bf(h3[o + 64]);
-                p3err = std::max(p3err, std::fabs(rec - got) / (std::fabs(got) + 1e-30));
+                if (c.pa && c.pb) p3err = std::max(p3err, std::fabs(rec - got) / (std::fabs(got) + 1e-30));
             }
             double cserr = 0;
             if (colsum) {
@@ -218,12 +222,13 @@ int main(int argc, char** argv) {
             const double rel = std::sqrt(num / (den + 1e-300));
             const bool ok = rel < 2e-6 && p3err < 2e-7 && cserr < 1e-6;
             if (!ok) ++bad;
-            printf("check %4dx%4dx%4d mode %d epi %d  %-11s rel L2 err %.3e  P3(C) max rel %.2e  colsum %.2e  %s\n", c.M, c.N, c.K, c.mode, c.epi,
-                   cfg_name[cfg], rel, p3err, cserr, ok ? "ok" : "FAIL");
+            printf("check %4dx%4dx%4d mode %d epi %d images %d%d  %-11s rel L2 err %.3e  P3(C) max rel %.2e  colsum %.2e  %s\n", c.M, c.N, c.K, c.mode, c.epi,
+                   c.pa, c.pb, cfg_name[cfg], rel, p3err, cserr, ok ? "ok" : "FAIL");
             CK(hipFree(A.d)); CK(hipFree(A.d3)); CK(hipFree(B.d)); CK(hipFree(B.d3)); CK(hipFree(C.d)); CK(hipFree(C.d3));
             CK(hipFree(bias.d)); CK(hipFree(bias.d3)); CK(hipFree(aux.d)); CK(hipFree(aux.d3));
             if (colsum) CK(hipFree(colsum));
         }
+      }
     }
     printf("correctness: %d failing\n", bad);
 
