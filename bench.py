@@ -119,10 +119,10 @@ def cpu_baseline(seed=1, budget_s=12.0, max_steps=120):
             "also": also}
 
 
-def measured_traffic():
-    """HBM-side bytes per update from the last committed PMC passes (profiles/traffic.json, written from
+def measured_traffic(workload="walker"):
+    """HBM-side bytes per update from the last committed PMC passes (profiles/traffic.json, traffic_quadruped.json, written from
     tools/pmc_summary.py output); bench.py itself cannot collect PMC counters.  None when no pass is on file."""
-    f = Path(__file__).resolve().parent / "profiles" / "traffic.json"
+    f = Path(__file__).resolve().parent / "profiles" / ("traffic.json" if workload == "walker" else f"traffic_{workload}.json")
     try:
         return float(json.loads(f.read_text())["hbm_bytes_per_update"])
     except (OSError, KeyError, ValueError):
@@ -181,6 +181,11 @@ def main():
                     help="N > 1: the gradient all-reduces as kernels INSIDE each rank's update graph (peers' buckets mapped with hipIpc, "
                          "csrc/peer.hip; FBHIP_DP_ALLREDUCE=peer) instead of RCCL calls between three phase graphs: one graph launch "
                          "per rank per --steps-per-launch updates.  Single node only")
+    ap.add_argument("--transport", choices=("rccl", "c10d", "peer"), default=None,
+                    help="N > 1: how the two gradient buckets are all-reduced.  rccl (default): the library's own RCCL communicator, "
+                         "ncclAllReduce captured inside each rank's n-step update graph (csrc/rccl.hip); c10d: torch.distributed "
+                         "collectives between / inside phase graphs (round 2's path); peer: hand-written peer-access kernels "
+                         "(= --peer-allreduce).  Falls back to c10d, and says so in the JSON line, if the library transport cannot be set up")
     ap.add_argument("--global-batch", action="store_true",
                     help="data-parallel mode B (FBHipAgent(dp_global_batch=True)): the exact loss of the concatenated "
                          "world x batch rows (one embedding all-gather per step) instead of per-rank blocks with gradient "
@@ -220,7 +225,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
+        # control plane: with the library-owned RCCL transport (the default) the process group only carries the 128-byte unique id,
+        # the replica checksums and this script's barriers -- gloo, so that no c10d watchdog thread exists that could poll an event
+        # during one of the library's stream captures; the c10d transports need the nccl backend (RCCL refuses two ranks per device:
+        # the one-GPU rehearsal stays on gloo and falls back to host-issued collectives)
+        transport = "peer" if args.peer_allreduce else (args.transport or "rccl")
+        if args.rehearse_on_one_gpu or transport == "rccl":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
@@ -233,8 +243,11 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
-    if args.peer_allreduce:
+    if args.peer_allreduce or args.transport == "peer":
+        args.peer_allreduce = True
         os.environ["FBHIP_DP_ALLREDUCE"] = "peer"
+    elif args.transport is not None:
+        os.environ["FBHIP_DP_ALLREDUCE"] = args.transport
     if args.pretend_world > 1:
         os.environ["FBHIP_PRETEND_WORLD"] = str(args.pretend_world)
     from controllable_agent_amd.agent import FBHipAgent
@@ -269,9 +282,22 @@ def main():
 
     # everything is enqueued on ONE explicit stream so that the HIP events below bracket the same launches the wall clock does
     # (torch.cuda.Event only sees the stream it is recorded on; on the legacy default stream the agent would hop to its own)
-    bench_stream = torch.cuda.Stream(device=dev)
+    bench_stream = torch.cuda.default_stream(dev) if os.environ.get("FBHIP_BENCH_LEGACY_STREAM") == "1" else torch.cuda.Stream(device=dev)
     with torch.cuda.stream(bench_stream):
         run(0, args.warmup)
+        if world > 1 and not args.rehearse_on_one_gpu and dist.get_backend() == "gloo":
+            # did the library transport come up on EVERY rank?  If not (the JSON line says why), do not time host-side gloo
+            # collectives: all ranks switch the process group to nccl and the torch.distributed schedule carries the gradients
+            flag = torch.tensor([1.0 if getattr(agent, "_rccl_failed", False) else 0.0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if float(flag.item()) > 0.0:
+                agent._rccl_failed = True
+                agent._dp_transport = getattr(agent, "_dp_transport", None) if str(getattr(agent, "_dp_transport", "")).startswith("c10d") else \
+                    "c10d (library RCCL transport refused on another rank)"
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+                dist.init_process_group("nccl", device_id=torch.device(dev))
+                run(0, args.warmup)
         # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
         # untimed launch of each size (these are additional warm-up steps)
         sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
@@ -374,9 +400,11 @@ def main():
             **({"replicas": replicas} if replicas is not None else {}),
             **({"data_parallel": {
                 # which path actually carried the gradients (a capture that failed once falls back to host-issued launches for good)
-                "transport": ("peer" if args.peer_allreduce else ("gloo-host" if args.rehearse_on_one_gpu else
-                              ("rccl-host" if (getattr(agent, "_dp_graph_failed", False) or os.environ.get("FBHIP_DP_GRAPH", "1") == "0"
-                                               or spl == 1) else "rccl-graph"))),
+                "transport": getattr(agent, "_dp_transport", None) or
+                             ("peer" if args.peer_allreduce else ("gloo-host" if args.rehearse_on_one_gpu else
+                              ("c10d-rccl-host" if (getattr(agent, "_dp_graph_failed", False) or os.environ.get("FBHIP_DP_GRAPH", "1") == "0"
+                                                    or spl == 1) else "c10d-rccl-graph"))),
+                "library_rccl_refused": bool(getattr(agent, "_rccl_failed", False)),
                 "schedule_graph_capture_failed": bool(getattr(agent, "_dp_graph_failed", False)),
                 "nccl_env": {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                                      "HSA_ENABLE_IPC_MODE_LEGACY")},
@@ -386,13 +414,11 @@ def main():
             **({"flags": [f"timed region of {dt * 1e3:.1f} ms < 0.5 s: --steps {args.steps} is too short for a stable rate "
                           f"(host launch jitter); the {len(walls)} repeats bound it, prefer --steps >= 1000"]} if dt < 0.5 else {}),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(),
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(args.workload),
                          "what": f"whole update step: {gflop:.2f} algorithmic GFLOP/update (SURVEY.md section 8d) x "
                                  "measured updates/s, per GPU, vs the exact-fp32 MFMA peak"},
         }
-        if args.workload != "walker":
-            out["roofline"]["traffic"] = None
-        elif world == 1:
+        if args.workload == "walker" and world == 1:
             out["roofline"]["dominant_kernel"] = dominant_kernel_probe()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()

@@ -88,6 +88,11 @@ PROTOTYPES = {
     "fbhip_peer_allreduce": (C.c_int, [_P, _I, _P]),
     "fbhip_update_many_dp": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_dp_status": (C.c_int, [_P, C.POINTER(_I), _P]),
+    "fbhip_order_legacy_stream_after": (C.c_int, [_P, _P]),
+    "fbhip_rccl_load": (C.c_int, [C.c_char_p]),
+    "fbhip_rccl_version": (C.c_int, []),
+    "fbhip_rccl_unique_id": (C.c_int, [_P]),
+    "fbhip_rccl_init": (C.c_int, [_P, _P, _I, _I, _P]),
     "fbhip_select_workspace_set": (C.c_int, [_P, _I]),
     "fbhip_fb_early_grad_range": (C.c_int, [C.POINTER(Dims), C.POINTER(_L), C.POINTER(_L)]),
     "fbhip_embeddings_floats": (_Z, [C.POINTER(Dims)]),
@@ -137,7 +142,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 15:
+    if lib.fbhip_abi_version() != 16:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -763,12 +763,17 @@ class FBHipAgent:
         if cur.cuda_stream != 0:
             fn()
             return
-        # the caller sits on the legacy default stream, where stream capture is not allowed: run on the agent's own
-        # stream, ordered after / before the caller's work with events (no host synchronisation)
+        # the caller sits on the legacy default stream, where stream capture is not allowed: run on the agent's own stream, ordered
+        # after the caller's earlier work by an event and before its later work by fbhip_order_legacy_stream_after -- NOT by making
+        # the legacy stream wait on an event: a command pending on the legacy stream while the n-step graph runs slowed that graph
+        # down 1.5x (include/fbhip.h; DESIGN.md section 6 "The legacy default stream").  No host synchronisation either way.
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
             fn()
-        cur.wait_stream(self._stream)
+            if os.environ.get("FBHIP_LEGACY_STREAM_ORDER", "gate") == "event":
+                cur.wait_stream(self._stream)
+            else:
+                check(_lib.load().fbhip_order_legacy_stream_after(self._ctx, stream_ptr()), self._ctx)
 
     def _dp_schedule_graph(self, n_steps: int, hp: HParams, launch: tp.Callable[[int], None]) -> bool:
         """The host-issued data-parallel schedule of ``n_steps`` updates -- four or five phase launches and two or three RCCL
@@ -990,7 +995,15 @@ class FBHipAgent:
         c = self.cfg
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
         if isinstance(replay_loader, DeviceReplayBuffer):
-            from . import peer
+            from . import peer, rccl
+            split_ = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
+            if (split_ and self._rccl_ready() and not getattr(c, "dp_global_batch", False) and self._use_graph and self._stddev_is_constant()):
+                self._bind_replay(replay_loader)
+                self._verify_replicas()
+                hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
+                if self._rccl_run(hp, 1):
+                    return self._metrics()
+                return self.update(replay_loader, step)
             if self._world() > 1 and peer.enabled() and not getattr(c, "dp_global_batch", False) and self._use_graph and self._stddev_is_constant():
                 self._bind_replay(replay_loader)
                 self._verify_replicas()
@@ -1008,6 +1021,45 @@ class FBHipAgent:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)
         return self._metrics()
+
+    def _rccl_ready(self) -> bool:
+        """Bind the library-owned RCCL transport on first use (rccl.py); a refusal (no librccl, communicator set-up failed) is
+        remembered and the c10d schedule of distributed.py takes over -- loudly, and visible in ``_dp_transport``."""
+        from . import rccl
+        if getattr(self, "_rccl_failed", False) or not rccl.usable():
+            return False
+        if getattr(self, "_rccl_bound", False):
+            return True
+        try:
+            rccl.bind(self)
+            return True
+        except Exception as e:                               # noqa: BLE001
+            import warnings
+            self._rccl_failed = True
+            self._dp_transport = f"c10d (library RCCL transport refused: {type(e).__name__}: {e})"
+            warnings.warn(f"fbhip: library-owned RCCL transport unavailable ({type(e).__name__}: {e}); using torch.distributed collectives")
+            return False
+
+    def _rccl_run(self, hp, n_total: int) -> bool:
+        """``n_total`` updates through ``fbhip_update_many_dp`` on the library's communicator, 64 per graph.  A failure of the
+        FIRST launch (capture of the collectives refused by this librccl build) demotes the agent to the torch.distributed
+        schedule -- recorded in ``_dp_transport`` -- and returns False with nothing applied; later failures raise."""
+        done = 0
+        while done < n_total:
+            n = min(64, n_total - done)
+            try:
+                self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many_dp(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
+            except RuntimeError as e:
+                if done or getattr(self, "_rccl_ran", False):
+                    raise
+                import warnings
+                self._rccl_failed = True
+                self._dp_transport = f"c10d (library RCCL transport gave up at its first launch: {e})"
+                warnings.warn(f"fbhip: {self._dp_transport}")
+                return False
+            self._rccl_ran = True
+            done += n
+        return True
 
     def _check_peer_status(self, every: int = 1) -> None:
         """The peer-access all-reduce kernels (csrc/peer.hip) give up on a cross-rank barrier after a bounded spin and set a status
@@ -1045,6 +1097,16 @@ class FBHipAgent:
                 out = self.update(replay_loader, step + i)
             return out
         from . import peer
+        if split and self._rccl_ready():
+            # data parallel with the library's own RCCL communicator: ncclAllReduce of the two gradient buckets INSIDE the n-step
+            # graph (csrc/rccl.hip): one graph launch per rank per call, no torch.distributed object on the hot path
+            want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+            self._bind_replay(replay_loader)
+            self._verify_replicas()
+            hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
+            if self._rccl_run(hp, n_steps):
+                return self._metrics()
+            return self.update_many(replay_loader, step, n_steps)
         if split and self._world() > 1 and peer.enabled():
             # data parallel without host-issued collectives: the peers' gradient buckets are mapped into this process and the
             # all-reduces are kernels INSIDE the n-step graph (csrc/peer.hip): one graph launch per rank per call
@@ -1667,10 +1729,22 @@ class SFHipAgent(FBHipAgent):
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         c = self.cfg
         total = n_steps * int(c.num_sf_updates)                  # (every update() call is num_sf_updates complete updates)
-        # (data parallel: single updates, each through the phase-split schedule with its two gradient all-reduces)
+        split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
+        const_std = len({schedule(c.stddev_schedule, step + i) for i in range(n_steps)}) == 1
+        if (split and total >= 2 and isinstance(replay_loader, DeviceReplayBuffer) and c.update_every_steps == 1 and self._use_graph and
+                const_std and self._rccl_ready()):
+            # data parallel, pipelined like the FB agent: the library's RCCL communicator reduces the [sf | phi] and actor buckets
+            # inside the n-step graph (fbhip_update_many_dp; csrc/rccl.hip)
+            want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
+            self._bind_replay(replay_loader)
+            self._verify_replicas()
+            hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
+            if self._rccl_run(hp, total):
+                return self._metrics()
+            return self.update_many(replay_loader, step, n_steps)
+        # (data parallel without that transport: single updates, each through the phase-split schedule with its two gradient all-reduces)
         if (total < 2 or not isinstance(replay_loader, DeviceReplayBuffer) or c.update_every_steps != 1 or not self._use_graph or
-                self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or
-                len({schedule(c.stddev_schedule, step + i) for i in range(n_steps)}) != 1):
+                split or not const_std):
             out: tp.Dict[str, float] = {}
             for i in range(n_steps):
                 out = self.update(replay_loader, step + i)

@@ -57,6 +57,27 @@ int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches
     return FBHIP_OK;
 }
 
+// The legacy default stream and work on another stream.  A caller that sits on the legacy (null) stream expects its LATER null-stream
+// work to see what an entry point enqueued elsewhere.  Making the null stream wait on an event does that, but leaves a pending command
+// on the null stream for as long as the graph runs -- and with one there the n-step graphs of this library ran 1.5x slower on
+// MI355X / ROCm 7.0 (measured round 3: 650 vs 970 SF update-steps/s, 700 vs 1117 FB; a wait on any OTHER stream costs nothing).
+// So the wait goes onto one process-wide BLOCKING stream instead: the runtime's own legacy-stream rule (null-stream work waits for
+// every blocking stream's earlier work) then orders the caller's next null-stream command behind it, at the moment there is one.
+std::mutex g_gate_mu;
+hipStream_t g_gate_stream = nullptr;
+
+int order_legacy_after(fbhip_ctx* c, hipStream_t s) {
+    if (s == nullptr) return FBHIP_OK;                 // already on the legacy stream
+    {
+        std::lock_guard<std::mutex> lk(g_gate_mu);
+        if (g_gate_stream == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_stream, hipStreamDefault));
+    }
+    if (!c->ev_gate) HIPCK(c, hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming));
+    HIPCK(c, hipEventRecord(c->ev_gate, s));
+    HIPCK(c, hipStreamWaitEvent(g_gate_stream, c->ev_gate, 0));
+    return FBHIP_OK;
+}
+
 // contexts whose destruction was asked for while a stream capture was open on their stream (hipGraphExecDestroy / hipHostFree /
 // hipDeviceSynchronize are illegal there): destroyed at the next entry point that is not inside a capture
 std::mutex g_reap_mu;
@@ -64,11 +85,13 @@ std::vector<fbhip_ctx*> g_reap;
 
 void destroy_now(fbhip_ctx* ctx) {
     (void)hipDeviceSynchronize();
+    rccl_release(ctx);
     for (auto& g : ctx->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto& g : ctx->infer_graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto e : ctx->events) (void)hipEventDestroy(e);
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
+    if (ctx->ev_gate) (void)hipEventDestroy(ctx->ev_gate);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
@@ -460,8 +483,9 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     hipError_t he = hipSuccess;
     const bool has_actor = !c->d.discrete;
     const int64_t n_fb = c->L[FBHIP_NET_FORWARD].numel + c->L[FBHIP_NET_BACKWARD].numel, n_ac = c->L[FBHIP_NET_ACTOR].numel;
-    auto allreduce = [&](int which) -> int {                     // the peers' gradients, summed in place (peer.hip)
-        HIPCK(c, launch_peer_allreduce(c->peers, which, which == 0 ? n_fb : n_ac, s));
+    auto allreduce = [&](int which) -> int {                     // every rank's gradients, summed in place
+        if (c->rccl_comm != nullptr) return rccl_allreduce(c, which, s);          // ncclAllReduce on the capture stream (rccl.hip)
+        HIPCK(c, launch_peer_allreduce(c->peers, which, which == 0 ? n_fb : n_ac, s));   // peer-access kernels (peer.hip)
         return (int)FBHIP_OK;
     };
     if (dp && !pipe) {
@@ -600,8 +624,21 @@ int fbhip_peer_allreduce(fbhip_ctx* c, int32_t which, void* stream) {
 
 int fbhip_update_many_dp(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
     RC(need_bound(c, true));
-    if (c->peers.world < 2) { c->err = g_err = "fbhip_update_many_dp: no peers bound (fbhip_dp_bind_peers)"; return FBHIP_E_STATE; }
+    if (c->peers.world < 2 && c->rccl_comm == nullptr) { c->err = g_err = "fbhip_update_many_dp: no transport bound (fbhip_rccl_init or fbhip_dp_bind_peers)"; return FBHIP_E_STATE; }
     return update_many_impl(c, hp, n_steps, nullptr, stream, /*dp=*/true);
+}
+
+int fbhip_rccl_load(const char* library_path) { return rccl_load(library_path); }
+int fbhip_rccl_version(void) { return rccl_version(); }
+int fbhip_rccl_unique_id(void* out_128_bytes) {
+    if (!out_128_bytes) return FBHIP_E_INVALID;
+    return rccl_unique_id(out_128_bytes);
+}
+int fbhip_rccl_init(fbhip_ctx* c, const void* unique_id_128_bytes, int32_t world, int32_t rank, void* stream) {
+    RC(need_bound(c, false));
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);            // the communicator is baked into captured launches
+    c->graphs.clear();
+    return rccl_init(c, unique_id_128_bytes, world, rank, (hipStream_t)stream);
 }
 
 int fbhip_dp_status(fbhip_ctx* c, int32_t* host_status, void* stream) {
@@ -614,6 +651,11 @@ int fbhip_dp_status(fbhip_ctx* c, int32_t* host_status, void* stream) {
     HIPCK(c, hipStreamSynchronize((hipStream_t)stream));
     *host_status = h.status;
     return FBHIP_OK;
+}
+
+int fbhip_order_legacy_stream_after(fbhip_ctx* c, void* stream) {
+    if (!c) return FBHIP_E_INVALID;
+    return order_legacy_after(c, (hipStream_t)stream);
 }
 
 int fbhip_update_many_injected(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injects, void* stream) {

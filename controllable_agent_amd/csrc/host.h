@@ -147,6 +147,7 @@ struct fbhip_ctx {
     hipStream_t side = nullptr;              // second capture branch of fbhip_update_many
     std::vector<hipEvent_t> events;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // bridge events of launch_graph (api.hip)
+    hipEvent_t ev_gate = nullptr;                   // fbhip_order_legacy_stream_after
     hipStream_t last_stream = nullptr;      // the stream of the last update call (fbhip_destroy asks it whether a capture is open)
     hipEvent_t v_ready = nullptr;            // set while the actor phase of a pipelined graph is being built: V comes from the side branch
     fbhip::ReplayView rv{};
@@ -165,6 +166,8 @@ struct fbhip_ctx {
     const float* gb_discount = nullptr;      //   F1, F2, B, tF1, tF2, tB of ALL ranks' rows, and their discounts [gb_rows]
     int gb_rows = 0, gb_off = 0;             //   this rank owns rows [gb_off, gb_off + batch)
     fbhip::PeerComm peers{};                        // fbhip_dp_bind_peers (world >= 2: bound)
+    void* rccl_comm = nullptr;                      // fbhip_rccl_init: the library's own RCCL communicator (rccl.hip)
+    int rccl_world = 0, rccl_rank = 0;
     fbhip::Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
     std::function<int(const fbhip::PolicyHeadJobs&, hipStream_t)> run_policy_heads;   // set by the update that declares Ops::ph
     fbhip::ColReduceJobs cr_pending{};              // LayerNorm column reduces waiting for the next split-K reduce launch (flush_round)
@@ -239,6 +242,13 @@ int check_hparams(fbhip_ctx* c, const fbhip_hparams* hp);
 char* p3_of(fbhip_ctx* c, const float* p, bool* weights = nullptr);       // image address of a block-aligned parameter address, or nullptr
 int p3_split_params(fbhip_ctx* c, hipStream_t s);                          // fp32 -> P3 of every parameter / target buffer
 int need_bound(fbhip_ctx* c, bool replay);
+// the library's own RCCL transport (rccl.hip)
+int rccl_load(const char* path);
+int rccl_unique_id(void* out128);
+int rccl_version();
+int rccl_init(fbhip_ctx* c, const void* id128, int world, int rank, hipStream_t s);
+void rccl_release(fbhip_ctx* c);
+int rccl_allreduce(fbhip_ctx* c, int which, hipStream_t s);
 
 }  // namespace host
 }  // namespace fbhip

@@ -1,0 +1,65 @@
+"""Host side of the library-owned RCCL transport (csrc/rccl.hip): load librccl into libfbhip, create one communicator per agent
+from a unique id that rank 0 draws and the default process group carries (its only use: 128 bytes, once), and from then on a
+data-parallel ``update_many`` is ONE hipGraph launch per rank -- ``fbhip_update_many_dp`` with ``ncclAllReduce`` of the two flat
+gradient buckets captured inside it.  No ``torch.distributed`` call, and therefore no c10d watchdog poll, on the hot path.
+
+``FBHIP_DP_ALLREDUCE``: ``rccl`` (default) this transport | ``c10d`` the round-2 path (``dist.all_reduce`` between phase graphs /
+inside a torch-level graph, distributed.py) | ``peer`` hand-written peer-access kernels (peer.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import typing as tp
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def selected() -> str:
+    return os.environ.get("FBHIP_DP_ALLREDUCE", "rccl").lower()
+
+
+def usable() -> bool:
+    return selected() == "rccl"
+
+
+def library_path() -> str:
+    """The librccl that shares the process's HIP runtime: the copy next to torch's libamdhip64."""
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else ""
+
+
+def bind(agent: tp.Any) -> None:
+    """Collective over the default process group (or local when there is none: world 1).  Idempotent per agent."""
+    import torch.distributed as dist
+    if getattr(agent, "_rccl_bound", False):
+        return
+    lib = _lib.load()
+    check(lib.fbhip_rccl_load(library_path().encode()))
+    live = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if live else (1, 0)
+    if live and world > 1:
+        # RCCL wants one device per rank: refuse BEFORE any communicator call when two ranks sit on one device (the one-GPU
+        # rehearsals over gloo) -- the caller falls back to the torch.distributed schedule
+        import socket
+        props = torch.cuda.get_device_properties(agent._device)
+        me = (socket.gethostname(), int(torch.device(agent._device).index or 0), str(getattr(props, "uuid", "")), int(getattr(props, "pci_bus_id", -1)))
+        everyone: tp.List[tp.Any] = [None] * world
+        dist.all_gather_object(everyone, me)
+        if len(set(everyone)) != world:
+            raise RuntimeError(f"{world} ranks on {len(set(everyone))} distinct devices: RCCL needs one device per rank")
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        check(lib.fbhip_rccl_unique_id(uid))
+    box = [bytes(uid.raw)]
+    if live and world > 1:
+        dist.broadcast_object_list(box, src=0)
+    torch.cuda.synchronize(agent._device)
+    with torch.cuda.device(agent._device), torch.cuda.stream(agent._stream):
+        check(lib.fbhip_rccl_init(agent._ctx, box[0], world, rank, _lib.stream_ptr()), agent._ctx)
+    torch.cuda.synchronize(agent._device)
+    agent._rccl_bound = True
+    agent._dp_transport = f"rccl-library (in-graph ncclAllReduce, librccl {lib.fbhip_rccl_version()})"

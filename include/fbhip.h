@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 15
+#define FBHIP_ABI_VERSION 16
 
 enum {
     FBHIP_OK = 0,
@@ -280,11 +280,29 @@ int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t 
  * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph, the
  * next step's SAMPLE | FB_FWD_ONLINE on the second branch beside the actor phase and its all-reduce.  fbhip_dp_status blocks and
  * returns the status word (0 ok, 1 = a peer did not arrive within the spin limit: results of that step are garbage, nothing hangs). */
+/* The library's own RCCL transport for the same two buckets (csrc/rccl.hip): fbhip_update_many_dp then enqueues ncclAllReduce on
+ * the update's stream INSIDE its capture -- one graph per rank per n_steps updates, collectives included, no process-group object
+ * (and no c10d watchdog thread) on the hot path.  fbhip_rccl_load dlopens librccl (pass the path of the copy that matches the
+ * process's HIP runtime -- the one torch bundles; NULL tries the loader's default); rank 0 draws fbhip_rccl_unique_id (128 bytes)
+ * and the host hands the same bytes to every rank's fbhip_rccl_init (collective: every rank calls it; it also runs both buckets'
+ * all-reduces once eagerly, on the zeroed gradient buffers, so that connection set-up happens outside any capture).  Takes
+ * precedence over bound peers.  Works for every agent kind (the buckets are the flat gradient buffers). */
+int fbhip_rccl_load(const char* library_path);
+int fbhip_rccl_version(void);                      /* ncclGetVersion of the loaded library, 0 if none */
+int fbhip_rccl_unique_id(void* out_128_bytes);
+int fbhip_rccl_init(fbhip_ctx* ctx, const void* unique_id_128_bytes, int32_t world, int32_t rank, void* stream);
 int fbhip_dp_bind_peers(fbhip_ctx* ctx, int32_t world, int32_t rank, float* const* fb_grad_ptrs, float* const* actor_grad_ptrs,
                         int32_t* const* flag_ptrs, int32_t* local_state);
 int fbhip_peer_allreduce(fbhip_ctx* ctx, int32_t which, void* stream);
 int fbhip_update_many_dp(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
 int fbhip_dp_status(fbhip_ctx* ctx, int32_t* host_status, void* stream);
+/* For hosts whose caller sits on the LEGACY default stream (torch's default stream, handle 0) while the entry points above ran on
+ * `stream`: orders every later legacy-stream command after what has been enqueued on `stream` so far WITHOUT enqueuing anything on
+ * the legacy stream (a wait is put on a process-wide blocking helper stream; the runtime's legacy-stream rule does the rest when
+ * the caller next uses the legacy stream).  A wait enqueued on the legacy stream itself stays pending while the n-step graph
+ * runs and was measured to slow that graph down 1.5x (DESIGN.md section 6 "The legacy default stream").  No reference
+ * counterpart (torch code is stream-ordered implicitly).  stream == NULL: no-op. */
+int fbhip_order_legacy_stream_after(fbhip_ctx* ctx, void* stream);
 /* The workspace holds two complete per-step sets (fbhip_update_many alternates them).  A host that pipelines steps itself
  * (data parallel: the next step's SAMPLE | FB_FWD_ONLINE under this step's actor all-reduce) selects the set the following
  * fbhip_update calls work on; phases of one step must all run on the same set.  Default 0. */

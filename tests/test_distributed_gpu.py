@@ -313,6 +313,27 @@ def test_bench_two_rank_rehearsal_at_walker_dims_keeps_replicas_identical():
 
 
 # ------------------------------------------------------------------------------------------ peer-access all-reduce (in-graph)
+def test_bench_launches_its_own_ranks_when_not_under_torchrun():
+    """``python bench.py --gpus 2 --rehearse-on-one-gpu`` -- the plain form the driver uses for N = 1 -- with WORLD_SIZE unset: the
+    script re-executes itself under torch.distributed.run (it used to die on an assertion), both ranks finish
+    with identical replicas, rank 0 prints the one JSON line and it names the transport that carried the gradients (two ranks on
+    one device: the library's RCCL transport refuses BEFORE any communicator call and the torch.distributed schedule takes over)."""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "32", "--warmup", "8",
+           "--repeats", "1", "--episodes", "400", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["replicas"]["identical"] is True and res["replicas"]["ranks"] == 2
+    dp = res["data_parallel"]
+    assert dp["library_rccl_refused"] is True and "one device per rank" in dp["transport"], dp
+    assert len(dp["per_rank_steps_per_s_median_repeat"]) == 2 and dp["schedule_graph_capture_failed"] is False
+
+
 def _worker_peer(rank, port, out_q, mode, world=T.WORLD):
     """``mode`` "peer": FBHIP_DP_ALLREDUCE=peer -- the ranks map each other's gradient buckets (hipIpc) and every data-parallel
     step is ONE graph launch per rank with the all-reduce kernels inside (csrc/peer.hip);  "host": the default schedule with
@@ -320,7 +341,7 @@ def _worker_peer(rank, port, out_q, mode, world=T.WORLD):
     import torch.distributed as dist
     from controllable_agent_amd import peer
     from controllable_agent_amd.replay import DeviceReplayBuffer
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_DP_ALLREDUCE="peer" if mode == "peer" else "rccl",
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_DP_ALLREDUCE="peer" if mode == "peer" else "c10d",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg, nets, storage, lengths = T._setup()
@@ -400,6 +421,7 @@ def _run_schedule(monkeypatch, graph: bool):
     agent = H.make_hip_agent(cfg, nets)
     rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
     monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+    monkeypatch.setenv("FBHIP_DP_ALLREDUCE", "c10d")      # (the host-issued / torch-level schedule is what this test is about)
     monkeypatch.setenv("FBHIP_DP_GRAPH", "1" if graph else "0")
     for call in range(3):                                   # the second and third call replay the cached graph
         agent.update_many(rb, 6 * call, 6)
@@ -425,7 +447,7 @@ def test_dp_schedule_captured_as_one_graph_equals_the_host_issued_schedule(monke
 def _worker_nccl_world1(graph, port, out_q):
     import torch.distributed as dist
     from controllable_agent_amd.replay import DeviceReplayBuffer
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_GRAPH="1" if graph else "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_GRAPH="1" if graph else "0", FBHIP_DP_ALLREDUCE="c10d")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     cfg, nets, storage, lengths = T._setup()
     torch.manual_seed(4321)            # the agent's device RNG key comes from torch's seed, which differs between fresh processes
@@ -558,7 +580,80 @@ def test_captures_beside_the_rccl_watchdog_do_not_abort_the_process():
             "    time.sleep(0.01)\n"
             "torch.cuda.synchronize(); dist.barrier(); print('clean exit', flush=True)\n"
             "os._exit(0)\n")
-    env = dict(os.environ, FBHIP_FORCE_PHASE_SPLIT="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(T._free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_ALLREDUCE="c10d", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(T._free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "clean exit" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# ------------------------------------------------------------------ the library's own RCCL transport (round 3, csrc/rccl.hip)
+def _run_library_rccl(monkeypatch, transport, sf=False):
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    if transport is None:
+        monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+        monkeypatch.setenv("FBHIP_DP_ALLREDUCE", transport)
+    torch.manual_seed(77)              # (the agent's device RNG key comes from torch's seed: the three runs must draw the same batches)
+    if sf:
+        agent, rb, _, get_state = _sf_inputs("tiny_sf_icm_trace")
+    else:
+        cfg, nets, storage, lengths = T._setup()
+        agent = H.make_hip_agent(cfg, nets)
+        rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+        get_state = H.get_agent_state
+    agent.update(rb, 0)
+    for call in range(3):
+        agent.update_many(rb, 1 + 6 * call, 6)
+    torch.cuda.synchronize()
+    return get_state(agent), agent.step_counts(), getattr(agent, "_dp_transport", "")
+
+
+@pytest.mark.parametrize("sf", [False, True])
+def test_library_rccl_transport_on_one_rank_lands_where_the_other_schedules_land(monkeypatch, sf):
+    """``fbhip_update_many_dp`` with the library's OWN communicator (dlopen'ed librccl, ncclCommInitRank from a unique id, ncclAllReduce
+    of both buckets captured inside the n-step graph -- world 1 is all this box can hold): 1 + 3 x 6 updates end on the state of the
+    c10d schedule and of the plain single-GPU path (same kernels and order inside each step: bit-identical at these dims), for the FB
+    agent and for an SFAgent (whose update_many now pipelines under data parallelism too)."""
+    s_rccl, c_rccl, t_rccl = _run_library_rccl(monkeypatch, "rccl", sf)
+    assert t_rccl.startswith("rccl-library"), t_rccl
+    s_c10d, c_c10d, _ = _run_library_rccl(monkeypatch, "c10d", sf)
+    s_one, c_one, _ = _run_library_rccl(monkeypatch, None, sf)
+    assert c_rccl == c_c10d == c_one == (19, 19)
+    for k in s_one:
+        np.testing.assert_array_equal(s_rccl[k], s_c10d[k], err_msg=k)
+        np.testing.assert_array_equal(s_rccl[k], s_one[k], err_msg=k)
+
+
+def _worker_library_rccl_beside_c10d(port, out_q):
+    import torch.distributed as dist
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_ALLREDUCE="rccl")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    cfg, nets, storage, lengths = T._setup()
+    agents = []
+    for i in range(6):                                        # several agents, each with captures of its own, under a LIVE c10d group:
+        torch.manual_seed(100 + i)                            # the round-2 abort scenario (watchdog poll during a capture) without any sleep
+        a = H.make_hip_agent(cfg, nets)
+        rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+        dist.all_reduce(torch.ones(8, device="cuda"))         # keeps the watchdog busy polling end events
+        a.update_many(rb, 0, 6)
+        a.update(rb, 6)
+        a.act(np.zeros(cfg.obs_dim, np.float32), a.init_meta(), 0, eval_mode=True)
+        agents.append(a)
+    torch.cuda.synchronize()
+    out_q.put(([a.step_counts() for a in agents], [getattr(a, "_dp_transport", "") for a in agents]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_library_rccl_transport_beside_a_live_c10d_group_needs_no_quiescing():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_library_rccl_beside_c10d, args=(T._free_port(), q))
+    p.start()
+    counts, transports = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert counts == [(7, 7)] * 6 and all(t.startswith("rccl-library") for t in transports), (counts, transports)

@@ -11,7 +11,7 @@ from oracle import fb_oracle as fo
 from oracle import sf_oracle as so
 from tests import helpers as H
 from tests.test_oracle_golden import sf_trace_inputs
-from tests.test_update_parity_gpu import GRAD_REL_L2, LOSS_RTOL, _buffer, _param_close
+from tests.test_update_parity_gpu import GRAD_REL_L2, LOSS_RTOL, _buffer, _param_close, _v_from_trace
 
 pytestmark = pytest.mark.gpu
 
@@ -115,7 +115,7 @@ def test_sf_teacher_forced_against_reference_trace(name):
             if k.startswith("adam_"):
                 assert H.rel_err(v, ref) < 2e-4, (s, k)
             else:
-                _param_close(v, ref, cfg.lr * max(1.0, cfg.lr_coef), f"step {s} {k}")
+                _param_close(v, ref, cfg.lr * max(1.0, cfg.lr_coef), f"step {s} {k}", _v_from_trace(z, s, k), s + 1)
         assert agent.step_counts() == (s + 1, s + 1)
         for nv in (agent.successor_net, agent.feature_learner, agent.actor, agent.successor_target_net, *agent._grad_views.values()):
             assert nv.pad_abs_max() == 0.0, (s, nv._name)
@@ -411,6 +411,7 @@ def test_sf_phase_split_schedule_equals_single_call(name, monkeypatch):
         monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
         m1 = a1.update_injected(rb, s, d)
         monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+        monkeypatch.setenv("FBHIP_DP_ALLREDUCE", "c10d")      # (the host-issued / torch-level schedule is what this test is about)
         m2 = a2.update_injected(rb, s, d)
         for k in m1:
             assert m2[k] == pytest.approx(m1[k], rel=2e-5, abs=1e-6), (s, k)

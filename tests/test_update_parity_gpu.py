@@ -3,6 +3,8 @@
   (2) the oracle replaying the same injected draws,
 teacher-forced (tight tolerances) and free-running (the reference's own fp32 drift envelope)."""
 import dataclasses
+import os
+
 import numpy as np
 import types
 
@@ -17,7 +19,7 @@ pytestmark = pytest.mark.gpu
 # Stated fp32 tolerances:
 LOSS_RTOL = 2e-5          # teacher-forced single step: loss scalars
 GRAD_REL_L2 = 1e-4        # teacher-forced: each gradient tensor, relative L2
-PARAM_ATOL = 1e-6         # teacher-forced: post-Adam parameters (99.9 % of entries; see _param_close)
+PARAM_ATOL = 1e-6         # teacher-forced: post-Adam parameters, flat part of the per-entry bound (see _param_close)
 
 
 def _buffer(storage, lengths, discount, future=1.0):
@@ -25,14 +27,59 @@ def _buffer(storage, lengths, discount, future=1.0):
     return DeviceReplayBuffer.from_arrays(storage, lengths, discount, future=future, device="cuda")
 
 
-def _param_close(got, ref, lr, name, max_step=0.5, one_in=1000):
-    """Post-Adam parameters.  Adam divides by sqrt(v): an entry whose gradient is O(eps=1e-8) can move by a
-    visible fraction of lr for an O(1e-9) gradient difference, so the bound is: every entry within lr/2 (the
-    step is at most ~lr), and all but 0.1 % (at least one entry: the tiny traces have 512-entry tensors) within PARAM_ATOL."""
-    diff = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
-    assert diff.max() <= max_step * lr + 1e-7, f"{name}: max |diff| {diff.max():.3e}"
-    bad = int((diff > PARAM_ATOL).sum())
-    assert bad <= max(1, diff.size // one_in), f"{name}: {bad} of {diff.size} entries beyond {PARAM_ATOL}"   # 0.1 %, at least one
+GRAD_NOISE = 8e-6         # 20 x the fp32 evaluation noise of a gradient tensor relative to its scale (measured: the fp32 oracle and the
+                          # HIP step both sit 3-4e-7 rel-L2 from the fp64 evaluation, tools/tolerance_probe.py -> profiles/r03_tolerance_probe.txt;
+                          # the factor covers the worst single ENTRY of a tensor against its rms: 5e-6 seen at hidden 2048)
+
+
+def _param_close(got, ref, lr, name, v_ref=None, t=1, max_step=2.2, flip_rows=0, grad_noise=None):
+    """Post-Adam parameters, entry by entry.  The step is lr m^ / (sqrt(v^) + eps): a gradient difference dg moves an entry by about
+    lr dg / (sqrt(v^) + eps), so next to the flat PARAM_ATOL every entry gets what fp32 gradient noise (GRAD_NOISE x the tensor's
+    gradient scale rms sqrt(v^)) can turn into THERE -- negligible where the gradient history is of normal size, up to the step
+    itself (<= ~lr, sign included) where it is rounding noise.  ``v_ref``: the reference's second moment AFTER the step (None:
+    the flat bound only), ``t`` its step count.  No entry may be excused wholesale (round 2 allowed 0.1 % of them any error up to
+    lr / 2).  ``flip_rows``: only for the maximal-dimension case, where ~4e6 ReLU pre-activations make one within fp32 summation
+    noise of the threshold a near-certainty -- that many ROWS of a weight matrix (entries of a vector) may leave the entry bound
+    (one flipped mask element moves one weight-gradient row); they stay under the one-step cap like everything else.
+    ``grad_noise``: the gradient noise to budget for instead of GRAD_NOISE, where the caller MEASURED it (fp32 oracle against
+    the fp64 oracle on the same tensor: at hidden 2048 a gradient entry is a 2048-deep chain of fp32 sums)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    diff = np.abs(got - ref)
+    if v_ref is None:
+        assert diff.max() <= PARAM_ATOL, f"{name}: max |diff| {diff.max():.3e}"
+        return
+    vh = np.sqrt(np.asarray(v_ref, np.float64) / (1.0 - 0.999 ** t))
+    scale = float(np.sqrt(np.mean(vh ** 2)))
+    cap = max_step * lr + 1e-7
+    tol = np.minimum(PARAM_ATOL + lr * (GRAD_NOISE if grad_noise is None else grad_noise) * scale / (vh + 1e-8), cap)
+    tol = np.where(vh == 0.0, PARAM_ATOL, tol)          # an exactly-zero gradient history (dead ReLU paths, pad rows): the entry did not move
+    bad = diff > tol
+    if flip_rows and bad.any():
+        assert diff.max() <= cap, f"{name}: max |diff| {diff.max():.3e} beyond one Adam step"
+        rows = np.flatnonzero(bad.reshape(bad.shape[0], -1).any(axis=1)) if bad.ndim > 1 else np.flatnonzero(bad)
+        assert rows.size <= flip_rows, f"{name}: {rows.size} rows leave the entry bound (first {rows[:8].tolist()}), {flip_rows} ReLU flips allowed"
+        bad = np.zeros_like(bad)
+    worst = int(np.argmax(diff - tol))
+    assert not bad.any(), (f"{name}: entry {worst}: |diff| {diff.flat[worst]:.3e} > {tol.flat[worst]:.3e} "
+                           f"(sqrt(v^) {vh.flat[worst]:.3e}, tensor scale {scale:.3e})")
+    # the bound must not be vacuous: entries it leaves (almost) free -- more than a tenth of a step -- stay a small minority
+    free = int(np.count_nonzero(tol > 0.1 * lr))
+    assert free <= max(2, 0.04 * tol.size), f"{name}: {free} of {tol.size} entries have gradients so far below the tensor's scale that the bound leaves them free"
+
+
+def _v_from_trace(z, s, key):
+    """the reference trace's post-step second moment for parameter / target ``key`` of step ``s`` (None if the trace holds none)"""
+    net, par = key.split("/", 1)
+    net = {"forward_target_net": "forward_net", "backward_target_net": "backward_net", "successor_target_net": "successor_net"}.get(net, net)
+    vk = f"state/{s}/adam_v/{net}/{par}"
+    return z[vk] if vk in z.files else None
+
+
+def _v_of(state, key):
+    """the second-moment tensor that governs parameter / target ``key`` ('net/param') in a state dict with adam_v/... entries"""
+    net, par = key.split("/", 1)
+    net = {"forward_target_net": "forward_net", "backward_target_net": "backward_net", "successor_target_net": "successor_net"}.get(net, net)
+    return state.get(f"adam_v/{net}/{par}")
 
 
 @pytest.mark.parametrize("name,goal_space", [("tiny_trace", None), ("tiny_goal_trace", "simplified_walker"),
@@ -93,7 +140,7 @@ def test_teacher_forced_against_reference_trace(name, goal_space):
             if k.startswith("adam_"):
                 assert H.rel_err(v, ref) < 2e-4, (s, k)
             else:
-                _param_close(v, ref, cfg.lr, f"step {s} {k}")
+                _param_close(v, ref, cfg.lr * max(1.0, cfg.lr_coef), f"step {s} {k}", _v_from_trace(z, s, k), s + 1)
         assert agent.step_counts() == (s + 1, s + 1)
         # alignment columns of every weight, gradient and target stay exactly zero (GEMMs run over padded widths)
         for nv in (agent.forward_net, agent.backward_net, agent.actor, agent.forward_target_net, agent.backward_target_net,
@@ -524,6 +571,7 @@ def test_phase_split_schedule_equals_single_call(monkeypatch):
         monkeypatch.delenv("FBHIP_FORCE_PHASE_SPLIT", raising=False)
         m1 = a1.update_injected(rb, s, d)
         monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+        monkeypatch.setenv("FBHIP_DP_ALLREDUCE", "c10d")      # (the host-issued / torch-level schedule is what this test is about)
         m2 = a2.update_injected(rb, s, d)
         for k in m1:
             assert m2[k] == pytest.approx(m1[k], rel=2e-5, abs=1e-6), (s, k)
@@ -671,6 +719,43 @@ def test_update_many_equals_consecutive_updates():
     for k in s1:
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
         np.testing.assert_array_equal(s1[k], s3[k], err_msg=k)
+
+
+def test_legacy_default_stream_callers_see_the_update_without_a_wait_on_that_stream():
+    """A caller on torch's legacy default stream (what plain reference code is): the update runs on the agent's own stream and
+    the caller's LATER default-stream work must still see it -- through fbhip_order_legacy_stream_after (a wait on a blocking
+    helper stream + the runtime's legacy-stream rule), not through a wait enqueued on the legacy stream, which slows the running
+    graph down 1.5x.  An asynchronous device-side copy enqueued right behind a 16-step launch at walker
+    width must read the FINAL weights; both orderings (FBHIP_LEGACY_STREAM_ORDER=event is the old one) give the same bits."""
+    cfg = fo.OracleConfig(obs_dim=24, action_dim=6, goal_dim=24, z_dim=50, hidden_dim=1024, feature_dim=512,
+                          backward_hidden_dim=526, batch_size=1024)
+    rng = np.random.default_rng(77)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 20, 60, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    assert torch.cuda.current_stream().cuda_stream == 0
+    snaps = []
+    for mode in ("gate", "event", "explicit"):
+        agent = H.make_hip_agent(cfg, nets, metrics=False)
+        torch.cuda.synchronize()
+        if mode == "explicit":
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                agent.update_many(rb, 0, 16)
+            st.synchronize()
+            snaps.append({k: v.clone() for k, v in agent.forward_net.state_dict().items()})
+        else:
+            os.environ["FBHIP_LEGACY_STREAM_ORDER"] = mode
+            try:
+                agent.update_many(rb, 0, 16)                       # returns while the graph is still running (~14 ms of GPU work)
+                snaps.append({k: v.clone() for k, v in agent.forward_net.state_dict().items()})     # async, legacy stream
+            finally:
+                os.environ.pop("FBHIP_LEGACY_STREAM_ORDER", None)
+        torch.cuda.synchronize()
+        assert agent.step_counts() == (16, 16)
+    for k in snaps[0]:
+        assert torch.equal(snaps[0][k], snaps[2][k]), k
+        assert torch.equal(snaps[1][k], snaps[2][k]), k
 
 
 @pytest.mark.parametrize("flags,goal_space", [
@@ -821,7 +906,9 @@ def test_one_update_at_the_edges_of_the_supported_dimensions(dims):
     # (seed note: with seed 41 the maximal case has ONE ForwardMap activation of 96 x 2048 within 2.3e-7 of the ReLU
     # threshold; whether it comes out as 0 or +2e-7 depends on the fp32 summation order of the launch it shares, the mask of
     # one gradient element flips and a whole weight-gradient row moves by 5e-4 -- a discontinuity of the function, found
-    # with tools/edge_probe2.py, not an error of either side.  The seed below keeps every activation clear of the threshold.)
+    # with tools/edge_probe2.py, not an error of either side.  No seed is safe for good: with ~4e6 pre-activations one of them sits
+    # that close for most seeds and any change of tiling moves the lottery, so the maximal case allows two such rows per tensor,
+    # _param_close(flip_rows=2); the gradient rel-L2 bound and the one-step cap hold regardless.)
     rng = np.random.default_rng(43)
     nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
     storage, lengths = fo.synthetic_storage(rng, 6, 9, cfg.obs_dim, cfg.action_dim)
@@ -842,11 +929,24 @@ def test_one_update_at_the_edges_of_the_supported_dimensions(dims):
                 assert H.rel_err(g.cpu(), ref) < 2 * GRAD_REL_L2, (net, k)
     state = H.get_agent_state(agent)
     want = oracle.state_tensors()
+    # the gradient noise the entry bound budgets for is MEASURED here: the fp32 oracle against the same oracle in fp64, per tensor
+    # (rms of the difference over the rms of the gradient; x 10 for the worst entry of up to 4e6 and for two independent fp32
+    # evaluations), never less than the suite-wide GRAD_NOISE
+    o64 = fo.OracleAgent(cfg, nets, torch.float64)
+    o64.update(fo.gather_batch(storage, draws.ep_idx, draws.step_idx, cfg.discount), draws, keep=True)
+    noise = {}
+    for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward"), ("actor", "grads_actor")):
+        for k, g64 in o64.last[key].items():
+            d = (oracle.last[key][k].double() - g64).pow(2).mean().sqrt()
+            noise[f"{net}/{k}"] = max(GRAD_NOISE, 10.0 * float(d / g64.pow(2).mean().sqrt().clamp_min(1e-300)))
+    assert max(noise.values()) < 1e-3, max(noise.items(), key=lambda kv: kv[1])          # (still a noise budget, not a licence)
     for k, v in state.items():
         if not k.startswith("adam_"):
             # the FIRST Adam step moves every entry by lr g / (|g| + 1e-8) ~ +-lr: an entry whose gradient is rounding noise
             # (|g| ~ 1e-8 next to typical 1e-3) can get the opposite sign on the two sides, i.e. differ by up to 2 lr
-            _param_close(v, want[k], cfg.lr, k, max_step=2.0, one_in=250)
+            src = k.replace("forward_target_net/", "forward_net/").replace("backward_target_net/", "backward_net/")
+            _param_close(v, want[k], cfg.lr * max(1.0, cfg.lr_coef), k, _v_of(want, k), 1, grad_noise=noise.get(src),
+                         flip_rows=2 if cfg.hidden_dim >= 2048 and cfg.batch_size >= 96 else 0)
     for nv in (agent.forward_net, agent.backward_net, agent.actor, *agent._grad_views.values()):
         assert nv.pad_abs_max() == 0.0, nv._name
 
@@ -919,13 +1019,20 @@ def _one_random_update(cfg, goal_space, seed):
         amp = max(1.0, float(torch.linalg.cond(Bm.T @ Bm / Bm.shape[0])) / 1e3)
     for k in H.LOSS_KEYS + (("q_loss",) if cfg.q_loss else ()):
         assert m[k] == pytest.approx(om[k], rel=min(2e-4 * amp, 5e-2), abs=2e-5), (k, cfg)
-    for net, key, tol in (("forward_net", "grads_forward", 1e-3), ("backward_net", "grads_backward", 1e-3), ("actor", "grads_actor", 5e-2)):
+    # Gradients: against the EXACT (fp64) evaluation of the same update, with the fp32 oracle's own distance from it as the yardstick:
+    # the HIP step may be at most 4 x as far (+ 1e-6).  Measured over these 124 configurations: ratio median 0.9, worst 3.0; where
+    # the absolute error is large (up to 2e-2: a covariance of condition 1e5 under q_loss, a row changing heads in torch.min) the
+    # fp32 oracle's is as large or larger (tools/tolerance_probe.py, profiles/r03_tolerance_probe.txt).  No fixed loose bound.
+    o64 = fo.OracleAgent(cfg, nets, torch.float64)
+    o64.update(batch, draws, keep=True)
+    for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward"), ("actor", "grads_actor")):
         for k, g in agent._grad_views[net].state_dict().items():
-            ref = oracle.last[key][k]
+            ref = o64.last[key][k]
             if float(ref.abs().max()) == 0.0:
                 assert float(g.abs().max()) == 0.0, (net, k, cfg)
             else:
-                assert H.rel_err(g.cpu(), ref) < min(tol * amp, 0.2), (net, k, H.rel_err(g.cpu(), ref), cfg)
+                e_hip, e_o32 = H.rel_err(g.cpu().double(), ref), H.rel_err(oracle.last[key][k].double(), ref)
+                assert e_hip <= 4.0 * e_o32 + 1e-6, (net, k, e_hip, e_o32, cfg)
     for nv in (agent.forward_net, agent.backward_net, agent.actor, *agent._grad_views.values()):
         assert nv.pad_abs_max() == 0.0, nv._name
 
@@ -960,7 +1067,7 @@ def test_fifty_steps_per_seed_against_the_oracle(seed):
             if k.startswith("adam_"):
                 assert H.rel_err(v, want[k]) < 5e-4, (s, k)
             else:
-                _param_close(v, want[k], cfg.lr, f"seed {seed} step {s} {k}")
+                _param_close(v, want[k], cfg.lr * max(1.0, cfg.lr_coef), f"seed {seed} step {s} {k}", _v_of(want, k), s + 1)
 
 
 def test_time_varying_stddev_schedule_runs_eagerly_and_matches_the_oracle():

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--learner", choices=("icm", "lap", "random", "autoencoder", "transition", "svd_p", "latent", "svd_sr", "svd_srv2", "contrastive", "contrastivev2"), default="icm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--explicit-stream", action="store_true", help="enqueue from an explicit torch stream (like bench.py) instead of the legacy default stream")
     ap.add_argument("--mix-ratio", type=float, default=0.0, help="SFAgent.mix_ratio (sf.py:725-739); the reference default is 0")
     args = ap.parse_args()
     W = dict(obs_dim=24, action_dim=6, goal_dim=24, z_dim=100, hidden_dim=1024, feature_dim=512, backward_hidden_dim=512, batch_size=1024)
@@ -70,6 +71,8 @@ def main():
             agent.update_many(rb, first + done, k) if k > 1 else agent.update(rb, first + done)
             done += k
 
+    if args.explicit_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     run(0, args.warmup)
     for sz in {spl} | ({args.steps % spl} if args.steps % spl else set()):
         run(args.warmup, sz)
