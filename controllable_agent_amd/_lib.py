@@ -89,6 +89,7 @@ PROTOTYPES = {
     "fbhip_update_many_dp": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_dp_status": (C.c_int, [_P, C.POINTER(_I), _P]),
     "fbhip_order_legacy_stream_after": (C.c_int, [_P, _P]),
+    "fbhip_order_stream_after_legacy": (C.c_int, [_P, _P]),
     "fbhip_rccl_load": (C.c_int, [C.c_char_p]),
     "fbhip_rccl_version": (C.c_int, []),
     "fbhip_rccl_unique_id": (C.c_int, [_P]),

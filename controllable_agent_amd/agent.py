@@ -764,16 +764,21 @@ class FBHipAgent:
             fn()
             return
         # the caller sits on the legacy default stream, where stream capture is not allowed: run on the agent's own stream, ordered
-        # after the caller's earlier work by an event and before its later work by fbhip_order_legacy_stream_after -- NOT by making
-        # the legacy stream wait on an event: a command pending on the legacy stream while the n-step graph runs slowed that graph
-        # down 1.5x (include/fbhip.h; DESIGN.md section 6 "The legacy default stream").  No host synchronisation either way.
-        self._stream.wait_stream(cur)
+        # after the caller's earlier work (fbhip_order_stream_after_legacy) and before its later work
+        # (fbhip_order_legacy_stream_after) -- NOT by events recorded on / waited for by the legacy stream: a command pending
+        # there while the n-step graph is enqueued and runs slowed that graph down 1.5x (include/fbhip.h; DESIGN.md section 6
+        # "The legacy default stream").  No host synchronisation either way.
+        gate = os.environ.get("FBHIP_LEGACY_STREAM_ORDER", "gate") != "event"
+        if not gate:
+            self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
+            if gate:
+                check(_lib.load().fbhip_order_stream_after_legacy(self._ctx, stream_ptr()), self._ctx)
             fn()
-            if os.environ.get("FBHIP_LEGACY_STREAM_ORDER", "gate") == "event":
-                cur.wait_stream(self._stream)
-            else:
+            if gate:
                 check(_lib.load().fbhip_order_legacy_stream_after(self._ctx, stream_ptr()), self._ctx)
+            else:
+                cur.wait_stream(self._stream)
 
     def _dp_schedule_graph(self, n_steps: int, hp: HParams, launch: tp.Callable[[int], None]) -> bool:
         """The host-issued data-parallel schedule of ``n_steps`` updates -- four or five phase launches and two or three RCCL

@@ -57,24 +57,41 @@ int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches
     return FBHIP_OK;
 }
 
-// The legacy default stream and work on another stream.  A caller that sits on the legacy (null) stream expects its LATER null-stream
-// work to see what an entry point enqueued elsewhere.  Making the null stream wait on an event does that, but leaves a pending command
-// on the null stream for as long as the graph runs -- and with one there the n-step graphs of this library ran 1.5x slower on
-// MI355X / ROCm 7.0 (measured round 3: 650 vs 970 SF update-steps/s, 700 vs 1117 FB; a wait on any OTHER stream costs nothing).
-// So the wait goes onto one process-wide BLOCKING stream instead: the runtime's own legacy-stream rule (null-stream work waits for
-// every blocking stream's earlier work) then orders the caller's next null-stream command behind it, at the moment there is one.
+// The legacy default stream and work on another stream.  A caller that sits on the legacy (null) stream expects the entry point's
+// work to come after its EARLIER null-stream work and its LATER null-stream work to see what the entry point enqueued elsewhere.
+// Events recorded on / waited for by the null stream do that, but leave a command pending on the null stream while the n-step
+// graph is enqueued and runs -- and with one there the branched graphs of this library ran 1.5x slower on MI355X / ROCm 7.0
+// (measured round 3: 650 vs 970 SF update-steps/s, 700 vs 1117 FB; pending work on a NON-blocking stream costs nothing).  So
+// neither direction touches the null stream: both go through process-wide BLOCKING helper streams and the runtime's own
+// legacy-stream rule (a blocking stream's command waits for earlier null-stream work; a null-stream command waits for every
+// blocking stream's earlier work), which applies at the moment the caller really uses the null stream.
 std::mutex g_gate_mu;
-hipStream_t g_gate_stream = nullptr;
+hipStream_t g_gate_in = nullptr, g_gate_out = nullptr;
 
+int gate_streams(fbhip_ctx* c) {
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    if (g_gate_in == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_in, hipStreamDefault));
+    if (g_gate_out == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_out, hipStreamDefault));
+    return FBHIP_OK;
+}
+
+// later legacy-stream work after everything enqueued on s so far
 int order_legacy_after(fbhip_ctx* c, hipStream_t s) {
     if (s == nullptr) return FBHIP_OK;                 // already on the legacy stream
-    {
-        std::lock_guard<std::mutex> lk(g_gate_mu);
-        if (g_gate_stream == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_stream, hipStreamDefault));
-    }
+    RC(gate_streams(c));
     if (!c->ev_gate) HIPCK(c, hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming));
     HIPCK(c, hipEventRecord(c->ev_gate, s));
-    HIPCK(c, hipStreamWaitEvent(g_gate_stream, c->ev_gate, 0));
+    HIPCK(c, hipStreamWaitEvent(g_gate_out, c->ev_gate, 0));
+    return FBHIP_OK;
+}
+
+// later work on s after everything enqueued on the legacy stream so far
+int order_after_legacy(fbhip_ctx* c, hipStream_t s) {
+    if (s == nullptr) return FBHIP_OK;
+    RC(gate_streams(c));
+    if (!c->ev_gate_in) HIPCK(c, hipEventCreateWithFlags(&c->ev_gate_in, hipEventDisableTiming));
+    HIPCK(c, hipEventRecord(c->ev_gate_in, g_gate_in));     // a blocking stream's marker: behind the null stream's earlier commands
+    HIPCK(c, hipStreamWaitEvent(s, c->ev_gate_in, 0));
     return FBHIP_OK;
 }
 
@@ -92,6 +109,7 @@ void destroy_now(fbhip_ctx* ctx) {
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->ev_out) (void)hipEventDestroy(ctx->ev_out);
     if (ctx->ev_gate) (void)hipEventDestroy(ctx->ev_gate);
+    if (ctx->ev_gate_in) (void)hipEventDestroy(ctx->ev_gate_in);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
@@ -656,6 +674,11 @@ int fbhip_dp_status(fbhip_ctx* c, int32_t* host_status, void* stream) {
 int fbhip_order_legacy_stream_after(fbhip_ctx* c, void* stream) {
     if (!c) return FBHIP_E_INVALID;
     return order_legacy_after(c, (hipStream_t)stream);
+}
+
+int fbhip_order_stream_after_legacy(fbhip_ctx* c, void* stream) {
+    if (!c) return FBHIP_E_INVALID;
+    return order_after_legacy(c, (hipStream_t)stream);
 }
 
 int fbhip_update_many_injected(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injects, void* stream) {

@@ -147,7 +147,7 @@ struct fbhip_ctx {
     hipStream_t side = nullptr;              // second capture branch of fbhip_update_many
     std::vector<hipEvent_t> events;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;   // bridge events of launch_graph (api.hip)
-    hipEvent_t ev_gate = nullptr;                   // fbhip_order_legacy_stream_after
+    hipEvent_t ev_gate = nullptr, ev_gate_in = nullptr;   // fbhip_order_legacy_stream_after / fbhip_order_stream_after_legacy
     hipStream_t last_stream = nullptr;      // the stream of the last update call (fbhip_destroy asks it whether a capture is open)
     hipEvent_t v_ready = nullptr;            // set while the actor phase of a pipelined graph is being built: V comes from the side branch
     fbhip::ReplayView rv{};

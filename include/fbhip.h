@@ -303,6 +303,10 @@ int fbhip_dp_status(fbhip_ctx* ctx, int32_t* host_status, void* stream);
  * runs and was measured to slow that graph down 1.5x (DESIGN.md section 6 "The legacy default stream").  No reference
  * counterpart (torch code is stream-ordered implicitly).  stream == NULL: no-op. */
 int fbhip_order_legacy_stream_after(fbhip_ctx* ctx, void* stream);
+/* The other direction: orders what is enqueued on `stream` from now on after everything the caller has enqueued on the legacy
+ * default stream so far, again without a command on the legacy stream (an event recorded on a blocking helper stream, which the
+ * runtime places behind the legacy stream's earlier work). */
+int fbhip_order_stream_after_legacy(fbhip_ctx* ctx, void* stream);
 /* The workspace holds two complete per-step sets (fbhip_update_many alternates them).  A host that pipelines steps itself
  * (data parallel: the next step's SAMPLE | FB_FWD_ONLINE under this step's actor all-reduce) selects the set the following
  * fbhip_update calls work on; phases of one step must all run on the same set.  Default 0. */

@@ -756,6 +756,31 @@ def test_legacy_default_stream_callers_see_the_update_without_a_wait_on_that_str
     for k in snaps[0]:
         assert torch.equal(snaps[0][k], snaps[2][k]), k
         assert torch.equal(snaps[1][k], snaps[2][k]), k
+    # the other direction: default-stream work enqueued BEFORE the call (a slow chain of matmuls ending in a copy into a weight
+    # matrix) must have landed before the update reads the weights
+    big = torch.randn(4096, 4096, device="cuda")
+    new_w = torch.as_tensor(nets["forward_net"]["F1.0.weight"]).cuda() * 0.5
+    outs = []
+    for mode in ("gate", "explicit"):
+        agent = H.make_hip_agent(cfg, nets, metrics=False)
+        w = agent.forward_net.state_dict()["F1.0.weight"]
+        torch.cuda.synchronize()
+        if mode == "explicit":
+            w.copy_(new_w)
+            torch.cuda.synchronize()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                agent.update_many(rb, 0, 2)
+        else:
+            acc = big
+            for _ in range(12):                                    # ~10 ms of default-stream work in front of the copy
+                acc = torch.mm(acc, big) * 1e-2
+            w.copy_(new_w + 0.0 * acc[:w.shape[0], :w.shape[1]])
+            agent.update_many(rb, 0, 2)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in agent.forward_net.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
 
 
 @pytest.mark.parametrize("flags,goal_space", [
