@@ -154,6 +154,109 @@ def dominant_kernel_probe(stream_iters=50):
                     "per update, whose shapes differ (4.3-8.7 GFLOP, 7-95 us)"}
 
 
+def _beat(what):
+    """progress mark for the supervising parent (supervise_ranks): the child is alive and got this far"""
+    f = os.environ.get("FBHIP_BENCH_HEARTBEAT")
+    if f:
+        try:
+            Path(f).write_text(f"{time.time():.3f} {what}\n")
+        except OSError:
+            pass
+
+
+def supervise_ranks(args, rank, world):
+    """N > 1 under torch.distributed.run: every launched worker becomes a SUPERVISOR that holds no GPU context and runs the real
+    bench rank in a child process, one attempt per gradient transport -- the library's RCCL communicator first, then the
+    torch.distributed schedule, then the peer-access kernels.  A multi-GPU node is available to this script once per round and
+    none of the three transports has ever run on more than one physical device: an attempt that crashes on any rank, or whose
+    slowest rank stops making progress (heartbeat file, --stall-timeout), is killed on ALL ranks (process groups this supervisor
+    started, by pid) and the next transport gets a fresh rendezvous on another port.  The supervisors agree once a second through
+    a gloo group on the launcher's rendezvous.  Rank 0 prints the successful child's JSON line with the attempt history added."""
+    import subprocess
+    import tempfile
+    import signal
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=1800))
+    first = "peer" if args.peer_allreduce else (args.transport or "rccl")
+    transports = [first] if (args.global_batch or args.no_fallback_transports) else [first] + [t for t in ("rccl", "c10d", "peer") if t != first]
+    argv = [a for a in sys.argv[1:] if a != "--peer-allreduce"]
+    while "--transport" in argv:
+        i = argv.index("--transport")
+        del argv[i:i + 2]
+    argv = [a for a in argv if not a.startswith("--transport=")]
+    history, line = [], None
+    tmp = Path(tempfile.mkdtemp(prefix=f"fbhip_bench_r{rank}_"))
+    for attempt, tr in enumerate(transports):
+        port = [0]
+        if rank == 0:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port[0] = sk.getsockname()[1]
+        dist.broadcast_object_list(port, src=0)
+        hb, so = tmp / f"beat{attempt}", tmp / f"out{attempt}"
+        env = dict(os.environ, MASTER_PORT=str(port[0]), FBHIP_BENCH_CHILD="1", FBHIP_BENCH_HEARTBEAT=str(hb),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        for k in ("TORCHELASTIC_USE_AGENT_STORE",):          # the child ranks rendezvous among themselves: rank 0 hosts the store
+            env.pop(k, None)
+        t0 = time.time()
+        with open(so, "wb") as fo:
+            child = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv + ["--transport", tr], env=env,
+                                     stdout=fo, stderr=None, start_new_session=True)
+        outcome = None
+        while True:
+            time.sleep(1.0)
+            rc = child.poll()
+            last = hb.stat().st_mtime if hb.exists() else t0
+            allow = args.stall_timeout if hb.exists() else max(args.stall_timeout, 420.0)      # (a fresh box pages torch in for minutes)
+            mine_failed = (rc is not None and rc != 0) or (rc is None and time.time() - last > allow)
+            st = torch.tensor([1.0 if mine_failed else 0.0, 1.0 if rc == 0 else 0.0])
+            failed, done = st[:1].clone(), st[1:].clone()
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+            dist.all_reduce(done, op=dist.ReduceOp.MIN)
+            if float(failed.item()) > 0:
+                why = f"exit code {rc}" if (rc is not None and rc != 0) else ("no progress" if rc is None and mine_failed else "another rank failed")
+                outcome = f"failed ({why} on rank {rank})" if why != "another rank failed" else "failed (another rank)"
+                if child.poll() is None:
+                    try:
+                        os.killpg(child.pid, signal.SIGKILL)          # the session this supervisor started, nothing else
+                    except ProcessLookupError:
+                        pass
+                child.wait()
+                break
+            if float(done.item()) > 0:
+                outcome = "ok"
+                break
+        beat = hb.read_text().strip() if hb.exists() else "never started"
+        every = [None] * world
+        dist.all_gather_object(every, {"outcome": outcome, "last_progress": beat.split(" ", 1)[-1]})
+        history.append({"transport": tr, "seconds": round(time.time() - t0, 1), "ranks": every})
+        if outcome == "ok":
+            if rank == 0:
+                text = so.read_text(errors="replace")
+                for ln in text.splitlines():
+                    if ln.startswith("{"):
+                        line = ln
+                    else:
+                        print(ln, file=sys.stderr)
+            break
+        if rank == 0:
+            print(f"bench.py: transport {tr} did not finish ({[e['outcome'] for e in every]}); "
+                  + ("trying the next one" if attempt + 1 < len(transports) else "no transport left"), file=sys.stderr, flush=True)
+    ok = [line is not None]
+    dist.broadcast_object_list(ok, src=0)
+    if rank == 0 and line is not None:
+        out = json.loads(line)
+        out.setdefault("data_parallel", {})["attempts"] = history
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok[0]:
+        raise SystemExit("bench.py: no gradient transport completed: " + json.dumps(history))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,6 +289,12 @@ def main():
                          "ncclAllReduce captured inside each rank's n-step update graph (csrc/rccl.hip); c10d: torch.distributed "
                          "collectives between / inside phase graphs (round 2's path); peer: hand-written peer-access kernels "
                          "(= --peer-allreduce).  Falls back to c10d, and says so in the JSON line, if the library transport cannot be set up")
+    ap.add_argument("--stall-timeout", type=float, default=240.0,
+                    help="N > 1: seconds without progress (initialisation, warm-up, each timed repeat) after which the supervising "
+                         "parent gives an attempt up on every rank and tries the next transport")
+    ap.add_argument("--no-fallback-transports", action="store_true", help="N > 1: one attempt, with --transport only")
+    ap.add_argument("--no-supervisor", action="store_true",
+                    help="N > 1: run the rank in the launched process itself (no child process, no second attempt)")
     ap.add_argument("--global-batch", action="store_true",
                     help="data-parallel mode B (FBHipAgent(dp_global_batch=True)): the exact loss of the concatenated "
                          "world x batch rows (one embedding all-gather per step) instead of per-rank blocks with gradient "
@@ -218,6 +327,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched under torch.distributed.run with another --nproc-per-node?)")
+    if world > 1 and os.environ.get("FBHIP_BENCH_CHILD") != "1" and not args.no_supervisor:
+        return supervise_ranks(args, rank, world)
+    _beat("started")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -243,6 +355,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
+    _beat("process group up")
     if args.peer_allreduce or args.transport == "peer":
         args.peer_allreduce = True
         os.environ["FBHIP_DP_ALLREDUCE"] = "peer"
@@ -261,6 +374,13 @@ def main():
     n_eps = max(args.episodes // world, 8) if args.workload == "walker" else max(min(args.episodes, 1000) // world, 8)
     rb = make_replay(n_eps, 1000, W["obs_dim"], W["action_dim"], dev, seed=100 + rank,
                      goal_dim=W["goal_dim"] if goal_space else None)
+
+    _beat("agent and replay shard built")
+    inject = os.environ.get("FBHIP_BENCH_FAIL_TRANSPORT", "")          # tests only: "<transport>:crash" | "<transport>:hang" on rank 1
+    if world > 1 and rank == 1 and inject.split(":")[0] == (args.transport or "rccl"):
+        if inject.endswith(":hang"):
+            time.sleep(3600)
+        os._exit(7)
 
     def barrier():
         torch.cuda.synchronize()
@@ -285,6 +405,8 @@ def main():
     bench_stream = torch.cuda.default_stream(dev) if os.environ.get("FBHIP_BENCH_LEGACY_STREAM") == "1" else torch.cuda.Stream(device=dev)
     with torch.cuda.stream(bench_stream):
         run(0, args.warmup)
+        torch.cuda.synchronize()
+        _beat("warm-up done")
         if world > 1 and not args.rehearse_on_one_gpu and dist.get_backend() == "gloo":
             # did the library transport come up on EVERY rank?  If not (the JSON line says why), do not time host-side gloo
             # collectives: all ranks switch the process group to nccl and the torch.distributed schedule carries the gradients
@@ -323,6 +445,7 @@ def main():
                 wall = float(t.item())
             walls.append(wall)
             events.append(e0.elapsed_time(e1) * 1e-3)
+            _beat(f"timed repeat {rep + 1} of {max(1, args.repeats)} done")
         # the host's own cost of a data-parallel step: one update_many call into an EMPTY queue returns as soon as its launches
         # (and, on the RCCL / gloo path, its collectives) are issued
         host_idle = None

@@ -334,6 +334,33 @@ def test_bench_launches_its_own_ranks_when_not_under_torchrun():
     assert len(dp["per_rank_steps_per_s_median_repeat"]) == 2 and dp["schedule_graph_capture_failed"] is False
 
 
+@pytest.mark.parametrize("how", ["crash", "hang"])
+def test_bench_supervisor_moves_to_the_next_transport_when_a_rank_is_lost(how):
+    """``bench.py --gpus N`` supervises its ranks (bench.py::supervise_ranks): every launched worker runs the real rank in a child
+    process, one attempt per gradient transport.  Here rank 1 of the FIRST attempt dies (exit code 7) or stops making progress
+    (sleeps; --stall-timeout 45) right after building its agent: the attempt must be given up on BOTH ranks -- rank 0's child is
+    then blocked in its first collective -- and the second transport must deliver the one JSON line, with the history in it."""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", FBHIP_BENCH_FAIL_TRANSPORT=f"rccl:{how}")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "32", "--warmup", "8",
+           "--repeats", "1", "--episodes", "400", "--no-cpu-baseline", "--stall-timeout", "45"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=str(root), env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                    # ONE JSON line, from the attempt that finished
+    res = json.loads(lines[0])
+    att = res["data_parallel"]["attempts"]
+    assert [a["transport"] for a in att] == ["rccl", "c10d"], att
+    first = [r["outcome"] for r in att[0]["ranks"]]
+    # (rank 0's child either is killed while blocked in its first collective or notices the closed connection by itself)
+    assert first[1].startswith("failed (" + ("exit code 7" if how == "crash" else "no progress")) and first[0].startswith("failed"), att
+    assert [r["outcome"] for r in att[1]["ranks"]] == ["ok", "ok"]
+    assert res["n_gpus"] == 2 and res["replicas"]["identical"] is True and res["value"] > 0
+
+
 def _worker_peer(rank, port, out_q, mode, world=T.WORLD):
     """``mode`` "peer": FBHIP_DP_ALLREDUCE=peer -- the ranks map each other's gradient buckets (hipIpc) and every data-parallel
     step is ONE graph launch per rank with the all-reduce kernels inside (csrc/peer.hip);  "host": the default schedule with
