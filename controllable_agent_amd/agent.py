@@ -1698,8 +1698,8 @@ class SFHipAgent(FBHipAgent):
     # ---- the hot path
     def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float, future: float = 1.0) -> HParams:
         c = self.cfg
-        if self._world() > 1 and (getattr(c, "dp_global_batch", False) or os.environ.get("FBHIP_DP_ALLREDUCE", "rccl").lower() == "peer"):
-            raise NotImplementedError("SFHipAgent: data parallel = gradient averaging with host-issued all-reduces only")
+        if self._world() > 1 and getattr(c, "dp_global_batch", False):
+            raise NotImplementedError("SFHipAgent: data parallel = gradient averaging (mode A) only; there is no global-batch loss to make exact (sf.py:594-698 has no batch x batch term)")
         # (grad_scale = 1 / world: the data-parallel schedule sums the ranks' gradient buckets, the optimiser passes average them)
         return HParams(lr=c.lr, lr_coef=c.lr_coef, fb_target_tau=c.sf_target_tau, stddev=schedule(c.stddev_schedule, step),
                        stddev_clip=c.stddev_clip, ortho_coef=1.0, mix_ratio=max(float(c.mix_ratio), 0.0), q_loss_coef=0.0, discount=discount, grad_scale=float(grad_scale),
@@ -1736,14 +1736,26 @@ class SFHipAgent(FBHipAgent):
         total = n_steps * int(c.num_sf_updates)                  # (every update() call is num_sf_updates complete updates)
         split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
         const_std = len({schedule(c.stddev_schedule, step + i) for i in range(n_steps)}) == 1
+        from . import peer
+        use_peer = self._world() > 1 and peer.enabled()
         if (split and total >= 2 and isinstance(replay_loader, DeviceReplayBuffer) and c.update_every_steps == 1 and self._use_graph and
-                const_std and self._rccl_ready()):
-            # data parallel, pipelined like the FB agent: the library's RCCL communicator reduces the [sf | phi] and actor buckets
-            # inside the n-step graph (fbhip_update_many_dp; csrc/rccl.hip)
+                const_std and (use_peer or self._rccl_ready())):
+            # data parallel, pipelined like the FB agent: the [sf | phi] and actor buckets are reduced INSIDE the n-step graph
+            # (fbhip_update_many_dp) -- by the library's RCCL communicator (csrc/rccl.hip) or, FBHIP_DP_ALLREDUCE=peer, by the
+            # peer-access kernels (csrc/peer.hip)
             want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
             self._bind_replay(replay_loader)
             self._verify_replicas()
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
+            if use_peer:
+                peer.bind(self)
+                done = 0
+                while done < total:
+                    n = min(64, total - done)
+                    self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many_dp(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
+                    done += n
+                self._check_peer_status(every=1)
+                return self._metrics()
             if self._rccl_run(hp, total):
                 return self._metrics()
             return self.update_many(replay_loader, step, n_steps)

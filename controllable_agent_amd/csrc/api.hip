@@ -615,7 +615,6 @@ int fbhip_dp_bind_peers(fbhip_ctx* c, int32_t world, int32_t rank, float* const*
     if (world > PEER_MAX_WORLD || rank < 0 || rank >= world || !fb_grad_ptrs || !flag_ptrs || !local_state || (has_actor && !actor_grad_ptrs)) {
         c->err = g_err = "fbhip_dp_bind_peers: bad argument (world <= 8, 0 <= rank < world, non-null pointer tables)"; return FBHIP_E_INVALID;
     }
-    if (c->d.sf) { c->err = g_err = "fbhip_dp_bind_peers: dims.sf runs on a single rank"; return FBHIP_E_INVALID; }
     PeerComm pc{};
     pc.world = world; pc.rank = rank; pc.state = (PeerState*)local_state;
     for (int q = 0; q < world; ++q) {

@@ -580,6 +580,59 @@ def test_sf_agent_two_ranks_average_gradients(name):
         np.testing.assert_allclose(got[0][0][k], v, rtol=0, atol=3e-6, err_msg=k)
 
 
+def _worker_sf_transport(rank, port, out_q, name, mode):
+    """device-drawn SF updates on two ranks, gradients carried by the peer-access kernels inside the update graph (``mode`` "peer")
+    or by torch.distributed between the phase launches ("host")"""
+    import torch.distributed as dist
+    from controllable_agent_amd import peer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_DP_ALLREDUCE="peer" if mode == "peer" else "c10d",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=T.WORLD)
+    torch.manual_seed(4321)
+    agent, rb, _, get_sf_state = _sf_inputs(name)
+    agent.update(rb, 0)                        # a single step (n = 1 graph) ...
+    agent.update_many(rb, 1, 4)                # ... four pipelined ones in one launch, twice (graph replay)
+    agent.update_many(rb, 5, 4)
+    torch.cuda.synchronize()
+    st = peer.status(agent) if mode == "peer" else 0
+    out_q.put((rank, get_sf_state(agent), agent.step_counts(), st, getattr(agent, "_peer_bound", False)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["tiny_sf_svdp_trace", "tiny_sf_icm_trace"])
+def test_sf_agent_peer_allreduce_inside_the_graph_equals_the_host_schedule(name):
+    """the SF sibling on the in-graph transports.  Two REAL ranks on one GPU (RCCL refuses two ranks per device,
+    so the peer kernels stand in for the library's communicator: same entry point, fbhip_update_many_dp, same places in the graph):
+    replicas bit-identical, no barrier timeout, and the state lands where the host-issued schedule lands (fp32 summation order of
+    the regrouped launches at most)."""
+    import torch.multiprocessing as mp
+    res = {}
+    for mode in ("peer", "host"):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = T._free_port()
+        procs = [ctx.Process(target=_worker_sf_transport, args=(r, port, q, name, mode)) for r in range(T.WORLD)]
+        for p in procs:
+            p.start()
+        res[mode] = sorted((q.get(timeout=300) for _ in range(T.WORLD)), key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    for mode, got in res.items():
+        assert got[0][2] == got[1][2], (mode, got[0][2], got[1][2])
+        for k in got[0][1]:
+            np.testing.assert_array_equal(got[0][1][k], got[1][1][k], err_msg=f"{mode} {k}")         # replicas identical
+    assert res["peer"][0][2] == res["host"][0][2]
+    assert all(r[3] == 0 for r in res["peer"]), "a peer barrier timed out"
+    assert all(r[4] for r in res["peer"]) and not any(r[4] for r in res["host"])
+    for k, v in res["host"][0][1].items():
+        if "adam_" in k or k.startswith(("m/", "v/")):
+            assert H.rel_err(res["peer"][0][1][k], v) < 2e-3, k
+        else:
+            np.testing.assert_allclose(res["peer"][0][1][k], v, rtol=0, atol=2e-5, err_msg=k)
+
+
 def test_captures_beside_the_rccl_watchdog_do_not_abort_the_process():
     """c10d's RCCL watchdog thread polls the end event of every finished collective; a poll that lands while a stream capture is active in
     the process makes the HIP runtime answer hipErrorCapturedEvent, the watchdog throws and the process aborts (SIGABRT) -- seen in ~7 %
