@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for i in $(seq 1 $N); do
   timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/${TAG}_last.log 2>&1
   rc=$?
-  echo "run $i rc=$rc $(tail -1 gpurun_out/${TAG}_last.log)" >> gpurun_out/$TAG.txt
+  echo "run $i rc=$rc $(grep -E '^(=+ )?[0-9]+ (passed|failed)|^[0-9]+ failed' gpurun_out/${TAG}_last.log | tail -1) [$(date +%H:%M:%S)]" >> gpurun_out/$TAG.txt
   if [ $rc -ne 0 ]; then cp gpurun_out/${TAG}_last.log gpurun_out/${TAG}_fail_$i.log; fi
 done
 cat gpurun_out/$TAG.txt
