@@ -338,11 +338,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane: with the library-owned RCCL transport (the default) the process group only carries the 128-byte unique id,
-        # the replica checksums and this script's barriers -- gloo, so that no c10d watchdog thread exists that could poll an event
-        # during one of the library's stream captures; the c10d transports need the nccl backend (RCCL refuses two ranks per device:
-        # the one-GPU rehearsal stays on gloo and falls back to host-issued collectives)
+        # the replica checksums and this script's barriers.  It is an nccl group all the same: on one rank the library's n-step
+        # data-parallel graph replays at 1112 update-steps/s beside a c10d nccl group and at 471 beside a gloo group or none
+        # (deterministic, cause not found: profiles/r03_world1_rccl_control_plane.txt), and the library captures in thread-local
+        # mode, which the c10d watchdog's event polls cannot invalidate (tests/test_distributed_gpu.py::
+        # test_library_rccl_transport_beside_a_live_c10d_group_needs_no_quiescing).  FBHIP_BENCH_CONTROL_PLANE=gloo selects the
+        # other one.  (RCCL refuses two ranks per device: the one-GPU rehearsal stays on gloo and falls back to host-issued
+        # collectives.)
         transport = "peer" if args.peer_allreduce else (args.transport or "rccl")
-        if args.rehearse_on_one_gpu or transport == "rccl":
+        if args.rehearse_on_one_gpu or (transport == "rccl" and os.environ.get("FBHIP_BENCH_CONTROL_PLANE", "nccl") == "gloo"):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
@@ -353,8 +357,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29535")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        dist.init_process_group(os.environ.get("FBHIP_BENCH_WORLD1_BACKEND", "nccl"), **({"device_id": torch.device(dev)} if os.environ.get("FBHIP_BENCH_WORLD1_BACKEND", "nccl") == "nccl" else {}))
 
+    if os.environ.get("FBHIP_BENCH_EXTRA_STREAMS"):          # diagnostic: shift the runtime's stream -> hardware-queue assignment
+        _extra_streams = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ["FBHIP_BENCH_EXTRA_STREAMS"]))]
     _beat("process group up")
     if args.peer_allreduce or args.transport == "peer":
         args.peer_allreduce = True
@@ -407,18 +413,19 @@ def main():
         run(0, args.warmup)
         torch.cuda.synchronize()
         _beat("warm-up done")
-        if world > 1 and not args.rehearse_on_one_gpu and dist.get_backend() == "gloo":
-            # did the library transport come up on EVERY rank?  If not (the JSON line says why), do not time host-side gloo
-            # collectives: all ranks switch the process group to nccl and the torch.distributed schedule carries the gradients
-            flag = torch.tensor([1.0 if getattr(agent, "_rccl_failed", False) else 0.0])
+        if world > 1 and not args.rehearse_on_one_gpu and os.environ.get("FBHIP_DP_ALLREDUCE", "rccl") == "rccl":
+            # did the library transport come up on EVERY rank?  If not (the JSON line says why), all ranks switch to the
+            # torch.distributed schedule together (on an nccl group: host-side gloo collectives are not what this line times)
+            flag = torch.tensor([1.0 if getattr(agent, "_rccl_failed", False) else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if float(flag.item()) > 0.0:
                 agent._rccl_failed = True
                 agent._dp_transport = getattr(agent, "_dp_transport", None) if str(getattr(agent, "_dp_transport", "")).startswith("c10d") else \
                     "c10d (library RCCL transport refused on another rank)"
                 torch.cuda.synchronize()
-                dist.destroy_process_group()
-                dist.init_process_group("nccl", device_id=torch.device(dev))
+                if dist.get_backend() != "nccl":
+                    dist.destroy_process_group()
+                    dist.init_process_group("nccl", device_id=torch.device(dev))
                 run(0, args.warmup)
         # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
         # untimed launch of each size (these are additional warm-up steps)

@@ -587,6 +587,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (he != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCK(c, he); }
     HIPCK(c, e);
+    if (const char* dot = getenv("FBHIP_GRAPH_DOT")) (void)hipGraphDebugDotPrint(graph, dot, 0);       // diagnostics: what a capture really holds
     GraphEntry ge{};
     ge.mask = FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0); ge.hp = *hp; ge.has_inj = injs != nullptr; ge.n_steps = n_steps; ge.set = c->cur;
     // (cache key: EVERY step's inject struct -- a caller that reuses its per-step buffers replays the same graph; one whose allocator
