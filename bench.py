@@ -427,6 +427,29 @@ def main():
                     dist.destroy_process_group()
                     dist.init_process_group("nccl", device_id=torch.device(dev))
                 run(0, args.warmup)
+        # The library's n-step data-parallel graph has two forms: pipelined (the next step's head on a second branch beside the
+        # actor phase and its all-reduce) and plain.  On ROCm 7.0 the branched form has a slow mode (2.3x) that depends on what
+        # else lives in the process (profiles/r03_world1_rccl_control_plane.txt); no multi-GPU box was ever available to see
+        # which way it falls there.  So: time two launches of each form now, untimed warm-up steps as far as the line is
+        # concerned, keep the faster one on ALL ranks (the slowest rank decides) and say so in the line.
+        dp_forms = None
+        if (world > 1 and spl > 1 and not args.global_batch and os.environ.get("FBHIP_DP_ALLREDUCE", "rccl") in ("rccl", "peer")
+                and not getattr(agent, "_rccl_failed", False) and os.environ.get("FBHIP_UPDATE_PIPELINE") is None):
+            rates = {}
+            for form in ("1", "0"):
+                os.environ["FBHIP_UPDATE_PIPELINE"] = form
+                run(args.warmup, spl)                          # captured here
+                barrier()
+                t0 = time.perf_counter()
+                run(args.warmup, 2 * spl)
+                barrier()
+                t = torch.tensor([2 * spl / (time.perf_counter() - t0)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                rates[form] = float(t.item())
+            keep = "1" if rates["1"] >= 0.97 * rates["0"] else "0"
+            os.environ["FBHIP_UPDATE_PIPELINE"] = keep
+            dp_forms = {"pipelined_kept": keep == "1", "calibration_steps_per_s_slowest_rank": {"pipelined": rates["1"], "plain": rates["0"]}}
+            _beat("graph form chosen")
         # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
         # untimed launch of each size (these are additional warm-up steps)
         sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
@@ -535,6 +558,7 @@ def main():
                               ("c10d-rccl-host" if (getattr(agent, "_dp_graph_failed", False) or os.environ.get("FBHIP_DP_GRAPH", "1") == "0"
                                                     or spl == 1) else "c10d-rccl-graph"))),
                 "library_rccl_refused": bool(getattr(agent, "_rccl_failed", False)),
+                "graph_form": dp_forms,
                 "schedule_graph_capture_failed": bool(getattr(agent, "_dp_graph_failed", False)),
                 "nccl_env": {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                                      "HSA_ENABLE_IPC_MODE_LEGACY")},

@@ -470,8 +470,13 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
     reap(s);
+    // (FBHIP_UPDATE_PIPELINE is read at every call: a host can time both forms of a graph and keep the faster one, bench.py does
+    // for the data-parallel graph, whose branched form has a slow mode on ROCm 7.0 that depends on what else lives in the process)
+    const char* pe = getenv("FBHIP_UPDATE_PIPELINE");
+    const bool pipe = !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete;    // (discrete: no actor phase to overlap with)
     for (auto& g : c->graphs) {
         if (g.n_steps == n_steps && g.set == c->cur && g.mask == (FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0)) && g.has_inj == (injs != nullptr) &&
+            g.branches == pipe &&
             (!injs || (g.injs.size() == (size_t)n_steps && memcmp(g.injs.data(), injs, sizeof(*injs) * n_steps) == 0)) && memcmp(&g.hp, hp, sizeof(*hp)) == 0)
             return launch_graph(c, g.exec, s, g.branches);
     }
@@ -485,8 +490,6 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     // chain: fp32 summation order, not math (tests/test_update_parity_gpu.py covers both).  Measured (walker, 8 steps per launch): 951 -> 965
     // updates/s.  (Zipping the two programs round by round into the SAME launches instead was slower, 933/s: one tile
     // configuration per launch makes the thin GEMMs of one program stragglers of the other's fat ones.)
-    static const bool pipelined = [] { const char* e = getenv("FBHIP_UPDATE_PIPELINE"); return !(e && e[0] == '0'); }();
-    const bool pipe = pipelined && n_steps > 1 && !c->d.discrete;               // (discrete: no actor phase to overlap with)
     if (pipe) {
         if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         while ((int)c->events.size() < 3 * 64) {

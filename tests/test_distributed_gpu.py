@@ -334,6 +334,28 @@ def test_bench_launches_its_own_ranks_when_not_under_torchrun():
     assert len(dp["per_rank_steps_per_s_median_repeat"]) == 2 and dp["schedule_graph_capture_failed"] is False
 
 
+def test_bench_times_both_forms_of_the_data_parallel_graph_and_keeps_the_faster():
+    """The library's n-step data-parallel graph (fbhip_update_many_dp) pipelined and plain: bench.py times both after the warm-up
+    (the branched form has a slow mode on ROCm 7.0 that depends on the rest of the process), keeps the faster
+    on every rank and reports the choice.  Two ranks on this GPU with the peer kernels inside the graph."""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FBHIP_UPDATE_PIPELINE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--peer-allreduce", "--no-fallback-transports",
+           "--steps", "64", "--warmup", "8", "--repeats", "1", "--episodes", "400", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    form = res["data_parallel"]["graph_form"]
+    cal = form["calibration_steps_per_s_slowest_rank"]
+    assert cal["pipelined"] > 0 and cal["plain"] > 0
+    assert form["pipelined_kept"] == (cal["pipelined"] >= 0.97 * cal["plain"])
+    assert res["replicas"]["identical"] is True and res["data_parallel"]["transport"] == "peer"
+    assert res["value"] > 0.5 * 2 * max(cal.values())            # (two ranks) the timed region ran in the kept form
+
+
 @pytest.mark.parametrize("how", ["crash", "hang"])
 def test_bench_supervisor_moves_to_the_next_transport_when_a_rank_is_lost(how):
     """``bench.py --gpus N`` supervises its ranks (bench.py::supervise_ranks): every launched worker runs the real rank in a child
