@@ -472,8 +472,10 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     reap(s);
     // (FBHIP_UPDATE_PIPELINE is read at every call: a host can time both forms of a graph and keep the faster one, bench.py does
     // for the data-parallel graph, whose branched form has a slow mode on ROCm 7.0 that depends on what else lives in the process)
+    // Default: pipelined for the single-rank graph (never seen slow), PLAIN for the data-parallel one unless asked for with "1".
     const char* pe = getenv("FBHIP_UPDATE_PIPELINE");
-    const bool pipe = !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete;    // (discrete: no actor phase to overlap with)
+    const bool want = dp ? (pe && pe[0] == '1') : !(pe && pe[0] == '0');
+    const bool pipe = want && n_steps > 1 && !c->d.discrete;                     // (discrete: no actor phase to overlap with)
     for (auto& g : c->graphs) {
         if (g.n_steps == n_steps && g.set == c->cur && g.mask == (FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0)) && g.has_inj == (injs != nullptr) &&
             g.branches == pipe &&

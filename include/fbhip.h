@@ -277,8 +277,10 @@ int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t 
  * fbhip_peer_allreduce enqueues a sum-all-reduce of one bucket (which: 0 FB, 1 actor) as three kernels -- reduce-scatter,
  * all-gather, release, each behind a flag barrier across the ranks -- on ``stream``; capturable; deterministic; every rank must
  * enqueue the same sequence.  fbhip_update_many_dp is fbhip_update_many for a bound rank: n_steps complete data-parallel updates
- * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph, the
- * next step's SAMPLE | FB_FWD_ONLINE on the second branch beside the actor phase and its all-reduce.  fbhip_dp_status blocks and
+ * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph; with
+ * FBHIP_UPDATE_PIPELINE=1 in the environment (read at every call) also the next step's SAMPLE | FB_FWD_ONLINE on a second branch
+ * beside the actor phase and its all-reduce -- opt-in, because that branched form has a 2.3x slow mode on ROCm 7.0 that depends on
+ * what else lives in the process: time both once and keep the faster, as bench.py does.  fbhip_dp_status blocks and
  * returns the status word (0 ok, 1 = a peer did not arrive within the spin limit: results of that step are garbage, nothing hangs). */
 /* The library's own RCCL transport for the same two buckets (csrc/rccl.hip): fbhip_update_many_dp then enqueues ncclAllReduce on
  * the update's stream INSIDE its capture -- one graph per rank per n_steps updates, collectives included, no process-group object
