@@ -19,6 +19,13 @@ import sys
 import time
 from pathlib import Path
 
+# Runtime configuration, set before the HIP runtime is loaded (import torch).  ROC_CPU_WAIT_FOR_SIGNAL=1: ROCclr resolves a
+# dependency on another hardware queue's signal by waiting for it on the host instead of parking a barrier packet on it.  The
+# n-step update graph has two to three branches, i.e. cross-queue dependencies at every fork and join: measured +3.2 % on the
+# bench line (1116.5 -> 1151.9 update-steps/s, same box) and the cure for most of the branched data-parallel graph's slow mode
+# (470 -> 992).  An explicit setting in the environment wins.  Reported in config.runtime_env.
+os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "1")
+
 import numpy as np
 import torch
 
@@ -446,7 +453,7 @@ def main():
                 t = torch.tensor([2 * spl / (time.perf_counter() - t0)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 rates[form] = float(t.item())
-            keep = "1" if rates["1"] >= 0.97 * rates["0"] else "0"
+            keep = "1" if rates["1"] >= 1.03 * rates["0"] else "0"        # (the branched form must EARN its place: two launches are a short sample)
             os.environ["FBHIP_UPDATE_PIPELINE"] = keep
             dp_forms = {"pipelined_kept": keep == "1", "calibration_steps_per_s_slowest_rank": {"pipelined": rates["1"], "plain": rates["0"]}}
             _beat("graph form chosen")
@@ -536,7 +543,7 @@ def main():
                                    ("fb_ddpg offline on quadruped_walk replay (configs[2]): obs 78, action 12, goal space "
                                     f"simplified_quadruped (g=2), z_dim 100, batch 2048 per GPU; {n_eps}-episode x 1000-step "
                                     "synthetic replay resident in HBM; metrics off"),
-                       "steps_per_graph_launch": spl, **({"dp_loss": "global batch (mode B)" + (f", pretend world {args.pretend_world}" if args.pretend_world > 1 else "")} if args.global_batch else {}),
+                       "steps_per_graph_launch": spl, "runtime_env": {"ROC_CPU_WAIT_FOR_SIGNAL": os.environ.get("ROC_CPU_WAIT_FOR_SIGNAL")}, **({"dp_loss": "global batch (mode B)" + (f", pretend world {args.pretend_world}" if args.pretend_world > 1 else "")} if args.global_batch else {}),
                        "global_batch": W["batch_size"] * world, "parallelism": f"dp{world}",
                        **({"allreduce": "peer-access kernels inside the update graph (csrc/peer.hip)" if args.peer_allreduce else
                            ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "RCCL via torch.distributed between phase graphs")} if world > 1 else {}),

@@ -351,7 +351,7 @@ def test_bench_times_both_forms_of_the_data_parallel_graph_and_keeps_the_faster(
     form = res["data_parallel"]["graph_form"]
     cal = form["calibration_steps_per_s_slowest_rank"]
     assert cal["pipelined"] > 0 and cal["plain"] > 0
-    assert form["pipelined_kept"] == (cal["pipelined"] >= 0.97 * cal["plain"])
+    assert form["pipelined_kept"] == (cal["pipelined"] >= 1.03 * cal["plain"])
     assert res["replicas"]["identical"] is True and res["data_parallel"]["transport"] == "peer"
     assert res["value"] > 0.5 * 2 * max(cal.values())            # (two ranks) the timed region ran in the kept form
 

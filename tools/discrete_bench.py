@@ -8,6 +8,8 @@ with the same roofline / cpu_baseline objects as bench.py (cpu_baseline = oracle
 
     python tools/discrete_bench.py [--steps 2000] [--warmup 100] [--actions 6] [--boltzmann] [--no-cpu-baseline]
 """
+import os
+os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "1")      # before the HIP runtime loads; see bench.py
 import argparse
 import json
 import sys

@@ -9,6 +9,8 @@ publishes no benchmark configuration for this agent.  Prints one JSON line with 
 
     python tools/sf_bench.py [--steps 2000] [--warmup 100] [--learner icm|lap|random|autoencoder|transition|svd_p|latent|svd_sr|svd_srv2|contrastive|contrastivev2] [--no-cpu-baseline]
 """
+import os
+os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "1")      # before the HIP runtime loads; see bench.py
 import argparse
 import json
 import sys
