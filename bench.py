@@ -9,6 +9,13 @@ One "step" = one FBDDPGAgent.update(): on-device replay sample + FB step + actor
 as one hipGraph; inputs (the 5000-episode synthetic replay buffer) are resident in HBM before the timed region.
 N>1 is data parallel (SURVEY.md section 8e mode A): every rank owns a replay shard and a 1024-transition
 minibatch, gradients are all-reduced (RCCL) twice per step -> weak scaling; value = N * K / max-over-ranks time.
+For N>1 every launched worker supervises a child process that is the real rank (supervise_ranks): a crash or a stall moves all
+ranks on to the next gradient transport; the line then carries data_parallel.attempts.
+
+Environment read by this script (diagnostics, none needed for the line): ROC_CPU_WAIT_FOR_SIGNAL (default set here to 1, see
+below), FBHIP_BENCH_CONTROL_PLANE=gloo|nccl (process group beside the library RCCL transport), FBHIP_BENCH_LEGACY_STREAM=1
+(enqueue from torch's legacy default stream), FBHIP_BENCH_WORLD1_BACKEND / FBHIP_BENCH_EXTRA_STREAMS (one-rank probes of
+DESIGN.md section 7's slow mode), FBHIP_BENCH_FAIL_TRANSPORT (tests of the supervisor).
 """
 from __future__ import annotations
 
