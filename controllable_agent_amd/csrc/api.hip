@@ -23,20 +23,25 @@ using namespace fbhip::host;
 // library's own, ordered behind and ahead of the caller's stream with two events (no host synchronisation).
 namespace {
 
+constexpr int MAX_DEVICES = 64;
 std::mutex g_launch_mu;
-hipStream_t g_launch_stream = nullptr;            // process-wide, never destroyed
+hipStream_t g_launch_stream[MAX_DEVICES] = {};    // one per device (of the CURRENT device of the calling thread), never destroyed
 
 hipError_t launch_stream(hipStream_t* out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MAX_DEVICES) return hipErrorInvalidDevice;
     std::lock_guard<std::mutex> lk(g_launch_mu);
-    if (g_launch_stream == nullptr) {
+    if (g_launch_stream[dev] == nullptr) {
         int lo = 0, hi = 0;
-        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (e != hipSuccess) return e;
         if (hi >= lo) return hipErrorNotSupported;     // no high-priority class: the guard above cannot be given
-        e = hipStreamCreateWithPriority(&g_launch_stream, hipStreamNonBlocking, hi);
+        e = hipStreamCreateWithPriority(&g_launch_stream[dev], hipStreamNonBlocking, hi);
         if (e != hipSuccess) return e;
     }
-    *out = g_launch_stream;
+    *out = g_launch_stream[dev];
     return hipSuccess;
 }
 
@@ -62,35 +67,41 @@ int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches
 // Events recorded on / waited for by the null stream do that, but leave a command pending on the null stream while the n-step
 // graph is enqueued and runs -- and with one there the branched graphs of this library ran 1.5x slower on MI355X / ROCm 7.0
 // (measured round 3: 650 vs 970 SF update-steps/s, 700 vs 1117 FB; pending work on a NON-blocking stream costs nothing).  So
-// neither direction touches the null stream: both go through process-wide BLOCKING helper streams and the runtime's own
+// neither direction touches the null stream: both go through per-device BLOCKING helper streams and the runtime's own
 // legacy-stream rule (a blocking stream's command waits for earlier null-stream work; a null-stream command waits for every
 // blocking stream's earlier work), which applies at the moment the caller really uses the null stream.
 std::mutex g_gate_mu;
-hipStream_t g_gate_in = nullptr, g_gate_out = nullptr;
+hipStream_t g_gate_in[MAX_DEVICES] = {}, g_gate_out[MAX_DEVICES] = {};      // per device: the legacy-stream rule is per device
 
-int gate_streams(fbhip_ctx* c) {
+int gate_streams(fbhip_ctx* c, hipStream_t* in, hipStream_t* out) {
+    int dev = 0;
+    HIPCK(c, hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) { c->err = g_err = "fbhip: device ordinal out of range"; return FBHIP_E_INVALID; }
     std::lock_guard<std::mutex> lk(g_gate_mu);
-    if (g_gate_in == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_in, hipStreamDefault));
-    if (g_gate_out == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_out, hipStreamDefault));
+    if (g_gate_in[dev] == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_in[dev], hipStreamDefault));
+    if (g_gate_out[dev] == nullptr) HIPCK(c, hipStreamCreateWithFlags(&g_gate_out[dev], hipStreamDefault));
+    *in = g_gate_in[dev]; *out = g_gate_out[dev];
     return FBHIP_OK;
 }
 
 // later legacy-stream work after everything enqueued on s so far
 int order_legacy_after(fbhip_ctx* c, hipStream_t s) {
     if (s == nullptr) return FBHIP_OK;                 // already on the legacy stream
-    RC(gate_streams(c));
+    hipStream_t gin = nullptr, gout = nullptr;
+    RC(gate_streams(c, &gin, &gout));
     if (!c->ev_gate) HIPCK(c, hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming));
     HIPCK(c, hipEventRecord(c->ev_gate, s));
-    HIPCK(c, hipStreamWaitEvent(g_gate_out, c->ev_gate, 0));
+    HIPCK(c, hipStreamWaitEvent(gout, c->ev_gate, 0));
     return FBHIP_OK;
 }
 
 // later work on s after everything enqueued on the legacy stream so far
 int order_after_legacy(fbhip_ctx* c, hipStream_t s) {
     if (s == nullptr) return FBHIP_OK;
-    RC(gate_streams(c));
+    hipStream_t gin = nullptr, gout = nullptr;
+    RC(gate_streams(c, &gin, &gout));
     if (!c->ev_gate_in) HIPCK(c, hipEventCreateWithFlags(&c->ev_gate_in, hipEventDisableTiming));
-    HIPCK(c, hipEventRecord(c->ev_gate_in, g_gate_in));     // a blocking stream's marker: behind the null stream's earlier commands
+    HIPCK(c, hipEventRecord(c->ev_gate_in, gin));           // a blocking stream's marker: behind the null stream's earlier commands
     HIPCK(c, hipStreamWaitEvent(s, c->ev_gate_in, 0));
     return FBHIP_OK;
 }
