@@ -300,7 +300,7 @@ int fbhip_update_many_dp(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_step
 int fbhip_dp_status(fbhip_ctx* ctx, int32_t* host_status, void* stream);
 /* For hosts whose caller sits on the LEGACY default stream (torch's default stream, handle 0) while the entry points above ran on
  * `stream`: orders every later legacy-stream command after what has been enqueued on `stream` so far WITHOUT enqueuing anything on
- * the legacy stream (a wait is put on a process-wide blocking helper stream; the runtime's legacy-stream rule does the rest when
+ * the legacy stream (a wait is put on a per-device blocking helper stream; the runtime's legacy-stream rule does the rest when
  * the caller next uses the legacy stream).  A wait enqueued on the legacy stream itself stays pending while the n-step graph
  * runs and was measured to slow that graph down 1.5x (DESIGN.md section 6 "The legacy default stream").  No reference
  * counterpart (torch code is stream-ordered implicitly).  stream == NULL: no-op. */
