@@ -227,8 +227,9 @@ def supervise_ranks(args, rank, world):
             env.pop(k, None)
         t0 = time.time()
         with open(so, "wb") as fo:
-            child = subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv + ["--transport", tr], env=env,
-                                     stdout=fo, stderr=None, start_new_session=True)
+            cmd = json.loads(os.environ["FBHIP_BENCH_CHILD_CMD"]) if os.environ.get("FBHIP_BENCH_CHILD_CMD") else \
+                [sys.executable, str(Path(__file__).resolve())]                    # (the override: CPU tests of this function)
+            child = subprocess.Popen(cmd + argv + ["--transport", tr], env=env, stdout=fo, stderr=None, start_new_session=True)
         outcome = None
         while True:
             time.sleep(1.0)
@@ -277,6 +278,8 @@ def supervise_ranks(args, rank, world):
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     if not ok[0]:
         raise SystemExit("bench.py: no gradient transport completed: " + json.dumps(history))
 

@@ -178,3 +178,32 @@ def test_dp_update_many_call_order_and_workspace_sets():
         assert per_step[st] & m == 0
         per_step[st] |= m
     assert per_step == [D.PHASE_ALL] * 3
+
+
+@pytest.mark.parametrize("plan,expect", [
+    ("", [("rccl", "1", "ok")]),
+    ("rccl:1:1:crash", [("rccl", "1", "failed"), ("rccl", "0", "ok")]),
+    ("rccl:*:1:hang,c10d:*:0:crash", [("rccl", "1", "failed"), ("rccl", "0", "failed"), ("c10d", "0", "failed"), ("peer", "0", "ok")]),
+])
+def test_bench_supervisor_walks_its_plan_of_transports(plan, expect, tmp_path):
+    """bench.py::supervise_ranks without a GPU: two supervisors under torch.distributed.run (gloo), the real ranks replaced by
+    tests/fake_bench_child.py.  A child that exits non-zero or stops writing its heartbeat fails the attempt on BOTH ranks; the
+    plan goes (first transport, host-side dependency waits) -> (same transport, runtime default) -> the other transports; rank 0
+    prints exactly one JSON line, the finishing child's, with the attempt history added."""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ROC_CPU_WAIT_FOR_SIGNAL",
+                                                            "FBHIP_BENCH_CPU_WAIT_DEFAULTED", "FBHIP_BENCH_CHILD")}
+    env.update(FBHIP_BENCH_CHILD_CMD=json.dumps([sys.executable, str(root / "tests" / "fake_bench_child.py")]), FAKE_CHILD_PLAN=plan)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--stall-timeout", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root), env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    att = res["data_parallel"]["attempts"]
+    got = [(a["transport"], a["ROC_CPU_WAIT_FOR_SIGNAL"], "ok" if all(r["outcome"] == "ok" for r in a["ranks"]) else "failed") for a in att]
+    assert got == expect, att
+    assert res["data_parallel"]["transport"] == expect[-1][0] and "some library banner" not in out.stdout
