@@ -18,7 +18,6 @@ PHASE_FB_FWD_TARGET, PHASE_FB_BWD_B = 128, 256
 PHASE_FB_BWD = PHASE_FB_BWD_A | PHASE_FB_BWD_B
 PHASE_FB_FWD = PHASE_FB_FWD_ONLINE | PHASE_FB_FWD_TARGET
 PHASE_FB_GRAD, PHASE_ALL = PHASE_FB_FWD | PHASE_FB_BWD, 511
-PHASE_KEEP_PLANES = 4096        # not a phase: skip the rebuild of the parameters' bf16-plane images (include/fbhip.h)
 NUM_METRICS = 32
 # metric name -> index in the device metrics array (fb_ddpg.py:356-377, 413-418)
 METRIC_INDEX = {n: i for i, n in enumerate(
@@ -110,8 +109,6 @@ PROTOTYPES = {
     "fbhip_discrete_act_host": (C.c_int, [_P, _P, _P, _P, _P]),
     "fbhip_gemm": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "fbhip_gemm_cfg": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "fbhip_gemm_p3": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P]),
-    "fbhip_p3_split": (C.c_int, [_P, _I, _P, _I, _P]),
     "fbhip_ln_tanh_fwd": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
     "fbhip_ln_tanh_bwd": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "fbhip_l2norm_fwd": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _P]),
@@ -143,7 +140,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 16:
+    if lib.fbhip_abi_version() != 17:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -188,16 +188,10 @@ int fbhip_layout_entry(const fbhip_dims* dims, int net, int idx, fbhip_tensor_de
     out->offset = s.off; out->rows = s.rows; out->cols = s.cols; out->ld = s.ld;
     return FBHIP_OK;
 }
-// bytes of the P3 images (csrc/p3.h: 1.5 x the fp32 bytes) of the parameter buffers that GEMMs read: FB parameters, FB targets, actor
-static size_t p3_param_shadow_bytes(const fbhip_dims& d) {
-    const size_t n_fb = (size_t)(build_layout(d, 0).numel + build_layout(d, 1).numel), n_ac = (size_t)build_layout(d, 2).numel;
-    return (2 * n_fb + n_ac) * 6 + 3 * 256;
-}
 size_t fbhip_workspace_bytes(const fbhip_dims* dims) {
     if (check_dims(dims) != FBHIP_OK) return 0;
-    // two complete sets (fbhip_update_many pipelines consecutive steps) + the P3 images of the parameter buffers
-    const size_t one = carve(*dims, nullptr).total_bytes;
-    return 2 * one + p3_param_shadow_bytes(*dims);
+    // two complete sets (fbhip_update_many pipelines consecutive steps)
+    return 2 * carve(*dims, nullptr).total_bytes;
 }
 
 int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
@@ -243,7 +237,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     if (!fb_params || !fb_grads || !fb_adam_m || !fb_adam_v || !fb_targets || !workspace ||
         (has_actor && (!actor_params || !actor_grads || !actor_adam_m || !actor_adam_v))) { c->err = g_err = "fbhip: null buffer"; return FBHIP_E_INVALID; }
     const size_t one = carve(c->d, nullptr).total_bytes, need = 2 * one;
-    if (workspace_bytes < need + p3_param_shadow_bytes(c->d)) { c->err = g_err = "fbhip: workspace too small (fbhip_workspace_bytes)"; return FBHIP_E_INVALID; }
+    if (workspace_bytes < need) { c->err = g_err = "fbhip: workspace too small (fbhip_workspace_bytes)"; return FBHIP_E_INVALID; }
     if (((uintptr_t)workspace & 255) || ((uintptr_t)fb_params & 15) || ((uintptr_t)fb_grads & 15) ||
         ((uintptr_t)fb_targets & 15) || (has_actor && (((uintptr_t)actor_params & 15) || ((uintptr_t)actor_grads & 15)))) {
         c->err = g_err = "fbhip: buffers must be 16-byte aligned (workspace 256)";
@@ -260,23 +254,6 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     c->sets[1].act_in = c->sets[0].act_in; c->sets[1].act_vec = c->sets[0].act_vec; c->sets[1].act_out = c->sets[0].act_out;
     c->ws_lo = (const char*)workspace; c->ws_bytes = need;
     const int64_t nf = c->L[FBHIP_NET_FORWARD].numel;
-    {   // P3 images of the parameters behind the two sets: [sets | image of fb params | of fb targets | of actor params]
-        // FBHIP_P3: 0 (default) the fp32-MFMA kernel everywhere | 1 gemm3_kernel where its launch estimate wins | 2 for every
-        // eligible problem (tests).  Off by default: measured inside the walker step (round 3) the bf16-plane
-        // kernel's faster tiles do not pay for what surrounds them at B = 1024 -- 1043-1075 vs 1112-1117 update-steps/s
-        static const int mode = [] { const char* e = getenv("FBHIP_P3"); return e ? atoi(e) : 0; }();
-        c->p3_mode = mode;
-        c->p3r.clear();
-        char* sh = (char*)workspace + need;
-        auto region = [&](const void* lo, size_t bytes) {
-            if (((uintptr_t)lo & 127) == 0 && bytes > 0) c->p3r.push_back(P3Region{(const char*)lo, bytes, sh, true});
-            sh += (bytes / 2 * 3 + 255) & ~(size_t)255;
-        };
-        const size_t n_fb = (size_t)(nf + c->L[FBHIP_NET_BACKWARD].numel) * 4, n_ac = (size_t)c->L[FBHIP_NET_ACTOR].numel * 4;
-        region(fb_params, n_fb);
-        region(fb_targets, n_fb);
-        if (has_actor) region(actor_params, n_ac);
-    }
     c->F_p = fwd_p(fb_params, c->L[0]); c->F_g = fwd_p(fb_grads, c->L[0]); c->F_t = fwd_p(fb_targets, c->L[0]);
     c->K_p = bwd_p(fb_params + nf, c->L[1]); c->K_g = bwd_p(fb_grads + nf, c->L[1]); c->K_t = bwd_p(fb_targets + nf, c->L[1]);
     c->I_p = icm_p(fb_params + nf, c->L[1]); c->I_g = icm_p(fb_grads + nf, c->L[1]);
@@ -288,7 +265,6 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     c->infer_graphs.clear();
     HIPCK(c, pairwise_prepare(c->d.batch, c->d.z_dim));
     HIPCK(c, gemm_init());
-    HIPCK(c, gemm3_init());
     HIPCK(c, inverse_prepare());
     if (has_actor) HIPCK(c, actor_head_bwd_prepare(c->d.hidden_dim, c->d.action_dim));
     c->bound = true;
@@ -422,15 +398,10 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     RC(check_hparams(c, hp));
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
-    const bool resplit = (phase_mask & FBHIP_PHASE_SAMPLE) && !(phase_mask & FBHIP_PHASE_KEEP_PLANES);
-    phase_mask &= ~FBHIP_PHASE_KEEP_PLANES;
-    if (!use_graph) {
-        if (resplit) RC(p3_split_params(c, s));
-        return enqueue_update(c, *hp, inject, phase_mask, s);
-    }
+    if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     reap(s);
     for (auto& g : c->graphs) {
-        if (g.n_steps == 1 && g.set == c->cur && g.mask == (phase_mask | (resplit ? 0 : FBHIP_PHASE_KEEP_PLANES)) && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
+        if (g.n_steps == 1 && g.set == c->cur && g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
             (!inject || memcmp(&g.inj, inject, sizeof(*inject)) == 0)) {
             HIPCK(c, hipGraphLaunch(g.exec, s));
             return FBHIP_OK;
@@ -438,13 +409,12 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     }
     hipGraph_t graph = nullptr;
     HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = resplit ? p3_split_params(c, s) : FBHIP_OK;
-    if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, inject, phase_mask, s);
+    int rc = enqueue_update(c, *hp, inject, phase_mask, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     HIPCK(c, e);
     GraphEntry ge{};
-    ge.mask = phase_mask | (resplit ? 0 : FBHIP_PHASE_KEEP_PLANES); ge.hp = *hp; ge.has_inj = inject != nullptr; ge.n_steps = 1; ge.set = c->cur;
+    ge.mask = phase_mask; ge.hp = *hp; ge.has_inj = inject != nullptr; ge.n_steps = 1; ge.set = c->cur;
     if (inject) ge.inj = *inject;
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -513,7 +483,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     }
     hipGraph_t graph = nullptr;
     HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = p3_split_params(c, s);              // the host may have written parameters since the last launch; Adam keeps the images from here on
+    int rc = FBHIP_OK;
     hipError_t he = hipSuccess;
     const bool has_actor = !c->d.discrete;
     const int64_t n_fb = c->L[FBHIP_NET_FORWARD].numel + c->L[FBHIP_NET_BACKWARD].numel, n_ac = c->L[FBHIP_NET_ACTOR].numel;
@@ -950,7 +920,6 @@ int fbhip_actor_forward(fbhip_ctx* c, const float* obs, int32_t ld_obs, const fl
     if (!obs || !z || !action_out || rows < 1) return FBHIP_E_INVALID;
     if (c->d.discrete) { c->err = g_err = "fbhip_actor_forward: discrete context has no actor"; return FBHIP_E_STATE; }
     hipStream_t s = (hipStream_t)stream;
-    RC(p3_split_params(c, s));                   // (the host may have written parameters; cheap next to a batched pass)
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
     const int La = pad4(head_width(d));
@@ -970,7 +939,6 @@ int fbhip_backward_map(fbhip_ctx* c, int32_t which, const float* goal, int32_t l
     RC(need_bound(c, false));
     if (!goal || !out || rows < 1) return FBHIP_E_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    RC(p3_split_params(c, s));                   // (the host may have written parameters; cheap next to a batched pass)
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
@@ -989,7 +957,6 @@ int fbhip_forward_map(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld_
     if (!obs || !z || !action || !f1_out || !f2_out || rows < 1) return FBHIP_E_INVALID;
     if (c->d.discrete) { c->err = g_err = "fbhip_forward_map: discrete context (use fbhip_discrete_act)"; return FBHIP_E_STATE; }
     hipStream_t s = (hipStream_t)stream;
-    RC(p3_split_params(c, s));                   // (the host may have written parameters; cheap next to a batched pass)
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
@@ -1015,7 +982,6 @@ int fbhip_discrete_act(fbhip_ctx* c, int32_t which, const float* obs, int32_t ld
     if (!obs || !z || rows < 1) return FBHIP_E_INVALID;
     if (!c->d.discrete) { c->err = g_err = "fbhip_discrete_act: the context was not created with discrete"; return FBHIP_E_STATE; }
     hipStream_t s = (hipStream_t)stream;
-    RC(p3_split_params(c, s));                   // (the host may have written parameters; cheap next to a batched pass)
     const fbhip_dims& d = c->d;
     Ws& w = c->W();
     for (int r0 = 0; r0 < rows; r0 += d.batch) {
@@ -1056,36 +1022,6 @@ int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* 
     fbhip_ctx* none = nullptr;
     HIPCK(none, gemm_init());
     HIPCK(none, launch_gemm_group(g, cfg, (hipStream_t)stream));
-    return FBHIP_OK;
-}
-
-int fbhip_p3_split(const float* x, int32_t ld, void* x3, int32_t rows, void* stream) {
-    if (!x || !x3 || rows < 1 || ld < 32 || (ld & 31) || ((uintptr_t)x & 15) || ((uintptr_t)x3 & 15)) { g_err = "fbhip_p3_split: bad argument (ld % 32 == 0, 16-byte aligned)"; return FBHIP_E_INVALID; }
-    fbhip_ctx* none = nullptr;
-    HIPCK(none, launch_p3_split(x, ld, (char*)x3, rows, ld, (hipStream_t)stream));
-    return FBHIP_OK;
-}
-
-int fbhip_gemm_p3(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig, float* C,
-                  int32_t ldc, int32_t M, int32_t N, int32_t K, const float* bias, const float* aux, int32_t ldaux, int32_t epi,
-                  float* colsum, void* a3, void* b3, void* c3, int32_t cfg, void* stream) {
-    if (!A || !B || !C || M < 1 || N < 1 || K < 32 || epi < 0 || epi > 4 || cfg < 0 || cfg >= G3_CFG_COUNT) { g_err = "fbhip_gemm_p3: bad argument"; return FBHIP_E_INVALID; }
-    if ((epi == EPI_BIAS || epi == EPI_BIAS_RELU) && !bias) { g_err = "fbhip_gemm_p3: bias required"; return FBHIP_E_INVALID; }
-    if ((epi == EPI_MASK_RELU || epi == EPI_TANH_BWD) && !aux) { g_err = "fbhip_gemm_p3: aux required"; return FBHIP_E_INVALID; }
-    fbhip_ctx* none = nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    GemmProblem p = P(A, lda, a_kcontig, B, ldb, b_kcontig, C, ldc, M, N, K, bias, epi, aux, ldaux, colsum);
-    p.A3 = (const char*)a3; p.B3 = (const char*)b3; p.C3 = (char*)c3;
-    if (!gemm3_problem_ok(p)) { g_err = "fbhip_gemm_p3: K % 32 == 0; an operand with an image needs ld % 32 == 0, one without 16-byte aligned rows (ld % 4 == 0); ldc % 32 == 0 with c3"; return FBHIP_E_INVALID; }
-    HIPCK(none, gemm3_init());
-    if (a3) HIPCK(none, launch_p3_split(A, lda, (char*)a3, a_kcontig ? M : K, lda, s));
-    if (b3) HIPCK(none, launch_p3_split(B, ldb, (char*)b3, b_kcontig ? N : K, ldb, s));
-    p.kslices = 1;
-    gemm3_problem_finalize(p, cfg);
-    GemmGroup g{};
-    p.tile_start = 0;
-    g.p[0] = p; g.n = 1; g.total_tiles = p.tiles_m * p.tiles_n;
-    HIPCK(none, launch_gemm3_group(g, cfg, s));
     return FBHIP_OK;
 }
 

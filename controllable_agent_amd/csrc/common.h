@@ -3,7 +3,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
-#include "p3.h"
 
 namespace fbhip {
 
@@ -32,11 +31,6 @@ struct GemmProblem {
     int kslices, kper;       // kper in units of the config's K chunk
     float* partial;
     int red_start;           // first element of this problem in the reduce launch
-    // P3 images (p3.h) of the operands / the output, set by the scheduler for problems that run on gemm3_kernel: the
-    // block of element (0, 0); C3 == nullptr: fp32 output only
-    const char* A3;
-    const char* B3;
-    char* C3;
 };
 
 constexpr int MAX_GROUP = 8;
@@ -67,20 +61,6 @@ hipError_t gemm_init();        // one-time kernel attribute setup (outside graph
 int pick_gemm_cfg(int M, int N, int K);
 bool gemm_problem_dma_ok(const GemmProblem& p);        // eligible for the LDS-DMA kernels (CFG_DMA128 requires it)
 void gemm_problem_finalize(GemmProblem& p, int cfg);   // fills a_vec/b_vec/tiles_*
-
-// ---- P3 GEMM (gemm3.hip, gemm3_kernel.h, p3.h): operands as three bf16 planes, six bf16 MFMA products per block --------
-enum Gemm3Cfg { G3_128x128 = 0, G3_128x64 = 1, G3_64x128 = 2, G3_64x64 = 3, G3_CFG_COUNT };
-hipError_t gemm3_init();                                  // one-time kernel attribute setup (outside graph capture)
-int gemm3_cfg_bm(int cfg);
-int gemm3_cfg_bn(int cfg);
-bool gemm3_problem_ok(const GemmProblem& p);              // P3 images present, whole blocks (ld % 32, K % 32), aligned
-void gemm3_problem_finalize(GemmProblem& p, int cfg);     // fills tiles_* (and kper of an unsliced problem)
-hipError_t launch_gemm3_group(const GemmGroup& g, int cfg, hipStream_t stream);
-// fp32 -> P3 for operands whose producer does not emit planes; views of whole 8-column groups, ld % 32 == 0
-struct P3SplitJob { const float* x; char* x3; int rows, cols, ld, block_start; };
-constexpr int P3_SPLIT_MAX = 8;
-struct P3SplitJobs { P3SplitJob j[P3_SPLIT_MAX]; int n; };
-hipError_t launch_p3_split_group(P3SplitJobs jobs, hipStream_t s);
 
 // ---- row-wise ops ------------------------------------------------------------------------------------
 hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
@@ -248,8 +228,7 @@ hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* 
                            float lr, float lr2, int64_t split, float grad_scale, float tau,
                            const StepState* st, int which, int t_explicit, hipStream_t s,
                            float tau2 = -1.f /* the target rate of the elements behind ``split`` (< 0: tau) */,
-                           int ema_before2 = 0 /* there, the target follows the parameter as it was BEFORE this step */,
-                           char* p3 = nullptr, char* t3 = nullptr /* nullable: P3 images of p / target, kept current by the pass */);
+                           int ema_before2 = 0 /* there, the target follows the parameter as it was BEFORE this step */);
 
 // ---- peer-access all-reduce (peer.hip): the data-parallel gradient exchange as graph-capturable kernels -------------------
 constexpr int PEER_MAX_WORLD = 8;

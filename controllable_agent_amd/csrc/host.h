@@ -119,12 +119,6 @@ IcmP icm_p(float* base, const NetLayout& L);
 BwdP mu_p(float* base, const NetLayout& L);               // svd_p's mu_net (same module structure as BackwardMap.B, no projection)
 ActP act_p(float* base, const NetLayout& L);
 
-// ---- P3 images (p3.h) of the parameter buffers ----------------------------------------------------------------------------------
-// A shadowed region [lo, lo + bytes) of fp32 parameters has its three-plane bf16 image at shadow + 1.5 x offset: FB parameters, FB
-// targets, actor parameters.  The shadows live behind the two workspace sets in the caller's workspace allocation
-// (fbhip_workspace_bytes covers them).
-struct P3Region { const char* lo; size_t bytes; char* shadow; bool weights; };
-
 struct GraphEntry { int mask; fbhip_hparams hp; bool has_inj; fbhip_inject inj; hipGraphExec_t exec; int n_steps; int set;
                     bool branches = false;                 // parallel branches: launched through launch_graph's high-priority stream (api.hip)
                     std::vector<fbhip_inject> injs; };     // multi-step injected graphs: every step's struct is part of the cache key
@@ -171,9 +165,6 @@ struct fbhip_ctx {
     fbhip::Squash sq{0, 1.f, -5.f, 2.f};            // boltzmann: temp, log_std_bounds (fb_ddpg.py:70-71); fbhip_set_policy_squash
     std::function<int(const fbhip::PolicyHeadJobs&, hipStream_t)> run_policy_heads;   // set by the update that declares Ops::ph
     fbhip::ColReduceJobs cr_pending{};              // LayerNorm column reduces waiting for the next split-K reduce launch (flush_round)
-    // P3 GEMM (schedule.hip::run_gemms): where the parameters' three-plane images live
-    std::vector<fbhip::host::P3Region> p3r;
-    int p3_mode = 0;                                // FBHIP_P3: 0 off (default), 1 on where the launch estimate wins, 2 on for every eligible problem (tests)
     std::string err;
 };
 
@@ -238,9 +229,6 @@ int actor_fwd(fbhip_ctx* c, const ActP& W, const float* Xo, int ldo, const float
 int enqueue_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj, int mask, hipStream_t s);
 int enqueue_actor_v(fbhip_ctx* c, hipStream_t s);
 int check_hparams(fbhip_ctx* c, const fbhip_hparams* hp);
-// P3 images of the parameters (schedule.hip)
-char* p3_of(fbhip_ctx* c, const float* p, bool* weights = nullptr);       // image address of a block-aligned parameter address, or nullptr
-int p3_split_params(fbhip_ctx* c, hipStream_t s);                          // fp32 -> P3 of every parameter / target buffer
 int need_bound(fbhip_ctx* c, bool replay);
 // the library's own RCCL transport (rccl.hip)
 int rccl_load(const char* path);

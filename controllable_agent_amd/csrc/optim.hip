@@ -26,8 +26,7 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
                                                        float4* __restrict__ tgt, int64_t nquad, float lr, float lr2,
                                                        int64_t split_quad, float grad_scale, float tau,
                                                        const StepState* __restrict__ st, int which, int t_explicit,
-                                                       float tau2, int ema_before2, char* __restrict__ p3,
-                                                       char* __restrict__ t3) {
+                                                       float tau2, int ema_before2) {
     double bc1, bc2s;
     if (st != nullptr) {
         bc1 = which == 0 ? st->fb_bc1 : st->actor_bc1;
@@ -57,15 +56,6 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
         ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
 #undef ADAM1
         m[i] = mm; v[i] = vv; p[i] = pp;
-        // the P3 images (p3.h) of the new parameters / targets ride along: the next GEMM stages planes, not fp32
-        auto planes = [&](char* base, const float4& q) {
-            const P3Triple a = p3_split(q.x), b = p3_split(q.y), c = p3_split(q.z), d = p3_split(q.w);
-            char* dst = base + p3_offset(0, (size_t)(4 * i), (size_t)1 << 40);
-            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)a.h | ((unsigned)b.h << 16), (unsigned)c.h | ((unsigned)d.h << 16));
-            *reinterpret_cast<uint2*>(dst + 64) = make_uint2((unsigned)a.m | ((unsigned)b.m << 16), (unsigned)c.m | ((unsigned)d.m << 16));
-            *reinterpret_cast<uint2*>(dst + 128) = make_uint2((unsigned)a.l | ((unsigned)b.l << 16), (unsigned)c.l | ((unsigned)d.l << 16));
-        };
-        if (p3 != nullptr) planes(p3, pp);
         if (tgt != nullptr) {
             float4 tt = tgt[i];
             // (sf.py:237 TransitionLatentModel: the learner's own target net is moved inside its forward(), i.e. towards the
@@ -75,14 +65,13 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
             tt.x = ta * src.x + om * tt.x; tt.y = ta * src.y + om * tt.y;
             tt.z = ta * src.z + om * tt.z; tt.w = ta * src.w + om * tt.w;
             tgt[i] = tt;
-            if (t3 != nullptr) planes(t3, tt);
         }
     }
 }
 
 hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* target, int64_t numel, float lr,
                            float lr2, int64_t split, float grad_scale, float tau, const StepState* st, int which,
-                           int t_explicit, hipStream_t s, float tau2, int ema_before2, char* p3, char* t3) {
+                           int t_explicit, hipStream_t s, float tau2, int ema_before2) {
     if (numel <= 0) return hipSuccess;
     if ((numel & 3) || (split & 3)) return hipErrorInvalidValue;
     const int64_t nquad = numel / 4;
@@ -90,7 +79,7 @@ hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m,
                        (float4*)v, (float4*)target, nquad, lr, lr2, split / 4, grad_scale, tau, st, which, t_explicit,
-                       tau2 < 0.f ? tau : tau2, ema_before2, p3, t3);
+                       tau2 < 0.f ? tau : tau2, ema_before2);
     return hipGetLastError();
 }
 

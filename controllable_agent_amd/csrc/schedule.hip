@@ -21,134 +21,12 @@ GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc
     return p;
 }
 
-// ---- P3 images of the parameters (p3.h, gemm3.hip) ------------------------------------------------------------------------------
-// gemm3_kernel stages the WEIGHT operand of a GEMM from its three-plane bf16 image by LDS-DMA; activations and gradient panels
-// stay fp32 (the kernel's staging waves split them on the way into LDS).  A parameter buffer's image lives at shadow + 1.5 x offset
-// (fbhip_bind_buffers); every update entry point rebuilds the images (the host may have written parameters through its views)
-// and the optimiser pass keeps them current from then on.
-char* p3_of(fbhip_ctx* c, const float* p, bool* weights) {
-    if (c == nullptr || c->p3_mode == 0) return nullptr;
-    for (const P3Region& r : c->p3r) {
-        const char* q = (const char*)p;
-        if (q >= r.lo && q < r.lo + r.bytes) {
-            const size_t off = (size_t)(q - r.lo);
-            if (off & 127) return nullptr;
-            if (weights) *weights = r.weights;
-            return r.shadow + off / 2 * 3;
-        }
-    }
-    return nullptr;
-}
-
-int p3_split_params(fbhip_ctx* c, hipStream_t s) {
-    if (c->p3_mode == 0) return FBHIP_OK;
-    P3SplitJobs jobs{};
-    for (const P3Region& r : c->p3r) {
-        if (!r.weights) continue;
-        // a flat buffer is a [numel / 32, 32] matrix of whole blocks
-        jobs.j[jobs.n++] = P3SplitJob{(const float*)r.lo, r.shadow, (int)(r.bytes / 128), 32, 32, 0};
-    }
-    if (jobs.n > 0) HIPCK(c, launch_p3_split_group(jobs, s));
-    return FBHIP_OK;
-}
-
 // scratch for split-K partials (launches of one update are stream-ordered, so one slab serves them all); standalone
 // fbhip_gemm (ctx == nullptr) never splits
 
 float* splitk_slab(fbhip_ctx* c) { return (c && c->W().splitk) ? c->W().splitk : nullptr; }
 
-// ---- the P3 GEMM inside a round -----------------------------------------------------------------------------------------------
-// Estimated time of a gemm3 launch of these problems with tile configuration ``cfg``: workgroups are dispatched in launch order
-// to whichever of the 256 CUs frees first (one 8-wave workgroup per CU: 108-144 KiB of LDS), a tile costs chunks x t_chunk + t_epi
-// (us; tools/gemm3_probe.hip on MI355X).  Problems are launched longest-K first.
-static double gemm3_estimate_us(const std::vector<GemmProblem>& v, int cfg) {
-    static const double chunk_us[G3_CFG_COUNT] = {1.40, 0.80, 0.80, 0.52}, epi_us[G3_CFG_COUNT] = {7.0, 4.5, 4.5, 3.5};
-    const int bm = gemm3_cfg_bm(cfg), bn = gemm3_cfg_bn(cfg);
-    std::vector<double> cu(256, 0.0);
-    std::make_heap(cu.begin(), cu.end(), std::greater<double>());
-    double end = 0;
-    for (const GemmProblem& p : v) {
-        const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-        const double t = (p.K / 32) * chunk_us[cfg] + epi_us[cfg];
-        for (long i = 0; i < tiles; ++i) {
-            std::pop_heap(cu.begin(), cu.end(), std::greater<double>());
-            cu.back() += t;
-            end = std::max(end, cu.back());
-            std::push_heap(cu.begin(), cu.end(), std::greater<double>());
-        }
-    }
-    return end + 3.0;
-}
-
-// what the fp32-MFMA kernel needs for the same problems as one grouped launch (measured rates of the step's own launches)
-static double legacy_estimate_us(const std::vector<GemmProblem>& v) {
-    double fl = 0;
-    for (const GemmProblem& p : v) fl += 2.0 * p.M * p.N * p.K;
-    const double rate = fl >= 4e9 ? 104e12 : fl >= 2e9 ? 82e12 : fl >= 1e9 ? 60e12 : 40e12;
-    return fl / rate * 1e6 + 4.0;
-}
-
-static int run_gemms_p3(fbhip_ctx* ctx, std::vector<GemmProblem>& v, int cfg, hipStream_t s) {
-    for (size_t i = 0; i < v.size();) {
-        GemmGroup g{};
-        int start = 0;
-        while (i < v.size() && g.n < MAX_GROUP) {
-            GemmProblem p = v[i++];
-            p.kslices = 1;
-            p.C3 = nullptr;                      // activations stay fp32: the consumer's producer waves split them while staging
-            gemm3_problem_finalize(p, cfg);
-            p.tile_start = start;
-            start += p.tiles_m * p.tiles_n;
-            g.p[g.n++] = p;
-        }
-        g.total_tiles = start;
-        static const bool log_launches = [] { const char* e = getenv("FBHIP_GEMM_LOG"); return e && e[0] == '1'; }();
-        if (log_launches) {
-            double fl = 0;
-            for (int q = 0; q < g.n; ++q) fl += 2.0 * g.p[q].M * g.p[q].N * g.p[q].K;
-            fprintf(stderr, "GEMMLOG p3cfg=%d wgs=%d gflop=%.4f reduce=0 :", cfg, start, fl * 1e-9);
-            for (int q = 0; q < g.n; ++q) fprintf(stderr, " %dx%dx%d/1", g.p[q].M, g.p[q].N, g.p[q].K);
-            fprintf(stderr, "\n");
-        }
-        HIPCK(ctx, launch_gemm3_group(g, cfg, s));
-    }
-    return FBHIP_OK;
-}
-
 int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
-    if (ctx != nullptr && ctx->p3_mode != 0 && !ctx->p3r.empty()) {
-        // The fat problems of a round go to gemm3_kernel (six bf16 MFMA products per block, fp32 accuracy) when its estimated
-        // launch time beats the fp32-MFMA kernel's: parameters are staged from their P3 images (kept current by the optimiser
-        // pass), activations and gradient panels from fp32 with the split done by the staging waves.  Thin / ragged problems stay
-        // below.  (FBHIP_P3=2, tests: every eligible problem moves, whatever the estimate.)
-        std::vector<GemmProblem> p3, rest;
-        for (auto& p : v) {
-            GemmProblem q = p;
-            bool wa = false, wb = false;
-            char* a3 = p3_of(ctx, p.A, &wa);
-            char* b3 = p3_of(ctx, p.B, &wb);
-            q.A3 = wa ? a3 : nullptr; q.B3 = wb ? b3 : nullptr; q.C3 = nullptr;
-            if (q.A3 != nullptr && (p.lda & 31)) q.A3 = nullptr;
-            if (q.B3 != nullptr && (p.ldb & 31)) q.B3 = nullptr;
-            const bool fat = ctx->p3_mode == 2 || (p.M >= 128 && p.N >= 128 && p.K >= 128);
-            if (fat && gemm3_problem_ok(q)) p3.push_back(q);
-            else rest.push_back(p);
-        }
-        if (!p3.empty()) {
-            std::stable_sort(p3.begin(), p3.end(), [](const GemmProblem& a, const GemmProblem& b) { return a.K > b.K; });
-            int cfg = G3_64x64;
-            double best = 1e30;
-            for (int c = 0; c < G3_CFG_COUNT; ++c) {
-                const double est = gemm3_estimate_us(p3, c);
-                if (est < best) { best = est; cfg = c; }
-            }
-            if (ctx->p3_mode == 2 || best < legacy_estimate_us(p3)) {
-                RC(run_gemms_p3(ctx, p3, cfg, s));
-                if (rest.empty()) return FBHIP_OK;
-                v.swap(rest);
-            }
-        }
-    }
     long tiles32 = 0;
     int kmax = 0, nmax = 0, mmax = 0;
     for (auto& p : v) {
@@ -895,7 +773,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         if (!fb_adv) HIPCK(c, launch_step_advance(w.st, fb_adv_which, s));   // (else pairwise_reduce_kernel did it)
         const int64_t nf = c->L[FBHIP_NET_FORWARD].numel, nb = c->L[FBHIP_NET_BACKWARD].numel;
         HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf,
-                                 hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, s, -1.f, 0, p3_of(c, c->fb_p), p3_of(c, c->fb_t)));
+                                 hp.grad_scale, hp.fb_target_tau, w.st, 0, 0, s));
         POST_END
     }
 
@@ -992,7 +870,7 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         if (!(mask & FBHIP_PHASE_FB_STEP) && !actor_adv) HIPCK(c, launch_step_advance(w.st, 1, s));   // (else actor_q_kernel did it)
         const int64_t na = c->L[FBHIP_NET_ACTOR].numel;
         HIPCK(c, launch_adam_ema(c->a_p, c->a_g, c->a_m, c->a_v, nullptr, na, hp.lr, hp.lr, na, hp.grad_scale, 0.f, w.st,
-                                 1, 0, s, -1.f, 0, p3_of(c, c->a_p), nullptr));
+                                 1, 0, s));
         POST_END
     }
     return FBHIP_OK;
@@ -1335,8 +1213,7 @@ int build_update_sf(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* i
     // (latent, sf.py:245: utils.soft_update_params(feature_net, target_feature_net, 0.01) runs inside the learner's forward(), i.e.
     // towards the feature parameters as they were BEFORE phi_opt.step(); the other learners never read that part of the target buffer)
     HIPCK(c, launch_adam_ema(c->fb_p, c->fb_g, c->fb_m, c->fb_v, c->fb_t, nf + nb, hp.lr, hp.lr_coef * hp.lr, nf, hp.grad_scale,
-                             hp.fb_target_tau, w.st, 0, 0, s, (d.sf >= 7 && d.sf <= 9) ? 0.01f : -1.f, (d.sf >= 7 && d.sf <= 9) ? 1 : 0,
-                             p3_of(c, c->fb_p), p3_of(c, c->fb_t)));
+                             hp.fb_target_tau, w.st, 0, 0, s, (d.sf >= 7 && d.sf <= 9) ? 0.01f : -1.f, (d.sf >= 7 && d.sf <= 9) ? 1 : 0));
     POST_END
     return FBHIP_OK;
 }

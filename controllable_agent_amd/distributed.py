@@ -41,7 +41,6 @@ PHASE_FB_FWD = PHASE_FB_FWD_ONLINE | PHASE_FB_FWD_TARGET
 PHASE_FB_BWD = PHASE_FB_BWD_A | PHASE_FB_BWD_B
 PHASE_FB_GRAD = PHASE_FB_FWD | PHASE_FB_BWD
 PHASE_ALL = 511
-PHASE_KEEP_PLANES = 4096        # include/fbhip.h: the caller has not written parameters since the previous call of this update sequence
 
 
 _COALESCE_OK = True
@@ -196,7 +195,7 @@ def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable
                 side.wait_stream(main)                   # fork: the head needs the new FB weights, nothing of the actor phase
                 select_set(cur ^ 1)
                 with torch.cuda.stream(side):
-                    run_phases(head | PHASE_KEEP_PLANES)   # (no rebuild of the parameter images beside the actor step that writes them)
+                    run_phases(head)
                 select_set(cur)
                 run_phases(PHASE_ACTOR_GRAD)
                 work = dist.all_reduce(actor_grads, async_op=True) if (live and actor_grads.numel() > 0) else None
@@ -211,7 +210,7 @@ def dp_update_many(run_phases: tp.Callable[[int], None], select_set: tp.Callable
             work = dist.all_reduce(actor_grads, async_op=True) if (live and actor_grads.numel() > 0) else None
             if t + 1 < n_steps:
                 select_set(cur ^ 1)
-                run_phases(head | PHASE_KEEP_PLANES) # the next step's head, under the all-reduce
+                run_phases(head)                     # the next step's head, under the all-reduce
                 select_set(cur)
             if work is not None:
                 work.wait()                          # nccl: the compute stream waits; gloo: the host does

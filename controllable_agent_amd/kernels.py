@@ -41,50 +41,6 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcontig:
     return (Cm, colsum) if want_colsum else Cm
 
 
-def gemm_p3(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcontig: bool = True,
-            bias: tp.Optional[torch.Tensor] = None, aux: tp.Optional[torch.Tensor] = None, epi: int = _lib.EPI_NONE,
-            want_colsum: bool = False, want_image: bool = False, cfg: int = 0, a_image: bool = True, b_image: bool = True):
-    """The same GEMM on three-plane bf16 images of the operands (csrc/p3.h, fbhip_gemm_p3): fp32-accurate products from six bf16
-    MFMAs per block.  ``a_image`` / ``b_image``: stage that operand from a prepared image (leading dimension a multiple of 32) or,
-    when False, straight from fp32 (rows 16-byte aligned); K a multiple of 32 either way.  ``want_image`` also returns the image of
-    C as a uint8 tensor of 1.5 x the bytes of C's padded storage ([hi x 32 | mid x 32 | lo x 32] per 32-float block)."""
-    _lib.require_device()
-    M, K = (A.shape if a_kcontig else A.shape[::-1])
-    N, K2 = (B.shape if b_kcontig else B.shape[::-1])
-    assert K == K2, (A.shape, B.shape)
-    ldc = (N + 31) // 32 * 32
-    Cs = torch.zeros((M, ldc), device=A.device, dtype=torch.float32)
-    Cm = Cs[:, :N]
-    a3 = torch.zeros(A.shape[0] * _ld(A) * 6, device=A.device, dtype=torch.uint8) if a_image else None
-    b3 = torch.zeros(B.shape[0] * _ld(B) * 6, device=A.device, dtype=torch.uint8) if b_image else None
-    c3 = torch.zeros(M * ldc * 6, device=A.device, dtype=torch.uint8) if want_image else None
-    colsum = torch.zeros(M, device=A.device) if want_colsum else None
-    check(_lib.load().fbhip_gemm_p3(ptr(A), _ld(A), int(a_kcontig), ptr(B), _ld(B), int(b_kcontig), ptr(Cm), ldc, M, N, K,
-                                    ptr(bias), ptr(aux), 0 if aux is None else _ld(aux), epi, ptr(colsum), ptr(a3), ptr(b3),
-                                    ptr(c3), cfg, stream_ptr()))
-    out = [Cm]
-    if want_colsum:
-        out.append(colsum)
-    if want_image:
-        out.append(c3)
-    return out[0] if len(out) == 1 else tuple(out)
-
-
-def p3_split(x: torch.Tensor) -> torch.Tensor:
-    """fp32 [rows, ld % 32 == 0] -> its three-plane bf16 image (uint8, 6 bytes per element)."""
-    _lib.require_device()
-    x3 = torch.zeros(x.shape[0] * _ld(x) * 6, device=x.device, dtype=torch.uint8)
-    check(_lib.load().fbhip_p3_split(ptr(x), _ld(x), ptr(x3), x.shape[0], stream_ptr()))
-    return x3
-
-
-def p3_decode(x3: torch.Tensor, rows: int, ld: int) -> torch.Tensor:
-    """hi + mid + lo of an image as float64 [rows, ld] (host-side check of what the planes hold)."""
-    u = x3.view(torch.int16).view(rows, ld // 32, 3, 32).to(torch.int32)
-    f = (u << 16).view(torch.float32).to(torch.float64)
-    return f.sum(dim=2).reshape(rows, ld)
-
-
 def ln_tanh_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     """y = tanh(LayerNorm(x)), stats[rows,2] = (mean, rstd)   (fb_modules.py:49-50)."""
     _lib.require_device()

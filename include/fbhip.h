@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 16
+#define FBHIP_ABI_VERSION 17
 
 enum {
     FBHIP_OK = 0,
@@ -69,13 +69,7 @@ enum {
      * halves then), else with ACTOR_GRAD.  An ACTOR_GRAD call WITHOUT this bit uses the pass of an earlier call on the same
      * batch.  Pass it to ONE place per step. */
     FBHIP_PHASE_ACTOR_FWD = 32,
-    FBHIP_PHASE_ALL = 511,
-    /* Not a phase: a promise.  The GEMMs stage three-plane bf16 images of their operands (csrc/p3.h); the images of the PARAMETERS
-     * are rebuilt from the fp32 buffers at the start of every update entry point that contains FBHIP_PHASE_SAMPLE (the host may
-     * have written parameters through its views since the last call) and kept current by the optimiser pass afterwards.  A
-     * caller that issues the phases of consecutive updates itself (the data-parallel schedule) and has not touched the
-     * parameters in between passes this bit with the later calls to skip the rebuild (~15 us at walker dims). */
-    FBHIP_PHASE_KEEP_PLANES = 4096
+    FBHIP_PHASE_ALL = 511
 };
 
 /* Both parameter structs start with their own size: the caller sets ``struct_size = sizeof(fbhip_dims)`` (resp.
@@ -385,20 +379,6 @@ int fbhip_gemm(const float* A, int32_t lda, int32_t a_kcontig, const float* B, i
  * M x N x K); no epilogue.  For tests and kernel benchmarking. */
 int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
                    float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t cfg, void* stream);
-/* The same contraction with six bf16 MFMA products per block in place of the fp32 MFMA (csrc/p3.h, csrc/gemm3_kernel.h): every
- * operand is taken apart into three bf16 planes (hi + mid + lo = the fp32 value) and the products reproduce the fp32 product
- * (error at or below an fp32 dot product's).  An operand is staged either from a prepared three-plane IMAGE by LDS-DMA -- how
- * the update reads its parameters: pass scratch a3 / b3 for the image (1.5 x the fp32 bytes of the [rows, ld] matrix, 16-byte
- * aligned, ld % 32 == 0; filled here by the split kernel) -- or straight from fp32 with the split done by the kernel's staging
- * waves -- how it reads activations: pass a3 / b3 = NULL (16-byte aligned rows, ld % 4 == 0).  K a multiple of 32.  c3 (nullable,
- * ldc % 32 == 0): also receives the image of C.  cfg: 0 128x128, 1 128x64, 2 64x128, 3 64x64 workgroup tiles.  Epilogues as
- * fbhip_gemm. */
-int fbhip_gemm_p3(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
-                  float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
-                  const float* bias, const float* aux, int32_t ldaux, int32_t epi, float* colsum,
-                  void* a3, void* b3, void* c3, int32_t cfg, void* stream);
-/* fp32 -> three-plane image (csrc/p3.h) of a [rows, ld] matrix (ld % 32 == 0; all ld columns are converted) */
-int fbhip_p3_split(const float* x, int32_t ld, void* x3, int32_t rows, void* stream);
 /* y = tanh(LayerNorm(x; gamma, beta, eps=1e-5)); stats[rows,2] = (mean, rstd)  (fb_modules.py:49-50) */
 int fbhip_ln_tanh_fwd(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
                       float* stats, int32_t rows, int32_t n, void* stream);

@@ -162,19 +162,15 @@ def test_dp_update_many_call_order_and_workspace_sets():
     head = D.PHASE_SAMPLE | D.PHASE_FB_FWD_ONLINE
     mid = D.PHASE_FB_FWD_TARGET | D.PHASE_FB_BWD | D.PHASE_ACTOR_FWD
     grad = D.PHASE_FB_STEP | D.PHASE_ACTOR_GRAD
-    # (the heads of the later steps carry PHASE_KEEP_PLANES: the parameters' bf16-plane images are kept current by the optimiser
-    # pass from the first step on, and a rebuild beside the actor step that writes them would race with it)
-    keep = D.PHASE_KEEP_PLANES
     assert calls == [(0, head),
-                     (0, mid), (0, grad), (1, head | keep), (0, D.PHASE_ACTOR_STEP),
-                     (1, mid), (1, grad), (0, head | keep), (1, D.PHASE_ACTOR_STEP),
+                     (0, mid), (0, grad), (1, head), (0, D.PHASE_ACTOR_STEP),
+                     (1, mid), (1, grad), (0, head), (1, D.PHASE_ACTOR_STEP),
                      (0, mid), (0, grad), (0, D.PHASE_ACTOR_STEP)]
     assert cur[0] == 0
     # every phase bit of an update is issued exactly once per step
     per_step = [0, 0, 0]
     step_of = [0, 0, 0, 1, 0, 1, 1, 2, 1, 2, 2, 2]
     for (_, m), st in zip(calls, step_of):
-        m &= ~keep
         assert per_step[st] & m == 0
         per_step[st] |= m
     assert per_step == [D.PHASE_ALL] * 3

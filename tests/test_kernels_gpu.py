@@ -358,73 +358,3 @@ def test_pairwise_randomised_sizes_and_alignment(K):
             assert torch.isfinite(got).all() and rel_err(got.cpu(), cf[k]) < 2e-5, (tag, k)
         for k in ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss"):
             assert m[k] == pytest.approx(float(cf[k]), rel=5e-5, abs=1e-5), (tag, k)
-
-
-# ------------------------------------------------------------------------------------------------ P3 GEMM (three bf16 planes)
-def _p3_operand(t, seed_pad=0):
-    """device copy with the leading dimension rounded up to 32 and ZERO pad columns (the K loop runs over whole blocks)"""
-    ld = (t.shape[1] + 31) // 32 * 32
-    buf = torch.zeros((t.shape[0], ld), device="cuda")
-    buf[:, :t.shape[1]] = t.cuda()
-    return buf[:, :t.shape[1]]
-
-
-P3_SHAPES = [(1024, 2048, 1024), (1024, 512, 1024), (1024, 1024, 96), (256, 256, 128), (200, 160, 64), (192, 320, 160), (64, 96, 32),
-             (33, 40, 64), (1024, 576, 576), (130, 1, 32)]
-
-
-@pytest.mark.parametrize("M,N,K_", P3_SHAPES)
-@pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, False)])
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
-@pytest.mark.parametrize("a_img,b_img", [(True, True), (False, True), (False, False), (True, False)])
-def test_gemm_p3_layouts_and_tiles(K, M, N, K_, akc, bkc, cfg, a_img, b_img):
-    """forward / dgrad / wgrad orientations (k-contiguous fragments by ds_read_b128, k-strided ones by the transposing LDS read) on
-    every workgroup tile, each operand staged either from its image by LDS-DMA (parameters) or from fp32 through the staging waves'
-    split (activations): fp32 accuracy from six bf16 products -- the SAME bound as the fp32-MFMA kernel's test above."""
-    if (M, N, K_) == (1024, 2048, 1024) and cfg not in (0, 3):
-        pytest.skip("the big shape runs on two tile configurations")
-    if (a_img, b_img) != (False, True) and cfg in (1, 2) and (M, N, K_) != (200, 160, 64):
-        pytest.skip("the asymmetric tiles run every staging combination on one ragged shape only")
-    if (not b_img and not bkc and N < 4) or (not a_img and not akc and M < 4):
-        pytest.skip("a k-strided operand staged from fp32 is read as float4 along its rows: at least 4 of them")
-    A = _r(M, K_, seed=11) if akc else _r(K_, M, seed=11)
-    B = _r(N, K_, seed=12) if bkc else _r(K_, N, seed=12)
-    C = K.gemm_p3(_p3_operand(A), _p3_operand(B), a_kcontig=akc, b_kcontig=bkc, cfg=cfg, a_image=a_img, b_image=b_img)
-    Am = A.double() if akc else A.double().T
-    Bm = B.double() if bkc else B.double().T
-    assert C.shape == (M, N)
-    assert rel_err(C.cpu(), Am @ Bm.T) < 2e-6
-
-
-def test_gemm_p3_epilogues_and_output_image(K):
-    """bias / relu / relu-mask / tanh' epilogues, the bias-gradient column sums of a wgrad, and the emitted image of C: hi + mid + lo
-    reproduces the fp32 C exactly (24 significant bits in three bf16 planes), pad columns of the image stay zero"""
-    M, N, Kd = 192, 160, 128
-    A, B, bias, aux = _r(M, Kd, seed=21), _r(N, Kd, seed=22), _r(N, seed=23), _r(M, N, seed=24, scale=0.6)
-    ref = A.double() @ B.double().T
-    from controllable_agent_amd import _lib as L
-    cases = ((L.EPI_BIAS, ref + bias.double()), (L.EPI_BIAS_RELU, torch.relu(ref + bias.double())),
-             (L.EPI_MASK_RELU, ref * (aux.double() > 0)), (L.EPI_TANH_BWD, ref * (1 - aux.double() ** 2)))
-    for epi, want in cases:
-        C, c3 = K.gemm_p3(_p3_operand(A), _p3_operand(B), bias=bias.cuda(), aux=aux.cuda().contiguous(), epi=epi, want_image=True, cfg=1,
-                          a_image=False)
-        assert rel_err(C.cpu(), want) < 2e-6, epi
-        img = K.p3_decode(c3, M, 160)
-        assert torch.equal(img[:, :N].float().cpu(), C.cpu()), epi
-    At = _r(Kd, M, seed=25)
-    C, cs = K.gemm_p3(_p3_operand(At), _p3_operand(_r(Kd, N, seed=26)), a_kcontig=False, b_kcontig=False, want_colsum=True, cfg=0,
-                      a_image=False, b_image=False)
-    assert rel_err(cs.cpu(), At.double().sum(0)) < 2e-6
-
-
-def test_p3_split_is_exact_over_the_range_training_sees(K):
-    """x == hi + mid + lo bit for bit for normal numbers from 1e-30 to 1e30 of either sign and for +-0 (three 8-bit significands
-    cover fp32's 24; below ~1e-35 the last residual leaves bf16's normal range and is flushed -- 2^-16 of a value that small --
-    and an infinity's residual is inf - inf: like the reference's own arithmetic on such inputs, garbage in, NaN out)"""
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(64, 96, generator=g) * torch.exp(torch.randn(64, 96, generator=g) * 12)
-    x = torch.where(x.abs() < 1e-30, torch.full_like(x, 1e-30), x).clamp(-1e30, 1e30)
-    x[0, :4] = torch.tensor([0.0, -0.0, 1.0, -1.0])
-    xd = x.cuda()
-    img = K.p3_decode(K.p3_split(xd), 64, 96)
-    assert torch.equal(img.float().cpu(), x)

@@ -91,7 +91,7 @@ hipError_t gemm3_init() {
 
 // An operand is staged either from its P3 image (whole 192-byte blocks: leading dimension a multiple of 32 floats) or from fp32
 // (16-byte aligned rows); K is a multiple of the 32-deep chunk either way
-bool gemm3_problem_ok(const GemmProblem& p) {
+bool gemm3_problem_ok(const Gemm3Problem& p) {
     auto operand_ok = [](const float* x, const char* x3, int ld, int kcontig, int nr) {
         if (x3 != nullptr) return (ld & 31) == 0 && ((uintptr_t)x3 & 15) == 0 && (kcontig || (nr & 31) == 0 || ld >= ((nr + 31) & ~31));
         return x != nullptr && ((uintptr_t)x & 15) == 0 && (ld & 3) == 0 && ld >= 4 && (kcontig || nr >= 4);
@@ -100,7 +100,7 @@ bool gemm3_problem_ok(const GemmProblem& p) {
            (p.C3 == nullptr || ((p.ldc & 31) == 0 && ((uintptr_t)p.C3 & 15) == 0));
 }
 
-void gemm3_problem_finalize(GemmProblem& p, int cfg) {
+void gemm3_problem_finalize(Gemm3Problem& p, int cfg) {
     if (p.kslices < 1) p.kslices = 1;
     if (p.kslices == 1) p.kper = p.K / 32;
     const int BM = gemm3_cfg_bm(cfg), BN = gemm3_cfg_bn(cfg);
@@ -108,7 +108,7 @@ void gemm3_problem_finalize(GemmProblem& p, int cfg) {
     p.tiles_n = (p.N + BN - 1) / BN;
 }
 
-hipError_t launch_gemm3_group(const GemmGroup& g, int cfg, hipStream_t stream) {
+hipError_t launch_gemm3_group(const Gemm3Group& g, int cfg, hipStream_t stream) {
     if (g.total_tiles <= 0) return hipSuccess;
     for (int i = 0; i < g.n; ++i)
         if (!gemm3_problem_ok(g.p[i])) return hipErrorInvalidValue;

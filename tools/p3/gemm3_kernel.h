@@ -28,7 +28,7 @@
 // patch and read back row-major, 8 consecutive columns per lane, so that C goes out as full 128-byte lines and its P3 image
 // as 16-byte stores (the bf16 split costs ~5.5 VALU per element once per produced element, not once per use).
 #pragma once
-#include "common.h"
+#include "p3_problem.h"
 #include "p3.h"
 
 #include <type_traits>
@@ -220,7 +220,7 @@ __device__ __forceinline__ void g3_consume(const char* __restrict__ smem, int nt
 // like loads, so a load issued after a store makes its s_waitcnt wait for that store to complete: with loads interleaved the
 // passes serialised on store latency (20 us per 128x128 tile in the first probe, as long as the tile's whole K loop).
 template <int TM, int TN, int EPI_LD, int EPI /* compile-time epilogue; -1: raw split-K partial */>
-__device__ __forceinline__ void g3_store_tile(const GemmProblem& p, const floatx16 (&acc)[TM][TN], float* __restrict__ patches, int slice,
+__device__ __forceinline__ void g3_store_tile(const Gemm3Problem& p, const floatx16 (&acc)[TM][TN], float* __restrict__ patches, int slice,
                                               int row0, int col0, int lane) {
     const int l31 = lane & 31, h = lane >> 5;
     const int M = p.M, N = p.N;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void g3_produce_f32(const float* __restrict__ base, i
 }
 
 template <int TM, int TN, int S>
-__global__ void __launch_bounds__(512) gemm3_kernel(const GemmGroup g) {
+__global__ void __launch_bounds__(512) gemm3_kernel(const Gemm3Group g) {
     using G = G3Geom<TM, TN, S>;
     constexpr int BM = G::BM, BN = G::BN, BK = G::BK;
     extern __shared__ __attribute__((aligned(16))) char smem3[];
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(512) gemm3_kernel(const GemmGroup g) {
 #pragma unroll
     for (int i = 1; i < MAX_GROUP; ++i)
         if (i < g.n && orig >= g.p[i].tile_start) pi = i;
-    const GemmProblem& p = g.p[pi];
+    const Gemm3Problem& p = g.p[pi];
     const int nwg = p.tiles_m * p.tiles_n * p.kslices;
     const int jb = orig - p.tile_start;
     const int xcd = jb & 7, qd = nwg >> 3, rm = nwg & 7;

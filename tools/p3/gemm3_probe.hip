@@ -1,7 +1,7 @@
 // Standalone probe of the P3 GEMM kernel (controllable_agent_amd/csrc/gemm3_kernel.h): correctness against an fp64 host
 // reference (sampled entries + the P3 image of C) and timing per shape / orientation / tile configuration, each shape alone and
-// as a 4-problem group.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I controllable_agent_amd/csrc -I include
-//                               tools/gemm3_probe.hip -o tools/scratch/gemm3_probe
+// as a 4-problem group.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools/p3 -I controllable_agent_amd/csrc -I include
+//                               tools/p3/gemm3_probe.hip -o tools/scratch/gemm3_probe
 // -DG3_KNOCK: the knock-out build (tools/scratch/gemm3_probe_knock); the clean build is the one to quote times from
 #include "gemm3_kernel.h"
 
@@ -64,7 +64,7 @@ static Mat make_out(int rows, int cols) {
 }
 
 template <int TM, int TN, int S>
-static void launch(const GemmGroup& g, hipStream_t s) {
+static void launch(const Gemm3Group& g, hipStream_t s) {
     using G = G3Geom<TM, TN, S>;
     static bool init = false;
     if (!init) {
@@ -74,7 +74,7 @@ static void launch(const GemmGroup& g, hipStream_t s) {
     hipLaunchKernelGGL((gemm3_kernel<TM, TN, S>), dim3(g.total_tiles), dim3(512), G::LDS_BYTES, s, g);
 }
 
-static void launch_cfg(int cfg, const GemmGroup& g, hipStream_t s) {
+static void launch_cfg(int cfg, const Gemm3Group& g, hipStream_t s) {
     switch (cfg) {
         case 0: launch<2, 2, 3>(g, s); break;
         case 1: launch<2, 1, 3>(g, s); break;
@@ -93,9 +93,9 @@ static const int cfg_bn[] = {128, 64, 64, 64, 128, 128, 64};
 // mode: 3 = NT (A [M,K], B [N,K]), 2 = NN (A [M,K], B [K,N]), 0 = TN (A [K,M], B [K,N])
 struct Case { int M, N, K, mode, epi; int pa = 1, pb = 1; };      // pa / pb: stage the operand from its image (1) or from fp32 (0)
 
-static GemmProblem problem(const Case& c, const Mat& A, const Mat& B, Mat& C, const float* bias, const float* aux, int ldaux,
+static Gemm3Problem problem(const Case& c, const Mat& A, const Mat& B, Mat& C, const float* bias, const float* aux, int ldaux,
                            float* colsum, int cfg) {
-    GemmProblem p{};
+    Gemm3Problem p{};
     p.A = A.d; p.B = B.d; p.C = C.d; p.A3 = c.pa ? A.d3 : nullptr; p.B3 = c.pb ? B.d3 : nullptr; p.C3 = c.pa && c.pb ? C.d3 : nullptr;
     p.bias = bias; p.aux = aux; p.ldaux = ldaux; p.colsum = colsum;
     p.M = c.M; p.N = c.N; p.K = c.K; p.lda = A.ld; p.ldb = B.ld; p.ldc = C.ld;
@@ -128,7 +128,7 @@ static void time_case(const Case& c, int group, int cfg, int iters, int knock, s
 #else
     if (knock) { printf("(clean build: no knock-outs)\n"); return; }
 #endif
-    GemmGroup g{};
+    Gemm3Group g{};
     int start = 0;
     for (int q = 0; q < group; ++q) {
         g.p[q] = problem(c, As[q], Bs[q], Cs[q], bias.d, aux.d, aux.ld, nullptr, cfg);
@@ -184,7 +184,7 @@ int main(int argc, char** argv) {
             Mat bias = make(1, c.N, rng), aux = make(c.M, c.N, rng, 0.6f);
             float* colsum = nullptr;
             if (c.mode == 0) CK(hipMalloc(&colsum, c.M * 4));
-            GemmGroup g{};
+            Gemm3Group g{};
             g.p[0] = problem(c, A, B, C, bias.d, aux.d, aux.ld, colsum, cfg);
             g.p[0].tile_start = 0; g.n = 1; g.total_tiles = g.p[0].tiles_m * g.p[0].tiles_n;
             launch_cfg(cfg, g, s);
@@ -248,7 +248,7 @@ int main(int argc, char** argv) {
             }
             Mat bias = make(1, c.N, rng), aux = make(c.M, c.N, rng, 0.6f);
             for (int cfg = 0; cfg < 7; ++cfg) {
-                GemmGroup g{};
+                Gemm3Group g{};
                 int start = 0;
                 for (int q = 0; q < group; ++q) {
                     g.p[q] = problem(c, As[q], Bs[q], Cs[q], bias.d, aux.d, aux.ld, nullptr, cfg);
