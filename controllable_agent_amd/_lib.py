@@ -109,6 +109,7 @@ PROTOTYPES = {
     "fbhip_discrete_act_host": (C.c_int, [_P, _P, _P, _P, _P]),
     "fbhip_gemm": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "fbhip_gemm_cfg": (C.c_int, [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "fbhip_head": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _F, _I, _I, _I, _I, _P]),
     "fbhip_ln_tanh_fwd": (C.c_int, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _P]),
     "fbhip_ln_tanh_bwd": (C.c_int, [_P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "fbhip_l2norm_fwd": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _P]),

@@ -1025,6 +1025,17 @@ int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* 
     return FBHIP_OK;
 }
 
+int fbhip_head(const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias, float* c, int32_t ldc, float* out2,
+               int32_t ldo, float* norms, float scale, int32_t rows, int32_t N, int32_t K, int32_t replicas, void* stream) {
+    fbhip_ctx* none = nullptr;
+    if (!x || !w || !bias || !c || replicas < 1 || replicas > HEAD_MAX_GROUP) { g_err = "fbhip_head: bad argument"; return FBHIP_E_INVALID; }
+    HeadGroup g{};
+    for (int i = 0; i < replicas; ++i) g.p[g.n++] = HeadProblem{x, ldx, w, ldw, bias, c, ldc, out2, ldo, norms, scale, rows, N, K};
+    if (!head_ok(g.p[0])) { g_err = "fbhip_head: needs N <= 64, K % 4 == 0, 16-byte aligned rows, ldc / ldo >= pad4(N)"; return FBHIP_E_INVALID; }
+    HIPCK(none, launch_head_group(g, (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
 int fbhip_ln_tanh_fwd(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
                       float* stats, int32_t rows, int32_t n, void* stream) {
     fbhip_ctx* none = nullptr;

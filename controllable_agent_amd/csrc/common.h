@@ -62,6 +62,17 @@ int pick_gemm_cfg(int M, int N, int K);
 bool gemm_problem_dma_ok(const GemmProblem& p);        // eligible for the LDS-DMA kernels (CFG_DMA128 requires it)
 void gemm_problem_finalize(GemmProblem& p, int cfg);   // fills a_vec/b_vec/tiles_*
 
+// ---- embedding heads in one launch (fused.hip) ----------------------------------------------------------------------------
+// C = X[rows, K] . W[N, K]^T + bias, N <= 64 (an embedding head); out2 != nullptr: also out2 = scale * C / max(|C|_row, 1e-12)
+// and norms[row] = |C|_row (sqrt(d) F.normalize, fb_modules.py:229).  K % 4 == 0, 16-byte aligned rows, ldc / ldo >= pad4(N)
+// (the pad columns are written as 0), bias readable to pad4(N).
+struct HeadProblem { const float* X; int ldx; const float* W; int ldw; const float* bias; float* C; int ldc;
+                     float* out2; int ldo; float* norms; float scale; int rows, N, K; };
+constexpr int HEAD_MAX_GROUP = 6;
+struct HeadGroup { HeadProblem p[HEAD_MAX_GROUP]; int n; };
+bool head_ok(const HeadProblem& p);
+hipError_t launch_head_group(const HeadGroup& g, hipStream_t s);
+
 // ---- row-wise ops ------------------------------------------------------------------------------------
 hipError_t launch_ln_tanh_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy,
                               float* stats, int rows, int n, hipStream_t s);

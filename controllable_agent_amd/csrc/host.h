@@ -201,6 +201,7 @@ struct Ops {
     std::vector<GemmProblem> gemms;
     std::vector<LnFwdProblem> lnf;
     std::vector<LnBwdProblem> lnb;
+    std::vector<HeadProblem> heads;           // embedding heads (+ projection) of this round that head_kernel can run (fused.hip)
     std::vector<L2Problem> l2n;               // run after this round's GEMMs
     std::vector<PolicyHeadJob> ph;            // fused policy heads of this round (one launch for all of them)
     std::vector<DiscreteHeadJob> dh;          // discrete: the selection / gather row jobs of this round (one launch)

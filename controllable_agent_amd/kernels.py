@@ -41,6 +41,21 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, a_kcontig: bool = True, b_kcontig:
     return (Cm, colsum) if want_colsum else Cm
 
 
+def head(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, *, normalize: bool = False, scale: float = 1.0, replicas: int = 1):
+    """c = x @ w.T + bias for an embedding head (N <= 64) and, with ``normalize``, scale * c / |c|_row and the row norms
+    (csrc/fused.hip).  bias must be readable up to pad4(N)."""
+    _lib.require_device()
+    rows, K = x.shape
+    N = w.shape[0]
+    ld = (N + 3) // 4 * 4
+    c = torch.full((rows, ld), float("nan"), device=x.device)
+    out2 = torch.full((rows, ld), float("nan"), device=x.device) if normalize else None
+    norms = torch.empty(rows, device=x.device) if normalize else None
+    check(_lib.load().fbhip_head(ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(c), ld, ptr(out2), ld, ptr(norms), scale, rows, N, K,
+                                 replicas, stream_ptr()))
+    return (c, out2, norms) if normalize else c
+
+
 def ln_tanh_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     """y = tanh(LayerNorm(x)), stats[rows,2] = (mean, rstd)   (fb_modules.py:49-50)."""
     _lib.require_device()

@@ -379,6 +379,12 @@ int fbhip_gemm(const float* A, int32_t lda, int32_t a_kcontig, const float* B, i
  * M x N x K); no epilogue.  For tests and kernel benchmarking. */
 int fbhip_gemm_cfg(const float* A, int32_t lda, int32_t a_kcontig, const float* B, int32_t ldb, int32_t b_kcontig,
                    float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t cfg, void* stream);
+/* The last layer of an embedding head in ONE launch (csrc/fused.hip): c = x[rows, K] . w[N, K]^T + bias with N <= 64, and, when
+ * out2 is given, out2 = scale * c / max(|c|_row, 1e-12), norms[row] = |c|_row  (fb_modules.py:78, :221, :229).  K % 4 == 0, rows
+ * 16-byte aligned, ldc / ldo >= pad4(N) (pad columns are written as 0), bias readable to pad4(N); FBHIP_E_INVALID otherwise (the
+ * update then runs the layer through fbhip_gemm's kernel).  replicas >= 1: the same problem that many times in one grouped launch. */
+int fbhip_head(const float* x, int32_t ldx, const float* w, int32_t ldw, const float* bias, float* c, int32_t ldc, float* out2,
+               int32_t ldo, float* norms, float scale, int32_t rows, int32_t N, int32_t K, int32_t replicas, void* stream);
 /* y = tanh(LayerNorm(x; gamma, beta, eps=1e-5)); stats[rows,2] = (mean, rstd)  (fb_modules.py:49-50) */
 int fbhip_ln_tanh_fwd(const float* x, int32_t ldx, const float* gamma, const float* beta, float* y, int32_t ldy,
                       float* stats, int32_t rows, int32_t n, void* stream);

@@ -358,3 +358,35 @@ def test_pairwise_randomised_sizes_and_alignment(K):
             assert torch.isfinite(got).all() and rel_err(got.cpu(), cf[k]) < 2e-5, (tag, k)
         for k in ("fb_loss", "fb_offdiag", "fb_diag", "orth_loss"):
             assert m[k] == pytest.approx(float(cf[k]), rel=5e-5, abs=1e-5), (tag, k)
+
+
+# ------------------------------------------------------------------------------------------------ embedding heads in one launch
+@pytest.mark.parametrize("rows,N,Kd", [(1024, 50, 1024), (1024, 50, 576), (2048, 64, 1024), (37, 6, 40), (5, 1, 4), (16, 48, 2048),
+                                       (3, 17, 36), (200, 64, 512), (64, 33, 1000)])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_head_last_layer_in_one_launch(K, rows, N, Kd, normalize):
+    """Linear(H, z) of an embedding head (+ sqrt(d) F.normalize, fb_modules.py:229) as ONE kernel (csrc/fused.hip): K split over
+    the workgroup's waves and folded in wave order -- against the fp64 statement; pad columns zero; bit-reproducible."""
+    x, w = _r(rows, Kd, seed=1), _r(N, Kd, seed=2, scale=0.2)
+    Np = (N + 3) // 4 * 4
+    b = torch.zeros(Np)
+    b[:N] = _r(N, seed=3)
+    ref = x.double() @ w.double().T + b[:N].double()
+    scale = math.sqrt(N)
+    out = K.head(x.cuda(), w.cuda(), b.cuda(), normalize=normalize, scale=scale)
+    c = out[0] if normalize else out
+    assert rel_err(c[:, :N].cpu(), ref) < 2e-6
+    assert torch.count_nonzero(c[:, N:]) == 0
+    if normalize:
+        nrm = ref.norm(dim=1)
+        assert rel_err(out[2].cpu(), nrm) < 2e-6
+        assert rel_err(out[1][:, :N].cpu(), scale * ref / nrm.clamp_min(1e-12)[:, None]) < 3e-6
+        assert torch.count_nonzero(out[1][:, N:]) == 0
+    again = K.head(x.cuda(), w.cuda(), b.cuda(), normalize=normalize, scale=scale, replicas=4)
+    assert torch.equal(again[0] if normalize else again, c)
+
+
+def test_head_refuses_what_it_cannot_run(K):
+    x, w, b = torch.zeros(8, 64, device="cuda"), torch.zeros(100, 64, device="cuda"), torch.zeros(100, device="cuda")
+    with pytest.raises(RuntimeError, match="N <= 64"):
+        K.head(x, w, b)
