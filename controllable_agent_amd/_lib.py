@@ -81,6 +81,7 @@ PROTOTYPES = {
     "fbhip_get_rng_counts": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _P]),
     "fbhip_set_rng_counts": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
+    "fbhip_update_chained": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_update_many": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_update_many_injected": (C.c_int, [_P, _P, _I, _P, _P]),
     "fbhip_dp_bind_peers": (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),

@@ -480,6 +480,7 @@ class FBHipAgent:
 
     # ------------------------------------------------------------------ pickling (pretrain.py:437-449 pickles the agent object)
     def __getstate__(self) -> tp.Dict[str, tp.Any]:
+        self._drop_prefetch()
         fb, ac = self.step_counts()
         flat = {k: getattr(self, k).detach().cpu() for k in ("_fb_params", "_fb_m", "_fb_v", "_fb_targets",
                                                               "_actor_params", "_actor_m", "_actor_v")}
@@ -520,11 +521,13 @@ class FBHipAgent:
 
     def rng_counts(self) -> tp.Tuple[int, int]:
         """(update() calls drawn, fast-path act() calls drawn): the counters of the device Philox streams"""
+        self._drop_prefetch()
         u, a = C.c_uint32(), C.c_uint32()
         check(_lib.load().fbhip_get_rng_counts(self._ctx, C.byref(u), C.byref(a), stream_ptr()), self._ctx)
         return int(u.value), int(a.value)
 
     def set_rng_counts(self, update_count: int, act_count: int) -> None:
+        self._chain_token = self._chain_seen = None      # (a pending prefetched head is void: the counters are being overwritten)
         check(_lib.load().fbhip_set_rng_counts(self._ctx, int(update_count), int(act_count), stream_ptr()), self._ctx)
 
     def _join_fast_path_stream(self) -> None:
@@ -1021,11 +1024,59 @@ class FBHipAgent:
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
             # a captured graph bakes stddev in: with a time-varying stddev_schedule (utils.py:235-255) every step would be a
             # fresh capture + instantiation (milliseconds), so those configurations run as eager launches instead
-            self._run_update(hp, None, self._use_graph and self._stddev_is_constant())
+            graph_ok = self._use_graph and self._stddev_is_constant()
+            if graph_ok and self._chain_update(replay_loader, hp):
+                return self._metrics()
+            self._run_update(hp, None, graph_ok)
         else:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)
         return self._metrics()
+
+    # ---- consecutive update() calls chain (fbhip_update_chained): the drop-in call of train_offline.py:118 at the pipelined rate
+    def _chain_state(self, rb: DeviceReplayBuffer, hp: HParams) -> tp.Tuple:
+        """Everything the validity of a prefetched head depends on: the replay contents (mutation counter), the hyper-parameters,
+        the caller's stream, and torch's version counters of the flat parameter / optimiser tensors -- every host-side in-place
+        write through a state_dict view, init_from, load_nets ... bumps them, the library's own kernels do not."""
+        flats = [self._fb_params, self._fb_targets, self._fb_m, self._fb_v] + ([] if self._discrete else [self._actor_params, self._actor_m, self._actor_v])
+        return (id(rb), rb._version, bytes(hp), tuple(t._version for t in flats), torch.cuda.current_stream(self._device).cuda_stream)
+
+    def _drop_prefetch(self) -> None:
+        """Another entry point is about to run (or the state changed): the head the last chained call prefetched will not be used.
+        It has consumed one value of the update RNG counter: give it back, so that the sequence of draws is the one of unchained
+        calls."""
+        self._chain_seen = None
+        if self.__dict__.get("_chain_token") is None:
+            return
+        self._chain_token = None
+
+        def roll_back() -> None:
+            u, a = C.c_uint32(), C.c_uint32()
+            check(_lib.load().fbhip_get_rng_counts(self._ctx, C.byref(u), C.byref(a), stream_ptr()), self._ctx)
+            check(_lib.load().fbhip_set_rng_counts(self._ctx, int(u.value) - 1, int(a.value), stream_ptr()), self._ctx)
+        self._on_update_stream(roll_back)
+
+    def _chain_update(self, rb: DeviceReplayBuffer, hp: HParams) -> bool:
+        """One update through ``fbhip_update_chained`` when consecutive calls can chain -- one rank, an actor phase to prefetch
+        beside, and NOTHING changed since the previous update() call (a loop that adds transitions between updates, the online
+        loop of pretrain.py:559-659, therefore never chains and keeps sampling at update time like the reference).  The first
+        call of a run of unchanged state is a plain update, the second runs its own head and prefetches, from the third on the
+        head is already there: same kernels, operands and draws as ``update_many`` over the same steps, bit for bit.
+        ``FBHIP_UPDATE_CHAIN=0`` turns it off."""
+        if self._discrete or self._world() > 1 or os.environ.get("FBHIP_UPDATE_CHAIN", "1") == "0" or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1":
+            self._drop_prefetch()
+            return False
+        state = self._chain_state(rb, hp)
+        have = self.__dict__.get("_chain_token") == state
+        if not have:
+            seen = self.__dict__.get("_chain_seen")
+            self._drop_prefetch()
+            if seen != state:                    # first call in this state: plain update; chain from the next call on if it still holds
+                self._chain_seen = state
+                return False
+        self._on_update_stream(lambda: check(_lib.load().fbhip_update_chained(self._ctx, C.byref(hp), int(have), stream_ptr()), self._ctx))
+        self._chain_token = self._chain_seen = state
+        return True
 
     def _rccl_ready(self) -> bool:
         """Bind the library-owned RCCL transport on first use (rccl.py); a refusal (no librccl, communicator set-up failed) is
@@ -1093,6 +1144,7 @@ class FBHipAgent:
         Returns the metrics of the LAST step (if metrics are on).  NOTE: step t+1's batch is sampled while step t is still
         running -- from the same buffer contents; do not use it when transitions are added between updates."""
         c = self.cfg
+        self._drop_prefetch()
         stds = {schedule(c.stddev_schedule, step + i) for i in range(n_steps)}
         split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
         if (n_steps < 2 or getattr(c, "dp_global_batch", False) or not isinstance(replay_loader, DeviceReplayBuffer) or
@@ -1175,6 +1227,7 @@ class FBHipAgent:
         """One update on an externally sampled batch (``EpisodeBatch``-like: obs, action, next_obs, discount
         [, goal, next_goal]).  ``draws`` optionally injects the remaining random draws (parity tests):
         z_gauss [B,d], perm [B], mix_uniform [B], eps_next [B,a], eps_actor [B,a]."""
+        self._drop_prefetch()
         c, dev, Bn = self.cfg, self._device, self.cfg.batch_size
         f = lambda x: torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32,
                                       device=dev).reshape(Bn, -1)
@@ -1229,6 +1282,7 @@ class FBHipAgent:
                         use_graph: bool = False) -> tp.Dict[str, float]:
         """Parity mode: every random draw of the step is supplied (``ep_idx, step_idx, z_gauss, perm,
         mix_uniform, eps_next, eps_actor``), exactly as recorded from the reference run."""
+        self._drop_prefetch()
         dev = self._device
         self._bind_replay(replay_loader)
         keep = {}
@@ -1270,6 +1324,7 @@ class FBHipAgent:
             raise ValueError("update_many_injected: 1..64 steps per call")
         if self._world() > 1 or len({schedule(self.cfg.stddev_schedule, step + i) for i in range(n)}) != 1:
             raise ValueError("update_many_injected: single rank and a constant stddev over the steps only")
+        self._drop_prefetch()
         dev = self._device
         self._bind_replay(replay_loader)
         # (SFAgentConfig has no future_ratio / rand_weight / norm_z; its contrastive learners read the hindsight goal, sf.py:125, 167)
@@ -1733,6 +1788,7 @@ class SFHipAgent(FBHipAgent):
 
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         c = self.cfg
+        self._drop_prefetch()
         total = n_steps * int(c.num_sf_updates)                  # (every update() call is num_sf_updates complete updates)
         split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
         const_std = len({schedule(c.stddev_schedule, step + i) for i in range(n_steps)}) == 1

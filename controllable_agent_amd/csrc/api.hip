@@ -398,6 +398,7 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     RC(check_hparams(c, hp));
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
+    c->view_set = -1;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     reap(s);
     for (auto& g : c->graphs) {
@@ -438,6 +439,7 @@ int fbhip_fb_early_grad_range(const fbhip_dims* dims, int64_t* offset, int64_t* 
 int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
     if (!c || which < 0 || which > 1) return FBHIP_E_INVALID;
     c->cur = which;
+    c->view_set = -1;
     return FBHIP_OK;
 }
 
@@ -450,6 +452,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     if (n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
+    c->view_set = -1;
     reap(s);
     // (FBHIP_UPDATE_PIPELINE is read at every call: a host can time both forms of a graph and keep the faster one, bench.py does
     // for the data-parallel graph, whose branched form has a slow mode on ROCm 7.0 that depends on what else lives in the process)
@@ -588,6 +591,77 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     return launch_graph(c, ge.exec, s, ge.branches);
 }
 
+// One update per call at the rate of the pipelined n-step graph: consecutive calls CHAIN.  A call runs the update whose head
+// (sampling, z mixing, B passes, online ForwardMap pass -- everything that depends on the previous update only through its FB
+// optimiser step) is already sitting in the current workspace set (have_head: left there by the previous chained call) or runs it
+// first (have_head == 0), and prefetches the NEXT update's head into the other set on the second capture branch beside this
+// update's actor phase -- one iteration of fbhip_update_many's pipelined loop, same kernels, operands and order, so a sequence
+// of chained calls is bit-identical to one fbhip_update_many over the same steps.  Afterwards the current set is the one that
+// holds the prefetched head.  The CALLER decides whether that head is still valid at the next call (nothing wrote the
+// parameters or the replay storage in between; same hparams) and passes have_head accordingly; a head that is not used costs
+// one RNG counter value (fbhip_set_rng_counts restores it).
+constexpr int CHAIN_BIT = 1 << 21, CHAIN_HEAD_BIT = 1 << 22;
+int fbhip_update_chained(fbhip_ctx* c, const fbhip_hparams* hp, int32_t have_head, void* stream) {
+    RC(need_bound(c, true));
+    RC(check_hparams(c, hp));
+    if (c->d.discrete) { c->err = g_err = "fbhip_update_chained: DiscreteFBAgent has no actor phase to prefetch beside (use fbhip_update)"; return FBHIP_E_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    c->last_stream = s;
+    reap(s);
+    const int key = FBHIP_PHASE_ALL | CHAIN_BIT | (have_head ? CHAIN_HEAD_BIT : 0);
+    auto done = [&](int rc) { if (rc == FBHIP_OK) { c->view_set = c->cur; c->cur ^= 1; } return rc; };
+    for (auto& g : c->graphs)
+        if (g.n_steps == 1 && g.set == c->cur && g.mask == key && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0)
+            return done(launch_graph(c, g.exec, s, g.branches));
+    if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    while ((int)c->events.size() < 3 * 64) {
+        hipEvent_t ev;
+        HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->events.push_back(ev);
+    }
+    const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
+    const int MID = FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD | FBHIP_PHASE_FB_STEP;   // (both FB_BWD bits)
+    const int TAIL = FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP;
+    hipGraph_t graph = nullptr;
+    HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int cur0 = c->cur;
+    int rc = FBHIP_OK;
+    hipError_t he = hipSuccess;
+    if (!have_head) rc = enqueue_update(c, *hp, nullptr, HEAD, s);
+    if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, MID, s);
+    if (rc == FBHIP_OK) {
+        // fork: V of this update's actor phase, then the next update's head on the twin workspace set
+        if ((he = hipEventRecord(c->events[0], s)) == hipSuccess) he = hipStreamWaitEvent(c->side, c->events[0], 0);
+        if (he == hipSuccess) rc = enqueue_actor_v(c, c->side);
+        if (he == hipSuccess && rc == FBHIP_OK) he = hipEventRecord(c->events[128], c->side);
+        if (he == hipSuccess && rc == FBHIP_OK) {
+            c->cur ^= 1;
+            rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
+            c->cur ^= 1;
+        }
+        if (he == hipSuccess && rc == FBHIP_OK) {
+            c->v_ready = c->events[128];
+            rc = enqueue_update(c, *hp, nullptr, TAIL, s);
+            c->v_ready = nullptr;
+        }
+        // join
+        if (he == hipSuccess && rc == FBHIP_OK && (he = hipEventRecord(c->events[1], c->side)) == hipSuccess) he = hipStreamWaitEvent(s, c->events[1], 0);
+    }
+    c->cur = cur0;
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (he != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCK(c, he); }
+    HIPCK(c, e);
+    GraphEntry ge{};
+    ge.mask = key; ge.hp = *hp; ge.has_inj = false; ge.n_steps = 1; ge.set = c->cur; ge.branches = true;
+    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    HIPCK(c, e);
+    if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
+    c->graphs.push_back(ge);
+    return done(launch_graph(c, ge.exec, s, ge.branches));
+}
+
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
     return update_many_impl(c, hp, n_steps, nullptr, stream);
 }
@@ -684,7 +758,7 @@ int fbhip_read_metrics(fbhip_ctx* c, float* host_out, void* stream) {
 int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld) {
     RC(need_bound(c, false));
     if (!name || !ptr) return FBHIP_E_INVALID;
-    Ws& w = c->W();
+    Ws& w = c->view_set >= 0 ? c->sets[c->view_set] : c->W();
     const fbhip_dims& d = c->d;
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, z = d.z_dim;
     const int aoff = geom_of(d).single ? o + z : o;

@@ -245,6 +245,17 @@ int fbhip_set_rng_counts(fbhip_ctx* ctx, uint32_t update_count, uint32_t act_cou
  * cached hipGraph of the launch sequence (captured on first use; re-captured when hparams change). */
 int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* inject,
                  int32_t phase_mask, int32_t use_graph, void* stream);
+/* One update per call at the rate of the pipelined n-step graph: consecutive calls chain.  The call runs the update whose HEAD
+ * (FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE: everything that depends on the previous update only through its FB optimiser
+ * step) already sits in the current workspace set (have_head != 0: left there by the previous chained call) or runs it first
+ * (have_head == 0), and prefetches the NEXT update's head into the other set beside this update's actor phase: one iteration of
+ * fbhip_update_many's pipelined loop, so a sequence of chained calls equals ONE fbhip_update_many over the same steps bit for
+ * bit.  On return the current workspace set is the one holding the prefetched head (fbhip_workspace_view keeps answering for the
+ * completed update).  The caller owns the validity of that head: pass have_head = 0 after anything wrote the parameters, the
+ * optimiser state or the replay storage, after another update entry point ran, or when hparams changed; the unused head has
+ * consumed one RNG counter value (fbhip_get_rng_counts / fbhip_set_rng_counts restore it).  This is the call behind the drop-in
+ * ``agent.update(replay_loader, step)`` of train_offline.py:118.  Not for dims.discrete (no actor phase): FBHIP_E_STATE. */
+int fbhip_update_chained(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t have_head, void* stream);
 /* n_steps consecutive complete updates (all phases, device-drawn batches) as ONE hipGraph launch: what the offline loop
  * (train_offline.py:101-134) does between two log lines.  The same kernels on the same operands as n_steps fbhip_update
  * calls -- the Adam / RNG counters advance on the device -- minus n_steps - 1 graph-launch gaps, with consecutive steps

@@ -721,6 +721,70 @@ def test_update_many_equals_consecutive_updates():
         np.testing.assert_array_equal(s1[k], s3[k], err_msg=k)
 
 
+def test_consecutive_update_calls_chain_and_equal_unchained_calls(monkeypatch):
+    """The drop-in call, ``agent.update(replay_loader, step)`` once per iteration (train_offline.py:118), chains: from the third
+    call of a run of unchanged state on, the update's head was prefetched beside the previous actor phase (fbhip_update_chained).
+    Same kernels, operands and draws as unchained calls: bit-identical state and RNG counters -- across everything that must
+    void a prefetched head: a host write to the parameters, a mutation of the replay buffer, another update entry point, a
+    pickle round trip, a read of the RNG counters."""
+    import contextlib
+    import pickle
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64)
+    rng = np.random.default_rng(23)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a, b = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(2))
+
+    @contextlib.contextmanager
+    def unchained():
+        monkeypatch.setenv("FBHIP_UPDATE_CHAIN", "0")
+        yield
+        monkeypatch.delenv("FBHIP_UPDATE_CHAIN")
+
+    def both(fn):
+        fn(a)
+        with unchained():
+            fn(b)
+
+    def same():
+        sa, sb = H.get_agent_state(a), H.get_agent_state(b)
+        for k in sa:
+            np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+        assert a.step_counts() == b.step_counts()
+
+    step = [0]
+
+    def updates(n):
+        for _ in range(n):
+            both(lambda ag: ag.update(rb, step[0]))
+            step[0] += 1
+
+    updates(5)
+    assert a.__dict__.get("_chain_token") is not None and b.__dict__.get("_chain_token") is None      # a chains, b does not
+    # the completed update's panels, not the prefetched head's, answer workspace_view
+    for name in ("F1", "Xoz", "z", "dF1"):
+        assert torch.equal(a.workspace_view(name), b.workspace_view(name)), name
+    same()
+    both(lambda ag: ag.forward_net.load_state_dict(ag.forward_net.state_dict()))       # a host write (same values): the head is void
+    updates(4)
+    same()
+    rb._version += 1                                                                   # a mutation of the buffer (add / load bump this)
+    updates(4)
+    same()
+    both(lambda ag: ag.update_many(rb, step[0], 3))                                    # another entry point in between
+    step[0] += 3
+    updates(3)
+    assert a.rng_counts() == b.rng_counts()                                            # (reading them voids the head as well)
+    updates(3)
+    same()
+    a = pickle.loads(pickle.dumps(a))                                                  # resumes with the draws an uninterrupted run makes
+    updates(3)
+    same()
+    assert a.rng_counts() == b.rng_counts() == (step[0], 0)
+
+
 def test_legacy_default_stream_callers_see_the_update_without_a_wait_on_that_stream():
     """A caller on torch's legacy default stream (what plain reference code is): the update runs on the agent's own stream and
     the caller's LATER default-stream work must still see it -- through fbhip_order_legacy_stream_after (a wait on a blocking
