@@ -1062,8 +1062,13 @@ class FBHipAgent:
         loop of pretrain.py:559-659, therefore never chains and keeps sampling at update time like the reference).  The first
         call of a run of unchanged state is a plain update, the second runs its own head and prefetches, from the third on the
         head is already there: same kernels, operands and draws as ``update_many`` over the same steps, bit for bit.
-        ``FBHIP_UPDATE_CHAIN=0`` turns it off."""
-        if self._discrete or self._world() > 1 or os.environ.get("FBHIP_UPDATE_CHAIN", "1") == "0" or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1":
+        OPT-IN (``FBHIP_UPDATE_CHAIN=1``): measured on MI355X / ROCm 7.0 (profiles/r04_chained_update.txt) a branched graph
+        launched once per update costs more than its overlap earns -- 973-1081 update-steps/s against 1089 for the plain
+        one-graph-per-update call under ROC_CPU_WAIT_FOR_SIGNAL=1 (the host resolves every cross-queue edge and cannot run
+        ahead), 1071-1108 without that setting and only from a high-priority caller stream (513 otherwise); loops that can hand
+        over several steps should call ``update_many`` (1136-1160)."""
+        if (self._discrete or self._world() > 1 or os.environ.get("FBHIP_UPDATE_CHAIN", "0") != "1" or
+                os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"):
             self._drop_prefetch()
             return False
         state = self._chain_state(rb, hp)

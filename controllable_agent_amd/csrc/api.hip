@@ -45,17 +45,33 @@ hipError_t launch_stream(hipStream_t* out) {
     return hipSuccess;
 }
 
-int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches) {
+// after_own: the previous command of this context on the launch stream was its own previous branched graph and the caller's
+// stream holds nothing newer that this graph depends on (fbhip_update_chained with a valid head): the launch stream's order is
+// the dependency, and the hop from the caller's stream is skipped -- with it every launch would wait (on the HOST, under
+// ROC_CPU_WAIT_FOR_SIGNAL=1) for the previous graph to finish before it is even submitted.
+int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches, bool after_own = false) {
     if (!branches) {
         HIPCK(c, hipGraphLaunch(exec, s));
         return FBHIP_OK;
+    }
+    {   // the caller's stream is itself of the high-priority class: its hardware queue comes from the other pool already -- launch
+        // there, without the two event hops (measured round 4, profiles/r04_chained_update.txt: per-update launches of a branched
+        // graph run at 1108 update-steps/s this way, at 513 through the hop under the runtime's default dependency handling)
+        int prio = 0, lo = 0, hi = 0;
+        if (s != nullptr && hipStreamGetPriority(s, &prio) == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo && prio == hi) {
+            HIPCK(c, hipGraphLaunch(exec, s));
+            return FBHIP_OK;
+        }
+        (void)hipGetLastError();
     }
     hipStream_t ls = nullptr;
     HIPCK(c, launch_stream(&ls));
     if (!c->ev_in) HIPCK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     if (!c->ev_out) HIPCK(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
-    HIPCK(c, hipEventRecord(c->ev_in, s));
-    HIPCK(c, hipStreamWaitEvent(ls, c->ev_in, 0));
+    if (!after_own) {
+        HIPCK(c, hipEventRecord(c->ev_in, s));
+        HIPCK(c, hipStreamWaitEvent(ls, c->ev_in, 0));
+    }
     HIPCK(c, hipGraphLaunch(exec, ls));
     HIPCK(c, hipEventRecord(c->ev_out, ls));
     HIPCK(c, hipStreamWaitEvent(s, c->ev_out, 0));
@@ -399,6 +415,7 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
     c->view_set = -1;
+    c->chain_live = false;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     reap(s);
     for (auto& g : c->graphs) {
@@ -440,6 +457,7 @@ int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
     if (!c || which < 0 || which > 1) return FBHIP_E_INVALID;
     c->cur = which;
     c->view_set = -1;
+    c->chain_live = false;
     return FBHIP_OK;
 }
 
@@ -453,6 +471,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
     c->view_set = -1;
+    c->chain_live = false;
     reap(s);
     // (FBHIP_UPDATE_PIPELINE is read at every call: a host can time both forms of a graph and keep the faster one, bench.py does
     // for the data-parallel graph, whose branched form has a slow mode on ROCm 7.0 that depends on what else lives in the process)
@@ -609,10 +628,12 @@ int fbhip_update_chained(fbhip_ctx* c, const fbhip_hparams* hp, int32_t have_hea
     c->last_stream = s;
     reap(s);
     const int key = FBHIP_PHASE_ALL | CHAIN_BIT | (have_head ? CHAIN_HEAD_BIT : 0);
-    auto done = [&](int rc) { if (rc == FBHIP_OK) { c->view_set = c->cur; c->cur ^= 1; } return rc; };
+    auto done = [&](int rc) { if (rc == FBHIP_OK) { c->view_set = c->cur; c->cur ^= 1; c->chain_stream = s; c->chain_live = true; } return rc; };
+    // (the head this call relies on was enqueued by the previous chained call, behind which this launch sits on the launch stream)
+    const bool after_own = have_head && c->chain_live && c->chain_stream == s;
     for (auto& g : c->graphs)
         if (g.n_steps == 1 && g.set == c->cur && g.mask == key && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0)
-            return done(launch_graph(c, g.exec, s, g.branches));
+            return done(launch_graph(c, g.exec, s, g.branches, after_own));
     if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     while ((int)c->events.size() < 3 * 64) {
         hipEvent_t ev;
@@ -659,7 +680,7 @@ int fbhip_update_chained(fbhip_ctx* c, const fbhip_hparams* hp, int32_t have_hea
     HIPCK(c, e);
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
-    return done(launch_graph(c, ge.exec, s, ge.branches));
+    return done(launch_graph(c, ge.exec, s, ge.branches, after_own));
 }
 
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {

@@ -135,6 +135,8 @@ struct fbhip_ctx {
     bool bound = false, replay_bound = false;
     fbhip::host::Ws sets[2];                              // two complete workspace sets: fbhip_update_many alternates them so that step
     int cur = 0;                             // t+1's sampling and online forward passes can run beside step t's actor phase
+    hipStream_t chain_stream = nullptr;      // fbhip_update_chained: the caller's stream of the last chained call, and whether that call
+    bool chain_live = false;                 // was this context's last update entry point
     int view_set = -1;                       // fbhip_workspace_view: the set of the last completed update when a chained call left ``cur`` on the prefetched one
     fbhip::host::Ws& W() { return sets[cur]; }            // the set kernels are currently enqueued on
     const char* ws_lo = nullptr;

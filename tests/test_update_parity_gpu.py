@@ -722,8 +722,8 @@ def test_update_many_equals_consecutive_updates():
 
 
 def test_consecutive_update_calls_chain_and_equal_unchained_calls(monkeypatch):
-    """The drop-in call, ``agent.update(replay_loader, step)`` once per iteration (train_offline.py:118), chains: from the third
-    call of a run of unchanged state on, the update's head was prefetched beside the previous actor phase (fbhip_update_chained).
+    """The drop-in call, ``agent.update(replay_loader, step)`` once per iteration (train_offline.py:118), can chain
+    (FBHIP_UPDATE_CHAIN=1; off by default, DESIGN.md says why): from the third call of a run of unchanged state on, the update's head was prefetched beside the previous actor phase (fbhip_update_chained).
     Same kernels, operands and draws as unchained calls: bit-identical state and RNG counters -- across everything that must
     void a prefetched head: a host write to the parameters, a mutation of the replay buffer, another update entry point, a
     pickle round trip, a read of the RNG counters."""
@@ -738,15 +738,15 @@ def test_consecutive_update_calls_chain_and_equal_unchained_calls(monkeypatch):
     a, b = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(2))
 
     @contextlib.contextmanager
-    def unchained():
-        monkeypatch.setenv("FBHIP_UPDATE_CHAIN", "0")
+    def chained():
+        monkeypatch.setenv("FBHIP_UPDATE_CHAIN", "1")
         yield
         monkeypatch.delenv("FBHIP_UPDATE_CHAIN")
 
     def both(fn):
-        fn(a)
-        with unchained():
-            fn(b)
+        with chained():
+            fn(a)
+        fn(b)
 
     def same():
         sa, sb = H.get_agent_state(a), H.get_agent_state(b)
@@ -779,7 +779,8 @@ def test_consecutive_update_calls_chain_and_equal_unchained_calls(monkeypatch):
     assert a.rng_counts() == b.rng_counts()                                            # (reading them voids the head as well)
     updates(3)
     same()
-    a = pickle.loads(pickle.dumps(a))                                                  # resumes with the draws an uninterrupted run makes
+    with chained():
+        a = pickle.loads(pickle.dumps(a))                                              # resumes with the draws an uninterrupted run makes
     updates(3)
     same()
     assert a.rng_counts() == b.rng_counts() == (step[0], 0)
