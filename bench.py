@@ -12,10 +12,9 @@ minibatch, gradients are all-reduced (RCCL) twice per step -> weak scaling; valu
 For N>1 every launched worker supervises a child process that is the real rank (supervise_ranks): a crash or a stall moves all
 ranks on to the next gradient transport; the line then carries data_parallel.attempts.
 
-Environment read by this script (diagnostics, none needed for the line): ROC_CPU_WAIT_FOR_SIGNAL (default set here to 1, see
-below), FBHIP_BENCH_CONTROL_PLANE=gloo|nccl (process group beside the library RCCL transport), FBHIP_BENCH_LEGACY_STREAM=1
-(enqueue from torch's legacy default stream), FBHIP_BENCH_WORLD1_BACKEND / FBHIP_BENCH_EXTRA_STREAMS (one-rank probes of
-DESIGN.md section 7's slow mode), FBHIP_BENCH_FAIL_TRANSPORT (tests of the supervisor).
+Environment read by this script (diagnostics, none needed for the line): ROC_CPU_WAIT_FOR_SIGNAL (default set here to 1 for N = 1,
+see below), FBHIP_BENCH_LEGACY_STREAM=1 (enqueue from torch's legacy default stream), FBHIP_BENCH_WORLD1_BACKEND /
+FBHIP_BENCH_EXTRA_STREAMS (one-rank probes), FBHIP_BENCH_FAIL_TRANSPORT (tests of the supervisor).
 """
 from __future__ import annotations
 
@@ -28,13 +27,23 @@ from pathlib import Path
 
 # Runtime configuration, set before the HIP runtime is loaded (import torch).  ROC_CPU_WAIT_FOR_SIGNAL=1: ROCclr resolves a
 # dependency on another hardware queue's signal by waiting for it on the host instead of parking a barrier packet on it.  The
-# n-step update graph has two to three branches, i.e. cross-queue dependencies at every fork and join: measured +3.2 % on the
-# bench line (1116.5 -> 1151.9 update-steps/s, same box) and the cure for most of the branched data-parallel graph's slow mode
-# (470 -> 992).  An explicit setting in the environment wins.  Reported in config.runtime_env.
-_CPU_WAIT_WAS_SET = "ROC_CPU_WAIT_FOR_SIGNAL" in os.environ and os.environ.get("FBHIP_BENCH_CPU_WAIT_DEFAULTED") != "1"
-if not _CPU_WAIT_WAS_SET:               # (an explicit setting is kept for every attempt of supervise_ranks; ours is marked as a default)
-    os.environ["ROC_CPU_WAIT_FOR_SIGNAL"] = os.environ.get("ROC_CPU_WAIT_FOR_SIGNAL", "1")
-    os.environ["FBHIP_BENCH_CPU_WAIT_DEFAULTED"] = "1"
+# SINGLE-GPU n-step update graph has two to three branches, i.e. cross-queue dependencies at every fork and join: measured +3.2 %
+# on the bench line (1116.5 -> 1151.9 update-steps/s, same box).  The data-parallel graph (--gpus N > 1) is single-queue by
+# construction and has no such dependency: those runs keep the runtime's default.  An explicit setting in the environment wins.
+# Reported in config.runtime_env.
+def _multi_gpu_invocation():
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return True
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return sys.argv[i + 1].isdigit() and int(sys.argv[i + 1]) > 1
+        if a.startswith("--gpus="):
+            return a[7:].isdigit() and int(a[7:]) > 1
+    return False
+
+
+if "ROC_CPU_WAIT_FOR_SIGNAL" not in os.environ and not _multi_gpu_invocation():
+    os.environ["ROC_CPU_WAIT_FOR_SIGNAL"] = "1"
 
 import numpy as np
 import torch
@@ -198,13 +207,6 @@ def supervise_ranks(args, rank, world):
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=1800))
     first = "peer" if args.peer_allreduce else (args.transport or "rccl")
     transports = [first] if (args.global_batch or args.no_fallback_transports) else [first] + [t for t in ("rccl", "c10d", "peer") if t != first]
-    # (transport, ROC_CPU_WAIT_FOR_SIGNAL): the first attempt runs like the single-GPU line (host-side dependency waits, +3 %); if it
-    # does not finish, the same transport is tried once more with the runtime's default before the next transport gets its turn --
-    # host-side waits inside a graph launch have never met a collective that spans real devices
-    cw = os.environ.get("ROC_CPU_WAIT_FOR_SIGNAL", "1")
-    plan = [(t, cw) for t in transports]
-    if cw == "1" and not _CPU_WAIT_WAS_SET and not args.no_fallback_transports:
-        plan = [(transports[0], "1"), (transports[0], "0")] + [(t, "0") for t in transports[1:]]
     argv = [a for a in sys.argv[1:] if a != "--peer-allreduce"]
     while "--transport" in argv:
         i = argv.index("--transport")
@@ -212,7 +214,7 @@ def supervise_ranks(args, rank, world):
     argv = [a for a in argv if not a.startswith("--transport=")]
     history, line = [], None
     tmp = Path(tempfile.mkdtemp(prefix=f"fbhip_bench_r{rank}_"))
-    for attempt, (tr, cpu_wait) in enumerate(plan):
+    for attempt, tr in enumerate(transports):
         port = [0]
         if rank == 0:
             import socket
@@ -221,7 +223,7 @@ def supervise_ranks(args, rank, world):
                 port[0] = sk.getsockname()[1]
         dist.broadcast_object_list(port, src=0)
         hb, so = tmp / f"beat{attempt}", tmp / f"out{attempt}"
-        env = dict(os.environ, MASTER_PORT=str(port[0]), FBHIP_BENCH_CHILD="1", FBHIP_BENCH_HEARTBEAT=str(hb), ROC_CPU_WAIT_FOR_SIGNAL=cpu_wait,
+        env = dict(os.environ, MASTER_PORT=str(port[0]), FBHIP_BENCH_CHILD="1", FBHIP_BENCH_HEARTBEAT=str(hb),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         for k in ("TORCHELASTIC_USE_AGENT_STORE",):          # the child ranks rendezvous among themselves: rank 0 hosts the store
             env.pop(k, None)
@@ -257,7 +259,7 @@ def supervise_ranks(args, rank, world):
         beat = hb.read_text().strip() if hb.exists() else "never started"
         every = [None] * world
         dist.all_gather_object(every, {"outcome": outcome, "last_progress": beat.split(" ", 1)[-1]})
-        history.append({"transport": tr, "ROC_CPU_WAIT_FOR_SIGNAL": cpu_wait, "seconds": round(time.time() - t0, 1), "ranks": every})
+        history.append({"transport": tr, "seconds": round(time.time() - t0, 1), "ranks": every})
         if outcome == "ok":
             if rank == 0:
                 text = so.read_text(errors="replace")
@@ -269,7 +271,7 @@ def supervise_ranks(args, rank, world):
             break
         if rank == 0:
             print(f"bench.py: transport {tr} did not finish ({[e['outcome'] for e in every]}); "
-                  + ("trying the next one" if attempt + 1 < len(plan) else "no transport left"), file=sys.stderr, flush=True)
+                  + ("trying the next one" if attempt + 1 < len(transports) else "no transport left"), file=sys.stderr, flush=True)
     ok = [line is not None]
     dist.broadcast_object_list(ok, src=0)
     if rank == 0 and line is not None:
@@ -364,16 +366,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # control plane: with the library-owned RCCL transport (the default) the process group only carries the 128-byte unique id,
-        # the replica checksums and this script's barriers.  It is an nccl group all the same: on one rank the library's n-step
-        # data-parallel graph replays at 1112 update-steps/s beside a c10d nccl group and at 471 beside a gloo group or none
-        # (deterministic, cause not found: profiles/r03_world1_rccl_control_plane.txt), and the library captures in thread-local
-        # mode, which the c10d watchdog's event polls cannot invalidate (tests/test_distributed_gpu.py::
-        # test_library_rccl_transport_beside_a_live_c10d_group_needs_no_quiescing).  FBHIP_BENCH_CONTROL_PLANE=gloo selects the
-        # other one.  (RCCL refuses two ranks per device: the one-GPU rehearsal stays on gloo and falls back to host-issued
-        # collectives.)
+        # control plane: with the library-owned RCCL transport (the default) or the peer kernels the process group only carries the
+        # 128-byte unique id / the hipIpc handles, the replica checksums, the ranks' agreement on the transport and this script's
+        # barriers: a gloo group.  Only the torch.distributed schedule (--transport c10d) needs an nccl group, for its all-reduces.
+        # (Round 3 kept an nccl group here because the BRANCHED data-parallel graph happened to replay 2.3x faster beside one; that
+        # graph form is gone -- the data-parallel graph is single-queue by construction -- and with it the reason.)
         transport = "peer" if args.peer_allreduce else (args.transport or "rccl")
-        if args.rehearse_on_one_gpu or (transport == "rccl" and os.environ.get("FBHIP_BENCH_CONTROL_PLANE", "nccl") == "gloo"):
+        if args.rehearse_on_one_gpu or transport in ("rccl", "peer"):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
@@ -435,48 +434,20 @@ def main():
 
     # everything is enqueued on ONE explicit stream so that the HIP events below bracket the same launches the wall clock does
     # (torch.cuda.Event only sees the stream it is recorded on; on the legacy default stream the agent would hop to its own)
-    bench_stream = torch.cuda.default_stream(dev) if os.environ.get("FBHIP_BENCH_LEGACY_STREAM") == "1" else torch.cuda.Stream(device=dev)
+    bench_stream = torch.cuda.default_stream(dev) if os.environ.get("FBHIP_BENCH_LEGACY_STREAM") == "1" else torch.cuda.Stream(device=dev, priority=-1)
     with torch.cuda.stream(bench_stream):
         run(0, args.warmup)
         torch.cuda.synchronize()
         _beat("warm-up done")
-        if world > 1 and not args.rehearse_on_one_gpu and os.environ.get("FBHIP_DP_ALLREDUCE", "rccl") == "rccl":
-            # did the library transport come up on EVERY rank?  If not (the JSON line says why), all ranks switch to the
-            # torch.distributed schedule together (on an nccl group: host-side gloo collectives are not what this line times)
-            flag = torch.tensor([1.0 if getattr(agent, "_rccl_failed", False) else 0.0], device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if float(flag.item()) > 0.0:
-                agent._rccl_failed = True
-                agent._dp_transport = getattr(agent, "_dp_transport", None) if str(getattr(agent, "_dp_transport", "")).startswith("c10d") else \
-                    "c10d (library RCCL transport refused on another rank)"
-                torch.cuda.synchronize()
-                if dist.get_backend() != "nccl":
-                    dist.destroy_process_group()
-                    dist.init_process_group("nccl", device_id=torch.device(dev))
-                run(0, args.warmup)
-        # The library's n-step data-parallel graph has two forms: pipelined (the next step's head on a second branch beside the
-        # actor phase and its all-reduce) and plain.  On ROCm 7.0 the branched form has a slow mode (2.3x) that depends on what
-        # else lives in the process (profiles/r03_world1_rccl_control_plane.txt); no multi-GPU box was ever available to see
-        # which way it falls there.  So: time two launches of each form now, untimed warm-up steps as far as the line is
-        # concerned, keep the faster one on ALL ranks (the slowest rank decides) and say so in the line.
-        dp_forms = None
-        if (world > 1 and spl > 1 and not args.global_batch and os.environ.get("FBHIP_DP_ALLREDUCE", "rccl") in ("rccl", "peer")
-                and not getattr(agent, "_rccl_failed", False) and os.environ.get("FBHIP_UPDATE_PIPELINE") is None):
-            rates = {}
-            for form in ("1", "0"):
-                os.environ["FBHIP_UPDATE_PIPELINE"] = form
-                run(args.warmup, spl)                          # captured here
-                barrier()
-                t0 = time.perf_counter()
-                run(args.warmup, 2 * spl)
-                barrier()
-                t = torch.tensor([2 * spl / (time.perf_counter() - t0)], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                rates[form] = float(t.item())
-            keep = "1" if rates["1"] >= 1.03 * rates["0"] else "0"        # (the branched form must EARN its place: two launches are a short sample)
-            os.environ["FBHIP_UPDATE_PIPELINE"] = keep
-            dp_forms = {"pipelined_kept": keep == "1", "calibration_steps_per_s_slowest_rank": {"pipelined": rates["1"], "plain": rates["0"]}}
-            _beat("graph form chosen")
+        if (world > 1 and not args.rehearse_on_one_gpu and os.environ.get("FBHIP_DP_ALLREDUCE", "rccl") == "rccl" and
+                getattr(agent, "_rccl_failed", False) and dist.get_backend() != "nccl"):
+            # the library transport was refused (the agent's ranks agreed on it, FBHipAgent._rccl_ready / _rccl_run; the JSON line
+            # says why): every rank is on the torch.distributed schedule now, whose all-reduces want an nccl group -- host-side
+            # gloo collectives are not what this line times
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+            run(0, args.warmup)
         # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
         # untimed launch of each size (these are additional warm-up steps)
         sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
@@ -579,14 +550,12 @@ def main():
             "timed_region_s": dt,
             **({"replicas": replicas} if replicas is not None else {}),
             **({"data_parallel": {
-                # which path actually carried the gradients (a capture that failed once falls back to host-issued launches for good)
+                # which path actually carried the gradients
                 "transport": getattr(agent, "_dp_transport", None) or
-                             ("peer" if args.peer_allreduce else ("gloo-host" if args.rehearse_on_one_gpu else
-                              ("c10d-rccl-host" if (getattr(agent, "_dp_graph_failed", False) or os.environ.get("FBHIP_DP_GRAPH", "1") == "0"
-                                                    or spl == 1) else "c10d-rccl-graph"))),
+                             ("peer" if args.peer_allreduce else ("gloo-host" if args.rehearse_on_one_gpu else "c10d-rccl-host")),
                 "library_rccl_refused": bool(getattr(agent, "_rccl_failed", False)),
-                "graph_form": dp_forms,
-                "schedule_graph_capture_failed": bool(getattr(agent, "_dp_graph_failed", False)),
+                "graph_form": "single-queue (one stream: every step's phases and both all-reduces in program order)",
+                "control_plane": dist.get_backend(),
                 "nccl_env": {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                                      "HSA_ENABLE_IPC_MODE_LEGACY")},
                 "per_rank_steps_per_s_median_repeat": [args.steps / w for w in per_rank_walls[mid]] if per_rank_walls else None,

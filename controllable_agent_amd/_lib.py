@@ -87,6 +87,7 @@ PROTOTYPES = {
     "fbhip_dp_bind_peers": (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
     "fbhip_peer_allreduce": (C.c_int, [_P, _I, _P]),
     "fbhip_update_many_dp": (C.c_int, [_P, _P, _I, _P]),
+    "fbhip_update_many_dp_prepare": (C.c_int, [_P, _P, _I, _P]),
     "fbhip_dp_status": (C.c_int, [_P, C.POINTER(_I), _P]),
     "fbhip_order_legacy_stream_after": (C.c_int, [_P, _P]),
     "fbhip_order_stream_after_legacy": (C.c_int, [_P, _P]),

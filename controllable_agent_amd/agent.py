@@ -263,17 +263,6 @@ class AdamView:
             g["lr"] = src.get("lr", g["lr"])
 
 
-def _quiesce_collectives(device: tp.Any) -> None:
-    """Before a stream capture in a process that holds an RCCL process group: let c10d's watchdog thread retire every finished
-    collective first.  The watchdog polls the end event of each enqueued Work (every ~100 ms) until it has seen it complete; if
-    such a poll lands while a capture is active in this process the HIP runtime answers hipErrorCapturedEvent, the watchdog
-    throws and the process aborts (seen on ROCm 7.0 / torch 2.10 in ~7 % of agent constructions under a live group).  Called before
-    the torch-level capture of the data-parallel schedule; captures happen a handful of times per run: the wait is free."""
-    import time
-    torch.cuda.synchronize(device)
-    time.sleep(float(os.environ.get("FBHIP_QUIESCE_S", "0.35")))
-
-
 class FBHipAgent:
     _config_cls: tp.Any = FBDDPGAgentConfig
     _discrete = False               # DiscreteFBHipAgent: no actor, [B, d, A] ForwardMap heads (discrete_fb.py)
@@ -646,7 +635,6 @@ class FBHipAgent:
         out = np.empty(self.action_dim, np.float32)
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
         self._join_fast_path_stream()
-        self._before_library_capture(("act", bool(eval_mode), nz is None))      # (the graph reads stddev from its staged inputs: one capture for a whole schedule)
         with torch.cuda.stream(self._stream):
             check(_lib.load().fbhip_act(self._ctx, obs.ctypes.data, z.ctypes.data, None if nz is None else nz.ctypes.data,
                                         float(stddev), int(bool(eval_mode)), out.ctypes.data,
@@ -699,7 +687,6 @@ class FBHipAgent:
             raise ValueError(f"compute_z_correl: expected goal[{self.goal_dim}] and z[{self.cfg.z_dim}]")
         out = np.empty(1, np.float32)
         self._join_fast_path_stream()
-        self._before_library_capture(("z_correl",))
         check(_lib.load().fbhip_z_correl(self._ctx, g.ctypes.data, z.ctypes.data, out.ctypes.data,
                                          self._stream.cuda_stream), self._ctx)
         return float(out[0])
@@ -739,24 +726,6 @@ class FBHipAgent:
                                             v["t1"], int(v["fixed_length"])), self._ctx)
         self._replay_view = v           # keeps the tensors alive while bound
         self._replay_token = token
-        self.__dict__.pop("_dp_graphs", None)       # (captured data-parallel schedules hold the old storage pointers, like the library's own graphs)
-        self.__dict__.pop("_warm_captures", None)
-
-    def _before_library_capture(self, key: tp.Any) -> None:
-        """The library captures a graph the first time it sees a (entry point, phase mask, hparams, ...) combination.  In a process
-        that holds an RCCL process group the watchdog is quiesced before such a first call (see _quiesce_collectives); ``key``
-        mirrors the library's cache key closely enough (the cache is dropped with the replay binding; it holds 16 entries, so a
-        long-running host that cycles through more combinations than that can still capture unannounced -- rare, and the schedule
-        captured as one graph, the default under backend nccl, never goes through here)."""
-        import torch.distributed as dist
-        warm = self.__dict__.setdefault("_warm_captures", set())
-        if key in warm:
-            return
-        if len(warm) >= 16:                 # the library's cache holds 16 graphs and evicts the oldest: forget with it (a recapture
-            warm.clear()                    # after an eviction must be announced again)
-        warm.add(key)
-        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl" and not torch.cuda.is_current_stream_capturing():
-            _quiesce_collectives(self._device)
 
     def _run_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         self._on_update_stream(lambda: self._launch_update(hp, inject, use_graph))
@@ -783,68 +752,14 @@ class FBHipAgent:
             else:
                 cur.wait_stream(self._stream)
 
-    def _dp_schedule_graph(self, n_steps: int, hp: HParams, launch: tp.Callable[[int], None]) -> bool:
-        """The host-issued data-parallel schedule of ``n_steps`` updates -- four or five phase launches and two or three RCCL
-        all-reduces per step (distributed.dp_update_many) -- captured ONCE, collectives included, into one graph and replayed:
-        the host then issues one launch per call instead of ~7 per step, like the single-GPU ``fbhip_update_many``.  Same
-        kernels, operands and order as the eager schedule.  Needs a capturable transport: backend nccl (RCCL), or no process
-        group at all (FBHIP_FORCE_PHASE_SPLIT rehearsal); with gloo the collectives run on the host and the eager schedule
-        stays.  ``FBHIP_DP_GRAPH=0`` turns it off; a capture that fails once is not retried.  Returns False when the caller
-        must run the eager schedule."""
+    def _c10d_collectives_in_flight(self) -> bool:
+        """The torch.distributed schedule (distributed.py) under backend nccl: c10d's watchdog thread polls the end events of the
+        collectives it has in flight, and a poll that lands while a stream capture is open in the process makes the runtime answer
+        hipErrorCapturedEvent -- the watchdog throws and the process aborts (round 2: 8 of 14 stress processes).  So that
+        schedule issues its phases as EAGER launches there: no capture, no hazard, no sleep.  It is the fallback transport; the
+        default one (the library's own communicator inside the n-step graph, rccl.py) has no c10d collective in flight at all."""
         import torch.distributed as dist
-        if os.environ.get("FBHIP_DP_GRAPH", "1") == "0" or getattr(self, "_dp_graph_failed", False):
-            return False
-        live = dist.is_available() and dist.is_initialized()
-        if live and dist.get_backend() != "nccl":
-            return False
-        cache = self.__dict__.setdefault("_dp_graphs", {})
-        key = (n_steps, bytes(hp), os.environ.get("FBHIP_DP_SIDE_STREAM", "1"))
-        g = cache.get(key)
-        if g is None:
-            # (the communicator exists by now: _verify_replicas() has issued an eager collective on this device; the collectives
-            # of the schedule, at their sizes, are run once eagerly first -- connection set-up cannot happen inside a capture)
-            cur = torch.cuda.current_stream(self._device)
-            cap = self._stream if cur.cuda_stream == 0 else cur
-            if live and not getattr(self, "_dp_collectives_warm", False):
-                from .distributed import warm_up_collectives
-                with torch.cuda.stream(cap):
-                    warm_up_collectives(self._fb_grads, self._actor_grads, self._early_grad_range())
-                self._dp_collectives_warm = True
-            if live:
-                _quiesce_collectives(self._device)
-            g = torch.cuda.CUDAGraph()
-            try:
-                # (thread_local: c10d's watchdog thread polls its events with cudaEventQuery while we capture; in the default
-                # global mode that call from another thread would invalidate the capture)
-                with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
-                    launch(0)                            # eager phase launches: they become nodes of THIS graph
-            except Exception as e:                       # noqa: BLE001 -- any refusal (transport, driver) falls back for good
-                self._dp_graph_failed = True
-                import warnings
-                warnings.warn(f"data-parallel schedule graph capture failed ({type(e).__name__}: {e}); using host-issued launches")
-                check(_lib.load().fbhip_select_workspace_set(self._ctx, 0), self._ctx)
-                self._cur_set = 0
-                return False
-            if len(cache) >= 4:
-                cache.pop(next(iter(cache)))
-            cache[key] = g
-        self._replay_on_high_priority_stream(g)
-        return True
-
-    def _replay_on_high_priority_stream(self, g: "torch.cuda.CUDAGraph") -> None:
-        """Replay a graph WITH PARALLEL BRANCHES (the schedule forks onto a side stream) from a high-priority stream, ordered behind
-        / ahead of the caller's stream by events.  ROCm 7.0's hipGraphLaunch walks off the end of the exec's parallel-stream list
-        when two of the streams it created at instantiate time share their hardware queue with the LAUNCH stream; those streams
-        are normal-priority, and a high-priority stream's queue comes from another pool (csrc/api.hip::launch_graph,
-        tools/graph_queue_collision.hip)."""
-        hp = self.__dict__.get("_hp_stream")
-        if hp is None:
-            hp = self._hp_stream = torch.cuda.Stream(device=self._device, priority=-1)
-        cur = torch.cuda.current_stream(self._device)
-        hp.wait_stream(cur)
-        with torch.cuda.stream(hp):
-            g.replay()
-        cur.wait_stream(hp)
+        return self._world() > 1 and dist.get_backend() == "nccl"
 
     def _launch_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         from .distributed import dp_update
@@ -866,9 +781,7 @@ class FBHipAgent:
             # injected draws only matter to the SAMPLE phase
             inj = C.byref(inject) if (inject is not None and mask & _lib.PHASE_SAMPLE) else None
             h = hp_fb if (mask & _lib.PHASE_FB_STEP) else hp
-            if use_graph:
-                self._before_library_capture(("update", mask, bytes(h), inj is not None, int(self.__dict__.get("_cur_set", 0))))
-            check(lib.fbhip_update(self._ctx, C.byref(h), inj, mask, int(use_graph), s), self._ctx)
+            check(lib.fbhip_update(self._ctx, C.byref(h), inj, mask, int(use_graph and not self._c10d_collectives_in_flight()), s), self._ctx)
 
         dp_update(run_phases, self._fb_grads, self._actor_grads, self._exchange_embeddings if global_batch else None,
                   early=self._early_grad_range())
@@ -1083,42 +996,71 @@ class FBHipAgent:
         self._chain_token = self._chain_seen = state
         return True
 
+    def _all_ranks_ok(self, ok: bool) -> bool:
+        """A transport decision must be the SAME on every rank (a rank that falls back alone leaves the others waiting inside a
+        collective it never joins): MAX-reduce the local failure flag over the default process group."""
+        import torch.distributed as dist
+        if self._world() < 2:
+            return ok
+        flag = torch.tensor([0.0 if ok else 1.0], device=self._device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return float(flag.item()) == 0.0
+
     def _rccl_ready(self) -> bool:
-        """Bind the library-owned RCCL transport on first use (rccl.py); a refusal (no librccl, communicator set-up failed) is
-        remembered and the c10d schedule of distributed.py takes over -- loudly, and visible in ``_dp_transport``."""
+        """Bind the library-owned RCCL transport on first use (rccl.py).  A refusal on ANY rank (no librccl, communicator set-up
+        failed) demotes EVERY rank to the torch.distributed schedule of distributed.py -- agreed through the default process
+        group, loudly, and visible in ``_dp_transport``."""
         from . import rccl
         if getattr(self, "_rccl_failed", False) or not rccl.usable():
             return False
         if getattr(self, "_rccl_bound", False):
             return True
+        err = None
         try:
             rccl.bind(self)
-            return True
         except Exception as e:                               # noqa: BLE001
-            import warnings
-            self._rccl_failed = True
-            self._dp_transport = f"c10d (library RCCL transport refused: {type(e).__name__}: {e})"
-            warnings.warn(f"fbhip: library-owned RCCL transport unavailable ({type(e).__name__}: {e}); using torch.distributed collectives")
-            return False
+            err = e
+            self._rccl_bound = False
+        if self._all_ranks_ok(err is None):
+            return True
+        import warnings
+        why = f"{type(err).__name__}: {err}" if err is not None else "refused on another rank"
+        self._rccl_failed, self._rccl_bound = True, False
+        self._dp_transport = f"c10d (library RCCL transport refused: {why})"
+        warnings.warn(f"fbhip: library-owned RCCL transport unavailable ({why}); using torch.distributed collectives")
+        return False
 
     def _rccl_run(self, hp, n_total: int) -> bool:
-        """``n_total`` updates through ``fbhip_update_many_dp`` on the library's communicator, 64 per graph.  A failure of the
-        FIRST launch (capture of the collectives refused by this librccl build) demotes the agent to the torch.distributed
-        schedule -- recorded in ``_dp_transport`` -- and returns False with nothing applied; later failures raise."""
+        """``n_total`` updates through ``fbhip_update_many_dp`` on the library's communicator, 64 per graph.  Every graph is first
+        PREPARED (captured and instantiated, not launched: ``fbhip_update_many_dp_prepare``) and the ranks agree that all of them
+        could build theirs before anyone launches -- a capture of the collectives refused on one rank only would otherwise leave
+        the others inside an all-reduce it never joins.  A refusal demotes every rank to the torch.distributed schedule, recorded
+        in ``_dp_transport``, and returns False with nothing applied."""
+        lib = _lib.load()
+        prepared = self.__dict__.setdefault("_rccl_prepared", set())
+        sizes = sorted({min(64, n_total - d) for d in range(0, n_total, 64)})
+        todo = [n for n in sizes if (n, bytes(hp), id(self._replay_token)) not in prepared]
+        if todo:
+            err = None
+            try:
+                for n in todo:
+                    self._on_update_stream(lambda n=n: check(lib.fbhip_update_many_dp_prepare(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
+            except RuntimeError as e:
+                err = e
+            if not self._all_ranks_ok(err is None):
+                import warnings
+                self._rccl_failed = True
+                self._dp_transport = ("c10d (library RCCL transport could not build its graph: "
+                                      f"{err if err is not None else 'refused on another rank'})")
+                warnings.warn(f"fbhip: {self._dp_transport}")
+                return False
+            if len(prepared) > 64:
+                prepared.clear()
+            prepared.update((n, bytes(hp), id(self._replay_token)) for n in todo)
         done = 0
         while done < n_total:
             n = min(64, n_total - done)
-            try:
-                self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many_dp(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
-            except RuntimeError as e:
-                if done or getattr(self, "_rccl_ran", False):
-                    raise
-                import warnings
-                self._rccl_failed = True
-                self._dp_transport = f"c10d (library RCCL transport gave up at its first launch: {e})"
-                warnings.warn(f"fbhip: {self._dp_transport}")
-                return False
-            self._rccl_ran = True
+            self._on_update_stream(lambda n=n: check(lib.fbhip_update_many_dp(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
             done += n
         return True
 
@@ -1193,8 +1135,9 @@ class FBHipAgent:
             hp = self._hparams(step, want, 1.0 / self._world(), float(replay_loader._discount), float(replay_loader._future))
             lib = _lib.load()
 
-            def launch(phase_graphs: int = 1) -> None:
+            def launch() -> None:
                 actor_bits = (_lib.PHASE_ACTOR_GRAD | _lib.PHASE_ACTOR_STEP | _lib.PHASE_ACTOR_FWD) if self._discrete else 0
+                phase_graphs = 0 if self._c10d_collectives_in_flight() else 1
 
                 def phases(mask: int) -> None:           # (on torch's CURRENT stream: dp_update_many switches to its side stream)
                     if mask & ~actor_bits:
@@ -1208,8 +1151,6 @@ class FBHipAgent:
                                lambda which: (self.__dict__.__setitem__("_cur_set", which),
                                               check(lib.fbhip_select_workspace_set(self._ctx, which), self._ctx))[1],
                                self._fb_grads, self._actor_grads, n_steps, early=self._early_grad_range(), side=side)
-            if self._dp_schedule_graph(n_steps, hp, launch):
-                return self._metrics()
             self._on_update_stream(launch)
             return self._metrics()
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
@@ -1219,7 +1160,6 @@ class FBHipAgent:
         while done < n_steps:
             n = min(64, n_steps - done)
 
-            self._before_library_capture(("update_many", n, bytes(hp)))
 
             def launch(n: int = n) -> None:
                 check(_lib.load().fbhip_update_many(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx)
@@ -1417,7 +1357,6 @@ class DiscreteFBHipAgent(FBHipAgent):
         if o.shape[0] != self.obs_dim or z.shape[0] != self.cfg.z_dim:
             raise ValueError(f"act: expected obs[{self.obs_dim}] and z[{self.cfg.z_dim}], got {o.shape} / {z.shape}")
         out = C.c_int32()
-        self._before_library_capture(("discrete_act",))
         self._join_fast_path_stream()
         with torch.cuda.stream(self._stream):
             check(_lib.load().fbhip_discrete_act_host(self._ctx, o.ctypes.data, z.ctypes.data, C.byref(out),
@@ -1833,7 +1772,6 @@ class SFHipAgent(FBHipAgent):
         done = 0
         while done < total:
             n = min(64, total - done)
-            self._before_library_capture(("update_many", n, bytes(hp)))
             self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
             done += n
         return self._metrics()

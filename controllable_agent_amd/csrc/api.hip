@@ -149,8 +149,27 @@ bool capture_open(hipStream_t s) {
     return st != hipStreamCaptureStatusNone;
 }
 
+// Every live context, for "is ANY stream this library has been handed capturing right now?": a caller on the legacy stream gives
+// each agent a stream of its own, so the context being destroyed (garbage-collected inside ANOTHER agent's capture, say) knows
+// nothing about the stream the open capture sits on.
+std::mutex g_live_mu;
+std::vector<fbhip_ctx*> g_live;
+
+bool any_capture_open(hipStream_t also) {
+    if (also != nullptr && capture_open(also)) return true;
+    std::vector<hipStream_t> streams;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (fbhip_ctx* c : g_live)
+            if (c->last_stream != nullptr) streams.push_back(c->last_stream);
+    }
+    for (hipStream_t s : streams)
+        if (capture_open(s)) return true;
+    return false;
+}
+
 void reap(hipStream_t s) {
-    if (capture_open(s)) return;
+    if (any_capture_open(s)) return;
     std::vector<fbhip_ctx*> dead;
     {
         std::lock_guard<std::mutex> lk(g_reap_mu);
@@ -225,6 +244,11 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
     } else {
         memset(c->h_in, 0, act_in_floats(*dims) * sizeof(float));
     }
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.push_back(c);
+    }
+    reap(nullptr);                               // contexts parked by a destroy inside a capture die at the next entry point outside one
     *out = c;
     return FBHIP_OK;
 }
@@ -233,9 +257,14 @@ int fbhip_destroy(fbhip_ctx* ctx) {
     if (!ctx) return FBHIP_OK;
     // The context's launches are asynchronous: its graphs, events and side stream (and, on the caller's side, the buffers it was
     // bound to) may still be in use by work in flight: destroy_now drains the device first.  None of that is legal while a stream
-    // capture is open (a torch-level capture of the data-parallel schedule, say, with a garbage-collected agent's __del__
-    // landing inside it): then the context goes to the reaper and dies at the next entry point outside a capture.
-    if (capture_open(ctx->last_stream)) {
+    // capture is open on ANY stream a live context was last called on (a caller's torch-level capture around agent calls, with a
+    // garbage-collected agent's __del__ landing inside it): then the context goes to the reaper and dies at the next entry point
+    // outside a capture.
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
+    }
+    if (any_capture_open(ctx->last_stream)) {
         std::lock_guard<std::mutex> lk(g_reap_mu);
         g_reap.push_back(ctx);
         return FBHIP_OK;
@@ -464,7 +493,7 @@ int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
 constexpr int DP_GRAPH_BIT = 1 << 20;         // graph-cache key: the data-parallel variant of an n-step graph
 // injs: NULL (device-drawn batches) or n_steps inject structs, one per step (parity runs through the pipelined graph)
 static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, const fbhip_inject* injs, void* stream,
-                            bool dp = false) {
+                            bool dp = false, bool launch = true) {
     RC(need_bound(c, true));
     RC(check_hparams(c, hp));
     if (n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
@@ -473,17 +502,18 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     c->view_set = -1;
     c->chain_live = false;
     reap(s);
-    // (FBHIP_UPDATE_PIPELINE is read at every call: a host can time both forms of a graph and keep the faster one, bench.py does
-    // for the data-parallel graph, whose branched form has a slow mode on ROCm 7.0 that depends on what else lives in the process)
-    // Default: pipelined for the single-rank graph (never seen slow), PLAIN for the data-parallel one unless asked for with "1".
+    // The single-rank graph pipelines consecutive steps on a second capture branch (FBHIP_UPDATE_PIPELINE=0, read at every call:
+    // the plain form, bit-identical to single updates).  The DATA-PARALLEL graph is single-queue by construction: one stream,
+    // every step's phases and the two all-reduces in program order.  Its branched form (round 3) ran at 471 vs 1112
+    // update-steps/s depending on what else lived in the process -- cross-queue dependencies inside a replayed graph are
+    // resolved by this runtime in a way a library cannot control -- for 3-6 % when it ran well.
     const char* pe = getenv("FBHIP_UPDATE_PIPELINE");
-    const bool want = dp ? (pe && pe[0] == '1') : !(pe && pe[0] == '0');
-    const bool pipe = want && n_steps > 1 && !c->d.discrete;                     // (discrete: no actor phase to overlap with)
+    const bool pipe = !dp && !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete;     // (discrete: no actor phase to overlap with)
     for (auto& g : c->graphs) {
         if (g.n_steps == n_steps && g.set == c->cur && g.mask == (FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0)) && g.has_inj == (injs != nullptr) &&
             g.branches == pipe &&
             (!injs || (g.injs.size() == (size_t)n_steps && memcmp(g.injs.data(), injs, sizeof(*injs) * n_steps) == 0)) && memcmp(&g.hp, hp, sizeof(*hp)) == 0)
-            return launch_graph(c, g.exec, s, g.branches);
+            return launch ? launch_graph(c, g.exec, s, g.branches) : (int)FBHIP_OK;
     }
     // Software pipeline over the steps.  Step t's actor phase is ONE dependency chain of ~20 small launches; step t+1's
     // sampling, z mixing, B passes and online ForwardMap pass depend on step t only through its FB optimiser step (new
@@ -514,7 +544,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
         HIPCK(c, launch_peer_allreduce(c->peers, which, which == 0 ? n_fb : n_ac, s));   // peer-access kernels (peer.hip)
         return (int)FBHIP_OK;
     };
-    if (dp && !pipe) {
+    if (dp) {
         for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) {
             rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_GRAD | FBHIP_PHASE_ACTOR_FWD, s);
             if (rc == FBHIP_OK) rc = allreduce(0);
@@ -522,41 +552,6 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
             if (rc == FBHIP_OK && has_actor) rc = allreduce(1);
             if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_STEP, s);
         }
-    } else if (dp) {
-        // the single-rank pipeline below with the optimiser steps cut off their phases and the two all-reduces in the cuts:
-        //   [target chain | FB backward | actor fwd] -> AR(fb) -> FB step -> fork [next head] || [actor grad -> AR(actor) -> actor step] -> join
-        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
-        const int cur0 = c->cur;
-        if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, HEAD, s);
-        for (int i = 0; i < n_steps && rc == FBHIP_OK && he == hipSuccess; ++i) {
-            rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD, s);
-            if (rc == FBHIP_OK) rc = allreduce(0);
-            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_FB_STEP, s);
-            if (rc != FBHIP_OK) break;
-            const bool more = i + 1 < n_steps;
-            if (more) {
-                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
-                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
-                rc = enqueue_actor_v(c, c->side);
-                if (rc != FBHIP_OK) break;
-                if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) break;
-                c->cur ^= 1;
-                rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
-                c->cur ^= 1;
-                if (rc != FBHIP_OK) break;
-                c->v_ready = c->events[128 + i];
-            }
-            rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_GRAD, s);
-            c->v_ready = nullptr;
-            if (rc == FBHIP_OK) rc = allreduce(1);
-            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_STEP, s);
-            if (more) {
-                if ((he = hipEventRecord(c->events[2 * i + 1], c->side)) != hipSuccess) break;
-                if ((he = hipStreamWaitEvent(s, c->events[2 * i + 1], 0)) != hipSuccess) break;
-                c->cur ^= 1;
-            }
-        }
-        c->cur = cur0;
     } else if (!pipe) {
         for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) rc = enqueue_update(c, *hp, injs ? &injs[i] : nullptr, FBHIP_PHASE_ALL, s);
     } else {
@@ -607,7 +602,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     HIPCK(c, e);
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
-    return launch_graph(c, ge.exec, s, ge.branches);
+    return launch ? launch_graph(c, ge.exec, s, ge.branches) : (int)FBHIP_OK;
 }
 
 // One update per call at the rate of the pipelined n-step graph: consecutive calls CHAIN.  A call runs the update whose head
@@ -727,6 +722,12 @@ int fbhip_update_many_dp(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps,
     return update_many_impl(c, hp, n_steps, nullptr, stream, /*dp=*/true);
 }
 
+int fbhip_update_many_dp_prepare(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
+    RC(need_bound(c, true));
+    if (c->peers.world < 2 && c->rccl_comm == nullptr) { c->err = g_err = "fbhip_update_many_dp_prepare: no transport bound (fbhip_rccl_init or fbhip_dp_bind_peers)"; return FBHIP_E_STATE; }
+    return update_many_impl(c, hp, n_steps, nullptr, stream, /*dp=*/true, /*launch=*/false);
+}
+
 int fbhip_rccl_load(const char* library_path) { return rccl_load(library_path); }
 int fbhip_rccl_version(void) { return rccl_version(); }
 int fbhip_rccl_unique_id(void* out_128_bytes) {
@@ -735,6 +736,7 @@ int fbhip_rccl_unique_id(void* out_128_bytes) {
 }
 int fbhip_rccl_init(fbhip_ctx* c, const void* unique_id_128_bytes, int32_t world, int32_t rank, void* stream) {
     RC(need_bound(c, false));
+    HIPCK(c, hipDeviceSynchronize());                                       // (an exec destroyed under an in-flight launch corrupts the runtime)
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);            // the communicator is baked into captured launches
     c->graphs.clear();
     return rccl_init(c, unique_id_128_bytes, world, rank, (hipStream_t)stream);

@@ -110,7 +110,12 @@ int rccl_init(fbhip_ctx* c, const void* id128, int world, int rank, hipStream_t 
     ncclComm_t comm = nullptr;
     RC(check(c, g_api.CommInitRank(&comm, world, id, rank), "ncclCommInitRank"));
     c->rccl_comm = comm; c->rccl_world = world; c->rccl_rank = rank;
-    return rccl_warm_up(c, s);
+    const int rc = rccl_warm_up(c, s);
+    if (rc != FBHIP_OK) {                      // a half-initialised communicator must not outlive the error: the update's all-reduce
+        (void)g_api.CommDestroy(comm);         // lambda prefers rccl_comm over bound peers
+        c->rccl_comm = nullptr; c->rccl_world = 0; c->rccl_rank = 0;
+    }
+    return rc;
 }
 
 void rccl_release(fbhip_ctx* c) {

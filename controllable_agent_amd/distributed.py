@@ -93,40 +93,6 @@ def _reduce_fb(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, ear
         dist.all_reduce(t)
 
 
-def warm_up_collectives(fb_grads: torch.Tensor, actor_grads: torch.Tensor, early: tp.Optional[tp.Tuple[int, int]]) -> None:
-    """The collectives of one mode-A step -- same sizes, same grouping, same stream -- issued once on scratch tensors.  RCCL sets up
-    the connections of an algorithm / protocol the first time a message size selects it (allocations, handle exchange, host
-    synchronisation): none of that may happen while the stream is being captured, so the schedule graph (FBHipAgent.
-    _dp_schedule_graph) is only captured after this has run eagerly -- the warm-up iterations of torch's own CUDA-graph recipe."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return
-    z = lambda n: torch.zeros(int(n), device=fb_grads.device, dtype=fb_grads.dtype)
-    if early is None:
-        dist.all_reduce(z(fb_grads.numel()))
-    else:
-        off, cnt = early
-        dist.all_reduce(z(cnt), async_op=True).wait()
-        rest = [z(n) for n in (off, fb_grads.numel() - off - cnt) if n > 0]
-        global _COALESCE_OK
-        done = False
-        if len(rest) == 2 and _COALESCE_OK and dist.get_backend() == "nccl":
-            try:
-                from torch.distributed.distributed_c10d import _coalescing_manager
-                with _coalescing_manager(device=fb_grads.device):
-                    for t in rest:
-                        dist.all_reduce(t)
-                done = True
-            except (ImportError, AttributeError, TypeError, ValueError, NotImplementedError):
-                _COALESCE_OK = False
-        if not done:
-            for t in rest:
-                dist.all_reduce(t)
-    if actor_grads.numel() > 0:
-        dist.all_reduce(z(actor_grads.numel()), async_op=True).wait()
-    torch.cuda.current_stream(fb_grads.device).synchronize()
-
-
 def dp_update(run_phases: tp.Callable[[int], None], fb_grads: torch.Tensor, actor_grads: torch.Tensor,
               exchange: tp.Optional[tp.Callable[[], None]] = None,
               early: tp.Optional[tp.Tuple[int, int]] = None) -> None:

@@ -38,17 +38,24 @@ def bind(agent: tp.Any) -> None:
     if getattr(agent, "_rccl_bound", False):
         return
     lib = _lib.load()
-    check(lib.fbhip_rccl_load(library_path().encode()))
     live = dist.is_available() and dist.is_initialized()
     world, rank = (dist.get_world_size(), dist.get_rank()) if live else (1, 0)
+    load_rc = lib.fbhip_rccl_load(library_path().encode())       # (local; its outcome travels with the collective below)
+    if not (live and world > 1):
+        check(load_rc)
     if live and world > 1:
         # RCCL wants one device per rank: refuse BEFORE any communicator call when two ranks sit on one device (the one-GPU
         # rehearsals over gloo) -- the caller falls back to the torch.distributed schedule
         import socket
         props = torch.cuda.get_device_properties(agent._device)
-        me = (socket.gethostname(), int(torch.device(agent._device).index or 0), str(getattr(props, "uuid", "")), int(getattr(props, "pci_bus_id", -1)))
+        me = (socket.gethostname(), int(torch.device(agent._device).index or 0), str(getattr(props, "uuid", "")), int(getattr(props, "pci_bus_id", -1)),
+              int(load_rc), rank if load_rc else -1)
         everyone: tp.List[tp.Any] = [None] * world
         dist.all_gather_object(everyone, me)
+        bad = [e[5] for e in everyone if e[4] != 0]
+        if bad:                                  # every rank raises together (a rank that raised alone would leave the others in the gather)
+            raise RuntimeError(f"librccl could not be loaded on rank(s) {bad}: {_lib.last_error() if load_rc else 'see those ranks'}")
+        everyone = [e[:4] for e in everyone]
         if len(set(everyone)) != world:
             raise RuntimeError(f"{world} ranks on {len(set(everyone))} distinct devices: RCCL needs one device per rank")
     uid = C.create_string_buffer(128)

@@ -282,10 +282,12 @@ int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t 
  * fbhip_peer_allreduce enqueues a sum-all-reduce of one bucket (which: 0 FB, 1 actor) as three kernels -- reduce-scatter,
  * all-gather, release, each behind a flag barrier across the ranks -- on ``stream``; capturable; deterministic; every rank must
  * enqueue the same sequence.  fbhip_update_many_dp is fbhip_update_many for a bound rank: n_steps complete data-parallel updates
- * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph; with
- * FBHIP_UPDATE_PIPELINE=1 in the environment (read at every call) also the next step's SAMPLE | FB_FWD_ONLINE on a second branch
- * beside the actor phase and its all-reduce -- opt-in, because that branched form has a 2.3x slow mode on ROCm 7.0 that depends on
- * what else lives in the process: time both once and keep the faster, as bench.py does.  fbhip_dp_status blocks and
+ * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph.  That
+ * graph is SINGLE-QUEUE by construction -- one stream, every step's phases and collectives in program order: its branched form
+ * (the next step's head beside the actor phase, round 3) replayed 2.3x slower or not depending on what else lived in the process
+ * (DESIGN.md section 7).  fbhip_update_many_dp_prepare captures and instantiates the same graph WITHOUT launching it: a host
+ * whose ranks must agree that every one of them could build its graph (a capture of the collectives that fails on one rank would
+ * leave the others waiting inside theirs) calls it first, exchanges the return codes, and only then launches.  fbhip_dp_status blocks and
  * returns the status word (0 ok, 1 = a peer did not arrive within the spin limit: results of that step are garbage, nothing hangs). */
 /* The library's own RCCL transport for the same two buckets (csrc/rccl.hip): fbhip_update_many_dp then enqueues ncclAllReduce on
  * the update's stream INSIDE its capture -- one graph per rank per n_steps updates, collectives included, no process-group object
@@ -302,6 +304,7 @@ int fbhip_dp_bind_peers(fbhip_ctx* ctx, int32_t world, int32_t rank, float* cons
                         int32_t* const* flag_ptrs, int32_t* local_state);
 int fbhip_peer_allreduce(fbhip_ctx* ctx, int32_t which, void* stream);
 int fbhip_update_many_dp(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
+int fbhip_update_many_dp_prepare(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
 int fbhip_dp_status(fbhip_ctx* ctx, int32_t* host_status, void* stream);
 /* For hosts whose caller sits on the LEGACY default stream (torch's default stream, handle 0) while the entry points above ran on
  * `stream`: orders every later legacy-stream command after what has been enqueued on `stream` so far WITHOUT enqueuing anything on

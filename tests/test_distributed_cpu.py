@@ -177,20 +177,20 @@ def test_dp_update_many_call_order_and_workspace_sets():
 
 
 @pytest.mark.parametrize("plan,expect", [
-    ("", [("rccl", "1", "ok")]),
-    ("rccl:1:1:crash", [("rccl", "1", "failed"), ("rccl", "0", "ok")]),
-    ("rccl:*:1:hang,c10d:*:0:crash", [("rccl", "1", "failed"), ("rccl", "0", "failed"), ("c10d", "0", "failed"), ("peer", "0", "ok")]),
+    ("", [("rccl", "ok")]),
+    ("rccl:*:1:crash", [("rccl", "failed"), ("c10d", "ok")]),
+    ("rccl:*:1:hang,c10d:*:0:crash", [("rccl", "failed"), ("c10d", "failed"), ("peer", "ok")]),
 ])
 def test_bench_supervisor_walks_its_plan_of_transports(plan, expect, tmp_path):
     """bench.py::supervise_ranks without a GPU: two supervisors under torch.distributed.run (gloo), the real ranks replaced by
     tests/fake_bench_child.py.  A child that exits non-zero or stops writing its heartbeat fails the attempt on BOTH ranks; the
-    plan goes (first transport, host-side dependency waits) -> (same transport, runtime default) -> the other transports; rank 0
+    plan goes library RCCL -> torch.distributed schedule -> peer kernels; rank 0
     prints exactly one JSON line, the finishing child's, with the attempt history added."""
     import json, subprocess, sys
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "ROC_CPU_WAIT_FOR_SIGNAL",
-                                                            "FBHIP_BENCH_CPU_WAIT_DEFAULTED", "FBHIP_BENCH_CHILD")}
+                                                            "FBHIP_BENCH_CHILD")}
     env.update(FBHIP_BENCH_CHILD_CMD=json.dumps([sys.executable, str(root / "tests" / "fake_bench_child.py")]), FAKE_CHILD_PLAN=plan)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--stall-timeout", "4"]
@@ -200,6 +200,84 @@ def test_bench_supervisor_walks_its_plan_of_transports(plan, expect, tmp_path):
     assert len(lines) == 1, out.stdout
     res = json.loads(lines[0])
     att = res["data_parallel"]["attempts"]
-    got = [(a["transport"], a["ROC_CPU_WAIT_FOR_SIGNAL"], "ok" if all(r["outcome"] == "ok" for r in a["ranks"]) else "failed") for a in att]
+    got = [(a["transport"], "ok" if all(r["outcome"] == "ok" for r in a["ranks"]) else "failed") for a in att]
     assert got == expect, att
     assert res["data_parallel"]["transport"] == expect[-1][0] and "some library banner" not in out.stdout
+
+
+def _worker_agreement(rank, port, out_q):
+    """two ranks, the library transport refused on rank 1 only (bind raises there) / the graph build failing on rank 0 only"""
+    import types
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_DP_ALLREDUCE="rccl")
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from controllable_agent_amd import agent as A, rccl
+
+    def stub():
+        me = types.SimpleNamespace(_device="cpu", _ctx=None, _replay_token=("rb", 0))
+        me._world = lambda: WORLD
+        me._all_ranks_ok = lambda ok: A.FBHipAgent._all_ranks_ok(me, ok)
+        me._on_update_stream = lambda fn: fn()
+        return me
+
+    # (1) bind: a local refusal becomes everybody's decision
+    def bind(agent):
+        if rank == 1:
+            raise RuntimeError("no librccl on this rank")
+        agent._rccl_bound = True
+    rccl.bind = bind
+    a = stub()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ready = A.FBHipAgent._rccl_ready(a)
+    # (2) graph preparation: rank 0's capture fails, rank 1's succeeds -- nobody launches
+    launched = []
+
+    class Lib:
+        @staticmethod
+        def fbhip_update_many_dp_prepare(ctx, hp, n, s):
+            return 3 if rank == 0 else 0
+
+        @staticmethod
+        def fbhip_update_many_dp(ctx, hp, n, s):
+            launched.append(n)
+            return 0
+    A._lib.load = lambda: Lib
+    A._lib.last_error = lambda ctx=None: "capture refused"
+    A.stream_ptr = lambda: 0
+    b = stub()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ran = A.FBHipAgent._rccl_run(b, A.HParams(), 70)
+    out_q.put((rank, ready, bool(getattr(a, "_rccl_failed", False)), a._dp_transport, ran, bool(getattr(b, "_rccl_failed", False)), launched))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_transport_fallback_is_agreed_by_all_ranks():
+    """the demotion from the library's RCCL transport to the torch.distributed schedule must be collective -- a rank
+    that falls back alone leaves the others inside a captured ncclAllReduce it never joins.  FBHipAgent._rccl_ready and _rccl_run
+    MAX-reduce their local failure flag over the default process group: with the bind refused on rank 1 only, and with the graph
+    build failing on rank 0 only, BOTH ranks end on the fallback and nothing was launched."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_agreement, args=(r, _free_port_shared(), q)) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(WORLD))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ready, failed, transport, ran, failed2, launched in got:
+        assert ready is False and failed is True and transport.startswith("c10d (library RCCL transport refused"), got
+        assert ran is False and failed2 is True and launched == [], got
+    assert "no librccl on this rank" in got[1][3] and "another rank" in got[0][3]
+
+
+_SHARED_PORT = []
+
+
+def _free_port_shared():
+    if not _SHARED_PORT:
+        _SHARED_PORT.append(_free_port())
+    return _SHARED_PORT[0]

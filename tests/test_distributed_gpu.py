@@ -331,29 +331,7 @@ def test_bench_launches_its_own_ranks_when_not_under_torchrun():
     assert res["n_gpus"] == 2 and res["replicas"]["identical"] is True and res["replicas"]["ranks"] == 2
     dp = res["data_parallel"]
     assert dp["library_rccl_refused"] is True and "one device per rank" in dp["transport"], dp
-    assert len(dp["per_rank_steps_per_s_median_repeat"]) == 2 and dp["schedule_graph_capture_failed"] is False
-
-
-def test_bench_times_both_forms_of_the_data_parallel_graph_and_keeps_the_faster():
-    """The library's n-step data-parallel graph (fbhip_update_many_dp) pipelined and plain: bench.py times both after the warm-up
-    (the branched form has a slow mode on ROCm 7.0 that depends on the rest of the process), keeps the faster
-    on every rank and reports the choice.  Two ranks on this GPU with the peer kernels inside the graph."""
-    import json, subprocess, sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parents[1]
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "FBHIP_UPDATE_PIPELINE")}
-    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--peer-allreduce", "--no-fallback-transports",
-           "--steps", "64", "--warmup", "8", "--repeats", "1", "--episodes", "400", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root), env=env)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    form = res["data_parallel"]["graph_form"]
-    cal = form["calibration_steps_per_s_slowest_rank"]
-    assert cal["pipelined"] > 0 and cal["plain"] > 0
-    assert form["pipelined_kept"] == (cal["pipelined"] >= 1.03 * cal["plain"])
-    assert res["replicas"]["identical"] is True and res["data_parallel"]["transport"] == "peer"
-    assert res["value"] > 0.5 * 2 * max(cal.values())            # (two ranks) the timed region ran in the kept form
+    assert len(dp["per_rank_steps_per_s_median_repeat"]) == 2
 
 
 @pytest.mark.parametrize("how", ["crash", "hang"])
@@ -367,7 +345,6 @@ def test_bench_supervisor_moves_to_the_next_transport_when_a_rank_is_lost(how):
     root = Path(__file__).resolve().parents[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", FBHIP_BENCH_FAIL_TRANSPORT=f"rccl:{how}")
-    env.pop("ROC_CPU_WAIT_FOR_SIGNAL", None); env.pop("FBHIP_BENCH_CPU_WAIT_DEFAULTED", None)
     cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "32", "--warmup", "8",
            "--repeats", "1", "--episodes", "400", "--no-cpu-baseline", "--stall-timeout", "30"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=str(root), env=env)
@@ -376,12 +353,11 @@ def test_bench_supervisor_moves_to_the_next_transport_when_a_rank_is_lost(how):
     assert len(lines) == 1, lines                                    # ONE JSON line, from the attempt that finished
     res = json.loads(lines[0])
     att = res["data_parallel"]["attempts"]
-    # (the first transport gets a second attempt without the host-side dependency waits bench.py runs with by default)
-    assert [(a["transport"], a["ROC_CPU_WAIT_FOR_SIGNAL"]) for a in att] == [("rccl", "1"), ("rccl", "0"), ("c10d", "0")], att
+    assert [a["transport"] for a in att] == ["rccl", "c10d"], att
     first = [r["outcome"] for r in att[0]["ranks"]]
     # (rank 0's child either is killed while blocked in its first collective or notices the closed connection by itself)
     assert first[1].startswith("failed (" + ("exit code 7" if how == "crash" else "no progress")) and first[0].startswith("failed"), att
-    assert [r["outcome"] for r in att[2]["ranks"]] == ["ok", "ok"] and all(r["outcome"].startswith("failed") for r in att[1]["ranks"])
+    assert [r["outcome"] for r in att[1]["ranks"]] == ["ok", "ok"]
     assert res["n_gpus"] == 2 and res["replicas"]["identical"] is True and res["value"] > 0
 
 
@@ -466,70 +442,84 @@ def test_peer_allreduce_inside_the_graph_equals_the_host_schedule():
 
 
 # ------------------------------------------------------------------------------ the schedule captured into one graph (round 2)
-def _run_schedule(monkeypatch, graph: bool):
+def _run_c10d_schedule(monkeypatch=None):
     from controllable_agent_amd.replay import DeviceReplayBuffer
     cfg, nets, storage, lengths = T._setup()
-    agent = H.make_hip_agent(cfg, nets)
-    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
-    monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
-    monkeypatch.setenv("FBHIP_DP_ALLREDUCE", "c10d")      # (the host-issued / torch-level schedule is what this test is about)
-    monkeypatch.setenv("FBHIP_DP_GRAPH", "1" if graph else "0")
-    for call in range(3):                                   # the second and third call replay the cached graph
-        agent.update_many(rb, 6 * call, 6)
-    # another buffer object (other device pointers): the captured schedule holds the old ones and must be re-captured
-    rb2 = DeviceReplayBuffer.from_arrays({k: v[::-1].copy() for k, v in storage.items()}, lengths[::-1].copy(), cfg.discount, device="cuda")
-    agent.update_many(rb2, 18, 6)
-    torch.cuda.synchronize()
-    assert bool(getattr(agent, "_dp_graphs", {})) == graph and not getattr(agent, "_dp_graph_failed", False)
-    return H.get_agent_state(agent), agent.step_counts()
-
-
-def test_dp_schedule_captured_as_one_graph_equals_the_host_issued_schedule(monkeypatch):
-    """FBHipAgent._dp_schedule_graph: the multi-step data-parallel schedule (phase launches on two streams + the places of its
-    all-reduces) captured once into a torch CUDAGraph and replayed, against the same schedule issued launch by launch: same
-    kernels, operands and order, so bit-identical state, device RNG streams included."""
-    s1, c1 = _run_schedule(monkeypatch, graph=False)
-    s2, c2 = _run_schedule(monkeypatch, graph=True)
-    assert c1 == c2 == (24, 24)
-    for k in s1:
-        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
-
-
-def _worker_nccl_world1(graph, port, out_q):
-    import torch.distributed as dist
-    from controllable_agent_amd.replay import DeviceReplayBuffer
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_GRAPH="1" if graph else "0", FBHIP_DP_ALLREDUCE="c10d")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-    cfg, nets, storage, lengths = T._setup()
-    torch.manual_seed(4321)            # the agent's device RNG key comes from torch's seed, which differs between fresh processes
     agent = H.make_hip_agent(cfg, nets)
     rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
     for call in range(3):
         agent.update_many(rb, 6 * call, 6)
+    agent.update(rb, 18)
+    # another buffer object (other device pointers): whatever was captured holds the old ones and must not be replayed
+    rb2 = DeviceReplayBuffer.from_arrays({k: v[::-1].copy() for k, v in storage.items()}, lengths[::-1].copy(), cfg.discount, device="cuda")
+    agent.update_many(rb2, 19, 5)
     torch.cuda.synchronize()
-    out_q.put((graph, H.get_agent_state(agent), agent.step_counts(), bool(getattr(agent, "_dp_graphs", {})),
-               bool(getattr(agent, "_dp_graph_failed", False))))
+    return H.get_agent_state(agent), agent.step_counts()
+
+
+def _worker_c10d_nccl_world1(port, out_q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_ALLREDUCE="c10d")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    torch.manual_seed(4321)            # the agent's device RNG key comes from torch's seed, which differs between fresh processes
+    state, counts = _run_c10d_schedule()
+    out_q.put((state, counts))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_dp_schedule_graph_captures_rccl_collectives_with_one_rank():
-    """The same comparison with a live RCCL process group (backend nccl, world 1 -- all this box can hold): the all-reduce
-    calls of the schedule are captured into the graph with the kernels around them and replayed; state equals the host-issued
-    schedule bit for bit."""
+def test_c10d_schedule_beside_a_live_nccl_group_equals_the_schedule_without_one(monkeypatch):
+    """The torch.distributed schedule (FBHIP_DP_ALLREDUCE=c10d: the fallback transport) with a live RCCL process group (backend
+    nccl, world 1 -- all this box can hold): its phases are issued as eager launches there (no stream capture beside c10d's
+    watchdog thread, FBHipAgent._c10d_collectives_in_flight) with the real all-reduce calls in between; without a process
+    group the same schedule replays one library graph per phase.  Same kernels, operands and order: bit-identical state, and the
+    process with the group exits cleanly."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    got = {}
-    for graph in (False, True):                               # one after the other: one RCCL rank per device at a time
-        q = ctx.Queue()
-        p = ctx.Process(target=_worker_nccl_world1, args=(graph, T._free_port(), q))
-        p.start()
-        g, state, counts, captured, failed = q.get(timeout=300)
-        p.join(timeout=120)
-        assert p.exitcode == 0 and counts == (18, 18) and captured == graph and not failed
-        got[g] = state
-    for k in got[False]:
-        np.testing.assert_array_equal(got[False][k], got[True][k], err_msg=k)
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_c10d_nccl_world1, args=(T._free_port(), q))
+    p.start()
+    state_nccl, counts_nccl = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")
+    monkeypatch.setenv("FBHIP_DP_ALLREDUCE", "c10d")
+    torch.manual_seed(4321)
+    state, counts = _run_c10d_schedule()
+    assert counts == counts_nccl == (24, 24)
+    for k in state:
+        np.testing.assert_array_equal(state[k], state_nccl[k], err_msg=k)
+
+
+def _dot_out_degrees(path):
+    import collections, re as _re
+    deg = collections.Counter()
+    for m in _re.finditer(r'"?([\w.]+)"?\s*->\s*"?([\w.]+)"?', open(path).read()):
+        deg[m.group(1)] += 1
+    return deg
+
+
+def test_the_data_parallel_graph_is_single_queue_by_construction(monkeypatch, tmp_path):
+    """fbhip_update_many_dp's n-step graph is a CHAIN: no node has two successors -- one stream, every step's phases and both
+    all-reduces in program order, hence no cross-queue dependency for the runtime to resolve (the branched form of round 3
+    replayed 2.3x slower or not depending on what else lived in the process).  The single-rank graph of
+    fbhip_update_many keeps its second branch (the next step's head beside the actor phase)."""
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    cfg, nets, storage, lengths = T._setup()
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+    monkeypatch.setenv("FBHIP_GRAPH_DOT", str(tmp_path / "single.dot"))
+    a1 = H.make_hip_agent(cfg, nets)
+    a1.update_many(rb, 0, 4)
+    torch.cuda.synchronize()
+    assert max(_dot_out_degrees(tmp_path / "single.dot").values()) >= 2          # (sanity of the reader: this one forks)
+    monkeypatch.setenv("FBHIP_GRAPH_DOT", str(tmp_path / "dp.dot"))
+    monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")                            # the library RCCL transport at world 1
+    a2 = H.make_hip_agent(cfg, nets)
+    a2.update_many(rb, 0, 4)
+    torch.cuda.synchronize()
+    assert "rccl-library" in a2._dp_transport
+    deg = _dot_out_degrees(tmp_path / "dp.dot")
+    assert deg and max(deg.values()) == 1, deg.most_common(3)
 
 
 # ------------------------------------------------------------------------------------------ the SF sibling, data parallel
@@ -657,40 +647,6 @@ def test_sf_agent_peer_allreduce_inside_the_graph_equals_the_host_schedule(name)
             np.testing.assert_allclose(res["peer"][0][1][k], v, rtol=0, atol=2e-5, err_msg=k)
 
 
-def test_captures_beside_the_rccl_watchdog_do_not_abort_the_process():
-    """c10d's RCCL watchdog thread polls the end event of every finished collective; a poll that lands while a stream capture is active in
-    the process makes the HIP runtime answer hipErrorCapturedEvent, the watchdog throws and the process aborts (SIGABRT) -- seen in ~7 %
-    of agent constructions under a live group before FBHipAgent quiesced the watchdog ahead of its capture of the schedule
-    (_quiesce_collectives): six agents built, warmed and replayed in one process with a world-1 RCCL group must now exit cleanly."""
-    import subprocess
-    import sys
-    code = ("import os, sys, time, torch, torch.distributed as dist\n"
-            "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda:0'))\n"
-            "from tests import helpers as H, test_distributed_cpu as T\n"
-            "from controllable_agent_amd.replay import DeviceReplayBuffer\n"
-            "agents = []\n"
-            "for i in range(6):\n"
-            "    cfg, nets, storage, lengths = T._setup()\n"
-            "    a = H.make_hip_agent(cfg, nets)\n"
-            "    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device='cuda')\n"
-            "    a.update_many(rb, 0, 6)\n"
-            "    assert a._dp_graphs and not getattr(a, '_dp_graph_failed', False)\n"
-            "    agents.append((a, rb))\n"
-            "t = torch.ones(4, device='cuda')\n"
-            "for it in range(10):\n"
-            "    for a, rb in agents:\n"
-            "        a.update_many(rb, 6, 6)\n"
-            "    dist.all_reduce(t)\n"
-            "    time.sleep(0.01)\n"
-            "torch.cuda.synchronize(); dist.barrier(); print('clean exit', flush=True)\n"
-            "os._exit(0)\n")
-    env = dict(os.environ, FBHIP_FORCE_PHASE_SPLIT="1", FBHIP_DP_ALLREDUCE="c10d", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(T._free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "clean exit" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-
-
-# ------------------------------------------------------------------ the library's own RCCL transport (round 3, csrc/rccl.hip)
 def _run_library_rccl(monkeypatch, transport, sf=False):
     from controllable_agent_amd.replay import DeviceReplayBuffer
     if transport is None:

@@ -1186,3 +1186,38 @@ def test_time_varying_stddev_schedule_runs_eagerly_and_matches_the_oracle():
             assert m[k] == pytest.approx(om[k], rel=2e-5, abs=2e-6), (s, k)
     n_graphs_before = len(agent.update(rb, 6))          # device draws through update(): must not raise, metrics come back
     assert n_graphs_before > 0
+
+
+def test_an_agent_dropped_inside_another_agents_capture_is_destroyed_later():
+    """fbhip_destroy may not synchronise the device or destroy graph execs while a stream capture is open -- on ANY
+    stream, not just the dying context's own (a caller on the legacy stream gives every agent its own stream).  Here agent b is
+    garbage-collected in the middle of a torch-level capture around agent a's eager update: the capture must survive, replay,
+    and b's context must be gone after the next entry point outside a capture."""
+    import gc
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64)
+    rng = np.random.default_rng(29)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a, b = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(2))
+    b.update(rb, 0)                                    # from the legacy stream: b ran on a stream of its own
+    a._use_graph = False                               # eager launches: capturable by the caller
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        a.update(rb, 0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+        a.update(rb, 1)
+        del b
+        gc.collect()                                   # b.__del__ -> fbhip_destroy inside a's capture: must be deferred
+        a.update(rb, 2)
+    with torch.cuda.stream(st):
+        g.replay()
+        g.replay()
+    torch.cuda.synchronize()
+    assert a.step_counts() == (5, 5)                   # 1 eager + 2 replays of 2 captured updates
+    c = H.make_hip_agent(cfg, nets, metrics=False)     # (fbhip_create reaps what was parked)
+    c.update(rb, 0)
+    torch.cuda.synchronize()
