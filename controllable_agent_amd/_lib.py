@@ -65,6 +65,7 @@ PROTOTYPES = {
     "fbhip_abi_version": (C.c_int, []),
     "fbhip_last_error": (C.c_char_p, [_P]),
     "fbhip_device_ok": (C.c_int, []),
+    "fbhip_branched_graphs": (C.c_int, [C.POINTER(C.c_char_p)]),
     "fbhip_net_numel": (_L, [C.POINTER(Dims), C.c_int]),
     "fbhip_net_param_count": (_L, [C.POINTER(Dims), C.c_int]),
     "fbhip_layout_count": (C.c_int, [C.POINTER(Dims), C.c_int]),

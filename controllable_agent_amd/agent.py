@@ -475,7 +475,10 @@ class FBHipAgent:
                                                               "_actor_params", "_actor_m", "_actor_v")}
         # (the device RNG counters travel too: a resumed run continues its Philox streams instead of replaying the batches,
         # z draws and exploration noise of the first steps of training)
-        return dict(cfg=dataclasses.asdict(self.cfg), flat=flat, fb_steps=fb, actor_steps=ac, seed=self._seed,
+        # (the flat buffers are the library's PHYSICAL layout -- padded leading dimensions, 32-float matrix alignment --, which has
+        # changed between rounds: the pickle says which one it holds)
+        return dict(layout_abi=int(_lib.load().fbhip_abi_version()), flat_numel={k: int(v.numel()) for k, v in flat.items()},
+                    cfg=dataclasses.asdict(self.cfg), flat=flat, fb_steps=fb, actor_steps=ac, seed=self._seed,
                     rng_counts=self.rng_counts(), solved_meta=self.solved_meta, training=self.training, goal_dim=self.goal_dim)
 
     def __setstate__(self, st: tp.Dict[str, tp.Any]) -> None:
@@ -489,6 +492,12 @@ class FBHipAgent:
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)
         for k, v in st["flat"].items():
+            if getattr(self, k).numel() != v.numel():
+                raise RuntimeError(
+                    f"FBHipAgent pickle holds {k} with {v.numel()} floats in the flat layout of library ABI {st.get('layout_abi', '< 17')}; "
+                    f"this library (ABI {_lib.load().fbhip_abi_version()}) lays the same nets out in {getattr(self, k).numel()}.  The flat "
+                    "buffers are the physical, padded layout and are not portable across library versions: re-export the agent "
+                    "with the version that wrote it through state_dict() of its nets / optimisers (name-based) and load_nets().")
             getattr(self, k).copy_(v)
         self.set_step_counts(st["fb_steps"], st["actor_steps"])
         if "rng_counts" in st:                   # (pickles of round 1 do not have it: those restart their streams)
@@ -981,7 +990,7 @@ class FBHipAgent:
         ahead), 1071-1108 without that setting and only from a high-priority caller stream (513 otherwise); loops that can hand
         over several steps should call ``update_many`` (1136-1160)."""
         if (self._discrete or self._world() > 1 or os.environ.get("FBHIP_UPDATE_CHAIN", "0") != "1" or
-                os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"):
+                os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or not _lib.load().fbhip_branched_graphs(None)):
             self._drop_prefetch()
             return False
         state = self._chain_state(rb, hp)

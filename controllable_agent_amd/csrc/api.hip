@@ -45,6 +45,39 @@ hipError_t launch_stream(hipStream_t* out) {
     return hipSuccess;
 }
 
+// May this process replay graphs with parallel branches at all?  The guard above rests on two properties of the HIP runtime that no
+// public API exposes (hardware-queue identity is runtime-internal: tools/stream_queue_probe.hip reads it through object offsets of
+// one libamdhip64 build, which a product must not do): (1) a high-priority stream's hardware queue never coincides with the
+// queues of the normal-priority streams an exec creates -- verified for the HIP 7.0 runtime torch 2.10 bundles
+// (tools/graph_queue_collision.hip: 3000 of 3000 trials) --, or (2) the runtime does not have the unbounded skip loop at all --
+// verified for HIP 7.2.  So: branched graphs on HIP 7.0.x (with the guard) and on HIP >= 7.2, provided the device has a
+// high-priority class; on any other runtime the library REFUSES them and builds its n-step graphs single-queue (the plain form:
+// same kernels and results, 3-6 % slower) instead of silently running the configuration that crashed.  FBHIP_BRANCHED_GRAPHS=1
+// forces them on an unlisted runtime, =0 refuses them everywhere (read at every call: tests force the fallback with it).
+const char* branched_graphs_verdict(bool* ok) {
+    static const char* cached = nullptr;
+    static bool cached_ok = false;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int v = 0, lo = 0, hi = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); cached = "refused: hipRuntimeGetVersion failed"; return; }
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hi >= lo) { (void)hipGetLastError(); cached = "refused: the device has no high-priority stream class"; return; }
+        const int major = v / 10000000, minor = (v / 100000) % 100;
+        if (major == 7 && minor == 0) { cached_ok = true; cached = "allowed: HIP 7.0 runtime, launched from a high-priority stream (verified workaround)"; }
+        else if (major > 7 || (major == 7 && minor >= 2)) { cached_ok = true; cached = "allowed: HIP >= 7.2 runtime (no unbounded skip in hip::Graph::UpdateStreams)"; }
+        else cached = "refused: unverified HIP runtime version for graphs with parallel branches (FBHIP_BRANCHED_GRAPHS=1 forces them)";
+    });
+    const char* e = getenv("FBHIP_BRANCHED_GRAPHS");
+    if (e != nullptr && e[0] == '0') { *ok = false; return "refused: FBHIP_BRANCHED_GRAPHS=0"; }
+    if (e != nullptr && e[0] == '1' && !cached_ok) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) { *ok = true; return "allowed: forced by FBHIP_BRANCHED_GRAPHS=1"; }
+        (void)hipGetLastError();
+    }
+    *ok = cached_ok;
+    return cached;
+}
+
 // after_own: the previous command of this context on the launch stream was its own previous branched graph and the caller's
 // stream holds nothing newer that this graph depends on (fbhip_update_chained with a valid head): the launch stream's order is
 // the dependency, and the hop from the caller's stream is skipped -- with it every launch would wait (on the HOST, under
@@ -186,6 +219,13 @@ extern "C" {
 int fbhip_abi_version(void) { return FBHIP_ABI_VERSION; }
 
 const char* fbhip_last_error(const fbhip_ctx* ctx) { return (ctx && !ctx->err.empty()) ? ctx->err.c_str() : g_err.c_str(); }
+
+int fbhip_branched_graphs(const char** why) {
+    bool ok = false;
+    const char* w = branched_graphs_verdict(&ok);
+    if (why != nullptr) *why = w;
+    return ok ? 1 : 0;
+}
 
 int fbhip_device_ok(void) {
     int dev = 0;
@@ -508,7 +548,9 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     // update-steps/s depending on what else lived in the process -- cross-queue dependencies inside a replayed graph are
     // resolved by this runtime in a way a library cannot control -- for 3-6 % when it ran well.
     const char* pe = getenv("FBHIP_UPDATE_PIPELINE");
-    const bool pipe = !dp && !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete;     // (discrete: no actor phase to overlap with)
+    bool branched_ok = false;
+    (void)branched_graphs_verdict(&branched_ok);
+    const bool pipe = !dp && branched_ok && !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete;     // (discrete: no actor phase to overlap with)
     for (auto& g : c->graphs) {
         if (g.n_steps == n_steps && g.set == c->cur && g.mask == (FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0)) && g.has_inj == (injs != nullptr) &&
             g.branches == pipe &&
@@ -619,6 +661,11 @@ int fbhip_update_chained(fbhip_ctx* c, const fbhip_hparams* hp, int32_t have_hea
     RC(need_bound(c, true));
     RC(check_hparams(c, hp));
     if (c->d.discrete) { c->err = g_err = "fbhip_update_chained: DiscreteFBAgent has no actor phase to prefetch beside (use fbhip_update)"; return FBHIP_E_STATE; }
+    {
+        bool branched_ok = false;
+        const char* why = branched_graphs_verdict(&branched_ok);
+        if (!branched_ok) { c->err = g_err = std::string("fbhip_update_chained: graphs with parallel branches are ") + why + " (use fbhip_update)"; return FBHIP_E_STATE; }
+    }
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
     reap(s);

@@ -198,6 +198,13 @@ typedef struct fbhip_ctx fbhip_ctx;
 
 /* ---- library / layout --------------------------------------------------------------------------- */
 int fbhip_abi_version(void);
+/* 1 when this process may replay graphs with parallel branches (the pipelined n-step graph of fbhip_update_many, fbhip_update_chained),
+ * 0 when the library builds its graphs single-queue instead; *why (nullable) receives a static one-line reason.  ROCm 7.0's
+ * hipGraphLaunch can walk off an exec's parallel-stream list; the library launches branched graphs from a high-priority stream,
+ * which is verified to avoid it on HIP 7.0 and unnecessary on HIP >= 7.2 -- on any other runtime version, or without a
+ * high-priority stream class, branched graphs are refused (same kernels and results, 3-6 % slower) rather than run unguarded.
+ * FBHIP_BRANCHED_GRAPHS=1 forces them, =0 refuses them (read at every call). */
+int fbhip_branched_graphs(const char** why);
 const char* fbhip_last_error(const fbhip_ctx* ctx);            /* ctx may be NULL: last global error   */
 int fbhip_device_ok(void);                                     /* 0 iff a gfx950 device is current     */
 

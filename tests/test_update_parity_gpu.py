@@ -1221,3 +1221,50 @@ def test_an_agent_dropped_inside_another_agents_capture_is_destroyed_later():
     c = H.make_hip_agent(cfg, nets, metrics=False)     # (fbhip_create reaps what was parked)
     c.update(rb, 0)
     torch.cuda.synchronize()
+
+
+def test_branched_graphs_are_refused_on_an_unverified_runtime_and_the_plain_form_takes_over(monkeypatch, tmp_path):
+    """the guard against ROCm 7.0's hipGraphLaunch crash (branched graphs launched from a high-priority stream)
+    rests on runtime properties no API exposes, so the library only replays branched graphs on runtime versions it was verified
+    on and builds single-queue graphs otherwise.  FBHIP_BRANCHED_GRAPHS=0 forces that fallback here: the 4-step graph is a chain,
+    the chained update() refuses, and the state equals the branched run's bit for bit (small dims)."""
+    import ctypes as C
+    import re
+    from controllable_agent_amd import _lib
+    why = C.c_char_p()
+    assert _lib.load().fbhip_branched_graphs(C.byref(why)) == 1 and why.value.decode().startswith("allowed: HIP"), why.value
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64)
+    rng = np.random.default_rng(31)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+
+    def degrees(path):
+        out = {}
+        for m in re.finditer(r'"?([\w.]+)"?\s*->\s*"?([\w.]+)"?', open(path).read()):
+            out[m.group(1)] = out.get(m.group(1), 0) + 1
+        return out
+
+    a = H.make_hip_agent(cfg, nets, metrics=False)
+    monkeypatch.setenv("FBHIP_GRAPH_DOT", str(tmp_path / "branched.dot"))
+    a.update_many(rb, 0, 4)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("FBHIP_BRANCHED_GRAPHS", "0")
+    assert _lib.load().fbhip_branched_graphs(C.byref(why)) == 0 and "FBHIP_BRANCHED_GRAPHS=0" in why.value.decode()
+    b = H.make_hip_agent(cfg, nets, metrics=False)
+    monkeypatch.setenv("FBHIP_GRAPH_DOT", str(tmp_path / "plain.dot"))
+    b.update_many(rb, 0, 4)
+    monkeypatch.setenv("FBHIP_UPDATE_CHAIN", "1")
+    for s in range(4, 8):
+        b.update(rb, s)                                  # (chaining asked for, branched graphs refused: plain updates)
+    assert b.__dict__.get("_chain_token") is None
+    monkeypatch.delenv("FBHIP_BRANCHED_GRAPHS")
+    monkeypatch.delenv("FBHIP_GRAPH_DOT")
+    for s in range(4, 8):
+        a.update(rb, s)
+    torch.cuda.synchronize()
+    assert max(degrees(tmp_path / "branched.dot").values()) >= 2 and max(degrees(tmp_path / "plain.dot").values()) == 1
+    sa, sb = H.get_agent_state(a), H.get_agent_state(b)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
