@@ -146,13 +146,50 @@ def cpu_baseline(seed=1, budget_s=12.0, max_steps=120):
 
 
 def measured_traffic(workload="walker"):
-    """HBM-side bytes per update from the last committed PMC passes (profiles/traffic.json, traffic_quadruped.json, written from
-    tools/pmc_summary.py output); bench.py itself cannot collect PMC counters.  None when no pass is on file."""
+    """(bytes per update, where the figure comes from) of the last COMMITTED PMC passes (profiles/traffic*.json, made by
+    tools/profile_round.sh + tools/pmc_summary.py); (None, None) when no pass is on file.  ``--pmc`` measures it live instead."""
     f = Path(__file__).resolve().parent / "profiles" / ("traffic.json" if workload == "walker" else f"traffic_{workload}.json")
     try:
-        return float(json.loads(f.read_text())["hbm_bytes_per_update"])
+        d = json.loads(f.read_text())
+        return float(d["hbm_bytes_per_update"]), f"profiles/{f.name} (round {d.get('round', '?')}: an earlier build's PMC passes, not this run)"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+
+
+def live_traffic(workload):
+    """--pmc: HBM-side bytes per update of THIS build, collected now: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- the TCC block
+    cannot hold both, and counters are collected with --kernel-trace only, MI355X_MICROARCH.md "rocprofv3 PMC slots") of a short
+    run of this script, summed over every kernel between two sampler launches (tools/pmc_summary.py's step definition), FETCH_SIZE
+    doubled per the guide's gfx950 note (wide coalesced reads are tallied at half).  Returns (bytes, description) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "--pmc: rocprofv3 not on PATH"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fbhip_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+               str(Path(__file__).resolve()), "--steps", "64", "--warmup", "32", "--repeats", "1", "--no-cpu-baseline",
+               "--no-single-update-probe", "--workload", workload]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=900)
+        rows = []
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                rows += [x for x in csv.DictReader(fh) if x["Counter_Name"] == counter]
+        shutil.rmtree(d, ignore_errors=True)
+        if r.returncode != 0 or not rows:
+            return None, f"--pmc: the {counter} pass failed (exit code {r.returncode}, {len(rows)} rows)"
+        rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+        draws = [int(x["Dispatch_Id"]) for x in rows if "draw_kernel" in x["Kernel_Name"]]
+        skip = 12 if len(draws) > 14 else 0
+        lo, hi, n = draws[skip], draws[-1], len(draws) - skip - 1
+        out[counter] = sum(float(x["Counter_Value"]) for x in rows if lo <= int(x["Dispatch_Id"]) < hi) * 1024.0 / max(1, n)
+    total = 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]
+    return total, (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build ({out['FETCH_SIZE'] / 1e6:.1f} MB raw x 2 + "
+                   f"{out['WRITE_SIZE'] / 1e6:.1f} MB per update)")
 
 
 def dominant_kernel_probe(stream_iters=50):
@@ -332,6 +369,8 @@ def main():
                     help="with --global-batch on ONE rank: replicate the rank's embeddings N times in the exchange step, so the "
                          "pairwise kernel runs its share of an N x batch global loss (cost rehearsal of mode B at world N; the "
                          "loss itself is not meaningful)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="collect roofline.traffic live: two extra rocprofv3 --pmc passes of a short run of this script (N = 1)")
     ap.add_argument("--workload", choices=("walker", "quadruped"), default="walker",
                     help="walker = configs[1], THE bench line; quadruped = configs[2] (no cpu_baseline / kernel probe)")
     args = ap.parse_args()
@@ -522,6 +561,10 @@ def main():
         gflop = algorithmic_gflop_per_update(W["obs_dim"], W["action_dim"], W["goal_dim"], W["z_dim"], W["hidden_dim"],
                                              W["feature_dim"], W["backward_hidden_dim"], W["batch_size"])
         achieved = gflop * steps_per_s / 1e3              # TFLOP/s per GPU
+        traffic, traffic_src = measured_traffic(args.workload)
+        if args.pmc and world == 1:
+            live, src = live_traffic(args.workload)
+            traffic, traffic_src = (live, src) if live is not None else (traffic, f"{src}; fell back to {traffic_src}")
         out = {
             "metric": f"FB update-steps/sec (batch={W['batch_size']}, z_dim={W['z_dim']})", "value": value, "unit": "update-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -564,7 +607,7 @@ def main():
             **({"flags": [f"timed region of {dt * 1e3:.1f} ms < 0.5 s: --steps {args.steps} is too short for a stable rate "
                           f"(host launch jitter); the {len(walls)} repeats bound it, prefer --steps >= 1000"]} if dt < 0.5 else {}),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(args.workload),
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "what": f"whole update step: {gflop:.2f} algorithmic GFLOP/update (SURVEY.md section 8d) x "
                                  "measured updates/s, per GPU, vs the exact-fp32 MFMA peak"},
         }

@@ -149,12 +149,20 @@ __device__ __forceinline__ void load_frag(float (&f)[KS], const float* __restric
 
 // VEC: 16-byte aligned panels with ld % 4 == 0 (the product's workspace).  A separate instantiation, not a runtime
 // branch: merging the two loaders' registers makes hipcc wait for the loads right after issuing them.
-template <int KS, bool VEC>
-__global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
+// NG wave groups of four waves each walk ALTERNATE J tiles of the workgroup's chunk concurrently (own LDS panels, own
+// accumulators; group g > 0 hands its sums to group 0 through LDS at the end, in group order: deterministic).  With one group a
+// SIMD holds a single wave whose every LDS round trip, barrier and staging phase leaves the matrix pipe idle (35 us for 14.5 us
+// of MFMA issue at B = 1024, d = 50); two groups put two independent chains on every SIMD.  NG = 2 needs 2 x 6 panels in LDS:
+// d <= 64.
+template <int KS, bool VEC, int NG>
+__global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     constexpr int NT = (2 * KS + 31) / 32;
     constexpr int W = (2 * KS > 32 * NT ? 2 * KS : 32 * NT);
     constexpr int LD = W + 1;                       // odd => conflict-free for both access patterns
-    extern __shared__ float lds[];                  // 6 x [32][LD] + gamma[32]
+    constexpr int GRP = 6 * 32 * LD + 32;           // floats per group: 6 x [32][LD] + gamma[32]
+    extern __shared__ float lds_all[];              // NG x GRP
+    const int grp = NG > 1 ? (int)(threadIdx.x >> 8) : 0;
+    float* lds = lds_all + grp * GRP;
     float* sBm = lds;
     float* stB = sBm + 32 * LD;
     float* sF1 = stB + 32 * LD;
@@ -163,7 +171,7 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
     float* stF2 = stF1 + 32 * LD;
     float* sGam = stF2 + 32 * LD;
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int I0 = blockIdx.x * 32 + p.i_off, chunk = blockIdx.y;
     const int B = p.B, d = p.d;
     const float n_off = (float)B * (float)(B - 1);
@@ -201,14 +209,19 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
 
     const int jt_begin = chunk * p.jpc;
     const int jt_end = min(jt_begin + p.jpc, p.njt);
+    // group g takes the tiles jt_begin + g, jt_begin + g + NG, ...; every group runs the same number of iterations (the
+    // barriers are workgroup-wide), a group without a tile in the last one only keeps them company
 #pragma unroll 1
-    for (int jt = jt_begin; jt < jt_end; ++jt) {
-        const int J0 = jt * 32;
-        if (jt == jt_begin) stg.load(srcs, p.ld, J0, B, d, tid);           // later tiles were prefetched below
+    for (int jt0 = jt_begin; jt0 < jt_end; jt0 += NG) {
+        const int jt = jt0 + grp;
+        const bool live = jt < jt_end;
+        const int J0 = min(jt, p.njt - 1) * 32;
+        if (jt0 == jt_begin) stg.load(srcs, p.ld, J0, B, d, tid);          // later tiles were prefetched below
         stg.store(lds, tid);
         if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
         __syncthreads();
-        if (jt + 1 < jt_end) stg.load(srcs, p.ld, J0 + 32, B, d, tid);      // next J tile in flight under the MFMAs
+        if (jt0 + NG < jt_end) stg.load(srcs, p.ld, min(jt + NG, p.njt - 1) * 32, B, d, tid);      // next J tile in flight under the MFMAs
+        if (live) {
 
         if (wid < 2) {
             // tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
@@ -279,7 +292,36 @@ __global__ void __launch_bounds__(256) pairwise_kernel(const PwArgs p) {
                 contract_rows<NT, LD>(out, C, sBm, l31, h);
             }
         }
+        }
         __syncthreads();
+    }
+
+    if constexpr (NG > 1) {
+        // groups 1 .. NG-1 hand their accumulators and scalar sums to group 0 (their own panels are free now), added in group order
+        constexpr int PER = (16 * NT + 6) * 256;     // floats a group parks: [16 NT + 6][256 threads]
+        static_assert(PER <= GRP, "the hand-off must fit a group's panels");
+        if (grp > 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) lds[(nt * 16 + reg) * 256 + tid] = out[nt][reg];
+            float* sc = lds + 16 * NT * 256;
+            sc[0 * 256 + tid] = s_sq; sc[1 * 256 + tid] = s_diag; sc[2 * 256 + tid] = s_all;
+            sc[3 * 256 + tid] = s_tall; sc[4 * 256 + tid] = s_csq; sc[5 * 256 + tid] = s_cdiag;
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < NG; ++g2) {
+            const float* src = lds_all + g2 * GRP;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) out[nt][reg] += src[(nt * 16 + reg) * 256 + tid];
+            const float* sc = src + 16 * NT * 256;
+            s_sq += sc[0 * 256 + tid]; s_diag += sc[1 * 256 + tid]; s_all += sc[2 * 256 + tid];
+            s_tall += sc[3 * 256 + tid]; s_csq += sc[4 * 256 + tid]; s_cdiag += sc[5 * 256 + tid];
+        }
     }
 
     // ---- write partial outputs ---------------------------------------------------------------------------
@@ -385,7 +427,7 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
     }
 }
 
-struct PwPlan { int ks, nt, ld, dp, njt, nchunks, jpc, Bp, nI; size_t lds_bytes; };
+struct PwPlan { int ks, nt, ld, dp, njt, nchunks, jpc, Bp, nI, ng; size_t lds_bytes; };
 
 // B: rows of the panels (the J extent); rows: the I extent this launch owns (== B for the square single-device loss)
 PwPlan make_plan(int B, int d, int rows = -1) {
@@ -408,7 +450,9 @@ PwPlan make_plan(int B, int d, int rows = -1) {
     if (nchunks < 1) nchunks = 1;
     pl.jpc = (pl.njt + nchunks - 1) / nchunks;
     pl.nchunks = (pl.njt + pl.jpc - 1) / pl.jpc;
-    pl.lds_bytes = (size_t)(6 * 32 * pl.ld + 32) * sizeof(float);
+    // two wave groups per workgroup when their panels fit the CU's LDS next to nothing else and a chunk has tiles for both
+    pl.ng = (pl.ld <= 65 && pl.jpc >= 2) ? 2 : 1;
+    pl.lds_bytes = (size_t)pl.ng * (6 * 32 * pl.ld + 32) * sizeof(float);
     return pl;
 }
 
@@ -425,23 +469,26 @@ size_t pairwise_scratch_floats(int B, int d) {
 hipError_t pairwise_prepare(int B, int d) {
     const PwPlan pl = make_plan(B, d);
     if (pl.ks < 0) return hipErrorInvalidValue;
-    if (pl.lds_bytes <= 48 * 1024) return hipSuccess;
-    const int bytes = (int)pl.lds_bytes;
-#define PW_ATTR(KS)                                                                                                   \
-    {                                                                                                                 \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS, true>),                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                        \
+    // (both group counts: the block mode of the global-batch schedule plans its own chunking)
+    const int bytes1 = (int)((size_t)(6 * 32 * pl.ld + 32) * sizeof(float)), bytes2 = 2 * bytes1;
+#define PW_ATTR1(KS, VEC, NG_, BYTES)                                                                                  \
+    if ((BYTES) > 48 * 1024) {                                                                                        \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS, VEC, NG_>),              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES));                      \
         if (e != hipSuccess) return e;                                                                                \
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS, false>),                        \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);                                \
     }
+#define PW_ATTR(KS) { PW_ATTR1(KS, true, 1, bytes1) PW_ATTR1(KS, false, 1, bytes1) if (pl.ld <= 65) { PW_ATTR1(KS, true, 2, bytes2) PW_ATTR1(KS, false, 2, bytes2) } return hipSuccess; }
     switch (pl.ks) {
+        case 4: PW_ATTR(4);
+        case 8: PW_ATTR(8);
+        case 16: PW_ATTR(16);
         case 25: PW_ATTR(25);
         case 32: PW_ATTR(32);
         case 50: PW_ATTR(50);
         case 64: PW_ATTR(64);
         default: return hipSuccess;
     }
+#undef PW_ATTR1
 #undef PW_ATTR
 }
 
@@ -472,11 +519,12 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     a.scal = scratch + (size_t)pl.nchunks * PW_SLOTS * pl.Bp * pl.dp;
     a.Bp = pl.Bp;
     a.i_off = row_off;
-    dim3 grid(pl.nI, pl.nchunks), block(256);
+    dim3 grid(pl.nI, pl.nchunks), block(256 * pl.ng);
     hipError_t e = hipSuccess;
-#define PW_LAUNCH(KS)                                                                                                 \
-    if (a.vec) hipLaunchKernelGGL((pairwise_kernel<KS, true>), grid, block, pl.lds_bytes, s, a);                       \
-    else hipLaunchKernelGGL((pairwise_kernel<KS, false>), grid, block, pl.lds_bytes, s, a)
+#define PW_LAUNCH1(KS, NG_)                                                                                            \
+    if (a.vec) hipLaunchKernelGGL((pairwise_kernel<KS, true, NG_>), grid, block, pl.lds_bytes, s, a);                  \
+    else hipLaunchKernelGGL((pairwise_kernel<KS, false, NG_>), grid, block, pl.lds_bytes, s, a)
+#define PW_LAUNCH(KS) if (pl.ng == 2) { PW_LAUNCH1(KS, 2); } else { PW_LAUNCH1(KS, 1); }
     switch (pl.ks) {
         case 4: PW_LAUNCH(4); break;
         case 8: PW_LAUNCH(8); break;
@@ -487,6 +535,7 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
         case 64: PW_LAUNCH(64); break;
         default: return hipErrorInvalidValue;
     }
+#undef PW_LAUNCH1
 #undef PW_LAUNCH
     if (e != hipSuccess) return e;
     e = hipGetLastError();
