@@ -14,10 +14,19 @@
 // registers across the J loop:
 //   role 1 (waves 0,1; I plays s, J plays t):  T = B[J] . F_i[I]^T  = M_i[s,t]^T  -> dF_i[I] += G_i^T-contract . B[J]
 //   role 2 (waves 2,3; I plays t, J plays s):  P = F_i[J] . B[I]^T  = M_i[s,t]    -> dB[I]  += G_i  -contract . F_i[J]
-//   cov    (waves 2/3 alternate):              C = B[J] . B[I]^T (symmetric)      -> dB[I]  += 2 c_o H-contract . B[J]
+//   cov    (waves 2 and 3, half each):         C = B[J] . B[I]^T (symmetric)      -> dB[I]  += 2 c_o H-contract . B[J]
 // I-side operands live in registers as MFMA B-fragments for the whole kernel; J-side tiles are staged in LDS and
 // shared by the four waves.  Partial results over J-chunks go to a scratch buffer and are folded in a fixed
 // order by pairwise_reduce_kernel (deterministic; no atomics).  Scalar sums are wave-shuffle reduced.
+//
+// Every wave computes ONE of the two target products of its role (wave i the one with target F_i) and the two waves of a role
+// swap them through LDS (min(t1, t2) is what both need); the covariance tile is computed half of K by wave 2 and half by wave 3,
+// swapped the same way, and each contracts one half of its rows -- every wave has the same work in every iteration (the
+// workgroup-wide barrier per J tile makes the slowest wave of an ITERATION the pace, not the average).
+//
+// LDS panels are [32][LD], LD = W + 4: a lane reads its row's k values four at a time (ds_read_b128; row stride = 4 banks, so
+// 8 lanes cover the 32 banks: conflict-free) and a quad feeds four MFMAs -- the k order of the contraction is permuted
+// (lane half h takes k = 8 q + 4 h + m), identically on the register operand.
 #include "common.h"
 #include "fbhip.h"
 
@@ -50,102 +59,172 @@ struct PwArgs {
                                // of the B-row panels; outputs / partials are indexed by the LOCAL row (I - i_off)
 };
 
-// Stage the same 32-row block of SIX matrices (zero filled outside [0,B) x [0,d)) into LDS [32][LD] each.  load() only
-// ISSUES the global loads (branch-free on the aligned path: out-of-range quads read a clamped, valid address), the
-// zero-fill masks are applied in store() -- so the loads of J tile t+1 stay in flight under the MFMAs of tile t and the
-// s_waitcnt lands right before the LDS writes of the next iteration, not behind every load.
+// Three panels of one 32-row block (zero filled outside [0,B) x [0,d)): global -> registers -> LDS [32][LD], one float4 quad per
+// "op" (op = 3 i + m: quad i of this thread, matrix m).  load() only ISSUES the global load (branch-free on the aligned path:
+// out-of-range quads read a clamped, valid address), the zero-fill masks are applied in store().  The kernel never stages a whole
+// tile at once: the ops are handed out one or two at a time to the k-steps of a product (tile_mm's ``side``), so the loads, the
+// selects and the LDS writes issue in the shadow of the matrix pipe (one wave per SIMD: nothing else would hide them).
 template <int LD, bool VEC>
-struct Stage6 {
-    static constexpr int W = LD - 1;                 // multiple of 32
-    static constexpr int QPT = 32 * (W / 4) / 256;   // float4 quads per thread per matrix (2 for W=64, 4 for W=128)
-    float4 v[6][QPT > 0 ? QPT : 1];
-    int row0_, B_, d_, ld_;
+struct Stage3 {
+    static constexpr int W = LD - 4;                 // multiple of 32
+    static constexpr int QPT = 32 * (W / 4) / 256;   // float4 quads per thread per matrix (1, 2, 4 for W = 32, 64, 128)
+    static constexpr int NOPS = 3 * QPT;
+    float4 v[NOPS];
 
-    __device__ __forceinline__ void load(const float* const (&X)[6], int ld, int row0, int B, int d, int tid) {
-        row0_ = row0; B_ = B; d_ = d; ld_ = ld;
+    __device__ __forceinline__ void load(int op, const float* __restrict__ X, int ld, int row0, int B, int d, int tid) {
+        const int q = tid + (op / 3) * 256;
+        const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
         if constexpr (VEC) {
-#pragma unroll
-            for (int i = 0; i < QPT; ++i) {
-                const int q = tid + i * 256;
-                const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
-                const bool ok = (row0 + r < B) && (n0 < ld);                 // ld % 4 == 0: the quad stays inside its row
-                const size_t off = ok ? (size_t)(row0 + r) * ld + n0 : 0;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) v[m][i] = *reinterpret_cast<const float4*>(X[m] + off);
-            }
+            const bool ok = (row0 + r < B) && (n0 < ld);                     // ld % 4 == 0: the quad stays inside its row
+            const size_t off = ok ? (size_t)(row0 + r) * ld + n0 : 0;
+            v[op] = *reinterpret_cast<const float4*>(X + off);
         } else {
-#pragma unroll
-            for (int m = 0; m < 6; ++m)
-#pragma unroll
-                for (int i = 0; i < QPT; ++i) {
-                    const int q = tid + i * 256;
-                    const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
-                    const int gr = row0 + r;
-                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (gr < B && n0 < d) {
-                        const float* ptr = X[m] + (size_t)gr * ld + n0;
-                        x.x = ptr[0];
-                        if (n0 + 1 < d) x.y = ptr[1];
-                        if (n0 + 2 < d) x.z = ptr[2];
-                        if (n0 + 3 < d) x.w = ptr[3];
-                    }
-                    v[m][i] = x;
-                }
+            const int gr = row0 + r;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < B && n0 < d) {
+                const float* ptr = X + (size_t)gr * ld + n0;
+                x.x = ptr[0];
+                if (n0 + 1 < d) x.y = ptr[1];
+                if (n0 + 2 < d) x.z = ptr[2];
+                if (n0 + 3 < d) x.w = ptr[3];
+            }
+            v[op] = x;
         }
     }
-    __device__ __forceinline__ void store(float* __restrict__ lds_base, int tid) {
-        // pin the first use of the loaded registers HERE: without it hipcc hoists the zero-fill selects up to the loads
-        // (before the MFMAs of the previous tile) and waits for every load right where it was issued
-#pragma unroll
-        for (int m = 0; m < 6; ++m)
-#pragma unroll
-            for (int i = 0; i < QPT; ++i)
-                asm volatile("" : "+v"(v[m][i].x), "+v"(v[m][i].y), "+v"(v[m][i].z), "+v"(v[m][i].w));
-#pragma unroll
-        for (int i = 0; i < QPT; ++i) {
-            const int q = tid + i * 256;
-            const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
-            const bool row_ok = row0_ + r < B_;
-            const bool k0 = row_ok && n0 < d_, k1 = row_ok && n0 + 1 < d_, k2 = row_ok && n0 + 2 < d_, k3 = row_ok && n0 + 3 < d_;
-#pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                float* dst = lds_base + m * 32 * LD + r * LD + n0;
-                dst[0] = k0 ? v[m][i].x : 0.f; dst[1] = k1 ? v[m][i].y : 0.f;
-                dst[2] = k2 ? v[m][i].z : 0.f; dst[3] = k3 ? v[m][i].w : 0.f;
-            }
-        }
+    __device__ __forceinline__ void store(int op, float* __restrict__ panel, int row0, int B, int d, int tid) const {
+        const int q = tid + (op / 3) * 256;
+        const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+        const bool row_ok = row0 + r < B;
+        const bool k0 = row_ok && n0 < d, k1 = row_ok && n0 + 1 < d, k2 = row_ok && n0 + 2 < d, k3 = row_ok && n0 + 3 < d;
+        *reinterpret_cast<float4*>(panel + r * LD + n0) =
+            make_float4(k0 ? v[op].x : 0.f, k1 ? v[op].y : 0.f, k2 ? v[op].z : 0.f, k3 ? v[op].w : 0.f);
     }
 };
 
-// acc(32x32) = rowsJ (LDS, [32][LD]) . fragI^T over KS k-steps
-template <int KS, int LD>
-__device__ __forceinline__ floatx16 tile_mm(const float* __restrict__ sJ, const float (&fragI)[KS], int l31, int h) {
+struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+
+// acc(32x32) = rowsJ (LDS, [32][LD]) . fragI^T over KS k-steps, in the permuted k order of load_frag: step 4 q + m contracts
+// k = 8 q + 4 h + m (one ds_read_b128 per four steps), the KS % 4 tail steps k = 8 (KS / 4) + 2 i + h.
+// PART 0: all of K; 1: the first half of the quads; 2: the other quads and the tail (1 + 2 = 0 as sets).
+// side(s, n): the caller's slot s of n for unrelated work (staging ops).
+// A wave issues in order and a dependent (or merely next) MFMA waits ~60 cycles for the matrix pipe: whatever is to hide behind
+// the MFMAs has to sit BETWEEN two of them, a few instructions per gap, and hipcc has to be kept from moving it (it otherwise emits
+// read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, and collects the VALU work in front): one scheduling fence per MFMA, the read of quad
+// q + 1 and one side slot right behind each MFMA of quad q.
+template <int KS, int LD, int PART, class Side>
+__device__ __forceinline__ floatx16 tile_mm(const float* __restrict__ sJ, const float (&fragI)[KS], int l31, int h, Side&& side) {
+    constexpr int KQ = KS / 4, KT = KS % 4;
+    constexpr int Q0 = PART == 2 ? KQ / 2 : 0, Q1 = PART == 1 ? KQ / 2 : KQ;
+    constexpr bool TAIL = PART != 1 && KT > 0;
+    constexpr int NS = 4 * (Q1 - Q0);
     floatx16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float* a = sJ + l31 * LD + h;
+    const float* a = sJ + l31 * LD + 4 * h;
+    const float* t = sJ + l31 * LD + 8 * KQ + h;
+    float4 v[2];
+    float tl[KT > 0 ? KT : 1];
+    if constexpr (Q1 > Q0) v[0] = *reinterpret_cast<const float4*>(a + 8 * Q0);
+    else if constexpr (TAIL) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * ks], fragI[ks], acc, 0, 0, 0);
+        for (int i = 0; i < KT; ++i) tl[i] = t[2 * i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+        const int c = (q - Q0) & 1;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].x, fragI[4 * q + 0], acc, 0, 0, 0);
+        if (q + 1 < Q1) v[c ^ 1] = *reinterpret_cast<const float4*>(a + 8 * (q + 1));
+        else if constexpr (TAIL) {
+#pragma unroll
+            for (int i = 0; i < KT; ++i) tl[i] = t[2 * i];
+        }
+        side(4 * (q - Q0) + 0, NS);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].y, fragI[4 * q + 1], acc, 0, 0, 0);
+        side(4 * (q - Q0) + 1, NS);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].z, fragI[4 * q + 2], acc, 0, 0, 0);
+        side(4 * (q - Q0) + 2, NS);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].w, fragI[4 * q + 3], acc, 0, 0, 0);
+        side(4 * (q - Q0) + 3, NS);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int i = 0; i < KT; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tl[i], fragI[4 * KQ + i], acc, 0, 0, 0);
+    }
     return acc;
 }
 
-// out[nt] += G^T-contract . X[J]:  out[c][n] += sum_r G[r][c] * X[r][n]
-template <int NT, int LD>
-__device__ __forceinline__ void contract_rows(floatx16 (&out)[NT], const floatx16& G, const float* __restrict__ sX,
-                                              int l31, int h) {
+// out[nt] += G^T-contract . X[J]:  out[c][n] += sum_r G[r][c] * X[r][n] over the accumulator registers [R0, R0 + NR) of the tile
+// (two tile rows each).  gen(reg) PRODUCES G[reg] -- the loss epilogue of that register (mask, diagonal, scalar sums) -- and is
+// called one register group (4 MFMAs) ahead, behind an MFMA of the running group, like the LDS reads of the next group's operands.
+template <int NT, int LD, int R0, int NR, class Gen>
+__device__ __forceinline__ void contract_gen(floatx16 (&out)[NT], Gen&& gen, const float* __restrict__ sX, int l31, int h) {
+    static_assert(NT == 1 || NT == 2 || NT == 4, "column tiles");
+    constexpr int GS = 4 / NT;                                        // registers per group: 4 MFMAs a group
+    static_assert(NR % GS == 0, "register groups");
+    constexpr int NGR = NR / GS;
+    float a[2][GS], b[2][4];
+    auto load = [&](int g, float (&dst)[4]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const float* b = sX + acc_row(reg, h) * LD + l31;
+        for (int i = 0; i < GS; ++i) {
+            const float* src = sX + acc_row(R0 + g * GS + i, h) * LD + l31;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) out[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G[reg], b[32 * nt], out[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) dst[i * NT + nt] = src[32 * nt];
+        }
+    };
+    load(0, b[0]);
+#pragma unroll
+    for (int i = 0; i < GS; ++i) a[0][i] = gen(R0 + i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NGR; ++g) {
+        const int cur = g & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int idx = 0; idx < 4; ++idx) {
+            out[idx % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][idx / NT], b[cur][idx], out[idx % NT], 0, 0, 0);
+            if (g + 1 < NGR) {
+                if (idx == 0) load(g + 1, b[nxt]);
+                if (idx < GS) a[nxt][idx] = gen(R0 + (g + 1) * GS + idx);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
 template <int KS, int LD>
 __device__ __forceinline__ void load_frag(float (&f)[KS], const float* __restrict__ sI, int l31, int h) {
+    constexpr int KQ = KS / 4, KT = KS % 4;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) f[ks] = sI[l31 * LD + 2 * ks + h];
+    for (int q = 0; q < KQ; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(sI + l31 * LD + 8 * q + 4 * h);
+        f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < KT; ++i) f[4 * KQ + i] = sI[l31 * LD + 8 * KQ + 2 * i + h];
 }
+
+// a wave parks / fetches one 32x32 accumulator: [4][64 lanes] float4, lanes adjacent
+__device__ __forceinline__ void put16(float* __restrict__ dst, const floatx16& v, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float4*>(dst + (i * 64 + lane) * 4) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+__device__ __forceinline__ floatx16 get16(const float* __restrict__ src, int lane) {
+    floatx16 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 u = *reinterpret_cast<const float4*>(src + (i * 64 + lane) * 4);
+        v[4 * i] = u.x; v[4 * i + 1] = u.y; v[4 * i + 2] = u.z; v[4 * i + 3] = u.w;
+    }
+    return v;
+}
+
+constexpr int PW_XCH = 6 * 1024;                                           // floats: t x 2 waves, (u, C-half) x 2 waves
+__host__ __device__ constexpr int pw_group_floats(int LD) { return 6 * 32 * LD + 32 + PW_XCH; }
 
 // VEC: 16-byte aligned panels with ld % 4 == 0 (the product's workspace).  A separate instantiation, not a runtime
 // branch: merging the two loaders' registers makes hipcc wait for the loads right after issuing them.
@@ -158,9 +237,9 @@ template <int KS, bool VEC, int NG>
 __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     constexpr int NT = (2 * KS + 31) / 32;
     constexpr int W = (2 * KS > 32 * NT ? 2 * KS : 32 * NT);
-    constexpr int LD = W + 1;                       // odd => conflict-free for both access patterns
-    constexpr int GRP = 6 * 32 * LD + 32;           // floats per group: 6 x [32][LD] + gamma[32]
-    extern __shared__ float lds_all[];              // NG x GRP
+    constexpr int LD = W + 4;                       // row stride = 4 banks: conflict-free for the b128 row reads and the b32 column reads
+    constexpr int GRP = pw_group_floats(LD);        // floats per group: 6 x [32][LD] + gamma[32] + the swap area
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];        // NG x GRP
     const int grp = NG > 1 ? (int)(threadIdx.x >> 8) : 0;
     float* lds = lds_all + grp * GRP;
     float* sBm = lds;
@@ -170,6 +249,7 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     float* stF1 = sF2 + 32 * LD;
     float* stF2 = stF1 + 32 * LD;
     float* sGam = stF2 + 32 * LD;
+    float* xch = sGam + 32;                         // [0, 2048): t of waves 0, 1; [2048, 6144): (u, C half) of waves 2, 3
 
     const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
     const int I0 = blockIdx.x * 32 + p.i_off, chunk = blockIdx.y;
@@ -177,27 +257,37 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     const float n_off = (float)B * (float)(B - 1);
     const float inv_noff = 1.0f / n_off, inv_b = 1.0f / (float)B;
 
-    // LDS order of the six panels: Bm, tB, F1, F2, tF1, tF2
-    const float* const srcs[6] = {p.Bm, p.tB, p.F1, p.F2, p.tF1, p.tF2};
-    Stage6<LD, VEC> stg;
+    // the panels in two halves: T = {tB, tF1, tF2} (the target products), M = {Bm, F1, F2} (the M_i / covariance products and
+    // every contraction)
+    const float* const srcT[3] = {p.tB, p.tF1, p.tF2};
+    const float* const srcM[3] = {p.Bm, p.F1, p.F2};
+    float* const dstT[3] = {stB, stF1, stF2};
+    float* const dstM[3] = {sBm, sF1, sF2};
+    using Stage = Stage3<LD, VEC>;
+    constexpr int NOPS = Stage::NOPS;
+    Stage R;
 
     // ---- I-side fragments (registers, whole kernel) ----------------------------------------------------
-    stg.load(srcs, p.ld, I0, B, d, tid);
-    stg.store(lds, tid);
+#pragma unroll
+    for (int op = 0; op < NOPS; ++op) R.load(op, srcT[op % 3], p.ld, I0, B, d, tid);
+#pragma unroll
+    for (int op = 0; op < NOPS; ++op) R.store(op, dstT[op % 3], I0, B, d, tid);
+#pragma unroll
+    for (int op = 0; op < NOPS; ++op) R.load(op, srcM[op % 3], p.ld, I0, B, d, tid);
+#pragma unroll
+    for (int op = 0; op < NOPS; ++op) R.store(op, dstM[op % 3], I0, B, d, tid);
     __syncthreads();
-    float fa[KS], fb[KS], fc[KS];
-    if (wid < 2) {                   // role 1: F_i[I], tF1[I], tF2[I]
+    float fa[KS], fb[KS];
+    if (wid < 2) {                   // role 1, wave i: F_i[I], tF_i[I]
         load_frag<KS, LD>(fa, wid == 0 ? sF1 : sF2, l31, h);
-        load_frag<KS, LD>(fb, stF1, l31, h);
-        load_frag<KS, LD>(fc, stF2, l31, h);
+        load_frag<KS, LD>(fb, wid == 0 ? stF1 : stF2, l31, h);
     } else {                         // role 2: B[I], tB[I]
         load_frag<KS, LD>(fa, sBm, l31, h);
         load_frag<KS, LD>(fb, stB, l31, h);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fc[ks] = 0.f;
     }
     const int gcol = I0 + l31;                              // batch index of this lane's tile column
     const float gam_col = (gcol < B) ? p.discount[gcol] : 0.f;
+    const float cdiag = (gcol < B) ? -inv_b : 0.f;          // d loss / d M on the diagonal
     __syncthreads();
 
     floatx16 out[NT];
@@ -209,6 +299,24 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
 
     const int jt_begin = chunk * p.jpc;
     const int jt_end = min(jt_begin + p.jpc, p.njt);
+    const float* sFi = (wid & 1) ? sF2 : sF1;               // role 2, wave 2 + i: F_i[J]
+    float* my_x = wid < 2 ? xch + wid * 1024 : xch + 2048 + (wid - 2) * 2048;
+    const float* their_x = wid < 2 ? xch + (wid ^ 1) * 1024 : xch + 2048 + ((wid - 2) ^ 1) * 2048;
+
+    // Staging schedule.  The T panels of a tile are read by the target products only (phase A), the M panels by everything
+    // after them (phase B): while phase A runs the M slots are free, while phase B runs the T slots are.  ONE register set R:
+    //   phase A(tile): R (= M panels of this tile) -> M slots;  R <- T panels of the next tile
+    //   phase B(tile): R (= T panels of the next tile) -> T slots;  R <- M panels of the next tile
+    // each op riding on one k-step of a product.  Before the loop: T panels of the first tile in LDS, its M panels in R.
+    {
+        const int J0 = min(jt_begin + grp, p.njt - 1) * 32;
+#pragma unroll
+        for (int op = 0; op < NOPS; ++op) R.load(op, srcT[op % 3], p.ld, J0, B, d, tid);
+#pragma unroll
+        for (int op = 0; op < NOPS; ++op) R.store(op, dstT[op % 3], J0, B, d, tid);
+#pragma unroll
+        for (int op = 0; op < NOPS; ++op) R.load(op, srcM[op % 3], p.ld, J0, B, d, tid);
+    }
     // group g takes the tiles jt_begin + g, jt_begin + g + NG, ...; every group runs the same number of iterations (the
     // barriers are workgroup-wide), a group without a tile in the last one only keeps them company
 #pragma unroll 1
@@ -216,85 +324,116 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
         const int jt = jt0 + grp;
         const bool live = jt < jt_end;
         const int J0 = min(jt, p.njt - 1) * 32;
-        if (jt0 == jt_begin) stg.load(srcs, p.ld, J0, B, d, tid);          // later tiles were prefetched below
-        stg.store(lds, tid);
-        if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
-        __syncthreads();
-        if (jt0 + NG < jt_end) stg.load(srcs, p.ld, min(jt + NG, p.njt - 1) * 32, B, d, tid);      // next J tile in flight under the MFMAs
+        const int Jn = min(jt + NG, p.njt - 1) * 32;        // (past the chunk's last tile: a clamped, unused tile)
+        __syncthreads();                                    // T(jt) in LDS; the M slots and gamma are free
+        floatx16 tm, G;
         if (live) {
-
-        if (wid < 2) {
-            // tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
-            floatx16 tm = tile_mm<KS, LD>(stB, fb, l31, h);
+            // ---- phase A: the wave's own target product (parked for the other wave of the role)
+            if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
+            auto side = [&](int sidx, int n) __attribute__((always_inline)) {      // slot sidx of n: its share of 2 NOPS sub-ops
+#pragma unroll
+                for (int u = sidx * (2 * NOPS) / n; u < (sidx + 1) * (2 * NOPS) / n; ++u) {
+                    if (u & 1) R.load(u >> 1, srcT[(u >> 1) % 3], p.ld, Jn, B, d, tid);
+                    else R.store(u >> 1, dstM[(u >> 1) % 3], J0, B, d, tid);
+                }
+            };
+            // role 1: tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
+            // role 2: tile rows = s (J), cols = t (I):  P[r][c] = M_i[s = J0+r][t = I0+c]
+            tm = tile_mm<KS, LD, 0>(wid < 2 ? stB : ((wid & 1) ? stF2 : stF1), fb, l31, h, side);
+            put16(my_x, tm, lane);
+        }
+        __syncthreads();                                    // M(jt), gamma and the target products in LDS; the T slots are free
+        if (live) {
+            // ---- phase B: (role 2) this wave's half of K of the covariance tile C[r][c] = B[J0+r] . B[I0+c]
+            // (fb_ddpg.py:344-348), parked; then the M_i tile
+            if (wid >= 2) {
+                floatx16 Ch;
+                if (wid == 2) Ch = tile_mm<KS, LD, 1>(sBm, fa, l31, h, NoSide());
+                else Ch = tile_mm<KS, LD, 2>(sBm, fa, l31, h, NoSide());
+                put16(my_x + 1024, Ch, lane);
+            }
+            auto side = [&](int sidx, int n) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = sidx * (2 * NOPS) / n; u < (sidx + 1) * (2 * NOPS) / n; ++u) {
+                    if (u & 1) R.load(u >> 1, srcM[(u >> 1) % 3], p.ld, Jn, B, d, tid);
+                    else R.store(u >> 1, dstT[(u >> 1) % 3], Jn, B, d, tid);
+                }
+            };
+            G = tile_mm<KS, LD, 0>(wid < 2 ? sBm : sFi, fa, l31, h, side);
+        }
+        __syncthreads();                                    // covariance halves in LDS
+        if (live) {
+            const bool dtile = (J0 == I0);                  // the only tile of this column block that holds diagonal entries
             {
-                const floatx16 t2 = tile_mm<KS, LD>(stB, fc, l31, h);
+                const floatx16 t2 = get16(their_x, lane);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) tm[i] = fminf(tm[i], t2[i]);
             }
-            floatx16 G = tile_mm<KS, LD>(sBm, fa, l31, h);
+            if (wid < 2) {
+                auto gen = [&](int reg) __attribute__((always_inline)) -> float {
+                    const float m = G[reg], t = tm[reg];
+                    const float dlt = m - gam_col * t;                 // discount is indexed by s = column here
+                    const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
+                    s_all += m;
+                    s_tall += t;
+                    s_diag += diag ? m : 0.f;
+                    s_sq += diag ? 0.f : dlt * dlt;
+                    return diag ? cdiag : dlt * inv_noff;
+                };
+                contract_gen<NT, LD, 0, 16>(out, gen, sBm, l31, h);            // dF_i[I] += G^T-contract . B[J]
+            } else {
+                float gj[16];                                                  // discount of this lane's 16 tile rows (s = row here)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int grow = J0 + acc_row(reg, h);
-                const float m = G[reg], t = tm[reg];
-                const float dlt = m - gam_col * t;                 // discount is indexed by s = column here
-                const bool diag = (grow == gcol);
-                s_all += m;
-                s_tall += t;
-                if (diag) {
-                    s_diag += m;
-                    G[reg] = (gcol < B) ? -inv_b : 0.f;
-                } else {
-                    s_sq += dlt * dlt;
-                    G[reg] = dlt * inv_noff;
+                for (int i = 0; i < 4; ++i) {
+                    const float4 u = *reinterpret_cast<const float4*>(sGam + 8 * i + 4 * h);
+                    gj[4 * i] = u.x; gj[4 * i + 1] = u.y; gj[4 * i + 2] = u.z; gj[4 * i + 3] = u.w;
                 }
-            }
-            contract_rows<NT, LD>(out, G, sBm, l31, h);            // dF_i[I] += G^T-contract . B[J]
-        } else {
-            // tile rows = s (J), cols = t (I):  P[r][c] = M_i[s = J0+r][t = I0+c]
-            floatx16 tm = tile_mm<KS, LD>(stF1, fb, l31, h);
-            {
-                const floatx16 t2 = tile_mm<KS, LD>(stF2, fb, l31, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tm[i] = fminf(tm[i], t2[i]);
-            }
-            const float* sFi = (wid == 2) ? sF1 : sF2;
-            floatx16 G = tile_mm<KS, LD>(sFi, fa, l31, h);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = acc_row(reg, h);
-                const int grow = J0 + r;
-                const float dlt = G[reg] - sGam[r] * tm[reg];      // discount is indexed by s = row here
-                const bool diag = (grow == gcol);
-                G[reg] = diag ? ((gcol < B) ? -inv_b : 0.f) : dlt * inv_noff;
-            }
-            contract_rows<NT, LD>(out, G, sFi, l31, h);            // dB[I] += G-contract . F_i[J]
-            if ((jt & 1) == (wid & 1)) {
-                // covariance tile C[r][c] = B[J0+r] . B[I0+c]  (fb_ddpg.py:344-348)
-                floatx16 C = tile_mm<KS, LD>(sBm, fa, l31, h);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int grow = J0 + acc_row(reg, h);
-                    const float c = C[reg];
-                    const bool diag = (grow == gcol);
-                    if (diag) {
-                        s_cdiag += c;
-                        C[reg] = (gcol < B) ? -p.ortho2 * inv_b : 0.f;
-                    } else {
-                        s_csq += c * c;
-                        C[reg] = p.ortho2 * c * inv_noff;
-                    }
-                }
+                auto gen = [&](int reg) __attribute__((always_inline)) -> float {
+                    const float dlt = G[reg] - gj[reg] * tm[reg];
+                    const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
+                    return diag ? cdiag : dlt * inv_noff;
+                };
+                contract_gen<NT, LD, 0, 16>(out, gen, sFi, l31, h);            // dB[I] += G-contract . F_i[J]
                 // L_orth = mean_offdiag C^2 - 2 mean_diag C;  dL/dC = Hm = 2C/N_off (off-diag), -2/B (diag);
                 // C = B B^T  =>  dB = ortho * (Hm + Hm^T) B = ortho * 2 * Hm . B.  With ortho2 = 2*ortho the tile
-                // coefficient is ortho2 * Hm = 2 * (ortho2*C/N_off) resp. 2 * (-ortho2/B):
+                // coefficient is ortho2 * Hm = 2 * (ortho2*C/N_off) resp. 2 * (-ortho2/B).  Wave 2 owns accumulator
+                // registers 0..7 (scalar sums and contraction), wave 3 registers 8..15; C = half of wave 2 + half of wave 3.
+                const float* cA = xch + 2048 + 1024, * cB = xch + 2048 + 2048 + 1024;
+                float cc[8];
+                auto fetch = [&](int f4) __attribute__((always_inline)) {      // accumulator registers 4 f4 .. 4 f4 + 7
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) C[reg] *= 2.0f;
-                contract_rows<NT, LD>(out, C, sBm, l31, h);
+                    for (int i = 0; i < 2; ++i) {
+                        const float4 x = *reinterpret_cast<const float4*>(cA + ((f4 + i) * 64 + lane) * 4);
+                        const float4 y = *reinterpret_cast<const float4*>(cB + ((f4 + i) * 64 + lane) * 4);
+                        cc[4 * i] = x.x + y.x; cc[4 * i + 1] = x.y + y.y; cc[4 * i + 2] = x.z + y.z; cc[4 * i + 3] = x.w + y.w;
+                    }
+                };
+                const float hdiag = 2.0f * p.ortho2 * cdiag, hoff = 2.0f * p.ortho2 * inv_noff;
+                if (wid == 2) {
+                    fetch(0);
+                    auto genc = [&](int reg) __attribute__((always_inline)) -> float {
+                        const float c = cc[reg];
+                        const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
+                        s_cdiag += diag ? c : 0.f;
+                        s_csq += diag ? 0.f : c * c;
+                        return diag ? hdiag : hoff * c;
+                    };
+                    contract_gen<NT, LD, 0, 8>(out, genc, sBm, l31, h);
+                } else {
+                    fetch(2);
+                    auto genc = [&](int reg) __attribute__((always_inline)) -> float {
+                        const float c = cc[reg - 8];
+                        const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
+                        s_cdiag += diag ? c : 0.f;
+                        s_csq += diag ? 0.f : c * c;
+                        return diag ? hdiag : hoff * c;
+                    };
+                    contract_gen<NT, LD, 8, 8>(out, genc, sBm, l31, h);
+                }
             }
         }
-        }
-        __syncthreads();
     }
+    __syncthreads();                                        // (the hand-off below reuses the panels)
 
     if constexpr (NG > 1) {
         // groups 1 .. NG-1 hand their accumulators and scalar sums to group 0 (their own panels are free now), added in group order
@@ -439,7 +578,7 @@ PwPlan make_plan(int B, int d, int rows = -1) {
     if (pl.ks < 0) return pl;
     pl.nt = (2 * pl.ks + 31) / 32;
     const int w = (2 * pl.ks > 32 * pl.nt) ? 2 * pl.ks : 32 * pl.nt;
-    pl.ld = w + 1;
+    pl.ld = w + 4;
     pl.dp = 32 * pl.nt;
     pl.njt = (B + 31) / 32;
     pl.nI = (rows + 31) / 32;
@@ -451,8 +590,8 @@ PwPlan make_plan(int B, int d, int rows = -1) {
     pl.jpc = (pl.njt + nchunks - 1) / nchunks;
     pl.nchunks = (pl.njt + pl.jpc - 1) / pl.jpc;
     // two wave groups per workgroup when their panels fit the CU's LDS next to nothing else and a chunk has tiles for both
-    pl.ng = (pl.ld <= 65 && pl.jpc >= 2) ? 2 : 1;
-    pl.lds_bytes = (size_t)pl.ng * (6 * 32 * pl.ld + 32) * sizeof(float);
+    pl.ng = (w <= 64 && pl.jpc >= 2) ? 2 : 1;
+    pl.lds_bytes = (size_t)pl.ng * pw_group_floats(pl.ld) * sizeof(float);
     return pl;
 }
 
@@ -470,14 +609,14 @@ hipError_t pairwise_prepare(int B, int d) {
     const PwPlan pl = make_plan(B, d);
     if (pl.ks < 0) return hipErrorInvalidValue;
     // (both group counts: the block mode of the global-batch schedule plans its own chunking)
-    const int bytes1 = (int)((size_t)(6 * 32 * pl.ld + 32) * sizeof(float)), bytes2 = 2 * bytes1;
+    const int bytes1 = (int)((size_t)pw_group_floats(pl.ld) * sizeof(float)), bytes2 = 2 * bytes1;
 #define PW_ATTR1(KS, VEC, NG_, BYTES)                                                                                  \
     if ((BYTES) > 48 * 1024) {                                                                                        \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pairwise_kernel<KS, VEC, NG_>),              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES));                      \
         if (e != hipSuccess) return e;                                                                                \
     }
-#define PW_ATTR(KS) { PW_ATTR1(KS, true, 1, bytes1) PW_ATTR1(KS, false, 1, bytes1) if (pl.ld <= 65) { PW_ATTR1(KS, true, 2, bytes2) PW_ATTR1(KS, false, 2, bytes2) } return hipSuccess; }
+#define PW_ATTR(KS) { PW_ATTR1(KS, true, 1, bytes1) PW_ATTR1(KS, false, 1, bytes1) if (pl.ld <= 68) { PW_ATTR1(KS, true, 2, bytes2) PW_ATTR1(KS, false, 2, bytes2) } return hipSuccess; }
     switch (pl.ks) {
         case 4: PW_ATTR(4);
         case 8: PW_ATTR(8);

@@ -1,0 +1,75 @@
+// Diagnostic (not part of the product): what can a wave issue in the shadow of its own v_mfma_f32_32x32x2_f32?
+// One wave per SIMD (256 threads a workgroup, one workgroup per CU); a loop of MFMAs on ONE accumulator (dependent chain) or on
+// FOUR (independent), with N filler instructions of one kind between two MFMAs; prints shader cycles per MFMA.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_shadow.hip -o tools/scratch/mfma_shadow
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define FENCE __builtin_amdgcn_sched_barrier(0)
+
+template <int KIND, int N, int CHAINS>
+__global__ void __launch_bounds__(256) probe(unsigned long long* out, int iters, float a, float b, float* sink) {
+    __shared__ __attribute__((aligned(16))) float lds[256 * 4 * 4];
+    floatx16 acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    float x0 = a, x1 = b, x2 = a + 1, x3 = b + 1;
+    float4 w = make_float4(a, b, a, b);
+    float* my = lds + threadIdx.x * 4;
+    const float* rd = lds + (threadIdx.x & 63);
+    float r0 = 0.f;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc[j % CHAINS] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j % CHAINS], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (KIND == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(x1));                 // dependent VALU chain
+                if (KIND == 2) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(x1)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x2) : "v"(x3)); }
+                if (KIND == 3) *reinterpret_cast<float4*>(my) = w;                                          // ds_write_b128
+                if (KIND == 4) { float t; asm volatile("ds_read_b32 %0, %1" : "=v"(t) : "v"((unsigned)(size_t)rd)); r0 = t; }
+                if (KIND == 5) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(x1));
+                if (KIND == 6) asm volatile("s_nop 3");
+                if (KIND == 7) asm volatile("v_accvgpr_mov_b32 a255, a254");
+            }
+            FENCE;
+        }
+        if (KIND == 4) asm volatile("s_waitcnt lgkmcnt(0)");
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float s = x0 + x2 + r0;
+    for (int c = 0; c < CHAINS; ++c) for (int i = 0; i < 16; ++i) s += acc[c][i];
+    if (s == 12345.f) sink[0] = s + lds[5];
+    if ((threadIdx.x & 63) == 0) out[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int KIND, int N, int CHAINS>
+void run(const char* name, unsigned long long* d, float* sink) {
+    const int iters = 200, wgs = 256;
+    probe<KIND, N, CHAINS><<<wgs, 256>>>(d, iters, 1.0f, 0.5f, sink);
+    probe<KIND, N, CHAINS><<<wgs, 256>>>(d, iters, 1.0f, 0.5f, sink);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(wgs * 4);
+    (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    printf("%-28s N=%2d chains=%d: %7.1f cycles per MFMA (median wave)\n", name, N, CHAINS, (double)h[h.size() / 2] / (iters * 16.0));
+}
+
+int main() {
+    unsigned long long* d; float* sink;
+    (void)hipMalloc(&d, 1024 * 8); (void)hipMalloc(&sink, 16);
+    run<0, 0, 1>("bare", d, sink);
+    run<0, 0, 4>("bare", d, sink);
+    run<1, 4, 1>("v_add dependent", d, sink);  run<1, 8, 1>("v_add dependent", d, sink);  run<1, 12, 1>("v_add dependent", d, sink);
+    run<1, 8, 4>("v_add dependent", d, sink);  run<1, 16, 4>("v_add dependent", d, sink);
+    run<2, 4, 1>("v_add 2 chains (x2)", d, sink); run<2, 6, 1>("v_add 2 chains (x2)", d, sink);
+    run<5, 8, 1>("v_cndmask", d, sink); run<5, 12, 1>("v_cndmask", d, sink);
+    run<3, 1, 1>("ds_write_b128", d, sink); run<3, 2, 1>("ds_write_b128", d, sink); run<3, 1, 4>("ds_write_b128", d, sink);
+    run<4, 1, 1>("ds_read_b32", d, sink); run<4, 2, 1>("ds_read_b32", d, sink); run<4, 4, 1>("ds_read_b32", d, sink);
+    run<6, 4, 1>("s_nop 3", d, sink); run<6, 8, 1>("s_nop 3", d, sink); run<6, 12, 1>("s_nop 3", d, sink);
+    run<7, 8, 1>("v_accvgpr_mov", d, sink); run<7, 16, 1>("v_accvgpr_mov", d, sink);
+    return 0;
+}
