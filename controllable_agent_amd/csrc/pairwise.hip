@@ -29,10 +29,14 @@
 // (lane half h takes k = 8 q + 4 h + m), identically on the register operand.
 #include "common.h"
 #include "fbhip.h"
+#include <type_traits>
+#include <utility>
 
 namespace fbhip {
 
 namespace {
+
+typedef float fx4 __attribute__((ext_vector_type(4)));
 
 constexpr int PW_SLOTS = 4;        // dF1, dF2, dB (wave 2), dB (wave 3)
 constexpr int PW_SCAL = 12;        // scalar partials per workgroup
@@ -51,7 +55,7 @@ struct PwArgs {
     float ortho2;              // 2 * ortho_coef
     int jpc;                   // J tiles per chunk
     int njt;                   // number of J tiles (ceil(B/32))
-    int vec;                   // 16-byte aligned panels with ld % 4 == 0 -> float4 loads
+    int vec;                   // staging mode (Stage3): 0 scalar loads, 1 aligned panels with zero-fill masks, 2 aligned, whole, d == 2 KS
     float* partial;            // [nchunks][PW_SLOTS][Bp][DP]
     float* scal;               // [nblocks][PW_SCAL]
     int Bp;
@@ -59,110 +63,140 @@ struct PwArgs {
                                // of the B-row panels; outputs / partials are indexed by the LOCAL row (I - i_off)
 };
 
-// Three panels of one 32-row block (zero filled outside [0,B) x [0,d)): global -> registers -> LDS [32][LD], one float4 quad per
-// "op" (op = 3 i + m: quad i of this thread, matrix m).  load() only ISSUES the global load (branch-free on the aligned path:
-// out-of-range quads read a clamped, valid address), the zero-fill masks are applied in store().  The kernel never stages a whole
-// tile at once: the ops are handed out one or two at a time to the k-steps of a product (tile_mm's ``side``), so the loads, the
-// selects and the LDS writes issue in the shadow of the matrix pipe (one wave per SIMD: nothing else would hide them).
-template <int LD, bool VEC>
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}) -- indices that select
+// registers (array elements held in VGPRs) must be constants in the source, not after some unrolling pass
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// Three panels of one 32-row block: global -> registers -> LDS [32][LD], one float4 quad per "op" (op = 3 i + m: quad i of this
+// thread, matrix m).  load() only ISSUES the global load, store() writes LDS.  The kernel never stages a whole tile at once: the
+// ops are handed out one at a time to the k-steps of a product (mm_steps' ``side``).
+// A wave's VALU instructions do NOT overlap its own MFMAs (tools/mfma_shadow.hip: +5..8 cycles per instruction between two
+// MFMAs, while ds_read / ds_write / global_load are free), and with one wave per SIMD nothing else hides them, so MODE 2 -- the
+// product's case: 16-byte aligned panels, ld % 4 == 0, B % 32 == 0, d == 2 KS -- stages with NO vector ALU work in the loop:
+// per-thread global and LDS offsets are loop invariants, the tile base is scalar, and nothing is zero-filled: quads at or past
+// ld land in the row's 4-float pad (never read), columns [d, W) of the panels only ever reach output columns >= d (dropped).
+// MODE 1: aligned panels, zero-fill masks applied in store() (ragged B or d < 2 KS); MODE 0: scalar loads (unaligned panels).
+template <int LD, int MODE>
 struct Stage3 {
     static constexpr int W = LD - 4;                 // multiple of 32
     static constexpr int QPT = 32 * (W / 4) / 256;   // float4 quads per thread per matrix (1, 2, 4 for W = 32, 64, 128)
     static constexpr int NOPS = 3 * QPT;
-    float4 v[NOPS];
+    fx4 v[NOPS];                                     // (a native vector, not HIP's float4 struct: struct copies become memcpys between
+                                                     //  address spaces that keep the whole stage in scratch memory)
+    unsigned goff[QPT], loff[QPT];                   // MODE 2: float offsets inside the tile (global) / the panel (LDS)
 
+    __device__ __forceinline__ void init(int ld, int tid) {
+        if constexpr (MODE == 2) {
+            static_for<QPT>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                const int q = tid + i * 256;
+                const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+                const bool ok = n0 < ld;
+                goff[i] = (unsigned)(r * ld + (ok ? n0 : 0));
+                loff[i] = (unsigned)(r * LD + (ok ? n0 : W));
+            });
+        }
+    }
     __device__ __forceinline__ void load(int op, const float* __restrict__ X, int ld, int row0, int B, int d, int tid) {
-        const int q = tid + (op / 3) * 256;
-        const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
-        if constexpr (VEC) {
+        if constexpr (MODE == 2) {
+            const float* tile = X + (size_t)row0 * ld;                           // (uniform: scalar registers)
+            v[op] = *reinterpret_cast<const fx4*>(tile + goff[op / 3]);
+        } else if constexpr (MODE == 1) {
+            const int q = tid + (op / 3) * 256;
+            const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
             const bool ok = (row0 + r < B) && (n0 < ld);                     // ld % 4 == 0: the quad stays inside its row
             const size_t off = ok ? (size_t)(row0 + r) * ld + n0 : 0;
-            v[op] = *reinterpret_cast<const float4*>(X + off);
+            v[op] = *reinterpret_cast<const fx4*>(X + off);
         } else {
+            const int q = tid + (op / 3) * 256;
+            const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
             const int gr = row0 + r;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            fx4 x = {0.f, 0.f, 0.f, 0.f};
             if (gr < B && n0 < d) {
                 const float* ptr = X + (size_t)gr * ld + n0;
-                x.x = ptr[0];
-                if (n0 + 1 < d) x.y = ptr[1];
-                if (n0 + 2 < d) x.z = ptr[2];
-                if (n0 + 3 < d) x.w = ptr[3];
+                x[0] = ptr[0];
+                if (n0 + 1 < d) x[1] = ptr[1];
+                if (n0 + 2 < d) x[2] = ptr[2];
+                if (n0 + 3 < d) x[3] = ptr[3];
             }
             v[op] = x;
         }
     }
     __device__ __forceinline__ void store(int op, float* __restrict__ panel, int row0, int B, int d, int tid) const {
-        const int q = tid + (op / 3) * 256;
-        const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
-        const bool row_ok = row0 + r < B;
-        const bool k0 = row_ok && n0 < d, k1 = row_ok && n0 + 1 < d, k2 = row_ok && n0 + 2 < d, k3 = row_ok && n0 + 3 < d;
-        *reinterpret_cast<float4*>(panel + r * LD + n0) =
-            make_float4(k0 ? v[op].x : 0.f, k1 ? v[op].y : 0.f, k2 ? v[op].z : 0.f, k3 ? v[op].w : 0.f);
+        if constexpr (MODE == 2) {
+            *reinterpret_cast<fx4*>(panel + loff[op / 3]) = v[op];
+        } else {
+            const int q = tid + (op / 3) * 256;
+            const int r = q / (W / 4), n0 = 4 * (q % (W / 4));
+            const bool row_ok = row0 + r < B;
+            const bool k0 = row_ok && n0 < d, k1 = row_ok && n0 + 1 < d, k2 = row_ok && n0 + 2 < d, k3 = row_ok && n0 + 3 < d;
+            const fx4 z = {k0 ? v[op][0] : 0.f, k1 ? v[op][1] : 0.f, k2 ? v[op][2] : 0.f, k3 ? v[op][3] : 0.f};
+            *reinterpret_cast<fx4*>(panel + r * LD + n0) = z;
+        }
     }
 };
 
-struct NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+struct NoSide { template <class A, class B> __device__ __forceinline__ void operator()(A, B) const {} };
 
-// acc(32x32) = rowsJ (LDS, [32][LD]) . fragI^T over KS k-steps, in the permuted k order of load_frag: step 4 q + m contracts
-// k = 8 q + 4 h + m (one ds_read_b128 per four steps), the KS % 4 tail steps k = 8 (KS / 4) + 2 i + h.
-// PART 0: all of K; 1: the first half of the quads; 2: the other quads and the tail (1 + 2 = 0 as sets).
-// side(s, n): the caller's slot s of n for unrelated work (staging ops).
-// A wave issues in order and a dependent (or merely next) MFMA waits ~60 cycles for the matrix pipe: whatever is to hide behind
-// the MFMAs has to sit BETWEEN two of them, a few instructions per gap, and hipcc has to be kept from moving it (it otherwise emits
-// read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs, and collects the VALU work in front): one scheduling fence per MFMA, the read of quad
-// q + 1 and one side slot right behind each MFMA of quad q.
-template <int KS, int LD, int PART, class Side>
-__device__ __forceinline__ floatx16 tile_mm(const float* __restrict__ sJ, const float (&fragI)[KS], int l31, int h, Side&& side) {
-    constexpr int KQ = KS / 4, KT = KS % 4;
-    constexpr int Q0 = PART == 2 ? KQ / 2 : 0, Q1 = PART == 1 ? KQ / 2 : KQ;
-    constexpr bool TAIL = PART != 1 && KT > 0;
-    constexpr int NS = 4 * (Q1 - Q0);
+// acc(32x32) = rowsJ (LDS) . frag^T over 4 NQ + KT k-steps: quad j of the row (``aq`` + 8 j: one ds_read_b128) feeds the steps
+// 4 j .. 4 j + 3, the KT tail steps read ``at`` + 2 i.  The k order of a product is permuted (load_frag: step 4 q + m contracts
+// k = 8 q + 4 h + m, tail step i contracts k = 8 (KS / 4) + 2 i + h), identically on both operands.
+// side(s, n): the caller's slot s of n for unrelated memory work (staging ops), one slot behind every MFMA.
+// hipcc has to be kept from reordering (it otherwise emits read -> s_waitcnt lgkmcnt(0) -> 4 MFMAs into ONE register quad):
+// one scheduling fence per MFMA, the read of quad j + 1 right behind the first MFMA of quad j.
+template <int NQ, int KT, class Side>
+__device__ __forceinline__ floatx16 mm_steps(const float* __restrict__ aq, const float* __restrict__ at,
+                                             const float (&frag)[4 * NQ + KT], Side&& side) {
+    using NS = std::integral_constant<int, 4 * NQ>;
     floatx16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const float* a = sJ + l31 * LD + 4 * h;
-    const float* t = sJ + l31 * LD + 8 * KQ + h;
     float4 v[2];
     float tl[KT > 0 ? KT : 1];
-    if constexpr (Q1 > Q0) v[0] = *reinterpret_cast<const float4*>(a + 8 * Q0);
-    else if constexpr (TAIL) {
+    if constexpr (NQ > 0) v[0] = *reinterpret_cast<const float4*>(aq);
+    else if constexpr (KT > 0) {
 #pragma unroll
-        for (int i = 0; i < KT; ++i) tl[i] = t[2 * i];
+        for (int i = 0; i < KT; ++i) tl[i] = at[2 * i];
     }
     __builtin_amdgcn_sched_barrier(0);
+    static_for<NQ>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value, c = q & 1;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].x, frag[4 * q + 0], acc, 0, 0, 0);
+        if constexpr (q + 1 < NQ) v[c ^ 1] = *reinterpret_cast<const float4*>(aq + 8 * (q + 1));
+        else if constexpr (KT > 0) {
 #pragma unroll
-    for (int q = Q0; q < Q1; ++q) {
-        const int c = (q - Q0) & 1;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].x, fragI[4 * q + 0], acc, 0, 0, 0);
-        if (q + 1 < Q1) v[c ^ 1] = *reinterpret_cast<const float4*>(a + 8 * (q + 1));
-        else if constexpr (TAIL) {
-#pragma unroll
-            for (int i = 0; i < KT; ++i) tl[i] = t[2 * i];
+            for (int i = 0; i < KT; ++i) tl[i] = at[2 * i];
         }
-        side(4 * (q - Q0) + 0, NS);
+        side(std::integral_constant<int, 4 * q + 0>{}, NS{});
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].y, fragI[4 * q + 1], acc, 0, 0, 0);
-        side(4 * (q - Q0) + 1, NS);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].y, frag[4 * q + 1], acc, 0, 0, 0);
+        side(std::integral_constant<int, 4 * q + 1>{}, NS{});
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].z, fragI[4 * q + 2], acc, 0, 0, 0);
-        side(4 * (q - Q0) + 2, NS);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].z, frag[4 * q + 2], acc, 0, 0, 0);
+        side(std::integral_constant<int, 4 * q + 2>{}, NS{});
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].w, fragI[4 * q + 3], acc, 0, 0, 0);
-        side(4 * (q - Q0) + 3, NS);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c].w, frag[4 * q + 3], acc, 0, 0, 0);
+        side(std::integral_constant<int, 4 * q + 3>{}, NS{});
         __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (TAIL) {
+    });
 #pragma unroll
-        for (int i = 0; i < KT; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tl[i], fragI[4 * KQ + i], acc, 0, 0, 0);
-    }
+    for (int i = 0; i < KT; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tl[i], frag[4 * NQ + i], acc, 0, 0, 0);
     return acc;
+}
+// all of K
+template <int KS, int LD, class Side>
+__device__ __forceinline__ floatx16 tile_mm(const float* __restrict__ sJ, const float (&fragI)[KS], int l31, int h, Side&& side) {
+    return mm_steps<KS / 4, KS % 4>(sJ + l31 * LD + 4 * h, sJ + l31 * LD + 8 * (KS / 4) + h, fragI, side);
 }
 
 // out[nt] += G^T-contract . X[J]:  out[c][n] += sum_r G[r][c] * X[r][n] over the accumulator registers [R0, R0 + NR) of the tile
 // (two tile rows each).  gen(reg) PRODUCES G[reg] -- the loss epilogue of that register (mask, diagonal, scalar sums) -- and is
 // called one register group (4 MFMAs) ahead, behind an MFMA of the running group, like the LDS reads of the next group's operands.
 template <int NT, int LD, int R0, int NR, class Gen>
-__device__ __forceinline__ void contract_gen(floatx16 (&out)[NT], Gen&& gen, const float* __restrict__ sX, int l31, int h) {
+__device__ __forceinline__ void contract_gen(floatx16 (&out)[NT], Gen&& gen, const float* __restrict__ sX, int l31, int h) {     // (sX: the panel at the first row of this call's registers)
     static_assert(NT == 1 || NT == 2 || NT == 4, "column tiles");
     constexpr int GS = 4 / NT;                                        // registers per group: 4 MFMAs a group
     static_assert(NR % GS == 0, "register groups");
@@ -226,19 +260,19 @@ __device__ __forceinline__ floatx16 get16(const float* __restrict__ src, int lan
 constexpr int PW_XCH = 6 * 1024;                                           // floats: t x 2 waves, (u, C-half) x 2 waves
 __host__ __device__ constexpr int pw_group_floats(int LD) { return 6 * 32 * LD + 32 + PW_XCH; }
 
-// VEC: 16-byte aligned panels with ld % 4 == 0 (the product's workspace).  A separate instantiation, not a runtime
-// branch: merging the two loaders' registers makes hipcc wait for the loads right after issuing them.
+// MODE: see Stage3 (separate instantiations, not a runtime branch).
 // NG wave groups of four waves each walk ALTERNATE J tiles of the workgroup's chunk concurrently (own LDS panels, own
 // accumulators; group g > 0 hands its sums to group 0 through LDS at the end, in group order: deterministic).  With one group a
-// SIMD holds a single wave whose every LDS round trip, barrier and staging phase leaves the matrix pipe idle (35 us for 14.5 us
-// of MFMA issue at B = 1024, d = 50); two groups put two independent chains on every SIMD.  NG = 2 needs 2 x 6 panels in LDS:
-// d <= 64.
-template <int KS, bool VEC, int NG>
+// SIMD holds a single wave whose every VALU instruction, LDS round trip and barrier leaves the matrix pipe idle; two groups put
+// two independent chains on every SIMD.  NG = 2 needs 2 x 6 panels in LDS and <= 256 registers a wave: d <= 64.
+template <int KS, int MODE, int NG>
 __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     constexpr int NT = (2 * KS + 31) / 32;
     constexpr int W = (2 * KS > 32 * NT ? 2 * KS : 32 * NT);
     constexpr int LD = W + 4;                       // row stride = 4 banks: conflict-free for the b128 row reads and the b32 column reads
     constexpr int GRP = pw_group_floats(LD);        // floats per group: 6 x [32][LD] + gamma[32] + the swap area
+    constexpr int KQ = KS / 4, KT = KS % 4;
+    constexpr int NQH = KQ - KQ / 2;                // quads of the larger half of K (the covariance product is split over K)
     extern __shared__ __attribute__((aligned(16))) float lds_all[];        // NG x GRP
     const int grp = NG > 1 ? (int)(threadIdx.x >> 8) : 0;
     float* lds = lds_all + grp * GRP;
@@ -251,11 +285,12 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     float* sGam = stF2 + 32 * LD;
     float* xch = sGam + 32;                         // [0, 2048): t of waves 0, 1; [2048, 6144): (u, C half) of waves 2, 3
 
-    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x & 255, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int I0 = blockIdx.x * 32 + p.i_off, chunk = blockIdx.y;
     const int B = p.B, d = p.d;
     const float n_off = (float)B * (float)(B - 1);
-    const float inv_noff = 1.0f / n_off, inv_b = 1.0f / (float)B;
+    const float inv_noff = 1.0f / n_off;
 
     // the panels in two halves: T = {tB, tF1, tF2} (the target products), M = {Bm, F1, F2} (the M_i / covariance products and
     // every contraction)
@@ -263,31 +298,44 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     const float* const srcM[3] = {p.Bm, p.F1, p.F2};
     float* const dstT[3] = {stB, stF1, stF2};
     float* const dstM[3] = {sBm, sF1, sF2};
-    using Stage = Stage3<LD, VEC>;
+    using Stage = Stage3<LD, MODE>;
     constexpr int NOPS = Stage::NOPS;
     Stage R;
+    R.init(p.ld, tid);
 
     // ---- I-side fragments (registers, whole kernel) ----------------------------------------------------
-#pragma unroll
-    for (int op = 0; op < NOPS; ++op) R.load(op, srcT[op % 3], p.ld, I0, B, d, tid);
-#pragma unroll
-    for (int op = 0; op < NOPS; ++op) R.store(op, dstT[op % 3], I0, B, d, tid);
-#pragma unroll
-    for (int op = 0; op < NOPS; ++op) R.load(op, srcM[op % 3], p.ld, I0, B, d, tid);
-#pragma unroll
-    for (int op = 0; op < NOPS; ++op) R.store(op, dstM[op % 3], I0, B, d, tid);
+    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcT[op % 3], p.ld, I0, B, d, tid); });
+    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.store(op, dstT[op % 3], I0, B, d, tid); });
+    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcM[op % 3], p.ld, I0, B, d, tid); });
+    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.store(op, dstM[op % 3], I0, B, d, tid); });
     __syncthreads();
     float fa[KS], fb[KS];
+    float fh[4 * NQH + KT];          // role 2: this wave's half of K of B[I] (wave 2: the first KQ / 2 quads; wave 3: the others + the tail)
+    const int hq0 = (wid & 1) ? KQ / 2 : 0;
     if (wid < 2) {                   // role 1, wave i: F_i[I], tF_i[I]
         load_frag<KS, LD>(fa, wid == 0 ? sF1 : sF2, l31, h);
         load_frag<KS, LD>(fb, wid == 0 ? stF1 : stF2, l31, h);
+#pragma unroll
+        for (int i = 0; i < 4 * NQH + KT; ++i) fh[i] = 0.f;
     } else {                         // role 2: B[I], tB[I]
         load_frag<KS, LD>(fa, sBm, l31, h);
         load_frag<KS, LD>(fb, stB, l31, h);
+        const int nq = (wid & 1) ? NQH : KQ / 2;
+#pragma unroll
+        for (int j = 0; j < NQH; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(sBm + l31 * LD + 8 * (hq0 + min(j, max(nq - 1, 0))) + 4 * h);
+            const bool on = j < nq;
+            fh[4 * j] = on ? v.x : 0.f; fh[4 * j + 1] = on ? v.y : 0.f; fh[4 * j + 2] = on ? v.z : 0.f; fh[4 * j + 3] = on ? v.w : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < KT; ++i) fh[4 * NQH + i] = (wid & 1) ? sBm[l31 * LD + 8 * KQ + 2 * i + h] : 0.f;
     }
     const int gcol = I0 + l31;                              // batch index of this lane's tile column
     const float gam_col = (gcol < B) ? p.discount[gcol] : 0.f;
-    const float cdiag = (gcol < B) ? -inv_b : 0.f;          // d loss / d M on the diagonal
+    // the contraction coefficients are kept WITHOUT their common factor 1 / N_off (applied once at the end): on the diagonal
+    // d loss / d M = -1/B = cdiag / N_off
+    const float cdiag = (gcol < B) ? -(float)(B - 1) : 0.f;
+    const float o2 = 2.0f * p.ortho2;
     __syncthreads();
 
     floatx16 out[NT];
@@ -303,136 +351,169 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     float* my_x = wid < 2 ? xch + wid * 1024 : xch + 2048 + (wid - 2) * 2048;
     const float* their_x = wid < 2 ? xch + (wid ^ 1) * 1024 : xch + 2048 + ((wid - 2) ^ 1) * 2048;
 
+    // Tile order.  Exactly one tile of a column block holds diagonal entries (J0 == I0), and a contraction that can handle them
+    // costs the others vector-ALU work they do not need; a second instantiation chosen per tile makes hipcc keep ``out`` in two
+    // places and copy 64 registers per tile.  So the chunk's tiles are walked with the diagonal one (if the chunk has it) LAST,
+    // and the last iteration of every wave is peeled: the loop body knows there is no diagonal, the peeled copy checks.
+    const int ntl = jt_end - jt_begin;                      // tiles of this chunk (>= 1)
+    const int jdiag = I0 >> 5;
+    const bool has_diag = jdiag >= jt_begin && jdiag < jt_end;
+    auto tile_at = [&](int k) __attribute__((always_inline)) -> int {          // k-th tile of the walk, k clamped to the chunk
+        k = min(k, ntl - 1);
+        if (!has_diag) return jt_begin + k;
+        const int t = jt_begin + k;
+        return k == ntl - 1 ? jdiag : (t >= jdiag ? t + 1 : t);
+    };
+    const int niter = (ntl + NG - 1) / NG;                  // group g takes the positions g, g + NG, ...; every group runs niter
+                                                            // iterations (the barriers are workgroup-wide), a group without a
+                                                            // tile in the last one only keeps the others company
+
     // Staging schedule.  The T panels of a tile are read by the target products only (phase A), the M panels by everything
     // after them (phase B): while phase A runs the M slots are free, while phase B runs the T slots are.  ONE register set R:
     //   phase A(tile): R (= M panels of this tile) -> M slots;  R <- T panels of the next tile
     //   phase B(tile): R (= T panels of the next tile) -> T slots;  R <- M panels of the next tile
-    // each op riding on one k-step of a product.  Before the loop: T panels of the first tile in LDS, its M panels in R.
+    // each op riding behind one MFMA of a product.  Before the loop: T panels of the first tile in LDS, its M panels in R.
     {
-        const int J0 = min(jt_begin + grp, p.njt - 1) * 32;
-#pragma unroll
-        for (int op = 0; op < NOPS; ++op) R.load(op, srcT[op % 3], p.ld, J0, B, d, tid);
-#pragma unroll
-        for (int op = 0; op < NOPS; ++op) R.store(op, dstT[op % 3], J0, B, d, tid);
-#pragma unroll
-        for (int op = 0; op < NOPS; ++op) R.load(op, srcM[op % 3], p.ld, J0, B, d, tid);
+        const int J0 = tile_at(grp) * 32;
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcT[op % 3], p.ld, J0, B, d, tid); });
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.store(op, dstT[op % 3], J0, B, d, tid); });
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcM[op % 3], p.ld, J0, B, d, tid); });
     }
-    // group g takes the tiles jt_begin + g, jt_begin + g + NG, ...; every group runs the same number of iterations (the
-    // barriers are workgroup-wide), a group without a tile in the last one only keeps them company
-#pragma unroll 1
-    for (int jt0 = jt_begin; jt0 < jt_end; jt0 += NG) {
-        const int jt = jt0 + grp;
-        const bool live = jt < jt_end;
-        const int J0 = min(jt, p.njt - 1) * 32;
-        const int Jn = min(jt + NG, p.njt - 1) * 32;        // (past the chunk's last tile: a clamped, unused tile)
-        __syncthreads();                                    // T(jt) in LDS; the M slots and gamma are free
-        floatx16 tm, G;
-        if (live) {
-            // ---- phase A: the wave's own target product (parked for the other wave of the role)
-            if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
-            auto side = [&](int sidx, int n) __attribute__((always_inline)) {      // slot sidx of n: its share of 2 NOPS sub-ops
-#pragma unroll
-                for (int u = sidx * (2 * NOPS) / n; u < (sidx + 1) * (2 * NOPS) / n; ++u) {
-                    if (u & 1) R.load(u >> 1, srcT[(u >> 1) % 3], p.ld, Jn, B, d, tid);
-                    else R.store(u >> 1, dstM[(u >> 1) % 3], J0, B, d, tid);
-                }
-            };
-            // role 1: tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
-            // role 2: tile rows = s (J), cols = t (I):  P[r][c] = M_i[s = J0+r][t = I0+c]
-            tm = tile_mm<KS, LD, 0>(wid < 2 ? stB : ((wid & 1) ? stF2 : stF1), fb, l31, h, side);
-            put16(my_x, tm, lane);
-        }
-        __syncthreads();                                    // M(jt), gamma and the target products in LDS; the T slots are free
-        if (live) {
-            // ---- phase B: (role 2) this wave's half of K of the covariance tile C[r][c] = B[J0+r] . B[I0+c]
-            // (fb_ddpg.py:344-348), parked; then the M_i tile
-            if (wid >= 2) {
-                floatx16 Ch;
-                if (wid == 2) Ch = tile_mm<KS, LD, 1>(sBm, fa, l31, h, NoSide());
-                else Ch = tile_mm<KS, LD, 2>(sBm, fa, l31, h, NoSide());
-                put16(my_x + 1024, Ch, lane);
+
+    // One loop per ROLE (the waves of a role run identical code: what differs between them is pointers and offsets), so the
+    // accumulators of a role are updated in straight-line code.  Every barrier below is executed by all waves of the workgroup
+    // the same number of times (the two roles have the same barrier sequence).
+    auto run = [&](auto role_tag) __attribute__((always_inline)) {
+        constexpr int ROLE = decltype(role_tag)::value;
+        auto body = [&](int it, auto diag_tag) __attribute__((always_inline)) {
+            constexpr bool DIAG = decltype(diag_tag)::value;
+            const int k = it * NG + grp;
+            const bool live = k < ntl;
+            const int J0 = tile_at(k) * 32;
+            const int Jn = tile_at(k + NG) * 32;                // (past the chunk's last tile: a clamped, unused tile)
+            __syncthreads();                                    // T(tile) in LDS; the M slots and gamma are free
+            floatx16 tm, G;
+            if (live) {
+                // ---- phase A: the wave's own target product (parked for the other wave of the role)
+                if (tid < 32) sGam[tid] = (J0 + tid < B) ? p.discount[J0 + tid] : 0.f;
+                auto side = [&](auto sc, auto nc) __attribute__((always_inline)) {     // slot sc of nc: its share of 2 NOPS sub-ops
+                    constexpr int sidx = decltype(sc)::value, n = decltype(nc)::value;
+                    constexpr int u0 = sidx * (2 * NOPS) / n, u1 = (sidx + 1) * (2 * NOPS) / n;
+                    static_for<u1 - u0>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int u = u0 + decltype(kc)::value, op = u >> 1;
+                        if constexpr (u & 1) R.load(op, srcT[op % 3], p.ld, Jn, B, d, tid);
+                        else R.store(op, dstM[op % 3], J0, B, d, tid);
+                    });
+                };
+                // role 1: tile rows = t (J), cols = s (I):  T[r][c] = M_i[s = I0+c][t = J0+r]
+                // role 2: tile rows = s (J), cols = t (I):  P[r][c] = M_i[s = J0+r][t = I0+c]
+                tm = tile_mm<KS, LD>(ROLE == 1 ? stB : ((wid & 1) ? stF2 : stF1), fb, l31, h, side);
+                put16(my_x, tm, lane);
             }
-            auto side = [&](int sidx, int n) __attribute__((always_inline)) {
-#pragma unroll
-                for (int u = sidx * (2 * NOPS) / n; u < (sidx + 1) * (2 * NOPS) / n; ++u) {
-                    if (u & 1) R.load(u >> 1, srcM[(u >> 1) % 3], p.ld, Jn, B, d, tid);
-                    else R.store(u >> 1, dstT[(u >> 1) % 3], Jn, B, d, tid);
+            __syncthreads();                                    // M(tile), gamma and the target products in LDS; the T slots are free
+            if (live) {
+                // ---- phase B: (role 2) this wave's half of K of the covariance tile C[r][c] = B[J0+r] . B[I0+c]
+                // (fb_ddpg.py:344-348), parked; then the M_i tile
+                if constexpr (ROLE == 2) {
+                    const floatx16 Ch = mm_steps<NQH, KT>(sBm + l31 * LD + 4 * h + 8 * hq0, sBm + l31 * LD + 8 * KQ + h, fh, NoSide());
+                    put16(my_x + 1024, Ch, lane);
                 }
-            };
-            G = tile_mm<KS, LD, 0>(wid < 2 ? sBm : sFi, fa, l31, h, side);
-        }
-        __syncthreads();                                    // covariance halves in LDS
-        if (live) {
-            const bool dtile = (J0 == I0);                  // the only tile of this column block that holds diagonal entries
-            {
+                auto side = [&](auto sc, auto nc) __attribute__((always_inline)) {
+                    constexpr int sidx = decltype(sc)::value, n = decltype(nc)::value;
+                    constexpr int u0 = sidx * (2 * NOPS) / n, u1 = (sidx + 1) * (2 * NOPS) / n;
+                    static_for<u1 - u0>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int u = u0 + decltype(kc)::value, op = u >> 1;
+                        if constexpr (u & 1) R.load(op, srcM[op % 3], p.ld, Jn, B, d, tid);
+                        else R.store(op, dstT[op % 3], Jn, B, d, tid);
+                    });
+                };
+                G = tile_mm<KS, LD>(ROLE == 1 ? sBm : sFi, fa, l31, h, side);
+            }
+            __syncthreads();                                    // covariance halves in LDS
+            if (live) {
+                const bool dtile = DIAG && (J0 == I0);
                 const floatx16 t2 = get16(their_x, lane);
+                if constexpr (ROLE == 1) {
+                    // discount is indexed by s = column here
+                    auto gen = [&](int reg) __attribute__((always_inline)) -> float {
+                        const float m = G[reg], t = fminf(tm[reg], t2[reg]);
+                        const float dlt = m - gam_col * t;
+                        s_all += m;
+                        s_tall += t;
+                        s_sq += dlt * dlt;
+                        return dlt;
+                    };
+                    auto gen_d = [&](int reg) __attribute__((always_inline)) -> float {
+                        const float m = G[reg], t = fminf(tm[reg], t2[reg]);
+                        const float dlt = m - gam_col * t;
+                        const bool diag = (J0 + acc_row(reg, h) == gcol);
+                        s_all += m;
+                        s_tall += t;
+                        s_diag += diag ? m : 0.f;
+                        s_sq += diag ? 0.f : dlt * dlt;
+                        return diag ? cdiag : dlt;
+                    };
+                    // dF_i[I] += G^T-contract . B[J]
+                    if (!dtile) contract_gen<NT, LD, 0, 16>(out, gen, sBm, l31, h);
+                    else contract_gen<NT, LD, 0, 16>(out, gen_d, sBm, l31, h);
+                } else {
+                    float gj[16];                                              // discount of this lane's 16 tile rows (s = row here)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) tm[i] = fminf(tm[i], t2[i]);
-            }
-            if (wid < 2) {
-                auto gen = [&](int reg) __attribute__((always_inline)) -> float {
-                    const float m = G[reg], t = tm[reg];
-                    const float dlt = m - gam_col * t;                 // discount is indexed by s = column here
-                    const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
-                    s_all += m;
-                    s_tall += t;
-                    s_diag += diag ? m : 0.f;
-                    s_sq += diag ? 0.f : dlt * dlt;
-                    return diag ? cdiag : dlt * inv_noff;
-                };
-                contract_gen<NT, LD, 0, 16>(out, gen, sBm, l31, h);            // dF_i[I] += G^T-contract . B[J]
-            } else {
-                float gj[16];                                                  // discount of this lane's 16 tile rows (s = row here)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 u = *reinterpret_cast<const float4*>(sGam + 8 * i + 4 * h);
-                    gj[4 * i] = u.x; gj[4 * i + 1] = u.y; gj[4 * i + 2] = u.z; gj[4 * i + 3] = u.w;
-                }
-                auto gen = [&](int reg) __attribute__((always_inline)) -> float {
-                    const float dlt = G[reg] - gj[reg] * tm[reg];
-                    const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
-                    return diag ? cdiag : dlt * inv_noff;
-                };
-                contract_gen<NT, LD, 0, 16>(out, gen, sFi, l31, h);            // dB[I] += G-contract . F_i[J]
-                // L_orth = mean_offdiag C^2 - 2 mean_diag C;  dL/dC = Hm = 2C/N_off (off-diag), -2/B (diag);
-                // C = B B^T  =>  dB = ortho * (Hm + Hm^T) B = ortho * 2 * Hm . B.  With ortho2 = 2*ortho the tile
-                // coefficient is ortho2 * Hm = 2 * (ortho2*C/N_off) resp. 2 * (-ortho2/B).  Wave 2 owns accumulator
-                // registers 0..7 (scalar sums and contraction), wave 3 registers 8..15; C = half of wave 2 + half of wave 3.
-                const float* cA = xch + 2048 + 1024, * cB = xch + 2048 + 2048 + 1024;
-                float cc[8];
-                auto fetch = [&](int f4) __attribute__((always_inline)) {      // accumulator registers 4 f4 .. 4 f4 + 7
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 u = *reinterpret_cast<const float4*>(sGam + 8 * i + 4 * h);
+                        gj[4 * i] = u.x; gj[4 * i + 1] = u.y; gj[4 * i + 2] = u.z; gj[4 * i + 3] = u.w;
+                    }
+                    auto gen = [&](int reg) __attribute__((always_inline)) -> float {
+                        return G[reg] - gj[reg] * fminf(tm[reg], t2[reg]);
+                    };
+                    auto gen_d = [&](int reg) __attribute__((always_inline)) -> float {
+                        const float dlt = G[reg] - gj[reg] * fminf(tm[reg], t2[reg]);
+                        return (J0 + acc_row(reg, h) == gcol) ? cdiag : dlt;
+                    };
+                    // dB[I] += G-contract . F_i[J]
+                    if (!dtile) contract_gen<NT, LD, 0, 16>(out, gen, sFi, l31, h);
+                    else contract_gen<NT, LD, 0, 16>(out, gen_d, sFi, l31, h);
+                    // L_orth = mean_offdiag C^2 - 2 mean_diag C;  dL/dC = Hm = 2C/N_off (off-diag), -2/B (diag);
+                    // C = B B^T  =>  dB = ortho * (Hm + Hm^T) B = ortho * 2 * Hm . B.  With ortho2 = 2*ortho the tile
+                    // coefficient is ortho2 * Hm = 2 * (ortho2*C/N_off) resp. 2 * (-ortho2/B).  Wave 2 owns accumulator
+                    // registers 0..7 = tile rows 0-3, 8-11 (+ 4 h) -- scalar sums and contraction --, wave 3 registers 8..15 =
+                    // the same rows + 16; C = half of wave 2 + half of wave 3.
+                    const int half = wid & 1;
+                    const float* cA = xch + 2048 + 1024 + half * 512, * cB = xch + 2048 + 2048 + 1024 + half * 512;
+                    float cc[8];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const float4 x = *reinterpret_cast<const float4*>(cA + ((f4 + i) * 64 + lane) * 4);
-                        const float4 y = *reinterpret_cast<const float4*>(cB + ((f4 + i) * 64 + lane) * 4);
+                        const float4 x = *reinterpret_cast<const float4*>(cA + (i * 64 + lane) * 4);
+                        const float4 y = *reinterpret_cast<const float4*>(cB + (i * 64 + lane) * 4);
                         cc[4 * i] = x.x + y.x; cc[4 * i + 1] = x.y + y.y; cc[4 * i + 2] = x.z + y.z; cc[4 * i + 3] = x.w + y.w;
                     }
-                };
-                const float hdiag = 2.0f * p.ortho2 * cdiag, hoff = 2.0f * p.ortho2 * inv_noff;
-                if (wid == 2) {
-                    fetch(0);
                     auto genc = [&](int reg) __attribute__((always_inline)) -> float {
                         const float c = cc[reg];
-                        const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
+                        s_csq += c * c;
+                        return o2 * c;
+                    };
+                    auto genc_d = [&](int reg) __attribute__((always_inline)) -> float {
+                        const float c = cc[reg];
+                        const bool diag = (J0 + 16 * half + acc_row(reg, h) == gcol);
                         s_cdiag += diag ? c : 0.f;
                         s_csq += diag ? 0.f : c * c;
-                        return diag ? hdiag : hoff * c;
+                        return diag ? o2 * cdiag : o2 * c;
                     };
-                    contract_gen<NT, LD, 0, 8>(out, genc, sBm, l31, h);
-                } else {
-                    fetch(2);
-                    auto genc = [&](int reg) __attribute__((always_inline)) -> float {
-                        const float c = cc[reg - 8];
-                        const bool diag = dtile && (J0 + acc_row(reg, h) == gcol);
-                        s_cdiag += diag ? c : 0.f;
-                        s_csq += diag ? 0.f : c * c;
-                        return diag ? hdiag : hoff * c;
-                    };
-                    contract_gen<NT, LD, 8, 8>(out, genc, sBm, l31, h);
+                    if (!dtile) contract_gen<NT, LD, 0, 8>(out, genc, sBm + 16 * half * LD, l31, h);
+                    else contract_gen<NT, LD, 0, 8>(out, genc_d, sBm + 16 * half * LD, l31, h);
                 }
             }
-        }
-    }
+        };
+#pragma unroll 1
+        for (int it = 0; it < niter - 1; ++it) body(it, std::false_type{});
+        body(niter - 1, std::true_type{});
+    };
+    if (wid < 2) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[nt][i] *= inv_noff;
     __syncthreads();                                        // (the hand-off below reuses the panels)
 
     if constexpr (NG > 1) {
@@ -616,7 +697,7 @@ hipError_t pairwise_prepare(int B, int d) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (BYTES));                      \
         if (e != hipSuccess) return e;                                                                                \
     }
-#define PW_ATTR(KS) { PW_ATTR1(KS, true, 1, bytes1) PW_ATTR1(KS, false, 1, bytes1) if (pl.ld <= 68) { PW_ATTR1(KS, true, 2, bytes2) PW_ATTR1(KS, false, 2, bytes2) } return hipSuccess; }
+#define PW_ATTR(KS) { PW_ATTR1(KS, 0, 1, bytes1) PW_ATTR1(KS, 1, 1, bytes1) PW_ATTR1(KS, 2, 1, bytes1) if (pl.ld <= 68) { PW_ATTR1(KS, 0, 2, bytes2) PW_ATTR1(KS, 1, 2, bytes2) PW_ATTR1(KS, 2, 2, bytes2) } return hipSuccess; }
     switch (pl.ks) {
         case 4: PW_ATTR(4);
         case 8: PW_ATTR(8);
@@ -654,6 +735,7 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     a.B = B; a.d = d; a.ld = ld; a.ortho2 = 2.0f * ortho_coef; a.jpc = pl.jpc; a.njt = pl.njt;
     a.vec = ((ld & 3) == 0);
     for (const float* q : {F1, F2, Bm, tF1, tF2, tB}) if ((uintptr_t)q & 15) a.vec = 0;
+    if (a.vec && (B & 31) == 0 && d == 2 * pl.ks) a.vec = 2;
     a.partial = scratch;
     a.scal = scratch + (size_t)pl.nchunks * PW_SLOTS * pl.Bp * pl.dp;
     a.Bp = pl.Bp;
@@ -661,8 +743,9 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     dim3 grid(pl.nI, pl.nchunks), block(256 * pl.ng);
     hipError_t e = hipSuccess;
 #define PW_LAUNCH1(KS, NG_)                                                                                            \
-    if (a.vec) hipLaunchKernelGGL((pairwise_kernel<KS, true, NG_>), grid, block, pl.lds_bytes, s, a);                  \
-    else hipLaunchKernelGGL((pairwise_kernel<KS, false, NG_>), grid, block, pl.lds_bytes, s, a)
+    if (a.vec == 2) hipLaunchKernelGGL((pairwise_kernel<KS, 2, NG_>), grid, block, pl.lds_bytes, s, a);                \
+    else if (a.vec == 1) hipLaunchKernelGGL((pairwise_kernel<KS, 1, NG_>), grid, block, pl.lds_bytes, s, a);           \
+    else hipLaunchKernelGGL((pairwise_kernel<KS, 0, NG_>), grid, block, pl.lds_bytes, s, a)
 #define PW_LAUNCH(KS) if (pl.ng == 2) { PW_LAUNCH1(KS, 2); } else { PW_LAUNCH1(KS, 1); }
     switch (pl.ks) {
         case 4: PW_LAUNCH(4); break;
