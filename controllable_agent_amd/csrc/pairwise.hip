@@ -39,8 +39,21 @@ namespace {
 typedef float fx4 __attribute__((ext_vector_type(4)));
 
 constexpr int PW_SLOTS = 4;        // dF1, dF2, dB (wave 2), dB (wave 3)
-constexpr int PW_SCAL = 12;        // scalar partials per workgroup
+constexpr int PW_SCAL = 20;        // scalar partials per workgroup: 10 sums as (hi, lo) float pairs, lo at [10 + k]
 
+// a wave's sum of per-lane fp32 partials, added in fp64 (the loss is a small difference of sums hundreds of times larger: the
+// fp32 rounding of the partials is what the 2e-5 / 5e-6 tolerances of the free-running parity tests see first)
+__device__ __forceinline__ double wsum_d(float v) {
+    double s = (double)v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+__device__ __forceinline__ void put_hilo(float* sc, int k, double s) {
+    const float hi = (float)s;
+    sc[k] = hi;
+    sc[10 + k] = (float)(s - (double)hi);
+}
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -257,7 +270,7 @@ __device__ __forceinline__ floatx16 get16(const float* __restrict__ src, int lan
     return v;
 }
 
-constexpr int PW_XCH = 6 * 1024;                                           // floats: t x 2 waves, (u, C-half) x 2 waves
+constexpr int PW_XCH = 6 * 1024 + 4;                                       // floats: 6 parked tiles (below) + 2 ready flags
 __host__ __device__ constexpr int pw_group_floats(int LD) { return 6 * 32 * LD + 32 + PW_XCH; }
 
 // MODE: see Stage3 (separate instantiations, not a runtime branch).
@@ -283,14 +296,14 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     float* stF1 = sF2 + 32 * LD;
     float* stF2 = stF1 + 32 * LD;
     float* sGam = stF2 + 32 * LD;
-    float* xch = sGam + 32;                         // [0, 2048): t of waves 0, 1; [2048, 6144): (u, C half) of waves 2, 3
+    float* xch = sGam + 32;                         // parked 32x32 tiles, 1024 floats each: t of wave 0, 1; u of wave 2, 3; the
+                                                    // covariance tile's K-halves of wave 0, 1; then the two "half is parked" flags
+    int* cflag = reinterpret_cast<int*>(xch + 6 * 1024);
 
     const int tid = threadIdx.x & 255, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int I0 = blockIdx.x * 32 + p.i_off, chunk = blockIdx.y;
     const int B = p.B, d = p.d;
-    const float n_off = (float)B * (float)(B - 1);
-    const float inv_noff = 1.0f / n_off;
 
     // the panels in two halves: T = {tB, tF1, tF2} (the target products), M = {Bm, F1, F2} (the M_i / covariance products and
     // every contraction)
@@ -304,22 +317,45 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     R.init(p.ld, tid);
 
     // ---- I-side fragments (registers, whole kernel) ----------------------------------------------------
-    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcT[op % 3], p.ld, I0, B, d, tid); });
-    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.store(op, dstT[op % 3], I0, B, d, tid); });
-    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcM[op % 3], p.ld, I0, B, d, tid); });
-    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.store(op, dstM[op % 3], I0, B, d, tid); });
+    // All four loads of the prologue -- both panel halves of the I block and of the first J tile -- are issued up front (the
+    // registers are free until the fragments exist): one global round trip instead of four.
+    const int jt_begin = chunk * p.jpc;
+    const int jt_end = min(jt_begin + p.jpc, p.njt);
+    // Tile order.  Exactly one tile of a column block holds diagonal entries (J0 == I0), and a contraction that can handle them
+    // costs the others vector-ALU work they do not need; a second instantiation chosen per tile makes hipcc keep ``out`` in two
+    // places and copy 64 registers per tile.  So the chunk's tiles are walked with the diagonal one (if the chunk has it) LAST,
+    // and the last iteration of every wave is peeled: the loop body knows there is no diagonal, the peeled copy checks.
+    const int ntl = jt_end - jt_begin;                      // tiles of this chunk (>= 1)
+    const int jdiag = I0 >> 5;
+    const bool has_diag = jdiag >= jt_begin && jdiag < jt_end;
+    auto tile_at = [&](int k) __attribute__((always_inline)) -> int {          // k-th tile of the walk, k clamped to the chunk
+        k = min(k, ntl - 1);
+        if (!has_diag) return jt_begin + k;
+        const int t = jt_begin + k;
+        return k == ntl - 1 ? jdiag : (t >= jdiag ? t + 1 : t);
+    };
+    Stage RT0;                                              // T panels of the first J tile (R: its M panels)
+    RT0.init(p.ld, tid);
+    {
+        Stage RA, RB;
+        RA.init(p.ld, tid);
+        RB.init(p.ld, tid);
+        const int J0 = tile_at(grp) * 32;
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; RA.load(op, srcT[op % 3], p.ld, I0, B, d, tid); });
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; RB.load(op, srcM[op % 3], p.ld, I0, B, d, tid); });
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; RT0.load(op, srcT[op % 3], p.ld, J0, B, d, tid); });
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcM[op % 3], p.ld, J0, B, d, tid); });
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; RA.store(op, dstT[op % 3], I0, B, d, tid); });
+        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; RB.store(op, dstM[op % 3], I0, B, d, tid); });
+    }
+    if (tid < 2) cflag[tid] = 0;
     __syncthreads();
     float fa[KS], fb[KS];
-    float fh[4 * NQH + KT];          // role 2: this wave's half of K of B[I] (wave 2: the first KQ / 2 quads; wave 3: the others + the tail)
+    float fh[4 * NQH + KT];          // role 1: this wave's half of K of B[I] (wave 0: the first KQ / 2 quads; wave 1: the others + the tail)
     const int hq0 = (wid & 1) ? KQ / 2 : 0;
-    if (wid < 2) {                   // role 1, wave i: F_i[I], tF_i[I]
+    if (wid < 2) {                   // role 1, wave i: F_i[I], tF_i[I], half i of B[I]
         load_frag<KS, LD>(fa, wid == 0 ? sF1 : sF2, l31, h);
         load_frag<KS, LD>(fb, wid == 0 ? stF1 : stF2, l31, h);
-#pragma unroll
-        for (int i = 0; i < 4 * NQH + KT; ++i) fh[i] = 0.f;
-    } else {                         // role 2: B[I], tB[I]
-        load_frag<KS, LD>(fa, sBm, l31, h);
-        load_frag<KS, LD>(fb, stB, l31, h);
         const int nq = (wid & 1) ? NQH : KQ / 2;
 #pragma unroll
         for (int j = 0; j < NQH; ++j) {
@@ -329,6 +365,11 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < KT; ++i) fh[4 * NQH + i] = (wid & 1) ? sBm[l31 * LD + 8 * KQ + 2 * i + h] : 0.f;
+    } else {                         // role 2: B[I], tB[I]
+        load_frag<KS, LD>(fa, sBm, l31, h);
+        load_frag<KS, LD>(fb, stB, l31, h);
+#pragma unroll
+        for (int i = 0; i < 4 * NQH + KT; ++i) fh[i] = 0.f;
     }
     const int gcol = I0 + l31;                              // batch index of this lane's tile column
     const float gam_col = (gcol < B) ? p.discount[gcol] : 0.f;
@@ -345,25 +386,11 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
         for (int i = 0; i < 16; ++i) out[nt][i] = 0.f;
     float s_sq = 0.f, s_diag = 0.f, s_all = 0.f, s_tall = 0.f, s_csq = 0.f, s_cdiag = 0.f;
 
-    const int jt_begin = chunk * p.jpc;
-    const int jt_end = min(jt_begin + p.jpc, p.njt);
     const float* sFi = (wid & 1) ? sF2 : sF1;               // role 2, wave 2 + i: F_i[J]
-    float* my_x = wid < 2 ? xch + wid * 1024 : xch + 2048 + (wid - 2) * 2048;
-    const float* their_x = wid < 2 ? xch + (wid ^ 1) * 1024 : xch + 2048 + ((wid - 2) ^ 1) * 2048;
+    float* my_x = xch + wid * 1024;                         // this wave's target product, read by the other wave of the role
+    const float* their_x = xch + (wid ^ 1) * 1024;
+    float* my_c = xch + 4096 + (wid & 1) * 1024;            // role 1: this wave's K-half of the covariance tile
 
-    // Tile order.  Exactly one tile of a column block holds diagonal entries (J0 == I0), and a contraction that can handle them
-    // costs the others vector-ALU work they do not need; a second instantiation chosen per tile makes hipcc keep ``out`` in two
-    // places and copy 64 registers per tile.  So the chunk's tiles are walked with the diagonal one (if the chunk has it) LAST,
-    // and the last iteration of every wave is peeled: the loop body knows there is no diagonal, the peeled copy checks.
-    const int ntl = jt_end - jt_begin;                      // tiles of this chunk (>= 1)
-    const int jdiag = I0 >> 5;
-    const bool has_diag = jdiag >= jt_begin && jdiag < jt_end;
-    auto tile_at = [&](int k) __attribute__((always_inline)) -> int {          // k-th tile of the walk, k clamped to the chunk
-        k = min(k, ntl - 1);
-        if (!has_diag) return jt_begin + k;
-        const int t = jt_begin + k;
-        return k == ntl - 1 ? jdiag : (t >= jdiag ? t + 1 : t);
-    };
     const int niter = (ntl + NG - 1) / NG;                  // group g takes the positions g, g + NG, ...; every group runs niter
                                                             // iterations (the barriers are workgroup-wide), a group without a
                                                             // tile in the last one only keeps the others company
@@ -373,12 +400,7 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     //   phase A(tile): R (= M panels of this tile) -> M slots;  R <- T panels of the next tile
     //   phase B(tile): R (= T panels of the next tile) -> T slots;  R <- M panels of the next tile
     // each op riding behind one MFMA of a product.  Before the loop: T panels of the first tile in LDS, its M panels in R.
-    {
-        const int J0 = tile_at(grp) * 32;
-        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcT[op % 3], p.ld, J0, B, d, tid); });
-        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.store(op, dstT[op % 3], J0, B, d, tid); });
-        static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; R.load(op, srcM[op % 3], p.ld, J0, B, d, tid); });
-    }
+    static_for<NOPS>([&](auto oc) __attribute__((always_inline)) { constexpr int op = decltype(oc)::value; RT0.store(op, dstT[op % 3], tile_at(grp) * 32, B, d, tid); });
 
     // One loop per ROLE (the waves of a role run identical code: what differs between them is pointers and offsets), so the
     // accumulators of a role are updated in straight-line code.  Every barrier below is executed by all waves of the workgroup
@@ -412,11 +434,14 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
             }
             __syncthreads();                                    // M(tile), gamma and the target products in LDS; the T slots are free
             if (live) {
-                // ---- phase B: (role 2) this wave's half of K of the covariance tile C[r][c] = B[J0+r] . B[I0+c]
-                // (fb_ddpg.py:344-348), parked; then the M_i tile
-                if constexpr (ROLE == 2) {
+                // ---- phase B.  Role 1 first computes its half of K of the covariance tile C[r][c] = B[J0+r] . B[I0+c]
+                // (fb_ddpg.py:344-348) for role 2, parks it and raises its flag (LDS operations of a wave complete in order: the
+                // flag is visible after the tile); role 2 needs it only at the end of the phase, ~100 MFMAs later, and checks
+                // the flags there -- no third workgroup barrier, and the two roles carry 189 / 196 MFMAs per tile at d = 100.
+                if constexpr (ROLE == 1) {
                     const floatx16 Ch = mm_steps<NQH, KT>(sBm + l31 * LD + 4 * h + 8 * hq0, sBm + l31 * LD + 8 * KQ + h, fh, NoSide());
-                    put16(my_x + 1024, Ch, lane);
+                    put16(my_c, Ch, lane);
+                    __hip_atomic_store(cflag + (wid & 1), it + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 auto side = [&](auto sc, auto nc) __attribute__((always_inline)) {
                     constexpr int sidx = decltype(sc)::value, n = decltype(nc)::value;
@@ -428,9 +453,6 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
                     });
                 };
                 G = tile_mm<KS, LD>(ROLE == 1 ? sBm : sFi, fa, l31, h, side);
-            }
-            __syncthreads();                                    // covariance halves in LDS
-            if (live) {
                 const bool dtile = DIAG && (J0 == I0);
                 const floatx16 t2 = get16(their_x, lane);
                 if constexpr (ROLE == 1) {
@@ -477,9 +499,11 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
                     // C = B B^T  =>  dB = ortho * (Hm + Hm^T) B = ortho * 2 * Hm . B.  With ortho2 = 2*ortho the tile
                     // coefficient is ortho2 * Hm = 2 * (ortho2*C/N_off) resp. 2 * (-ortho2/B).  Wave 2 owns accumulator
                     // registers 0..7 = tile rows 0-3, 8-11 (+ 4 h) -- scalar sums and contraction --, wave 3 registers 8..15 =
-                    // the same rows + 16; C = half of wave 2 + half of wave 3.
+                    // the same rows + 16; C = half of wave 0 + half of wave 1.
+                    while (__hip_atomic_load(cflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= it ||
+                           __hip_atomic_load(cflag + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= it) {}
                     const int half = wid & 1;
-                    const float* cA = xch + 2048 + 1024 + half * 512, * cB = xch + 2048 + 2048 + 1024 + half * 512;
+                    const float* cA = xch + 4096 + half * 512, * cB = xch + 5120 + half * 512;
                     float cc[8];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
@@ -510,10 +534,8 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
     };
     if (wid < 2) run(std::integral_constant<int, 1>{});
     else run(std::integral_constant<int, 2>{});
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out[nt][i] *= inv_noff;
+    // (``out`` still lacks the factor 1 / N_off: pairwise_reduce_kernel applies it -- no vector-ALU use of the accumulators here,
+    //  or hipcc carries them through the loop in scattered VGPRs and copies 64 registers into MFMA tuples per tile)
     __syncthreads();                                        // (the hand-off below reuses the panels)
 
     if constexpr (NG > 1) {
@@ -553,13 +575,16 @@ __global__ void __launch_bounds__(256 * NG) pairwise_kernel(const PwArgs p) {
         for (int reg = 0; reg < 16; ++reg) dst[(size_t)acc_row(reg, h) * DP + nt * 32 + l31] = out[nt][reg];
 
     float* sc = p.scal + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PW_SCAL;
-    s_sq = wsum(s_sq); s_diag = wsum(s_diag); s_all = wsum(s_all); s_tall = wsum(s_tall);
-    s_csq = wsum(s_csq); s_cdiag = wsum(s_cdiag);
-    if (lane == 0) {
-        if (wid == 0) { sc[0] = s_sq; sc[1] = s_diag; sc[2] = s_all; sc[3] = s_tall; }
-        if (wid == 1) { sc[4] = s_sq; sc[5] = s_diag; }
-        if (wid == 2) { sc[6] = s_csq; sc[7] = s_cdiag; }
-        if (wid == 3) { sc[8] = s_csq; sc[9] = s_cdiag; }
+    if (wid < 2) {
+        const double a = wsum_d(s_sq), b = wsum_d(s_diag), c = wsum_d(s_all), e = wsum_d(s_tall);
+        if (lane == 0) {
+            put_hilo(sc, 4 * wid, a);
+            put_hilo(sc, 4 * wid + 1, b);
+            if (wid == 0) { put_hilo(sc, 2, c); put_hilo(sc, 3, e); }
+        }
+    } else {
+        const double a = wsum_d(s_csq), b = wsum_d(s_cdiag);
+        if (lane == 0) { put_hilo(sc, 6 + 2 * (wid - 2), a); put_hilo(sc, 7 + 2 * (wid - 2), b); }
     }
 }
 
@@ -584,6 +609,7 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
                 const int n = lane + 64 * i;
                 float a = 0.f, b = 0.f, c = 0.f;
                 if (n < d) {
+#pragma unroll 4
                     for (int ch = 0; ch < nchunks; ++ch) {
                         const float* base = partial + ((size_t)ch * PW_SLOTS * Bp + r) * DP + n;
                         a += base[0];
@@ -623,7 +649,8 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         for (int slot = wid; slot < 10; slot += 4) {
             double s = 0.0;
-            for (int bk = lane; bk < nblocks; bk += 64) s += (double)scal[(size_t)bk * PW_SCAL + slot];
+            for (int bk = lane; bk < nblocks; bk += 64)
+                s += (double)scal[(size_t)bk * PW_SCAL + slot] + (double)scal[(size_t)bk * PW_SCAL + 10 + slot];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
             if (lane == 0) tot[slot] = s;
@@ -765,7 +792,7 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     if (d > 128 || (y != nullptr && (norms == nullptr || dy == nullptr))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a.partial, a.scal,
                        pl.nchunks, pl.nchunks * pl.nI, rows, pl.Bp, d, pl.dp, ld, B, ortho_coef, dF1, dF2, dB, metrics, adv,
-                       adv_which, y, norms, dy, out_scale);
+                       adv_which, y, norms, dy, out_scale / ((float)B * (float)(B - 1)));
     return hipGetLastError();
 }
 
