@@ -154,7 +154,11 @@ __device__ unsigned g_trace_hw[TRACE_WGS];
 // store/barrier/refill phase (PMC: 44-52 % MFMA busy); here the pipe-owning waves have nothing else to do.
 // (A deeper producer prefetch -- two chunks in flight behind the landing one -- was built and measured in round 1: ISA as intended,
 // 9 % slower on the step: the staging path is not latency-bound.  Removed in round 2; DESIGN.md section 9 keeps the record.)
-template <int WM, int WN, int WK, int BK>
+// CSUM: some problem of the launch wants the column sums of its A operand (bias gradients).  A template parameter, and the
+// consumers' LDS addresses are loop invariants of a loop unrolled over the two stages: a wave's own vector-ALU instructions do not
+// overlap its MFMAs (tools/mfma_shadow.hip: +5..8 cycles each), and the consumer chunk used to carry 16 adds for the sums and 14
+// address adds per 16 MFMAs.
+template <int WM, int WN, int WK, int BK, bool CSUM>
 __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     constexpr int BM = 32 * WM, BN = 32 * WN, BKT = BK * WK;
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
@@ -336,19 +340,18 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     float csum = 0.f;
 
     __syncthreads();                                                    // barrier #0
-    for (int it = 0; it < nt; ++it) {
+    auto chunk = [&](int it, const float* __restrict__ fa_, const float* __restrict__ fb_) __attribute__((always_inline)) {
         if (wid == 0) FBHIP_TR(0, it, 0);
-        const float* st = smem + (it & 1) * STAGE;
         float av[NF], bv[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            av[j] = st[frag_a + 2 * j * LDA_S];
-            bv[j] = st[frag_b + 2 * j * LDB_S];
+            av[j] = fa_[2 * j * LDA_S];
+            bv[j] = fb_[2 * j * LDB_S];
         }
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-            csum += av[j];
+            if constexpr (CSUM) csum += av[j];
         }
         // Pin the issue order: fragment reads run ahead of the MFMA pair that consumes them, so each s_waitcnt only
         // covers reads issued >= 128 MFMA-cycles earlier (ds_read_b32 pairs are merged into ds_read2_b32).
@@ -362,6 +365,17 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
         if (wid == 0) FBHIP_TR(0, it, 1);
         __syncthreads();
         if (wid == 0) FBHIP_TR(0, it, 2);
+    };
+    {
+        // (accumulating the sums only in the waves whose epilogue stores them -- a second copy of the loop behind a uniform
+        //  branch -- measured 1168 against 1183 update-steps/s: not done)
+        const float* a0 = smem + frag_a, * b0 = smem + frag_b, * a1 = smem + STAGE + frag_a, * b1 = smem + STAGE + frag_b;
+        int it = 0;
+        for (; it + 1 < nt; it += 2) {
+            chunk(it, a0, b0);
+            chunk(it + 1, a1, b1);
+        }
+        if (it < nt) chunk(it, a0, b0);
     }
 #ifdef FBHIP_TRACE
     __syncthreads();
@@ -718,9 +732,12 @@ hipError_t gemm_init() {
     if (done) return hipSuccess;
 #define X(id, wm, wn, wk, bk)                                                                                       \
     {                                                                                                                \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<wm, wn, wk, bk>),              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<wm, wn, wk, bk, false>),       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize,                               \
                                            (int)gemm_lds_bytes<wm, wn, wk, bk>());                                   \
+        if (e != hipSuccess) return e;                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<wm, wn, wk, bk, true>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<wm, wn, wk, bk>());  \
         if (e != hipSuccess) return e;                                                                               \
     }
     FBHIP_CFGS(X)
@@ -773,10 +790,13 @@ hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
         hipLaunchKernelGGL(gemm_dma_kernel<2>, grid, dim3(256 + 64 * DmaGeom<2>::NPW), DmaGeom<2>::LDS_BYTES, stream, g);
         return hipGetLastError();
     }
+    bool csum = false;
+    for (int i = 0; i < g.n; ++i) csum = csum || g.p[i].colsum != nullptr;
     switch (cfg) {
 #define X(id, wm, wn, wk, bk)                                                                                       \
     case id:                                                                                                         \
-        hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
+        if (csum) hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk, true>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
+        else hipLaunchKernelGGL((gemm_kernel<wm, wn, wk, bk, false>), grid, block, (gemm_lds_bytes<wm, wn, wk, bk>()), stream, g); \
         break;
         FBHIP_CFGS(X)
 #undef X

@@ -46,6 +46,59 @@ __global__ void __launch_bounds__(256) probe(unsigned long long* out, int iters,
     if ((threadIdx.x & 63) == 0) out[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// Two waves per SIMD: waves 0-3 of a 512-thread workgroup run the bare dependent MFMA chain, waves 4-7 spin on ONE kind of
+// instruction until the chain waves are done (flag in LDS).  What does the chain lose to a NEIGHBOUR wave's instruction stream?
+template <int KIND>
+__global__ void __launch_bounds__(512) neighbour(unsigned long long* out, int iters, float a, float b, float* sink) {
+    __shared__ __attribute__((aligned(16))) float lds[512 * 4];
+    __shared__ int done;
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    const int wid = threadIdx.x >> 6;
+    if (wid < 4) {
+        floatx16 acc;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        float s = 0.f;
+        for (int i = 0; i < 16; ++i) s += acc[i];
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        if (s == 12345.f) sink[0] = s;
+        if ((threadIdx.x & 63) == 0) { out[(size_t)blockIdx.x * 4 + wid] = t1 - t0; __hip_atomic_fetch_add(&done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    } else {
+        float x0 = a, x1 = b, x2 = a + 1, x3 = b + 1;
+        float4 w = make_float4(a, b, a, b);
+        float* my = lds + threadIdx.x * 4;
+        int guard = 0;
+        while (__hip_atomic_load(&done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 && guard < (1 << 22)) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                if (KIND == 1) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(x0) : "v"(x1)); asm volatile("v_add_f32 %0, %0, %1" : "+v"(x2) : "v"(x3)); }
+                if (KIND == 2) { *reinterpret_cast<float4*>(my) = w; asm volatile("" ::: "memory"); }
+                if (KIND == 3) asm volatile("s_nop 7");
+                if (KIND == 4) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(x1)); asm volatile("v_mov_b32 %0, %1" : "=v"(x2) : "v"(x3)); }
+            }
+            ++guard;
+        }
+        if (x0 + x2 == 12345.f) sink[1] = x0 + lds[3];
+    }
+}
+
+template <int KIND>
+void run_neighbour(const char* name, unsigned long long* d, float* sink) {
+    const int iters = 200, wgs = 256;
+    neighbour<KIND><<<wgs, 512>>>(d, iters, 1.0f, 0.5f, sink);
+    neighbour<KIND><<<wgs, 512>>>(d, iters, 1.0f, 0.5f, sink);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(wgs * 4);
+    (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    printf("neighbour wave spinning on %-18s: %7.1f cycles per MFMA of the chain wave (median)\n", name, (double)h[h.size() / 2] / (iters * 16.0));
+}
+
 template <int KIND, int N, int CHAINS>
 void run(const char* name, unsigned long long* d, float* sink) {
     const int iters = 200, wgs = 256;
@@ -71,5 +124,10 @@ int main() {
     run<4, 1, 1>("ds_read_b32", d, sink); run<4, 2, 1>("ds_read_b32", d, sink); run<4, 4, 1>("ds_read_b32", d, sink);
     run<6, 4, 1>("s_nop 3", d, sink); run<6, 8, 1>("s_nop 3", d, sink); run<6, 12, 1>("s_nop 3", d, sink);
     run<7, 8, 1>("v_accvgpr_mov", d, sink); run<7, 16, 1>("v_accvgpr_mov", d, sink);
+    run_neighbour<0>("nothing (flag poll)", d, sink);
+    run_neighbour<1>("v_add_f32", d, sink);
+    run_neighbour<4>("v_cndmask / v_mov", d, sink);
+    run_neighbour<2>("ds_write_b128", d, sink);
+    run_neighbour<3>("s_nop 7", d, sink);
     return 0;
 }
