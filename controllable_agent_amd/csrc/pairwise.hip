@@ -597,10 +597,12 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
                                                               float* __restrict__ metrics, StepState* adv, int adv_which,
                                                               const float* __restrict__ y, const float* __restrict__ norms,
                                                               float* __restrict__ dy, float out_scale) {
-    if (adv != nullptr && blockIdx.x == 0 && threadIdx.x == 255) step_advance_device(adv, adv_which);
+    // the LAST workgroup has no rows: it folds the scalar partials (and advances the step state) beside the row work of the others
+    const bool scalar_wg = blockIdx.x == gridDim.x - 1;
+    if (adv != nullptr && scalar_wg && threadIdx.x == 255) step_advance_device(adv, adv_which);
     // one wavefront per row (d <= 128: two elements per lane); with ``y`` the backward of B = sqrt(d) y / |y|
     // (dy = (sqrt(d)/|y|)(dB - yhat (yhat . dB)), exactly l2norm_bwd_kernel) follows in the same registers
-    {
+    if (!scalar_wg) {
         const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
         if (r < B) {
             float cc[2];
@@ -642,8 +644,8 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
             }
         }
     }
-    if (blockIdx.x == 0) {
-        // workgroup 0: wave w folds scalar slots w, w+4, w+8 over all workgroups -- each lane a strided slice in
+    if (scalar_wg) {
+        // wave w folds scalar slots w, w+4, w+8 over all workgroups -- each lane a strided slice in
         // fp64, then a fixed xor-shuffle tree (deterministic)
         __shared__ double tot[12];
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -790,7 +792,7 @@ hipError_t launch_pairwise_fb_block(const float* F1, const float* F2, const floa
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (d > 128 || (y != nullptr && (norms == nullptr || dy == nullptr))) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a.partial, a.scal,
+    hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((rows + 3) / 4 + 1), dim3(256), 0, s, a.partial, a.scal,
                        pl.nchunks, pl.nchunks * pl.nI, rows, pl.Bp, d, pl.dp, ld, B, ortho_coef, dF1, dF2, dB, metrics, adv,
                        adv_which, y, norms, dy, out_scale / ((float)B * (float)(B - 1)));
     return hipGetLastError();
