@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) probe(unsigned long long* out, int iters,
 
 // Two waves per SIMD: waves 0-3 of a 512-thread workgroup run the bare dependent MFMA chain, waves 4-7 spin on ONE kind of
 // instruction until the chain waves are done (flag in LDS).  What does the chain lose to a NEIGHBOUR wave's instruction stream?
-template <int KIND>
+template <int KIND, int CHAIN>
 __global__ void __launch_bounds__(512) neighbour(unsigned long long* out, int iters, float a, float b, float* sink) {
     __shared__ __attribute__((aligned(16))) float lds[512 * 4];
     __shared__ int done;
@@ -56,15 +56,32 @@ __global__ void __launch_bounds__(512) neighbour(unsigned long long* out, int it
     __syncthreads();
     const int wid = threadIdx.x >> 6;
     if (wid < 4) {
-        floatx16 acc;
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        // CHAIN 0: no MFMA (sleep); 1: one dependent chain; 2: four independent accumulators; 3 / 4: dependent chain with 2 / 3
+        // s_nop 15 between two MFMAs; 5: dependent chain at s_setprio 0 against neighbours at s_setprio 3; 6: s_sleep 1 between MFMAs
+        floatx16 acc, acc1, acc2, acc3;
+        for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc1[i] = 0.f; acc2[i] = 0.f; acc3[i] = 0.f; }
+        if (CHAIN == 5) __builtin_amdgcn_s_setprio(0);
         const unsigned long long t0 = __builtin_readcyclecounter();
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            for (int j = 0; j < 16; ++j) {
+                if (CHAIN == 0) __builtin_amdgcn_s_sleep(16);
+                else if (CHAIN == 2) {
+                    if ((j & 3) == 0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                    if ((j & 3) == 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc1, 0, 0, 0);
+                    if ((j & 3) == 2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
+                    if ((j & 3) == 3) acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc3, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+                    if (CHAIN == 3) { asm volatile("s_nop 15\n s_nop 15"); }
+                    if (CHAIN == 4) { asm volatile("s_nop 15\n s_nop 15\n s_nop 15"); }
+                    if (CHAIN == 6) __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         float s = 0.f;
-        for (int i = 0; i < 16; ++i) s += acc[i];
+        for (int i = 0; i < 16; ++i) s += acc[i] + acc1[i] + acc2[i] + acc3[i];
         const unsigned long long t1 = __builtin_readcyclecounter();
         if (s == 12345.f) sink[0] = s;
         if ((threadIdx.x & 63) == 0) { out[(size_t)blockIdx.x * 4 + wid] = t1 - t0; __hip_atomic_fetch_add(&done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -72,7 +89,9 @@ __global__ void __launch_bounds__(512) neighbour(unsigned long long* out, int it
         float x0 = a, x1 = b, x2 = a + 1, x3 = b + 1;
         float4 w = make_float4(a, b, a, b);
         float* my = lds + threadIdx.x * 4;
+        if (CHAIN == 5) __builtin_amdgcn_s_setprio(3);
         int guard = 0;
+        const unsigned long long n0 = __builtin_readcyclecounter();
         while (__hip_atomic_load(&done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 && guard < (1 << 22)) {
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
@@ -83,20 +102,28 @@ __global__ void __launch_bounds__(512) neighbour(unsigned long long* out, int it
             }
             ++guard;
         }
+        const unsigned long long n1 = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0) { out[1024 + (size_t)blockIdx.x * 8 + 2 * (wid - 4)] = n1 - n0; out[1024 + (size_t)blockIdx.x * 8 + 2 * (wid - 4) + 1] = (unsigned long long)guard; }
         if (x0 + x2 == 12345.f) sink[1] = x0 + lds[3];
     }
 }
 
-template <int KIND>
+template <int KIND, int CHAIN = 1>
 void run_neighbour(const char* name, unsigned long long* d, float* sink) {
     const int iters = 200, wgs = 256;
-    neighbour<KIND><<<wgs, 512>>>(d, iters, 1.0f, 0.5f, sink);
-    neighbour<KIND><<<wgs, 512>>>(d, iters, 1.0f, 0.5f, sink);
+    neighbour<KIND, CHAIN><<<wgs, 512>>>(d, iters, 1.0f, 0.5f, sink);
+    neighbour<KIND, CHAIN><<<wgs, 512>>>(d, iters, 1.0f, 0.5f, sink);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(wgs * 4);
     (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
-    printf("neighbour wave spinning on %-18s: %7.1f cycles per MFMA of the chain wave (median)\n", name, (double)h[h.size() / 2] / (iters * 16.0));
+    std::vector<unsigned long long> nb(wgs * 8);
+    (void)hipMemcpy(nb.data(), d + 1024, nb.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<double> per;
+    for (int i = 0; i < wgs * 4; ++i) if (nb[2 * i + 1] > 0) per.push_back((double)nb[2 * i] / ((double)nb[2 * i + 1] * 32.0));
+    std::sort(per.begin(), per.end());
+    printf("neighbour wave spinning on %-18s: %7.1f cycles per MFMA of the chain wave; the neighbour: %6.1f cycles per loop slot (median)\n", name,
+           (double)h[h.size() / 2] / (iters * 16.0), per.empty() ? 0.0 : per[per.size() / 2]);
 }
 
 template <int KIND, int N, int CHAINS>
@@ -113,7 +140,7 @@ void run(const char* name, unsigned long long* d, float* sink) {
 
 int main() {
     unsigned long long* d; float* sink;
-    (void)hipMalloc(&d, 1024 * 8); (void)hipMalloc(&sink, 16);
+    (void)hipMalloc(&d, (1024 + 2048) * 8); (void)hipMalloc(&sink, 16);
     run<0, 0, 1>("bare", d, sink);
     run<0, 0, 4>("bare", d, sink);
     run<1, 4, 1>("v_add dependent", d, sink);  run<1, 8, 1>("v_add dependent", d, sink);  run<1, 12, 1>("v_add dependent", d, sink);
@@ -129,5 +156,15 @@ int main() {
     run_neighbour<4>("v_cndmask / v_mov", d, sink);
     run_neighbour<2>("ds_write_b128", d, sink);
     run_neighbour<3>("s_nop 7", d, sink);
+    run_neighbour<1, 0>("v_add_f32 (NO chain)", d, sink);
+    run_neighbour<2, 0>("ds_write (NO chain)", d, sink);
+    run_neighbour<1, 2>("v_add_f32 (4 accs)", d, sink);
+    run_neighbour<2, 2>("ds_write (4 accs)", d, sink);
+    run_neighbour<1, 3>("v_add_f32 (2 nops)", d, sink);
+    run_neighbour<1, 4>("v_add_f32 (3 nops)", d, sink);
+    run_neighbour<2, 4>("ds_write (3 nops)", d, sink);
+    run_neighbour<1, 5>("v_add_f32 (setprio)", d, sink);
+    run_neighbour<2, 5>("ds_write (setprio)", d, sink);
+    run_neighbour<1, 6>("v_add_f32 (s_sleep 1)", d, sink);
     return 0;
 }
