@@ -14,15 +14,21 @@
 // registers across the J loop:
 //   role 1 (waves 0,1; I plays s, J plays t):  T = B[J] . F_i[I]^T  = M_i[s,t]^T  -> dF_i[I] += G_i^T-contract . B[J]
 //   role 2 (waves 2,3; I plays t, J plays s):  P = F_i[J] . B[I]^T  = M_i[s,t]    -> dB[I]  += G_i  -contract . F_i[J]
-//   cov    (waves 2 and 3, half each):         C = B[J] . B[I]^T (symmetric)      -> dB[I]  += 2 c_o H-contract . B[J]
+//   cov    (product: role 1, half of K per wave; contraction: role 2, half of the rows per wave):
+//                                                C = B[J] . B[I]^T (symmetric)      -> dB[I]  += 2 c_o H-contract . B[J]
 // I-side operands live in registers as MFMA B-fragments for the whole kernel; J-side tiles are staged in LDS and
 // shared by the four waves.  Partial results over J-chunks go to a scratch buffer and are folded in a fixed
-// order by pairwise_reduce_kernel (deterministic; no atomics).  Scalar sums are wave-shuffle reduced.
+// order by pairwise_reduce_kernel (deterministic; no atomics).  Scalar sums: fp64 wave sums, (hi, lo) float partials.
 //
-// Every wave computes ONE of the two target products of its role (wave i the one with target F_i) and the two waves of a role
-// swap them through LDS (min(t1, t2) is what both need); the covariance tile is computed half of K by wave 2 and half by wave 3,
-// swapped the same way, and each contracts one half of its rows -- every wave has the same work in every iteration (the
-// workgroup-wide barrier per J tile makes the slowest wave of an ITERATION the pace, not the average).
+// Balance.  Every wave computes ONE of the two target products of its role (wave i the one with target F_i) and the two waves of
+// a role swap them through LDS (min(t1, t2) is what both need).  The covariance PRODUCT is computed by the role-1 waves (half of K
+// each, parked in LDS behind a flag), its CONTRACTION by the role-2 waves (half of the tile rows each) -- 2.5 products + 1
+// contraction for role 1, 2 products + 1.5 contractions for role 2 (189 / 196 MFMAs per tile at d = 100) and two workgroup
+// barriers per tile: a barrier makes the slowest wave of an ITERATION the pace, not the average.
+//
+// Vector-ALU work.  A wave's own v_* instructions do not overlap its MFMAs (tools/mfma_shadow.hip; LDS and global instructions
+// do), and at d = 100 the registers allow one wave per SIMD: staging, epilogue and bookkeeping are arranged so that the tile loop
+// holds almost none (see Stage3, mm_steps, contract_gen and the kernel body).
 //
 // LDS panels are [32][LD], LD = W + 4: a lane reads its row's k values four at a time (ds_read_b128; row stride = 4 banks, so
 // 8 lanes cover the 32 banks: conflict-free) and a quad feeds four MFMAs -- the k order of the contraction is permuted
