@@ -352,6 +352,7 @@ int fbhip_bind_buffers(fbhip_ctx* c, float* fb_params, float* fb_grads, float* f
     HIPCK(c, gemm_init());
     HIPCK(c, inverse_prepare());
     if (has_actor) HIPCK(c, actor_head_bwd_prepare(c->d.hidden_dim, c->d.action_dim));
+    if (has_actor) HIPCK(c, policy_head_prepare(c->d.hidden_dim, c->d.action_dim, head_width(c->d)));
     c->bound = true;
     return FBHIP_OK;
 }

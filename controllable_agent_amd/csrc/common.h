@@ -130,7 +130,15 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
 // policy head (premu = p . W4^T + b4, na = a or 2a outputs) + policy_sample in one row kernel (policy_head_kernel)
 bool policy_head_ok(int H, int na);
 constexpr int PH_MAX_JOBS = 2;
-struct PolicyHeadJob { const float* P; int ldp; float* premu; const float* noise; float* mu; float* action; int lda; };
+struct PolicyHeadJob { const float* P; int ldp; float* premu; const float* noise; float* mu; float* action; int lda;
+    // optional (base != nullptr): the FIRST layer of the ForwardMap trunk that consumes the action, finished in the same kernel.
+    // ``base`` [rows, H] holds W1[:, :aoff] . x + b1 (a GEMM that does not need the action: off the dependency chain); the kernel
+    // adds W1[:, aoff + j] action[j], applies LayerNorm + tanh (exactly ln_tanh_fwd_kernel's arithmetic) and writes t1; with
+    // ``stats`` also the full pre-activation (in place, over base) and (mean, rstd) for a later LayerNorm backward.
+    const float* base; int ldb; const float* W1a; int ldw1; const float* gamma; const float* beta; float* t1; int ldt1; float* stats; };
+// the fused first layer needs H % 256 == 0, H <= 2048 and (na + a) * H floats of LDS (<= 96 KB)
+bool policy_first_ok(int H, int a, int na);
+hipError_t policy_head_prepare(int H, int a, int na);   // raises the dynamic-LDS limit (not inside a stream capture)
 struct PolicyHeadJobs { PolicyHeadJob j[PH_MAX_JOBS]; int n; };
 hipError_t launch_policy_head(const PolicyHeadJobs& jobs, const float* W4, int ldw4, const float* b4, int ldpre, int ldn,
                               float stddev, float clip, int ldmu, int rows, int H, int a, int na, Squash sq, hipStream_t s);

@@ -220,7 +220,11 @@ int run_program(fbhip_ctx* c, Program& p, hipStream_t s);
 
 void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
                            int rows, Chain& out, bool with_heads = true, int disc_mode = 0, const float* disc_z = nullptr,
-                           int disc_ldz = 0);
+                           int disc_ldz = 0, int oa_base_k = 0, int part = 0);
+// oa_base_k > 0: the obs_action trunk's first layer is finished by the policy-head kernel (PolicyHeadJob::base): the chain's first
+// round holds only its action-free part (K = oa_base_k input columns), its LayerNorm round only the other trunk.
+// part 1: only what does NOT depend on the action (that first round, the obs_z trunk up to its half of h: three rounds);
+// part 2: only what does (the obs_action trunk's second layer onward), for a caller that ran part 1 earlier
 int forward_map_fwd(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S, int rows, hipStream_t s);
 void backward_map_fwd_chain(fbhip_ctx* c, const BwdP& W, const float* X, int ldx, BSet& S, int rows, Chain& out,
                             bool with_projection = true, int in_dim = -1);     // in_dim: input width if not goal_dim (mu_net)

@@ -713,7 +713,10 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
 // LDS.  NA is a template parameter and every load is unconditional (see actor_head_bwd_kernel).
 // Up to PH_MAX_JOBS row sets share the launch (blockIdx.y): the target chain's actor(next_obs) and update_actor's actor(obs)
 // reach their heads in the same round.
-template <int NA>
+// MAXQ > 0: jobs may carry the first layer of the trunk that consumes the action (PolicyHeadJob::base; H = 256 MAXQ): policy head,
+// sample, rank-a update of the pre-activation, LayerNorm and tanh for one row per wave -- three launches of the critical path
+// (policy head, K = 32 GEMM, LayerNorm) in one.
+template <int NA, int MAXQ>
 __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs jobs, const float* __restrict__ W4, int ldw4,
                                                           const float* __restrict__ b4, int ldpre, int ldn, float stddev,
                                                           float clip, int ldmu, int rows, int H, int a, const Squash sq) {
@@ -725,7 +728,31 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
     float* __restrict__ mu = jb.mu;
     float* __restrict__ action = jb.action;
     const int lda = jb.lda;
-    extern __shared__ float ph_lds[];              // [NA][H]
+    extern __shared__ float ph_lds[];              // [NA][H] (+ [a][H]: the action columns of the first layer's weight, transposed)
+    const bool first = MAXQ > 0 && jb.base != nullptr;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (same stores)
+    float4 pre[MAXQ > 0 ? MAXQ : 1], gm[MAXQ > 0 ? MAXQ : 1], bt[MAXQ > 0 ? MAXQ : 1];
+    if constexpr (MAXQ > 0) {
+        if (first) {
+            float* sW1 = ph_lds + (size_t)NA * H;
+            for (int n = threadIdx.x; n < H; n += 256) {
+                float v[NA];
+#pragma unroll
+                for (int jj = 0; jj < NA; ++jj) v[jj] = jb.W1a[(size_t)n * jb.ldw1 + min(jj, a - 1)];
+#pragma unroll
+                for (int jj = 0; jj < NA; ++jj) if (jj < a) sW1[(size_t)jj * H + n] = v[jj];
+            }
+            // the row's base values and the LayerNorm parameters: in flight under the head's dot products
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                const int n0 = 4 * (lane + 64 * i);
+                pre[i] = *reinterpret_cast<const float4*>(jb.base + (size_t)row * jb.ldb + n0);
+                gm[i] = *reinterpret_cast<const float4*>(jb.gamma + n0);
+                bt[i] = *reinterpret_cast<const float4*>(jb.beta + n0);
+            }
+        }
+    }
     for (int k4 = threadIdx.x; k4 < H / 4; k4 += 256) {
         float4 v[NA];
 #pragma unroll
@@ -734,8 +761,6 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
         for (int jj = 0; jj < NA; ++jj) reinterpret_cast<float4*>(ph_lds + (size_t)jj * H)[k4] = v[jj];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (same stores)
     constexpr int U = 4;
     float acc[NA];
 #pragma unroll
@@ -780,7 +805,57 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
             act = fminf(fmaxf(m + e, lo), hi);
         }
         if (action != nullptr) action[(size_t)row * lda + lane] = act;
+        mine = act;
     }
+    if constexpr (MAXQ > 0) {
+        if (!first) return;
+        // pre += W1[:, aoff + j] * action[j]   (lane j < a holds action[j] in ``mine``)
+        const float* sW1 = ph_lds + (size_t)NA * H;
+#pragma unroll
+        for (int jj = 0; jj < NA; ++jj) {
+            if (jj < a) {
+                const float aj = __shfl(mine, jj);
+#pragma unroll
+                for (int i = 0; i < MAXQ; ++i) {
+                    const float4 wv = *reinterpret_cast<const float4*>(sW1 + (size_t)jj * H + 4 * (lane + 64 * i));
+                    pre[i].x += aj * wv.x; pre[i].y += aj * wv.y; pre[i].z += aj * wv.z; pre[i].w += aj * wv.w;
+                }
+            }
+        }
+        // LayerNorm + tanh: ln_tanh_fwd_kernel's arithmetic (n = H, every quad whole)
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) sm += (pre[i].x + pre[i].y) + (pre[i].z + pre[i].w);
+        const float mean = wave_sum(sm) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const float4 cc = make_float4(pre[i].x - mean, pre[i].y - mean, pre[i].z - mean, pre[i].w - mean);
+            q += (cc.x * cc.x + cc.y * cc.y) + (cc.z * cc.z + cc.w * cc.w);
+        }
+        const float var = wave_sum(q) / (float)H;            // biased, like nn.LayerNorm
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int n0 = 4 * (lane + 64 * i);
+            float4 o;
+            o.x = tanhf((pre[i].x - mean) * rstd * gm[i].x + bt[i].x);
+            o.y = tanhf((pre[i].y - mean) * rstd * gm[i].y + bt[i].y);
+            o.z = tanhf((pre[i].z - mean) * rstd * gm[i].z + bt[i].z);
+            o.w = tanhf((pre[i].w - mean) * rstd * gm[i].w + bt[i].w);
+            *reinterpret_cast<float4*>(jb.t1 + (size_t)row * jb.ldt1 + n0) = o;
+            if (jb.stats != nullptr) *reinterpret_cast<float4*>(const_cast<float*>(jb.base) + (size_t)row * jb.ldb + n0) = pre[i];
+        }
+        if (jb.stats != nullptr && lane == 0) {
+            jb.stats[2 * row] = mean;
+            jb.stats[2 * row + 1] = rstd;
+        }
+    }
+}
+
+bool policy_first_ok(int H, int a, int na) {
+    return policy_head_ok(H, na) && (H == 512 || H == 1024 || H == 2048) && a >= 1 && a <= na &&
+           (size_t)(na + a) * H * sizeof(float) <= 96 * 1024;
 }
 
 // exact widths with an instantiation: the walker / quadruped / test actors and their 2a-wide boltzmann heads
@@ -789,22 +864,47 @@ bool policy_head_ok(int H, int na) {
     return inst && (H & 3) == 0 && (size_t)na * H * sizeof(float) <= 48 * 1024;
 }
 
+#define PH_FOR_EACH(X) X(3, 0) X(6, 0) X(12, 0) X(24, 0) X(3, 2) X(6, 2) X(12, 2) X(24, 2) X(3, 4) X(6, 4) X(12, 4) X(24, 4) X(3, 8) X(6, 8) X(12, 8) X(24, 8)
+hipError_t policy_head_prepare(int H, int a, int na) {
+    if (!policy_first_ok(H, a, na)) return hipSuccess;
+    const int bytes = (int)((size_t)(na + a) * H * sizeof(float));
+    if (bytes <= 48 * 1024) return hipSuccess;
+#define PH_ATTR(NB, Q)                                                                                                    \
+    if (Q > 0) {                                                                                                          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_head_kernel<NB, Q>),                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                        \
+        if (e != hipSuccess) return e;                                                                                    \
+    }
+    PH_FOR_EACH(PH_ATTR)
+#undef PH_ATTR
+    return hipSuccess;
+}
+
 hipError_t launch_policy_head(const PolicyHeadJobs& jobs, const float* W4, int ldw4, const float* b4, int ldpre, int ldn,
                               float stddev, float clip, int ldmu, int rows, int H, int a, int na, Squash sq, hipStream_t s) {
     if (!policy_head_ok(H, na) || (na != a && na != 2 * a) || (ldw4 & 3) || jobs.n < 1 || jobs.n > PH_MAX_JOBS)
         return hipErrorInvalidValue;
-#define PH_LAUNCH(NB)                                                                                                     \
-    hipLaunchKernelGGL(policy_head_kernel<NB>, dim3((rows + 3) / 4, jobs.n), dim3(256), (size_t)na * H * sizeof(float), s, jobs,  \
-                       W4, ldw4, b4, ldpre, ldn, stddev, clip, ldmu, rows, H, a, sq)
-    switch (na) {
-        case 3: PH_LAUNCH(3); break;
-        case 6: PH_LAUNCH(6); break;
-        case 12: PH_LAUNCH(12); break;
-        case 24: PH_LAUNCH(24); break;
-        default: return hipErrorInvalidValue;
+    bool first = false;
+    for (int i = 0; i < jobs.n; ++i) {
+        const PolicyHeadJob& j = jobs.j[i];
+        if (j.base == nullptr) continue;
+        first = true;
+        if (!policy_first_ok(H, a, na) || j.W1a == nullptr || j.gamma == nullptr || j.beta == nullptr || j.t1 == nullptr ||
+            (j.ldb & 3) || (j.ldt1 & 3) || ((uintptr_t)j.base & 15) || ((uintptr_t)j.t1 & 15) || ((uintptr_t)j.gamma & 15) ||
+            ((uintptr_t)j.beta & 15))
+            return hipErrorInvalidValue;
     }
+    const int q = first ? H / 256 : 0;
+    const size_t lds = (size_t)(na + (first ? a : 0)) * H * sizeof(float);
+#define PH_LAUNCH(NB, Q)                                                                                                  \
+    if (na == NB && q == Q) {                                                                                             \
+        hipLaunchKernelGGL((policy_head_kernel<NB, Q>), dim3((rows + 3) / 4, jobs.n), dim3(256), lds, s, jobs, W4, ldw4, b4, \
+                           ldpre, ldn, stddev, clip, ldmu, rows, H, a, sq);                                               \
+        return hipGetLastError();                                                                                         \
+    }
+    PH_FOR_EACH(PH_LAUNCH)
 #undef PH_LAUNCH
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -233,22 +233,33 @@ int run_program(fbhip_ctx* c, Program& p, hipStream_t s) {
 // ForwardMap.forward (fb_modules.py:186-199); Xa = [obs|action] panel, Xz = [obs|z] panel
 // (discrete: disc_mode 1 = target-side selection with z = disc_z, 2 = online-side gather of the sampled actions)
 void forward_map_fwd_chain(fbhip_ctx* c, const FwdP& W, const float* Xa, int lda, const float* Xz, int ldz, FSet& S,
-                           int rows, Chain& out, bool with_heads, int disc_mode, const float* disc_z, int disc_ldz) {
+                           int rows, Chain& out, bool with_heads, int disc_mode, const float* disc_z, int disc_ldz,
+                           int oa_base_k, int part) {
     const fbhip_dims& d = c->d;
     const Geom gm = geom_of(d);
     const int H = d.hidden_dim, z = d.z_dim, Lz = pad4(z), Fo = gm.Fo, hw = gm.hw, feat = gm.feat;
     FSet* Sp = &S;
-    out.push_back([=](Ops& o) {
-        o.gemms.push_back(P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, W.oa.ld1, W.oa.b1, EPI_BIAS));
-        if (!gm.single) o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
-    });
-    out.push_back([=](Ops& o) {
-        o.lnf.push_back(LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0, H});
-        if (!gm.single) o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
-    });
+    if (part != 2) {
+        out.push_back([=](Ops& o) {
+            o.gemms.push_back(P(Xa, lda, 1, W.oa.W1, W.oa.ld1, 1, Sp->pre1a.p, H, rows, H, oa_base_k > 0 ? oa_base_k : W.oa.ld1, W.oa.b1,
+                                EPI_BIAS));
+            if (!gm.single) o.gemms.push_back(P(Xz, ldz, 1, W.oz.W1, W.oz.ld1, 1, Sp->pre1z.p, H, rows, H, W.oz.ld1, W.oz.b1, EPI_BIAS));
+        });
+        out.push_back([=](Ops& o) {
+            if (oa_base_k <= 0) o.lnf.push_back(LnFwdProblem{Sp->pre1a.p, H, W.oa.g1, W.oa.be1, Sp->t1a.p, H, Sp->statsA, rows, H, 0, 0, 0, H});
+            if (!gm.single) o.lnf.push_back(LnFwdProblem{Sp->pre1z.p, H, W.oz.g1, W.oz.be1, Sp->t1z.p, H, Sp->statsZ, rows, H, 0, 0, 0, H});
+        });
+    }
+    if (part == 1) {
+        if (!gm.single)
+            out.push_back([=](Ops& o) {
+                o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fo, hw, rows, Fo, H, W.oz.b2, EPI_BIAS_RELU));
+            });
+        return;
+    }
     out.push_back([=](Ops& o) {
         o.gemms.push_back(P(Sp->t1a.p, H, 1, W.oa.W2, H, 1, Sp->h.p, hw, rows, Fo, H, W.oa.b2, EPI_BIAS_RELU));
-        if (!gm.single) o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fo, hw, rows, Fo, H, W.oz.b2, EPI_BIAS_RELU));
+        if (!gm.single && part != 2) o.gemms.push_back(P(Sp->t1z.p, H, 1, W.oz.W2, H, 1, Sp->h.p + Fo, hw, rows, Fo, H, W.oz.b2, EPI_BIAS_RELU));
     });
     // what feeds the heads: h [hw], or with a trunk layer relu(trunk(h)) [H]   (fb_modules.py:194-195)
     if (gm.trunk)
@@ -668,11 +679,20 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             return (int)FBHIP_OK;
         };
     }
-    auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst, ASet* set = nullptr) {
+    // fs / fw: the ForwardMap whose obs_action trunk consumes this action, when the head kernel is to finish that trunk's first layer
+    // (the chain was built with oa_base_k = aoff); keep_pre: the pass has a backward (pre-activation and LayerNorm statistics kept)
+    auto policy_stage = [=, &w](const float* noise, float* mu, float* action_dst, int ld_dst, ASet* set = nullptr,
+                                FSet* fs = nullptr, const FwdP* fw = nullptr, bool keep_pre = false) {
         ASet* S = set ? set : &w.as;
         return [=](Ops& o2) {
             if (fused_policy) {                  // all heads of a round go out as one launch (flush_round)
-                o2.ph.push_back(PolicyHeadJob{d.boltzmann ? S->h.p : S->p.p, H, S->premu.p, noise, mu, action_dst, ld_dst});
+                PolicyHeadJob jb{d.boltzmann ? S->h.p : S->p.p, H, S->premu.p, noise, mu, action_dst, ld_dst};
+                if (fs != nullptr) {
+                    jb.base = fs->pre1a.p; jb.ldb = H; jb.W1a = fw->oa.W1 + aoff; jb.ldw1 = fw->oa.ld1;
+                    jb.gamma = fw->oa.g1; jb.beta = fw->oa.be1; jb.t1 = fs->t1a.p; jb.ldt1 = H;
+                    jb.stats = keep_pre ? fs->statsA : nullptr;
+                }
+                o2.ph.push_back(jb);
                 return;
             }
             o2.post.push_back([=](hipStream_t q) -> int {
@@ -682,6 +702,8 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
             });
         };
     };
+    // the policy-head kernel finishes the first layer of the trunk that consumes its action (see PolicyHeadJob)
+    const bool fuse_first = fused_policy && !d.discrete && policy_first_ok(H, a, head_width(d));
 
     if (mask & FBHIP_PHASE_FB_FWD) {
         {
@@ -693,8 +715,17 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                 forward_map_fwd_chain(c, c->F_t, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0], true, 1, w.z.p, Lz);
             else if (mask & FBHIP_PHASE_FB_FWD_TARGET) {
                 actor_fwd_chain(c, c->A_p, w.Xnoz.p, w.Xnoz.ld, w.Xnoz.p, w.Xnoz.ld, w.asT, B, ch[0], !fused_policy);
-                ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
-                forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
+                if (fuse_first) {
+                    // what forward_target computes without the action -- the action-free part of the obs_action trunk's first
+                    // layer and the whole obs_z trunk -- is part of the ONLINE phase (below): like the online passes it depends on
+                    // the previous update only through its FB optimiser step.  Here: the head kernel finishes the obs_action
+                    // trunk's first layer, and the chain continues with that trunk's second layer.
+                    ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT, &w.fsT, &c->F_t));
+                    forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0], true, 0, nullptr, 0, aoff, 2);
+                } else {
+                    ch[0].push_back(policy_stage(w.so.eps_next, nullptr, w.Xnoa.p + aoff, w.Xnoa.ld, &w.asT));
+                    forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch[0]);
+                }
             }
             if ((mask & FBHIP_PHASE_FB_FWD_ONLINE) && d.discrete)      // discrete_fb.py:309-311
                 forward_map_fwd_chain(c, c->F_p, w.Xoz.p, w.Xoz.ld, w.Xoz.p, w.Xoz.ld, w.fsO, B, ch[1], true, 2);
@@ -704,6 +735,10 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                 ch.emplace_back();
                 actor_fwd_chain(c, c->A_p, w.Xo.p, w.Xo.ld, w.Xoz.p, w.Xoz.ld, w.as, B, ch.back(), !fused_policy);
                 ch.back().push_back(policy_stage(w.so.eps_actor, w.as.mu.p, w.Xopi.p + aoff, w.Xopi.ld));
+            }
+            if ((mask & FBHIP_PHASE_FB_FWD_ONLINE) && fuse_first) {      // forward_target without the action (see above)
+                ch.emplace_back();
+                forward_map_fwd_chain(c, c->F_t, w.Xnoa.p, w.Xnoa.ld, w.Xnoz.p, w.Xnoz.ld, w.fsT, B, ch.back(), true, 0, nullptr, 0, aoff, 1);
             }
             if ((mask & FBHIP_PHASE_FB_FWD_ONLINE) && !(mask & FBHIP_PHASE_SAMPLE)) {
                 ch.emplace_back();

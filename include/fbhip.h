@@ -50,8 +50,10 @@ enum { FBHIP_NET_FORWARD = 0, FBHIP_NET_BACKWARD = 1, FBHIP_NET_ACTOR = 2 };
 /* phases of one update(); a mask selects which are enqueued (multi-GPU inserts all-reduces between them) */
 enum {
     FBHIP_PHASE_SAMPLE = 1,      /* replay gather + z sampling + z mixing           (fb_ddpg.py:433-491) */
-    FBHIP_PHASE_FB_FWD_ONLINE = 2,   /* online F(obs, z, action) and the online / target B(next_goal) passes (fb_ddpg.py:312, 318-319):
-                                      * need this step's batch and z but NOT the previous actor step */
+    FBHIP_PHASE_FB_FWD_ONLINE = 2,   /* online F(obs, z, action), the online / target B(next_goal) passes (fb_ddpg.py:312, 318-319) and
+                                      * what forward_target computes without next_action (its obs_z trunk, the action-free part of
+                                      * its obs_action trunk's first layer): need this step's batch and z but NOT the previous actor
+                                      * step.  Runs before FB_FWD_TARGET of the same update (same call or an earlier one) */
     FBHIP_PHASE_FB_FWD_TARGET = 128, /* actor(next_obs) -> next_action -> forward_target (fb_ddpg.py:303-311) */
     FBHIP_PHASE_FB_FWD = 130,    /* = FB_FWD_ONLINE | FB_FWD_TARGET: everything up to the six embeddings F1 F2 B tF1 tF2 tB */
     FBHIP_PHASE_FB_BWD_A = 64,   /* pairwise loss (on the rows bound by fbhip_bind_global_batch when a global batch is bound) + the
