@@ -988,6 +988,15 @@ def test_trunk_inference_paths(flags):
     # the documented maxima of the kernels: hidden 2048 (LayerNorm row kernel), z_dim 128 (pairwise kernel)
     dict(obs_dim=40, action_dim=20, goal_dim=40, z_dim=128, hidden_dim=2048, feature_dim=1024, backward_hidden_dim=2048,
          batch_size=96),
+    # hidden 512 / action 3: the policy-head kernel finishes forward_target's first layer (rank-a update + LayerNorm + tanh) and
+    # forward_target's action-free half runs with the online passes -- in every topology variant
+    dict(obs_dim=11, action_dim=3, goal_dim=11, z_dim=12, hidden_dim=512, feature_dim=64, backward_hidden_dim=40, batch_size=48),
+    dict(obs_dim=11, action_dim=3, goal_dim=11, z_dim=12, hidden_dim=512, feature_dim=64, backward_hidden_dim=40, batch_size=48,
+         preprocess=False),
+    dict(obs_dim=11, action_dim=3, goal_dim=11, z_dim=12, hidden_dim=512, feature_dim=64, backward_hidden_dim=40, batch_size=48,
+         add_trunk=True),
+    dict(obs_dim=11, action_dim=3, goal_dim=11, z_dim=12, hidden_dim=512, feature_dim=64, backward_hidden_dim=40, batch_size=48,
+         boltzmann=True, temp=0.5),
 ])
 def test_one_update_at_the_edges_of_the_supported_dimensions(dims):
     """One injected update at degenerate, ragged and maximal dimensions: losses, gradients and post-step parameters against
