@@ -136,7 +136,7 @@ struct PolicyHeadJob { const float* P; int ldp; float* premu; const float* noise
     // adds W1[:, aoff + j] action[j], applies LayerNorm + tanh (exactly ln_tanh_fwd_kernel's arithmetic) and writes t1; with
     // ``stats`` also the full pre-activation (in place, over base) and (mean, rstd) for a later LayerNorm backward.
     const float* base; int ldb; const float* W1a; int ldw1; const float* gamma; const float* beta; float* t1; int ldt1; float* stats; };
-// the fused first layer needs H = 512 / 1024 / 2048 and (na + a) * H floats of LDS within 48 KB
+// the fused first layer needs H = 512 / 1024 / 2048 (and what the head itself needs: na * H floats of LDS within 48 KB)
 bool policy_first_ok(int H, int a, int na);
 hipError_t policy_head_prepare(int H, int a, int na);   // raises the dynamic-LDS limit (not inside a stream capture)
 struct PolicyHeadJobs { PolicyHeadJob j[PH_MAX_JOBS]; int n; };

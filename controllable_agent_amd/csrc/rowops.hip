@@ -728,21 +728,20 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
     float* __restrict__ mu = jb.mu;
     float* __restrict__ action = jb.action;
     const int lda = jb.lda;
-    extern __shared__ float ph_lds[];              // [NA][H] (+ [a][H]: the action columns of the first layer's weight, transposed)
+    extern __shared__ float ph_lds[];              // [NA][H]; later [a][H]: the action columns of the first layer's weight, transposed
     const bool first = MAXQ > 0 && jb.base != nullptr;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (same stores)
     float4 pre[MAXQ > 0 ? MAXQ : 1], gm[MAXQ > 0 ? MAXQ : 1], bt[MAXQ > 0 ? MAXQ : 1];
+    float w1r[MAXQ > 0 ? MAXQ : 1][NA];                              // W1[n][aoff + j], n = threadIdx.x + 256 i: parked in registers
     if constexpr (MAXQ > 0) {
         if (first) {
-            float* sW1 = ph_lds + (size_t)NA * H;
-            for (int n = threadIdx.x; n < H; n += 256) {
-                float v[NA];
+            // the action columns of the first layer's weight go through the SAME LDS bytes as W4, after the head's dot products
+            // (two more barriers, half the LDS: at quadruped dims 48 KB instead of 96): loaded now, written to LDS later
 #pragma unroll
-                for (int jj = 0; jj < NA; ++jj) v[jj] = jb.W1a[(size_t)n * jb.ldw1 + min(jj, a - 1)];
+            for (int i = 0; i < MAXQ; ++i)
 #pragma unroll
-                for (int jj = 0; jj < NA; ++jj) if (jj < a) sW1[(size_t)jj * H + n] = v[jj];
-            }
+                for (int jj = 0; jj < NA; ++jj) w1r[i][jj] = jb.W1a[(size_t)(threadIdx.x + 256 * i) * jb.ldw1 + min(jj, a - 1)];
             // the row's base values and the LayerNorm parameters: in flight under the head's dot products
 #pragma unroll
             for (int i = 0; i < MAXQ; ++i) {
@@ -808,9 +807,16 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
         mine = act;
     }
     if constexpr (MAXQ > 0) {
-        if (!first) return;
+        if (!first) return;                        // (uniform per workgroup: every wave of it takes the barriers below)
+        __syncthreads();                           // all waves are done with W4
+        float* sW1 = ph_lds;
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NA; ++jj)
+                if (jj < a) sW1[(size_t)jj * H + threadIdx.x + 256 * i] = w1r[i][jj];
+        __syncthreads();
         // pre += W1[:, aoff + j] * action[j]   (lane j < a holds action[j] in ``mine``)
-        const float* sW1 = ph_lds + (size_t)NA * H;
 #pragma unroll
         for (int jj = 0; jj < NA; ++jj) {
             if (jj < a) {
@@ -853,12 +859,8 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
     }
 }
 
-// (na + a) * H floats of LDS within 48 KB: at quadruped dims (a = 12, H = 1024: 96 KB, one workgroup per CU, every workgroup filling
-// 96 KB before its four rows) the fused kernel takes 41 us against ~30 for the three launches it replaces (597.9 vs 609.6
-// update-steps/s): refused there
 bool policy_first_ok(int H, int a, int na) {
-    return policy_head_ok(H, na) && (H == 512 || H == 1024 || H == 2048) && a >= 1 && a <= na &&
-           (size_t)(na + a) * H * sizeof(float) <= 48 * 1024;
+    return policy_head_ok(H, na) && (H == 512 || H == 1024 || H == 2048) && a >= 1 && a <= na;
 }
 
 // exact widths with an instantiation: the walker / quadruped / test actors and their 2a-wide boltzmann heads
@@ -869,17 +871,7 @@ bool policy_head_ok(int H, int na) {
 
 #define PH_FOR_EACH(X) X(3, 0) X(6, 0) X(12, 0) X(24, 0) X(3, 2) X(6, 2) X(12, 2) X(24, 2) X(3, 4) X(6, 4) X(12, 4) X(24, 4) X(3, 8) X(6, 8) X(12, 8) X(24, 8)
 hipError_t policy_head_prepare(int H, int a, int na) {
-    if (!policy_first_ok(H, a, na)) return hipSuccess;
-    const int bytes = (int)((size_t)(na + a) * H * sizeof(float));
-    if (bytes <= 48 * 1024) return hipSuccess;
-#define PH_ATTR(NB, Q)                                                                                                    \
-    if (Q > 0) {                                                                                                          \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_head_kernel<NB, Q>),                     \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                        \
-        if (e != hipSuccess) return e;                                                                                    \
-    }
-    PH_FOR_EACH(PH_ATTR)
-#undef PH_ATTR
+    (void)H; (void)a; (void)na;                    // na * H floats <= 48 KB (policy_head_ok): no limit to raise
     return hipSuccess;
 }
 
@@ -898,7 +890,7 @@ hipError_t launch_policy_head(const PolicyHeadJobs& jobs, const float* W4, int l
             return hipErrorInvalidValue;
     }
     const int q = first ? H / 256 : 0;
-    const size_t lds = (size_t)(na + (first ? a : 0)) * H * sizeof(float);
+    const size_t lds = (size_t)na * H * sizeof(float);
 #define PH_LAUNCH(NB, Q)                                                                                                  \
     if (na == NB && q == Q) {                                                                                             \
         hipLaunchKernelGGL((policy_head_kernel<NB, Q>), dim3((rows + 3) / 4, jobs.n), dim3(256), lds, s, jobs, W4, ldw4, b4, \
