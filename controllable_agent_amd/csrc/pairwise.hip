@@ -617,12 +617,26 @@ __global__ void __launch_bounds__(256) pairwise_reduce_kernel(const float* __res
                 const int n = lane + 64 * i;
                 float a = 0.f, b = 0.f, c = 0.f;
                 if (n < d) {
-#pragma unroll 4
-                    for (int ch = 0; ch < nchunks; ++ch) {
-                        const float* base = partial + ((size_t)ch * PW_SLOTS * Bp + r) * DP + n;
-                        a += base[0];
-                        b += base[(size_t)Bp * DP];
-                        c += base[(size_t)2 * Bp * DP] + base[(size_t)3 * Bp * DP];
+                    // eight chunks' partials in flight at once (clamped index, masked add; same summation order): written as a
+                    // plain loop hipcc waits for every chunk's loads before it issues the next chunk's -- 2 x nchunks round trips
+                    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+                        float xa[8], xb[8], xc[8], xd[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int ch = min(c0 + u, nchunks - 1);
+                            const float* base = partial + ((size_t)ch * PW_SLOTS * Bp + r) * DP + n;
+                            xa[u] = base[0];
+                            xb[u] = base[(size_t)Bp * DP];
+                            xc[u] = base[(size_t)2 * Bp * DP];
+                            xd[u] = base[(size_t)3 * Bp * DP];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool on = c0 + u < nchunks;
+                            a += on ? xa[u] : 0.f;
+                            b += on ? xb[u] : 0.f;
+                            c += on ? xc[u] + xd[u] : 0.f;
+                        }
                     }
                     a *= out_scale; b *= out_scale; c *= out_scale;
                     dF1[(size_t)r * ld + n] = a;
