@@ -639,7 +639,13 @@ __device__ __forceinline__ void colreduce_job(const ColReduceJobs& cr, int b) {
     const int j = bx * 32 + c;
     float s = 0.f;
     if (j < 2 * n)
-        for (int q = rg; q < nb; q += 8) s += cr.partials[pi][(size_t)q * 2 * n + j];
+        for (int q0 = rg; q0 < nb; q0 += 64) {             // eight partial rows in flight at once (same summation order)
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = cr.partials[pi][(size_t)min(q0 + 8 * u, nb - 1) * 2 * n + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (q0 + 8 * u < nb) ? x[u] : 0.f;
+        }
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && j < 2 * n) {
@@ -664,8 +670,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g, c
     const int mn = M * N;
     if (idx < mn) {
         const int row = idx / N, col = idx % N;
+        // eight slices in flight at once (clamped index, masked add; same summation order): as a plain loop every slice costs a
+        // round trip of its own
         float v = 0.f;
-        for (int s = 0; s < ks; ++s) v += p.partial[(size_t)s * mn + idx];
+        for (int s0 = 0; s0 < ks; s0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p.partial[(size_t)min(s0 + u, ks - 1) * mn + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (s0 + u < ks) ? x[u] : 0.f;
+        }
         const int epi = p.epi;
         if (epi == EPI_BIAS) {
             v += p.bias[col];
@@ -681,7 +695,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g, c
     } else if (p.colsum != nullptr && idx < mn + M) {
         const int r = idx - mn;
         float v = 0.f;
-        for (int s = 0; s < ks; ++s) v += p.partial[(size_t)ks * mn + (size_t)s * M + r];
+        for (int s0 = 0; s0 < ks; s0 += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p.partial[(size_t)ks * mn + (size_t)min(s0 + u, ks - 1) * M + r];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += (s0 + u < ks) ? x[u] : 0.f;
+        }
         p.colsum[r] = v;
     }
 }

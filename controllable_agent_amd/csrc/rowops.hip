@@ -304,7 +304,13 @@ __global__ void __launch_bounds__(256) ln_colreduce_kernel(const LnBwdGroup grp)
     if (blockIdx.x * 32 >= 2 * n) return;
     float s = 0.f;
     if (j < 2 * n)
-        for (int b = rg; b < nb; b += 8) s += p.partials[(size_t)b * 2 * n + j];
+        for (int b0 = rg; b0 < nb; b0 += 64) {              // eight partial rows in flight at once (same summation order)
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p.partials[(size_t)min(b0 + 8 * u, nb - 1) * 2 * n + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (b0 + 8 * u < nb) ? x[u] : 0.f;
+        }
     red[rg][c] = s;
     __syncthreads();
     if (rg == 0 && j < 2 * n) {
