@@ -601,6 +601,9 @@ __global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict
 //   d p_i[s] = (dF_i[s] W4_i) * relu'(p_i) = -(w_i[s] / B) V_i[s] * (p_i[s] > 0)          (dF_i = -z w_i / B)
 // i.e. the heads' output GEMM + its split-K reduce, the loss kernel and the heads' data-gradient GEMM collapse into this
 // one row kernel: one wavefront per row reads p [B, 2H] and V [B, 2H] and overwrites V with d p.
+// QM: float4 quads per lane and half row, H <= 256 QM: the rows of p and V are read ONCE, every load in flight before the first
+// use (as loops over k: 2 x H / 256 dependent round trips)
+template <int QM>
 __global__ void __launch_bounds__(256) actor_q_kernel(const float* __restrict__ P, int ldp_, float* __restrict__ V, int ldv,
                                                       const float* __restrict__ z, int ldz,
                                                       const float* __restrict__ b41, const float* __restrict__ b42,
@@ -620,10 +623,19 @@ __global__ void __launch_bounds__(256) actor_q_kernel(const float* __restrict__ 
         float4* v1 = reinterpret_cast<float4*>(V + (size_t)row * ldv);
         float4* v2 = reinterpret_cast<float4*>(V + (size_t)row * ldv + H);
         float q1 = 0.f, q2 = 0.f;
-        for (int k = lane; k < H / 4; k += 64) {
-            const float4 a1 = p1[k], c1 = v1[k], a2 = p2[k], c2 = v2[k];
-            q1 += a1.x * c1.x + a1.y * c1.y + a1.z * c1.z + a1.w * c1.w;
-            q2 += a2.x * c2.x + a2.y * c2.y + a2.z * c2.z + a2.w * c2.w;
+        const int nq = H / 4;
+        float4 A1[QM], C1[QM], A2[QM], C2[QM];
+#pragma unroll
+        for (int i = 0; i < QM; ++i) {
+            const int k = min(lane + 64 * i, nq - 1);
+            A1[i] = p1[k]; C1[i] = v1[k]; A2[i] = p2[k]; C2[i] = v2[k];
+        }
+#pragma unroll
+        for (int i = 0; i < QM; ++i) {
+            if (lane + 64 * i < nq) {
+                q1 += A1[i].x * C1[i].x + A1[i].y * C1[i].y + A1[i].z * C1[i].z + A1[i].w * C1[i].w;
+                q2 += A2[i].x * C2[i].x + A2[i].y * C2[i].y + A2[i].z * C2[i].z + A2[i].w * C2[i].w;
+            }
         }
         for (int j = lane; j < d; j += 64) {
             const float zz = z[(size_t)row * ldz + j];
@@ -635,14 +647,18 @@ __global__ void __launch_bounds__(256) actor_q_kernel(const float* __restrict__ 
         // torch.min(Q1, Q2) backward: all of the gradient to the strict arg-min, split evenly on exact ties
         const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f), w2 = 1.f - w1;
         const float s1 = -inv_b * w1, s2 = -inv_b * w2;
-        for (int k = lane; k < H / 4; k += 64) {
-            const float4 a1 = p1[k], a2 = p2[k];
-            float4 c1 = v1[k], c2 = v2[k];
-            c1.x = a1.x > 0.f ? s1 * c1.x : 0.f; c1.y = a1.y > 0.f ? s1 * c1.y : 0.f;
-            c1.z = a1.z > 0.f ? s1 * c1.z : 0.f; c1.w = a1.w > 0.f ? s1 * c1.w : 0.f;
-            c2.x = a2.x > 0.f ? s2 * c2.x : 0.f; c2.y = a2.y > 0.f ? s2 * c2.y : 0.f;
-            c2.z = a2.z > 0.f ? s2 * c2.z : 0.f; c2.w = a2.w > 0.f ? s2 * c2.w : 0.f;
-            v1[k] = c1; v2[k] = c2;
+#pragma unroll
+        for (int i = 0; i < QM; ++i) {
+            const int k = lane + 64 * i;
+            if (k < nq) {
+                const float4 a1 = A1[i], a2 = A2[i];
+                float4 c1 = C1[i], c2 = C2[i];
+                c1.x = a1.x > 0.f ? s1 * c1.x : 0.f; c1.y = a1.y > 0.f ? s1 * c1.y : 0.f;
+                c1.z = a1.z > 0.f ? s1 * c1.z : 0.f; c1.w = a1.w > 0.f ? s1 * c1.w : 0.f;
+                c2.x = a2.x > 0.f ? s2 * c2.x : 0.f; c2.y = a2.y > 0.f ? s2 * c2.y : 0.f;
+                c2.z = a2.z > 0.f ? s2 * c2.z : 0.f; c2.w = a2.w > 0.f ? s2 * c2.w : 0.f;
+                v1[k] = c1; v2[k] = c2;
+            }
         }
         if (lane < a && sq.on) {                   // SquashedNormal.log_prob(action) with the cached pre-image (utils.py:212-215)
             const float loc = pre[(size_t)row * ldp + lane], e = noise[(size_t)row * ldn + lane];
@@ -704,8 +720,12 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
     if ((H & 3) || (ldp_ & 3) || (ldv & 3) || a > 64 || scratch == nullptr) return hipErrorInvalidValue;
     if (sq.on && (pre == nullptr || noise == nullptr)) return hipErrorInvalidValue;
     const int nblk = (rows + 3) / 4;
-    hipLaunchKernelGGL(actor_q_kernel, dim3(nblk), dim3(256), 0, s, P, ldp_, V, ldv, z, ldz, b41, b42, mu, ldmu, action, lda,
-                       stddev, scratch, rows, H, d, a, sq, pre, ldp, noise, ldn, adv, adv_which);
+    if (H > 2048 || ((uintptr_t)P & 15) || ((uintptr_t)V & 15)) return hipErrorInvalidValue;
+#define AQ_LAUNCH(QM)                                                                                                     \
+    hipLaunchKernelGGL(actor_q_kernel<QM>, dim3(nblk), dim3(256), 0, s, P, ldp_, V, ldv, z, ldz, b41, b42, mu, ldmu, action, lda, \
+                       stddev, scratch, rows, H, d, a, sq, pre, ldp, noise, ldn, adv, adv_which)
+    if (H <= 256) { AQ_LAUNCH(1); } else if (H <= 512) { AQ_LAUNCH(2); } else if (H <= 1024) { AQ_LAUNCH(4); } else { AQ_LAUNCH(8); }
+#undef AQ_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
     hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17,
@@ -766,7 +786,7 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
         for (int jj = 0; jj < NA; ++jj) reinterpret_cast<float4*>(ph_lds + (size_t)jj * H)[k4] = v[jj];
     }
     __syncthreads();
-    constexpr int U = 4;
+    constexpr int U = MAXQ > 0 ? 4 * MAXQ : 4;      // MAXQ > 0: H = 256 MAXQ, the whole row of P in flight at once (one round trip)
     float acc[NA];
 #pragma unroll
     for (int jj = 0; jj < NA; ++jj) acc[jj] = 0.f;
@@ -968,6 +988,7 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (no early exit: same stores)
     constexpr int U = 4;                                            // elements per lane per batch of loads
     float acc[AHB_N];
+    float pva[LNE > 0 ? LNE : 1];
 #pragma unroll
     for (int jj = 0; jj < AHB_N; ++jj) acc[jj] = 0.f;
     if constexpr (LNE > 0) {
@@ -979,6 +1000,7 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
             const int mc = min(lane + 64 * i, H - 1);
             dyv[i] = dt1[(size_t)row * ldt + mc]; yv[i] = lnY[(size_t)row * ldy + mc]; xv[i] = lnX[(size_t)row * ldx + mc];
             gam[i] = lnGamma[mc];
+            pva[i] = P[(size_t)row * ldp_ + mc];   // (for the last loop: in flight with everything else of the row)
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1028,6 +1050,19 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
 #pragma unroll
         for (int jj = 0; jj < AHB_N; ++jj) v = (jj == lane) ? acc[jj] : v;
         dpremu[(size_t)row * ldd + lane] = v;
+    }
+    if constexpr (LNE > 0) {
+#pragma unroll
+        for (int i = 0; i < LNE; ++i) {
+            const int k = lane + 64 * i;
+            const int kc = min(k, H - 1);
+            float v = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < AHB_N; ++jj)
+                if (EXACT || jj < a) v += acc[jj] * sW4[(size_t)jj * H + kc];
+            if (k < H) dp[(size_t)row * lddp + k] = pva[i] > 0.f ? v : 0.f;
+        }
+        return;
     }
     for (int k0 = lane; k0 < H; k0 += 64 * U) {
         float pv[U];
