@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
         const bool second = i >= split_quad;
         const float ss = second ? ss2 : ss1;
         float4 gg = g[i], mm = m[i], vv = v[i], pp = p[i];
+        float4 tt = (tgt != nullptr ? tgt : p)[i];          // (in flight with the other four streams, not behind the stores)
         const float4 p0 = pp;
 #define ADAM1(c)                                                         \
         {                                                                \
@@ -57,7 +58,6 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float4* __restrict__ p, c
 #undef ADAM1
         m[i] = mm; v[i] = vv; p[i] = pp;
         if (tgt != nullptr) {
-            float4 tt = tgt[i];
             // (sf.py:237 TransitionLatentModel: the learner's own target net is moved inside its forward(), i.e. towards the
             // parameters BEFORE phi_opt.step(), at its own fixed rate)
             const float4 src = (second && ema_before2) ? p0 : pp;
