@@ -111,6 +111,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx
     const int epi = p.epi;
     const float bias = (epi == EPI_BIAS || epi == EPI_BIAS_RELU) ? p.bias[col] : 0.f;
     float* __restrict__ C = p.C;
+    // the sixteen aux values of this lane FIRST (clamped rows), then the stores: read inside the store loop every row waits for
+    // its own load AND for the previous row's store (vmcnt counts both) -- sixteen dependent round trips per tile
+    float ax[16];
+    if (epi == EPI_MASK_RELU || epi == EPI_TANH_BWD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            ax[r] = p.aux[(size_t)min(row, M - 1) * p.ldaux + col];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -121,10 +134,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx
             } else if (epi == EPI_BIAS_RELU) {
                 v = fmaxf(v + bias, 0.f);
             } else if (epi == EPI_MASK_RELU) {
-                v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
+                v = ax[r] > 0.f ? v : 0.f;
             } else if (epi == EPI_TANH_BWD) {
-                const float y = p.aux[(size_t)row * p.ldaux + col];
-                v = v * (1.f - y * y);
+                v = v * (1.f - ax[r] * ax[r]);
             }
             C[(size_t)row * p.ldc + col] = v;
         }
