@@ -759,6 +759,11 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (same stores)
     float4 pre[MAXQ > 0 ? MAXQ : 1], gm[MAXQ > 0 ? MAXQ : 1], bt[MAXQ > 0 ? MAXQ : 1];
+    float xrow[MAXQ > 0 ? 4 * MAXQ : 1];                              // MAXQ > 0: the row of P, requested before the LDS fill
+    if constexpr (MAXQ > 0) {
+#pragma unroll
+        for (int u = 0; u < 4 * MAXQ; ++u) xrow[u] = P[(size_t)row * ldp_ + min(lane + 64 * u, H - 1)];
+    }
     float w1r[MAXQ > 0 ? MAXQ : 1][NA];                              // W1[n][aoff + j], n = threadIdx.x + 256 i: parked in registers
     if constexpr (MAXQ > 0) {
         if (first) {
@@ -793,7 +798,10 @@ __global__ void __launch_bounds__(256) policy_head_kernel(const PolicyHeadJobs j
     for (int k0 = lane; k0 < H; k0 += 64 * U) {
         float x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = P[(size_t)row * ldp_ + min(k0 + 64 * u, H - 1)];
+        for (int u = 0; u < U; ++u) {
+            if constexpr (MAXQ > 0) x[u] = xrow[u];                   // (k0 == lane: the loop runs once)
+            else x[u] = P[(size_t)row * ldp_ + min(k0 + 64 * u, H - 1)];
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 64 * u;
@@ -958,6 +966,21 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     extern __shared__ float ahb_lds[];             // [a][H] (W1 action columns, transposed) then [a][H] (W4)
     float* sW1 = ahb_lds;
     float* sW4 = ahb_lds + (size_t)a * H;
+    // LNE > 0: everything this wave needs of its row is requested BEFORE the LDS fill (one round trip for both)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (no early exit: same stores)
+    float dyv[LNE > 0 ? LNE : 1], yv[LNE > 0 ? LNE : 1], xv[LNE > 0 ? LNE : 1], gam[LNE > 0 ? LNE : 1], pva[LNE > 0 ? LNE : 1];
+    float mean = 0.f, rstd = 0.f;
+    if constexpr (LNE > 0) {
+        mean = lnStats[2 * row]; rstd = lnStats[2 * row + 1];
+#pragma unroll
+        for (int i = 0; i < LNE; ++i) {
+            const int mc = min(lane + 64 * i, H - 1);
+            dyv[i] = dt1[(size_t)row * ldt + mc]; yv[i] = lnY[(size_t)row * ldy + mc]; xv[i] = lnX[(size_t)row * ldx + mc];
+            gam[i] = lnGamma[mc];
+            pva[i] = P[(size_t)row * ldp_ + mc];
+        }
+    }
     // Every global load below is UNCONDITIONAL (clamped index, mask at the use): hipcc otherwise waits for each load right
     // where a select meets it, and a 24-load fill becomes 24 round trips (measured: 27 us for this kernel).
     for (int m = threadIdx.x; m < H; m += 256) {
@@ -984,24 +1007,12 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
                 if (EXACT || jj < a) reinterpret_cast<float4*>(sW4 + (size_t)jj * H)[kk] = reinterpret_cast<const float4*>(W4 + (size_t)jj * ldw4)[kk];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (no early exit: same stores)
     constexpr int U = 4;                                            // elements per lane per batch of loads
     float acc[AHB_N];
-    float pva[LNE > 0 ? LNE : 1];
 #pragma unroll
     for (int jj = 0; jj < AHB_N; ++jj) acc[jj] = 0.f;
     if constexpr (LNE > 0) {
         // du = dy (1 - y^2); g = du gamma; dx = rstd (g - mean(g) - xhat mean(g xhat))      (ln_tanh_bwd_kernel, same math)
-        const float mean = lnStats[2 * row], rstd = lnStats[2 * row + 1];
-        float dyv[LNE], yv[LNE], xv[LNE], gam[LNE];
-#pragma unroll
-        for (int i = 0; i < LNE; ++i) {
-            const int mc = min(lane + 64 * i, H - 1);
-            dyv[i] = dt1[(size_t)row * ldt + mc]; yv[i] = lnY[(size_t)row * ldy + mc]; xv[i] = lnX[(size_t)row * ldx + mc];
-            gam[i] = lnGamma[mc];
-            pva[i] = P[(size_t)row * ldp_ + mc];   // (for the last loop: in flight with everything else of the row)
-        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LNE; ++i) {
