@@ -76,6 +76,8 @@ __global__ void __launch_bounds__(512) head_kernel(const HeadGroup g) {
     floatx4 acc[NTL];
 #pragma unroll
     for (int j = 0; j < NTL; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // the bias quad of the tile this wave finalises: requested now, used after the fold (not a round trip of its own at the end)
+    const float4 bias4 = ldg4(p.bias + min(16 * wave + 4 * kk, ((N + 3) & ~3) - 4));
 
     const int KT = (K + 31) >> 5;
     {
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(512) head_kernel(const HeadGroup g) {
             const float4 u = *reinterpret_cast<const float4*>(red + ((w * NTL + wave) * 64 + lane) * 4);
             yv.x += u.x; yv.y += u.y; yv.z += u.z; yv.w += u.w;
         }
-        const float4 b = ldg4(p.bias + c0);                               // bias readable up to pad4(N)
+        const float4 b = bias4;                                           // (c0 < N here: the clamp above did not move it)
         yv.x += b.x;
         yv.y = c0 + 1 < N ? yv.y + b.y : 0.f;
         yv.z = c0 + 2 < N ? yv.z + b.z : 0.f;
