@@ -684,6 +684,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g, c
         const int row = idx / N, col = idx % N;
         // eight slices in flight at once (clamped index, masked add; same summation order): as a plain loop every slice costs a
         // round trip of its own
+        // (the epilogue's operand is requested with the slices, not behind them)
+        const int epi = p.epi;
+        float eo = 0.f;
+        if (epi == EPI_BIAS || epi == EPI_BIAS_RELU) eo = p.bias[col];
+        else if (epi == EPI_MASK_RELU || epi == EPI_TANH_BWD) eo = p.aux[(size_t)row * p.ldaux + col];
         float v = 0.f;
         for (int s0 = 0; s0 < ks; s0 += 8) {
             float x[8];
@@ -692,16 +697,14 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g, c
 #pragma unroll
             for (int u = 0; u < 8; ++u) v += (s0 + u < ks) ? x[u] : 0.f;
         }
-        const int epi = p.epi;
         if (epi == EPI_BIAS) {
-            v += p.bias[col];
+            v += eo;
         } else if (epi == EPI_BIAS_RELU) {
-            v = fmaxf(v + p.bias[col], 0.f);
+            v = fmaxf(v + eo, 0.f);
         } else if (epi == EPI_MASK_RELU) {
-            v = p.aux[(size_t)row * p.ldaux + col] > 0.f ? v : 0.f;
+            v = eo > 0.f ? v : 0.f;
         } else if (epi == EPI_TANH_BWD) {
-            const float y = p.aux[(size_t)row * p.ldaux + col];
-            v = v * (1.f - y * y);
+            v = v * (1.f - eo * eo);
         }
         p.C[(size_t)row * p.ldc + col] = v;
     } else if (p.colsum != nullptr && idx < mn + M) {
