@@ -454,6 +454,7 @@ def main():
         os._exit(7)
 
     def barrier():
+        agent.flush()                             # update() calls the agent still holds back (deferred batching) go out first
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -528,7 +529,8 @@ def main():
         single = None
         if world == 1 and args.workload == "walker" and not args.no_single_update_probe and not args.global_batch:
             # what a reference workspace literally does: agent.update(replay_loader, step) once per loop iteration
-            # (train_offline.py:118) -- one graph launch per update, no cross-step pipelining
+            # (train_offline.py:118).  With metrics off the agent queues such calls and launches them as n-step graphs
+            # (FBHipAgent "deferred batching"); barrier() flushes the rest of the queue before it synchronises
             n1 = max(300, min(args.steps, 1000))
             for i in range(20):
                 agent.update(rb, i)
@@ -579,11 +581,17 @@ def main():
                                     "synthetic replay resident in HBM; metrics off"),
                        "steps_per_graph_launch": spl, "runtime_env": {"ROC_CPU_WAIT_FOR_SIGNAL": os.environ.get("ROC_CPU_WAIT_FOR_SIGNAL")}, **({"dp_loss": "global batch (mode B)" + (f", pretend world {args.pretend_world}" if args.pretend_world > 1 else "")} if args.global_batch else {}),
                        "global_batch": W["batch_size"] * world, "parallelism": f"dp{world}",
-                       **({"allreduce": "peer-access kernels inside the update graph (csrc/peer.hip)" if args.peer_allreduce else
-                           ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "RCCL via torch.distributed between phase graphs")} if world > 1 else {}),
+                       **({"allreduce": getattr(agent, "_dp_transport", None) or
+                                        ("peer-access kernels inside the update graph (csrc/peer.hip)" if args.peer_allreduce else
+                                         ("gloo (rehearsal)" if args.rehearse_on_one_gpu else "RCCL via torch.distributed between phase graphs"))} if world > 1 else {}),
                        "host_enqueue_ms_per_step": 1e3 * host_enqueue[mid] / args.steps,
                        **({"host_issue_ms_per_step_idle_queue": 1e3 * host_idle} if host_idle is not None else {}),
                        "updates_per_hour": 3600 * value, "steps_per_s_per_gpu": steps_per_s,
+                       # data parallel = gradient averaging: ONE optimiser step per global step, on a batch of world x B samples
+                       "global_steps_per_s": steps_per_s, "samples_per_s": world * W["batch_size"] * steps_per_s,
+                       **({"value_is": f"{world} ranks x {steps_per_s:.1f} per-rank update-steps/s of batch {W['batch_size']} each (weak scaling: "
+                                       f"batch-{W['batch_size']}-equivalents per second); the model itself makes global_steps_per_s "
+                                       "optimiser steps per second on the global batch"} if world > 1 else {}),
                        **({"single_update_steps_per_s": single} if single is not None else {})},
             "repeats": {"n": len(walls), "steps_each": args.steps, "reported": "median by wall time",
                         "wall_s": walls, "hip_event_s": events,

@@ -21,11 +21,13 @@ import logging
 import math
 import os
 import re
+import operator
 import typing as tp
 import weakref
 
 import numpy as np
 import torch
+import torch.distributed as _dist
 
 from . import _lib
 from ._lib import Dims, HParams, Inject, TensorDesc, check, ptr, stream_ptr
@@ -155,10 +157,13 @@ class NetView:
     for parameter access (``state_dict / load_state_dict / parameters / named_parameters / train``)."""
 
     def __init__(self, name: str, flat: torch.Tensor, layout: tp.List[TensorDesc],
-                 forward: tp.Optional[tp.Callable[[torch.Tensor], torch.Tensor]] = None) -> None:
+                 forward: tp.Optional[tp.Callable[[torch.Tensor], torch.Tensor]] = None,
+                 sync: tp.Optional[tp.Callable[[], None]] = None) -> None:
         self._name = name
         self._flat = flat
         self._forward = forward
+        # called before any access to the tensors: the agent launches the update() calls it still holds back (FBHipAgent.flush)
+        self._sync = sync if sync is not None else (lambda: None)
         self.training = True
         self._views: "collections.OrderedDict[str, torch.Tensor]" = collections.OrderedDict()
         self._pads: tp.List[torch.Tensor] = []        # the alignment columns right of every matrix (must stay zero)
@@ -171,17 +176,21 @@ class NetView:
             self._views[n] = seg[0] if (n.endswith("bias") or ".1." in n) else seg      # vectors: 1-D views
 
     def state_dict(self) -> "collections.OrderedDict[str, torch.Tensor]":
+        self._sync()
         return collections.OrderedDict(self._views)
 
     def pad_abs_max(self) -> float:
         """max |x| over the alignment columns.  The kernels run GEMMs over padded widths and rely on these being zero:
         anything else means a panel leaked foreign columns into a weight gradient."""
+        self._sync()
         return max([float(p.abs().max()) for p in self._pads], default=0.0)
 
     def named_parameters(self) -> tp.Iterator[tp.Tuple[str, torch.Tensor]]:
+        self._sync()
         return iter(self._views.items())
 
     def parameters(self) -> tp.Iterator[torch.Tensor]:
+        self._sync()
         return iter(self._views.values())
 
     def load_state_dict(self, sd: tp.Mapping[str, tp.Any], strict: bool = True) -> None:
@@ -189,6 +198,7 @@ class NetView:
         extra = set(sd) - set(self._views)
         if strict and (missing or extra):
             raise KeyError(f"{self._name}: missing {sorted(missing)}, unexpected {sorted(extra)}")
+        self._sync()
         with torch.no_grad():
             for k, v in self._views.items():
                 if k in sd:
@@ -403,19 +413,24 @@ class FBHipAgent:
         nf = self._numel[0]
         lay = {n: layout(i) for i, n in enumerate(("forward_net", "backward_net", "actor"))}
         seg = {"forward_net": slice(0, nf), "backward_net": slice(nf, nfb)}
-        self.forward_net = NetView("forward_net", self._fb_params[seg["forward_net"]], lay["forward_net"])
         me = weakref.ref(self)                   # (the views' callables must not keep the agent alive: no reference cycles, see AdamView)
+
+        def sync() -> None:                      # every access to the tensors first launches the update() calls still held back
+            a = me()
+            if a is not None:
+                a.flush()
+        self.forward_net = NetView("forward_net", self._fb_params[seg["forward_net"]], lay["forward_net"], sync=sync)
         self.backward_net = NetView("backward_net", self._fb_params[seg["backward_net"]], lay["backward_net"],
-                                    forward=lambda x: me()._backward_map(x, target=False))
-        self.forward_target_net = NetView("forward_target_net", self._fb_targets[seg["forward_net"]], lay["forward_net"])
+                                    forward=lambda x: me()._backward_map(x, target=False), sync=sync)
+        self.forward_target_net = NetView("forward_target_net", self._fb_targets[seg["forward_net"]], lay["forward_net"], sync=sync)
         self.backward_target_net = NetView("backward_target_net", self._fb_targets[seg["backward_net"]],
-                                           lay["backward_net"], forward=lambda x: me()._backward_map(x, target=True))
-        self.actor = NetView("actor", self._actor_params, lay["actor"])
+                                           lay["backward_net"], forward=lambda x: me()._backward_map(x, target=True), sync=sync)
+        self.actor = NetView("actor", self._actor_params, lay["actor"], sync=sync)
         self.encoder = torch.nn.Identity()      # states only (fb_ddpg.py:108-110)
         self.aug = torch.nn.Identity()
-        self._grad_views = {"forward_net": NetView("g", self._fb_grads[seg["forward_net"]], lay["forward_net"]),
-                            "backward_net": NetView("g", self._fb_grads[seg["backward_net"]], lay["backward_net"]),
-                            "actor": NetView("g", self._actor_grads, lay["actor"])}
+        self._grad_views = {"forward_net": NetView("g", self._fb_grads[seg["forward_net"]], lay["forward_net"], sync=sync),
+                            "backward_net": NetView("g", self._fb_grads[seg["backward_net"]], lay["backward_net"], sync=sync),
+                            "actor": NetView("g", self._actor_grads, lay["actor"], sync=sync)}
         self._adam_views = {
             "forward_net": {"m": NetView("m", self._fb_m[seg["forward_net"]], lay["forward_net"]).state_dict(),
                             "v": NetView("v", self._fb_v[seg["forward_net"]], lay["forward_net"]).state_dict()},
@@ -440,6 +455,7 @@ class FBHipAgent:
 
     def load_nets(self, nets: tp.Mapping[str, tp.Mapping[str, tp.Any]], copy_targets: bool = True) -> None:
         """Load {net: state_dict} (reference key names); targets start as copies (fb_ddpg.py:140-141)."""
+        self.flush()
         self._replicas_verified = False
         for n in (() if self._discrete else ("actor",)) + ("forward_net", "backward_net"):
             if n in nets:
@@ -469,7 +485,7 @@ class FBHipAgent:
 
     # ------------------------------------------------------------------ pickling (pretrain.py:437-449 pickles the agent object)
     def __getstate__(self) -> tp.Dict[str, tp.Any]:
-        self._drop_prefetch()
+        self.flush()
         fb, ac = self.step_counts()
         flat = {k: getattr(self, k).detach().cpu() for k in ("_fb_params", "_fb_m", "_fb_v", "_fb_targets",
                                                               "_actor_params", "_actor_m", "_actor_v")}
@@ -477,7 +493,7 @@ class FBHipAgent:
         # z draws and exploration noise of the first steps of training)
         # (the flat buffers are the library's PHYSICAL layout -- padded leading dimensions, 32-float matrix alignment --, which has
         # changed between rounds: the pickle says which one it holds)
-        return dict(layout_abi=int(_lib.load().fbhip_abi_version()), flat_numel={k: int(v.numel()) for k, v in flat.items()},
+        return dict(layout_abi=int(_lib.load().fbhip_abi_version()), layout_digest=self._layout_digest(), flat_numel={k: int(v.numel()) for k, v in flat.items()},
                     cfg=dataclasses.asdict(self.cfg), flat=flat, fb_steps=fb, actor_steps=ac, seed=self._seed,
                     rng_counts=self.rng_counts(), solved_meta=self.solved_meta, training=self.training, goal_dim=self.goal_dim)
 
@@ -491,6 +507,14 @@ class FBHipAgent:
         self._dims = self._make_dims()
         self._ctx, self._replay_token, self._ext_replay, self._use_graph, self._seed = None, None, None, True, st["seed"]
         self._allocate(None)
+        # the flat buffers are the library's PHYSICAL layout: a pickle is only loadable into the layout that wrote it.  The digest covers
+        # every tensor's (name, offset, rows, cols, ld); the element counts below stay as the guard for pickles older than the digest
+        if "layout_digest" in st and st["layout_digest"] != self._layout_digest():
+            raise RuntimeError(
+                f"FBHipAgent pickle was written with the flat parameter layout {st['layout_digest']} (library ABI {st.get('layout_abi', '?')}); "
+                f"this library (ABI {_lib.load().fbhip_abi_version()}) lays the same nets out as {self._layout_digest()}.  The flat buffers "
+                "are the physical, padded layout and are not portable across layouts: re-export the agent with the version that wrote "
+                "it through state_dict() of its nets / optimisers (name-based) and load_nets().")
         for k, v in st["flat"].items():
             if getattr(self, k).numel() != v.numel():
                 raise RuntimeError(
@@ -503,40 +527,56 @@ class FBHipAgent:
         if "rng_counts" in st:                   # (pickles of round 1 do not have it: those restart their streams)
             self.set_rng_counts(*st["rng_counts"])
 
+    def _layout_digest(self) -> str:
+        """sha1 over every tensor's (name, offset, rows, cols, ld) of the three flat segments: equal digests == same physical layout"""
+        import hashlib
+        lib, h = _lib.load(), hashlib.sha1()
+        for net in range(3):
+            for i in range(lib.fbhip_layout_count(C.byref(self._dims), net)):
+                t = TensorDesc()
+                check(lib.fbhip_layout_entry(C.byref(self._dims), net, i, C.byref(t)))
+                h.update(repr((net, t.name, int(t.offset), int(t.rows), int(t.cols), int(t.ld))).encode())
+        return h.hexdigest()[:16]
+
     # ------------------------------------------------------------------ small surface methods
     def train(self, training: bool = True) -> None:                      # fb_ddpg.py:161-164
+        self.flush()
         self.training = training
         for net in (() if self._discrete else (self.actor,)) + (self.forward_net, self.backward_net):
             net.train(training)
 
     def step_counts(self) -> tp.Tuple[int, int]:
+        self.flush()
         fb, ac = C.c_int32(), C.c_int32()
         check(_lib.load().fbhip_get_step_counts(self._ctx, C.byref(fb), C.byref(ac), stream_ptr()), self._ctx)
         return fb.value, ac.value
 
     def set_step_counts(self, fb_steps: int, actor_steps: int) -> None:
+        self.flush()
         check(_lib.load().fbhip_set_step_counts(self._ctx, int(fb_steps), int(actor_steps), stream_ptr()), self._ctx)
 
     def rng_counts(self) -> tp.Tuple[int, int]:
         """(update() calls drawn, fast-path act() calls drawn): the counters of the device Philox streams"""
-        self._drop_prefetch()
+        self.flush()
         u, a = C.c_uint32(), C.c_uint32()
         check(_lib.load().fbhip_get_rng_counts(self._ctx, C.byref(u), C.byref(a), stream_ptr()), self._ctx)
         return int(u.value), int(a.value)
 
     def set_rng_counts(self, update_count: int, act_count: int) -> None:
-        self._chain_token = self._chain_seen = None      # (a pending prefetched head is void: the counters are being overwritten)
+        self.flush()
         check(_lib.load().fbhip_set_rng_counts(self._ctx, int(update_count), int(act_count), stream_ptr()), self._ctx)
 
     def _join_fast_path_stream(self) -> None:
         """The batch-1 entry points launch on the agent's own stream.  Whatever last wrote the weights -- an update enqueued
         on the caller's (non-default) stream, ``load_state_dict`` / ``init_from`` copies -- was issued on torch's current
         stream: order the fast path behind it (an event, no host synchronisation)."""
+        self.flush()
         cur = torch.cuda.current_stream(self._device)
         if cur != self._stream:
             self._stream.wait_stream(cur)
 
     def init_from(self, other: tp.Any) -> None:                          # fb_ddpg.py:166-175
+        self.flush()
         self._replicas_verified = False
         names = [] if self._discrete else ["actor"]          # (discrete_fb.py:170-178 copies "encoder" only, + the FB nets)
         if self.cfg.init_fb:
@@ -596,6 +636,7 @@ class FBHipAgent:
 
     def _backward_map(self, goal: tp.Any, target: bool = False) -> torch.Tensor:
         """B(goal) with norm_z (fb_modules.py:223-230)"""
+        self.flush()
         g = self._dev(goal)
         assert g.shape[1] == self.goal_dim, (g.shape, self.goal_dim)
         out = torch.empty((g.shape[0], self.cfg.z_dim), device=self._device)
@@ -604,6 +645,7 @@ class FBHipAgent:
         return out
 
     def _forward_map(self, obs: torch.Tensor, z: torch.Tensor, action: torch.Tensor, target: bool = False):
+        self.flush()
         f1 = torch.empty((obs.shape[0], self.cfg.z_dim), device=self._device)
         f2 = torch.empty_like(f1)
         check(_lib.load().fbhip_forward_map(self._ctx, int(target), ptr(obs), obs.stride(0), ptr(z), z.stride(0),
@@ -613,6 +655,7 @@ class FBHipAgent:
 
     def _actor(self, obs: torch.Tensor, z: torch.Tensor, noise: tp.Optional[torch.Tensor], std: float,
                clip: tp.Optional[float]) -> torch.Tensor:
+        self.flush()
         out = torch.empty((obs.shape[0], self.action_dim), device=self._device)
         check(_lib.load().fbhip_actor_forward(self._ctx, ptr(obs), obs.stride(0), ptr(z), z.stride(0), obs.shape[0],
                                               ptr(noise), float(std), -1.0 if clip is None else float(clip), ptr(out),
@@ -735,6 +778,7 @@ class FBHipAgent:
                                             v["t1"], int(v["fixed_length"])), self._ctx)
         self._replay_view = v           # keeps the tensors alive while bound
         self._replay_token = token
+        self._replay_binds = self.__dict__.get("_replay_binds", 0) + 1
 
     def _run_update(self, hp: HParams, inject: tp.Optional[Inject], use_graph: bool) -> None:
         self._on_update_stream(lambda: self._launch_update(hp, inject, use_graph))
@@ -808,6 +852,7 @@ class FBHipAgent:
         after ``init_from`` / ``load_nets`` / unpickling on some ranks only -- anything that may leave replicas different.
         (The RNG seed stays per rank: ranks must draw different batches.)"""
         import torch.distributed as dist
+        self.flush()
         if self._world() < 2:
             return
         on_dev = dist.get_backend() == "nccl"
@@ -922,6 +967,17 @@ class FBHipAgent:
     def update(self, replay_loader: tp.Any, step: int) -> tp.Dict[str, float]:      # fb_ddpg.py:427-520
         if step % self.cfg.update_every_steps != 0:
             return {}
+        key = self._defer_key(replay_loader)
+        if key is not None:                      # metrics off, one rank, graphs allowed: the call is queued (see "deferred batching")
+            p = self.__dict__.get("_pending")
+            if p is not None and p[2] == key:
+                p[3] += 1
+                if p[3] >= self.DEFER_MAX:
+                    self.flush()
+                return {}
+            if self._defer_update(replay_loader, key, step):
+                return {}
+        self.flush()
         c = self.cfg
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
         if isinstance(replay_loader, DeviceReplayBuffer):
@@ -947,63 +1003,86 @@ class FBHipAgent:
             # a captured graph bakes stddev in: with a time-varying stddev_schedule (utils.py:235-255) every step would be a
             # fresh capture + instantiation (milliseconds), so those configurations run as eager launches instead
             graph_ok = self._use_graph and self._stddev_is_constant()
-            if graph_ok and self._chain_update(replay_loader, hp):
-                return self._metrics()
             self._run_update(hp, None, graph_ok)
         else:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)
         return self._metrics()
 
-    # ---- consecutive update() calls chain (fbhip_update_chained): the drop-in call of train_offline.py:118 at the pipelined rate
-    def _chain_state(self, rb: DeviceReplayBuffer, hp: HParams) -> tp.Tuple:
-        """Everything the validity of a prefetched head depends on: the replay contents (mutation counter), the hyper-parameters,
-        the caller's stream, and torch's version counters of the flat parameter / optimiser tensors -- every host-side in-place
-        write through a state_dict view, init_from, load_nets ... bumps them, the library's own kernels do not."""
-        flats = [self._fb_params, self._fb_targets, self._fb_m, self._fb_v] + ([] if self._discrete else [self._actor_params, self._actor_m, self._actor_v])
-        return (id(rb), rb._version, bytes(hp), tuple(t._version for t in flats), torch.cuda.current_stream(self._device).cuda_stream)
+    # ---- deferred batching: the drop-in call of train_offline.py:118 at the rate of the n-step graph
+    # With metrics off (the default, pretrain.py:58-60) ``update()`` returns {} and the reference's offline loop does nothing
+    # else between two calls (train_offline.py:116-119).  Such a call is QUEUED -- validated, counted, nothing launched -- and
+    # the queue goes out as ONE ``fbhip_update_many(k <= 32)`` when it is full or when anything is about to observe or change
+    # what the queued updates read or write: act / infer_meta / compute_z_correl / the batched inference entry points, any
+    # parameter or optimiser access through the net / optimiser views (state_dict, parameters, load_state_dict, init_from,
+    # pickling), the step / RNG counters, another update entry point, a call with other hyper-parameters, another replay
+    # buffer or another stream, and every mutation of the replay buffer (the buffer asks its observers to flush BEFORE it
+    # writes: queued updates sample the contents they were called on).  Same kernels, operands and draws as eager calls:
+    # the queue is exactly ``update_many`` over the same steps.  What cannot be intercepted is a bare
+    # ``torch.cuda.synchronize()`` (a caller timing the loop, say): ``agent.flush()`` is the explicit form.
+    DEFER_MAX = 32
+    # every cfg field the hyper-parameter struct, the metrics switch and the update cadence are made of (FBDDPGAgentConfig)
+    _hp_fields = operator.attrgetter("lr", "lr_coef", "fb_target_tau", "stddev_schedule", "stddev_clip", "ortho_coef", "mix_ratio",
+                                     "q_loss_coef", "q_loss", "future_ratio", "rand_weight", "use_tb", "use_wandb", "use_hiplog")
 
-    def _drop_prefetch(self) -> None:
-        """Another entry point is about to run (or the state changed): the head the last chained call prefetched will not be used.
-        It has consumed one value of the update RNG counter: give it back, so that the sequence of draws is the one of unchained
-        calls."""
-        self._chain_seen = None
-        if self.__dict__.get("_chain_token") is None:
-            return
-        self._chain_token = None
+    def _defer_key(self, rb: tp.Any) -> tp.Optional[tp.Tuple]:
+        """None when this call cannot be queued; else everything a queued update depends on besides the library's own state: the
+        replay contents (mutation counter) and its discount / future, the cfg fields behind the hyper-parameters, the caller's
+        stream, and torch's version counters of the flat parameter / optimiser tensors -- every host-side in-place write
+        through a state_dict view bumps them, the library's own kernels do not.  Equal keys == the call joins the queue (a few
+        microseconds per call: the host's share of a queued update)."""
+        d = self.__dict__
+        if (rb.__class__ is not DeviceReplayBuffer or not d.get("defer_updates", True) or not d["_use_graph"] or (_dist.is_available() and _dist.is_initialized()) or
+                os.environ.get("FBHIP_UPDATE_DEFER", "1") == "0" or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"):
+            return None
+        f = self._hp_fields(self.cfg)
+        if f[-1] or f[-2] or f[-3]:              # metrics on: the caller reads the result of THIS call
+            return None
+        return (id(rb), rb._version, rb._discount, rb._future, f, d["_fb_params"]._version, d["_fb_targets"]._version, d["_fb_m"]._version,
+                d["_fb_v"]._version, d["_actor_params"]._version, d["_actor_m"]._version, d["_actor_v"]._version,
+                torch._C._cuda_getCurrentRawStream(self._device.index))
 
-        def roll_back() -> None:
-            u, a = C.c_uint32(), C.c_uint32()
-            check(_lib.load().fbhip_get_rng_counts(self._ctx, C.byref(u), C.byref(a), stream_ptr()), self._ctx)
-            check(_lib.load().fbhip_set_rng_counts(self._ctx, int(u.value) - 1, int(a.value), stream_ptr()), self._ctx)
-        self._on_update_stream(roll_back)
-
-    def _chain_update(self, rb: DeviceReplayBuffer, hp: HParams) -> bool:
-        """One update through ``fbhip_update_chained`` when consecutive calls can chain -- one rank, an actor phase to prefetch
-        beside, and NOTHING changed since the previous update() call (a loop that adds transitions between updates, the online
-        loop of pretrain.py:559-659, therefore never chains and keeps sampling at update time like the reference).  The first
-        call of a run of unchanged state is a plain update, the second runs its own head and prefetches, from the third on the
-        head is already there: same kernels, operands and draws as ``update_many`` over the same steps, bit for bit.
-        OPT-IN (``FBHIP_UPDATE_CHAIN=1``): measured on MI355X / ROCm 7.0 (profiles/r04_chained_update.txt) a branched graph
-        launched once per update costs more than its overlap earns -- 973-1081 update-steps/s against 1089 for the plain
-        one-graph-per-update call under ROC_CPU_WAIT_FOR_SIGNAL=1 (the host resolves every cross-queue edge and cannot run
-        ahead), 1071-1108 without that setting and only from a high-priority caller stream (513 otherwise); loops that can hand
-        over several steps should call ``update_many`` (1136-1160)."""
-        if (self._discrete or self._world() > 1 or os.environ.get("FBHIP_UPDATE_CHAIN", "0") != "1" or
-                os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or not _lib.load().fbhip_branched_graphs(None)):
-            self._drop_prefetch()
+    def _defer_update(self, rb: DeviceReplayBuffer, key: tp.Tuple, step: int) -> bool:
+        """the slow path of a queued call: a new queue (the old one, if any, goes out first)"""
+        self.flush()
+        if not self._stddev_is_constant():       # (a captured graph bakes stddev in: time-varying schedules run as eager launches)
             return False
-        state = self._chain_state(rb, hp)
-        have = self.__dict__.get("_chain_token") == state
-        if not have:
-            seen = self.__dict__.get("_chain_seen")
-            self._drop_prefetch()
-            if seen != state:                    # first call in this state: plain update; chain from the next call on if it still holds
-                self._chain_seen = state
-                return False
-        self._on_update_stream(lambda: check(_lib.load().fbhip_update_chained(self._ctx, C.byref(hp), int(have), stream_ptr()), self._ctx))
-        self._chain_token = self._chain_seen = state
+        hp = self._hparams(step, False, 1.0, float(rb._discount), float(rb._future))
+        self._bind_replay(rb)                     # (dimension / device errors surface at the call, not at the flush)
+        self._pending = [rb, hp, key, 1, torch.cuda.current_stream(self._device)]
+        rb._observe(self)
         return True
+
+    def flush(self) -> None:
+        """Launch every queued ``update()`` call (see above) on the stream it was called on.  Asynchronous like the updates
+        themselves: follow with a stream / device synchronise to wait for the results."""
+        p = self.__dict__.get("_pending")
+        if p is None:
+            return
+        self._pending = None
+        rb, hp, _, n, stream = p
+        rb._unobserve(self)
+        now = torch.cuda.current_stream(self._device)
+        if now != stream:
+            # the queue goes out later than its calls were made, on THEIR stream: whatever the caller has enqueued on the stream it
+            # is on now comes first, and what it enqueues next sees the updates -- as if they had run when they were called and the
+            # caller had ordered its streams then
+            stream.wait_stream(now)
+        with torch.cuda.stream(stream):
+            self._bind_replay(rb)
+            if n == 1:
+                self._run_update(hp, None, True)
+            else:
+                self._launch_many(hp, n)
+        if now != stream:
+            now.wait_stream(stream)
+
+    def _launch_many(self, hp: HParams, n_steps: int) -> None:
+        done = 0
+        while done < n_steps:
+            n = min(64, n_steps - done)
+            self._on_update_stream(lambda n=n: check(_lib.load().fbhip_update_many(self._ctx, C.byref(hp), n, stream_ptr()), self._ctx))
+            done += n
 
     def _all_ranks_ok(self, ok: bool) -> bool:
         """A transport decision must be the SAME on every rank (a rank that falls back alone leaves the others waiting inside a
@@ -1046,9 +1125,13 @@ class FBHipAgent:
         the others inside an all-reduce it never joins.  A refusal demotes every rank to the torch.distributed schedule, recorded
         in ``_dp_transport``, and returns False with nothing applied."""
         lib = _lib.load()
-        prepared = self.__dict__.setdefault("_rccl_prepared", set())
+        # mirrors the library's graph cache: 16 entries, oldest evicted first (a graph the library has dropped must be PREPARED again,
+        # under the ranks' agreement, not re-captured inside a launch); keyed on the replay BIND COUNTER -- a rebind drops every graph
+        # in the library, and an id() can be reused by a later token (ADVICE r04)
+        prepared: tp.List[tp.Tuple] = self.__dict__.setdefault("_rccl_prepared", [])
         sizes = sorted({min(64, n_total - d) for d in range(0, n_total, 64)})
-        todo = [n for n in sizes if (n, bytes(hp), id(self._replay_token)) not in prepared]
+        key = lambda n: (n, bytes(hp), self.__dict__.get("_replay_binds", 0))
+        todo = [n for n in sizes if key(n) not in prepared]
         if todo:
             err = None
             try:
@@ -1063,9 +1146,9 @@ class FBHipAgent:
                                       f"{err if err is not None else 'refused on another rank'})")
                 warnings.warn(f"fbhip: {self._dp_transport}")
                 return False
-            if len(prepared) > 64:
-                prepared.clear()
-            prepared.update((n, bytes(hp), id(self._replay_token)) for n in todo)
+            for n in todo:
+                prepared.append(key(n))
+            del prepared[:max(0, len(prepared) - 16)]
         done = 0
         while done < n_total:
             n = min(64, n_total - done)
@@ -1100,7 +1183,7 @@ class FBHipAgent:
         Returns the metrics of the LAST step (if metrics are on).  NOTE: step t+1's batch is sampled while step t is still
         running -- from the same buffer contents; do not use it when transitions are added between updates."""
         c = self.cfg
-        self._drop_prefetch()
+        self.flush()
         stds = {schedule(c.stddev_schedule, step + i) for i in range(n_steps)}
         split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
         if (n_steps < 2 or getattr(c, "dp_global_batch", False) or not isinstance(replay_loader, DeviceReplayBuffer) or
@@ -1181,7 +1264,7 @@ class FBHipAgent:
         """One update on an externally sampled batch (``EpisodeBatch``-like: obs, action, next_obs, discount
         [, goal, next_goal]).  ``draws`` optionally injects the remaining random draws (parity tests):
         z_gauss [B,d], perm [B], mix_uniform [B], eps_next [B,a], eps_actor [B,a]."""
-        self._drop_prefetch()
+        self.flush()
         c, dev, Bn = self.cfg, self._device, self.cfg.batch_size
         f = lambda x: torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.float32,
                                       device=dev).reshape(Bn, -1)
@@ -1236,7 +1319,7 @@ class FBHipAgent:
                         use_graph: bool = False) -> tp.Dict[str, float]:
         """Parity mode: every random draw of the step is supplied (``ep_idx, step_idx, z_gauss, perm,
         mix_uniform, eps_next, eps_actor``), exactly as recorded from the reference run."""
-        self._drop_prefetch()
+        self.flush()
         dev = self._device
         self._bind_replay(replay_loader)
         keep = {}
@@ -1278,7 +1361,7 @@ class FBHipAgent:
             raise ValueError("update_many_injected: 1..64 steps per call")
         if self._world() > 1 or len({schedule(self.cfg.stddev_schedule, step + i) for i in range(n)}) != 1:
             raise ValueError("update_many_injected: single rank and a constant stddev over the steps only")
-        self._drop_prefetch()
+        self.flush()
         dev = self._device
         self._bind_replay(replay_loader)
         # (SFAgentConfig has no future_ratio / rand_weight / norm_z; its contrastive learners read the hindsight goal, sf.py:125, 167)
@@ -1305,6 +1388,7 @@ class FBHipAgent:
 
     def workspace_view(self, name: str) -> torch.Tensor:
         """A named intermediate of the last update as a tensor view into the workspace (tests / debugging)."""
+        self.flush()
         p, rows, cols, ld = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
         check(_lib.load().fbhip_workspace_view(self._ctx, name.encode(), C.byref(p), C.byref(rows), C.byref(cols),
                                                C.byref(ld)), self._ctx)
@@ -1313,6 +1397,27 @@ class FBHipAgent:
         is_int = name in ("ep_idx", "step_idx", "perm", "future_idx")
         flat = self._workspace[off:off + 4 * rows.value * ld.value].view(torch.int32 if is_int else torch.float32)
         return flat.view(rows.value, ld.value)[:, :cols.value]
+
+
+def _flushing_attribute(name: str) -> property:
+    """The flat device buffers (and the views built on them) as attributes that first launch the agent's queued updates:
+    whoever reads ``agent._fb_params`` / ``agent._adam_views`` ... sees every update() call made so far (FBHipAgent.flush)."""
+    def get(self: "FBHipAgent") -> tp.Any:
+        self.flush()
+        try:
+            return self.__dict__[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def put(self: "FBHipAgent", value: tp.Any) -> None:
+        self.__dict__[name] = value
+    return property(get, put)
+
+
+for _n in ("_fb_params", "_fb_grads", "_fb_m", "_fb_v", "_fb_targets", "_actor_params", "_actor_grads", "_actor_m", "_actor_v",
+           "_workspace", "_adam_views", "_grad_views"):
+    setattr(FBHipAgent, _n, _flushing_attribute(_n))
+del _n
 
 
 # ================================================================================================== sibling agent (SURVEY 8 n4)
@@ -1588,7 +1693,7 @@ class SFHipAgent(FBHipAgent):
         fwd._name, tgt._name = "successor_net", "successor_target_net"
         me = weakref.ref(self)
         self.feature_learner = FeatureLearnerView("feature_learner", bwd._flat, self._layout_of(1),
-                                                  forward=lambda x: me()._backward_map(x, target=False))
+                                                  forward=lambda x: me()._backward_map(x, target=False), sync=bwd._sync)
         if self._sf_mode in (7, 8, 9):
             # latent (sf.py:234) / svd_sr, svd_srv2 (:266-267, :306-307): ``feature_learner.target_feature_net`` [and ``target_mu_net``] are blocks of the
             # TARGET buffer -- modules without gradients to the optimiser, part of ``feature_learner.state_dict()`` for checkpoints
@@ -1704,6 +1809,9 @@ class SFHipAgent(FBHipAgent):
         return self._act_fast(np.asarray(obs, np.float32).reshape(-1), np.asarray(meta["z"], np.float32).reshape(-1), None, stddev, eval_mode)
 
     # ---- the hot path
+    _hp_fields = operator.attrgetter("lr", "lr_coef", "sf_target_tau", "stddev_schedule", "stddev_clip", "mix_ratio", "q_loss",
+                                     "num_sf_updates", "use_tb", "use_wandb", "use_hiplog")        # (SFAgentConfig, sf.py:57-96)
+
     def _hparams(self, step: int, want_metrics: bool, grad_scale: float, discount: float, future: float = 1.0) -> HParams:
         c = self.cfg
         if self._world() > 1 and getattr(c, "dp_global_batch", False):
@@ -1741,7 +1849,7 @@ class SFHipAgent(FBHipAgent):
 
     def update_many(self, replay_loader: DeviceReplayBuffer, step: int, n_steps: int) -> tp.Dict[str, float]:
         c = self.cfg
-        self._drop_prefetch()
+        self.flush()
         total = n_steps * int(c.num_sf_updates)                  # (every update() call is num_sf_updates complete updates)
         split = self._world() > 1 or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"
         const_std = len({schedule(c.stddev_schedule, step + i) for i in range(n_steps)}) == 1

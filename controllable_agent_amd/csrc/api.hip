@@ -78,17 +78,13 @@ const char* branched_graphs_verdict(bool* ok) {
     return cached;
 }
 
-// after_own: the previous command of this context on the launch stream was its own previous branched graph and the caller's
-// stream holds nothing newer that this graph depends on (fbhip_update_chained with a valid head): the launch stream's order is
-// the dependency, and the hop from the caller's stream is skipped -- with it every launch would wait (on the HOST, under
-// ROC_CPU_WAIT_FOR_SIGNAL=1) for the previous graph to finish before it is even submitted.
-int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches, bool after_own = false) {
+int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches) {
     if (!branches) {
         HIPCK(c, hipGraphLaunch(exec, s));
         return FBHIP_OK;
     }
     {   // the caller's stream is itself of the high-priority class: its hardware queue comes from the other pool already -- launch
-        // there, without the two event hops (measured round 4, profiles/r04_chained_update.txt: per-update launches of a branched
+        // there, without the two event hops (measured round 4, HISTORY.md: per-update launches of a branched
         // graph run at 1108 update-steps/s this way, at 513 through the hop under the runtime's default dependency handling)
         int prio = 0, lo = 0, hi = 0;
         if (s != nullptr && hipStreamGetPriority(s, &prio) == hipSuccess && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo && prio == hi) {
@@ -101,10 +97,8 @@ int launch_graph(fbhip_ctx* c, hipGraphExec_t exec, hipStream_t s, bool branches
     HIPCK(c, launch_stream(&ls));
     if (!c->ev_in) HIPCK(c, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     if (!c->ev_out) HIPCK(c, hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
-    if (!after_own) {
-        HIPCK(c, hipEventRecord(c->ev_in, s));
-        HIPCK(c, hipStreamWaitEvent(ls, c->ev_in, 0));
-    }
+    HIPCK(c, hipEventRecord(c->ev_in, s));
+    HIPCK(c, hipStreamWaitEvent(ls, c->ev_in, 0));
     HIPCK(c, hipGraphLaunch(exec, ls));
     HIPCK(c, hipEventRecord(c->ev_out, ls));
     HIPCK(c, hipStreamWaitEvent(s, c->ev_out, 0));
@@ -484,8 +478,6 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     RC(check_hparams(c, hp));
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
-    c->view_set = -1;
-    c->chain_live = false;
     if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
     reap(s);
     for (auto& g : c->graphs) {
@@ -526,8 +518,6 @@ int fbhip_fb_early_grad_range(const fbhip_dims* dims, int64_t* offset, int64_t* 
 int fbhip_select_workspace_set(fbhip_ctx* c, int32_t which) {
     if (!c || which < 0 || which > 1) return FBHIP_E_INVALID;
     c->cur = which;
-    c->view_set = -1;
-    c->chain_live = false;
     return FBHIP_OK;
 }
 
@@ -540,8 +530,6 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     if (n_steps < 1 || n_steps > 64) { c->err = g_err = "fbhip_update_many: bad argument"; return FBHIP_E_INVALID; }
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
-    c->view_set = -1;
-    c->chain_live = false;
     reap(s);
     // The single-rank graph pipelines consecutive steps on a second capture branch (FBHIP_UPDATE_PIPELINE=0, read at every call:
     // the plain form, bit-identical to single updates).  The DATA-PARALLEL graph is single-queue by construction: one stream,
@@ -607,20 +595,38 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
             rc = enqueue_update(c, *hp, nullptr, MID, s);
             if (rc != FBHIP_OK) break;
             const bool more = i + 1 < n_steps;
-            if (more) {                          // fork: V of this step's actor phase, then the next step's head on the twin workspace set
-                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
-                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
-                rc = enqueue_actor_v(c, c->side);
-                if (rc != FBHIP_OK) break;
-                if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) break;
+            // fork: V of this step's actor phase, then the next step's head on the twin workspace set
+            static const int fork_mode = [] { const char* e = getenv("FBHIP_FORK_LATE"); return e ? atoi(e) : 0; }();
+            const bool fork_late = fork_mode >= 1, v_in_chain = fork_mode == 2;
+            auto side_branch = [&, i]() -> int {
+                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) return (int)FBHIP_E_HIP;
+                int r = FBHIP_OK;
+                if (!v_in_chain) {
+                    r = enqueue_actor_v(c, c->side);
+                    if (r != FBHIP_OK) return r;
+                    if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) return (int)FBHIP_E_HIP;
+                }
                 c->cur ^= 1;
-                rc = enqueue_update(c, *hp, injs ? &injs[i + 1] : nullptr, HEAD, c->side);
+                r = enqueue_update(c, *hp, injs ? &injs[i + 1] : nullptr, HEAD, c->side);
                 c->cur ^= 1;
-                if (rc != FBHIP_OK) break;
-                c->v_ready = c->events[128 + i];
+                return r;
+            };
+            if (more) {
+                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;      // the fork point: behind MID
+                if (fork_late) {
+                    // the side branch is CAPTURED when the actor phase reaches actor_q (its first consumer): the phase's own first
+                    // launches are then the first successors of the fork node, and the critical path MID -> TAIL -> MID keeps one queue
+                    c->before_actor_q = side_branch;
+                } else {
+                    rc = side_branch();
+                    if (rc != FBHIP_OK) break;
+                }
+                if (!v_in_chain) c->v_ready = c->events[128 + i];
             }
             rc = enqueue_update(c, *hp, nullptr, TAIL, s);
             c->v_ready = nullptr;
+            c->before_actor_q = nullptr;
+            if (he != hipSuccess) break;
             if (more) {                          // join, then continue on the set the head filled
                 if ((he = hipEventRecord(c->events[2 * i + 1], c->side)) != hipSuccess) break;
                 if ((he = hipStreamWaitEvent(s, c->events[2 * i + 1], 0)) != hipSuccess) break;
@@ -646,84 +652,6 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
     return launch ? launch_graph(c, ge.exec, s, ge.branches) : (int)FBHIP_OK;
-}
-
-// One update per call at the rate of the pipelined n-step graph: consecutive calls CHAIN.  A call runs the update whose head
-// (sampling, z mixing, B passes, online ForwardMap pass -- everything that depends on the previous update only through its FB
-// optimiser step) is already sitting in the current workspace set (have_head: left there by the previous chained call) or runs it
-// first (have_head == 0), and prefetches the NEXT update's head into the other set on the second capture branch beside this
-// update's actor phase -- one iteration of fbhip_update_many's pipelined loop, same kernels, operands and order, so a sequence
-// of chained calls is bit-identical to one fbhip_update_many over the same steps.  Afterwards the current set is the one that
-// holds the prefetched head.  The CALLER decides whether that head is still valid at the next call (nothing wrote the
-// parameters or the replay storage in between; same hparams) and passes have_head accordingly; a head that is not used costs
-// one RNG counter value (fbhip_set_rng_counts restores it).
-constexpr int CHAIN_BIT = 1 << 21, CHAIN_HEAD_BIT = 1 << 22;
-int fbhip_update_chained(fbhip_ctx* c, const fbhip_hparams* hp, int32_t have_head, void* stream) {
-    RC(need_bound(c, true));
-    RC(check_hparams(c, hp));
-    if (c->d.discrete) { c->err = g_err = "fbhip_update_chained: DiscreteFBAgent has no actor phase to prefetch beside (use fbhip_update)"; return FBHIP_E_STATE; }
-    {
-        bool branched_ok = false;
-        const char* why = branched_graphs_verdict(&branched_ok);
-        if (!branched_ok) { c->err = g_err = std::string("fbhip_update_chained: graphs with parallel branches are ") + why + " (use fbhip_update)"; return FBHIP_E_STATE; }
-    }
-    hipStream_t s = (hipStream_t)stream;
-    c->last_stream = s;
-    reap(s);
-    const int key = FBHIP_PHASE_ALL | CHAIN_BIT | (have_head ? CHAIN_HEAD_BIT : 0);
-    auto done = [&](int rc) { if (rc == FBHIP_OK) { c->view_set = c->cur; c->cur ^= 1; c->chain_stream = s; c->chain_live = true; } return rc; };
-    // (the head this call relies on was enqueued by the previous chained call, behind which this launch sits on the launch stream)
-    const bool after_own = have_head && c->chain_live && c->chain_stream == s;
-    for (auto& g : c->graphs)
-        if (g.n_steps == 1 && g.set == c->cur && g.mask == key && !g.has_inj && memcmp(&g.hp, hp, sizeof(*hp)) == 0)
-            return done(launch_graph(c, g.exec, s, g.branches, after_own));
-    if (!c->side) HIPCK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    while ((int)c->events.size() < 3 * 64) {
-        hipEvent_t ev;
-        HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        c->events.push_back(ev);
-    }
-    const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
-    const int MID = FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD | FBHIP_PHASE_FB_STEP;   // (both FB_BWD bits)
-    const int TAIL = FBHIP_PHASE_ACTOR_GRAD | FBHIP_PHASE_ACTOR_STEP;
-    hipGraph_t graph = nullptr;
-    HIPCK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    const int cur0 = c->cur;
-    int rc = FBHIP_OK;
-    hipError_t he = hipSuccess;
-    if (!have_head) rc = enqueue_update(c, *hp, nullptr, HEAD, s);
-    if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, MID, s);
-    if (rc == FBHIP_OK) {
-        // fork: V of this update's actor phase, then the next update's head on the twin workspace set
-        if ((he = hipEventRecord(c->events[0], s)) == hipSuccess) he = hipStreamWaitEvent(c->side, c->events[0], 0);
-        if (he == hipSuccess) rc = enqueue_actor_v(c, c->side);
-        if (he == hipSuccess && rc == FBHIP_OK) he = hipEventRecord(c->events[128], c->side);
-        if (he == hipSuccess && rc == FBHIP_OK) {
-            c->cur ^= 1;
-            rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
-            c->cur ^= 1;
-        }
-        if (he == hipSuccess && rc == FBHIP_OK) {
-            c->v_ready = c->events[128];
-            rc = enqueue_update(c, *hp, nullptr, TAIL, s);
-            c->v_ready = nullptr;
-        }
-        // join
-        if (he == hipSuccess && rc == FBHIP_OK && (he = hipEventRecord(c->events[1], c->side)) == hipSuccess) he = hipStreamWaitEvent(s, c->events[1], 0);
-    }
-    c->cur = cur0;
-    hipError_t e = hipStreamEndCapture(s, &graph);
-    if (rc != FBHIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (he != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); HIPCK(c, he); }
-    HIPCK(c, e);
-    GraphEntry ge{};
-    ge.mask = key; ge.hp = *hp; ge.has_inj = false; ge.n_steps = 1; ge.set = c->cur; ge.branches = true;
-    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    HIPCK(c, e);
-    if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
-    c->graphs.push_back(ge);
-    return done(launch_graph(c, ge.exec, s, ge.branches, after_own));
 }
 
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
@@ -787,6 +715,7 @@ int fbhip_rccl_init(fbhip_ctx* c, const void* unique_id_128_bytes, int32_t world
     HIPCK(c, hipDeviceSynchronize());                                       // (an exec destroyed under an in-flight launch corrupts the runtime)
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);            // the communicator is baked into captured launches
     c->graphs.clear();
+    if (unique_id_128_bytes == nullptr && world == 0) { rccl_release(c); c->rccl_world = 0; c->rccl_rank = 0; return FBHIP_OK; }   // release
     return rccl_init(c, unique_id_128_bytes, world, rank, (hipStream_t)stream);
 }
 
@@ -829,7 +758,7 @@ int fbhip_read_metrics(fbhip_ctx* c, float* host_out, void* stream) {
 int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld) {
     RC(need_bound(c, false));
     if (!name || !ptr) return FBHIP_E_INVALID;
-    Ws& w = c->view_set >= 0 ? c->sets[c->view_set] : c->W();
+    Ws& w = c->W();
     const fbhip_dims& d = c->d;
     const int B = d.batch, o = d.obs_dim, a = d.action_dim, z = d.z_dim;
     const int aoff = geom_of(d).single ? o + z : o;

@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace fbhip {
@@ -78,33 +79,83 @@ __device__ __forceinline__ void store_quad(float* __restrict__ d, int step, cons
     d[3 * step] = v.w;
 }
 
-// accumulator tile -> C (or the split-K partial slab) with the fused epilogue; acc row = (r&3) + 8(r>>2) + 4h, col = l31
-__device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx16& acc, float csum, int slice, int row0,
-                                              int col0, int wm, int wn, int tn, int l31, int h) {
+// write-through store / cache-bypassing load (global_store_dword ... sc1 / global_load_dword ... sc1): what one wave hands to a wave
+// on another CU -- possibly another XCD, whose L2 is not coherent with this one -- without a release / acquire fence pair
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// accumulator tile -> C with the fused epilogue; acc row = (r&3) + 8(r>>2) + 4h, col = l31.
+// Grid-level split-K (p.kslices > 1): every slice writes its raw 32x32 partial tile (+ partial column sums) to the slab, write-through,
+// and takes a ticket of the tile's arrival counter; the wave that takes the LAST ticket folds all slices in slice order -- the
+// fixed order and the arithmetic of the reduce launch this replaces, so the results are the same bits whichever wave arrives last --
+// and finishes the tile with the epilogue.  One 32x32 sub-tile = one wave = one counter: nothing here crosses waves of a workgroup.
+// ``sub``: index of this wave's sub-tile inside its problem.
+__device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, floatx16 acc, float csum, int slice, int row0,
+                                              int col0, int wm, int wn, int tn, int l31, int h, int sub) {
     const int M = p.M, N = p.N;
     if (p.kslices > 1) {
-        // raw partial tile (+ partial column sums behind the tiles); splitk_reduce_kernel applies the epilogue
-        float* part = p.partial + (size_t)slice * M * N;
-        if (p.colsum != nullptr && tn == 0 && wn == 0) {
+        const int ks = p.kslices;
+        const size_t mn = (size_t)M * N;
+        float* part = p.partial + (size_t)slice * mn;
+        const bool sums = p.colsum != nullptr && tn == 0 && wn == 0;
+        const int rs = row0 + wm * 32 + l31;                       // the row whose A-operand sum this lane holds
+        if (sums) {
             const float tot = csum + __shfl_xor(csum, 32);
-            const int r = row0 + wm * 32 + l31;
-            if (h == 0 && r < M) p.partial[(size_t)p.kslices * M * N + (size_t)slice * M + r] = tot;
+            if (h == 0 && rs < M) st_sc1(p.partial + (size_t)ks * mn + (size_t)slice * M + rs, tot);
         }
         const int col = col0 + wn * 32 + l31;
-        if (col >= N) return;
+        const int cc = min(col, N - 1);
+        if (col < N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (row < M) part[(size_t)row * N + col] = acc[r];
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) st_sc1(part + (size_t)row * N + col, acc[r]);
+            }
         }
-        return;
-    }
-
-    if (p.colsum != nullptr && tn == 0 && wn == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the partials have left this CU before the ticket is taken
+        int old = 0;
+        if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(p.arrive + sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old != ks - 1) return;
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(p.arrive + sub, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        // fold, slice order, eight slices of four rows in flight at once (clamped index, masked add)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            for (int s0 = 0; s0 < ks; s0 += 8) {
+                float x[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = min(row0 + wm * 32 + j + 8 * rq + 4 * h, M - 1);
+                        x[u][j] = ld_sc1(p.partial + (size_t)min(s0 + u, ks - 1) * mn + (size_t)row * N + cc);
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[4 * rq + j] += (s0 + u < ks) ? x[u][j] : 0.f;
+            }
+        }
+        if (sums) {
+            float v = 0.f;
+            const int rc = min(rs, M - 1);
+            for (int s0 = 0; s0 < ks; s0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = ld_sc1(p.partial + (size_t)ks * mn + (size_t)min(s0 + u, ks - 1) * M + rc);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += (s0 + u < ks) ? x[u] : 0.f;
+            }
+            if (h == 0 && rs < M) p.colsum[rs] = v;
+        }
+    } else if (p.colsum != nullptr && tn == 0 && wn == 0) {
         const float tot = csum + __shfl_xor(csum, 32);
         const int r = row0 + wm * 32 + l31;
         if (h == 0 && r < M) p.colsum[r] = tot;
     }
+
 
     const int col = col0 + wn * 32 + l31;
     if (col >= N) return;
@@ -141,6 +192,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProblem& p, const floatx
             C[(size_t)row * p.ldc + col] = v;
         }
     }
+}
+
+// LayerNorm-backward column reduces: out[j] = sum_b partials[b][j], j < 2n -- exactly ln_colreduce_kernel (rowops.hip), addressed by a
+// linear job block index.  Tiny fold-the-partials jobs whose results only the optimiser reads: they ride as the FIRST workgroups of
+// the next grouped GEMM launch (threads 0..255 of its 512; ``red``: 256 floats of LDS) instead of paying for a launch of their own.
+__device__ __forceinline__ void colreduce_job(const ColReduceJobs& cr, int b, float* __restrict__ red) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CR_MAX; ++i)
+        if (i < cr.count && b >= cr.block_start[i]) pi = i;
+    const bool live = threadIdx.x < 256 && b < cr.block_start[cr.count];
+    const int bx = b - cr.block_start[pi];
+    const int n = cr.n[pi], nb = (cr.rows[pi] + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK;
+    const int c = threadIdx.x & 31, rg = (threadIdx.x >> 5) & 7;
+    const int j = bx * 32 + c;
+    float s = 0.f;
+    if (live && j < 2 * n)
+        for (int q0 = rg; q0 < nb; q0 += 64) {             // eight partial rows in flight at once (same summation order)
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = cr.partials[pi][(size_t)min(q0 + 8 * u, nb - 1) * 2 * n + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (q0 + 8 * u < nb) ? x[u] : 0.f;
+        }
+    if (threadIdx.x < 256) red[rg * 32 + c] = s;
+    __syncthreads();
+    if (live && rg == 0 && j < 2 * n) {
+        float t = red[c];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k * 32 + c];
+        if (j < n) cr.dgamma[pi][j] = t; else cr.dbeta[pi][j - n] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256) colreduce_kernel(const ColReduceJobs cr) {
+    __shared__ float red[256];
+    colreduce_job(cr, (int)blockIdx.x, red);
 }
 
 // -DFBHIP_TRACE (tools/gemm_trace.hip only): cycle stamps of one consumer and one producer wave per workgroup, kept in LDS
@@ -182,10 +270,12 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     static_assert((WK - 1) * WM * WN * 17 * 64 <= 2 * STAGE, "split-K reduction scratch must fit");
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 * STAGE floats
 
+    // the launch's first g.cr_blocks workgroups (a multiple of 8: the tile -> XCD map below stays aligned) fold LayerNorm partials
+    if ((int)blockIdx.x < g.cr_blocks) { colreduce_job(g.cr, (int)blockIdx.x, smem); return; }
     // problem lookup by launch position, then an XCD-aware bijective remap INSIDE the problem: workgroup b runs on
     // XCD b % 8; each XCD gets a contiguous run of the problem's tiles (neighbours share an A row-panel / adjacent
     // B panels in that XCD's L2) while every problem of a heterogeneous group still spreads over all 8 XCDs.
-    const int orig = blockIdx.x;
+    const int orig = (int)blockIdx.x - g.cr_blocks;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < MAX_GROUP; ++i)
@@ -423,7 +513,7 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
         }
     }
 
-    gemm_epilogue(p, acc, csum, slice, row0, col0, wm, wn, tn, l31, h);
+    gemm_epilogue(p, acc, csum, slice, row0, col0, wm, wn, tn, l31, h, tt * (WM * WN) + wrem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -633,101 +723,13 @@ __global__ void __launch_bounds__(256 + 64 * DmaGeom<TM>::NPW) gemm_dma_kernel(c
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-        gemm_epilogue(p, acc[i], csum[i], slice, row0 + wm * 32 * TM + 32 * i, col0, 0, wn, tn, l31, h);
+        gemm_epilogue(p, acc[i], csum[i], slice, row0 + wm * 32 * TM + 32 * i, col0, 0, wn, tn, l31, h, tt * (4 * TM) + (wm * TM + i) * 2 + wn);
 }
 
-// C = epi(sum_slices partial[s]) for every split-K problem of a group; one thread per output element (+ the column
-// sums appended behind the M*N elements of each problem)
-// out[j] = sum_b partials[b][j], j < 2n: exactly ln_colreduce_kernel (rowops.hip), addressed by a linear job block index
-__device__ __forceinline__ void colreduce_job(const ColReduceJobs& cr, int b) {
-    __shared__ float red[8][32];
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < CR_MAX; ++i)
-        if (i < cr.count && b >= cr.block_start[i]) pi = i;
-    const int bx = b - cr.block_start[pi];
-    const int n = cr.n[pi], nb = (cr.rows[pi] + LN_BWD_ROWS_PER_BLOCK - 1) / LN_BWD_ROWS_PER_BLOCK;
-    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int j = bx * 32 + c;
-    float s = 0.f;
-    if (j < 2 * n)
-        for (int q0 = rg; q0 < nb; q0 += 64) {             // eight partial rows in flight at once (same summation order)
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = cr.partials[pi][(size_t)min(q0 + 8 * u, nb - 1) * 2 * n + j];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += (q0 + 8 * u < nb) ? x[u] : 0.f;
-        }
-    red[rg][c] = s;
-    __syncthreads();
-    if (rg == 0 && j < 2 * n) {
-        float t = red[0][c];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][c];
-        if (j < n) cr.dgamma[pi][j] = t; else cr.dbeta[pi][j - n] = t;
-    }
-}
-
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const GemmGroup g, const ColReduceJobs cr, const int red_blocks) {
-    if ((int)blockIdx.x >= red_blocks) { colreduce_job(cr, (int)blockIdx.x - red_blocks); return; }
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    int pi = -1;
-#pragma unroll
-    for (int i = 0; i < MAX_GROUP; ++i)
-        if (i < g.n && g.p[i].kslices > 1 && e >= g.p[i].red_start) pi = i;
-    if (pi < 0) return;
-    const GemmProblem& p = g.p[pi];
-    const int M = p.M, N = p.N, ks = p.kslices;
-    int idx = e - p.red_start;
-    const int mn = M * N;
-    if (idx < mn) {
-        const int row = idx / N, col = idx % N;
-        // eight slices in flight at once (clamped index, masked add; same summation order): as a plain loop every slice costs a
-        // round trip of its own
-        // (the epilogue's operand is requested with the slices, not behind them)
-        const int epi = p.epi;
-        float eo = 0.f;
-        if (epi == EPI_BIAS || epi == EPI_BIAS_RELU) eo = p.bias[col];
-        else if (epi == EPI_MASK_RELU || epi == EPI_TANH_BWD) eo = p.aux[(size_t)row * p.ldaux + col];
-        float v = 0.f;
-        for (int s0 = 0; s0 < ks; s0 += 8) {
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p.partial[(size_t)min(s0 + u, ks - 1) * mn + idx];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v += (s0 + u < ks) ? x[u] : 0.f;
-        }
-        if (epi == EPI_BIAS) {
-            v += eo;
-        } else if (epi == EPI_BIAS_RELU) {
-            v = fmaxf(v + eo, 0.f);
-        } else if (epi == EPI_MASK_RELU) {
-            v = eo > 0.f ? v : 0.f;
-        } else if (epi == EPI_TANH_BWD) {
-            v = v * (1.f - eo * eo);
-        }
-        p.C[(size_t)row * p.ldc + col] = v;
-    } else if (p.colsum != nullptr && idx < mn + M) {
-        const int r = idx - mn;
-        float v = 0.f;
-        for (int s0 = 0; s0 < ks; s0 += 8) {
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p.partial[(size_t)ks * mn + (size_t)min(s0 + u, ks - 1) * M + r];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v += (s0 + u < ks) ? x[u] : 0.f;
-        }
-        p.colsum[r] = v;
-    }
-}
-
-hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream, const ColReduceJobs* extra) {
-    const int red_blocks = total_elems > 0 ? (total_elems + 255) / 256 : 0;
-    ColReduceJobs cr{};
-    if (extra != nullptr) cr = *extra;
-    const int cr_blocks = cr.count > 0 ? cr.block_start[cr.count] : 0;
-    if (red_blocks + cr_blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(red_blocks + cr_blocks), dim3(256), 0, stream, g, cr, red_blocks);
+hipError_t launch_colreduce(const ColReduceJobs& cr, hipStream_t stream) {
+    const int blocks = cr.count > 0 ? cr.block_start[cr.count] : 0;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(colreduce_kernel, dim3(blocks), dim3(256), 0, stream, cr);
     return hipGetLastError();
 }
 
@@ -761,9 +763,17 @@ int gemm_cfg_bkt(int cfg) {
 int gemm_cfg_bm(int cfg) { return 32 * kCfgWM[cfg]; }
 int gemm_cfg_bn(int cfg) { return 32 * kCfgWN[cfg]; }
 
-// one-time: raise the dynamic-LDS limit of every instantiation (must not happen inside a stream capture)
+// once per DEVICE (hipFuncSetAttribute applies to the current device's copy of the function): raise the dynamic-LDS limit of
+// every instantiation (must not happen inside a stream capture)
 hipError_t gemm_init() {
-    static bool done = false;
+    static std::mutex mu;
+    static bool done_on[64] = {};
+    int dev = 0;
+    hipError_t de = hipGetDevice(&dev);
+    if (de != hipSuccess) return de;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(mu);
+    bool& done = done_on[dev];
     if (done) return hipSuccess;
 #define X(id, wm, wn, wk, bk)                                                                                       \
     {                                                                                                                \
@@ -819,9 +829,9 @@ int pick_gemm_cfg(int M, int N, int K) {
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream) {
     if (g.total_tiles <= 0) return hipSuccess;
-    dim3 grid(g.total_tiles), block(512);
+    dim3 grid(g.total_tiles + g.cr_blocks), block(512);
     if (cfg == CFG_DMA128) {
-        if (!gemm_group_dma_ok(g)) return hipErrorInvalidValue;
+        if (!gemm_group_dma_ok(g) || g.cr_blocks != 0) return hipErrorInvalidValue;
         hipLaunchKernelGGL(gemm_dma_kernel<2>, grid, dim3(256 + 64 * DmaGeom<2>::NPW), DmaGeom<2>::LDS_BYTES, stream, g);
         return hipGetLastError();
     }

@@ -135,9 +135,6 @@ struct fbhip_ctx {
     bool bound = false, replay_bound = false;
     fbhip::host::Ws sets[2];                              // two complete workspace sets: fbhip_update_many alternates them so that step
     int cur = 0;                             // t+1's sampling and online forward passes can run beside step t's actor phase
-    hipStream_t chain_stream = nullptr;      // fbhip_update_chained: the caller's stream of the last chained call, and whether that call
-    bool chain_live = false;                 // was this context's last update entry point
-    int view_set = -1;                       // fbhip_workspace_view: the set of the last completed update when a chained call left ``cur`` on the prefetched one
     fbhip::host::Ws& W() { return sets[cur]; }            // the set kernels are currently enqueued on
     const char* ws_lo = nullptr;
     size_t ws_bytes = 0;
@@ -147,6 +144,8 @@ struct fbhip_ctx {
     hipEvent_t ev_gate = nullptr, ev_gate_in = nullptr;   // fbhip_order_legacy_stream_after / fbhip_order_stream_after_legacy
     hipStream_t last_stream = nullptr;      // the stream of the last update call (fbhip_destroy asks it whether a capture is open)
     hipEvent_t v_ready = nullptr;            // set while the actor phase of a pipelined graph is being built: V comes from the side branch
+    std::function<int()> before_actor_q;     // pipelined graph: captures the side branch (V + the next step's head) at this point of the actor
+                                             // phase, so that the phase's own first launches are the FIRST successors of the fork node
     fbhip::ReplayView rv{};
     uint64_t seed = 0;
     uint32_t rank = 0;
@@ -197,7 +196,8 @@ namespace host {
 GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc, float* C, int ldc, int M, int N,
               int K, const float* bias = nullptr, int epi = EPI_NONE, const float* aux = nullptr, int ldaux = 0,
               float* colsum = nullptr);
-constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB
+constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB: partial tiles, then ...
+constexpr size_t SPLITK_ARRIVE_INTS = (size_t)1 << 16;     // ... the arrival counters of the split problems' sub-tiles (the slab's tail)
 int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s);
 
 struct Ops {

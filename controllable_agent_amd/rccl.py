@@ -58,15 +58,35 @@ def bind(agent: tp.Any) -> None:
         everyone = [e[:4] for e in everyone]
         if len(set(everyone)) != world:
             raise RuntimeError(f"{world} ranks on {len(set(everyone))} distinct devices: RCCL needs one device per rank")
+    # From here on every step that can fail on ONE rank is followed by an agreement of ALL ranks before anyone enters the next
+    # collective: a rank that raised alone would leave the others inside a broadcast / ncclCommInitRank it never joins.
     uid = C.create_string_buffer(128)
+    uid_rc, uid_err = 0, ""
     if rank == 0:
-        check(lib.fbhip_rccl_unique_id(uid))
-    box = [bytes(uid.raw)]
+        uid_rc = int(lib.fbhip_rccl_unique_id(uid))
+        uid_err = _lib.last_error() if uid_rc else ""
+    box = [(uid_rc, uid_err, bytes(uid.raw))]
     if live and world > 1:
-        dist.broadcast_object_list(box, src=0)
+        dist.broadcast_object_list(box, src=0)      # rank 0 broadcasts (ok, id): every rank raises together on !ok
+    if box[0][0] != 0:
+        raise RuntimeError(f"fbhip_rccl_unique_id failed on rank 0: {box[0][1]}")
     torch.cuda.synchronize(agent._device)
     with torch.cuda.device(agent._device), torch.cuda.stream(agent._stream):
-        check(lib.fbhip_rccl_init(agent._ctx, box[0], world, rank, _lib.stream_ptr()), agent._ctx)
+        init_rc = int(lib.fbhip_rccl_init(agent._ctx, box[0][2], world, rank, _lib.stream_ptr()))
+    init_err = _lib.last_error(agent._ctx) if init_rc else ""
     torch.cuda.synchronize(agent._device)
+    if live and world > 1:
+        # (ncclCommInitRank is itself a rendezvous: a rank that fails in it fails on its peers too, or they time out inside RCCL;
+        # what this catches is a LOCAL failure after the rendezvous -- exec teardown, a refused stream -- on some ranks only)
+        flags: tp.List[tp.Any] = [None] * world
+        dist.all_gather_object(flags, (rank, init_rc, init_err))
+        bad = [f for f in flags if f[1] != 0]
+        if bad:
+            if init_rc == 0:                      # this rank's communicator is live: give it back before raising with the others
+                agent._rccl_bound = False
+                lib.fbhip_rccl_init(agent._ctx, None, 0, 0, _lib.stream_ptr())
+            raise RuntimeError("fbhip_rccl_init failed on rank(s) " + ", ".join(f"{r}: {e}" for r, _, e in bad))
+    elif init_rc != 0:
+        raise RuntimeError(f"fbhip_rccl_init failed: {init_err}")
     agent._rccl_bound = True
     agent._dp_transport = f"rccl-library (in-graph ncclAllReduce, librccl {lib.fbhip_rccl_version()})"

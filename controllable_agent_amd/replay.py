@@ -23,6 +23,7 @@ from __future__ import annotations
 import collections.abc
 import dataclasses
 import typing as tp
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -195,6 +196,27 @@ class DeviceReplayBuffer:
         self._version = 0                   # bumped on every mutation; FBHipAgent re-binds device pointers when it changes
         self._dev_cache: tp.Optional[tp.Dict[str, tp.Any]] = None
 
+    # ------------------------------------------------------------------ observers
+    # An FBHipAgent holds consecutive ``update()`` calls back and launches them as one n-step graph (agent.py "deferred
+    # batching"); the batches of those updates are drawn from THIS buffer when they run.  Every mutation therefore first asks
+    # the agents with calls in the queue to launch them: queued updates sample the contents they were called on.
+    def _observe(self, agent: tp.Any) -> None:
+        obs = self.__dict__.get("_observers")
+        if obs is None:
+            obs = self.__dict__["_observers"] = weakref.WeakSet()
+        obs.add(agent)
+
+    def _unobserve(self, agent: tp.Any) -> None:
+        obs = self.__dict__.get("_observers")
+        if obs is not None:
+            obs.discard(agent)
+
+    def _before_mutation(self) -> None:
+        obs = self.__dict__.get("_observers")
+        if obs:
+            for agent in list(obs):
+                agent.flush()
+
     # ------------------------------------------------------------------ bookkeeping
     def __len__(self) -> int:
         return self._max_episodes if self._full else self._idx
@@ -209,6 +231,7 @@ class DeviceReplayBuffer:
         return round(float(stored.sum(dtype=np.int64)) / len(stored))
 
     def _touch(self) -> None:
+        self._before_mutation()
         self._version += 1
         self._dev_cache = None
         self._episodes_selection_probability = None
@@ -232,6 +255,7 @@ class DeviceReplayBuffer:
 
     def _put_episode(self, episode: tp.Mapping[str, tp.Any], steps: tp.Optional[int] = None) -> None:
         """one finished episode (``{name: [rows, dim]}``, host arrays or tensors) -> ring slot ``_idx``"""
+        self._before_mutation()
         n_rows = 0
         for name, values in episode.items():
             block = values if isinstance(values, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(values, dtype=np.float32))
@@ -242,12 +266,13 @@ class DeviceReplayBuffer:
 
     # ------------------------------------------------------------------ pickling (workspaces torch.save the buffer object)
     def __getstate__(self) -> tp.Dict[str, tp.Any]:
-        state = {k: v for k, v in self.__dict__.items() if k not in ("_dev_cache", "_current_episode")}
+        state = {k: v for k, v in self.__dict__.items() if k not in ("_dev_cache", "_current_episode", "_observers")}
         state["_storage"] = {k: v.cpu().numpy() for k, v in self._storage.items()}
         state["_device"] = str(self._device)
         return state
 
     def __setstate__(self, state: tp.Dict[str, tp.Any]) -> None:
+        self._before_mutation()
         dev = torch.device(state.get("_device", "cuda"))
         if dev.type == "cuda" and not torch.cuda.is_available():
             dev = torch.device("cpu")
@@ -368,6 +393,7 @@ class DeviceReplayBuffer:
         self._touch()
 
     def relabel(self, custom_reward: tp.Any) -> None:
+        self._before_mutation()
         physics = self._storage["physics"]
         n, depth = physics.shape[:2]
         self._storage["reward"] = self._rewards_of(custom_reward, physics.reshape(n * depth, -1)).reshape(n, depth, 1)
@@ -378,6 +404,7 @@ class DeviceReplayBuffer:
     # ------------------------------------------------------------------ ingestion / sharding / device view
     def _adopt(self, storage: tp.Mapping[str, tp.Any], lengths: tp.Optional[np.ndarray]) -> None:
         """take complete episode-major arrays as the storage"""
+        self._before_mutation()
         self._storage = {name: torch.as_tensor(np.asarray(arr, dtype=np.float32), device=self._device)
                          for name, arr in storage.items()}
         if lengths is None:                                    # no record: every stored episode is full length

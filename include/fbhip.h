@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 17
+#define FBHIP_ABI_VERSION 18
 
 enum {
     FBHIP_OK = 0,
@@ -200,7 +200,7 @@ typedef struct fbhip_ctx fbhip_ctx;
 
 /* ---- library / layout --------------------------------------------------------------------------- */
 int fbhip_abi_version(void);
-/* 1 when this process may replay graphs with parallel branches (the pipelined n-step graph of fbhip_update_many, fbhip_update_chained),
+/* 1 when this process may replay graphs with parallel branches (the pipelined n-step graph of fbhip_update_many),
  * 0 when the library builds its graphs single-queue instead; *why (nullable) receives a static one-line reason.  ROCm 7.0's
  * hipGraphLaunch can walk off an exec's parallel-stream list; the library launches branched graphs from a high-priority stream,
  * which is verified to avoid it on HIP 7.0 and unnecessary on HIP >= 7.2 -- on any other runtime version, or without a
@@ -254,17 +254,6 @@ int fbhip_set_rng_counts(fbhip_ctx* ctx, uint32_t update_count, uint32_t act_cou
  * cached hipGraph of the launch sequence (captured on first use; re-captured when hparams change). */
 int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* inject,
                  int32_t phase_mask, int32_t use_graph, void* stream);
-/* One update per call at the rate of the pipelined n-step graph: consecutive calls chain.  The call runs the update whose HEAD
- * (FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE: everything that depends on the previous update only through its FB optimiser
- * step) already sits in the current workspace set (have_head != 0: left there by the previous chained call) or runs it first
- * (have_head == 0), and prefetches the NEXT update's head into the other set beside this update's actor phase: one iteration of
- * fbhip_update_many's pipelined loop, so a sequence of chained calls equals ONE fbhip_update_many over the same steps bit for
- * bit.  On return the current workspace set is the one holding the prefetched head (fbhip_workspace_view keeps answering for the
- * completed update).  The caller owns the validity of that head: pass have_head = 0 after anything wrote the parameters, the
- * optimiser state or the replay storage, after another update entry point ran, or when hparams changed; the unused head has
- * consumed one RNG counter value (fbhip_get_rng_counts / fbhip_set_rng_counts restore it).  This is the call behind the drop-in
- * ``agent.update(replay_loader, step)`` of train_offline.py:118.  Not for dims.discrete (no actor phase): FBHIP_E_STATE. */
-int fbhip_update_chained(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t have_head, void* stream);
 /* n_steps consecutive complete updates (all phases, device-drawn batches) as ONE hipGraph launch: what the offline loop
  * (train_offline.py:101-134) does between two log lines.  The same kernels on the same operands as n_steps fbhip_update
  * calls -- the Adam / RNG counters advance on the device -- minus n_steps - 1 graph-launch gaps, with consecutive steps
@@ -304,7 +293,9 @@ int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t 
  * process's HIP runtime -- the one torch bundles; NULL tries the loader's default); rank 0 draws fbhip_rccl_unique_id (128 bytes)
  * and the host hands the same bytes to every rank's fbhip_rccl_init (collective: every rank calls it; it also runs both buckets'
  * all-reduces once eagerly, on the zeroed gradient buffers, so that connection set-up happens outside any capture).  Takes
- * precedence over bound peers.  Works for every agent kind (the buckets are the flat gradient buffers). */
+ * precedence over bound peers.  Works for every agent kind (the buckets are the flat gradient buffers).
+ * fbhip_rccl_init(ctx, NULL, 0, 0, stream) RELEASES the context's communicator (local, not collective): what a rank whose own
+ * init succeeded does when the host's agreement says another rank's failed. */
 int fbhip_rccl_load(const char* library_path);
 int fbhip_rccl_version(void);                      /* ncclGetVersion of the loaded library, 0 if none */
 int fbhip_rccl_unique_id(void* out_128_bytes);

@@ -721,14 +721,18 @@ def test_update_many_equals_consecutive_updates():
         np.testing.assert_array_equal(s1[k], s3[k], err_msg=k)
 
 
-def test_consecutive_update_calls_chain_and_equal_unchained_calls(monkeypatch):
-    """The drop-in call, ``agent.update(replay_loader, step)`` once per iteration (train_offline.py:118), can chain
-    (FBHIP_UPDATE_CHAIN=1; off by default, DESIGN.md says why): from the third call of a run of unchanged state on, the update's head was prefetched beside the previous actor phase (fbhip_update_chained).
-    Same kernels, operands and draws as unchained calls: bit-identical state and RNG counters -- across everything that must
-    void a prefetched head: a host write to the parameters, a mutation of the replay buffer, another update entry point, a
-    pickle round trip, a read of the RNG counters."""
+def test_deferred_update_calls_equal_eager_calls_across_every_flush_trigger(monkeypatch):
+    """The drop-in call, ``agent.update(replay_loader, step)`` once per iteration (train_offline.py:118), with metrics off: the
+    agent QUEUES the call and launches the queue as one ``fbhip_update_many(k <= 32)`` when it is full or when anything observes or
+    changes state (agent.py "deferred batching").  Agent ``a`` defers (the default), agent ``b`` launches every call at once
+    (FBHIP_UPDATE_DEFER=0): same kernels, operands and draws -- bit-identical parameters, Adam state, step and RNG counters --
+    with every flush trigger interleaved: a full queue, the net / optimiser views (read and write), the workspace view, the step
+    and RNG counters, the inference entry points (batched and batch-1), a mutation of the replay buffer (which must flush BEFORE
+    it writes), other hyper-parameters, another buffer, another stream, another update entry point, a metrics-on call, train(),
+    a pickle round trip, init_from, an explicit flush()."""
     import contextlib
     import pickle
+    from controllable_agent_amd.replay import DeviceReplayBuffer, TimeStep
     cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
                           backward_hidden_dim=18, batch_size=64)
     rng = np.random.default_rng(23)
@@ -738,50 +742,123 @@ def test_consecutive_update_calls_chain_and_equal_unchained_calls(monkeypatch):
     a, b = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(2))
 
     @contextlib.contextmanager
-    def chained():
-        monkeypatch.setenv("FBHIP_UPDATE_CHAIN", "1")
+    def eager():
+        monkeypatch.setenv("FBHIP_UPDATE_DEFER", "0")
         yield
-        monkeypatch.delenv("FBHIP_UPDATE_CHAIN")
+        monkeypatch.delenv("FBHIP_UPDATE_DEFER")
 
     def both(fn):
-        with chained():
-            fn(a)
-        fn(b)
+        ra = fn(a)
+        with eager():
+            rb_ = fn(b)
+        return ra, rb_
+
+    def pending(ag):
+        p = ag.__dict__.get("_pending")
+        return 0 if p is None else p[3]
 
     def same():
         sa, sb = H.get_agent_state(a), H.get_agent_state(b)
+        assert pending(a) == 0                                                     # (reading the state flushed the queue)
         for k in sa:
             np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
         assert a.step_counts() == b.step_counts()
 
     step = [0]
 
-    def updates(n):
+    def updates(n, buf=None):
         for _ in range(n):
-            both(lambda ag: ag.update(rb, step[0]))
+            out = both(lambda ag: ag.update(buf if buf is not None else rb, step[0]))
+            assert out == ({}, {})
             step[0] += 1
 
     updates(5)
-    assert a.__dict__.get("_chain_token") is not None and b.__dict__.get("_chain_token") is None      # a chains, b does not
-    # the completed update's panels, not the prefetched head's, answer workspace_view
-    for name in ("F1", "Xoz", "z", "dF1"):
-        assert torch.equal(a.workspace_view(name), b.workspace_view(name)), name
+    assert pending(a) == 5 and pending(b) == 0 and b.step_counts() == (5, 5)      # a holds its calls back, b ran them
+    assert a.step_counts() == (5, 5) and pending(a) == 0                           # reading the counters launches the queue
+    updates(3)
+    for name in ("F1", "Xoz", "z", "dF1"):                                          # the workspace view of the LAST update
+        va, vb = both(lambda ag: ag.workspace_view(name).clone())
+        assert torch.equal(va, vb), name
     same()
-    both(lambda ag: ag.forward_net.load_state_dict(ag.forward_net.state_dict()))       # a host write (same values): the head is void
+    updates(32 + 7)                                                                 # a full queue goes out on its own
+    assert pending(a) == 7
+    same()
     updates(4)
-    same()
-    rb._version += 1                                                                   # a mutation of the buffer (add / load bump this)
+    both(lambda ag: ag.forward_net.load_state_dict(ag.forward_net.state_dict()))   # a host write through a view
+    assert pending(a) == 0
     updates(4)
+    assert pending(a) == 4
+    both(lambda ag: ag.fb_opt.load_state_dict(ag.fb_opt.state_dict()))             # the optimiser view, read and write
+    assert pending(a) == 0
+    updates(3)
+    goal = rng.standard_normal((7, cfg.goal_dim)).astype(np.float32)
+    za, zb = both(lambda ag: ag.backward_net(torch.as_tensor(goal, device="cuda")).cpu())      # batched inference entry point
+    assert pending(a) == 0 and torch.equal(za, zb)
+    updates(3)
+    meta = {"z": za[0].numpy()}
+    obs = rng.standard_normal(cfg.obs_dim).astype(np.float32)
+    aa, ab = both(lambda ag: ag.act(obs, meta, 10 ** 6, eval_mode=True))            # batch-1 fast path
+    assert pending(a) == 0 and np.array_equal(aa, ab)
+    updates(3)
+    # a mutation of the buffer: the queued updates must sample the contents they were CALLED on -- the buffer flushes its
+    # observers before it writes (b ran its updates before the write anyway)
+    assert pending(a) == 3
+    ep = [TimeStep(step_type=0 if t == 0 else (2 if t == 6 else 1), reward=0.1, discount=1.0,
+                   observation=rng.standard_normal(cfg.obs_dim).astype(np.float32), action=rng.uniform(-1, 1, cfg.action_dim).astype(np.float32),
+                   physics=np.zeros(2, np.float32)) for t in range(7)]
+    rbw = DeviceReplayBuffer(max_episodes=3, discount=cfg.discount, future=1.0, device="cuda")
+    for _ in range(2):
+        for ts in ep:
+            rbw.add(ts, {})
+    updates(4, rbw)                                                                 # another buffer: the queue on ``rb`` goes out first
+    assert pending(a) == 4
+    for ts in ep:
+        rbw.add(ts, {})                                                             # third episode lands: the ring changes under the queue
+    assert pending(a) == 0
+    updates(3, rbw)
     same()
-    both(lambda ag: ag.update_many(rb, step[0], 3))                                    # another entry point in between
+    updates(2)
+    a.cfg.lr = b.cfg.lr = 2e-4                                                       # other hyper-parameters from the next call on
+    updates(2)
+    assert pending(a) == 2
+    a.cfg.lr = b.cfg.lr = 1e-4
+    updates(2)
+    assert pending(a) == 2
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):                                                   # another stream: the queue goes out on ITS stream
+        updates(2)
+    torch.cuda.synchronize()
+    assert pending(a) == 2
+    both(lambda ag: ag.update_many(rb, step[0], 3))                                 # another update entry point
     step[0] += 3
+    assert pending(a) == 0
     updates(3)
-    assert a.rng_counts() == b.rng_counts()                                            # (reading them voids the head as well)
+    assert a.rng_counts() == b.rng_counts() and pending(a) == 0
+    updates(2)
+    a.cfg.use_hiplog = b.cfg.use_hiplog = True                                      # a metrics-on call: launched at once, behind the queue
+    ma, mb = both(lambda ag: ag.update(rb, step[0]))
+    step[0] += 1
+    a.cfg.use_hiplog = b.cfg.use_hiplog = False
+    assert pending(a) == 0 and ma == mb and len(ma) >= 14
+    updates(2)
+    both(lambda ag: ag.train(False))
+    assert pending(a) == 0
+    both(lambda ag: ag.train(True))
+    updates(3)
+    a = pickle.loads(pickle.dumps(a))                                               # the pickle holds every update() call made so far
     updates(3)
     same()
-    with chained():
-        a = pickle.loads(pickle.dumps(a))                                              # resumes with the draws an uninterrupted run makes
+    fresh = H.make_hip_agent(cfg, nets, metrics=False)
+    updates(2)
+    fresh.init_from(a)                                                              # reads a's views: a's queue goes out first
+    assert pending(a) == 0
+    fa, fb = H.get_agent_state(fresh), H.get_agent_state(b)
+    for k in fa:
+        np.testing.assert_array_equal(fa[k], fb[k], err_msg=k)
     updates(3)
+    a.flush()                                                                       # the explicit form
+    assert pending(a) == 0
     same()
     assert a.rng_counts() == b.rng_counts() == (step[0], 0)
 
@@ -1160,7 +1237,12 @@ def test_fifty_steps_per_seed_against_the_oracle(seed):
         assert set(m) == set(om)
         for k, v in om.items():
             tol = LOSS_RTOL if k not in ("M1", "F1", "B", "target_M", "q_loss") else 5e-4
-            assert m[k] == pytest.approx(v, rel=tol, abs=5e-6), (s, k)
+            # fb_loss = fb_diag + fb_offdiag + q_loss_coef q_loss (fb_ddpg.py:326, :340-342): its bound is the sum of its terms' bounds.
+            # Where the terms cancel (seed 1, step 12: -1.0213 + 0.9171 + 0.01 * 59.14 = -0.0322) the q_loss term alone -- an inverted
+            # covariance, rel 5e-4 here, and 4e-6 between two intra-op thread counts of the oracle itself -- moves the sum by more
+            # than the 5e-6 floor that holds for every other entry (r04: "within 1e-6 of its 5e-6 bound" at the box's thread count).
+            floor = 5e-6 + (cfg.q_loss_coef * 5e-4 * abs(om["q_loss"]) if (k == "fb_loss" and cfg.q_loss) else 0.0)
+            assert m[k] == pytest.approx(v, rel=tol, abs=floor), (s, k)
         want = oracle.state_tensors()
         for k, v in H.get_agent_state(agent).items():
             if k.startswith("adam_"):
@@ -1236,7 +1318,7 @@ def test_branched_graphs_are_refused_on_an_unverified_runtime_and_the_plain_form
     """the guard against ROCm 7.0's hipGraphLaunch crash (branched graphs launched from a high-priority stream)
     rests on runtime properties no API exposes, so the library only replays branched graphs on runtime versions it was verified
     on and builds single-queue graphs otherwise.  FBHIP_BRANCHED_GRAPHS=0 forces that fallback here: the 4-step graph is a chain,
-    the chained update() refuses, and the state equals the branched run's bit for bit (small dims)."""
+    deferred update() calls go out as such chains too, and the state equals the branched run's bit for bit (small dims)."""
     import ctypes as C
     import re
     from controllable_agent_amd import _lib
@@ -1264,10 +1346,9 @@ def test_branched_graphs_are_refused_on_an_unverified_runtime_and_the_plain_form
     b = H.make_hip_agent(cfg, nets, metrics=False)
     monkeypatch.setenv("FBHIP_GRAPH_DOT", str(tmp_path / "plain.dot"))
     b.update_many(rb, 0, 4)
-    monkeypatch.setenv("FBHIP_UPDATE_CHAIN", "1")
     for s in range(4, 8):
-        b.update(rb, s)                                  # (chaining asked for, branched graphs refused: plain updates)
-    assert b.__dict__.get("_chain_token") is None
+        b.update(rb, s)                                  # (queued; launched below as ONE 4-step single-queue graph)
+    b.flush()
     monkeypatch.delenv("FBHIP_BRANCHED_GRAPHS")
     monkeypatch.delenv("FBHIP_GRAPH_DOT")
     for s in range(4, 8):
