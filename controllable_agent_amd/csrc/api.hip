@@ -595,38 +595,23 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
             rc = enqueue_update(c, *hp, nullptr, MID, s);
             if (rc != FBHIP_OK) break;
             const bool more = i + 1 < n_steps;
-            // fork: V of this step's actor phase, then the next step's head on the twin workspace set
-            static const int fork_mode = [] { const char* e = getenv("FBHIP_FORK_LATE"); return e ? atoi(e) : 0; }();
-            const bool fork_late = fork_mode >= 1, v_in_chain = fork_mode == 2;
-            auto side_branch = [&, i]() -> int {
-                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) return (int)FBHIP_E_HIP;
-                int r = FBHIP_OK;
-                if (!v_in_chain) {
-                    r = enqueue_actor_v(c, c->side);
-                    if (r != FBHIP_OK) return r;
-                    if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) return (int)FBHIP_E_HIP;
-                }
+            if (more) {                          // fork: V of this step's actor phase, then the next step's head on the twin workspace set
+                // (capturing the side branch only when the actor phase reaches its first consumer of V, so that the critical path
+                //  MID -> TAIL -> MID keeps ONE queue and the join has 100 us of slack, was measured in round 5: the trace shows the
+                //  path on one queue, the rate moved by -0.5..+0.5 % -- a cross-queue edge costs its ~18 us wherever it lands)
+                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
+                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
+                rc = enqueue_actor_v(c, c->side);
+                if (rc != FBHIP_OK) break;
+                if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) break;
                 c->cur ^= 1;
-                r = enqueue_update(c, *hp, injs ? &injs[i + 1] : nullptr, HEAD, c->side);
+                rc = enqueue_update(c, *hp, injs ? &injs[i + 1] : nullptr, HEAD, c->side);
                 c->cur ^= 1;
-                return r;
-            };
-            if (more) {
-                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;      // the fork point: behind MID
-                if (fork_late) {
-                    // the side branch is CAPTURED when the actor phase reaches actor_q (its first consumer): the phase's own first
-                    // launches are then the first successors of the fork node, and the critical path MID -> TAIL -> MID keeps one queue
-                    c->before_actor_q = side_branch;
-                } else {
-                    rc = side_branch();
-                    if (rc != FBHIP_OK) break;
-                }
-                if (!v_in_chain) c->v_ready = c->events[128 + i];
+                if (rc != FBHIP_OK) break;
+                c->v_ready = c->events[128 + i];
             }
             rc = enqueue_update(c, *hp, nullptr, TAIL, s);
             c->v_ready = nullptr;
-            c->before_actor_q = nullptr;
-            if (he != hipSuccess) break;
             if (more) {                          // join, then continue on the set the head filled
                 if ((he = hipEventRecord(c->events[2 * i + 1], c->side)) != hipSuccess) break;
                 if ((he = hipStreamWaitEvent(s, c->events[2 * i + 1], 0)) != hipSuccess) break;

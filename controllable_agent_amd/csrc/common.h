@@ -26,21 +26,11 @@ struct GemmProblem {
     int epi;
     int tiles_m, tiles_n, tile_start;
     // grid-level split-K (small outputs): slice s handles K chunks [s*kper, (s+1)*kper) and writes raw partial
-    // tiles to partial[s][M][N] (+ partial column sums after them); the wave that arrives LAST at a 32x32 sub-tile's counter
-    // (``arrive``: one int per sub-tile, zero between launches) folds the slices in slice order and applies the epilogue --
-    // deterministic (the fold order is fixed, whoever folds), inside the launch.
+    // tiles to partial[s][M][N] (+ partial column sums after them); splitk_reduce folds them in slice order and
+    // applies the epilogue -- deterministic, no atomics.
     int kslices, kper;       // kper in units of the config's K chunk
     float* partial;
-    int* arrive;
-};
-
-// LayerNorm-backward column reduces (d gamma, d beta = sums of per-block partials) that ride in the next grouped GEMM launch
-// instead of paying for a launch of their own: tiny fold-the-partials jobs whose results only the optimiser reads
-constexpr int CR_MAX = 6;
-struct ColReduceJobs {
-    const float* partials[CR_MAX]; float* dgamma[CR_MAX]; float* dbeta[CR_MAX];
-    int rows[CR_MAX], n[CR_MAX], block_start[CR_MAX + 1];
-    int count;
+    int red_start;           // first element of this problem in the reduce launch
 };
 
 constexpr int MAX_GROUP = 8;
@@ -48,8 +38,6 @@ struct GemmGroup {
     GemmProblem p[MAX_GROUP];
     int n;
     int total_tiles;
-    int cr_blocks;           // workgroups in front of the tiles that run ``cr`` (0 or block_start[count] rounded up to 8)
-    ColReduceJobs cr;
 };
 
 // tile configurations: <waves along M, waves along N, waves along K>, each wave owns one 32x32 MFMA tile
@@ -57,7 +45,15 @@ enum GemmCfg { CFG_2x2x1 = 0, CFG_2x1x2 = 1, CFG_1x2x2 = 2, CFG_1x1x4 = 3, CFG_4
                CFG_COUNT };   // the last: the LDS-DMA kernel (128x64 tiles), needs gemm_problem_dma_ok()
 
 hipError_t launch_gemm_group(const GemmGroup& g, int cfg, hipStream_t stream);
-hipError_t launch_colreduce(const ColReduceJobs& cr, hipStream_t stream);   // the same jobs as a launch of their own (no GEMM follows)
+// LayerNorm-backward column reduces (d gamma, d beta = sums of per-block partials) that ride in a split-K reduce launch instead
+// of paying for a launch of their own: both are tiny fold-the-partials jobs whose results only the optimiser reads
+constexpr int CR_MAX = 6;
+struct ColReduceJobs {
+    const float* partials[CR_MAX]; float* dgamma[CR_MAX]; float* dbeta[CR_MAX];
+    int rows[CR_MAX], n[CR_MAX], block_start[CR_MAX + 1];
+    int count;
+};
+hipError_t launch_splitk_reduce(const GemmGroup& g, int total_elems, hipStream_t stream, const ColReduceJobs* extra = nullptr);
 int gemm_cfg_bkt(int cfg);    // K extent of one chunk of a tile configuration
 int gemm_cfg_bm(int cfg);     // tile rows / columns
 int gemm_cfg_bn(int cfg);
@@ -97,7 +93,7 @@ struct LnBwdProblem { const float* dy; int lddy; const float* y; int ldy; const 
                       int rows, n, vdy, vy, vx, vdx, vp, np; };
 struct LnBwdGroup { LnBwdProblem p[LN_MAX_GROUP]; int n; };
 // defer != nullptr: the column reduce of (d gamma, d beta) is NOT launched; its jobs are appended to *defer for
-// the next grouped GEMM launch / launch_colreduce (bit-identical result: same partials, same fold order)
+// launch_splitk_reduce (bit-identical result: same partials, same fold order)
 hipError_t launch_ln_tanh_bwd_group(LnBwdGroup g, hipStream_t s, ColReduceJobs* defer = nullptr);
 // out = scale * y / max(||y||, 1e-12) per row (F.normalize, fb_modules.py:229); grouped like the LayerNorm launches
 struct L2Problem { const float* y; int ldy; float* out; int ldo; float* norms; int rows, d; float scale; };

@@ -144,8 +144,6 @@ struct fbhip_ctx {
     hipEvent_t ev_gate = nullptr, ev_gate_in = nullptr;   // fbhip_order_legacy_stream_after / fbhip_order_stream_after_legacy
     hipStream_t last_stream = nullptr;      // the stream of the last update call (fbhip_destroy asks it whether a capture is open)
     hipEvent_t v_ready = nullptr;            // set while the actor phase of a pipelined graph is being built: V comes from the side branch
-    std::function<int()> before_actor_q;     // pipelined graph: captures the side branch (V + the next step's head) at this point of the actor
-                                             // phase, so that the phase's own first launches are the FIRST successors of the fork node
     fbhip::ReplayView rv{};
     uint64_t seed = 0;
     uint32_t rank = 0;
@@ -196,8 +194,7 @@ namespace host {
 GemmProblem P(const float* A, int lda, int akc, const float* B, int ldb, int bkc, float* C, int ldc, int M, int N,
               int K, const float* bias = nullptr, int epi = EPI_NONE, const float* aux = nullptr, int ldaux = 0,
               float* colsum = nullptr);
-constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB: partial tiles, then ...
-constexpr size_t SPLITK_ARRIVE_INTS = (size_t)1 << 16;     // ... the arrival counters of the split problems' sub-tiles (the slab's tail)
+constexpr size_t SPLITK_SLAB_FLOATS = (size_t)6 << 20;     // 24 MiB
 int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s);
 
 struct Ops {

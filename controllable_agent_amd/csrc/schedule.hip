@@ -62,12 +62,10 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
     // longest workgroups first, so that the stragglers of a heterogeneous group start at t = 0 and hide under the
     // bulk (the hardware dispatches workgroups in launch order)
     std::stable_sort(v.begin(), v.end(), [&](const GemmProblem& a, const GemmProblem& b) { return cost_of(a) > cost_of(b); });
-    // the slab's tail holds the arrival counters of the split problems' 32x32 sub-tiles (zero between launches: the last arriver resets its own)
-    int* const arrive = slab ? reinterpret_cast<int*>(slab + SPLITK_SLAB_FLOATS - SPLITK_ARRIVE_INTS) : nullptr;
     size_t i = 0;
     while (i < v.size()) {
         GemmGroup g{};
-        int start = 0, arrive_used = 0;
+        int start = 0, red = 0;
         size_t slab_used = 0;
         // workgroups / total work of this launch without K slicing
         long base_blocks = 0, work = 0;
@@ -100,11 +98,10 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
                 const int kper = (kchunks + want - 1) / want;
                 const int ks = (kchunks + kper - 1) / kper;
                 const size_t need = (size_t)ks * p.M * p.N + (size_t)ks * p.M;
-                const int subs = p.tiles_m * p.tiles_n * (cfg == CFG_DMA128 ? 8 : gemm_cfg_bm(cfg) * gemm_cfg_bn(cfg) / 1024);
-                if (ks > 1 && slab_used + need <= SPLITK_SLAB_FLOATS - SPLITK_ARRIVE_INTS && arrive_used + subs <= (int)SPLITK_ARRIVE_INTS) {
-                    p.kslices = ks; p.kper = kper; p.partial = slab + slab_used; p.arrive = arrive + arrive_used;
+                if (ks > 1 && slab_used + need <= SPLITK_SLAB_FLOATS) {
+                    p.kslices = ks; p.kper = kper; p.partial = slab + slab_used; p.red_start = red;
                     slab_used += (need + 3) & ~(size_t)3;
-                    arrive_used += subs;
+                    red += p.M * p.N + p.M;
                 }
             }
             p.tile_start = start;
@@ -112,21 +109,20 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
             g.p[g.n++] = p;
         }
         g.total_tiles = start;
-        // the LayerNorm column reduces deferred by the previous round ride in front of this launch's tiles
-        if (ctx != nullptr && ctx->cr_pending.count > 0 && cfg != CFG_DMA128) {
-            g.cr = ctx->cr_pending;
-            g.cr_blocks = (g.cr.block_start[g.cr.count] + 7) & ~7;
-            ctx->cr_pending.count = 0;
-        }
         static const bool log_launches = [] { const char* e = getenv("FBHIP_GEMM_LOG"); return e && e[0] == '1'; }();
         if (log_launches) {                      // tools/gemm_launch_report.py joins these lines with a kernel trace
             double fl = 0;
             for (int q = 0; q < g.n; ++q) fl += 2.0 * g.p[q].M * g.p[q].N * g.p[q].K;
-            fprintf(stderr, "GEMMLOG cfg=%d wgs=%d gflop=%.4f reduce=%d :", cfg, start + g.cr_blocks, fl * 1e-9, 0);
+            fprintf(stderr, "GEMMLOG cfg=%d wgs=%d gflop=%.4f reduce=%d :", cfg, start, fl * 1e-9, red > 0 ? 1 : 0);
             for (int q = 0; q < g.n; ++q) fprintf(stderr, " %dx%dx%d/%d", g.p[q].M, g.p[q].N, g.p[q].K, g.p[q].kslices);
             fprintf(stderr, "\n");
         }
         HIPCK(ctx, launch_gemm_group(g, cfg, s));
+        if (red > 0) {
+            const bool take = ctx != nullptr && ctx->cr_pending.count > 0;
+            HIPCK(ctx, launch_splitk_reduce(g, red, s, take ? &ctx->cr_pending : nullptr));
+            if (take) ctx->cr_pending.count = 0;
+        }
     }
     return FBHIP_OK;
 }
@@ -140,10 +136,11 @@ int run_gemms(fbhip_ctx* ctx, std::vector<GemmProblem> v, hipStream_t s) {
 // (Measured on MI355X: running independent chains as parallel hipGraph branches instead buys nothing -- the step
 // costs the SUM of its kernels' standalone times -- so everything is enqueued on the caller's stream.)
 
-// the LayerNorm column reduces deferred by the previous round go out now if no grouped GEMM launch took them
+// the LayerNorm column reduces deferred by the previous round go out now if no split-K reduce launch took them
 int flush_colreduce(fbhip_ctx* c, hipStream_t s) {
     if (c->cr_pending.count > 0) {
-        HIPCK(c, launch_colreduce(c->cr_pending, s));
+        GemmGroup none{};
+        HIPCK(c, launch_splitk_reduce(none, 0, s, &c->cr_pending));
         c->cr_pending.count = 0;
     }
     return FBHIP_OK;
@@ -855,7 +852,6 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
         // gradient of forward_net here)
         ch.push_back([=, &w](Ops& o2) {
             o2.post.push_back([=, &w](hipStream_t q) -> int {
-                if (c->before_actor_q) { auto f = std::move(c->before_actor_q); c->before_actor_q = nullptr; RC(f()); }
                 if (v_ready != nullptr) HIPCK(c, hipStreamWaitEvent(q, v_ready, 0));
                 HIPCK(c, launch_actor_q(w.fsO.p.p, 2 * H, w.dp.p, 2 * H, w.z.p, Lz, c->F_p.b4[0], c->F_p.b4[1], w.as.mu.p, La,
                                         w.Xopi.p + aoff, w.Xopi.ld, hp.stddev, hp.want_metrics ? w.metrics : nullptr,
