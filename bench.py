@@ -217,6 +217,22 @@ def dominant_kernel_probe(stream_iters=50):
                     "per update, whose shapes differ (4.3-8.7 GFLOP, 7-95 us)"}
 
 
+def dominant_in_step():
+    """What the dominant kernel gets INSIDE the benchmarked step (its launched-alone figure above is its best single shape): sum of
+    GFLOP / sum of kernel time over all its launches of an update, from the kernel trace of the same bench command
+    (tools/profile_round.sh -> tools/dominant_in_step.py -> profiles/dominant_in_step.json; not measured by this run)."""
+    f = Path(__file__).resolve().parent / "profiles" / "dominant_in_step.json"
+    try:
+        d = json.loads(f.read_text())
+        k = d["kernels"][0]
+        return {"kernel": k["kernel"], "launches_per_update": k["launches_per_update"], "gflop_per_update": k["gflop_per_update"],
+                "us_per_update": k["us_per_update"], "tflops": k["tflops_in_step"], "frac_of_peak": k["frac_of_peak_in_step"],
+                "source": f"profiles/dominant_in_step.json ({d.get('tag', '?')}: rocprofv3 kernel trace of this bench command + the library's "
+                          "launch log; kernel times of the graph's two branches overlap)"}
+    except (OSError, KeyError, IndexError, ValueError):
+        return None
+
+
 def _beat(what):
     """progress mark for the supervising parent (supervise_ranks): the child is alive and got this far"""
     f = os.environ.get("FBHIP_BENCH_HEARTBEAT")
@@ -333,6 +349,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps updates between barrier + synchronize pairs) is run this many times; "
                          "value / ms_per_step are the MEDIAN repeat, every repeat is listed under 'repeats'")
+    ap.add_argument("--no-dominant-probe", action="store_true",
+                    help="skip the launched-alone timing of the dominant GEMM shape (kernel traces of the step without its 55 extra launches)")
     ap.add_argument("--no-single-update-probe", action="store_true",
                     help="skip the extra measurement of plain agent.update() calls (config.single_update_steps_per_s)")
     ap.add_argument("--steps-per-launch", type=int, default=32,
@@ -620,7 +638,9 @@ def main():
                                  "measured updates/s, per GPU, vs the exact-fp32 MFMA peak"},
         }
         if args.workload == "walker" and world == 1:
-            out["roofline"]["dominant_kernel"] = dominant_kernel_probe()
+            if not args.no_dominant_probe:
+                out["roofline"]["dominant_kernel"] = dominant_kernel_probe()
+                out["roofline"]["dominant_kernel"]["in_step"] = dominant_in_step()
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

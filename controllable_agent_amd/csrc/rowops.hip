@@ -951,8 +951,11 @@ constexpr int AHB_MAXA = 16;
 // LNE > 0: ``dt1`` is dL/d(tanh output) of forward_net's obs_action trunk and the LayerNorm+tanh backward of that row (no
 // parameter gradients: forward_net's are discarded in update_actor) happens here too, LNE = ceil(H / 64) elements per lane --
 // one more launch off the phase's dependency chain.  LNE == 0: ``dt1`` already is the gradient wrt the pre-LayerNorm values.
+// The workgroup is 4 or 8 waves (blockDim.x = 256 / 512; one row per wave): where the two weight slices allow only ONE workgroup per
+// CU (a = 12, H = 1024: 98 KB) and there are more than 256 x 4 rows, eight waves share a fill -- 256 workgroups, one round, instead of
+// two rounds of 512 four-wave ones.
 template <int AHB_N, bool EXACT, int LNE>
-__global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __restrict__ dt1, int ldt,
+__global__ void __launch_bounds__(LNE <= 16 ? 512 : 256) actor_head_bwd_kernel(const float* __restrict__ dt1, int ldt,
                                                              const float* __restrict__ lnY, int ldy,
                                                              const float* __restrict__ lnX, int ldx,
                                                              const float* __restrict__ lnStats,
@@ -968,7 +971,8 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     float* sW4 = ahb_lds + (size_t)a * H;
     // LNE > 0: everything this wave needs of its row is requested BEFORE the LDS fill (one round trip for both)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int row = min(blockIdx.x * 4 + wid, rows - 1);            // surplus waves redo the last row (no early exit: same stores)
+    const int NT = blockDim.x;
+    const int row = min((int)(blockIdx.x * (NT >> 6)) + wid, rows - 1);   // surplus waves redo the last row (no early exit: same stores)
     float dyv[LNE > 0 ? LNE : 1], yv[LNE > 0 ? LNE : 1], xv[LNE > 0 ? LNE : 1], gam[LNE > 0 ? LNE : 1], pva[LNE > 0 ? LNE : 1];
     float mean = 0.f, rstd = 0.f;
     if constexpr (LNE > 0) {
@@ -983,7 +987,7 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
     }
     // Every global load below is UNCONDITIONAL (clamped index, mask at the use): hipcc otherwise waits for each load right
     // where a select meets it, and a 24-load fill becomes 24 round trips (measured: 27 us for this kernel).
-    for (int m = threadIdx.x; m < H; m += 256) {
+    for (int m = threadIdx.x; m < H; m += NT) {
         float v[AHB_N];
 #pragma unroll
         for (int jj = 0; jj < AHB_N; ++jj) v[jj] = W1a[(size_t)m * ldw1 + min(jj, a - 1)];
@@ -1001,7 +1005,7 @@ __global__ void __launch_bounds__(256) actor_head_bwd_kernel(const float* __rest
             for (int jj = 0; jj < AHB_N; ++jj)
                 if (EXACT || jj < a) reinterpret_cast<float4*>(sW4 + (size_t)jj * H)[k4] = v[jj];
         }
-        for (int kk = threadIdx.x + 256; kk < H / 4; kk += 256)
+        for (int kk = threadIdx.x + NT; kk < H / 4; kk += NT)
 #pragma unroll
             for (int jj = 0; jj < AHB_N; ++jj)
                 if (EXACT || jj < a) reinterpret_cast<float4*>(sW4 + (size_t)jj * H)[kk] = reinterpret_cast<const float4*>(W4 + (size_t)jj * ldw4)[kk];
@@ -1138,8 +1142,13 @@ hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, in
     const bool ln = lnY != nullptr;
     if (ln && (H > 2048 || !lnX || !lnStats || !lnGamma)) return hipErrorInvalidValue;
     const int lne = !ln ? 0 : (H <= 1024 ? 16 : 32);
+    // eight waves per workgroup where the LDS image leaves room for one workgroup per CU only and four-wave workgroups would need a
+    // second round (FBHIP_AHB_WAVES=4 / 8 forces either)
+    static const int force = [] { const char* e = getenv("FBHIP_AHB_WAVES"); return e ? atoi(e) : 0; }();
+    const size_t lds_bytes = (size_t)2 * a * H * sizeof(float);
+    const int nw = lne > 16 ? 4 : (force == 4 || force == 8 ? force : ((lds_bytes > 80 * 1024 && rows > 4 * 256) ? 8 : 4));   // (H > 1024: a row's registers need the four-wave budget)
 #define AHB_LAUNCH1(NA, EX, LN)                                                                                          \
-    hipLaunchKernelGGL((actor_head_bwd_kernel<NA, EX, LN>), dim3((rows + 3) / 4), dim3(256), (size_t)2 * a * H * sizeof(float), \
+    hipLaunchKernelGGL((actor_head_bwd_kernel<NA, EX, LN>), dim3((rows + nw - 1) / nw), dim3(64 * nw), (size_t)2 * a * H * sizeof(float), \
                        s, dt1, ldt, lnY, ldy, lnX, ldx, lnStats, lnGamma, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd,  \
                        dp, lddp, rows, H, a)
 #define AHB_LAUNCH(NA, EX)                                                                                               \

@@ -10,6 +10,13 @@ import typing as tp
 import torch
 
 
+def _flush(agent: tp.Any) -> None:
+    """A bare ``torch.cuda.synchronize()`` does not launch what ``FBHipAgent.update`` has queued: the loop's timing points do."""
+    f = getattr(agent, "flush", None)
+    if f is not None:
+        f()
+
+
 def run_offline(agent: tp.Any, replay_loader: tp.Any, num_grad_steps: int, log_every_steps: int = 1000,
                 log_fn: tp.Optional[tp.Callable[[int, tp.Dict[str, float]], None]] = None, start_step: int = 0,
                 steps_per_launch: int = 1) -> float:
@@ -31,11 +38,13 @@ def run_offline(agent: tp.Any, replay_loader: tp.Any, num_grad_steps: int, log_e
         if log_fn is not None and metrics:
             log_fn(step, metrics)
         if log_every_steps and (i + 1) % log_every_steps == 0:
+            _flush(agent)                                             # update() calls the agent still holds back (deferred batching)
             torch.cuda.synchronize()
             now = time.time()
             if log_fn is not None:
                 log_fn(step, {"fps": log_every_steps / (now - t0)})
             t0 = now
         i += 1
+    _flush(agent)
     torch.cuda.synchronize()
     return num_grad_steps / (time.time() - t_all)

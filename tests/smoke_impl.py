@@ -23,6 +23,8 @@ def run_smoke() -> None:
         got = agent.update_injected(rb, s, H.draws_dict(d))
         for k in ("fb_loss", "fb_offdiag", "orth_loss", "actor_loss", "q"):
             assert abs(got[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k])), (s, k, got[k], want[k])
-    agent.update(rb, 2)                          # production mode: on-device sampler + hipGraph
+    agent.update(rb, 2)                          # production mode: on-device sampler + hipGraph (queued: metrics are off ...)
+    agent.flush()                                # ... and launched here
     torch.cuda.synchronize()
+    assert agent.step_counts()[0] >= 1
     print("smoke ok:", {k: round(got[k], 5) for k in ("fb_loss", "actor_loss")})

@@ -1201,13 +1201,25 @@ def _one_random_update(cfg, goal_space, seed):
     # fp32 oracle's is as large or larger (tools/tolerance_probe.py, profiles/r03_tolerance_probe.txt).  No fixed loose bound.
     o64 = fo.OracleAgent(cfg, nets, torch.float64)
     o64.update(batch, draws, keep=True)
+    # The yardstick is what fp32 EVALUATION ORDER does to this configuration, not one run's luck: the fp32 oracle at the suite's
+    # intra-op thread count and at a second one (1 <-> 8 threads = serial / blocked summation in torch's CPU kernels), the larger of
+    # the two distances.  (With one thread only, config 363's actor gradient -- a row changing heads in torch.min -- sits 2.6e-6 from
+    # fp64 where the 8-thread evaluation sits 6e-6 and the HIP step 2.2e-5: the bound must not depend on the box's core count.)
+    n_now = torch.get_num_threads()
+    torch.set_num_threads(8 if n_now == 1 else 1)
+    try:
+        oracle_b = fo.OracleAgent(cfg, nets)
+        oracle_b.update(batch, draws, keep=True)
+    finally:
+        torch.set_num_threads(n_now)
     for net, key in (("forward_net", "grads_forward"), ("backward_net", "grads_backward"), ("actor", "grads_actor")):
         for k, g in agent._grad_views[net].state_dict().items():
             ref = o64.last[key][k]
             if float(ref.abs().max()) == 0.0:
                 assert float(g.abs().max()) == 0.0, (net, k, cfg)
             else:
-                e_hip, e_o32 = H.rel_err(g.cpu().double(), ref), H.rel_err(oracle.last[key][k].double(), ref)
+                e_hip = H.rel_err(g.cpu().double(), ref)
+                e_o32 = max(H.rel_err(oracle.last[key][k].double(), ref), H.rel_err(oracle_b.last[key][k].double(), ref))
                 assert e_hip <= 4.0 * e_o32 + 1e-6, (net, k, e_hip, e_o32, cfg)
     for nv in (agent.forward_net, agent.backward_net, agent.actor, *agent._grad_views.values()):
         assert nv.pad_abs_max() == 0.0, nv._name

@@ -21,5 +21,6 @@ while done < n:
     k = min(8, n - done) if mode == "many" else 1
     agent.update_many(rb, done, k) if k > 1 else agent.update(rb, done)
     done += k
+agent.flush()
 torch.cuda.synchronize()
 print(n, mode, repr(ck()))

@@ -65,9 +65,11 @@ def main():
     run(0, args.warmup)
     for sz in {spl} | ({args.steps % spl} if args.steps % spl else set()):
         run(args.warmup, sz)
+    agent.flush()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
+    agent.flush()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     rate = args.steps / dt

@@ -15,6 +15,19 @@ if [ -n "$DB" ]; then
   python $ROOT/tools/prof_timeline.py $DB > $OUT/${TAG}_step_timeline.txt
   rm -f $OUT/${TAG}_trace/*.db
 fi
+# the GEMM kernels inside the benchmarked step: GFLOP (launch log) and kernel time (trace) per update and tile configuration
+FBHIP_GEMM_LOG=1 timeout 600 rocprofv3 --kernel-trace -d $OUT/${TAG}_gtrace -o t -- python $ROOT/bench.py --steps 320 --warmup 64 --repeats 1 --no-cpu-baseline --no-single-update-probe --no-dominant-probe > /dev/null 2> $OUT/${TAG}_gemmlog.txt
+DB=$(ls $OUT/${TAG}_gtrace/*.db 2>/dev/null | head -1)
+if [ -n "$DB" ]; then
+  python $ROOT/tools/dominant_in_step.py $DB $OUT/${TAG}_gemmlog.txt $OUT/${TAG}_dominant_in_step.json > $OUT/${TAG}_gemm_in_step.txt
+  python - <<PY
+import json
+f = "$OUT/${TAG}_dominant_in_step.json"
+d = json.load(open(f)); d["tag"] = "$TAG"; json.dump(d, open(f, "w"), indent=1)
+PY
+  rm -rf $OUT/${TAG}_gtrace
+fi
+grep -c GEMMLOG $OUT/${TAG}_gemmlog.txt > /dev/null && grep GEMMLOG $OUT/${TAG}_gemmlog.txt | head -120 > $OUT/${TAG}_gemm_launch_log.txt; rm -f $OUT/${TAG}_gemmlog.txt
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
   timeout 420 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$N -o p -- python $ROOT/bench.py --steps 64 --warmup 32 --repeats 1 --no-cpu-baseline --no-single-update-probe > $OUT/${TAG}_pmc_$N.log 2>&1

@@ -80,9 +80,11 @@ def main():
         run(args.warmup, sz)
     rates = []
     for rep in range(3):
+        agent.flush()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(args.warmup, args.steps)
+        agent.flush()
         torch.cuda.synchronize()
         rates.append(args.steps / (time.perf_counter() - t0))
     rate = sorted(rates)[1]

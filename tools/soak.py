@@ -21,6 +21,7 @@ while done < n:
     k = min(8, n - done)
     agent.update_many(rb, done, k) if k > 1 else agent.update(rb, done)
     done += k
+agent.flush()
 torch.cuda.synchronize()
 dt = time.time() - t0
 agent.cfg.use_tb = True
