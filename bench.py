@@ -145,13 +145,26 @@ def cpu_baseline(seed=1, budget_s=12.0, max_steps=120):
             "also": also}
 
 
+def kernel_sources_sha16():
+    """digest of controllable_agent_amd/csrc/*.{hip,h,inc}: which build a recorded profile belongs to"""
+    import hashlib
+    h = hashlib.sha256()
+    src = Path(__file__).resolve().parent / "controllable_agent_amd" / "csrc"
+    for f in sorted(list(src.glob("*.hip")) + list(src.glob("*.h")) + list(src.glob("*.inc"))):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload="walker"):
     """(bytes per update, where the figure comes from) of the last COMMITTED PMC passes (profiles/traffic*.json, made by
     tools/profile_round.sh + tools/pmc_summary.py); (None, None) when no pass is on file.  ``--pmc`` measures it live instead."""
     f = Path(__file__).resolve().parent / "profiles" / ("traffic.json" if workload == "walker" else f"traffic_{workload}.json")
     try:
         d = json.loads(f.read_text())
-        return float(d["hbm_bytes_per_update"]), f"profiles/{f.name} (round {d.get('round', '?')}: an earlier build's PMC passes, not this run)"
+        same = d.get("kernel_sources_sha16") == kernel_sources_sha16()
+        return float(d["hbm_bytes_per_update"]), (f"profiles/{f.name} (round {d.get('round', '?')}: PMC passes of "
+                                                  + ("THIS build -- the same kernel sources, csrc digest " + str(d.get("kernel_sources_sha16")) if same else
+                                                     "an earlier build, not this run") + "; --pmc measures live)")
     except (OSError, KeyError, ValueError):
         return None, None
 
@@ -227,8 +240,10 @@ def dominant_in_step():
         k = d["kernels"][0]
         return {"kernel": k["kernel"], "launches_per_update": k["launches_per_update"], "gflop_per_update": k["gflop_per_update"],
                 "us_per_update": k["us_per_update"], "tflops": k["tflops_in_step"], "frac_of_peak": k["frac_of_peak_in_step"],
-                "source": f"profiles/dominant_in_step.json ({d.get('tag', '?')}: rocprofv3 kernel trace of this bench command + the library's "
-                          "launch log; kernel times of the graph's two branches overlap)"}
+                "source": f"profiles/dominant_in_step.json ({d.get('tag', '?')}, "
+                          + ("the same kernel sources as this run" if d.get("kernel_sources_sha16") == kernel_sources_sha16() else "an earlier build")
+                          + ": rocprofv3 kernel trace of this bench command + the library's launch log; kernel times of the graph's two "
+                          "branches overlap)"}
     except (OSError, KeyError, IndexError, ValueError):
         return None
 

@@ -475,13 +475,13 @@ class FBHipAgent:
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     def __del__(self) -> None:
-        ctx = getattr(self, "_ctx", None)
+        ctx = self.__dict__.get("_ctx")          # (not the flushing attribute: update() calls nobody can observe any more are dropped)
         if ctx:
             try:
                 _lib.load().fbhip_destroy(ctx)
             except Exception:       # interpreter shutdown
                 pass
-            self._ctx = None
+            self.__dict__["_ctx"] = None
 
     # ------------------------------------------------------------------ pickling (pretrain.py:437-449 pickles the agent object)
     def __getstate__(self) -> tp.Dict[str, tp.Any]:
@@ -1033,7 +1033,8 @@ class FBHipAgent:
         microseconds per call: the host's share of a queued update)."""
         d = self.__dict__
         if (rb.__class__ is not DeviceReplayBuffer or not d.get("defer_updates", True) or not d["_use_graph"] or (_dist.is_available() and _dist.is_initialized()) or
-                os.environ.get("FBHIP_UPDATE_DEFER", "1") == "0" or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1"):
+                os.environ.get("FBHIP_UPDATE_DEFER", "1") == "0" or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or
+                torch.cuda.is_current_stream_capturing()):       # (inside a caller's capture the launches must land IN it)
             return None
         f = self._hp_fields(self.cfg)
         if f[-1] or f[-2] or f[-3]:              # metrics on: the caller reads the result of THIS call
@@ -1414,8 +1415,9 @@ def _flushing_attribute(name: str) -> property:
     return property(get, put)
 
 
+# (``_ctx`` too: EVERY call into the library on behalf of this agent first launches what the agent still holds back)
 for _n in ("_fb_params", "_fb_grads", "_fb_m", "_fb_v", "_fb_targets", "_actor_params", "_actor_grads", "_actor_m", "_actor_v",
-           "_workspace", "_adam_views", "_grad_views"):
+           "_workspace", "_adam_views", "_grad_views", "_ctx"):
     setattr(FBHipAgent, _n, _flushing_attribute(_n))
 del _n
 

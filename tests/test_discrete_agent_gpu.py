@@ -486,3 +486,20 @@ def test_two_ranks_global_batch_equal_one_device_on_the_concatenated_batch(q_los
             assert H.rel_err(results[0][k], v) < 2e-4, k
         else:
             np.testing.assert_allclose(results[0][k], v, rtol=0, atol=3e-6, err_msg=k)
+
+
+def test_deferred_update_calls_equal_eager_calls():
+    """DiscreteFBHipAgent with metrics off: update() calls are queued and go out as n-step graphs (agent.py "deferred batching");
+    same state as eager single launches, bit for bit; act() launches the queue first."""
+    cfg, rng, nets, storage, lengths = _mid_case(133, action_dim=4, batch_size=128, hidden_dim=64, z_dim=16)
+    a1, a2 = (H.make_hip_agent(cfg, nets, metrics=False, discrete=True) for _ in range(2))
+    a2.defer_updates = False
+    rb = _buffer(storage, lengths, cfg.discount, cfg.future)
+    for s in range(40):
+        assert a1.update(rb, s) == {} and a2.update(rb, s) == {}
+    assert a1.__dict__["_pending"][3] == 8                  # 32 went out when the queue was full
+    a1.act(storage["observation"][0, 1], a1.init_meta(), step=10, eval_mode=True)
+    assert a1.__dict__.get("_pending") is None
+    for a, b in zip(H.get_agent_state(a1).values(), H.get_agent_state(a2).values()):
+        np.testing.assert_array_equal(a, b)
+    assert a1.step_counts() == a2.step_counts()

@@ -300,6 +300,7 @@ def test_sf_pipelined_update_many_equals_single_updates(name):
     rb = _buffer(storage, lengths, cfg.discount, cfg.future)
     a1 = make_sf_agent(cfg, nets, meta["feature_learner"], meta["sf_q_loss"], meta["goal_space"], metrics=False)
     a2 = pickle.loads(pickle.dumps(a1))
+    a2.defer_updates = False                               # single fbhip_update launches (not queued into an n-step graph)
     a1.update_many(rb, 0, 5)
     for s in range(5):
         a2.update(rb, s)
@@ -474,11 +475,33 @@ def test_sf_num_sf_updates_runs_that_many_updates_per_call():
     a1 = mk()
     a1.load_nets({n: dict(p) for n, p in nets.items()})
     a2 = pickle.loads(pickle.dumps(a1))
+    a1.defer_updates = False
     a1.update(rb, 0)
     assert a1.step_counts() == (3, 3)
     a1.update(rb, 1)
     a2.update_many(rb, 0, 2)
     assert a1.step_counts() == a2.step_counts() == (6, 6)
     s1, s2 = get_sf_state(a1), get_sf_state(a2)
+    for k in s1:
+        np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)
+
+
+def test_sf_deferred_update_calls_equal_eager_calls():
+    """SFHipAgent.update() = num_sf_updates queued updates per call (agent.py "deferred batching"): the queue is launched as n-step
+    graphs and equals eager single launches bit for bit; reading the state launches it."""
+    from controllable_agent_amd.agent import SFHipAgent
+    meta, z, cfg, nets, storage, lengths = sf_trace_inputs("tiny_sf_icm_trace")
+    rb = _buffer(storage, lengths, cfg.discount)
+    mk = lambda: SFHipAgent(**sf_kwargs(cfg, "icm", True, metrics=False, num_sf_updates=2))
+    torch.manual_seed(7)
+    a1 = mk()
+    a1.load_nets({n: dict(p) for n, p in nets.items()})
+    a2 = pickle.loads(pickle.dumps(a1))
+    a2.defer_updates = False
+    for s in range(9):
+        assert a1.update(rb, s) == {} and a2.update(rb, s) == {}
+    assert a1.__dict__["_pending"][3] == 18 and a2.__dict__.get("_pending") is None
+    s1, s2 = get_sf_state(a1), get_sf_state(a2)
+    assert a1.__dict__.get("_pending") is None and a1.step_counts() == a2.step_counts() == (18, 18)
     for k in s1:
         np.testing.assert_array_equal(s1[k], s2[k], err_msg=k)

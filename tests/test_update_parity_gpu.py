@@ -416,6 +416,7 @@ def test_debug_identity_backward_map_surface_and_pipelined_graph():
     a2 = pickle.loads(pickle.dumps(a1))
     assert len(a2.backward_net.state_dict()) == 0
     a1.update_many(rb, 0, 5)
+    a2.defer_updates = False                               # single fbhip_update launches
     for s in range(5):
         a2.update(rb, s)
     s1, s2 = H.get_agent_state(a1), H.get_agent_state(a2)
@@ -709,6 +710,7 @@ def test_update_many_equals_consecutive_updates():
     storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
     rb = _buffer(storage, lengths, cfg.discount)
     a1, a2, a3 = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(3))
+    a1.defer_updates = False                               # every call its own fbhip_update launch (not queued into an n-step graph)
     for s in range(7):
         a1.update(rb, s)
     a2.update_many(rb, 0, 4)
