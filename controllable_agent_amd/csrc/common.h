@@ -25,6 +25,7 @@ struct GemmProblem {
     int a_vec, b_vec;        // 16-byte aligned base + ld % 4 == 0 -> float4 global loads
     int epi;
     int tiles_m, tiles_n, tile_start;
+    int xgm, xgn;            // > 0: the 8 XCDs own an xgm x xgn grid of BLOCKS of this problem's tiles (gemm_problem_finalize); 0: bands of rows
     // grid-level split-K (small outputs): slice s handles K chunks [s*kper, (s+1)*kper) and writes raw partial
     // tiles to partial[s][M][N] (+ partial column sums after them); splitk_reduce folds them in slice order and
     // applies the epilogue -- deterministic, no atomics.

@@ -198,7 +198,14 @@ __global__ void __launch_bounds__(512) gemm_kernel(const GemmGroup g) {
     const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (jb >> 3);
     const int tiles_mn = p.tiles_m * p.tiles_n;
     const int slice = t / tiles_mn, tt = t % tiles_mn;        // slice-major: neighbours share operand panels
-    const int tn = tt % p.tiles_n, tm = tt / p.tiles_n;
+    int tn = tt % p.tiles_n, tm = tt / p.tiles_n;
+    if (p.xgn > 0) {
+        // 2-D ownership: XCD x owns block (x / xgn, x % xgn) of an xgm x xgn grid of tile blocks, so its L2 holds 1 / xgm of the A
+        // rows and 1 / xgn of the B rows instead of a band of A and ALL of B (the fabric fetch of a 1024 x 2048 output: 2.1x less)
+        const int bn = p.tiles_n / p.xgn, bm = p.tiles_m / p.xgm, j = jb >> 3;
+        tm = (xcd / p.xgn) * bm + j / bn;
+        tn = (xcd % p.xgn) * bn + j % bn;
+    }
     const int M = p.M, N = p.N;
     const int kb = slice * p.kper * BKT;                       // this workgroup's K range [kb, K)
     const int K = min(p.K, kb + p.kper * BKT);
@@ -560,7 +567,12 @@ __global__ void __launch_bounds__(256 + 64 * DmaGeom<TM>::NPW) gemm_dma_kernel(c
     const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (jb >> 3);
     const int tiles_mn = p.tiles_m * p.tiles_n;
     const int slice = t / tiles_mn, tt = t % tiles_mn;
-    const int tn = tt % p.tiles_n, tm = tt / p.tiles_n;
+    int tn = tt % p.tiles_n, tm = tt / p.tiles_n;
+    if (p.xgn > 0) {                                            // 2-D XCD ownership, see gemm_kernel
+        const int bn = p.tiles_n / p.xgn, bm = p.tiles_m / p.xgm, j = jb >> 3;
+        tm = (xcd / p.xgn) * bm + j / bn;
+        tn = (xcd % p.xgn) * bn + j % bn;
+    }
     const int M = p.M, N = p.N;
     const int kb = slice * p.kper * BKT;
     const int K = min(p.K, kb + p.kper * BKT);
@@ -816,6 +828,23 @@ void gemm_problem_finalize(GemmProblem& p, int cfg) {
     p.tiles_n = (p.N + BN - 1) / BN;
     p.a_vec = (((uintptr_t)p.A & 15) == 0 && (p.lda & 3) == 0) ? 1 : 0;
     p.b_vec = (((uintptr_t)p.B & 15) == 0 && (p.ldb & 3) == 0) ? 1 : 0;
+    // Which tiles of a problem go through which XCD's L2 (workgroup b runs on XCD b % 8: observed, used for speed only, never for
+    // correctness).  Default: bands of tile rows (each XCD a contiguous run of the row-major tile list).  FBHIP_GEMM_XCD2D=1: a grid of
+    // xgm x xgn tile BLOCKS, the one that minimises what an XCD's L2 has to hold (M / xgm rows of A + N / xgn rows of B) -- measured in
+    // round 5 (profiles/r05m_*, r05o_*, r05p_*): FETCH_SIZE 753 -> 545 MB raw per update (-28 %), and the step 0.6 % SLOWER (walker
+    // 1210.4 -> 1203.2, quadruped 613.2 -> 608.8; kernel table: 64x32 tiles -3.6 %, 64x64 +0.7 %, 32x32 +8 %): the re-fetch
+    // through eight L2s is served by the Infinity Cache and is not what bounds these kernels, so the bands stay the default.
+    p.xgm = p.xgn = 0;
+    const char* xe = getenv("FBHIP_GEMM_XCD2D");                  // (host side, when a launch is built: read every time so that tests can switch it)
+    if (xe != nullptr && xe[0] == '1' && p.kslices == 1 && cfg != CFG_1x1x4) {
+        long best = -1;
+        for (int gm = 1; gm <= 8; gm *= 2) {
+            const int gn = 8 / gm;
+            if (p.tiles_m % gm || p.tiles_n % gn) continue;
+            const long cost = (long)p.M / gm + (long)p.N / gn;
+            if (best < 0 || cost < best) { best = cost; p.xgm = gm; p.xgn = gn; }
+        }
+    }
 }
 
 int pick_gemm_cfg(int M, int N, int K) {

@@ -1144,7 +1144,8 @@ hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, in
     const int lne = !ln ? 0 : (H <= 1024 ? 16 : 32);
     // eight waves per workgroup where the LDS image leaves room for one workgroup per CU only and four-wave workgroups would need a
     // second round (FBHIP_AHB_WAVES=4 / 8 forces either)
-    static const int force = [] { const char* e = getenv("FBHIP_AHB_WAVES"); return e ? atoi(e) : 0; }();
+    const char* fe = getenv("FBHIP_AHB_WAVES");                      // (read at every launch: tests force either form)
+    const int force = fe ? atoi(fe) : 0;
     const size_t lds_bytes = (size_t)2 * a * H * sizeof(float);
     const int nw = lne > 16 ? 4 : (force == 4 || force == 8 ? force : ((lds_bytes > 80 * 1024 && rows > 4 * 256) ? 8 : 4));   // (H > 1024: a row's registers need the four-wave budget)
 #define AHB_LAUNCH1(NA, EX, LN)                                                                                          \

@@ -390,3 +390,22 @@ def test_head_refuses_what_it_cannot_run(K):
     x, w, b = torch.zeros(8, 64, device="cuda"), torch.zeros(100, 64, device="cuda"), torch.zeros(100, device="cuda")
     with pytest.raises(RuntimeError, match="N <= 64"):
         K.head(x, w, b)
+
+
+@pytest.mark.parametrize("M,N,Kd,lay", [(1024, 2048, 1024, "NT"), (2048, 1024, 1024, "TN"), (1024, 1024, 2048, "NN"), (1024, 512, 1024, "NT"),
+                                        (512, 1024, 1024, "TN"), (576, 576, 1024, "TN"), (1000, 520, 96, "NT"), (128, 256, 64, "NT")])
+def test_gemm_tile_to_xcd_maps_give_the_same_bits(K, M, N, Kd, lay, monkeypatch):
+    """Which XCD's L2 a tile's operands go through is a permutation of the launch's workgroups (gemm.hip: bands of tile rows -- the
+    default -- or, FBHIP_GEMM_XCD2D=1, an xgm x xgn grid of tile blocks that minimises what one L2 has to hold: FETCH_SIZE 753 -> 545
+    MB raw per update, the step 0.6 % slower).  The results must not depend on it, bit for bit, incl. shapes whose tile counts do not
+    divide (those keep the bands)."""
+    akc, bkc = {"NT": (True, True), "NN": (True, False), "TN": (False, False)}[lay]
+    A = _r(*((M, Kd) if akc else (Kd, M)), seed=1).cuda()
+    B = _r(*((N, Kd) if bkc else (Kd, N)), seed=2).cuda()
+    c0 = K.gemm(A, B, a_kcontig=akc, b_kcontig=bkc)
+    monkeypatch.setenv("FBHIP_GEMM_XCD2D", "1")
+    c1 = K.gemm(A, B, a_kcontig=akc, b_kcontig=bkc)
+    monkeypatch.delenv("FBHIP_GEMM_XCD2D")
+    assert torch.equal(c0, c1)
+    ref = (A.double() if akc else A.double().T) @ (B.double().T if bkc else B.double())
+    assert rel_err(c1.cpu(), ref.cpu()) < 2e-6

@@ -1372,3 +1372,30 @@ def test_branched_graphs_are_refused_on_an_unverified_runtime_and_the_plain_form
     sa, sb = H.get_agent_state(a), H.get_agent_state(b)
     for k in sa:
         np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+
+
+def test_actor_head_bwd_with_eight_waves_per_workgroup_equals_four(monkeypatch):
+    """actor_head_bwd_kernel runs one row per wave behind one LDS fill per workgroup; where the fill allows one workgroup per CU only
+    (quadruped: a = 12, H = 1024) the launcher uses eight waves per workgroup instead of four (FBHIP_AHB_WAVES forces either).  Rows
+    are independent: the same bits either way, here at dims with a ragged last workgroup, three device-drawn updates."""
+    cfg = fo.OracleConfig(obs_dim=9, action_dim=5, goal_dim=9, z_dim=12, hidden_dim=64, feature_dim=32, backward_hidden_dim=20, batch_size=44)
+    rng = np.random.default_rng(77)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 8, 20, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    states = []
+    for waves in ("4", "8"):
+        monkeypatch.setenv("FBHIP_AHB_WAVES", waves)
+        torch.manual_seed(5)
+        agent = H.make_hip_agent(cfg, nets)
+        for s in range(3):
+            m = agent.update(rb, s)
+        torch.cuda.synchronize()
+        states.append((H.get_agent_state(agent), m, {k: v.cpu().numpy().copy() for k, v in agent._grad_views["actor"].state_dict().items()}))
+    monkeypatch.delenv("FBHIP_AHB_WAVES")
+    (s4, m4, g4), (s8, m8, g8) = states
+    assert m4 == m8
+    for k in s4:
+        np.testing.assert_array_equal(s4[k], s8[k], err_msg=k)
+    for k in g4:
+        np.testing.assert_array_equal(g4[k], g8[k], err_msg=k)
