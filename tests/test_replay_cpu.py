@@ -315,3 +315,56 @@ def test_reference_sf_checkpoint_reads_without_the_reference():
             np.testing.assert_array_equal(v.numpy(), exp[f"state/{net}/{k}"], err_msg=f"{net}/{k}")
     assert "inverse_dynamic_net.4.bias" in agent.feature_learner.state_dict()
     assert len(agent.phi_opt.state_dict()["state"]) == 14 and len(agent.sf_opt.state_dict()["state"]) == 20
+
+
+def _episode(steps, seed, o=4, a=2):
+    rng = np.random.default_rng(seed)
+    return [TimeStep(step_type=0 if t == 0 else (2 if t == steps else 1), reward=0.0, discount=1.0, physics=np.zeros(2, np.float32),
+                     observation=rng.standard_normal(o).astype(np.float32), action=np.zeros(a, np.float32)) for t in range(steps + 1)]
+
+
+def test_observers_are_asked_to_flush_before_every_mutation(tmp_path):
+    """FBHipAgent queues metrics-off update() calls and launches them as n-step graphs (agent.py "deferred batching"); the batches of
+    queued updates are drawn from the buffer when they RUN, so the buffer asks every agent with calls in its queue to launch them
+    BEFORE it writes -- a finished episode (add), load, relabel, adopting new arrays, unpickling over it -- and never on the steps
+    that only stage a transition.  Observers are weak references and do not travel with a pickle."""
+    import gc
+
+    class Observer:
+        def __init__(self, rb):
+            self.rb, self.seen = rb, []
+
+        def flush(self):
+            # what a queued update would sample from at this moment
+            self.seen.append((len(self.rb), int(self.rb._version),
+                              None if "observation" not in self.rb._storage else float(self.rb._storage["observation"].sum())))
+
+    rb = DeviceReplayBuffer(max_episodes=3, discount=0.98, future=1.0, device="cpu")
+    ob = Observer(rb)
+    rb._observe(ob)
+    for ep in range(2):
+        for ts in _episode(4, seed=ep):
+            before = len(ob.seen)
+            rb.add(ts, {})
+            if not ts.last():
+                assert len(ob.seen) == before                      # staging a transition touches nothing a sampler can see
+    # each finished episode: asked once before the block is written (and once more by the bookkeeping that follows it)
+    assert [s[0] for s in ob.seen][:1] == [0] and ob.seen[0][2] is None   # first flush saw the EMPTY buffer
+    assert any(s[0] == 1 for s in ob.seen)                                  # the second episode's flush saw exactly one stored episode
+    first_two = float(rb._storage["observation"].sum())
+    n = len(ob.seen)
+    rb._adopt({k: v.numpy() for k, v in rb._storage.items()}, None)         # new arrays: asked first
+    assert len(ob.seen) == n + 1 and ob.seen[-1][2] == pytest.approx(first_two)
+    rb2 = pickle.loads(pickle.dumps(rb))
+    assert "_observers" not in rb2.__dict__ or len(rb2.__dict__["_observers"]) == 0
+    rb._unobserve(ob)
+    n = len(ob.seen)
+    for ts in _episode(4, seed=9):
+        rb.add(ts, {})
+    assert len(ob.seen) == n                                                 # no longer an observer
+    rb._observe(ob)
+    del ob
+    gc.collect()
+    for ts in _episode(4, seed=10):                                          # a dead observer is dropped, not called
+        rb.add(ts, {})
+    assert len(rb) == 3
