@@ -1034,7 +1034,8 @@ class FBHipAgent:
         d = self.__dict__
         if (rb.__class__ is not DeviceReplayBuffer or not d.get("defer_updates", True) or not d["_use_graph"] or (_dist.is_available() and _dist.is_initialized()) or
                 os.environ.get("FBHIP_UPDATE_DEFER", "1") == "0" or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or
-                torch.cuda.is_current_stream_capturing()):       # (inside a caller's capture the launches must land IN it)
+                torch.cuda.is_current_stream_capturing() or      # (inside a caller's capture the launches must land IN it)
+                getattr(self.cfg, "dp_global_batch", False)):    # (mode B: an embedding exchange between the phases of every update)
             return None
         f = self._hp_fields(self.cfg)
         if f[-1] or f[-2] or f[-3]:              # metrics on: the caller reads the result of THIS call

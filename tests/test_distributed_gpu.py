@@ -186,6 +186,23 @@ def test_global_batch_schedule_on_one_rank_is_the_plain_update():
             assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-7), k
 
 
+def test_global_batch_updates_are_never_queued():
+    """Mode B runs an embedding exchange between the phases of EVERY update: such agents launch each metrics-off update() call at once
+    (agent.py "deferred batching" queues only what fbhip_update_many can run), world 1 included."""
+    cfg, nets, storage, lengths = T._setup()
+    from controllable_agent_amd.agent import FBHipAgent
+    from controllable_agent_amd.replay import DeviceReplayBuffer
+    rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
+    for flag, queued in ((True, 0), (False, 3)):
+        agent = FBHipAgent(**H.agent_kwargs(cfg, metrics=False, dp_global_batch=flag))
+        agent.load_nets({n: dict(p) for n, p in nets.items()})
+        for step in range(3):
+            assert agent.update(rb, step) == {}
+        p = agent.__dict__.get("_pending")
+        assert (0 if p is None else p[3]) == queued
+        assert agent.step_counts() == (3, 3)
+
+
 # ------------------------------------------------------------------- pipelined data-parallel steps (dp_update_many)
 def _worker_many(rank, port, out_q):
     import torch.distributed as dist
