@@ -565,14 +565,18 @@ def main():
             # (train_offline.py:118).  With metrics off the agent queues such calls and launches them as n-step graphs
             # (FBHipAgent "deferred batching"); barrier() flushes the rest of the queue before it synchronises
             n1 = max(300, min(args.steps, 1000))
-            for i in range(20):
+            # a queue goes out as graphs of 32 / 16 / 8 / 4 / 2 / 1 steps (FBHipAgent.DEFER_MENU): warm every size first -- one
+            # eager call, a full queue, and 31 = 16 + 8 + 4 + 2 + 1 -- so that the timed loop below captures nothing
+            for i in range(1 + 32 + 31):
                 agent.update(rb, i)
             barrier()
+            caps0 = agent.graph_captures()
             t1 = time.perf_counter()
             for i in range(n1):
                 agent.update(rb, i)
             barrier()
             single = n1 / (time.perf_counter() - t1)
+            single_captures = agent.graph_captures() - caps0
 
     replicas = None
     if world > 1:
@@ -625,7 +629,7 @@ def main():
                        **({"value_is": f"{world} ranks x {steps_per_s:.1f} per-rank update-steps/s of batch {W['batch_size']} each (weak scaling: "
                                        f"batch-{W['batch_size']}-equivalents per second); the model itself makes global_steps_per_s "
                                        "optimiser steps per second on the global batch"} if world > 1 else {}),
-                       **({"single_update_steps_per_s": single} if single is not None else {})},
+                       **({"single_update_steps_per_s": single, "single_update_probe_graph_captures": single_captures} if single is not None else {})},
             "repeats": {"n": len(walls), "steps_each": args.steps, "reported": "median by wall time",
                         "wall_s": walls, "hip_event_s": events,
                         "steps_per_s": {"median": world * args.steps / dt, "min": world * args.steps / max(walls),

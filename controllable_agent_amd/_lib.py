@@ -83,6 +83,7 @@ PROTOTYPES = {
     "fbhip_set_rng_counts": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
     "fbhip_update": (C.c_int, [_P, C.POINTER(HParams), C.POINTER(Inject), _I, _I, _P]),
     "fbhip_update_many": (C.c_int, [_P, _P, _I, _P]),
+    "fbhip_graph_captures": (C.c_int64, [_P]),
     "fbhip_update_many_injected": (C.c_int, [_P, _P, _I, _P, _P]),
     "fbhip_dp_bind_peers": (C.c_int, [_P, _I, _I, _P, _P, _P, _P]),
     "fbhip_peer_allreduce": (C.c_int, [_P, _I, _P]),
@@ -143,7 +144,7 @@ def load() -> C.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError here == header / library mismatch
         fn.restype, fn.argtypes = res, args
-    if lib.fbhip_abi_version() != 18:
+    if lib.fbhip_abi_version() != 19:
         raise RuntimeError("libfbhip.so ABI version mismatch")
     _lib = lib
     return lib

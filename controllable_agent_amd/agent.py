@@ -968,14 +968,20 @@ class FBHipAgent:
         if step % self.cfg.update_every_steps != 0:
             return {}
         key = self._defer_key(replay_loader)
-        if key is not None:                      # metrics off, one rank, graphs allowed: the call is queued (see "deferred batching")
-            p = self.__dict__.get("_pending")
+        if key is not None:                      # metrics off, one process, graphs allowed: a candidate for the queue (see "deferred batching")
+            d = self.__dict__
+            p = d.get("_pending")
             if p is not None and p[2] == key:
                 p[3] += 1
                 if p[3] >= self.DEFER_MAX:
                     self.flush()
+                    d["_run_key"] = key          # (a full queue going out does not end the run of update() calls)
                 return {}
-            if self._defer_update(replay_loader, key, step):
+            # Run-length rule: a call is QUEUED only when the previous call into the agent was itself an update() with the same
+            # key.  The first update() after anything else (act, compute_z_correl, a state read, a buffer mutation ...) is launched
+            # at once: the online loop of pretrain.py:627-652 (act -> update -> env.step -> add -> compute_z_correl) puts its
+            # update on the device BEFORE the host steps the environment, and never queues.
+            if d.get("_run_key") == key and self._defer_update(replay_loader, key, step):
                 return {}
         self.flush()
         c = self.cfg
@@ -1004,6 +1010,9 @@ class FBHipAgent:
             # fresh capture + instantiation (milliseconds), so those configurations run as eager launches instead
             graph_ok = self._use_graph and self._stddev_is_constant()
             self._run_update(hp, None, graph_ok)
+            if key is not None and graph_ok:
+                self.__dict__["_run_key"] = key  # an eager update() that COULD have queued: the next one with this key starts a queue
+                return {}                        # (key is not None == metrics off)
         else:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)
@@ -1021,6 +1030,7 @@ class FBHipAgent:
     # the queue is exactly ``update_many`` over the same steps.  What cannot be intercepted is a bare
     # ``torch.cuda.synchronize()`` (a caller timing the loop, say): ``agent.flush()`` is the explicit form.
     DEFER_MAX = 32
+    DEFER_MENU = (32, 16, 8, 4, 2, 1)            # the only n-step graph sizes a queue is ever launched as (flush)
     # every cfg field the hyper-parameter struct, the metrics switch and the update cadence are made of (FBDDPGAgentConfig)
     _hp_fields = operator.attrgetter("lr", "lr_coef", "fb_target_tau", "stddev_schedule", "stddev_clip", "ortho_coef", "mix_ratio",
                                      "q_loss_coef", "q_loss", "future_ratio", "rand_weight", "use_tb", "use_wandb", "use_hiplog")
@@ -1032,7 +1042,7 @@ class FBHipAgent:
         through a state_dict view bumps them, the library's own kernels do not.  Equal keys == the call joins the queue (a few
         microseconds per call: the host's share of a queued update)."""
         d = self.__dict__
-        if (rb.__class__ is not DeviceReplayBuffer or not d.get("defer_updates", True) or not d["_use_graph"] or (_dist.is_available() and _dist.is_initialized()) or
+        if (rb.__class__ is not DeviceReplayBuffer or not d.get("defer_updates", True) or not d["_use_graph"] or (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1) or
                 os.environ.get("FBHIP_UPDATE_DEFER", "1") == "0" or os.environ.get("FBHIP_FORCE_PHASE_SPLIT", "0") == "1" or
                 torch.cuda.is_current_stream_capturing() or      # (inside a caller's capture the launches must land IN it)
                 getattr(self.cfg, "dp_global_batch", False)):    # (mode B: an embedding exchange between the phases of every update)
@@ -1058,10 +1068,12 @@ class FBHipAgent:
     def flush(self) -> None:
         """Launch every queued ``update()`` call (see above) on the stream it was called on.  Asynchronous like the updates
         themselves: follow with a stream / device synchronise to wait for the results."""
-        p = self.__dict__.get("_pending")
+        d = self.__dict__
+        d["_run_key"] = None                     # whoever asks for a flush is not a queued update(): the run of calls ends here
+        p = d.get("_pending")
         if p is None:
             return
-        self._pending = None
+        d["_pending"] = None
         rb, hp, _, n, stream = p
         rb._unobserve(self)
         now = torch.cuda.current_stream(self._device)
@@ -1070,14 +1082,35 @@ class FBHipAgent:
             # is on now comes first, and what it enqueues next sees the updates -- as if they had run when they were called and the
             # caller had ordered its streams then
             stream.wait_stream(now)
-        with torch.cuda.stream(stream):
-            self._bind_replay(rb)
-            if n == 1:
-                self._run_update(hp, None, True)
-            else:
-                self._launch_many(hp, n)
-        if now != stream:
-            now.wait_stream(stream)
+        # A queue of k goes out as graphs from a FIXED MENU of sizes, largest first (k = 23 -> 16 + 4 + 2 + 1): whatever the flush
+        # points of a caller are, at most len(DEFER_MENU) n-step graphs ever exist per (hyper-parameters, replay binding), and none
+        # is captured inside a steady-state loop once each size has been seen (``graph_captures()`` counts them).
+        done = 0
+        try:
+            with torch.cuda.stream(stream):
+                self._bind_replay(rb)
+                for size in self.DEFER_MENU:
+                    while n - done >= size:
+                        if size == 1:
+                            self._run_update(hp, None, True)
+                        else:
+                            self._launch_many(hp, size)
+                        done += size
+        except BaseException:
+            # nothing is dropped silently: the calls that were not launched stay queued (the error repeats at the next flush if its
+            # cause persists), and the step / RNG counters never fall behind what the caller issued without an exception saying so
+            if done < n:
+                p[3] = n - done
+                d["_pending"] = p
+                rb._observe(self)
+            raise
+        finally:
+            if now != stream:
+                now.wait_stream(stream)
+
+    def graph_captures(self) -> int:
+        """update graphs the library has captured for this agent so far (``fbhip_graph_captures``); does not launch the queue"""
+        return int(_lib.load().fbhip_graph_captures(self.__dict__["_ctx"]))
 
     def _launch_many(self, hp: HParams, n_steps: int) -> None:
         done = 0

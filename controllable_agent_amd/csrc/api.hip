@@ -499,6 +499,7 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCK(c, e);
+    ++c->graph_captures;
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
     HIPCK(c, hipGraphLaunch(ge.exec, s));
@@ -634,6 +635,7 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     HIPCK(c, e);
+    ++c->graph_captures;
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
     return launch ? launch_graph(c, ge.exec, s, ge.branches) : (int)FBHIP_OK;
@@ -642,6 +644,8 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
     return update_many_impl(c, hp, n_steps, nullptr, stream);
 }
+
+int64_t fbhip_graph_captures(const fbhip_ctx* c) { return c ? c->graph_captures : -1; }
 
 int fbhip_dp_bind_peers(fbhip_ctx* c, int32_t world, int32_t rank, float* const* fb_grad_ptrs, float* const* actor_grad_ptrs,
                         int32_t* const* flag_ptrs, int32_t* local_state) {

@@ -153,6 +153,7 @@ struct fbhip_ctx {
     fbhip::host::IcmP I_p, I_g;                           // dims.sf == 1
     fbhip::host::ActP A_p, A_g;
     std::vector<fbhip::host::GraphEntry> graphs;
+    int64_t graph_captures = 0;              // update graphs captured + instantiated so far (fbhip_graph_captures)
     std::vector<fbhip::host::InferGraph> infer_graphs;    // batch-1 fast path (fbhip_act / fbhip_z_correl)
     float* h_in = nullptr;                   // pinned host staging, same layout as w.act_in
     float* h_out = nullptr;                  // pinned: action / correlation

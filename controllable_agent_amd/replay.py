@@ -294,6 +294,10 @@ class DeviceReplayBuffer:
     # ------------------------------------------------------------------ add (in_memory_replay_buffer.py:104-133)
     def add(self, time_step: tp.Any, meta: tp.Mapping[str, np.ndarray]) -> None:
         stage = self._current_episode
+        if _is_last(time_step):
+            # the transition that completes an episode changes the ring: queued updates of an observing agent go out FIRST, before
+            # anything of this call is staged -- if their launch raises, the buffer is exactly as it was before the call
+            self._before_mutation()
         for name, value in meta.items():
             stage.append(name, np.asarray(value, np.float32))
         for name, row in _step_items(time_step):

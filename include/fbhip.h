@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FBHIP_ABI_VERSION 18
+#define FBHIP_ABI_VERSION 19
 
 enum {
     FBHIP_OK = 0,
@@ -264,6 +264,11 @@ int fbhip_update(fbhip_ctx* ctx, const fbhip_hparams* hp, const fbhip_inject* in
  * the gradient all-reduce inside the graph); ``hp`` is constant over the n_steps (1 <= n_steps <= 64).
  * After the call fbhip_workspace_view refers to set 0, which holds the last or the second-to-last step's intermediates. */
 int fbhip_update_many(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t n_steps, void* stream);
+/* How many update graphs (fbhip_update with use_graph, fbhip_update_many*, their data-parallel forms) this context has CAPTURED
+ * and instantiated since fbhip_create -- a cache hit replays and does not count.  A host that launches a queue of k update()
+ * calls as a fixed menu of n_steps (FBHipAgent.flush: 32 / 16 / 8 / 4 / 2 / 1; train_offline.py:116-119 is the caller) checks with
+ * this that no capture happens inside its steady-state loop.  -1 for a NULL context. */
+int64_t fbhip_graph_captures(const fbhip_ctx* ctx);
 /* The same n-step pipelined graph with every random draw supplied: ``injects`` is an array of n_steps structs, one per step
  * (all fields a single update needs, like fbhip_update's parity mode).  For parity runs of the bench configuration -- the
  * reference's recorded draws through the pipelined multi-step graph; the graph is cached on (hp, n_steps, injects[0]), so a

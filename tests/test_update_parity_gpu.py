@@ -775,21 +775,22 @@ def test_deferred_update_calls_equal_eager_calls_across_every_flush_trigger(monk
             step[0] += 1
 
     updates(5)
-    assert pending(a) == 5 and pending(b) == 0 and b.step_counts() == (5, 5)      # a holds its calls back, b ran them
+    # a launches the first call of a run at once (run-length rule: a lone update is never held back) and queues the rest; b ran all
+    assert pending(a) == 4 and pending(b) == 0 and b.step_counts() == (5, 5)
     assert a.step_counts() == (5, 5) and pending(a) == 0                           # reading the counters launches the queue
-    updates(3)
+    updates(4)          # (1 at once + a queue of 3 = graphs of 2 + 1 steps: the last step runs on workspace set 0, which the view reads)
     for name in ("F1", "Xoz", "z", "dF1"):                                          # the workspace view of the LAST update
         va, vb = both(lambda ag: ag.workspace_view(name).clone())
         assert torch.equal(va, vb), name
     same()
-    updates(32 + 7)                                                                 # a full queue goes out on its own
+    updates(1 + 32 + 7)                                                             # a full queue goes out on its own, the run goes on
     assert pending(a) == 7
     same()
     updates(4)
     both(lambda ag: ag.forward_net.load_state_dict(ag.forward_net.state_dict()))   # a host write through a view
     assert pending(a) == 0
     updates(4)
-    assert pending(a) == 4
+    assert pending(a) == 3
     both(lambda ag: ag.fb_opt.load_state_dict(ag.fb_opt.state_dict()))             # the optimiser view, read and write
     assert pending(a) == 0
     updates(3)
@@ -804,7 +805,7 @@ def test_deferred_update_calls_equal_eager_calls_across_every_flush_trigger(monk
     updates(3)
     # a mutation of the buffer: the queued updates must sample the contents they were CALLED on -- the buffer flushes its
     # observers before it writes (b ran its updates before the write anyway)
-    assert pending(a) == 3
+    assert pending(a) == 2
     ep = [TimeStep(step_type=0 if t == 0 else (2 if t == 6 else 1), reward=0.1, discount=1.0,
                    observation=rng.standard_normal(cfg.obs_dim).astype(np.float32), action=rng.uniform(-1, 1, cfg.action_dim).astype(np.float32),
                    physics=np.zeros(2, np.float32)) for t in range(7)]
@@ -813,7 +814,7 @@ def test_deferred_update_calls_equal_eager_calls_across_every_flush_trigger(monk
         for ts in ep:
             rbw.add(ts, {})
     updates(4, rbw)                                                                 # another buffer: the queue on ``rb`` goes out first
-    assert pending(a) == 4
+    assert pending(a) == 3
     for ts in ep:
         rbw.add(ts, {})                                                             # third episode lands: the ring changes under the queue
     assert pending(a) == 0
@@ -822,16 +823,16 @@ def test_deferred_update_calls_equal_eager_calls_across_every_flush_trigger(monk
     updates(2)
     a.cfg.lr = b.cfg.lr = 2e-4                                                       # other hyper-parameters from the next call on
     updates(2)
-    assert pending(a) == 2
+    assert pending(a) == 1
     a.cfg.lr = b.cfg.lr = 1e-4
     updates(2)
-    assert pending(a) == 2
+    assert pending(a) == 1
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     with torch.cuda.stream(side):                                                   # another stream: the queue goes out on ITS stream
         updates(2)
     torch.cuda.synchronize()
-    assert pending(a) == 2
+    assert pending(a) == 1
     both(lambda ag: ag.update_many(rb, step[0], 3))                                 # another update entry point
     step[0] += 3
     assert pending(a) == 0
@@ -863,6 +864,89 @@ def test_deferred_update_calls_equal_eager_calls_across_every_flush_trigger(monk
     assert pending(a) == 0
     same()
     assert a.rng_counts() == b.rng_counts() == (step[0], 0)
+
+
+def test_online_call_sequence_puts_the_update_on_the_device_before_the_host_steps_the_environment(monkeypatch):
+    """pretrain.py:627-652: ``act -> update -> env.step -> add -> compute_z_correl``.  Deferred batching must never hold that lone
+    update back across the host's environment step (it did, configs[4] 475 -> 404 update-steps/s): the run-length rule
+    launches the first ``update()`` after any other call into the agent at once.  The library's ``fbhip_update`` is wrapped with a
+    launch log; every loop iteration must show the launch BEFORE the (emulated) ``env.step`` and nothing queued during it."""
+    import time
+    from controllable_agent_amd import _lib
+    from controllable_agent_amd.replay import TimeStep
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64)
+    rng = np.random.default_rng(5)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a = H.make_hip_agent(cfg, nets, metrics=False)
+    assert a._defer_key(rb) is not None                                             # (these calls ARE candidates for the queue)
+    lib = _lib.load()
+    log = []
+    real_update, real_many = lib.fbhip_update, lib.fbhip_update_many
+    monkeypatch.setattr(lib, "fbhip_update", lambda *args: (log.append(("update", time.perf_counter())), real_update(*args))[1])
+    monkeypatch.setattr(lib, "fbhip_update_many", lambda *args: (log.append(("many", time.perf_counter())), real_many(*args))[1])
+    meta = a.init_meta()
+    for step in range(6):
+        obs = rng.standard_normal(cfg.obs_dim).astype(np.float32)
+        a.act(obs, meta, step, eval_mode=False)
+        n0 = len(log)
+        assert a.update(rb, step) == {}
+        t_env = time.perf_counter()
+        assert len(log) == n0 + 1 and log[-1][0] == "update" and log[-1][1] <= t_env   # launched inside the call, as ONE update
+        assert a.__dict__.get("_pending") is None                                    # nothing is held back while the host works
+        time.sleep(0.002)                                                            # env.step (host)
+        ts = TimeStep(step_type=1, reward=0.0, discount=1.0, observation=obs, action=np.zeros(cfg.action_dim, np.float32),
+                      physics=np.zeros(2, np.float32))
+        a.compute_z_correl(ts, meta)
+        assert len(log) == n0 + 1                                                    # ... and nothing was left to launch after it
+    assert a.step_counts() == (6, 6)
+    # the offline caller (train_offline.py:116-119) still queues: one eager call per run, then n-step graphs
+    for step in range(6, 6 + 40):
+        a.update(rb, step)
+    assert a.__dict__["_pending"][3] == 7 and [k for k, _ in log[6:]] == ["update", "many"]
+    assert a.step_counts() == (46, 46)
+
+
+def test_queued_updates_go_out_as_a_fixed_menu_of_graph_sizes():
+    """A flush launches its queue of k as graphs of 32 / 16 / 8 / 4 / 2 / 1 steps, largest first (FBHipAgent.DEFER_MENU): whatever the
+    flush points of the caller are (log every M, eval every N, checkpoints), at most six update graphs ever exist and none is
+    captured in the steady state -- counted by the library (``fbhip_graph_captures``).  2000 deferred updates with random flush
+    points against an eager twin: identical state (these dims keep every K-slicing)."""
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64)
+    rng = np.random.default_rng(29)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a, b = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(2))
+    b.defer_updates = False
+    assert a.graph_captures() == 0
+    step, seen = 0, set()
+    while step < 2000:
+        run = int(rng.integers(1, 75))
+        for _ in range(run):
+            a.update(rb, step)
+            b.update(rb, step)
+            step += 1
+        seen.add(run)
+        a.flush()
+    assert len(seen) > 40                                                           # (far more distinct run lengths than cache entries)
+    assert a.graph_captures() <= len(a.DEFER_MENU) == 6, a.graph_captures()
+    assert b.graph_captures() == 1
+    n = a.graph_captures()
+    for run in (1, 2, 3, 5, 9, 17, 33, 64, 31):                                     # steady state: every size is warm, nothing is captured
+        for _ in range(run):
+            a.update(rb, step)
+            b.update(rb, step)
+            step += 1
+        a.flush()
+    assert a.graph_captures() == n
+    sa, sb = H.get_agent_state(a), H.get_agent_state(b)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    assert a.step_counts() == b.step_counts() == (step, step)
 
 
 def test_legacy_default_stream_callers_see_the_update_without_a_wait_on_that_stream():
