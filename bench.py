@@ -354,6 +354,11 @@ def supervise_ranks(args, rank, world):
         raise SystemExit("bench.py: no gradient transport completed: " + json.dumps(history))
 
 
+def _branched_ok() -> bool:
+    from controllable_agent_amd import _lib
+    return bool(_lib.load().fbhip_branched_graphs(None))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -642,7 +647,10 @@ def main():
                 "transport": getattr(agent, "_dp_transport", None) or
                              ("peer" if args.peer_allreduce else ("gloo-host" if args.rehearse_on_one_gpu else "c10d-rccl-host")),
                 "library_rccl_refused": bool(getattr(agent, "_rccl_failed", False)),
-                "graph_form": "single-queue (one stream: every step's phases and both all-reduces in program order)",
+                "graph_form": ("single-queue (one stream: every step's phases and both all-reduces in program order)"
+                               if os.environ.get("FBHIP_DP_PIPELINE") == "0" or os.environ.get("FBHIP_UPDATE_PIPELINE") == "0" or not _branched_ok() else
+                               "pipelined (step t+1's head on a second graph branch beside step t's actor pass, actor all-reduce and actor "
+                               "step; both all-reduces on the main branch in program order; FBHIP_DP_PIPELINE=0 = the single-queue chain)"),
                 "control_plane": dist.get_backend(),
                 "nccl_env": {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                                      "HSA_ENABLE_IPC_MODE_LEGACY")},

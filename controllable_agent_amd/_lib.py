@@ -102,6 +102,7 @@ PROTOTYPES = {
     "fbhip_export_embeddings": (C.c_int, [_P, _P, _P]),
     "fbhip_bind_global_batch": (C.c_int, [_P, _P, _P, _I, _I]),
     "fbhip_read_metrics": (C.c_int, [_P, C.POINTER(C.c_float), _P]),
+    "fbhip_wait_metrics": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "fbhip_workspace_view": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "fbhip_actor_forward": (C.c_int, [_P, _P, _I, _P, _I, _I, _P, _F, _F, _P, _I, _P]),
     "fbhip_backward_map": (C.c_int, [_P, _I, _P, _I, _I, _P, _I, _P]),

@@ -930,13 +930,22 @@ class FBHipAgent:
         self._gb_disc.view(world, B).copy_(self._gb_recv[:, 6 * B * Lz:])
         check(lib.fbhip_bind_global_batch(self._ctx, ptr(self._gb_panels), ptr(self._gb_disc), world * B, rank * B), self._ctx)
 
+    def _wait_metrics(self) -> tp.Any:
+        """the metric array of the last metrics-on update, as soon as the running step has published it (fbhip_wait_metrics: no
+        copy command, no stream synchronise -- the update's tail is still running when this returns)"""
+        d = self.__dict__
+        buf = d.get("_metrics_buf")
+        if buf is None:
+            buf = d["_metrics_buf"] = (C.c_float * _lib.NUM_METRICS)()
+        check(_lib.load().fbhip_wait_metrics(self._ctx, buf), d["_ctx"])
+        return buf
+
     def _metrics(self) -> tp.Dict[str, float]:
         c = self.cfg
         out: tp.Dict[str, float] = {}
         if not (c.use_tb or c.use_wandb or c.use_hiplog):
             return out
-        buf = (C.c_float * _lib.NUM_METRICS)()
-        check(_lib.load().fbhip_read_metrics(self._ctx, buf, stream_ptr()), self._ctx)
+        buf = self._wait_metrics()
         if getattr(c, "dp_global_batch", False) and self._world() > 1:
             # every rank holds its SHARE of the pairwise terms (global normalisers) and local means of the row-wise
             # ones: sum the former, average the latter (orth_linf / orth_l2 come from the gathered B: equal everywhere)
@@ -968,21 +977,26 @@ class FBHipAgent:
         if step % self.cfg.update_every_steps != 0:
             return {}
         key = self._defer_key(replay_loader)
-        if key is not None:                      # metrics off, one process, graphs allowed: a candidate for the queue (see "deferred batching")
+        if key is not None:                      # one process, graphs allowed, the buffer on the device: the short ways
             d = self.__dict__
-            p = d.get("_pending")
-            if p is not None and p[2] == key:
-                p[3] += 1
-                if p[3] >= self.DEFER_MAX:
-                    self.flush()
-                    d["_run_key"] = key          # (a full queue going out does not end the run of update() calls)
-                return {}
-            # Run-length rule: a call is QUEUED only when the previous call into the agent was itself an update() with the same
-            # key.  The first update() after anything else (act, compute_z_correl, a state read, a buffer mutation ...) is launched
-            # at once: the online loop of pretrain.py:627-652 (act -> update -> env.step -> add -> compute_z_correl) puts its
-            # update on the device BEFORE the host steps the environment, and never queues.
-            if d.get("_run_key") == key and self._defer_update(replay_loader, key, step):
-                return {}
+            f = key[4]
+            want = bool(f[-1] or f[-2] or f[-3])
+            if not want:                         # metrics off: a candidate for the queue (see "deferred batching")
+                p = d.get("_pending")
+                if p is not None and p[2] == key:
+                    p[3] += 1
+                    if p[3] >= self.DEFER_MAX:
+                        self.flush()
+                        d["_run_key"] = key      # (a full queue going out does not end the run of update() calls)
+                    return {}
+                # Run-length rule: a call is QUEUED only when the previous call into the agent was itself an update() with the same
+                # key.  The first update() after anything else (act, compute_z_correl, a state read, a buffer mutation ...) is
+                # launched at once: the online loop of pretrain.py:627-652 (act -> update -> env.step -> add -> compute_z_correl)
+                # puts its update on the device BEFORE the host steps the environment, and never queues.
+                if d.get("_run_key") == key and self._defer_update(replay_loader, key, step):
+                    return {}
+            if self._update_now(replay_loader, key, step, want):
+                return self._metrics() if want else {}
         self.flush()
         c = self.cfg
         want = bool(c.use_tb or c.use_wandb or c.use_hiplog)
@@ -1010,9 +1024,6 @@ class FBHipAgent:
             # fresh capture + instantiation (milliseconds), so those configurations run as eager launches instead
             graph_ok = self._use_graph and self._stddev_is_constant()
             self._run_update(hp, None, graph_ok)
-            if key is not None and graph_ok:
-                self.__dict__["_run_key"] = key  # an eager update() that COULD have queued: the next one with this key starts a queue
-                return {}                        # (key is not None == metrics off)
         else:
             # any other loader with the reference's .sample(batch_size) -> EpisodeBatch contract (host sampling)
             return self.update_from_batch(replay_loader.sample(c.batch_size), step)
@@ -1036,7 +1047,8 @@ class FBHipAgent:
                                      "q_loss_coef", "q_loss", "future_ratio", "rand_weight", "use_tb", "use_wandb", "use_hiplog")
 
     def _defer_key(self, rb: tp.Any) -> tp.Optional[tp.Tuple]:
-        """None when this call cannot be queued; else everything a queued update depends on besides the library's own state: the
+        """None when this call is not the plain single-process graph update (it then takes the general path of ``update``); else
+        everything a queued update depends on besides the library's own state: the
         replay contents (mutation counter) and its discount / future, the cfg fields behind the hyper-parameters, the caller's
         stream, and torch's version counters of the flat parameter / optimiser tensors -- every host-side in-place write
         through a state_dict view bumps them, the library's own kernels do not.  Equal keys == the call joins the queue (a few
@@ -1047,12 +1059,34 @@ class FBHipAgent:
                 torch.cuda.is_current_stream_capturing() or      # (inside a caller's capture the launches must land IN it)
                 getattr(self.cfg, "dp_global_batch", False)):    # (mode B: an embedding exchange between the phases of every update)
             return None
-        f = self._hp_fields(self.cfg)
-        if f[-1] or f[-2] or f[-3]:              # metrics on: the caller reads the result of THIS call
-            return None
+        f = self._hp_fields(self.cfg)            # (the last three fields are the metrics switches: such a call is never QUEUED)
         return (id(rb), rb._version, rb._discount, rb._future, f, d["_fb_params"]._version, d["_fb_targets"]._version, d["_fb_m"]._version,
                 d["_fb_v"]._version, d["_actor_params"]._version, d["_actor_m"]._version, d["_actor_v"]._version,
                 torch._C._cuda_getCurrentRawStream(self._device.index))
+
+    def _update_now(self, rb: DeviceReplayBuffer, key: tp.Tuple, step: int, want: bool) -> bool:
+        """ONE update, launched at once through the cached single-update graph -- the short way for a call ``_defer_key`` accepted:
+        no phase machinery, no data-parallel checks, the hyper-parameter struct built once per key.  What a metrics-on caller
+        (README.md:50, ``use_tb=1 use_hiplog=1``) pays per call on the host is GPU idle time: the step publishes its metrics
+        from inside (``fbhip_wait_metrics``), this call returns, and the next one must be enqueued before the running step's tail
+        (actor backward + optimiser step) has drained.  False: not eligible (time-varying stddev: eager launches)."""
+        self.flush()
+        if not self._stddev_is_constant():       # (a captured graph bakes stddev in)
+            return False
+        d = self.__dict__
+        fh = d.get("_now_hp")
+        if fh is None or fh[0] != key:
+            hp = self._hparams(step, want, 1.0, float(rb._discount), float(rb._future))
+            fh = d["_now_hp"] = (key, hp, C.byref(hp))
+        self._bind_replay(rb)
+        lib, ctx, raw = _lib.load(), d["_ctx"], key[-1]
+        if raw != 0:
+            check(lib.fbhip_update(ctx, fh[2], None, _lib.PHASE_ALL, 1, raw), ctx)
+        else:                                    # (the legacy default stream: on the agent's own stream, ordered both ways)
+            self._on_update_stream(lambda: check(lib.fbhip_update(ctx, fh[2], None, _lib.PHASE_ALL, 1, stream_ptr()), ctx))
+        if not want:
+            d["_run_key"] = key                  # an update() that COULD have queued: the next one with this key starts a queue
+        return True
 
     def _defer_update(self, rb: DeviceReplayBuffer, key: tp.Tuple, step: int) -> bool:
         """the slow path of a queued call: a new queue (the old one, if any, goes out first)"""
@@ -1862,8 +1896,7 @@ class SFHipAgent(FBHipAgent):
         out: tp.Dict[str, float] = {}
         if not (c.use_tb or c.use_wandb or c.use_hiplog):
             return out
-        buf = (C.c_float * _lib.NUM_METRICS)()
-        check(_lib.load().fbhip_read_metrics(self._ctx, buf, stream_ptr()), self._ctx)
+        buf = self._wait_metrics()
         g = lambda k: float(buf[_lib.METRIC_INDEX[k]])
         for k in ("target_F", "F1", "phi", "phi_norm", "z_norm", "sf_loss") + (("phi_loss",) if self._sf_mode not in (3, 12) else ()):
             out[k] = g(k)                        # (sf.py:634-635: "random" has no phi_loss)

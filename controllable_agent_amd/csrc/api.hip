@@ -5,6 +5,7 @@
 // allocates flat fp32 tensors and binds them; after that an update is a few dozen asynchronous kernel launches on the caller's
 // stream with no allocation and no host synchronisation, captured once into a hipGraph and replayed.
 #include "host.h"
+#include <chrono>
 
 using namespace fbhip;
 using namespace fbhip::host;
@@ -167,6 +168,9 @@ void destroy_now(fbhip_ctx* ctx) {
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->h_in) (void)hipHostFree(ctx->h_in);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    if (ctx->h_metrics) (void)hipHostFree(ctx->h_metrics);
+    if (ctx->d_pubseq) (void)hipFree(ctx->d_pubseq);
+    if (ctx->d_xm_part) (void)hipFree(ctx->d_xm_part);
     delete ctx;
 }
 
@@ -277,6 +281,19 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
         c->h_in = c->h_out = nullptr;
     } else {
         memset(c->h_in, 0, act_in_floats(*dims) * sizeof(float));
+        // the metrics' way out of a running step (metrics_publish_kernel): fine-grained pinned host memory + a 4-byte device counter.
+        // Without them (allocation refused) metrics travel by copy + synchronise as before.
+        if (hipHostMalloc((void**)&c->h_metrics, 2 * FBHIP_NUM_METRICS * sizeof(float), hipHostMallocCoherent) != hipSuccess ||
+            hipMalloc((void**)&c->d_pubseq, 16 * sizeof(unsigned int)) != hipSuccess || hipMemset(c->d_pubseq, 0, 16 * sizeof(unsigned int)) != hipSuccess ||
+            hipMalloc((void**)&c->d_xm_part, EXTRA_METRICS_MAX_BLOCKS * 4 * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->h_metrics) (void)hipHostFree(c->h_metrics);
+            if (c->d_pubseq) (void)hipFree(c->d_pubseq);
+            if (c->d_xm_part) (void)hipFree(c->d_xm_part);
+            c->h_metrics = nullptr; c->d_pubseq = nullptr; c->d_xm_part = nullptr;
+        } else {
+            memset(c->h_metrics, 0, 2 * FBHIP_NUM_METRICS * sizeof(float));
+        }
     }
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
@@ -472,18 +489,30 @@ int fbhip_set_rng_counts(fbhip_ctx* c, uint32_t update_count, uint32_t act_count
     return FBHIP_OK;
 }
 
+// how many metrics_publish_kernel launches a call with this phase mask enqueues (schedule.hip: after the actor loss; after the FB
+// metrics for an agent without an actor)
+static unsigned int publishes(const fbhip_ctx* c, const fbhip_hparams* hp, int mask) {
+    if (!hp->want_metrics || c->h_metrics == nullptr) return 0;
+    return (mask & (c->d.discrete ? FBHIP_PHASE_FB_BWD_A : FBHIP_PHASE_ACTOR_GRAD)) ? 1u : 0u;
+}
+
 int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inject, int32_t phase_mask,
                  int32_t use_graph, void* stream) {
     RC(need_bound(c, (phase_mask & FBHIP_PHASE_SAMPLE) != 0));
     RC(check_hparams(c, hp));
     hipStream_t s = (hipStream_t)stream;
     c->last_stream = s;
-    if (!use_graph) return enqueue_update(c, *hp, inject, phase_mask, s);
+    if (!use_graph) {
+        RC(enqueue_update(c, *hp, inject, phase_mask, s));
+        c->pub_issued += publishes(c, hp, phase_mask);
+        return FBHIP_OK;
+    }
     reap(s);
     for (auto& g : c->graphs) {
         if (g.n_steps == 1 && g.set == c->cur && g.mask == phase_mask && memcmp(&g.hp, hp, sizeof(*hp)) == 0 && g.has_inj == (inject != nullptr) &&
             (!inject || memcmp(&g.inj, inject, sizeof(*inject)) == 0)) {
             HIPCK(c, hipGraphLaunch(g.exec, s));
+            c->pub_issued += publishes(c, hp, phase_mask);
             return FBHIP_OK;
         }
     }
@@ -503,6 +532,7 @@ int fbhip_update(fbhip_ctx* c, const fbhip_hparams* hp, const fbhip_inject* inje
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
     HIPCK(c, hipGraphLaunch(ge.exec, s));
+    c->pub_issued += publishes(c, hp, phase_mask);
     return FBHIP_OK;
 }
 
@@ -540,12 +570,24 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     const char* pe = getenv("FBHIP_UPDATE_PIPELINE");
     bool branched_ok = false;
     (void)branched_graphs_verdict(&branched_ok);
-    const bool pipe = !dp && branched_ok && !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete;     // (discrete: no actor phase to overlap with)
+    // Round 6: the data-parallel graph takes the SAME fork when branched graphs are usable (they are launched from a high-priority
+    // stream, launch_graph: the instability of round 3's branched data-parallel graph was the launch queue, found in round 4):
+    // step t+1's head on the side branch beside step t's actor phase, its actor all-reduce and its actor step -- the actor bucket
+    // (8.9 MB) travels while the next head computes, and the per-rank rate before communication is the pipelined single-GPU rate.
+    // FBHIP_DP_PIPELINE=0 (read at every call) keeps the single-queue chain: the fallback every rank can agree on.
+    const char* dpe = getenv("FBHIP_DP_PIPELINE");
+    const bool pipe_dp = dp && branched_ok && !(dpe && dpe[0] == '0') && !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete;
+    const bool pipe = (!dp && branched_ok && !(pe && pe[0] == '0') && n_steps > 1 && !c->d.discrete) || pipe_dp;     // (discrete: no actor phase to overlap with)
     for (auto& g : c->graphs) {
         if (g.n_steps == n_steps && g.set == c->cur && g.mask == (FBHIP_PHASE_ALL | (dp ? DP_GRAPH_BIT : 0)) && g.has_inj == (injs != nullptr) &&
             g.branches == pipe &&
             (!injs || (g.injs.size() == (size_t)n_steps && memcmp(g.injs.data(), injs, sizeof(*injs) * n_steps) == 0)) && memcmp(&g.hp, hp, sizeof(*hp)) == 0)
-            return launch ? launch_graph(c, g.exec, s, g.branches) : (int)FBHIP_OK;
+        {
+            if (!launch) return FBHIP_OK;
+            RC(launch_graph(c, g.exec, s, g.branches));
+            c->pub_issued += (unsigned int)n_steps * publishes(c, hp, FBHIP_PHASE_ALL);
+            return FBHIP_OK;
+        }
     }
     // Software pipeline over the steps.  Step t's actor phase is ONE dependency chain of ~20 small launches; step t+1's
     // sampling, z mixing, B passes and online ForwardMap pass depend on step t only through its FB optimiser step (new
@@ -576,7 +618,42 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
         HIPCK(c, launch_peer_allreduce(c->peers, which, which == 0 ? n_fb : n_ac, s));   // peer-access kernels (peer.hip)
         return (int)FBHIP_OK;
     };
-    if (dp) {
+    if (pipe_dp) {
+        const int HEAD = FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_FWD_ONLINE;
+        const int GRAD = FBHIP_PHASE_FB_FWD_TARGET | FBHIP_PHASE_FB_BWD | FBHIP_PHASE_ACTOR_FWD;
+        const int cur0 = c->cur;
+        rc = enqueue_update(c, *hp, nullptr, HEAD, s);
+        for (int i = 0; i < n_steps && rc == FBHIP_OK && he == hipSuccess; ++i) {
+            rc = enqueue_update(c, *hp, nullptr, GRAD, s);
+            if (rc == FBHIP_OK) rc = allreduce(0);
+            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_FB_STEP, s);
+            if (rc != FBHIP_OK) break;
+            const bool more = i + 1 < n_steps;
+            if (more) {                          // fork: V of this step's actor phase, then the next step's head on the twin workspace set
+                if ((he = hipEventRecord(c->events[2 * i], s)) != hipSuccess) break;
+                if ((he = hipStreamWaitEvent(c->side, c->events[2 * i], 0)) != hipSuccess) break;
+                rc = enqueue_actor_v(c, c->side);
+                if (rc != FBHIP_OK) break;
+                if ((he = hipEventRecord(c->events[128 + i], c->side)) != hipSuccess) break;
+                c->cur ^= 1;
+                rc = enqueue_update(c, *hp, nullptr, HEAD, c->side);
+                c->cur ^= 1;
+                if (rc != FBHIP_OK) break;
+                c->v_ready = c->events[128 + i];
+            }
+            rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_GRAD, s);
+            c->v_ready = nullptr;
+            if (rc == FBHIP_OK && has_actor) rc = allreduce(1);        // ... beside the next step's head
+            if (rc == FBHIP_OK) rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_ACTOR_STEP, s);
+            if (rc != FBHIP_OK) break;
+            if (more) {                          // join, then continue on the set the head filled
+                if ((he = hipEventRecord(c->events[2 * i + 1], c->side)) != hipSuccess) break;
+                if ((he = hipStreamWaitEvent(s, c->events[2 * i + 1], 0)) != hipSuccess) break;
+                c->cur ^= 1;
+            }
+        }
+        c->cur = cur0;
+    } else if (dp) {
         for (int i = 0; i < n_steps && rc == FBHIP_OK; ++i) {
             rc = enqueue_update(c, *hp, nullptr, FBHIP_PHASE_SAMPLE | FBHIP_PHASE_FB_GRAD | FBHIP_PHASE_ACTOR_FWD, s);
             if (rc == FBHIP_OK) rc = allreduce(0);
@@ -638,7 +715,10 @@ static int update_many_impl(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_ste
     ++c->graph_captures;
     if (c->graphs.size() >= 16) { (void)hipGraphExecDestroy(c->graphs.front().exec); c->graphs.erase(c->graphs.begin()); }
     c->graphs.push_back(ge);
-    return launch ? launch_graph(c, ge.exec, s, ge.branches) : (int)FBHIP_OK;
+    if (!launch) return FBHIP_OK;
+    RC(launch_graph(c, ge.exec, s, ge.branches));
+    c->pub_issued += (unsigned int)n_steps * publishes(c, hp, FBHIP_PHASE_ALL);
+    return FBHIP_OK;
 }
 
 int fbhip_update_many(fbhip_ctx* c, const fbhip_hparams* hp, int32_t n_steps, void* stream) {
@@ -704,7 +784,9 @@ int fbhip_rccl_init(fbhip_ctx* c, const void* unique_id_128_bytes, int32_t world
     HIPCK(c, hipDeviceSynchronize());                                       // (an exec destroyed under an in-flight launch corrupts the runtime)
     for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);            // the communicator is baked into captured launches
     c->graphs.clear();
-    if (unique_id_128_bytes == nullptr && world == 0) { rccl_release(c); c->rccl_world = 0; c->rccl_rank = 0; return FBHIP_OK; }   // release
+    if (unique_id_128_bytes == nullptr && world == 0) {          // release; rank != 0: after a failure, by ncclCommAbort
+        rccl_release(c, rank != 0); c->rccl_world = 0; c->rccl_rank = 0; return FBHIP_OK;
+    }
     return rccl_init(c, unique_id_128_bytes, world, rank, (hipStream_t)stream);
 }
 
@@ -742,6 +824,29 @@ int fbhip_read_metrics(fbhip_ctx* c, float* host_out, void* stream) {
     HIPCK(c, hipMemcpyAsync(host_out, c->W().metrics, FBHIP_NUM_METRICS * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCK(c, hipStreamSynchronize(s));
     return FBHIP_OK;
+}
+
+int fbhip_wait_metrics(fbhip_ctx* c, float* host_out) {
+    RC(need_bound(c, false));
+    if (!host_out) return FBHIP_E_INVALID;
+    if (c->h_metrics != nullptr) {
+        const unsigned int* seq = reinterpret_cast<const unsigned int*>(c->h_metrics + FBHIP_NUM_METRICS);
+        const unsigned int want = c->pub_issued;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned int spins = 0;; ++spins) {
+            if ((int)(__atomic_load_n(seq, __ATOMIC_ACQUIRE) - want) >= 0) {
+                memcpy(host_out, c->h_metrics, FBHIP_NUM_METRICS * sizeof(float));
+                return FBHIP_OK;
+            }
+            __builtin_ia32_pause();
+            if ((spins & 0x3fff) == 0x3fff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+        }
+        // the number never arrived (a launch that failed after it was counted?): drain the stream, take what the device holds and
+        // re-align the count with what was really published
+        HIPCK(c, hipStreamSynchronize(c->last_stream));
+        c->pub_issued = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+    }
+    return fbhip_read_metrics(c, host_out, c->last_stream);
 }
 
 int fbhip_workspace_view(fbhip_ctx* c, const char* name, float** ptr, int32_t* rows, int32_t* cols, int32_t* ld) {

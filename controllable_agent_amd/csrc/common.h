@@ -119,6 +119,10 @@ hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const fl
                              int rows, int d, int a, hipStream_t s, Squash sq = Squash{0, 1.f, -5.f, 2.f},
                              const float* pre = nullptr, int ldp = 0, const float* noise = nullptr, int ldn = 0);
 
+// metrics -> pinned host memory + sequence number, from inside the step (metrics_publish_kernel)
+hipError_t launch_metrics_publish(const float* metrics, float* host /* pinned: NUM_METRICS floats + 1 uint */, unsigned int* dseq,
+                                  hipStream_t s);
+
 // the update's actor phase: Q and d p straight from the heads' hidden activations p [rows, 2H] and V = z . W4 [rows, 2H]
 // (overwritten with d p); see actor_q_kernel
 struct StepState;
@@ -126,7 +130,9 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
                           const float* b42, const float* mu, int ldmu, const float* action, int lda, float stddev,
                           float* metrics, float* scratch /* >= 3*ceil(rows/4) floats */, int rows, int H, int d, int a,
                           Squash sq, const float* pre, int ldp, const float* noise, int ldn, hipStream_t s,
-                          StepState* adv = nullptr, int adv_which = 0 /* also does step_advance(adv, adv_which), see there */);
+                          StepState* adv = nullptr, int adv_which = 0 /* also does step_advance(adv, adv_which), see there */,
+                          float* pub_host = nullptr, unsigned int* pub_seq = nullptr /* both set (and metrics): the finalize launch
+                          also publishes every metric to the host, like launch_metrics_publish */);
 
 // policy head (premu = p . W4^T + b4, na = a or 2a outputs) + policy_sample in one row kernel (policy_head_kernel)
 bool policy_head_ok(int H, int na);
@@ -143,6 +149,17 @@ hipError_t policy_head_prepare(int H, int a, int na);   // raises the dynamic-LD
 struct PolicyHeadJobs { PolicyHeadJob j[PH_MAX_JOBS]; int n; };
 hipError_t launch_policy_head(const PolicyHeadJobs& jobs, const float* W4, int ldw4, const float* b4, int ldpre, int ldn,
                               float stddev, float clip, int ldmu, int rows, int H, int a, int na, Squash sq, hipStream_t s);
+// the same two seams as 16-row MFMA tiles (headtiles.hip): no weight image in LDS; TruncatedNormal actor, a <= 16, and for the fused
+// first layer / LayerNorm backward H = 512 / 1024.  FBHIP_HEAD_TILES=0 keeps the row kernels.  The launchers below dispatch.
+bool policy_head_tiles_ok(const PolicyHeadJobs& jobs, int ldw4, int rows, int H, int a, int na, const Squash& sq);
+hipError_t launch_policy_head_tiles(const PolicyHeadJobs& jobs, const float* W4, int ldw4, const float* b4, int ldpre, int ldn,
+                                    float stddev, float clip, int ldmu, int rows, int H, int a, hipStream_t s);
+bool actor_head_bwd_tiles_ok(int ldt, int ldy, int ldx, int ldp_, int lddp, int rows, int H, int a, const void* p0, const void* p1,
+                             const void* p2, const void* p3, const void* p4, const void* p5);
+hipError_t launch_actor_head_bwd_tiles(const float* dt1, int ldt, const float* W1a, int ldw1, const float* mu, int ldmu, const float* W4,
+                                       int ldw4, const float* P, int ldp_, float* dpremu, int ldd, float* dp, int lddp, int rows, int H,
+                                       int a, hipStream_t s, const float* lnY, int ldy, const float* lnX, int ldx, const float* lnStats,
+                                       const float* lnGamma);
 // d action -> d premu -> d p of the actor's policy hidden layer in one row kernel (actor_head_bwd_kernel; a <= 16)
 bool actor_head_bwd_ok(int H, int a);
 hipError_t actor_head_bwd_prepare(int H, int a);   // raises the kernel's dynamic-LDS limit (not inside a stream capture)
@@ -184,8 +201,10 @@ struct StepState {          // device-resident, advanced in-graph
     double actor_bc1;
     double actor_bc2_sqrt;
 };
+constexpr int EXTRA_METRICS_MAX_BLOCKS = 128;   // part: [EXTRA_METRICS_MAX_BLOCKS][4] doubles (64 rows per workgroup: batch <= 8192)
 hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z, int ld, int rows, int d,
-                                const float* cov, int ldc, float* metrics, hipStream_t s, int cov_rows = 0 /* 0: rows */);
+                                const float* cov, int ldc, float* metrics, hipStream_t s, int cov_rows = 0 /* 0: rows */,
+                                double* part = nullptr, unsigned int* ticket = nullptr /* both set: the many-workgroup form */);
 // DiscreteFBAgent heads, [rows, d * A] with (k, a) at column k * A + a (discrete_fb.py:289-311): target-side selection
 // (greedy column or softmax mix, + next_Q and the greedy index), online-side gather of the taken action's column, and the
 // gather's backward

@@ -14,7 +14,7 @@
 //   * LayerNorm statistics of a row span the 8 waves: wave-shuffle over the 4 lanes of a row, then an 8-way LDS fold.
 // No weight image in LDS, no refill, 4x / 2x fewer workgroup-level passes over the weight slices.
 // Math is rowops.hip's (fb_modules.py:112-126, :190; utils.py:171-185; LayerNorm + tanh as ln_tanh_fwd / bwd_kernel), the
-// fp32 summation ORDER differs (MFMA k order, 8-way folds): covered by the same oracle tolerances.
+// fp32 summation ORDER differs (MFMA k order, 8-way folds): covered by the same parity tolerances.
 #include "common.h"
 
 namespace fbhip {
@@ -121,8 +121,17 @@ __global__ void __launch_bounds__(512) policy_head_tile_kernel(const PolicyHeadJ
             gm[t] = ldg4(jb.gamma + n0 + 4 * kk);
             bt[t] = ldg4(jb.beta + n0 + 4 * kk);
             // A fragment of the rank-a update: W1[n0 + li][aoff + 4 kk + m], m = 0..3 (columns past a: clamped, their B is zero)
+            // (one 16-byte load where the quad lies inside the a columns -- 4-byte aligned only: the action columns start at obs_dim;
+            //  gfx950 global loads need no natural alignment -- else clamped scalars)
+            const float* q = jb.W1a + (size_t)(n0 + li) * jb.ldw1;
+            if (4 * kk + 3 < a) {
+                float4 v;
+                __builtin_memcpy(&v, q + 4 * kk, 16);
+                w1[t][0] = v.x; w1[t][1] = v.y; w1[t][2] = v.z; w1[t][3] = v.w;
+            } else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) w1[t][m] = jb.W1a[(size_t)(n0 + li) * jb.ldw1 + min(4 * kk + m, a - 1)];
+                for (int m = 0; m < 4; ++m) w1[t][m] = q[min(4 * kk + m, a - 1)];
+            }
         }
     }
     float nz[4], bias[4];
@@ -197,17 +206,21 @@ __global__ void __launch_bounds__(512) policy_head_tile_kernel(const PolicyHeadJ
     }
 }
 
-static bool tiles_env_on() {
-    const char* e = getenv("FBHIP_HEAD_TILES");                     // (read at every launch: A/B runs and tests force the row kernels)
-    return !(e && e[0] == '0');
+// FBHIP_HEAD_TILES (read at every launch: A/B runs and tests force either form): a bit mask, 1 = policy head, 2 = backward seam;
+// unset = both where the launch fills the chip (>= 2048 batch rows: 128 workgroups of 16 rows per job; measured same-box, round 6:
+// quadruped B = 2048 +1.9 %, walker B = 1024 -1.3 % -- 64 workgroups per job leave the serial latency of one tile chain exposed)
+static bool tiles_on(int which, int rows) {
+    const char* e = getenv("FBHIP_HEAD_TILES");
+    if (e && e[0] >= '0' && e[0] <= '3') return ((e[0] - '0') & which) != 0;
+    return rows >= 2048;
 }
 
 bool policy_head_tiles_ok(const PolicyHeadJobs& jobs, int ldw4, int rows, int H, int a, int na, const Squash& sq) {
-    if (!tiles_env_on() || sq.on || na != a || a < 1 || a > 16 || (H & 3) || H < 32 || (ldw4 & 3) || rows < 1) return false;
+    if (!tiles_on(1, rows) || sq.on || na != a || a < 1 || a > 16 || (H & 3) || H < 32 || (ldw4 & 3) || rows < 1) return false;
     for (int i = 0; i < jobs.n; ++i) {
         const PolicyHeadJob& j = jobs.j[i];
         if ((j.ldp & 3) || ((uintptr_t)j.P & 15)) return false;
-        if (j.base != nullptr && !(H == 512 || H == 1024 || H == 2048)) return false;
+        if (j.base != nullptr && !(H == 512 || H == 1024)) return false;      // (H = 2048: 16 tiles per wave spill; the row kernel stays)
     }
     return true;
 }
@@ -219,8 +232,7 @@ hipError_t launch_policy_head_tiles(const PolicyHeadJobs& jobs, const float* W4,
     bool first = false;
     for (int i = 0; i < jobs.n; ++i) first = first || jobs.j[i].base != nullptr;
     if (!first || H == 512) hipLaunchKernelGGL(policy_head_tile_kernel<4>, grid, block, 0, s, jobs, W4, ldw4, b4, ldpre, ldn, stddev, clip, ldmu, rows, H, a);
-    else if (H == 1024) hipLaunchKernelGGL(policy_head_tile_kernel<8>, grid, block, 0, s, jobs, W4, ldw4, b4, ldpre, ldn, stddev, clip, ldmu, rows, H, a);
-    else hipLaunchKernelGGL(policy_head_tile_kernel<16>, grid, block, 0, s, jobs, W4, ldw4, b4, ldpre, ldn, stddev, clip, ldmu, rows, H, a);
+    else hipLaunchKernelGGL(policy_head_tile_kernel<8>, grid, block, 0, s, jobs, W4, ldw4, b4, ldpre, ldn, stddev, clip, ldmu, rows, H, a);
     return hipGetLastError();
 }
 
@@ -330,7 +342,7 @@ __global__ void __launch_bounds__(512) actor_head_bwd_tile_kernel(const float* _
 bool actor_head_bwd_tiles_ok(int ldt, int ldy, int ldx, int ldp_, int lddp, int rows, int H, int a, const void* p0, const void* p1,
                              const void* p2, const void* p3, const void* p4, const void* p5) {
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    return tiles_env_on() && a >= 1 && a <= 16 && (H == 512 || H == 1024 || H == 2048) && rows >= 1 && !((ldt | ldy | ldx | ldp_ | lddp) & 3) &&
+    return tiles_on(2, rows) && a >= 1 && a <= 16 && (H == 512 || H == 1024) && rows >= 1 && !((ldt | ldy | ldx | ldp_ | lddp) & 3) &&
            al(p0) && al(p1) && al(p2) && al(p3) && al(p4) && al(p5);
 }
 
@@ -341,7 +353,7 @@ hipError_t launch_actor_head_bwd_tiles(const float* dt1, int ldt, const float* W
     dim3 grid((rows + 15) / 16), block(512);
 #define AHT(T) hipLaunchKernelGGL(actor_head_bwd_tile_kernel<T>, grid, block, 0, s, dt1, ldt, lnY, ldy, lnX, ldx, lnStats, lnGamma, W1a, \
                                   ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a)
-    if (H == 512) AHT(4); else if (H == 1024) AHT(8); else AHT(16);
+    if (H == 512) AHT(4); else AHT(8);
 #undef AHT
     return hipGetLastError();
 }

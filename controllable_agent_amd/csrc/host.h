@@ -155,6 +155,10 @@ struct fbhip_ctx {
     std::vector<fbhip::host::GraphEntry> graphs;
     int64_t graph_captures = 0;              // update graphs captured + instantiated so far (fbhip_graph_captures)
     std::vector<fbhip::host::InferGraph> infer_graphs;    // batch-1 fast path (fbhip_act / fbhip_z_correl)
+    float* h_metrics = nullptr;              // pinned: FBHIP_NUM_METRICS floats + the sequence number the publish kernel writes last
+    unsigned int* d_pubseq = nullptr;        // device: [0] number of publishes so far (advanced in-graph), [1] extra_metrics ticket
+    double* d_xm_part = nullptr;             // device: partial sums of extra_metrics_wide_kernel
+    unsigned int pub_issued = 0;             // host: number of publishes ENQUEUED so far (graph replays included)
     float* h_in = nullptr;                   // pinned host staging, same layout as w.act_in
     float* h_out = nullptr;                  // pinned: action / correlation
     const float* gb_panels = nullptr;        // global-batch data parallel (fbhip_bind_global_batch): [6][gb_rows][Lz]
@@ -241,7 +245,7 @@ int rccl_load(const char* path);
 int rccl_unique_id(void* out128);
 int rccl_version();
 int rccl_init(fbhip_ctx* c, const void* id128, int world, int rank, hipStream_t s);
-void rccl_release(fbhip_ctx* c);
+void rccl_release(fbhip_ctx* c, bool abort = false);
 int rccl_allreduce(fbhip_ctx* c, int which, hipStream_t s);
 
 }  // namespace host

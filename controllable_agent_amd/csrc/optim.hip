@@ -133,8 +133,80 @@ __global__ void __launch_bounds__(1024) extra_metrics_kernel(const float* __rest
     }
 }
 
+// The same metrics from many workgroups (round 6: the one-workgroup form above walks 64 rows per wave behind a shuffle reduction
+// each -- 75 us at B = 1024 on the critical path of every metrics-on update, README.md:50's invocation).  A workgroup owns 64 rows,
+// FOUR LANES per row (independent loads, two shuffles per row), and leaves four fp64 partial sums; the workgroup that draws the
+// last ticket folds all partials IN INDEX ORDER (deterministic whatever the arrival order), adds the B^T B statistics and writes
+// the six metrics.  ``part`` = [gridDim.x][4] doubles, ``ticket`` = one zero-initialised counter, reset by the last workgroup.
+constexpr int XM_ROWS = 64;
+__global__ void __launch_bounds__(256) extra_metrics_wide_kernel(const float* __restrict__ F1, const float* __restrict__ Bm,
+                                                                  const float* __restrict__ z, int ld, int rows, int d,
+                                                                  const float* __restrict__ cov, int ldc, float* __restrict__ metrics,
+                                                                  int cov_rows, double* __restrict__ part, unsigned int* ticket) {
+    __shared__ double red[4][4];
+    __shared__ double red2[4][2];
+    __shared__ unsigned int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, q = lane & 3;
+    const int r = blockIdx.x * XM_ROWS + wid * 16 + (lane >> 2);
+    const int rc = min(r, rows - 1);
+    float f = 0.f, b = 0.f, b2 = 0.f, z2 = 0.f;
+    for (int j = q; j < d; j += 4) {
+        const float bv = Bm[(size_t)rc * ld + j], zv = z[(size_t)rc * ld + j];
+        f += F1[(size_t)rc * ld + j]; b += bv; b2 += bv * bv; z2 += zv * zv;
+    }
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) { f += __shfl_xor(f, o); b += __shfl_xor(b, o); b2 += __shfl_xor(b2, o); z2 += __shfl_xor(z2, o); }
+    const bool mine = q == 0 && r < rows;
+    double sF = mine ? (double)f : 0.0, sB = mine ? (double)b : 0.0, sBn = mine ? (double)sqrtf(b2) : 0.0, sZn = mine ? (double)sqrtf(z2) : 0.0;
+#pragma unroll
+    for (int o = 4; o <= 32; o <<= 1) { sF += __shfl_xor(sF, o); sB += __shfl_xor(sB, o); sBn += __shfl_xor(sBn, o); sZn += __shfl_xor(sZn, o); }
+    if (lane == 0) { red[wid][0] = sF; red[wid][1] = sB; red[wid][2] = sBn; red[wid][3] = sZn; }
+    __syncthreads();
+    if (tid < 4) part[4 * blockIdx.x + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // ---- the last workgroup: B^T B / rows - I, then the fold
+    double sL2 = 0.0, mx = 0.0;
+    for (int e = tid; e < d * d; e += 256) {
+        const int i = e / d, j = e % d;
+        const float v = cov[(size_t)i * ldc + j] / (float)cov_rows - (i == j ? 1.f : 0.f);
+        sL2 += (double)v * v;
+        mx = fmax(mx, (double)fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sL2 += __shfl_xor(sL2, o); mx = fmax(mx, __shfl_xor(mx, o)); }
+    if (lane == 0) { red2[wid][0] = sL2; red2[wid][1] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        double a[4] = {0, 0, 0, 0};
+        const volatile double* pv = part;
+        for (unsigned int g = 0; g < gridDim.x; ++g)
+            for (int k = 0; k < 4; ++k) a[k] += pv[4 * g + k];
+        const double l2 = (red2[0][0] + red2[1][0]) + (red2[2][0] + red2[3][0]);
+        const double linf = fmax(fmax(red2[0][1], red2[1][1]), fmax(red2[2][1], red2[3][1]));
+        metrics[FBHIP_M_F1] = (float)(a[0] / ((double)rows * d));
+        metrics[FBHIP_M_B] = (float)(a[1] / ((double)rows * d));
+        metrics[FBHIP_M_B_NORM] = (float)(a[2] / rows);
+        metrics[FBHIP_M_Z_NORM] = (float)(a[3] / rows);
+        metrics[FBHIP_M_ORTH_L2] = (float)(sqrt(l2) / sqrt((double)d));
+        metrics[FBHIP_M_ORTH_LINF] = (float)linf;
+        *ticket = 0u;                            // (the next launch -- the next graph replay -- starts from zero again)
+    }
+}
+
 hipError_t launch_extra_metrics(const float* F1, const float* Bm, const float* z, int ld, int rows, int d,
-                                const float* cov, int ldc, float* metrics, hipStream_t s, int cov_rows) {
+                                const float* cov, int ldc, float* metrics, hipStream_t s, int cov_rows, double* part,
+                                unsigned int* ticket) {
+    const int nblk = (rows + XM_ROWS - 1) / XM_ROWS;
+    if (part != nullptr && ticket != nullptr && nblk >= 2 && nblk <= EXTRA_METRICS_MAX_BLOCKS) {
+        hipLaunchKernelGGL(extra_metrics_wide_kernel, dim3(nblk), dim3(256), 0, s, F1, Bm, z, ld, rows, d, cov, ldc, metrics,
+                           cov_rows > 0 ? cov_rows : rows, part, ticket);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(extra_metrics_kernel, dim3(1), dim3(1024), 0, s, F1, Bm, z, ld, rows, d, cov, ldc, metrics,
                        cov_rows > 0 ? cov_rows : rows);
     return hipGetLastError();

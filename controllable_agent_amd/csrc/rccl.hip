@@ -28,6 +28,7 @@ struct Api {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: the release path after a FAILURE (a peer may never arrive)
     ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -67,6 +68,7 @@ int rccl_load(const char* path) {
     SYM(AllReduce, "ncclAllReduce") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
     SYM(GetErrorString, "ncclGetErrorString") SYM(GetVersion, "ncclGetVersion")
 #undef SYM
+    a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(lib, "ncclCommAbort"));      // (absent: ncclCommDestroy is used)
     g_api = a;
     return FBHIP_OK;
 }
@@ -112,14 +114,19 @@ int rccl_init(fbhip_ctx* c, const void* id128, int world, int rank, hipStream_t 
     c->rccl_comm = comm; c->rccl_world = world; c->rccl_rank = rank;
     const int rc = rccl_warm_up(c, s);
     if (rc != FBHIP_OK) {                      // a half-initialised communicator must not outlive the error: the update's all-reduce
-        (void)g_api.CommDestroy(comm);         // lambda prefers rccl_comm over bound peers
+        // lambda prefers rccl_comm over bound peers.  ABORT, not destroy: the warm-up collective may still be
+        // outstanding because a peer failed after the rendezvous, and ncclCommDestroy would wait for it
+        (void)(g_api.CommAbort ? g_api.CommAbort(comm) : g_api.CommDestroy(comm));
         c->rccl_comm = nullptr; c->rccl_world = 0; c->rccl_rank = 0;
     }
     return rc;
 }
 
-void rccl_release(fbhip_ctx* c) {
-    if (c->rccl_comm != nullptr && g_api.lib != nullptr) (void)g_api.CommDestroy((ncclComm_t)c->rccl_comm);
+// abort = true: the release after a failure agreed by the ranks (rccl.py: a peer's init failed after the rendezvous) -- collectives
+// of this communicator may be outstanding with no partner; ncclCommAbort tears down without waiting for them
+void rccl_release(fbhip_ctx* c, bool abort) {
+    if (c->rccl_comm != nullptr && g_api.lib != nullptr)
+        (void)((abort && g_api.CommAbort) ? g_api.CommAbort((ncclComm_t)c->rccl_comm) : g_api.CommDestroy((ncclComm_t)c->rccl_comm));
     c->rccl_comm = nullptr;
 }
 

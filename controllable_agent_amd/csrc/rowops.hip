@@ -682,19 +682,58 @@ __global__ void __launch_bounds__(256) actor_q_kernel(const float* __restrict__ 
     }
 }
 
+// ``host`` != nullptr: these are the LAST metrics of the update -- the kernel also publishes all FBHIP_NUM_METRICS to the host (what
+// metrics_publish_kernel does, see there; one launch less on the metrics-on critical path)
 __global__ void __launch_bounds__(64) actor_loss_finalize_kernel(const float* __restrict__ part, int nblk, int rows,
                                                                  float* __restrict__ metrics, int m_loss, int m_q,
-                                                                 int m_lp, float temp /* 0: loss = -mean Q */) {
+                                                                 int m_lp, float temp /* 0: loss = -mean Q */,
+                                                                 float* host, unsigned int* dseq) {
+    const int lane = threadIdx.x;
+    // (the other metrics were written by earlier launches: requested before the fold below)
+    float mine = (host != nullptr && lane < FBHIP_NUM_METRICS) ? metrics[lane] : 0.f;
     double q = 0.0, l = 0.0, w = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 64) { q += (double)part[3 * b]; l += (double)part[3 * b + 1]; w += (double)part[3 * b + 2]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o); l += __shfl_xor(l, o); w += __shfl_xor(w, o); }
+    const float v_w = (float)(w / rows), v_loss = (float)((temp * l - q) / rows) /* fb_ddpg.py:406 */, v_q = (float)(q / rows),
+                v_lp = (float)(l / rows);
     if (threadIdx.x == 0) {
-        metrics[FBHIP_M_Q1_SUCCESS] = (float)(w / rows);
-        metrics[m_loss] = (float)((temp * l - q) / rows);         // fb_ddpg.py:406
-        metrics[m_q] = (float)(q / rows);
-        metrics[m_lp] = (float)(l / rows);
+        metrics[FBHIP_M_Q1_SUCCESS] = v_w;
+        metrics[m_loss] = v_loss;
+        metrics[m_q] = v_q;
+        metrics[m_lp] = v_lp;
     }
+    if (host == nullptr) return;
+    mine = lane == FBHIP_M_Q1_SUCCESS ? v_w : lane == m_loss ? v_loss : lane == m_q ? v_q : lane == m_lp ? v_lp : mine;
+    if (lane < FBHIP_NUM_METRICS) host[lane] = mine;
+    __threadfence_system();
+    if (lane == 0) {
+        const unsigned int sq = *dseq + 1u;
+        *dseq = sq;
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(host + FBHIP_NUM_METRICS), sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The step's metrics to the HOST, from inside the step: the 32 device floats are written into pinned host memory, then a sequence
+// number behind a system-scope fence.  Enqueued right after the LAST metric of an update is final (actor_loss_finalize_kernel; the
+// FB metrics for an agent without an actor) -- i.e. before the actor's backward pass and optimiser step: the host that called
+// update() with use_tb / use_hiplog (README.md:50; fb_ddpg.py:356-377, 413-418) spins on the number (fbhip_wait_metrics), returns
+// the dict and enqueues the NEXT update while this one's tail still runs.  No D2H copy command, no stream synchronise.
+__global__ void __launch_bounds__(64) metrics_publish_kernel(const float* __restrict__ metrics, float* host, unsigned int* dseq) {
+    const int lane = threadIdx.x;
+    if (lane < FBHIP_NUM_METRICS) host[lane] = metrics[lane];
+    __threadfence_system();
+    if (lane == 0) {
+        const unsigned int sq = *dseq + 1u;
+        *dseq = sq;
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(host + FBHIP_NUM_METRICS), sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_metrics_publish(const float* metrics, float* host, unsigned int* dseq, hipStream_t s) {
+    if (metrics == nullptr || host == nullptr || dseq == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(metrics_publish_kernel, dim3(1), dim3(64), 0, s, metrics, host, dseq);
+    return hipGetLastError();
 }
 
 hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const float* z, int ldz, const float* mu,
@@ -709,14 +748,15 @@ hipError_t launch_actor_loss(const float* F1, const float* F2, int ldf, const fl
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
     hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17,
-                       sq.on ? sq.temp : 0.f);
+                       sq.on ? sq.temp : 0.f, (float*)nullptr, (unsigned int*)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const float* z, int ldz, const float* b41,
                           const float* b42, const float* mu, int ldmu, const float* action, int lda, float stddev,
                           float* metrics, float* scratch, int rows, int H, int d, int a, Squash sq, const float* pre, int ldp,
-                          const float* noise, int ldn, hipStream_t s, StepState* adv, int adv_which) {
+                          const float* noise, int ldn, hipStream_t s, StepState* adv, int adv_which, float* pub_host,
+                          unsigned int* pub_seq) {
     if ((H & 3) || (ldp_ & 3) || (ldv & 3) || a > 64 || scratch == nullptr) return hipErrorInvalidValue;
     if (sq.on && (pre == nullptr || noise == nullptr)) return hipErrorInvalidValue;
     const int nblk = (rows + 3) / 4;
@@ -729,7 +769,7 @@ hipError_t launch_actor_q(const float* P, int ldp_, float* V, int ldv, const flo
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || metrics == nullptr) return e;       // loss / Q / log-prob are metrics only
     hipLaunchKernelGGL(actor_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, nblk, rows, metrics, 15, 16, 17,
-                       sq.on ? sq.temp : 0.f);
+                       sq.on ? sq.temp : 0.f, pub_seq != nullptr ? pub_host : nullptr, pub_seq);
     return hipGetLastError();
 }
 
@@ -913,6 +953,16 @@ hipError_t launch_policy_head(const PolicyHeadJobs& jobs, const float* W4, int l
                               float stddev, float clip, int ldmu, int rows, int H, int a, int na, Squash sq, hipStream_t s) {
     if (!policy_head_ok(H, na) || (na != a && na != 2 * a) || (ldw4 & 3) || jobs.n < 1 || jobs.n > PH_MAX_JOBS)
         return hipErrorInvalidValue;
+    if (policy_head_tiles_ok(jobs, ldw4, rows, H, a, na, sq)) {       // 16-row MFMA tiles, no LDS image (headtiles.hip)
+        for (int i = 0; i < jobs.n; ++i) {
+            const PolicyHeadJob& j = jobs.j[i];
+            if (j.base != nullptr && (!policy_first_ok(H, a, na) || j.W1a == nullptr || j.gamma == nullptr || j.beta == nullptr || j.t1 == nullptr ||
+                                      (j.ldb & 3) || (j.ldt1 & 3) || ((uintptr_t)j.base & 15) || ((uintptr_t)j.t1 & 15) ||
+                                      ((uintptr_t)j.gamma & 15) || ((uintptr_t)j.beta & 15)))
+                return hipErrorInvalidValue;
+        }
+        return launch_policy_head_tiles(jobs, W4, ldw4, b4, ldpre, ldn, stddev, clip, ldmu, rows, H, a, s);
+    }
     bool first = false;
     for (int i = 0; i < jobs.n; ++i) {
         const PolicyHeadJob& j = jobs.j[i];
@@ -1141,6 +1191,10 @@ hipError_t launch_actor_head_bwd(const float* dt1, int ldt, const float* W1a, in
     if (!actor_head_bwd_ok(H, a)) return hipErrorInvalidValue;
     const bool ln = lnY != nullptr;
     if (ln && (H > 2048 || !lnX || !lnStats || !lnGamma)) return hipErrorInvalidValue;
+    if (ln && getenv("FBHIP_AHB_WAVES") == nullptr &&
+        actor_head_bwd_tiles_ok(ldt, ldy, ldx, ldp_, lddp, rows, H, a, dt1, lnY, lnX, P, dp, lnGamma))       // headtiles.hip
+        return launch_actor_head_bwd_tiles(dt1, ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldp_, dpremu, ldd, dp, lddp, rows, H, a, s, lnY,
+                                           ldy, lnX, ldx, lnStats, lnGamma);
     const int lne = !ln ? 0 : (H <= 1024 ? 16 : 32);
     // eight waves per workgroup where the LDS image leaves room for one workgroup per CU only and four-wave workgroups would need a
     // second round (FBHIP_AHB_WAVES=4 / 8 forces either)

@@ -789,7 +789,9 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                                   d.discrete ? w.nextq : nullptr));      // discrete_fb.py:297, :302, :329
         }
         if (hp.want_metrics) {                  // fb_ddpg.py:356-377
-            HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s, Bg));
+            HIPCK(c, launch_extra_metrics(w.fsO.F1.p, BmO, w.z.p, Lz, B, z, w.cov.p, w.cov.ld, w.metrics, s, Bg, c->d_xm_part,
+                                          c->d_pubseq ? c->d_pubseq + 1 : nullptr));
+            if (d.discrete && c->h_metrics) HIPCK(c, launch_metrics_publish(w.metrics, c->h_metrics, c->d_pubseq, s));   // (no actor phase: these are the last)
         }
         if (d.discrete && (mask & FBHIP_PHASE_FB_BWD_A))      // backward of the action gather (discrete_fb.py:310)
             HIPCK(c, launch_discrete_scatter(w.dF1.p, w.dF2.p, Lz, w.act_idx, w.dFall1.p, w.dFall2.p, pad4(fhead_out(d)), B, z,
@@ -858,7 +860,10 @@ int build_update(fbhip_ctx* c, const fbhip_hparams& hp, const fbhip_inject* inj,
                 HIPCK(c, launch_actor_q(w.fsO.p.p, 2 * H, w.dp.p, 2 * H, w.z.p, Lz, c->F_p.b4[0], c->F_p.b4[1], w.as.mu.p, La,
                                         w.Xopi.p + aoff, w.Xopi.ld, hp.stddev, hp.want_metrics ? w.metrics : nullptr,
                                         w.pw_scratch, B, H, z, a, c->sq, w.as.premu.p, Lh, w.so.eps_actor, a, q,
-                                        actor_adv ? w.st : nullptr, 1));
+                                        actor_adv ? w.st : nullptr, 1,
+                                        // every metric of this update is final with this launch: its finalize kernel hands them to
+                                        // the host, BEFORE the actor's backward pass and optimiser step
+                                        hp.want_metrics ? c->h_metrics : nullptr, hp.want_metrics && c->h_metrics ? c->d_pubseq : nullptr));
                 return (int)FBHIP_OK;
             });
         });

@@ -83,8 +83,11 @@ def bind(agent: tp.Any) -> None:
         bad = [f for f in flags if f[1] != 0]
         if bad:
             if init_rc == 0:                      # this rank's communicator is live: give it back before raising with the others
+                # (release with rank = 1: ncclCommAbort -- a peer failed AFTER the rendezvous, e.g. in its warm-up all-reduce, and
+                #  ncclCommDestroy would wait for that collective instead of tearing down; the library dropped its graphs too)
                 agent._rccl_bound = False
-                lib.fbhip_rccl_init(agent._ctx, None, 0, 0, _lib.stream_ptr())
+                agent._rccl_prepared = []
+                lib.fbhip_rccl_init(agent._ctx, None, 0, 1, _lib.stream_ptr())
             raise RuntimeError("fbhip_rccl_init failed on rank(s) " + ", ".join(f"{r}: {e}" for r, _, e in bad))
     elif init_rc != 0:
         raise RuntimeError(f"fbhip_rccl_init failed: {init_err}")

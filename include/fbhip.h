@@ -285,10 +285,13 @@ int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t 
  * fbhip_peer_allreduce enqueues a sum-all-reduce of one bucket (which: 0 FB, 1 actor) as three kernels -- reduce-scatter,
  * all-gather, release, each behind a flag barrier across the ranks -- on ``stream``; capturable; deterministic; every rank must
  * enqueue the same sequence.  fbhip_update_many_dp is fbhip_update_many for a bound rank: n_steps complete data-parallel updates
- * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph.  That
- * graph is SINGLE-QUEUE by construction -- one stream, every step's phases and collectives in program order: its branched form
- * (the next step's head beside the actor phase, round 3) replayed 2.3x slower or not depending on what else lived in the process
- * (DESIGN.md section 7).  fbhip_update_many_dp_prepare captures and instantiates the same graph WITHOUT launching it: a host
+ * (mode A: per-rank loss blocks, summed gradients, hp->grad_scale = 1 / world) with both all-reduces INSIDE the one graph.
+ * Where branched graphs are usable (fbhip_branched_graphs) the steps are pipelined like fbhip_update_many's: step t+1's
+ * SAMPLE | FB_FWD_ONLINE on a second capture branch beside step t's actor gradient pass, its ACTOR all-reduce and its actor step
+ * (both collectives stay on the main branch, in program order: one communicator, one queue).  FBHIP_DP_PIPELINE=0, or a runtime
+ * that refuses branched graphs, gives the SINGLE-QUEUE chain -- one stream, every step's phases and collectives in program order
+ * (round 3's branched form replayed 2.3x slower or not depending on what else lived in the process: it was launched from a
+ * normal-priority stream; branched graphs now go out from a high-priority one).  fbhip_update_many_dp_prepare captures and instantiates the same graph WITHOUT launching it: a host
  * whose ranks must agree that every one of them could build its graph (a capture of the collectives that fails on one rank would
  * leave the others waiting inside theirs) calls it first, exchanges the return codes, and only then launches.  fbhip_dp_status blocks and
  * returns the status word (0 ok, 1 = a peer did not arrive within the spin limit: results of that step are garbage, nothing hangs). */
@@ -299,8 +302,9 @@ int fbhip_update_many_injected(fbhip_ctx* ctx, const fbhip_hparams* hp, int32_t 
  * and the host hands the same bytes to every rank's fbhip_rccl_init (collective: every rank calls it; it also runs both buckets'
  * all-reduces once eagerly, on the zeroed gradient buffers, so that connection set-up happens outside any capture).  Takes
  * precedence over bound peers.  Works for every agent kind (the buckets are the flat gradient buffers).
- * fbhip_rccl_init(ctx, NULL, 0, 0, stream) RELEASES the context's communicator (local, not collective): what a rank whose own
- * init succeeded does when the host's agreement says another rank's failed. */
+ * fbhip_rccl_init(ctx, NULL, 0, rank, stream) RELEASES the context's communicator (local, not collective): rank = 0 by
+ * ncclCommDestroy (orderly), rank != 0 by ncclCommAbort -- what a rank whose own init succeeded does when the host's agreement
+ * says another rank's failed after the rendezvous (its collectives may be outstanding with no partner; Destroy would wait). */
 int fbhip_rccl_load(const char* library_path);
 int fbhip_rccl_version(void);                      /* ncclGetVersion of the loaded library, 0 if none */
 int fbhip_rccl_unique_id(void* out_128_bytes);
@@ -342,6 +346,14 @@ size_t fbhip_embeddings_floats(const fbhip_dims* dims);
 int fbhip_export_embeddings(fbhip_ctx* ctx, float* out, void* stream);
 int fbhip_bind_global_batch(fbhip_ctx* ctx, const float* panels, const float* discount, int32_t global_rows,
                             int32_t row_offset);
+/* The metrics of the LAST update that was enqueued with hp->want_metrics, as soon as they are final -- which is before that
+ * update has finished: the step itself writes them into pinned host memory right after the actor loss (the last metric of
+ * fb_ddpg.py:356-377, 413-418; for an agent without an actor: after the FB metrics) and then a sequence number; this call spins
+ * on the number (no copy command, no stream synchronise) and returns while the update's remaining kernels (the actor's
+ * backward pass and optimiser step) still run -- the caller's next update is enqueued behind them on the same stream.  Replaces
+ * copy + synchronise for a caller that reads the metric dict of every update (README.md:50: use_tb=1 use_hiplog=1).  Falls back
+ * to fbhip_read_metrics on the update's stream if the number does not arrive within 5 s or pinned memory was refused. */
+int fbhip_wait_metrics(fbhip_ctx* ctx, float* host_out /* FBHIP_NUM_METRICS floats */);
 /* Blocking: copies the FBHIP_NUM_METRICS device floats to host_out after the stream drains. */
 int fbhip_read_metrics(fbhip_ctx* ctx, float* host_out, void* stream);
 /* Named views into the workspace for tests / host code ("z", "F1", "dF1", "obs", ...). */

@@ -497,7 +497,7 @@ def test_deferred_update_calls_equal_eager_calls():
     rb = _buffer(storage, lengths, cfg.discount, cfg.future)
     for s in range(40):
         assert a1.update(rb, s) == {} and a2.update(rb, s) == {}
-    assert a1.__dict__["_pending"][3] == 8                  # 32 went out when the queue was full
+    assert a1.__dict__["_pending"][3] == 7                  # 1 went out at once (run-length rule), 32 when the queue was full
     a1.act(storage["observation"][0, 1], a1.init_meta(), step=10, eval_mode=True)
     assert a1.__dict__.get("_pending") is None
     for a, b in zip(H.get_agent_state(a1).values(), H.get_agent_state(a2).values()):

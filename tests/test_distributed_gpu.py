@@ -193,7 +193,7 @@ def test_global_batch_updates_are_never_queued():
     from controllable_agent_amd.agent import FBHipAgent
     from controllable_agent_amd.replay import DeviceReplayBuffer
     rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
-    for flag, queued in ((True, 0), (False, 3)):
+    for flag, queued in ((True, 0), (False, 2)):              # (mode A: the first call of a run goes out at once, the rest queue)
         agent = FBHipAgent(**H.agent_kwargs(cfg, metrics=False, dp_global_batch=flag))
         agent.load_nets({n: dict(p) for n, p in nets.items()})
         for step in range(3):
@@ -516,11 +516,12 @@ def _dot_out_degrees(path):
     return deg
 
 
-def test_the_data_parallel_graph_is_single_queue_by_construction(monkeypatch, tmp_path):
-    """fbhip_update_many_dp's n-step graph is a CHAIN: no node has two successors -- one stream, every step's phases and both
-    all-reduces in program order, hence no cross-queue dependency for the runtime to resolve (the branched form of round 3
-    replayed 2.3x slower or not depending on what else lived in the process).  The single-rank graph of
-    fbhip_update_many keeps its second branch (the next step's head beside the actor phase)."""
+def test_the_data_parallel_graph_is_pipelined_and_keeps_a_single_queue_fallback(monkeypatch, tmp_path):
+    """fbhip_update_many_dp's n-step graph forks like the single-rank one (round 6): step t+1's head on a second branch beside step
+    t's actor gradient pass, actor all-reduce and actor step -- both collectives stay on the main branch, in program order.  With
+    FBHIP_DP_PIPELINE=0 (or on a runtime that refuses branched graphs) it is a CHAIN: no node has two successors -- the fallback
+    every rank can agree on (round 3's branched form, launched from a normal-priority stream, replayed 2.3x slower or not depending
+    on what else lived in the process).  Same kernels and operands either way: at these dims the same bits."""
     from controllable_agent_amd.replay import DeviceReplayBuffer
     cfg, nets, storage, lengths = T._setup()
     rb = DeviceReplayBuffer.from_arrays(storage, lengths, cfg.discount, device="cuda")
@@ -529,14 +530,28 @@ def test_the_data_parallel_graph_is_single_queue_by_construction(monkeypatch, tm
     a1.update_many(rb, 0, 4)
     torch.cuda.synchronize()
     assert max(_dot_out_degrees(tmp_path / "single.dot").values()) >= 2          # (sanity of the reader: this one forks)
-    monkeypatch.setenv("FBHIP_GRAPH_DOT", str(tmp_path / "dp.dot"))
     monkeypatch.setenv("FBHIP_FORCE_PHASE_SPLIT", "1")                            # the library RCCL transport at world 1
-    a2 = H.make_hip_agent(cfg, nets)
-    a2.update_many(rb, 0, 4)
-    torch.cuda.synchronize()
-    assert "rccl-library" in a2._dp_transport
-    deg = _dot_out_degrees(tmp_path / "dp.dot")
-    assert deg and max(deg.values()) == 1, deg.most_common(3)
+    states = {}
+    for form, env in (("pipelined", None), ("chain", "0")):
+        monkeypatch.setenv("FBHIP_GRAPH_DOT", str(tmp_path / f"dp_{form}.dot"))
+        if env is not None:
+            monkeypatch.setenv("FBHIP_DP_PIPELINE", env)
+        torch.manual_seed(11)
+        a2 = H.make_hip_agent(cfg, nets)
+        a2.update_many(rb, 0, 4)
+        torch.cuda.synchronize()
+        assert "rccl-library" in a2._dp_transport
+        assert a2.step_counts() == (4, 4)
+        states[form] = H.get_agent_state(a2)
+        deg = _dot_out_degrees(tmp_path / f"dp_{form}.dot")
+        if form == "chain":
+            assert deg and max(deg.values()) == 1, deg.most_common(3)
+        else:
+            from controllable_agent_amd import _lib
+            if _lib.load().fbhip_branched_graphs(None):
+                assert deg and max(deg.values()) >= 2, deg.most_common(3)
+    for k in states["chain"]:
+        np.testing.assert_array_equal(states["chain"][k], states["pipelined"][k], err_msg=k)
 
 
 # ------------------------------------------------------------------------------------------ the SF sibling, data parallel
