@@ -276,11 +276,12 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
     for (int n = 0; n < 3; ++n) c->L[n] = build_layout(*dims, n);
     // pinned staging of the batch-1 entry points (a few hundred bytes; host memory, not device memory)
     if (hipHostMalloc((void**)&c->h_in, act_in_floats(*dims) * sizeof(float), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_out, 64 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&c->h_out, 64 * sizeof(float), hipHostMallocCoherent) != hipSuccess) {
         (void)hipGetLastError();             // no usable device here (e.g. the CPU-only build check): fast path disabled
         c->h_in = c->h_out = nullptr;
     } else {
         memset(c->h_in, 0, act_in_floats(*dims) * sizeof(float));
+        memset(c->h_out, 0, 64 * sizeof(float));
         // the metrics' way out of a running step (metrics_publish_kernel): fine-grained pinned host memory + a 4-byte device counter.
         // Without them (allocation refused) metrics travel by copy + synchronise as before.
         if (hipHostMalloc((void**)&c->h_metrics, 2 * FBHIP_NUM_METRICS * sizeof(float), hipHostMallocCoherent) != hipSuccess ||
@@ -293,6 +294,9 @@ int fbhip_create(const fbhip_dims* dims, fbhip_ctx** out) {
             c->h_metrics = nullptr; c->d_pubseq = nullptr; c->d_xm_part = nullptr;
         } else {
             memset(c->h_metrics, 0, 2 * FBHIP_NUM_METRICS * sizeof(float));
+            // the same way out for the batch-1 results (act / compute_z_correl): FBHIP_INFER_DIRECT=0 keeps copy node + synchronise
+            const char* e = getenv("FBHIP_INFER_DIRECT");
+            c->infer_direct = !(e && e[0] == '0');
         }
     }
     {
@@ -945,8 +949,9 @@ int enqueue_act(fbhip_ctx* c, float stddev, int eval_mode, bool has_noise, hipSt
     }
     // ... head + TruncatedNormal / SquashedNormal
     HIPCK(c, launch_act_head(feat, A.W4, H, A.b4, a, H, stddev, eval_mode, has_noise ? w.act_in + act_noise_off(d) : nullptr,
-                             c->seed, c->rank, w.st, w.act_out, c->sq, s, w.act_in + (act_in_floats(d) - 1)));
-    HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, (size_t)a * sizeof(float), hipMemcpyDeviceToHost, s));
+                             c->seed, c->rank, w.st, w.act_out, c->sq, s, w.act_in + (act_in_floats(d) - 1),
+                             c->infer_direct ? c->h_out : nullptr, c->infer_direct ? c->d_pubseq + 2 : nullptr));
+    if (!c->infer_direct) HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, (size_t)a * sizeof(float), hipMemcpyDeviceToHost, s));
     (void)o; (void)z;
     return FBHIP_OK;
 }
@@ -991,8 +996,9 @@ int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
     float* pre1 = w.act_vec; float* r2 = pre1 + 2048; float* y = r2 + 2048;
     HIPCK(c, hipMemcpyAsync(w.act_in, c->h_in, (act_z_off(d) + z) * sizeof(float), hipMemcpyHostToDevice, s));
     if (d.backward_identity) {                   // IdentityMap: B(goal) = goal, no projection
-        HIPCK(c, launch_zcorrel(w.act_in, w.act_in + act_z_off(d), z, 0, w.act_out, s));
-        HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCK(c, launch_zcorrel(w.act_in, w.act_in + act_z_off(d), z, 0, w.act_out, s, c->infer_direct ? c->h_out : nullptr,
+                                c->infer_direct ? c->d_pubseq + 2 : nullptr));
+        if (!c->infer_direct) HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(float), hipMemcpyDeviceToHost, s));
         return FBHIP_OK;
     }
     // BackwardMap.forward (fb_modules.py:223-230) on the padded layout: pad rows of W1 / W2 are zero
@@ -1005,8 +1011,9 @@ int enqueue_zcorrel(fbhip_ctx* c, hipStream_t s) {
     GemvGroup g3{}; g3.n = 1;
     g3.p[0] = GV(r2, K.W3, Lb, K.b3, y, z, Lb, false);
     HIPCK(c, launch_gemv_group(g3, s));
-    HIPCK(c, launch_zcorrel(y, w.act_in + act_z_off(d), z, d.norm_z, w.act_out, s));
-    HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCK(c, launch_zcorrel(y, w.act_in + act_z_off(d), z, d.norm_z, w.act_out, s, c->infer_direct ? c->h_out : nullptr,
+                            c->infer_direct ? c->d_pubseq + 2 : nullptr));
+    if (!c->infer_direct) HIPCK(c, hipMemcpyAsync(c->h_out, w.act_out, sizeof(float), hipMemcpyDeviceToHost, s));
     return FBHIP_OK;
 }
 
@@ -1030,6 +1037,21 @@ int run_infer_graph(fbhip_ctx* c, int kind, float stddev, int eval_mode, bool ha
         c->infer_graphs.push_back(InferGraph{kind, eval_mode, (int)has_noise, stddev, exec});
     }
     HIPCK(c, hipGraphLaunch(exec, s));
+    if (c->infer_direct && kind != INFER_DISCRETE_ACT) {
+        // the graph's last kernel writes the result into h_out and then a sequence number: spin on it (a few microseconds after the
+        // kernel's store -- no D2H copy node, no interrupt / signal wait of hipStreamSynchronize); the stream drains on its own
+        const unsigned int want = ++c->infer_issued;
+        const unsigned int* seq = reinterpret_cast<const unsigned int*>(c->h_out + INFER_SEQ_SLOT);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned int spins = 0;; ++spins) {
+            if ((int)(__atomic_load_n(seq, __ATOMIC_ACQUIRE) - want) >= 0) return FBHIP_OK;
+            __builtin_ia32_pause();
+            if ((spins & 0x3fff) == 0x3fff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) break;
+        }
+        HIPCK(c, hipStreamSynchronize(s));       // (never arrived: drain, take what the kernel stored, re-align the count)
+        c->infer_issued = __atomic_load_n(seq, __ATOMIC_ACQUIRE);
+        return FBHIP_OK;
+    }
     HIPCK(c, hipStreamSynchronize(s));
     return FBHIP_OK;
 }

@@ -290,8 +290,13 @@ struct GemvGroup { GemvProblem p[GEMV_MAX_GROUP]; int n; };
 hipError_t launch_gemv_group(GemvGroup g, hipStream_t s);
 hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
                            int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
-                           Squash sq, hipStream_t s, const float* stddev_dev = nullptr /* device-resident stddev (replayable graphs) */);
-hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s);
+                           Squash sq, hipStream_t s, const float* stddev_dev = nullptr /* device-resident stddev (replayable graphs) */,
+                           float* host_out = nullptr, unsigned int* dseq = nullptr);
+hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s, float* host_out = nullptr,
+                          unsigned int* dseq = nullptr);
+// host_out + dseq (both set): the result ALSO goes straight into pinned host memory, then a sequence number into slot INFER_SEQ_SLOT
+// behind a system-scope fence: the batch-1 caller spins on the number instead of a D2H copy node + hipStreamSynchronize (api.hip)
+constexpr int INFER_SEQ_SLOT = 63;
 
 // ---- sampler -----------------------------------------------------------------------------------------------
 struct ReplayView {

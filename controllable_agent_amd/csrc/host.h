@@ -158,6 +158,8 @@ struct fbhip_ctx {
     float* h_metrics = nullptr;              // pinned: FBHIP_NUM_METRICS floats + the sequence number the publish kernel writes last
     unsigned int* d_pubseq = nullptr;        // device: [0] number of publishes so far (advanced in-graph), [1] extra_metrics ticket
     double* d_xm_part = nullptr;             // device: partial sums of extra_metrics_wide_kernel
+    unsigned int infer_issued = 0;           // host: batch-1 results requested through the direct-to-host path (d_pubseq[2] counts them)
+    bool infer_direct = false;               // act / z_correl write their result into h_out themselves (no D2H node, no stream sync)
     unsigned int pub_issued = 0;             // host: number of publishes ENQUEUED so far (graph replays included)
     float* h_in = nullptr;                   // pinned host staging, same layout as w.act_in
     float* h_out = nullptr;                  // pinned: action / correlation

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) act_head_kernel(const float* __restrict__
                                                        const float* __restrict__ stddev_dev, int eval_mode,
                                                        const float* __restrict__ noise, unsigned k0,
                                                        unsigned k1, StepState* __restrict__ st, float* __restrict__ out,
-                                                       const Squash sq) {
+                                                       const Squash sq, float* host_out, unsigned int* dseq) {
     __shared__ float pre[64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     // (the batch-1 graph reads the exploration stddev from its staged inputs: a schedule-driven stddev then replays ONE graph
@@ -142,15 +142,22 @@ __global__ void __launch_bounds__(256) act_head_kernel(const float* __restrict__
             }
         }
         out[n] = act;
+        if (host_out != nullptr) host_out[n] = act;          // pinned host memory: the caller spins on the number written below
     }
+    if (host_out != nullptr) __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0 && !eval_mode && noise == nullptr) st->act_count += 1u;
+    if (threadIdx.x == 0 && host_out != nullptr) {
+        const unsigned int sq_ = *dseq + 1u;
+        *dseq = sq_;
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(host_out + INFER_SEQ_SLOT), sq_, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // compute_z_correl's tail (fb_ddpg.py:286-289): b = sqrt(d) y / max(|y|_2, 1e-12) (BackwardMap's own projection), then
 // BOTH vectors divided by their L1 norm (the reference's ``F.normalize(z, 1)``: the positional 1 is p) and dotted.
 __global__ void __launch_bounds__(64) zcorrel_kernel(const float* __restrict__ y, const float* __restrict__ z, int d,
-                                                     int project, float* __restrict__ out) {
+                                                     int project, float* __restrict__ out, float* host_out, unsigned int* dseq) {
     const int lane = threadIdx.x;
     float yv[4], zv[4], s2 = 0.f;
 #pragma unroll
@@ -173,7 +180,16 @@ __global__ void __launch_bounds__(64) zcorrel_kernel(const float* __restrict__ y
 #pragma unroll
     for (int i = 0; i < 4; ++i) dot += (yv[i] * ib) * (zv[i] * iz);
     dot = wsum(dot);
-    if (lane == 0) out[0] = dot;
+    if (lane == 0) {
+        out[0] = dot;
+        if (host_out != nullptr) {
+            host_out[0] = dot;
+            __threadfence_system();
+            const unsigned int sq_ = *dseq + 1u;
+            *dseq = sq_;
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(host_out + INFER_SEQ_SLOT), sq_, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace
@@ -193,17 +209,18 @@ hipError_t launch_gemv_group(GemvGroup g, hipStream_t s) {
 
 hipError_t launch_act_head(const float* x, const float* W, int ldw, const float* bias, int a, int K, float stddev,
                            int eval_mode, const float* noise, uint64_t seed, uint32_t rank, StepState* st, float* out,
-                           Squash sq, hipStream_t s, const float* stddev_dev) {
-    if ((sq.on ? 2 * a : a) > 64 || (K & 3) || (ldw & 3)) return hipErrorInvalidValue;
+                           Squash sq, hipStream_t s, const float* stddev_dev, float* host_out, unsigned int* dseq) {
+    if ((sq.on ? 2 * a : a) > 64 || a > INFER_SEQ_SLOT || (K & 3) || (ldw & 3)) return hipErrorInvalidValue;
     const unsigned k0 = (unsigned)(seed & 0xffffffffu), k1 = (unsigned)(seed >> 32) ^ (0x9E3779B9u * (rank + 1u));
     hipLaunchKernelGGL(act_head_kernel, dim3(1), dim3(256), 0, s, x, W, ldw, bias, a, K, stddev, stddev_dev, eval_mode, noise, k0, k1, st,
-                       out, sq);
+                       out, sq, dseq != nullptr ? host_out : nullptr, dseq);
     return hipGetLastError();
 }
 
-hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s) {
+hipError_t launch_zcorrel(const float* y, const float* z, int d, int project, float* out, hipStream_t s, float* host_out,
+                          unsigned int* dseq) {
     if (d > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(zcorrel_kernel, dim3(1), dim3(64), 0, s, y, z, d, project, out);
+    hipLaunchKernelGGL(zcorrel_kernel, dim3(1), dim3(64), 0, s, y, z, d, project, out, dseq != nullptr ? host_out : nullptr, dseq);
     return hipGetLastError();
 }
 
