@@ -687,10 +687,14 @@ class FBHipAgent:
         out = np.empty(self.action_dim, np.float32)
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
         self._join_fast_path_stream()
-        with torch.cuda.stream(self._stream):
-            check(_lib.load().fbhip_act(self._ctx, obs.ctypes.data, z.ctypes.data, None if nz is None else nz.ctypes.data,
-                                        float(stddev), int(bool(eval_mode)), out.ctypes.data,
-                                        self._stream.cuda_stream), self._ctx)
+        ctx = self.__dict__["_ctx"]                  # (the join above has flushed; the stream travels as an argument: no context switch
+        call = lambda: check(_lib.load().fbhip_act(ctx, obs.ctypes.data, z.ctypes.data, None if nz is None else nz.ctypes.data,  # noqa: E731
+                                                   float(stddev), int(bool(eval_mode)), out.ctypes.data, self._stream.cuda_stream), ctx)
+        if torch.cuda.current_device() == self._device.index:      #  -- unless the caller sits on another device)
+            call()
+        else:
+            with torch.cuda.device(self._device):
+                call()
         return out
 
     def _normalize_z(self, z: torch.Tensor) -> torch.Tensor:            # ``if self.cfg.norm_z:`` of fb_ddpg.py:181, :217
@@ -739,8 +743,12 @@ class FBHipAgent:
             raise ValueError(f"compute_z_correl: expected goal[{self.goal_dim}] and z[{self.cfg.z_dim}]")
         out = np.empty(1, np.float32)
         self._join_fast_path_stream()
-        check(_lib.load().fbhip_z_correl(self._ctx, g.ctypes.data, z.ctypes.data, out.ctypes.data,
-                                         self._stream.cuda_stream), self._ctx)
+        ctx = self.__dict__["_ctx"]
+        if torch.cuda.current_device() == self._device.index:
+            check(_lib.load().fbhip_z_correl(ctx, g.ctypes.data, z.ctypes.data, out.ctypes.data, self._stream.cuda_stream), ctx)
+        else:
+            with torch.cuda.device(self._device):
+                check(_lib.load().fbhip_z_correl(ctx, g.ctypes.data, z.ctypes.data, out.ctypes.data, self._stream.cuda_stream), ctx)
         return float(out[0])
 
     # ------------------------------------------------------------------ the hot path

@@ -909,6 +909,44 @@ def test_online_call_sequence_puts_the_update_on_the_device_before_the_host_step
     assert a.step_counts() == (46, 46)
 
 
+def test_a_failing_flush_keeps_the_calls_it_could_not_launch(monkeypatch):
+    """``flush()`` used to clear the queue before launching -- a launch that raised (capture failure, bind error, HIP
+    error) silently dropped the queued updates and left the step / RNG counters behind what the caller had issued.  Now the calls
+    that were not launched stay queued, the error surfaces at the flush, and a later flush (cause removed) launches them: the
+    end state equals an eager twin's."""
+    from controllable_agent_amd import _lib
+    cfg = fo.OracleConfig(obs_dim=5, action_dim=3, goal_dim=5, z_dim=8, hidden_dim=32, feature_dim=16,
+                          backward_hidden_dim=18, batch_size=64)
+    rng = np.random.default_rng(31)
+    nets = {n: fo.synthetic_params(rng, fo.NET_SHAPES[n](cfg)) for n in ("actor", "forward_net", "backward_net")}
+    storage, lengths = fo.synthetic_storage(rng, 10, 30, cfg.obs_dim, cfg.action_dim)
+    rb = _buffer(storage, lengths, cfg.discount)
+    a, b = (H.make_hip_agent(cfg, nets, metrics=False) for _ in range(2))
+    b.defer_updates = False
+    for step in range(1 + 13):                                                      # 1 at once, 13 queued = 8 + 4 + 1
+        a.update(rb, step)
+        b.update(rb, step)
+    assert a.__dict__["_pending"][3] == 13
+    lib = _lib.load()
+    real_many = lib.fbhip_update_many
+    calls = []
+
+    def failing(ctx, hp, n, stream):                                                # the 8-step graph goes out, the 4-step one "fails"
+        calls.append(n)
+        return real_many(ctx, hp, n, stream) if n == 8 else -2
+    monkeypatch.setattr(lib, "fbhip_update_many", failing)
+    with pytest.raises(RuntimeError):
+        a.flush()
+    assert calls == [8, 4] and a.__dict__["_pending"][3] == 5                       # 13 - 8 launched: 5 still queued, nothing dropped
+    with pytest.raises(RuntimeError):
+        a.step_counts()                                                             # (every observer keeps hitting the same error)
+    monkeypatch.setattr(lib, "fbhip_update_many", real_many)
+    assert a.step_counts() == b.step_counts() == (14, 14)                           # cause removed: the rest goes out, nothing was lost
+    sa, sb = H.get_agent_state(a), H.get_agent_state(b)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+
+
 def test_queued_updates_go_out_as_a_fixed_menu_of_graph_sizes():
     """A flush launches its queue of k as graphs of 32 / 16 / 8 / 4 / 2 / 1 steps, largest first (FBHipAgent.DEFER_MENU): whatever the
     flush points of the caller are (log every M, eval every N, checkpoints), at most six update graphs ever exist and none is

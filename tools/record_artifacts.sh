@@ -9,13 +9,20 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-# configs[2]: quadruped + goal space, batch 2048, z_dim 100
-python bench.py --workload quadruped --steps 1000 --warmup 100 --repeats 3 > $OUT/${TAG}_quadruped_bench.json 2> $OUT/${TAG}_quadruped_bench.err
+# configs[2] (quadruped + goal space, batch 2048, z_dim 100): below, under tools/profile_cmd.sh
 # configs[4] rehearsal: online loop at quadruped dims, 2000-episode ring, synthetic env (free, and 300 us of emulated physics)
 python tools/online_bench.py --frames 12000 > $OUT/${TAG}_online_bench.txt 2>&1
 python tools/online_bench.py --frames 12000 --env-us 300 >> $OUT/${TAG}_online_bench.txt 2>&1
-# metrics dict ON, read back after every update
+# metrics dict ON, read back after every update (and the single-update-graph yardstick with metrics off; the host-side breakdown)
 python tools/metrics_on_bench.py > $OUT/${TAG}_metrics_on_bench.txt 2>&1
+python tools/metrics_on_bench.py --off >> $OUT/${TAG}_metrics_on_bench.txt 2>&1
+python tools/metrics_turnaround.py 2>&1 | grep "metrics ON" > $OUT/${TAG}_metrics_turnaround.txt
+# siblings
+python tools/discrete_bench.py > $OUT/${TAG}_discrete_bench.json 2> $OUT/${TAG}_discrete_bench.err
+python tools/sf_bench.py --learner icm > $OUT/${TAG}_sf_icm_bench.json 2> $OUT/${TAG}_sf_icm_bench.err
+python tools/sf_bench.py --learner lap > $OUT/${TAG}_sf_lap_bench.json 2> $OUT/${TAG}_sf_lap_bench.err
+# configs[2] under the profiler: kernel table, timeline, PMC passes
+tools/profile_cmd.sh ${TAG}_quadruped "python bench.py --workload quadruped --steps 1000 --warmup 100 --repeats 3" "python bench.py --workload quadruped --steps 160 --warmup 32 --repeats 1 --no-cpu-baseline --no-single-update-probe" > /dev/null 2>&1
 # sustained rate + finiteness
 python tools/soak.py 100000 > $OUT/${TAG}_soak_100k.txt 2>&1
 # batch-1 act / compute_z_correl latency
