@@ -260,8 +260,8 @@ def _beat(what):
 
 def supervise_ranks(args, rank, world):
     """N > 1 under torch.distributed.run: every launched worker becomes a SUPERVISOR that holds no GPU context and runs the real
-    bench rank in a child process, one attempt per gradient transport -- the library's RCCL communicator first, then the
-    torch.distributed schedule, then the peer-access kernels.  A multi-GPU node is available to this script once per round and
+    bench rank in a child process, one attempt per gradient transport -- the library's RCCL communicator first (its pipelined graph,
+    then its single-queue chain), then the torch.distributed schedule, then the peer-access kernels.  A multi-GPU node is available to this script once per round and
     none of the three transports has ever run on more than one physical device: an attempt that crashes on any rank, or whose
     slowest rank stops making progress (heartbeat file, --stall-timeout), is killed on ALL ranks (process groups this supervisor
     started, by pid) and the next transport gets a fresh rendezvous on another port.  The supervisors agree once a second through
@@ -275,6 +275,14 @@ def supervise_ranks(args, rank, world):
     dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=1800))
     first = "peer" if args.peer_allreduce else (args.transport or "rccl")
     transports = [first] if (args.global_batch or args.no_fallback_transports) else [first] + [t for t in ("rccl", "c10d", "peer") if t != first]
+    # (transport, extra environment): the library's graph is PIPELINED by default since round 6 (the next step's head on a second branch);
+    # that form has run on one device only, so its single-queue chain (FBHIP_DP_PIPELINE=0, the form of rounds 4-5) is the next attempt
+    # before the transport itself is given up
+    plan = []
+    for t in transports:
+        plan.append((t, {}))
+        if t == "rccl" and not args.no_fallback_transports and os.environ.get("FBHIP_DP_PIPELINE") != "0":
+            plan.append((t, {"FBHIP_DP_PIPELINE": "0"}))
     argv = [a for a in sys.argv[1:] if a != "--peer-allreduce"]
     while "--transport" in argv:
         i = argv.index("--transport")
@@ -282,7 +290,7 @@ def supervise_ranks(args, rank, world):
     argv = [a for a in argv if not a.startswith("--transport=")]
     history, line = [], None
     tmp = Path(tempfile.mkdtemp(prefix=f"fbhip_bench_r{rank}_"))
-    for attempt, tr in enumerate(transports):
+    for attempt, (tr, extra_env) in enumerate(plan):
         port = [0]
         if rank == 0:
             import socket
@@ -292,7 +300,7 @@ def supervise_ranks(args, rank, world):
         dist.broadcast_object_list(port, src=0)
         hb, so = tmp / f"beat{attempt}", tmp / f"out{attempt}"
         env = dict(os.environ, MASTER_PORT=str(port[0]), FBHIP_BENCH_CHILD="1", FBHIP_BENCH_HEARTBEAT=str(hb),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
         for k in ("TORCHELASTIC_USE_AGENT_STORE",):          # the child ranks rendezvous among themselves: rank 0 hosts the store
             env.pop(k, None)
         t0 = time.time()
@@ -327,7 +335,7 @@ def supervise_ranks(args, rank, world):
         beat = hb.read_text().strip() if hb.exists() else "never started"
         every = [None] * world
         dist.all_gather_object(every, {"outcome": outcome, "last_progress": beat.split(" ", 1)[-1]})
-        history.append({"transport": tr, "seconds": round(time.time() - t0, 1), "ranks": every})
+        history.append({"transport": tr, **({"env": extra_env} if extra_env else {}), "seconds": round(time.time() - t0, 1), "ranks": every})
         if outcome == "ok":
             if rank == 0:
                 text = so.read_text(errors="replace")
@@ -339,7 +347,7 @@ def supervise_ranks(args, rank, world):
             break
         if rank == 0:
             print(f"bench.py: transport {tr} did not finish ({[e['outcome'] for e in every]}); "
-                  + ("trying the next one" if attempt + 1 < len(transports) else "no transport left"), file=sys.stderr, flush=True)
+                  + ("trying the next one" if attempt + 1 < len(plan) else "no transport left"), file=sys.stderr, flush=True)
     ok = [line is not None]
     dist.broadcast_object_list(ok, src=0)
     if rank == 0 and line is not None:

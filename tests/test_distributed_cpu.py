@@ -178,13 +178,14 @@ def test_dp_update_many_call_order_and_workspace_sets():
 
 @pytest.mark.parametrize("plan,expect", [
     ("", [("rccl", "ok")]),
-    ("rccl:*:1:crash", [("rccl", "failed"), ("c10d", "ok")]),
-    ("rccl:*:1:hang,c10d:*:0:crash", [("rccl", "failed"), ("c10d", "failed"), ("peer", "ok")]),
+    ("rccl:*:1:crash", [("rccl", "failed"), ("rccl", "failed"), ("c10d", "ok")]),
+    ("rccl:*:1:hang,c10d:*:0:crash", [("rccl", "failed"), ("rccl", "failed"), ("c10d", "failed"), ("peer", "ok")]),
 ])
 def test_bench_supervisor_walks_its_plan_of_transports(plan, expect, tmp_path):
     """bench.py::supervise_ranks without a GPU: two supervisors under torch.distributed.run (gloo), the real ranks replaced by
     tests/fake_bench_child.py.  A child that exits non-zero or stops writing its heartbeat fails the attempt on BOTH ranks; the
-    plan goes library RCCL -> torch.distributed schedule -> peer kernels; rank 0
+    plan goes library RCCL (pipelined graph, then FBHIP_DP_PIPELINE=0: the single-queue chain) -> torch.distributed schedule -> peer
+    kernels; rank 0
     prints exactly one JSON line, the finishing child's, with the attempt history added."""
     import json, subprocess, sys
     from pathlib import Path
@@ -202,6 +203,7 @@ def test_bench_supervisor_walks_its_plan_of_transports(plan, expect, tmp_path):
     att = res["data_parallel"]["attempts"]
     got = [(a["transport"], "ok" if all(r["outcome"] == "ok" for r in a["ranks"]) else "failed") for a in att]
     assert got == expect, att
+    assert [a.get("env") for a in att if a["transport"] == "rccl"][1:] == [{"FBHIP_DP_PIPELINE": "0"}] * (len([a for a in att if a["transport"] == "rccl"]) - 1)
     assert res["data_parallel"]["transport"] == expect[-1][0] and "some library banner" not in out.stdout
 
 

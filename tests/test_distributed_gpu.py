@@ -370,11 +370,12 @@ def test_bench_supervisor_moves_to_the_next_transport_when_a_rank_is_lost(how):
     assert len(lines) == 1, lines                                    # ONE JSON line, from the attempt that finished
     res = json.loads(lines[0])
     att = res["data_parallel"]["attempts"]
-    assert [a["transport"] for a in att] == ["rccl", "c10d"], att
+    assert [a["transport"] for a in att] == ["rccl", "rccl", "c10d"], att           # (pipelined graph, single-queue chain, next transport)
+    assert att[1].get("env") == {"FBHIP_DP_PIPELINE": "0"}
     first = [r["outcome"] for r in att[0]["ranks"]]
     # (rank 0's child either is killed while blocked in its first collective or notices the closed connection by itself)
     assert first[1].startswith("failed (" + ("exit code 7" if how == "crash" else "no progress")) and first[0].startswith("failed"), att
-    assert [r["outcome"] for r in att[1]["ranks"]] == ["ok", "ok"]
+    assert [r["outcome"] for r in att[2]["ranks"]] == ["ok", "ok"]
     assert res["n_gpus"] == 2 and res["replicas"]["identical"] is True and res["value"] > 0
 
 
