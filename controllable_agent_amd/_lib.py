@@ -119,6 +119,8 @@ PROTOTYPES = {
     "fbhip_l2norm_fwd": (C.c_int, [_P, _I, _P, _I, _P, _I, _I, _P]),
     "fbhip_l2norm_bwd": (C.c_int, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _P]),
     "fbhip_actor_loss": (C.c_int, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fbhip_policy_head": (C.c_int, [_P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "fbhip_actor_head_bwd": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _P]),
     "fbhip_pairwise_scratch_floats": (_Z, [_I, _I]),
     "fbhip_pairwise_fb": (C.c_int, [_P] * 7 + [_I, _I, _I, _F] + [_P] * 5 + [_P]),
     "fbhip_pairwise_fb_block": (C.c_int, [_P] * 7 + [_I, _I, _I, _F, _I, _I] + [_P] * 5 + [_P]),

@@ -1305,5 +1305,34 @@ int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float*
     return FBHIP_OK;
 }
 
+// per-kernel test exports of the two a-wide seams of the actor (rowops.hip row kernels / headtiles.hip MFMA tiles; the launchers
+// pick the form: FBHIP_HEAD_TILES, batch rows): tests/test_kernels_gpu.py compares both forms with fp64 statements
+int fbhip_policy_head(const float* P, int32_t ldp, const float* W4, int32_t ldw4, const float* b4, const float* noise, float stddev,
+                      float clip, float* premu, float* mu, float* action, int32_t ld_out, const float* base, int32_t ldb,
+                      const float* W1a, int32_t ldw1, const float* gamma, const float* beta, float* t1, int32_t ldt1, float* stats,
+                      int32_t rows, int32_t H, int32_t a, void* stream) {
+    fbhip_ctx* none = nullptr;
+    if (!P || !W4 || !b4 || !premu || rows < 1) { g_err = "fbhip_policy_head: bad argument"; return FBHIP_E_INVALID; }
+    if (!policy_head_ok(H, a) || (base != nullptr && !policy_first_ok(H, a, a))) { g_err = "fbhip_policy_head: unsupported (H, a)"; return FBHIP_E_INVALID; }
+    HIPCK(none, policy_head_prepare(H, a, a));
+    PolicyHeadJobs jobs{};
+    jobs.n = 1;
+    jobs.j[0] = PolicyHeadJob{P, ldp, premu, noise, mu, action, ld_out, base, ldb, W1a, ldw1, gamma, beta, t1, ldt1, stats};
+    HIPCK(none, launch_policy_head(jobs, W4, ldw4, b4, ld_out, a, stddev, clip, ld_out, rows, H, a, a, Squash{0, 1.f, -5.f, 2.f},
+                                   (hipStream_t)stream));
+    return FBHIP_OK;
+}
+
+int fbhip_actor_head_bwd(const float* dt1, int32_t ldt, const float* lnY, const float* lnX, const float* lnStats, const float* lnGamma,
+                         const float* W1a, int32_t ldw1, const float* mu, int32_t ldmu, const float* W4, int32_t ldw4, const float* P,
+                         float* dpremu, int32_t ldd, float* dp, int32_t rows, int32_t H, int32_t a, void* stream) {
+    fbhip_ctx* none = nullptr;
+    if (!dt1 || !W1a || !mu || !W4 || !P || !dpremu || !dp || rows < 1 || !actor_head_bwd_ok(H, a)) { g_err = "fbhip_actor_head_bwd: bad argument"; return FBHIP_E_INVALID; }
+    HIPCK(none, actor_head_bwd_prepare(H, a));
+    HIPCK(none, launch_actor_head_bwd(dt1, ldt, W1a, ldw1, mu, ldmu, W4, ldw4, P, ldt, dpremu, ldd, dp, ldt, rows, H, a, (hipStream_t)stream,
+                                      lnY, ldt, lnX, ldt, lnStats, lnGamma));
+    return FBHIP_OK;
+}
+
 }  // extern "C"
 

@@ -167,3 +167,36 @@ def actor_loss(F1, F2, z, mu, action, stddev: float):
                                        rows, d, a, stream_ptr()))
     m = metrics.cpu()
     return dF1, dF2, {k: float(m[_lib.METRIC_INDEX[k]]) for k in ("actor_loss", "q", "actor_logprob", "q1_success")}
+
+
+def policy_head(P, W4, b4, noise, stddev: float, clip: float, base=None, W1a=None, gamma=None, beta=None, keep_pre: bool = False):
+    """(premu, mu, action[, t1, pre, stats]) of the policy head launch (csrc/rowops.hip row kernel or csrc/headtiles.hip MFMA tiles)."""
+    _lib.require_device()
+    rows, H = P.shape
+    a = W4.shape[0]
+    La = (a + 3) // 4 * 4
+    premu, mu, action = (torch.zeros((rows, La), device=P.device) for _ in range(3))
+    t1 = stats = pre = None
+    if base is not None:
+        pre = base.clone()
+        t1 = torch.empty((rows, H), device=P.device)
+        stats = torch.empty(2 * rows, device=P.device) if keep_pre else None
+    check(_lib.load().fbhip_policy_head(ptr(P), _ld(P), ptr(W4), _ld(W4), ptr(b4), ptr(noise), float(stddev), float(clip), ptr(premu),
+                                        ptr(mu), ptr(action), La, ptr(pre), 0 if pre is None else _ld(pre), ptr(W1a),
+                                        0 if W1a is None else _ld(W1a), ptr(gamma), ptr(beta), ptr(t1), 0 if t1 is None else _ld(t1),
+                                        ptr(stats), rows, H, a, stream_ptr()))
+    return premu[:, :a], mu[:, :a], action[:, :a], t1, pre, stats
+
+
+def actor_head_bwd(dt1, lnY, lnX, lnStats, lnGamma, W1a, mu, W4, P):
+    """(d premu [rows, a], d p [rows, H]) of the actor's backward seam behind the LayerNorm + tanh backward."""
+    _lib.require_device()
+    rows, H = dt1.shape
+    a = W4.shape[0]
+    La = (a + 3) // 4 * 4
+    dpremu = torch.zeros((rows, La), device=dt1.device)
+    dp = torch.empty((rows, H), device=dt1.device)
+    assert _ld(dt1) == _ld(lnY) == _ld(lnX) == _ld(P) == _ld(dp)
+    check(_lib.load().fbhip_actor_head_bwd(ptr(dt1), _ld(dt1), ptr(lnY), ptr(lnX), ptr(lnStats), ptr(lnGamma), ptr(W1a), _ld(W1a), ptr(mu),
+                                           _ld(mu), ptr(W4), _ld(W4), ptr(P), ptr(dpremu), La, ptr(dp), rows, H, a, stream_ptr()))
+    return dpremu[:, :a], dp

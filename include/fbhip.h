@@ -434,6 +434,19 @@ int fbhip_l2norm_bwd(const float* dB, int32_t lddb, const float* y, int32_t ldy,
 int fbhip_actor_loss(const float* F1, const float* F2, int32_t ldf, const float* z, int32_t ldz, const float* mu,
                      int32_t ldmu, const float* action, int32_t lda, float stddev, float* dF1, float* dF2, float* metrics,
                      float* scratch, int32_t rows, int32_t d, int32_t a, void* stream);
+/* The two a-wide seams of the actor as stand-alone launches (tests; the update calls the same launchers): (1) premu = P W4^T + b4,
+ * mu = tanh(premu), action = TruncatedNormal sample (utils.py:176-185; noise NULL: action = mu) and -- base != NULL -- the first layer
+ * of the trunk that consumes the action: t1 = tanh(LayerNorm(base + W1[:, action columns] action)), with stats also the full
+ * pre-activation over base and (mean, rstd) (fb_modules.py:112-126, :190); (2) d action = LayerNormTanhBackward(dt1) W1[:, action
+ * columns], d premu = d action (1 - mu^2), d p = (d premu W4) relu'(P) (the reverse of the same lines).  premu / mu / action / d premu
+ * share one leading dimension; [rows, H] operands share ldt.  Row kernels or 16-row MFMA tiles by FBHIP_HEAD_TILES / rows. */
+int fbhip_policy_head(const float* P, int32_t ldp, const float* W4, int32_t ldw4, const float* b4, const float* noise, float stddev,
+                      float clip, float* premu, float* mu, float* action, int32_t ld_out, const float* base, int32_t ldb,
+                      const float* W1a, int32_t ldw1, const float* gamma, const float* beta, float* t1, int32_t ldt1, float* stats,
+                      int32_t rows, int32_t H, int32_t a, void* stream);
+int fbhip_actor_head_bwd(const float* dt1, int32_t ldt, const float* lnY, const float* lnX, const float* lnStats, const float* lnGamma,
+                         const float* W1a, int32_t ldw1, const float* mu, int32_t ldmu, const float* W4, int32_t ldw4, const float* P,
+                         float* dpremu, int32_t ldd, float* dp, int32_t rows, int32_t H, int32_t a, void* stream);
 /* Pairwise FB + orthonormality loss and its gradients (fb_ddpg.py:313-348).
  * All inputs [B,d] with leading dim ld; discount [B].  Outputs dF1,dF2,dB [B,d] (ld), scalars -> metrics
  * (device float[FBHIP_NUM_METRICS]; writes TARGET_M, M1, FB_LOSS, FB_DIAG, FB_OFFDIAG, ORTH_*).

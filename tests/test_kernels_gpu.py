@@ -409,3 +409,82 @@ def test_gemm_tile_to_xcd_maps_give_the_same_bits(K, M, N, Kd, lay, monkeypatch)
     assert torch.equal(c0, c1)
     ref = (A.double() if akc else A.double().T) @ (B.double().T if bkc else B.double())
     assert rel_err(c1.cpu(), ref.cpu()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ the actor's a-wide seams
+def _ln_stats64(x64):
+    mean = x64.mean(1, keepdim=True)
+    var = ((x64 - mean) ** 2).mean(1, keepdim=True)
+    return mean, 1.0 / torch.sqrt(var + 1e-5)
+
+
+@pytest.mark.parametrize("tiles", ["0", "3"])
+@pytest.mark.parametrize("rows,H,a,aoff,ldw1", [(100, 1024, 12, 78, 96), (64, 512, 6, 24, 32), (37, 512, 3, 5, 8), (2048, 1024, 12, 78, 96)])
+def test_policy_head_and_first_layer_vs_fp64(monkeypatch, tiles, rows, H, a, aoff, ldw1):
+    """premu = p W4^T + b4, mu = tanh, TruncatedNormal sample with clip and straight-through clamp (fb_modules.py:117-126,
+    utils.py:176-185), then the first layer of the trunk that consumes the action: tanh(LayerNorm(base + W1[:, action] action))
+    (fb_modules.py:190) with the pre-activation and (mean, rstd) kept -- row kernel (FBHIP_HEAD_TILES=0, rowops.hip) and 16-row MFMA
+    tiles (=3, headtiles.hip) against an fp64 statement; ragged row counts, action columns at 16-byte-aligned and unaligned offsets."""
+    from controllable_agent_amd import kernels as K
+    monkeypatch.setenv("FBHIP_HEAD_TILES", tiles)
+    g = torch.Generator(device="cuda").manual_seed(rows + H + a)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    P = torch.relu(rn(rows, H))
+    W4, b4 = rn(a, H) / H ** 0.5, rn(16)[:a] * 0.1
+    noise = rn(rows, a)
+    W1 = rn(H, ldw1) * 0.3
+    W1a = W1[:, aoff:aoff + a]
+    base, gamma, beta = rn(rows, H), 1.0 + 0.1 * rn(H), 0.1 * rn(H)
+    stddev, clip = 0.2, 0.3
+    premu, mu, action, t1, pre, stats = K.policy_head(P, W4, b4, noise, stddev, clip, base, W1a, gamma, beta, keep_pre=True)
+    torch.cuda.synchronize()
+    d = lambda t: t.double()
+    premu64 = d(P) @ d(W4).T + d(b4)
+    mu64 = torch.tanh(premu64)
+    act64 = torch.clamp(mu64 + torch.clamp(d(noise) * stddev, -clip, clip), -1.0 + 1e-6, 1.0 - 1e-6)
+    pre64 = d(base) + act64 @ d(W1a).T
+    mean, rstd = _ln_stats64(pre64)
+    t164 = torch.tanh((pre64 - mean) * rstd * d(gamma) + d(beta))
+    for name, got, ref, tol in (("premu", premu, premu64, 2e-6), ("mu", mu, mu64, 2e-6), ("action", action, act64, 2e-6),
+                                ("pre", pre, pre64, 2e-6), ("t1", t1, t164, 1e-5)):
+        err = float((d(got) - ref).abs().max() / ref.abs().max())
+        assert err < tol, (name, err)
+    st = stats.view(rows, 2).double()
+    assert float((st[:, 0:1] - mean).abs().max()) < 1e-5 and float(((st[:, 1:2] - rstd) / rstd).abs().max()) < 1e-5
+    # the plain head (no first layer, no noise): action = mu
+    premu2, mu2, action2, *_ = K.policy_head(P, W4, b4, None, stddev, clip)
+    assert float((d(premu2) - premu64).abs().max() / premu64.abs().max()) < 2e-6 and torch.equal(mu2, action2)
+
+
+@pytest.mark.parametrize("tiles", ["0", "3"])
+@pytest.mark.parametrize("rows,H,a,aoff,ldw1", [(100, 1024, 12, 78, 96), (64, 512, 6, 24, 32), (37, 512, 3, 5, 8), (2048, 1024, 12, 78, 96)])
+def test_actor_head_bwd_vs_fp64(monkeypatch, tiles, rows, H, a, aoff, ldw1):
+    """d action = LayerNormTanhBackward(dt1) W1[:, action columns]; d premu = d action (1 - mu^2) (straight-through clamp + tanh,
+    utils.py:171-174); d p = (d premu W4) relu'(p) (fb_modules.py:119-124 reversed) -- both kernel forms against an fp64 statement."""
+    from controllable_agent_amd import kernels as K
+    monkeypatch.setenv("FBHIP_HEAD_TILES", tiles)
+    g = torch.Generator(device="cuda").manual_seed(7 * rows + H + a)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    d = lambda t: t.double()
+    x, gamma, beta = rn(rows, H), 1.0 + 0.1 * rn(H), 0.1 * rn(H)
+    mean, rstd = _ln_stats64(d(x))
+    y = torch.tanh((d(x) - mean) * rstd * d(gamma) + d(beta)).float()
+    stats = torch.cat([mean, rstd], 1).float().contiguous().view(-1)
+    dt1 = rn(rows, H)
+    W1 = rn(H, ldw1) * 0.3
+    W1a = W1[:, aoff:aoff + a]
+    W4 = rn(a, H) / H ** 0.5
+    mu = torch.tanh(rn(rows, (a + 3) // 4 * 4))[:, :a]
+    P = rn(rows, H)
+    dpremu, dp = K.actor_head_bwd(dt1, y, x, stats, gamma, W1a, mu, W4, P)
+    torch.cuda.synchronize()
+    du = d(dt1) * (1.0 - d(y) ** 2)
+    gg = du * d(gamma)
+    xh = (d(x) - d(stats.view(rows, 2)[:, 0:1])) * d(stats.view(rows, 2)[:, 1:2])
+    dx = d(stats.view(rows, 2)[:, 1:2]) * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True))
+    dpremu64 = (dx @ d(W1a)) * (1.0 - d(mu) ** 2)
+    dp64 = (dpremu64 @ d(W4)) * (d(P) > 0)
+    for name, got, ref in (("dpremu", dpremu, dpremu64), ("dp", dp, dp64)):
+        err = float((d(got) - ref).abs().max() / ref.abs().max())
+        assert err < 5e-6, (name, err)
+    assert torch.equal(dp == 0, ~(P > 0) | (dp == 0))                                # masked entries are exact zeros
