@@ -534,6 +534,33 @@ def main():
             dist.destroy_process_group()
             dist.init_process_group("nccl", device_id=torch.device(dev))
             run(0, args.warmup)
+        # N > 1, gradients reduced inside the library's graph: that graph has two forms since round 6 -- pipelined (the next step's
+        # head on a second branch; the default) and the single-queue chain (FBHIP_DP_PIPELINE=0; rounds 4-5).  The pipelined form has
+        # only ever run on ONE device (a branched data-parallel graph replayed at half speed in round 3, for a reason that was a
+        # launch-queue matter then), and a slow replay is not something the supervisor can see.  So, unless the environment pins the
+        # form: a short trial of both on every rank (8 launches each, outside the timed region), the slower rank's time decides, all ranks take the same form; the line
+        # reports both rates (data_parallel.graph_form_trial).
+        form_trial = None
+        in_graph = world > 1 and spl > 1 and not args.global_batch and not getattr(agent, "_rccl_failed", False) and \
+            os.environ.get("FBHIP_DP_ALLREDUCE", "rccl") in ("rccl", "peer") and (args.peer_allreduce or getattr(agent, "_rccl_bound", False))
+        if in_graph and "FBHIP_DP_PIPELINE" not in os.environ and os.environ.get("FBHIP_UPDATE_PIPELINE") != "0" and _branched_ok():
+            rates = {}
+            for form, env in (("chain", "0"), ("pipelined", "1")):
+                os.environ["FBHIP_DP_PIPELINE"] = env
+                agent._rccl_prepared = []                 # (the other form's graphs are PREPARED under the ranks' agreement, like the first)
+                run(0, 2 * spl)
+                barrier()
+                t0 = time.perf_counter()
+                run(0, 8 * spl)
+                barrier()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rates[form] = 8 * spl / float(t.item())
+            chosen = "pipelined" if rates["pipelined"] >= rates["chain"] else "chain"
+            os.environ["FBHIP_DP_PIPELINE"] = "1" if chosen == "pipelined" else "0"
+            agent._rccl_prepared = []
+            form_trial = {"per_rank_steps_per_s": rates, "chosen": chosen, "trial": f"8 x {spl} steps per form after 2 x {spl} untimed ones, slowest rank"}
+            _beat(f"graph form trial done: {chosen}")
         # every graph size the timed region will launch must already be captured (a capture costs milliseconds): one extra
         # untimed launch of each size (these are additional warm-up steps)
         sizes = ({spl} if args.steps >= spl else set()) | ({args.steps % spl} if args.steps % spl else set())
@@ -659,6 +686,7 @@ def main():
                                if os.environ.get("FBHIP_DP_PIPELINE") == "0" or os.environ.get("FBHIP_UPDATE_PIPELINE") == "0" or not _branched_ok() else
                                "pipelined (step t+1's head on a second graph branch beside step t's actor pass, actor all-reduce and actor "
                                "step; both all-reduces on the main branch in program order; FBHIP_DP_PIPELINE=0 = the single-queue chain)"),
+                **({"graph_form_trial": form_trial} if form_trial is not None else {}),
                 "control_plane": dist.get_backend(),
                 "nccl_env": {k: os.environ.get(k, "default") for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
                                                                      "HSA_ENABLE_IPC_MODE_LEGACY")},
