@@ -28,9 +28,10 @@ from pathlib import Path
 # Runtime configuration, set before the HIP runtime is loaded (import torch).  ROC_CPU_WAIT_FOR_SIGNAL=1: ROCclr resolves a
 # dependency on another hardware queue's signal by waiting for it on the host instead of parking a barrier packet on it.  The
 # SINGLE-GPU n-step update graph has two to three branches, i.e. cross-queue dependencies at every fork and join: measured +3.2 %
-# on the bench line (1116.5 -> 1151.9 update-steps/s, same box).  The data-parallel graph (--gpus N > 1) is single-queue by
-# construction and has no such dependency: those runs keep the runtime's default.  An explicit setting in the environment wins.
-# Reported in config.runtime_env.
+# on the bench line (1116.5 -> 1151.9 update-steps/s, same box).  Runs with --gpus N > 1 keep the runtime's default: the setting has
+# never been exercised beside RCCL's own signal waits on more than one device (the data-parallel graph is pipelined too since round
+# 6 -- on ONE device with the real RCCL calls the setting is fine, 1205 update-steps/s -- and its single-queue fallback form has no
+# cross-queue dependency at all).  An explicit setting in the environment wins.  Reported in config.runtime_env.
 def _multi_gpu_invocation():
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         return True
